@@ -1,0 +1,1354 @@
+/*
+ * procgen_oracle.c -- TEST INFRASTRUCTURE ONLY (see procgen_oracle.h).
+ *
+ * Plain-C restatement of the reference hot path, one function per reference function, each citing
+ * the reference file:line it follows ("BAG" = reference procgen/src/basic-abstract-game.cpp).
+ * Floating point follows the C++ promotion rules of the reference expressions exactly (double
+ * literals promote, results narrow on assignment); build with -ffp-contract=off (no FMA), matching
+ * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
+ *
+ * Games restated so far: coinrun.
+ */
+#include "procgen_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------- */
+/* constants: reference src/object-ids.h, src/game.h:23-26, BAG:6-20                             */
+#define RES_W 64
+#define RES_H 64
+#define INVALID_OBJ (-1)
+#define PLAYER 0
+#define SPACE 100
+#define WALL_OBJ 51
+#define EXPLOSION 54
+#define EXPLOSION5 58
+#define TRAIL 59
+#define USE_ASSET_THRESHOLD 100
+#define MAX_ASSETS 100
+#define MAX_IMAGE_THEMES 10
+
+static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-utils.h:12 */
+#define MAXVTHETA (15 * PI_F / 180) /* BAG:6 */
+#define MIXRATEROT 0.5f             /* BAG:7 */
+static const float POS_EPS = -0.001f;   /* BAG:10 */
+static const float RENDER_EPS = 0.02f;  /* BAG:14 */
+
+enum { GAME_COINRUN = 5 };
+
+/* coinrun ids: reference src/games/coinrun.cpp:11-31 */
+#define CR_GOAL 1
+#define CR_SAW 2
+#define CR_SAW2 3
+#define CR_ENEMY 5
+#define CR_ENEMY1 6
+#define CR_ENEMY2 7
+#define CR_PLAYER_JUMP 9
+#define CR_PLAYER_RIGHT1 12
+#define CR_PLAYER_RIGHT2 13
+#define CR_WALL_MID 15
+#define CR_WALL_TOP 16
+#define CR_LAVA_MID 17
+#define CR_LAVA_TOP 18
+#define CR_ENEMY_BARRIER 19
+#define CR_CRATE 20
+
+static void fatal(const char *msg) {
+    fprintf(stderr, "procgen_oracle: %s\n", msg);
+    exit(1);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* RandGen over std::mt19937: reference src/randgen.cpp:6-31,90-98; libstdc++ bits/random.tcc   */
+typedef struct {
+    uint32_t mt[624];
+    int idx;
+    int seeded;
+    int64_t draws;
+} Rng;
+
+static void rng_seed(Rng *r, int seed) { /* randgen.cpp:95-98; mersenne_twister_engine::seed */
+    r->mt[0] = (uint32_t)seed;
+    for (int i = 1; i < 624; i++) r->mt[i] = 1812433253u * (r->mt[i - 1] ^ (r->mt[i - 1] >> 30)) + (uint32_t)i;
+    r->idx = 624;
+    r->seeded = 1;
+    r->draws = 0;
+}
+
+static uint32_t rng_u32(Rng *r) {
+    if (!r->seeded) fatal("RandGen used before seed (randgen.cpp:7)");
+    if (r->idx >= 624) {
+        uint32_t *mt = r->mt;
+        for (int k = 0; k < 624; k++) {
+            uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+            mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        r->idx = 0;
+    }
+    uint32_t z = r->mt[r->idx++];
+    z ^= (z >> 11);
+    z ^= (z << 7) & 0x9d2c5680u;
+    z ^= (z << 15) & 0xefc60000u;
+    z ^= (z >> 18);
+    r->draws++;
+    return z;
+}
+
+static int rng_randint(Rng *r, int low, int high) { /* randgen.cpp:6-11 */
+    uint32_t x = rng_u32(r);
+    uint32_t range = (uint32_t)(high - low);
+    return (int)((uint32_t)low + (x % range));
+}
+static int rng_randn(Rng *r, int high) { /* randgen.cpp:13-17 */
+    uint32_t x = rng_u32(r);
+    return (int)(x % (uint32_t)high);
+}
+static float rng_rand01(Rng *r) { /* randgen.cpp:19-23 */
+    uint32_t x = rng_u32(r);
+    return (float)((double)x / 4294967296.0);
+}
+static int rng_randint_raw(Rng *r) { return (int)rng_u32(r); } /* randgen.cpp:90-93 */
+
+/* ------------------------------------------------------------------------------------------- */
+/* Entity: reference src/entity.h:7-48, src/entity.cpp:8-82                                      */
+typedef struct {
+    float x, y, vx, vy, rx, ry;
+    int type, image_type, image_theme, render_z;
+    int will_erase, collides_with_entities;
+    float collision_margin, rotation, vrot;
+    int is_reflected, fire_time, spawn_time, life_time, expire_time, use_abs_coords;
+    float friction;
+    int smart_step, avoids_collisions, auto_erase;
+    float alpha, health, theta, grow_rate, alpha_decay, climber_spawn_x;
+} Ent;
+
+static void ent_init(Ent *e, float x, float y, float vx, float vy, float rx, float ry, int type) { /* entity.cpp:11-51 */
+    memset(e, 0, sizeof(*e));
+    e->x = x; e->y = y; e->vx = vx; e->vy = vy; e->rx = rx; e->ry = ry;
+    e->type = type;
+    e->image_type = type;
+    e->image_theme = 0;
+    e->collision_margin = 0.0f;
+    e->rotation = 0.0f;
+    e->vrot = 0.0f;
+    e->alpha = 1.0f;
+    e->grow_rate = 1.0f;
+    e->alpha_decay = 1.0f;
+    e->fire_time = -1;
+    e->spawn_time = -1;
+    e->expire_time = -1;
+    e->life_time = 0;
+    e->health = 1;
+    e->theta = -100;
+    e->friction = 1;
+    e->auto_erase = 1;
+    if (type == EXPLOSION) {
+        e->grow_rate = 1.4f;
+        e->expire_time = 4;
+    } else if (type == TRAIL) {
+        e->grow_rate = 1.05f;
+        e->alpha_decay = 0.8f;
+    }
+}
+
+static void ent_step(Ent *e) { /* entity.cpp:57-82 */
+    if (!e->smart_step) {
+        e->x += e->vx;
+        e->y += e->vy;
+    }
+    e->rotation += e->vrot;
+    e->vx *= e->friction;
+    e->vy *= e->friction;
+    e->life_time += 1;
+    if (e->expire_time > 0 && e->life_time > e->expire_time) e->will_erase = 1;
+    if (e->type == EXPLOSION) {
+        if (e->image_type < EXPLOSION5) e->image_type++;
+    }
+    e->rx *= e->grow_rate;
+    e->ry *= e->grow_rate;
+    e->alpha = e->alpha_decay * e->alpha;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* images                                                                                         */
+typedef struct {
+    int w, h;
+    uint32_t *px;
+} Img;
+
+#define MAX_GAME_IMAGES 256
+typedef struct {
+    int n;
+    char names[MAX_GAME_IMAGES][96];
+    int is_bg[MAX_GAME_IMAGES];
+    Img img[MAX_GAME_IMAGES];
+    /* asset table: (type, theme) -> image index, built from asset_for_type */
+    int type_num_themes[MAX_ASSETS];
+    int type_theme_img[MAX_ASSETS][MAX_IMAGE_THEMES];
+    int n_bg;
+    int bg_img[128];
+    int built;
+} GameAssets;
+
+static GameAssets g_assets[16];
+
+static int assets_add(GameAssets *a, const char *name, int is_bg) {
+    for (int i = 0; i < a->n; i++)
+        if (a->is_bg[i] == is_bg && strcmp(a->names[i], name) == 0) return i;
+    if (a->n >= MAX_GAME_IMAGES) fatal("too many images");
+    strncpy(a->names[a->n], name, 95);
+    a->is_bg[a->n] = is_bg;
+    return a->n++;
+}
+
+static void assets_type(GameAssets *a, int type, const char *name) {
+    int t = a->type_num_themes[type];
+    a->type_theme_img[type][t] = assets_add(a, name, 0);
+    a->type_num_themes[type] = t + 1;
+}
+
+/* reference src/resources.cpp:848-903 + :950-953 (space backgrounds appended) */
+static const char *PLATFORM_BGS[] = {
+    "platform_backgrounds/alien_bg.png", "platform_backgrounds/another_world_bg.png", "platform_backgrounds/back_cave.png",
+    "platform_backgrounds/caverns.png", "platform_backgrounds/cyberpunk_bg.png", "platform_backgrounds/parallax_forest.png",
+    "platform_backgrounds/scifi_bg.png", "platform_backgrounds/scifi2_bg.png", "platform_backgrounds/living_tissue_bg.png",
+    "platform_backgrounds/airadventurelevel1.png", "platform_backgrounds/airadventurelevel2.png",
+    "platform_backgrounds/airadventurelevel3.png", "platform_backgrounds/airadventurelevel4.png",
+    "platform_backgrounds/cave_background.png", "platform_backgrounds/blue_desert.png", "platform_backgrounds/blue_grass.png",
+    "platform_backgrounds/blue_land.png", "platform_backgrounds/blue_shroom.png", "platform_backgrounds/colored_desert.png",
+    "platform_backgrounds/colored_grass.png", "platform_backgrounds/colored_land.png", "platform_backgrounds/colored_shroom.png",
+    "platform_backgrounds/landscape1.png", "platform_backgrounds/landscape2.png", "platform_backgrounds/landscape3.png",
+    "platform_backgrounds/landscape4.png", "platform_backgrounds/battleback1.png", "platform_backgrounds/battleback2.png",
+    "platform_backgrounds/battleback3.png", "platform_backgrounds/battleback4.png", "platform_backgrounds/battleback5.png",
+    "platform_backgrounds/battleback6.png", "platform_backgrounds/battleback7.png", "platform_backgrounds/battleback8.png",
+    "platform_backgrounds/battleback9.png", "platform_backgrounds/battleback10.png", "platform_backgrounds/sunrise.png",
+    "platform_backgrounds_2/beach1.png", "platform_backgrounds_2/beach2.png", "platform_backgrounds_2/beach3.png",
+    "platform_backgrounds_2/beach4.png", "platform_backgrounds_2/fantasy1.png", "platform_backgrounds_2/fantasy2.png",
+    "platform_backgrounds_2/fantasy3.png", "platform_backgrounds_2/fantasy4.png", "platform_backgrounds_2/candy1.png",
+    "platform_backgrounds_2/candy2.png", "platform_backgrounds_2/candy3.png", "platform_backgrounds_2/candy4.png",
+    /* space_backgrounds, reference src/resources.cpp:829-845 */
+    "space_backgrounds/deep_space_01.png", "space_backgrounds/spacegen_01.png", "space_backgrounds/milky_way_01.png",
+    "space_backgrounds/ez_space_lite_01.png", "space_backgrounds/meyespace_v1_01.png", "space_backgrounds/eye_nebula_01.png",
+    "space_backgrounds/deep_sky_01.png", "space_backgrounds/space_nebula_01.png", "space_backgrounds/Background-1.png",
+    "space_backgrounds/Background-2.png", "space_backgrounds/Background-3.png", "space_backgrounds/Background-4.png",
+    "space_backgrounds/parallax-space-backgound.png"};
+
+static void lower_copy(char *dst, const char *src) {
+    for (; *src; src++, dst++) *dst = (char)((*src >= 'A' && *src <= 'Z') ? (*src + 32) : *src);
+    *dst = 0;
+}
+
+static void assets_build(int game_id) {
+    GameAssets *a = &g_assets[game_id];
+    if (a->built) return;
+    a->built = 1;
+    char buf[128], lc[32];
+    /* BAG:416-430 reserved assets */
+    assets_type(a, EXPLOSION, "misc_assets/explosion1.png");
+    assets_type(a, EXPLOSION + 1, "misc_assets/explosion2.png");
+    assets_type(a, EXPLOSION + 2, "misc_assets/explosion3.png");
+    assets_type(a, EXPLOSION + 3, "misc_assets/explosion4.png");
+    assets_type(a, EXPLOSION + 4, "misc_assets/explosion5.png");
+    assets_type(a, TRAIL, "misc_assets/iconCircle_white.png");
+    if (game_id == GAME_COINRUN) { /* coinrun.cpp:33-35,72-121 */
+        static const char *ENEMIES[] = {"slimeBlock", "slimePurple", "slimeBlue", "slimeGreen", "mouse", "snail", "ladybug", "wormGreen", "wormPink"};
+        static const char *COLORS[] = {"Beige", "Blue", "Green", "Pink", "Yellow"};
+        static const char *GROUNDS[] = {"Dirt", "Grass", "Planet", "Sand", "Snow", "Stone"};
+        static const int ptypes[4] = {PLAYER, CR_PLAYER_JUMP, CR_PLAYER_RIGHT1, CR_PLAYER_RIGHT2};
+        static const char *pnames[4] = {"stand", "jump", "walk1", "walk2"};
+        for (int k = 0; k < 4; k++)
+            for (int c = 0; c < 5; c++) {
+                snprintf(buf, sizeof buf, "kenney/Players/128x256/%s/alien%s_%s.png", COLORS[c], COLORS[c], pnames[k]);
+                assets_type(a, ptypes[k], buf);
+            }
+        for (int e = 0; e < 9; e++) {
+            snprintf(buf, sizeof buf, "kenney/Enemies/%s.png", ENEMIES[e]);
+            assets_type(a, CR_ENEMY1, buf);
+        }
+        for (int e = 0; e < 9; e++) {
+            snprintf(buf, sizeof buf, "kenney/Enemies/%s_move.png", ENEMIES[e]);
+            assets_type(a, CR_ENEMY2, buf);
+        }
+        assets_type(a, CR_GOAL, "kenney/Items/coinGold.png");
+        for (int g = 0; g < 6; g++) {
+            lower_copy(lc, GROUNDS[g]);
+            snprintf(buf, sizeof buf, "kenney/Ground/%s/%sMid.png", GROUNDS[g], lc);
+            assets_type(a, CR_WALL_TOP, buf);
+        }
+        for (int g = 0; g < 6; g++) {
+            lower_copy(lc, GROUNDS[g]);
+            snprintf(buf, sizeof buf, "kenney/Ground/%s/%sCenter.png", GROUNDS[g], lc);
+            assets_type(a, CR_WALL_MID, buf);
+        }
+        assets_type(a, CR_LAVA_TOP, "kenney/Tiles/lavaTop_low.png");
+        assets_type(a, CR_LAVA_MID, "kenney/Tiles/lava.png");
+        assets_type(a, CR_SAW, "kenney/Enemies/sawHalf.png");
+        assets_type(a, CR_SAW2, "kenney/Enemies/sawHalf_move.png");
+        assets_type(a, CR_CRATE, "kenney/Tiles/boxCrate.png");
+        assets_type(a, CR_CRATE, "kenney/Tiles/boxCrate_double.png");
+        assets_type(a, CR_CRATE, "kenney/Tiles/boxCrate_single.png");
+        assets_type(a, CR_CRATE, "kenney/Tiles/boxCrate_warning.png");
+        /* coinrun.cpp:60-62 load_background_images: platform_backgrounds */
+        a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
+        for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else {
+        fatal("game not restated in the oracle");
+    }
+}
+
+int pgo_game_id(const char *name) {
+    if (strcmp(name, "coinrun") == 0) return GAME_COINRUN;
+    return -1;
+}
+int pgo_num_images(int game_id) {
+    assets_build(game_id);
+    return g_assets[game_id].n;
+}
+const char *pgo_image_name(int game_id, int idx) {
+    assets_build(game_id);
+    return g_assets[game_id].names[idx];
+}
+int pgo_image_is_background(int game_id, int idx) {
+    assets_build(game_id);
+    return g_assets[game_id].is_bg[idx];
+}
+void pgo_set_image(int game_id, int idx, int w, int h, const uint32_t *px) {
+    assets_build(game_id);
+    Img *im = &g_assets[game_id].img[idx];
+    free(im->px);
+    im->w = w;
+    im->h = h;
+    im->px = (uint32_t *)malloc((size_t)w * h * 4);
+    memcpy(im->px, px, (size_t)w * h * 4);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Game state: reference src/game.h:62-126, src/basic-abstract-game.h:110-160, coinrun.cpp:38-47 */
+#define MAX_ENTS 2048
+#define MAX_GRID (64 * 64)
+
+typedef struct {
+    int game_id;
+    GameAssets *assets;
+    PgoOptions opt;
+    /* Game */
+    int level_seed_low, level_seed_high;
+    Rng level_seed_rand_gen, rand_gen;
+    float reward;
+    int done, level_complete;
+    int action, timeout;
+    int current_level_seed, prev_level_seed, episodes_remaining, episode_done;
+    int last_reward_timer;
+    float last_reward;
+    int default_action;
+    int cur_time;
+    int grid_step;
+    float total_reward;
+    uint32_t render_buf[RES_W * RES_H];
+    /* BAG */
+    Ent pool[MAX_ENTS];
+    int pool_free[MAX_ENTS], n_free;
+    int ents[MAX_ENTS]; /* entity list (indices into pool), in vector order */
+    int n_ents;
+    int agent; /* pool index; stays valid after erase (shared_ptr semantics) */
+    int background_index;
+    float bg_tile_ratio, bg_pct_x;
+    int last_move_action, move_action, special_action;
+    float mixrate, maxspeed, max_jump;
+    float action_vx, action_vy, action_vrot;
+    float center_x, center_y;
+    int random_agent_start, has_useful_vel_info, step_rand_int;
+    int main_width, main_height, out_of_bounds_object;
+    float unit, view_dim, x_off, y_off, visibility, min_visibility;
+    int grid_w, grid_h;
+    int grid[MAX_GRID];
+    /* CoinRun */
+    float last_agent_y;
+    int wall_theme, has_support, facing_right, is_on_crate;
+    float gravity, air_control;
+} Game;
+
+struct PgoVec {
+    int n;
+    Game *games;
+};
+
+/* ---- entity list helpers (std::vector<std::shared_ptr<Entity>> semantics) ---- */
+static int pool_alloc(Game *g) {
+    if (g->n_free <= 0) fatal("entity pool exhausted");
+    return g->pool_free[--g->n_free];
+}
+static Ent *push_entity(Game *g, float x, float y, float vx, float vy, float rx, float ry, int type) { /* BAG:566-576 */
+    int id = pool_alloc(g);
+    ent_init(&g->pool[id], x, y, vx, vy, rx, ry, type);
+    if (g->n_ents >= MAX_ENTS) fatal("entity list overflow");
+    g->ents[g->n_ents++] = id;
+    return &g->pool[id];
+}
+static void ents_clear(Game *g) {
+    g->n_ents = 0;
+    g->n_free = 0;
+    for (int i = MAX_ENTS - 1; i >= 0; i--) g->pool_free[g->n_free++] = i;
+}
+
+/* ---- grid: reference src/grid.h, BAG:125-131,167-223 ---- */
+static int grid_contains(const Game *g, int x, int y) { return 0 <= y && y < g->grid_h && 0 <= x && x < g->grid_w; }
+static int get_obj(const Game *g, int x, int y) { /* BAG:180-185 */
+    if (!grid_contains(g, x, y)) return g->out_of_bounds_object;
+    return g->grid[y * g->grid_w + x];
+}
+static void set_obj(Game *g, int x, int y, int v) { /* grid.h:54-57 */
+    if (!grid_contains(g, x, y)) fatal("fassert grid.contains (grid.h:55)");
+    g->grid[y * g->grid_w + x] = v;
+}
+static void fill_elem(Game *g, int x, int y, int dx, int dy, int elem) { /* BAG:125-131 (elem is a char there) */
+    for (int j = 0; j < dx; j++)
+        for (int k = 0; k < dy; k++) set_obj(g, x + j, y + k, elem);
+}
+static int get_obj_from_floats(const Game *g, float i, float j) { /* BAG:167-174 */
+    if (i < 0) return g->out_of_bounds_object;
+    if (j < 0) return g->out_of_bounds_object;
+    return get_obj(g, (int)floor(i), (int)floor(j));
+}
+
+/* ---- collision predicates ---- */
+static int has_collision(const Ent *e1, const Ent *e2, float margin) { /* BAG:1145-1150 */
+    float threshold_x = (e1->rx + e2->rx) + margin;
+    float threshold_y = (e1->ry + e2->ry) + margin;
+    return (fabsf(e1->x - e2->x) < threshold_x) && (fabsf(e1->y - e2->y) < threshold_y);
+}
+static int is_out_of_bounds(const Game *g, const Ent *e) { /* BAG:1068-1084 */
+    if (e->x + e->rx < 0) return 1;
+    if (e->y + e->ry < 0) return 1;
+    if (e->x - e->rx > g->main_width) return 1;
+    if (e->y - e->ry > g->main_height) return 1;
+    return 0;
+}
+static int has_agent_collision(const Game *g, const Ent *e) { /* BAG:1126-1131 */
+    if (e->type == PLAYER) return 0;
+    return has_collision(e, &g->pool[g->agent], e->collision_margin);
+}
+
+/* ---- per-game hooks (virtuals of BasicAbstractGame) ---- */
+static int cr_is_wall(int t) { return t == CR_WALL_MID || t == CR_WALL_TOP; }
+static int cr_is_lava(int t) { return t == CR_LAVA_MID || t == CR_LAVA_TOP; }
+
+static int hook_is_blocked(const Game *g, const Ent *src, int target, int is_horizontal) {
+    (void)is_horizontal;
+    if (target == WALL_OBJ) return 1; /* BAG:485-492 */
+    if (target == g->out_of_bounds_object) return 1;
+    if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:204-211 */
+        if (src->type == PLAYER && cr_is_wall(target)) return 1;
+    }
+    return 0;
+}
+static int hook_is_blocked_ents(Game *g, const Ent *src, const Ent *target, int is_horizontal) {
+    if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:187-202 */
+        if (target->type == CR_CRATE && !is_horizontal) {
+            const Ent *agent = &g->pool[g->agent];
+            if (agent->vy >= 0) return 0;
+            if (g->action_vy < 0) return 0;
+            if (g->last_agent_y < (target->y + target->ry + agent->ry)) return 0;
+            g->is_on_crate = 1;
+            return 1;
+        }
+    }
+    return hook_is_blocked(g, src, target->type, is_horizontal); /* BAG:494-496 */
+}
+static int hook_will_reflect(const Game *g, int src, int target) {
+    if (g->game_id == GAME_COINRUN) /* coinrun.cpp:140-142 */
+        return (src == CR_ENEMY && (cr_is_wall(target) || target == CR_ENEMY_BARRIER));
+    return 0; /* BAG:498-500 */
+}
+static void hook_handle_agent_collision(Game *g, Ent *obj) {
+    if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:123-131 */
+        if (obj->type == CR_ENEMY) g->done = 1;
+        else if (obj->type == CR_SAW) g->done = 1;
+    }
+}
+static void hook_handle_grid_collision(Game *g, Ent *obj, int type, int i, int j) {
+    (void)i; (void)j;
+    if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:144-154 */
+        if (obj->type == PLAYER) {
+            if (type == CR_GOAL) {
+                g->reward += 10.0f;
+                g->done = 1;
+                g->level_complete = 1;
+            } else if (cr_is_lava(type)) {
+                g->done = 1;
+            }
+        }
+    }
+}
+static void hook_handle_collision(Game *g, Ent *src, Ent *target) { (void)g; (void)src; (void)target; } /* BAG:398 */
+
+/* ---- physics: BAG:240-372 ---- */
+static int sub_step(Game *g, Ent *obj, float _vx, float _vy, int depth);
+
+static double sign_d(double x) { return x > 0 ? +1 : (x == 0 ? 0 : -1); } /* src/cpp-utils.h:43-45 */
+
+static int push_obj(Game *g, Ent *src, Ent *target, int is_horizontal, int depth) { /* BAG:240-268 */
+    float rsum = is_horizontal ? (src->rx + target->rx) : (src->ry + target->ry);
+    float delx = target->x - src->x;
+    float dely = target->y - src->y;
+    float t_vx = 0, t_vy = 0;
+    if (is_horizontal) t_vx = (float)(src->x + sign_d(delx) * rsum - target->x);
+    else t_vy = (float)(src->y + sign_d(dely) * rsum - target->y);
+    int block = 0;
+    if (depth < 5) block = sub_step(g, target, t_vx, t_vy, depth + 1);
+    if (is_horizontal) target->vx = 0;
+    else target->vy = 0;
+    return block;
+}
+
+static int sub_step(Game *g, Ent *obj, float _vx, float _vy, int depth) { /* BAG:270-372 */
+    if (obj->will_erase) return 0;
+    float ny = obj->y + _vy;
+    float nx = obj->x + _vx;
+    float margin = 0.98f;
+    int is_horizontal = _vx != 0;
+    int block = 0, reflect = 0;
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) {
+            int type2 = get_obj_from_floats(g, nx + obj->rx * margin * (2 * i - 1), ny + obj->ry * margin * (2 * j - 1));
+            block = block || hook_is_blocked(g, obj, type2, is_horizontal);
+            reflect = reflect || hook_will_reflect(g, obj->type, type2);
+        }
+    if (reflect) {
+        if (is_horizontal) {
+            float delta;
+            if (_vx < 0) delta = (float)(ceil(nx - obj->rx) - (nx - obj->rx));
+            else delta = (float)(floor(nx + obj->rx) - (nx + obj->rx));
+            obj->vx = -1 * obj->vx;
+            nx = nx + 2 * delta;
+        } else {
+            float delta;
+            if (_vy < 0) delta = (float)(ceil(ny - obj->ry) - (ny - obj->ry));
+            else delta = (float)(floor(ny + obj->ry) - (ny + obj->ry));
+            obj->vy = -1 * obj->vy;
+            ny = ny + 2 * delta;
+        }
+    } else if (block) {
+        if (is_horizontal) {
+            if (g->grid_step) nx = obj->x;
+            else nx = (float)(_vx > 0 ? (floor(nx + obj->rx) - obj->rx) : (ceil(nx - obj->rx) + obj->rx));
+        } else {
+            if (g->grid_step) ny = obj->y;
+            else ny = (float)(_vy > 0 ? (floor(ny + obj->ry) - obj->ry) : (ceil(ny - obj->ry) + obj->ry));
+        }
+    }
+    obj->x = nx;
+    obj->y = ny;
+    int block2 = 0;
+    for (int i = g->n_ents - 1; i >= 0; i--) {
+        Ent *m = &g->pool[g->ents[i]];
+        if (m == obj || m->will_erase) continue;
+        int curr_block = 0;
+        if (has_collision(obj, m, POS_EPS)) {
+            if (hook_is_blocked_ents(g, obj, m, is_horizontal)) {
+                curr_block = 1;
+            } else if (hook_will_reflect(g, obj->type, m->type)) {
+                if (is_horizontal) {
+                    float delx = m->x - obj->x;
+                    float rsum = m->rx + obj->rx;
+                    obj->x += _vx > 0 ? -2 * (rsum - delx) : 2 * (rsum + delx);
+                    obj->vx = -1 * obj->vx;
+                } else {
+                    float dely = m->y - obj->y;
+                    float rsum = m->ry + obj->ry;
+                    obj->y += _vy > 0 ? -2 * (rsum - dely) : 2 * (rsum + dely);
+                    obj->vy = -1 * obj->vy;
+                }
+            }
+            if (curr_block) push_obj(g, m, obj, is_horizontal, depth);
+        }
+        block2 = block2 || curr_block;
+    }
+    return block || block2;
+}
+
+static void basic_step_object(Game *g, Ent *obj) { /* BAG:593-656 */
+    if (obj->will_erase) return;
+    int num_sub_steps;
+    if (g->grid_step) {
+        num_sub_steps = 1;
+    } else {
+        /* sqrt resolves to the double overload in this TU (checked in the reference object code) */
+        num_sub_steps = (int)(4 * sqrt((double)(obj->vx * obj->vx + obj->vy * obj->vy)));
+        if (num_sub_steps < 4) num_sub_steps = 4;
+    }
+    float pct = (float)(1.0 / num_sub_steps);
+    float cmp = fabsf(obj->vx) - fabsf(obj->vy);
+    int step_x_first = cmp == 0 ? g->step_rand_int % 2 == 0 : (cmp > 0);
+    if (obj->type == PLAYER) {
+        if (g->action_vx != 0) step_x_first = 1;
+        if (g->action_vy != 0) step_x_first = 0;
+    }
+    float vx_pct = 0, vy_pct = 0;
+    for (int s = 0; s < num_sub_steps; s++) {
+        int block_x, block_y;
+        if (step_x_first) {
+            block_x = sub_step(g, obj, obj->vx * pct, 0, 0);
+            block_y = sub_step(g, obj, 0, obj->vy * pct, 0);
+        } else {
+            block_y = sub_step(g, obj, 0, obj->vy * pct, 0);
+            block_x = sub_step(g, obj, obj->vx * pct, 0, 0);
+        }
+        if (!block_x) vx_pct += 1;
+        if (!block_y) vy_pct += 1;
+        if (block_x && block_y) break;
+    }
+    vx_pct = vx_pct / num_sub_steps;
+    vy_pct = vy_pct / num_sub_steps;
+    obj->vx *= vx_pct;
+    obj->vy *= vy_pct;
+}
+
+static void check_grid_collisions(Game *g, Ent *ent) { /* BAG:145-165 */
+    float ax = ent->x, ay = ent->y, arx = ent->rx, ary = ent->ry;
+    int min_x = (int)(ax - (arx + POS_EPS));
+    int max_x = (int)(ax + (arx + POS_EPS));
+    int min_y = (int)(ay - (ary + POS_EPS));
+    int max_y = (int)(ay + (ary + POS_EPS));
+    for (int x = min_x; x <= max_x; x++)
+        for (int y = min_y; y <= max_y; y++) {
+            int grid_type = get_obj_from_floats(g, (float)x, (float)y);
+            if (grid_type != SPACE) hook_handle_grid_collision(g, ent, grid_type, x, y);
+        }
+}
+
+static void erase_if_needed(Game *g) { /* BAG:748-756 */
+    for (int i = g->n_ents - 1; i >= 0; i--) {
+        int id = g->ents[i];
+        Ent *e = &g->pool[id];
+        if (e->will_erase || (e->auto_erase && is_out_of_bounds(g, e))) {
+            for (int k = i; k < g->n_ents - 1; k++) g->ents[k] = g->ents[k + 1];
+            g->n_ents--;
+            if (id != g->agent) g->pool_free[g->n_free++] = id;
+        }
+    }
+}
+
+/* ---- coinrun control: coinrun.cpp:156-173,447-472 ---- */
+static float clip_abs(float x, float y) { /* cpp-utils.h:47-53 */
+    if (x > y) return y;
+    if (x < -y) return -y;
+    return x;
+}
+
+static void hook_set_action_xy(Game *g, int move_act) {
+    g->action_vx = (float)(move_act / 3 - 1);
+    g->action_vy = (float)(move_act % 3 - 1);
+    if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:451-472 */
+        Ent *agent = &g->pool[g->agent];
+        if (g->action_vx > 0) g->facing_right = 1;
+        if (g->action_vx < 0) g->facing_right = 0;
+        int obj_below_1 = get_obj_from_floats(g, (float)(agent->x - (agent->rx - .01)), (float)(agent->y - (agent->ry + .01)));
+        int obj_below_2 = get_obj_from_floats(g, (float)(agent->x + (agent->rx - .01)), (float)(agent->y - (agent->ry + .01)));
+        int s1 = cr_is_wall(obj_below_1) || obj_below_1 == g->out_of_bounds_object;
+        int s2 = cr_is_wall(obj_below_2) || obj_below_2 == g->out_of_bounds_object;
+        g->has_support = (g->is_on_crate || s1 || s2) && agent->vy == 0;
+        g->is_on_crate = 0;
+        if (g->action_vy == 1) {
+            if (!g->has_support) g->action_vy = 0;
+        }
+    } else {
+        g->action_vrot = 0; /* BAG:658-662 */
+    }
+}
+
+static void hook_update_agent_velocity(Game *g) {
+    Ent *agent = &g->pool[g->agent];
+    if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:156-173 */
+        float mixrate_x = g->has_support ? g->mixrate : (g->mixrate * g->air_control);
+        agent->vx = (1 - mixrate_x) * agent->vx + mixrate_x * g->maxspeed * g->action_vx;
+        if (fabsf(agent->vx) < mixrate_x * g->maxspeed) agent->vx = 0;
+        if (g->action_vy > 0) {
+            agent->vy = g->max_jump;
+        } else {
+            if (g->has_support) agent->vy = (float)(agent->vy + .2 * g->action_vy);
+        }
+        if (!(g->has_support && g->action_vy > 0)) {
+            agent->vy -= g->gravity;
+            agent->vy = clip_abs(agent->vy, g->max_jump);
+        }
+    } else { /* BAG:669-684 */
+        float v_scale = 1.0f;
+        agent->vx = (1 - g->mixrate) * agent->vx;
+        agent->vy = (1 - g->mixrate) * agent->vy;
+        agent->vx += g->mixrate * g->maxspeed * g->action_vx * v_scale;
+        agent->vy += g->mixrate * g->maxspeed * g->action_vy * v_scale;
+        agent->vx = (float)(.9 * agent->vx);
+        agent->vy = (float)(.9 * agent->vy);
+    }
+}
+
+/* ---- BasicAbstractGame::game_step: BAG:686-746 ---- */
+static void bag_game_step(Game *g) {
+    g->step_rand_int = rng_randint(&g->rand_gen, 0, 1000000);
+    g->move_action = g->action % 9;
+    g->special_action = 0;
+    if (g->action >= 9) {
+        g->special_action = g->action - 8;
+        g->move_action = 4;
+    }
+    if (g->move_action != 4) g->last_move_action = g->move_action;
+    g->action_vrot = 0;
+    g->action_vx = 0;
+    g->action_vy = 0;
+    hook_set_action_xy(g, g->move_action);
+    Ent *agent = &g->pool[g->agent];
+    if (g->grid_step) {
+        agent->vx = g->action_vx;
+        agent->vy = g->action_vy;
+    } else {
+        hook_update_agent_velocity(g);
+        agent->vrot = MIXRATEROT * agent->vrot;
+        agent->vrot += MIXRATEROT * MAXVTHETA * g->action_vrot;
+    }
+    /* step_entities BAG:1086-1098 (count captured before the loop) */
+    int entities_count = g->n_ents;
+    for (int i = entities_count - 1; i >= 0; i--) {
+        Ent *ent = &g->pool[g->ents[i]];
+        if (ent->smart_step) basic_step_object(g, ent);
+        ent_step(ent);
+    }
+    for (int i = g->n_ents - 1; i >= 0; i--) { /* BAG:719-741 */
+        Ent *ent = &g->pool[g->ents[i]];
+        if (has_agent_collision(g, ent)) hook_handle_agent_collision(g, ent);
+        if (ent->collides_with_entities) {
+            for (int j = g->n_ents - 1; j >= 0; j--) {
+                if (i == j) continue;
+                Ent *ent2 = &g->pool[g->ents[j]];
+                if (has_collision(ent, ent2, ent->collision_margin) && !ent->will_erase && !ent2->will_erase) hook_handle_collision(g, ent, ent2);
+            }
+        }
+        if (ent->smart_step) check_grid_collisions(g, ent);
+    }
+    erase_if_needed(g);
+    g->done = g->done || is_out_of_bounds(g, &g->pool[g->agent]);
+}
+
+/* ---- CoinRun::game_step: coinrun.cpp:474-498 ---- */
+static void game_step(Game *g) {
+    bag_game_step(g);
+    if (g->game_id == GAME_COINRUN) {
+        Ent *agent = &g->pool[g->agent];
+        if (g->action_vx > 0) agent->is_reflected = 0;
+        if (g->action_vx < 0) agent->is_reflected = 1;
+        for (int i = g->n_ents - 1; i >= 0; i--) {
+            Ent *ent = &g->pool[g->ents[i]];
+            if (ent->type == CR_ENEMY) {
+                float ty = (float)(ent->y - ent->ry * .5);
+                float tx = ent->x;
+                Ent *trail = push_entity(g, tx, ty, 0, 0.01f, 0.3f, 0.2f, TRAIL);
+                ent = &g->pool[g->ents[i]];
+                trail->expire_time = 8;
+                trail->alpha = (float).5;
+                ent->image_type = g->cur_time / 5 % 2 == 0 ? CR_ENEMY1 : CR_ENEMY2;
+                ent->is_reflected = ent->vx > 0;
+            } else if (ent->type == CR_SAW) {
+                ent->image_type = g->cur_time % 2 == 0 ? CR_SAW : CR_SAW2;
+            }
+        }
+        g->last_agent_y = agent->y;
+    }
+}
+
+/* ---- level generation ---- */
+static void choose_random_theme(Game *g, Ent *ent) { /* BAG:1038-1041 */
+    ent->image_theme = rng_randn(&g->rand_gen, g->assets->type_num_themes[ent->image_type]);
+}
+
+static void cr_fill_block_top(Game *g, int x, int y, int dx, int dy, int fill, int top) { /* coinrun.cpp:227-231 */
+    if (!(dy > 0)) fatal("fassert dy > 0 (coinrun.cpp:228)");
+    fill_elem(g, x, y, dx, dy - 1, fill);
+    fill_elem(g, x, y + dy - 1, dx, 1, top);
+}
+static void cr_fill_ground_block(Game *g, int x, int y, int dx, int dy) { cr_fill_block_top(g, x, y, dx, dy, CR_WALL_MID, CR_WALL_TOP); }
+static void cr_fill_lava_block(Game *g, int x, int y, int dx, int dy) { cr_fill_block_top(g, x, y, dx, dy, CR_LAVA_MID, CR_LAVA_TOP); }
+static void cr_create_saw_enemy(Game *g, int x, int y) { /* coinrun.cpp:248-250 */
+    push_entity(g, (float)(x + .5), (float)(y + .5), 0, 0, (float).5, (float).5, CR_SAW);
+}
+static void cr_create_enemy(Game *g, int x, int y) { /* coinrun.cpp:252-258 */
+    float vx = (float)(.15 * (rng_randn(&g->rand_gen, 2) * 2 - 1));
+    Ent *ent = push_entity(g, (float)(x + .5), (float)(y + .5), vx, 0, (float).5, (float).5, CR_ENEMY);
+    ent->smart_step = 1;
+    ent->image_type = CR_ENEMY1;
+    ent->render_z = 1;
+    choose_random_theme(g, ent);
+}
+static void cr_create_crate(Game *g, int x, int y) { /* coinrun.cpp:260-263 */
+    Ent *ent = push_entity(g, (float)(x + .5), (float)(y + .5), 0, 0, (float).5, (float).5, CR_CRATE);
+    choose_random_theme(g, ent);
+}
+
+static void cr_generate_coin_to_the_right(Game *g) { /* coinrun.cpp:265-414 */
+    Rng *r = &g->rand_gen;
+    int max_difficulty = 3;
+    int dif = rng_randn(r, max_difficulty) + 1;
+    int num_sections = rng_randn(r, dif) + dif;
+    int curr_x = 5, curr_y = 1;
+    int pit_threshold = dif;
+    int danger_type = rng_randn(r, 3);
+    int allow_pit = (g->opt.debug_mode & (1 << 1)) == 0;
+    int allow_crate = (g->opt.debug_mode & (1 << 2)) == 0;
+    int allow_dy = (g->opt.debug_mode & (1 << 3)) == 0;
+    int w = g->main_width;
+    float _max_dy = g->max_jump * g->max_jump / (2 * g->gravity);
+    float _max_dx = g->maxspeed * 2 * g->max_jump / g->gravity;
+    int max_dy = (int)(_max_dy - .5);
+    int max_dx = (int)(_max_dx - .5);
+    int allow_monsters = 1;
+    if (g->opt.distribution_mode == 0) allow_monsters = 0;
+    for (int section_idx = 0; section_idx < num_sections; section_idx++) {
+        if (curr_x + 15 >= w) break;
+        int dy = rng_randn(r, 4) + 1 + (int)(dif / 3);
+        if (!allow_dy) dy = 0;
+        if (dy > max_dy) dy = max_dy;
+        if (curr_y >= 20) dy *= -1;
+        else if (curr_y >= 5 && rng_randn(r, 2) == 1) dy *= -1;
+        int dx = rng_randn(r, 2 * dif) + 3 + (int)(dif / 3);
+        curr_y += dy;
+        if (curr_y < 1) curr_y = 1;
+        int use_pit = allow_pit && (dx > 7) && (curr_y > 3) && (rng_randn(r, 20) >= pit_threshold);
+        if (use_pit) {
+            int x1 = rng_randn(r, 3) + 1;
+            int x2 = rng_randn(r, 3) + 1;
+            int pit_width = dx - x1 - x2;
+            if (pit_width > max_dx) {
+                pit_width = max_dx;
+                x2 = dx - x1 - pit_width;
+            }
+            cr_fill_ground_block(g, curr_x, 0, x1, curr_y);
+            cr_fill_ground_block(g, curr_x + dx - x2, 0, x2, curr_y);
+            int lava_height = rng_randn(r, curr_y - 3) + 1;
+            if (danger_type == 0) {
+                cr_fill_lava_block(g, curr_x + x1, 1, pit_width, lava_height);
+            } else if (danger_type == 1) {
+                for (int ei = 0; ei < pit_width; ei++) cr_create_saw_enemy(g, curr_x + x1 + ei, 1);
+            } else if (danger_type == 2) {
+                for (int ei = 0; ei < pit_width; ei++) cr_create_enemy(g, curr_x + x1 + ei, 1);
+            }
+            if (pit_width > 4) {
+                int x3, w1;
+                if (pit_width == 5) {
+                    x3 = 1 + rng_randn(r, 2);
+                    w1 = 1 + rng_randn(r, 2);
+                } else if (pit_width == 6) {
+                    x3 = 2 + rng_randn(r, 2);
+                    w1 = 1 + rng_randn(r, 2);
+                } else {
+                    x3 = 2 + rng_randn(r, 2);
+                    int x4 = 2 + rng_randn(r, 2);
+                    w1 = pit_width - x3 - x4;
+                }
+                cr_fill_ground_block(g, curr_x + x1 + x3, curr_y - 1, w1, 1);
+            }
+        } else {
+            cr_fill_ground_block(g, curr_x, 0, dx, curr_y);
+            int ob1_x = -1, ob2_x = -1;
+            if (rng_randn(r, 10) < (2 * dif) && dx > 3) {
+                ob1_x = curr_x + rng_randn(r, dx - 2) + 1;
+                cr_create_saw_enemy(g, ob1_x, curr_y);
+            }
+            if (rng_randn(r, 10) < dif && dx > 3 && (max_dx >= 4) && allow_monsters) {
+                ob2_x = curr_x + rng_randn(r, dx - 2) + 1;
+                cr_create_enemy(g, ob2_x, curr_y);
+            }
+            if (allow_crate) {
+                for (int i = 0; i < 2; i++) {
+                    int crate_x = curr_x + rng_randn(r, dx - 2) + 1;
+                    if (rng_randn(r, 2) == 1 && ob1_x != crate_x && ob2_x != crate_x) {
+                        int pile_height = rng_randn(r, 3) + 1;
+                        for (int j = 0; j < pile_height; j++) cr_create_crate(g, crate_x, curr_y + j);
+                    }
+                }
+            }
+        }
+        if (!cr_is_wall(get_obj(g, curr_x - 1, curr_y))) set_obj(g, curr_x - 1, curr_y, CR_ENEMY_BARRIER);
+        curr_x += dx;
+        set_obj(g, curr_x, curr_y, CR_ENEMY_BARRIER);
+    }
+    set_obj(g, curr_x, curr_y, CR_GOAL);
+    cr_fill_ground_block(g, curr_x, 0, 1, curr_y);
+    fill_elem(g, curr_x + 1, 0, g->main_width - curr_x - 1, g->main_height, CR_WALL_MID);
+}
+
+static void bag_game_reset(Game *g) { /* BAG:758-797 */
+    if (!(g->main_width > 0 && g->main_height > 0)) fatal("fassert main dims (BAG:760)");
+    g->bg_pct_x = rng_rand01(&g->rand_gen);
+    g->grid_w = g->main_width;
+    g->grid_h = g->main_height;
+    memset(g->grid, 0, sizeof(int) * (size_t)(g->grid_w * g->grid_h));
+    g->background_index = rng_randn(&g->rand_gen, g->assets->n_bg);
+    ents_clear(g);
+    float ax, ay;
+    float a_r = 0.4f;
+    if (g->random_agent_start) {
+        ax = rng_rand01(&g->rand_gen) * (g->main_width - 2 * a_r) + a_r;
+        ay = rng_rand01(&g->rand_gen) * (g->main_height - 2 * a_r) + a_r;
+    } else {
+        ax = a_r;
+        ay = a_r;
+    }
+    Ent *agent = push_entity(g, ax, ay, 0, 0, a_r, a_r, PLAYER);
+    g->agent = g->ents[g->n_ents - 1];
+    agent->smart_step = 1;
+    agent->render_z = 1;
+    erase_if_needed(g);
+    fill_elem(g, 0, 0, g->main_width, g->main_height, SPACE);
+}
+
+static void game_reset(Game *g) {
+    bag_game_reset(g);
+    if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:416-445 */
+        Ent *agent = &g->pool[g->agent];
+        g->gravity = 0.2f;
+        g->max_jump = 1.5;
+        g->air_control = 0.15f;
+        g->maxspeed = (float).5;
+        g->has_support = 0;
+        g->facing_right = 1;
+        if (g->opt.distribution_mode == 0) {
+            agent->image_theme = 0;
+            g->wall_theme = 0;
+            g->background_index = 0;
+        } else {
+            choose_random_theme(g, agent);
+            g->wall_theme = rng_randn(&g->rand_gen, 6);
+        }
+        agent->rx = (float).5;
+        agent->ry = 0.5787f;
+        agent->x = 1 + agent->rx;
+        agent->y = 1 + agent->ry;
+        g->last_agent_y = agent->y;
+        g->is_on_crate = 0;
+        /* init_floor_and_walls coinrun.cpp:241-246 */
+        fill_elem(g, 0, 0, g->main_width, 1, CR_WALL_TOP);
+        fill_elem(g, 0, 0, 1, g->main_height, CR_WALL_MID);
+        fill_elem(g, g->main_width - 1, 0, 1, g->main_height, CR_WALL_MID);
+        fill_elem(g, 0, g->main_height - 1, g->main_width, 1, CR_WALL_MID);
+        cr_generate_coin_to_the_right(g);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Rendering: replaces QPainter on a 64x64 Format_RGB32 buffer (reference src/game.cpp:77-91).   */
+/* Third-party arithmetic restated: Qt5Gui 5.9.7 raster engine, non-antialiased, SourceOver:     */
+/*   fillRect(QRectF)      -> [qRound(L),qRound(L+W)) x [qRound(T),qRound(T+H))                  */
+/*   drawImage(QRectF,img) -> qt_scale_image_32 (qblendfunctions_p.h): 16.16 fixed-point nearest */
+/*                            sampling, premultiplied SourceOver, const alpha = int(opacity*256) */
+/* Pinned against the compiled reference's frames (tests/golden) and PyQt5 5.9.7 probes.         */
+static int q_round(double d) { /* qglobal.h qRound(double), Qt 5.9 */
+    return d >= 0.0 ? (int)(d + 0.5) : (int)(d - (double)((int)(d - 1)) + 0.5) + (int)(d - 1);
+}
+static uint32_t byte_mul(uint32_t x, uint32_t a) { /* qdrawhelper_p.h BYTE_MUL */
+    uint32_t t = (x & 0xff00ffu) * a;
+    t = (t + ((t >> 8) & 0xff00ffu) + 0x800080u) >> 8;
+    t &= 0xff00ffu;
+    x = ((x >> 8) & 0xff00ffu) * a;
+    x = (x + ((x >> 8) & 0xff00ffu) + 0x800080u);
+    x &= 0xff00ff00u;
+    return x | t;
+}
+
+typedef struct { double x, y, w, h; } RectD;
+
+static void fill_rect(uint32_t *dst, RectD r, uint32_t color) {
+    int x1 = q_round(r.x), x2 = q_round(r.x + r.w), y1 = q_round(r.y), y2 = q_round(r.y + r.h);
+    if (x1 < 0) x1 = 0;
+    if (y1 < 0) y1 = 0;
+    if (x2 > RES_W) x2 = RES_W;
+    if (y2 > RES_H) y2 = RES_H;
+    for (int y = y1; y < y2; y++)
+        for (int x = x1; x < x2; x++) dst[y * RES_W + x] = color;
+}
+
+static void draw_image_scaled(uint32_t *dst, const Img *src, int mirrored, RectD tr, float opacity) {
+    if (!src->px) fatal("image not provided to the oracle");
+    double sx = tr.w / (double)src->w;
+    double sy = tr.h / (double)src->h;
+    int ix = (int)(65536 / sx);
+    int iy = (int)(65536 / sy);
+    int tx1 = q_round(tr.x), tx2 = q_round(tr.x + tr.w), ty1 = q_round(tr.y), ty2 = q_round(tr.y + tr.h);
+    if (tx1 < 0) tx1 = 0;
+    if (ty1 < 0) ty1 = 0;
+    if (tx2 > RES_W) tx2 = RES_W;
+    if (ty2 > RES_H) ty2 = RES_H;
+    int w = tx2 - tx1, h = ty2 - ty1;
+    if (w <= 0 || h <= 0) return;
+    /* Qt 5.9: qCeil(..) - 1 (newer Qt uses qFloor(..) + 1; pinned with tests/tools/qt_drawimage_probe.py) */
+    uint32_t basex = (uint32_t)((int)ceil((tx1 + 0.5 - tr.x) * ix) - 1);
+    uint32_t srcy = (uint32_t)((int)ceil((ty1 + 0.5 - tr.y) * iy) - 1);
+    int yend = (int)((srcy + (uint32_t)iy * (uint32_t)(h - 1)) >> 16);
+    if (yend < 0 || yend >= src->h) --h;
+    int xend = (int)((basex + (uint32_t)ix * (uint32_t)(w - 1)) >> 16);
+    if (xend < 0 || xend >= src->w) --w;
+    double o = opacity;
+    if (o < 0) o = 0;
+    if (o > 1) o = 1;
+    int io = (int)(o * 256);
+    uint32_t ca = (uint32_t)((io * 255) >> 8);
+    for (int y = 0; y < h; y++) {
+        const uint32_t *srow = src->px + (size_t)(srcy >> 16) * src->w;
+        uint32_t srcx = basex;
+        uint32_t *drow = dst + (ty1 + y) * RES_W + tx1;
+        for (int x = 0; x < w; x++) {
+            int sxp = (int)(srcx >> 16);
+            uint32_t s = srow[mirrored ? (src->w - 1 - sxp) : sxp];
+            if (io != 256) s = byte_mul(s, ca);
+            drow[x] = s + byte_mul(drow[x], 255u - (s >> 24));
+            srcx += (uint32_t)ix;
+        }
+        srcy += (uint32_t)iy;
+    }
+}
+
+static RectD get_screen_rect(const Game *g, float x, float y, float dx, float dy, float render_eps) { /* BAG:799-801 */
+    RectD r;
+    r.x = (x - render_eps) * g->unit - g->x_off;
+    r.y = (g->view_dim - y - render_eps) * g->unit + g->y_off;
+    r.w = (dx + 2 * render_eps) * g->unit;
+    r.h = (dy + 2 * render_eps) * g->unit;
+    return r;
+}
+static RectD adjust_rect(RectD b, RectD a) { /* src/qt-utils.h:12-19 */
+    RectD r;
+    r.x = b.x + b.w * a.x;
+    r.y = b.y + b.h * a.y;
+    r.w = b.w * a.w;
+    r.h = b.h * a.h;
+    return r;
+}
+
+static void prepare_for_drawing(Game *g, float rect_height) { /* BAG:819-838 */
+    g->center_x = (float)(g->main_width * .5);
+    g->center_y = (float)(g->main_height * .5);
+    if (g->opt.center_agent) {
+        g->center_x = g->pool[g->agent].x; /* choose_center BAG:664-667 */
+        g->center_y = g->pool[g->agent].y;
+    } else {
+        g->visibility = (float)(g->main_width > g->main_height ? g->main_width : g->main_height);
+        if (g->visibility < g->min_visibility) g->visibility = g->min_visibility;
+    }
+    float raw_unit = 64 / g->visibility;
+    g->unit = (float)(raw_unit * (rect_height / 64.0));
+    g->view_dim = (float)(64.0 / raw_unit);
+    g->x_off = g->unit * (g->center_x - g->view_dim / 2);
+    g->y_off = g->unit * (g->center_y - g->view_dim / 2);
+}
+
+static int hook_image_for_type(const Game *g, int type) {
+    if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:213-225 */
+        if (type == PLAYER) {
+            const Ent *agent = &g->pool[g->agent];
+            if (fabs((double)agent->vx) < .01 && g->action_vx == 0 && g->has_support) return PLAYER;
+            return (g->cur_time / 5 % 2 == 0 || !g->has_support) ? CR_PLAYER_RIGHT1 : CR_PLAYER_RIGHT2;
+        } else if (type == CR_ENEMY_BARRIER) {
+            return -1;
+        }
+    }
+    return abs(type); /* BAG:438-440 */
+}
+static int hook_theme_for_grid_obj(const Game *g, int type) {
+    if (g->game_id == GAME_COINRUN && cr_is_wall(type)) return g->wall_theme; /* coinrun.cpp:133-138 */
+    return 0;
+}
+static RectD hook_adjusted_image_rect(const Game *g, int type, RectD rect) {
+    if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:64-70 */
+        if (type == PLAYER || type == CR_PLAYER_JUMP || type == CR_PLAYER_RIGHT1 || type == CR_PLAYER_RIGHT2) {
+            RectD a = {0, -.7415, 1, 1.7415};
+            return adjust_rect(rect, a);
+        }
+    }
+    return rect;
+}
+
+static void draw_image(Game *g, uint32_t *dst, RectD base_rect, float rotation, int is_reflected, int base_type, int theme, float alpha, float tile_ratio) { /* BAG:877-913 */
+    int img_type = hook_image_for_type(g, base_type);
+    if (img_type < 0) return;
+    if (g->opt.use_monochrome_assets || img_type >= USE_ASSET_THRESHOLD) {
+        if (img_type == SPACE) return; /* draw_grid_obj BAG:915-919 */
+        fatal("monochrome / colored grid objects not restated yet");
+    }
+    if (theme >= MAX_IMAGE_THEMES) fatal("fassert theme < MAX_IMAGE_THEMES (BAG:888)");
+    RectD adjusted = hook_adjusted_image_rect(g, img_type, base_rect);
+    int mt = theme; /* mask_theme_if_necessary BAG:450-453 (restrict_themes) */
+    if (g->opt.restrict_themes) mt = 0;
+    if (g->assets->type_num_themes[img_type] <= mt) fatal("asset theme out of range");
+    const Img *img = &g->assets->img[g->assets->type_theme_img[img_type][mt]];
+    if (rotation != 0) fatal("rotated drawImage not restated yet");
+    if (tile_ratio != 0) fatal("tiled drawImage not restated yet");
+    draw_image_scaled(dst, img, is_reflected, adjusted, alpha);
+}
+
+static void draw_entities(Game *g, uint32_t *dst, int render_z) { /* BAG:1052-1066 */
+    for (int i = 0; i < g->n_ents; i++) {
+        const Ent *m = &g->pool[g->ents[i]];
+        if (m->render_z != render_z) continue;
+        RectD r1; /* get_object_rect BAG:811-817 */
+        if (m->use_abs_coords) {
+            float vd = g->view_dim;
+            r1.x = (vd * (m->x - m->rx)) * g->unit;
+            r1.y = (vd * (m->y + m->ry)) * g->unit;
+            r1.w = (2 * vd * m->rx) * g->unit;
+            r1.h = (2 * vd * m->ry) * g->unit;
+        } else {
+            r1 = get_screen_rect(g, m->x - m->rx, m->y + m->ry, 2 * m->rx, 2 * m->ry, 0);
+        }
+        draw_image(g, dst, r1, m->rotation, m->is_reflected, m->image_type, m->image_theme, m->alpha, 0);
+    }
+}
+
+static void game_draw(Game *g, uint32_t *dst) { /* BAG:979-1012,921-970 */
+    for (int i = 0; i < RES_W * RES_H; i++) dst[i] = 0xff000000u; /* fillRect black */
+    prepare_for_drawing(g, (float)RES_H);
+    if (g->opt.use_backgrounds) {
+        RectD main_rect = get_screen_rect(g, 0, (float)g->main_height, (float)g->main_width, (float)g->main_height, 0);
+        const Img *bg = &g->assets->img[g->assets->bg_img[g->background_index]];
+        if (g->bg_tile_ratio < 0) fatal("tiled backgrounds not restated yet");
+        float bgw = (float)bg->w, bgh = (float)bg->h;
+        float bg_ar = bgw / bgh;
+        float world_ar = (float)(g->main_width * 1.0 / g->main_height);
+        float extra_w = bg_ar - world_ar;
+        float offset_x = g->bg_pct_x * extra_w;
+        RectD a = {-offset_x, 0, bg_ar / world_ar, 1};
+        draw_image_scaled(dst, bg, 0, adjust_rect(main_rect, a), 1.0f);
+    }
+    prepare_for_drawing(g, (float)RES_H);
+    draw_entities(g, dst, -1);
+    int low_x, high_x, low_y, high_y;
+    if (g->opt.center_agent) {
+        float margin = (float)(g->visibility / 2.0 + 1);
+        low_x = (int)(g->center_x - margin);
+        high_x = (int)(g->center_x + margin);
+        low_y = (int)(g->center_y - margin);
+        high_y = (int)(g->center_y + margin);
+    } else {
+        low_x = 0;
+        high_x = g->main_width - 1;
+        low_y = 0;
+        high_y = g->main_height - 1;
+    }
+    for (int x = low_x; x <= high_x; x++)
+        for (int y = low_y; y <= high_y; y++) {
+            int type = get_obj(g, x, y);
+            if (type == INVALID_OBJ) continue;
+            int theme = hook_theme_for_grid_obj(g, type);
+            RectD r2 = get_screen_rect(g, (float)x, (float)(y + 1), 1, 1, RENDER_EPS);
+            draw_image(g, dst, r2, 0, 0, type, theme, 1.0f, 0.0f);
+        }
+    draw_entities(g, dst, 0);
+    draw_entities(g, dst, 1);
+    if (g->has_useful_vel_info && g->opt.paint_vel_info) { /* BAG:960-969 */
+        const Ent *agent = &g->pool[g->agent];
+        float infodim = (float)(RES_H * .2);
+        int s1 = (int)((float)(.5 * agent->vx / g->maxspeed + .5) * 255);
+        int s2 = (int)((float)(.5 * agent->vy / g->max_jump + .5) * 255);
+        if (s1 < 0) s1 = 0;
+        if (s1 > 255) s1 = 255;
+        if (s2 < 0) s2 = 0;
+        if (s2 > 255) s2 = 255;
+        RectD d2 = {0, 0, infodim, infodim}, d3 = {infodim, 0, infodim, infodim};
+        fill_rect(dst, d2, 0xff000000u | ((uint32_t)s1 << 16) | ((uint32_t)s1 << 8) | (uint32_t)s1);
+        fill_rect(dst, d3, 0xff000000u | ((uint32_t)s2 << 16) | ((uint32_t)s2 << 8) | (uint32_t)s2);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Game::reset / step: reference src/game.cpp:93-155                                             */
+static void g_reset(Game *g) {
+    if (g->episodes_remaining == 0) {
+        if (g->opt.use_sequential_levels && g->level_complete) {
+            g->current_level_seed = (int32_t)((uint32_t)g->current_level_seed + 997u);
+        } else {
+            g->current_level_seed = rng_randint(&g->level_seed_rand_gen, g->level_seed_low, g->level_seed_high);
+        }
+        g->episodes_remaining = 1;
+    } else {
+        g->reward = 0;
+        g->done = 0;
+        g->level_complete = 0;
+    }
+    rng_seed(&g->rand_gen, g->current_level_seed);
+    game_reset(g);
+    g->cur_time = 0;
+    g->total_reward = 0;
+    g->episodes_remaining -= 1;
+    g->action = g->default_action;
+}
+
+static void g_step(Game *g) {
+    g->cur_time += 1;
+    int will_force_reset = 0;
+    if (g->action == -1) {
+        g->action = g->default_action;
+        will_force_reset = 1;
+    }
+    g->reward = 0;
+    g->done = 0;
+    g->level_complete = 0;
+    game_step(g);
+    g->done = g->done || will_force_reset || (g->cur_time >= g->timeout);
+    g->total_reward += g->reward;
+    if (g->reward != 0) {
+        g->last_reward_timer = 10;
+        g->last_reward = g->reward;
+    }
+    g->prev_level_seed = g->current_level_seed;
+    if (g->done) g_reset(g);
+    if (g->opt.use_sequential_levels && g->level_complete) g->done = 0;
+    g->episode_done = g->done;
+    game_draw(g, g->render_buf);
+}
+
+static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
+    memset(g, 0, sizeof(*g));
+    g->game_id = game_id;
+    g->assets = &g_assets[game_id];
+    g->opt = *opt;
+    /* Game::Game src/game.cpp:25-38 */
+    g->timeout = 1000;
+    g->last_reward = -1;
+    g->reward = 0;
+    g->done = 1;
+    /* BasicAbstractGame ctor BAG:22-46 */
+    g->visibility = 16;
+    g->min_visibility = 0;
+    g->mixrate = 0.5f;
+    g->maxspeed = 0.5f;
+    g->max_jump = g->maxspeed;
+    g->default_action = 4;
+    g->last_move_action = 7;
+    g->bg_tile_ratio = 0;
+    g->out_of_bounds_object = INVALID_OBJ;
+    g->has_useful_vel_info = 1;
+    g->random_agent_start = 1; /* basic-abstract-game.h:144 */
+    ents_clear(g);
+    if (game_id == GAME_COINRUN) { /* coinrun.cpp:48-58 */
+        g->visibility = 13;
+        g->mixrate = 0.2f;
+        g->main_width = 64;
+        g->main_height = 64;
+        g->out_of_bounds_object = CR_WALL_MID;
+    }
+}
+
+PgoVec *pgo_make(int game_id, int num_envs, const PgoOptions *opt) {
+    assets_build(game_id);
+    if (opt->use_generated_assets) fatal("use_generated_assets is out of scope");
+    PgoVec *v = (PgoVec *)calloc(1, sizeof(PgoVec));
+    v->n = num_envs;
+    v->games = (Game *)malloc(sizeof(Game) * (size_t)num_envs);
+    int lo = 0, hi = 0; /* src/vecgame.cpp:284-293 */
+    if (opt->num_levels == 0) {
+        lo = 0;
+        hi = INT32_MAX;
+    } else if (opt->num_levels > 0) {
+        lo = opt->start_level;
+        hi = opt->start_level + opt->num_levels;
+    }
+    Rng seedgen; /* src/vecgame.cpp:301-314 */
+    rng_seed(&seedgen, opt->rand_seed);
+    for (int n = 0; n < num_envs; n++) {
+        Game *g = &v->games[n];
+        game_construct(g, game_id, opt);
+        rng_seed(&g->level_seed_rand_gen, rng_randint_raw(&seedgen));
+        g->level_seed_low = lo;
+        g->level_seed_high = hi;
+    }
+    return v;
+}
+
+void pgo_free(PgoVec *v) {
+    if (!v) return;
+    free(v->games);
+    free(v);
+}
+
+void pgo_init(PgoVec *v) { /* src/vecgame.cpp:128-131 */
+    for (int n = 0; n < v->n; n++) {
+        g_reset(&v->games[n]);
+        game_draw(&v->games[n], v->games[n].render_buf);
+    }
+}
+
+void pgo_step(PgoVec *v, const int32_t *actions) { /* src/vecgame.cpp:378-401 */
+    for (int n = 0; n < v->n; n++) {
+        v->games[n].action = actions[n];
+        g_step(&v->games[n]);
+    }
+}
+
+void pgo_observe(PgoVec *v, uint8_t *rgb, float *rew, uint8_t *first, int32_t *prev_level_seed, uint8_t *prev_level_complete, int32_t *level_seed) {
+    for (int n = 0; n < v->n; n++) { /* src/game.cpp:157-165, bgr32_to_rgb888 :8-23 */
+        Game *g = &v->games[n];
+        if (rgb) {
+            uint8_t *d = rgb + (size_t)n * RES_W * RES_H * 3;
+            for (int i = 0; i < RES_W * RES_H; i++) {
+                uint32_t p = g->render_buf[i];
+                d[3 * i + 0] = (uint8_t)(p >> 16);
+                d[3 * i + 1] = (uint8_t)(p >> 8);
+                d[3 * i + 2] = (uint8_t)p;
+            }
+        }
+        if (rew) rew[n] = g->reward;
+        if (first) first[n] = (uint8_t)g->done;
+        if (prev_level_seed) prev_level_seed[n] = g->prev_level_seed;
+        if (prev_level_complete) prev_level_complete[n] = (uint8_t)g->level_complete;
+        if (level_seed) level_seed[n] = g->current_level_seed;
+    }
+}
+
+int pgo_num_entities(PgoVec *v, int env) { return v->games[env].n_ents; }
+
+void pgo_dump_entities(PgoVec *v, int env, int32_t *out) { /* order of src/entity.cpp:90-137 */
+    Game *g = &v->games[env];
+    for (int i = 0; i < g->n_ents; i++) {
+        const Ent *e = &g->pool[g->ents[i]];
+        int32_t *o = out + 31 * i;
+        float f[31];
+        int isf[31];
+        int k = 0;
+#define PF(v) f[k] = (v); isf[k] = 1; k++;
+#define PI_(v) o[k] = (int32_t)(v); isf[k] = 0; k++;
+        PF(e->x) PF(e->y) PF(e->vx) PF(e->vy) PF(e->rx) PF(e->ry)
+        PI_(e->type) PI_(e->image_type) PI_(e->image_theme) PI_(e->render_z) PI_(e->will_erase) PI_(e->collides_with_entities)
+        PF(e->collision_margin) PF(e->rotation) PF(e->vrot)
+        PI_(e->is_reflected) PI_(e->fire_time) PI_(e->spawn_time) PI_(e->life_time) PI_(e->expire_time) PI_(e->use_abs_coords)
+        PF(e->friction) PI_(e->smart_step) PI_(e->avoids_collisions) PI_(e->auto_erase)
+        PF(e->alpha) PF(e->health) PF(e->theta) PF(e->grow_rate) PF(e->alpha_decay) PF(e->climber_spawn_x)
+#undef PF
+#undef PI_
+        for (int q = 0; q < 31; q++)
+            if (isf[q]) memcpy(&o[q], &f[q], 4);
+    }
+}
+
+void pgo_dump_grid(PgoVec *v, int env, int32_t *out, int *w, int *h) {
+    Game *g = &v->games[env];
+    *w = g->grid_w;
+    *h = g->grid_h;
+    memcpy(out, g->grid, sizeof(int) * (size_t)(g->grid_w * g->grid_h));
+}
+
+void pgo_dump_scalars(PgoVec *v, int env, int32_t *out) {
+    Game *g = &v->games[env];
+    memset(out, 0, 16 * sizeof(int32_t));
+    out[0] = g->cur_time;
+    out[1] = (int32_t)(g->rand_gen.draws & 0x7fffffff);
+    out[2] = g->step_rand_int;
+    out[3] = g->background_index;
+    memcpy(&out[4], &g->bg_pct_x, 4);
+    out[5] = g->wall_theme;
+    out[6] = g->has_support;
+    out[7] = g->is_on_crate;
+    memcpy(&out[8], &g->last_agent_y, 4);
+    out[9] = g->current_level_seed;
+    out[10] = g->prev_level_seed;
+    out[11] = g->last_move_action;
+}

@@ -1,0 +1,86 @@
+"""
+Generates the committed golden fixtures from the COMPILED REFERENCE (oracle/_ref/libenv.so, built by
+`make -C oracle ref` from the unmodified sources under /root/reference).  Run in the build container:
+
+    python tests/golden/make_golden.py
+
+Fixtures (npz, small):
+  <game>_rollout.npz : the reference's own determinism protocol (reference procgen/env_test.py:33-52:
+                       rand_seed=23, actions = RandomState(0).randint(0, 15, (num,), int32) per step) extended to
+                       N envs x T steps: actions, rew, first, prev_level_seed, prev_level_complete, level_seed,
+                       per-frame CRC32 of the RGB888 frame, full frames every `frame_every` steps, and the entity
+                       table / grid / key scalars parsed from get_state at a few checkpoints.
+  <game>_seeding.npz : reference procgen/env_test.py:7-30 (num_levels=1, start_level in {0,1}): first frames after
+                       one step of action 0.
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+sys.path.insert(0, os.path.join(REPO, "tests", "tools"))
+
+import ref_env  # noqa: E402
+import state_parse  # noqa: E402
+
+
+def rollout(game, n, t_steps, frame_every, state_at):
+    env = ref_env.make_ref_env(n, game, rand_seed=23)
+    rng = np.random.RandomState(0)
+    out = {k: [] for k in ("actions", "rew", "first", "prev_level_seed", "prev_level_complete", "level_seed", "crc")}
+    frames, frame_t = [], []
+    states = {}
+    for t in range(t_steps + 1):
+        rew, ob, first = env.observe()
+        info = env.info_arrays()
+        out["rew"].append(rew.copy())
+        out["first"].append(first.astype(np.uint8))
+        for k in ("prev_level_seed", "prev_level_complete", "level_seed"):
+            out[k].append(info[k].copy())
+        out["crc"].append(np.array([zlib.crc32(ob["rgb"][e].tobytes()) for e in range(n)], dtype=np.uint32))
+        if t % frame_every == 0:
+            frames.append(ob["rgb"][: min(n, 4)].copy())
+            frame_t.append(t)
+        if t in state_at:
+            sts = [state_parse.parse_state(s) for s in env.get_state()]
+            states[t] = sts
+        ac = rng.randint(0, 15, size=(n,), dtype=np.int32)
+        out["actions"].append(ac)
+        env.act(ac)
+    res = {k: np.array(v) for k, v in out.items()}
+    res["frames"] = np.array(frames)
+    res["frame_t"] = np.array(frame_t)
+    for t, sts in states.items():
+        for e, st in enumerate(sts[: min(n, 4)]):
+            res[f"state{t}_e{e}_entities"] = state_parse.entities_as_words(st)
+            res[f"state{t}_e{e}_grid"] = st["grid"].astype(np.int16)
+            res[f"state{t}_e{e}_scalars"] = np.array(
+                [st["cur_time"], st["step_rand_int"], st["background_index"], np.float32(st["bg_pct_x"]).view(np.int32),
+                 st["rand_gen"]["idx"], st["current_level_seed"], st["last_move_action"]], dtype=np.int64)
+    env.close()
+    return res
+
+
+def seeding(game):
+    res = {}
+    for lvl in (0, 1):
+        env = ref_env.make_ref_env(1, game, num_levels=1, start_level=lvl, rand_seed=5)
+        env.act(np.zeros(1, np.int32))
+        _, ob, _ = env.observe()
+        res[f"level{lvl}"] = ob["rgb"][0].copy()
+        env.close()
+    return res
+
+
+if __name__ == "__main__":
+    games = sys.argv[1:] or ["coinrun"]
+    for game in games:
+        r = rollout(game, n=16, t_steps=512, frame_every=64, state_at=(0, 100, 300, 512))
+        np.savez_compressed(os.path.join(HERE, f"{game}_rollout.npz"), **r)
+        np.savez_compressed(os.path.join(HERE, f"{game}_seeding.npz"), **seeding(game))
+        print(game, "done", {k: v.shape for k, v in r.items() if not k.startswith("state")})
