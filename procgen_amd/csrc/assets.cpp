@@ -1,0 +1,185 @@
+#include "assets.h"
+
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+
+namespace pgamd {
+
+static const char *GAME_NAMES[NUM_GAMES] = {"bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot",
+                                             "heist", "jumper", "leaper", "maze", "miner", "ninja", "plunder", "starpilot"};
+
+int game_id_from_name(const std::string &name) {
+    for (int i = 0; i < NUM_GAMES; i++)
+        if (name == GAME_NAMES[i]) return i;
+    return -1;
+}
+const char *game_name_from_id(int id) { return (id >= 0 && id < NUM_GAMES) ? GAME_NAMES[id] : "?"; }
+
+static std::string lower(std::string s) {
+    std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+    return s;
+}
+
+// background groups: reference src/resources.cpp:817-953
+static const char *SPACE_BGS[] = {"deep_space_01", "spacegen_01", "milky_way_01", "ez_space_lite_01", "meyespace_v1_01", "eye_nebula_01", "deep_sky_01",
+                                  "space_nebula_01", "Background-1", "Background-2", "Background-3", "Background-4", "parallax-space-backgound"};
+static const char *PLATFORM_BGS[] = {"alien_bg", "another_world_bg", "back_cave", "caverns", "cyberpunk_bg", "parallax_forest", "scifi_bg", "scifi2_bg",
+                                     "living_tissue_bg", "airadventurelevel1", "airadventurelevel2", "airadventurelevel3", "airadventurelevel4",
+                                     "cave_background", "blue_desert", "blue_grass", "blue_land", "blue_shroom", "colored_desert", "colored_grass",
+                                     "colored_land", "colored_shroom", "landscape1", "landscape2", "landscape3", "landscape4", "battleback1",
+                                     "battleback2", "battleback3", "battleback4", "battleback5", "battleback6", "battleback7", "battleback8",
+                                     "battleback9", "battleback10", "sunrise"};
+static const char *PLATFORM2_BGS[] = {"beach1", "beach2", "beach3", "beach4", "fantasy1", "fantasy2", "fantasy3", "fantasy4", "candy1", "candy2", "candy3", "candy4"};
+
+static void platform_backgrounds(std::vector<std::string> *out) {
+    for (const char *n : PLATFORM_BGS) out->push_back(std::string("platform_backgrounds/") + n + ".png");
+    for (const char *n : PLATFORM2_BGS) out->push_back(std::string("platform_backgrounds_2/") + n + ".png");
+    for (const char *n : SPACE_BGS) out->push_back(std::string("space_backgrounds/") + n + ".png");  // resources.cpp:950-953
+}
+
+static void reserved_assets(std::vector<SpriteName> *s) {  // reference BAG:416-430
+    for (int k = 0; k < 5; k++) s->push_back({EXPLOSION + k, 0, "misc_assets/explosion" + std::to_string(k + 1) + ".png"});
+    s->push_back({TRAIL, 0, "misc_assets/iconCircle_white.png"});
+}
+
+bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector<std::string> *backgrounds) {
+    sprites->clear();
+    backgrounds->clear();
+    auto add_themes = [&](int type, const std::vector<std::string> &paths) {
+        for (size_t t = 0; t < paths.size(); t++) sprites->push_back({type, (int)t, paths[t]});
+    };
+    if (game_id == GAME_COINRUN) {  // reference src/games/coinrun.cpp:33-35,60-62,72-121
+        const std::vector<std::string> enemies = {"slimeBlock", "slimePurple", "slimeBlue", "slimeGreen", "mouse", "snail", "ladybug", "wormGreen", "wormPink"};
+        const std::vector<std::string> colors = {"Beige", "Blue", "Green", "Pink", "Yellow"};
+        const std::vector<std::string> grounds = {"Dirt", "Grass", "Planet", "Sand", "Snow", "Stone"};
+        const int ptypes[4] = {0, 9, 12, 13};
+        const char *pnames[4] = {"stand", "jump", "walk1", "walk2"};
+        for (int k = 0; k < 4; k++) {
+            std::vector<std::string> v;
+            for (auto &c : colors) v.push_back("kenney/Players/128x256/" + c + "/alien" + c + "_" + pnames[k] + ".png");
+            add_themes(ptypes[k], v);
+        }
+        std::vector<std::string> e1, e2, top, mid;
+        for (auto &e : enemies) e1.push_back("kenney/Enemies/" + e + ".png");
+        for (auto &e : enemies) e2.push_back("kenney/Enemies/" + e + "_move.png");
+        for (auto &g : grounds) top.push_back("kenney/Ground/" + g + "/" + lower(g) + "Mid.png");
+        for (auto &g : grounds) mid.push_back("kenney/Ground/" + g + "/" + lower(g) + "Center.png");
+        add_themes(6, e1);
+        add_themes(7, e2);
+        add_themes(1, {"kenney/Items/coinGold.png"});
+        add_themes(16, top);
+        add_themes(15, mid);
+        add_themes(18, {"kenney/Tiles/lavaTop_low.png"});
+        add_themes(17, {"kenney/Tiles/lava.png"});
+        add_themes(2, {"kenney/Enemies/sawHalf.png"});
+        add_themes(3, {"kenney/Enemies/sawHalf_move.png"});
+        add_themes(20, {"kenney/Tiles/boxCrate.png", "kenney/Tiles/boxCrate_double.png", "kenney/Tiles/boxCrate_single.png", "kenney/Tiles/boxCrate_warning.png"});
+        platform_backgrounds(backgrounds);
+    } else {
+        return false;
+    }
+    reserved_assets(sprites);
+    return true;
+}
+
+static bool file_exists(const std::string &p) {
+    struct stat st;
+    return !p.empty() && stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+static bool gather_images(int game_id, const std::string &resource_root, const AtlasPack *pack, std::vector<SpriteName> *sprites,
+                          std::vector<std::string> *bgs, AtlasPack *out, std::string *err) {
+    if (!game_asset_names(game_id, sprites, bgs)) {
+        if (err) *err = std::string("no asset table for game ") + game_name_from_id(game_id);
+        return false;
+    }
+    auto fetch = [&](const std::string &path, ImageFormat fmt) -> bool {
+        const std::string key = fmt == IMG_RGB32 ? path + "|bg" : path;
+        if (out->images.count(key)) return true;
+        if (pack) {
+            auto it = pack->images.find(key);
+            if (it == pack->images.end()) {
+                if (err) *err = "atlas pack lacks " + key;
+                return false;
+            }
+            out->images[key] = it->second;
+            return true;
+        }
+        Image im;
+        if (!decode_png(resource_root + path, fmt, &im, err)) return false;
+        out->images[key] = std::move(im);
+        return true;
+    };
+    for (auto &s : *sprites)
+        if (!fetch(s.path, IMG_ARGB32_PM)) return false;
+    for (auto &b : *bgs)
+        if (!fetch(b, IMG_RGB32)) return false;
+    return true;
+}
+
+bool bake_game_atlas(int game_id, const std::string &resource_root, const std::string &atlas_path, std::string *err) {
+    std::vector<SpriteName> sprites;
+    std::vector<std::string> bgs;
+    AtlasPack out;
+    if (!gather_images(game_id, resource_root, nullptr, &sprites, &bgs, &out, err)) return false;
+    return out.save(atlas_path, err);
+}
+
+bool load_game_assets(int game_id, const std::string &resource_root, const std::string &atlas_path, HostAssets *out, std::string *err) {
+    std::vector<SpriteName> sprites;
+    std::vector<std::string> bgs;
+    AtlasPack pack, imgs;
+    const bool use_pack = file_exists(atlas_path);
+    if (use_pack && !pack.load(atlas_path, err)) return false;
+    if (!gather_images(game_id, resource_root, use_pack ? &pack : nullptr, &sprites, &bgs, &imgs, err)) return false;
+
+    GameAssetsDev &t = out->table;
+    memset(&t, 0, sizeof(t));
+    for (auto &row : t.type_theme_img)
+        for (auto &v : row) v = -1;
+    out->pixels.clear();
+    out->image_names.clear();
+    std::map<std::string, int> index;
+    auto place = [&](const std::string &key) -> int {
+        auto it = index.find(key);
+        if (it != index.end()) return it->second;
+        const Image &im = imgs.images.at(key);
+        const int idx = (int)out->image_names.size();
+        if (idx >= MAX_GAME_IMAGES) return -1;
+        t.img[idx].off = (uint32_t)out->pixels.size();
+        t.img[idx].w = (uint16_t)im.w;
+        t.img[idx].h = (uint16_t)im.h;
+        out->pixels.insert(out->pixels.end(), im.px.begin(), im.px.end());
+        out->image_names.push_back(key);
+        index[key] = idx;
+        return idx;
+    };
+    for (auto &s : sprites) {
+        const int idx = place(s.path);
+        if (idx < 0 || s.type < 0 || s.type >= MAX_ASSETS || s.theme >= MAX_IMAGE_THEMES) {
+            if (err) *err = "asset table overflow";
+            return false;
+        }
+        t.type_theme_img[s.type][s.theme] = (int16_t)idx;
+        if (t.type_num_themes[s.type] < s.theme + 1) t.type_num_themes[s.type] = (uint8_t)(s.theme + 1);
+    }
+    t.n_bg = (int32_t)bgs.size();
+    if (t.n_bg > MAX_BACKGROUNDS) {
+        if (err) *err = "too many backgrounds";
+        return false;
+    }
+    for (size_t i = 0; i < bgs.size(); i++) {
+        const int idx = place(bgs[i] + "|bg");
+        if (idx < 0) {
+            if (err) *err = "asset table overflow";
+            return false;
+        }
+        t.bg_img[i] = (int16_t)idx;
+    }
+    return true;
+}
+
+}  // namespace pgamd

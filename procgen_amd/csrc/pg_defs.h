@@ -1,0 +1,132 @@
+// pg_defs.h -- constants and HBM-resident data layout shared by the host driver and the kernels.
+//
+// References: object ids reference src/object-ids.h; resolution reference src/game.h:23-26;
+// BasicAbstractGame constants reference src/basic-abstract-game.cpp:6-20 ("BAG").
+#pragma once
+#include <stdint.h>
+
+namespace pgamd {
+
+constexpr int RES_W = 64;
+constexpr int RES_H = 64;
+constexpr int OBS_BYTES = RES_W * RES_H * 3;
+
+constexpr int INVALID_OBJ = -1;
+constexpr int PLAYER = 0;
+constexpr int SPACE = 100;
+constexpr int WALL_OBJ = 51;
+constexpr int EXPLOSION = 54;
+constexpr int EXPLOSION5 = 58;
+constexpr int TRAIL = 59;
+constexpr int USE_ASSET_THRESHOLD = 100;
+constexpr int MAX_ASSETS = 100;
+constexpr int MAX_IMAGE_THEMES = 10;
+
+enum GameId : int {
+    GAME_BIGFISH = 0, GAME_BOSSFIGHT, GAME_CAVEFLYER, GAME_CHASER, GAME_CLIMBER, GAME_COINRUN, GAME_DODGEBALL,
+    GAME_FRUITBOT, GAME_HEIST, GAME_JUMPER, GAME_LEAPER, GAME_MAZE, GAME_MINER, GAME_NINJA, GAME_PLUNDER,
+    GAME_STARPILOT, NUM_GAMES
+};
+
+enum DistributionMode : int { EasyMode = 0, HardMode = 1, ExtremeMode = 2, MemoryMode = 10 };
+
+// ---- options common to every env of a handle (reference src/game.h:45-60, src/vecgame.cpp:183-190) ----
+struct GameOptions {
+    int paint_vel_info, use_generated_assets, use_monochrome_assets, restrict_themes, use_backgrounds, center_agent;
+    int debug_mode, distribution_mode, use_sequential_levels;
+    int level_seed_low, level_seed_high;
+};
+
+// ---- per-env scalar state: one record per env in HBM (Game + BasicAbstractGame + game scalars) ----
+// Field names follow the reference members (reference src/game.h:62-111, src/basic-abstract-game.h:110-160).
+// Every field is one 32-bit word; the list macro lets the kernels move the record HBM <-> registers field by
+// field (the record stays in registers while an env steps).
+#define PG_HDR_FIELDS(X)                                                                                          \
+    /* Game */                                                                                                    \
+    X(float, reward) X(int, done) X(int, level_complete) X(int, action) X(int, timeout)                           \
+    X(int, current_level_seed) X(int, prev_level_seed) X(int, episodes_remaining) X(int, episode_done)            \
+    X(int, last_reward_timer) X(float, last_reward) X(int, default_action) X(int, cur_time) X(int, grid_step)     \
+    X(float, total_reward)                                                                                        \
+    X(int, rand_idx)     /* position in rand_gen's 624-word state (std::mt19937 _M_p) */                          \
+    X(int, lvl_rand_idx) /* same for level_seed_rand_gen */                                                       \
+    X(int, initial_reset_complete)                                                                                \
+    /* BasicAbstractGame */                                                                                       \
+    X(int, n_ents) X(int, agent) /* index of the agent in the entity list */                                      \
+    X(int, background_index) X(float, bg_tile_ratio) X(float, bg_pct_x)                                           \
+    X(int, last_move_action) X(int, move_action) X(int, special_action)                                           \
+    X(float, mixrate) X(float, maxspeed) X(float, max_jump)                                                       \
+    X(float, action_vx) X(float, action_vy) X(float, action_vrot) X(float, center_x) X(float, center_y)           \
+    X(int, random_agent_start) X(int, has_useful_vel_info) X(int, step_rand_int)                                  \
+    X(int, main_width) X(int, main_height) X(int, out_of_bounds_object)                                           \
+    X(float, unit) X(float, view_dim) X(float, x_off) X(float, y_off) X(float, visibility) X(float, min_visibility) \
+    /* bookkeeping of this implementation */                                                                      \
+    X(int, error)      /* first failed reference fassert / capacity overflow (0 = none) -> host fatal() */        \
+    X(int, big)        /* 1: entity count may exceed the small-LDS kernel's capacity next step */                 \
+    X(int, grid_dirty)                                                                                            \
+    /* game-specific scalars (meaning defined by the game policy, e.g. game_coinrun.h) */                         \
+    X(int, gsi0) X(int, gsi1) X(int, gsi2) X(int, gsi3) X(int, gsi4) X(int, gsi5) X(int, gsi6) X(int, gsi7)       \
+    X(float, gsf0) X(float, gsf1) X(float, gsf2) X(float, gsf3) X(float, gsf4) X(float, gsf5) X(float, gsf6) X(float, gsf7)
+
+struct EnvHdr {
+#define PG_X(type, name) type name;
+    PG_HDR_FIELDS(PG_X)
+#undef PG_X
+};
+constexpr int ENV_HDR_WORDS = (int)(sizeof(EnvHdr) / 4);
+
+constexpr int MT_N = 624;
+constexpr int MT_STRIDE = 640;  // words per generator state in HBM (624 + pad, 128-B multiple)
+
+// ---- entity table: SoA [field][slot], one table per env in HBM, staged in LDS while an env steps ----
+// The 31 members of the reference Entity (reference src/entity.h:9-48) with the 4 small ints and 7 bools
+// packed into EF_META.
+enum EntField : int {
+    EF_X = 0, EF_Y, EF_VX, EF_VY, EF_RX, EF_RY,
+    EF_META,  // type:10 | image_type:8 | image_theme:4 | (render_z+1):2 | flags:7  (see pg_ents.h)
+    EF_FIRE_TIME, EF_SPAWN_TIME, EF_LIFE_TIME, EF_EXPIRE_TIME,
+    EF_COLLISION_MARGIN, EF_ROTATION, EF_VROT, EF_FRICTION,
+    EF_ALPHA, EF_HEALTH, EF_THETA, EF_GROW_RATE, EF_ALPHA_DECAY, EF_CLIMBER_SPAWN_X,
+    EF_COUNT
+};
+
+// ---- sprite atlas in HBM ----
+struct ImgDesc {
+    uint32_t off;  // first pixel (0xAARRGGBB words) in the atlas blob
+    uint16_t w, h;
+};
+constexpr int MAX_GAME_IMAGES = 256;
+constexpr int MAX_BACKGROUNDS = 128;
+struct GameAssetsDev {
+    ImgDesc img[MAX_GAME_IMAGES];
+    int16_t type_theme_img[MAX_ASSETS][MAX_IMAGE_THEMES];  // -1 = none
+    uint8_t type_num_themes[MAX_ASSETS];
+    int32_t n_bg;
+    int16_t bg_img[MAX_BACKGROUNDS];
+};
+
+// ---- everything a kernel launch needs ----
+struct DevCtx {
+    int num_envs;
+    GameOptions opt;
+    // per-env state
+    EnvHdr *hdr;          // [num_envs]
+    uint32_t *rng;        // [num_envs][2][MT_STRIDE]  (0: rand_gen, 1: level_seed_rand_gen)
+    uint32_t *ents;       // [num_envs][EF_COUNT][ent_cap]
+    int ent_cap;          // slots per env in HBM
+    uint8_t *grid;        // [num_envs][grid_bytes]
+    int grid_bytes;
+    // boundary buffers (device side)
+    const int32_t *action;  // [num_envs]
+    uint8_t *obs;           // [num_envs][64][64][3]
+    float *rew;             // [num_envs]
+    int32_t *prev_level_seed, *level_seed;  // [num_envs]
+    uint8_t *first, *prev_level_complete;   // [num_envs]
+    // assets
+    const GameAssetsDev *assets;
+    const uint32_t *pixels;
+    // routing between the small-LDS and large-LDS kernels
+    int *big_list;   // [num_envs] env ids routed to the large kernel
+    int *big_count;  // [1]
+};
+
+}  // namespace pgamd

@@ -1,0 +1,1126 @@
+// pg_env.h -- the per-environment stepper: ONE wavefront (= one workgroup) advances ONE environment.
+//
+// This file is the device-side equivalent of the reference's Game / BasicAbstractGame runtime
+// (reference src/game.cpp:93-165, src/basic-abstract-game.cpp ["BAG"], src/entity.cpp, src/randgen.cpp) and of
+// the Qt raster calls it issues (QPainter::drawImage / fillRect on a 64x64 RGB32 image).  It is NOT a
+// translation: entities live as an SoA table staged in LDS, order-dependent loops become
+// ballot + highest-set-bit walks, level generation consumes a bit-exact MT19937 stream held in LDS, and the
+// frame is produced by a two-phase rasterizer (lane-parallel draw-command setup in fp64, then 8x8 pixel
+// blocks per command into an LDS framebuffer, then one coalesced RGB888 store).
+//
+// Written against wave.h's wave-structured execution model; game rules come from a policy class
+// (game_coinrun.h, ...).  Floating point mirrors the reference expression by expression (float/double
+// promotion order); build with -ffp-contract=off.
+#pragma once
+#include "pg_defs.h"
+#include "wave.h"
+
+namespace pgamd {
+
+constexpr float PG_PI = 3.14159265358979323846264338327950288f;  // reference src/cpp-utils.h:12
+constexpr float MAXVTHETA = 15 * PG_PI / 180;                    // BAG:6
+constexpr float MIXRATEROT = 0.5f;                               // BAG:7
+constexpr float POS_EPS = -0.001f;                               // BAG:10
+constexpr float RENDER_EPS = 0.02f;                              // BAG:14
+
+// error codes stored in EnvHdr::error (host turns them into the reference's fatal()/fassert exit)
+enum PgError : int { PGE_NONE = 0, PGE_ENT_OVERFLOW = 1, PGE_GRID_OOB = 2, PGE_ASSERT = 3, PGE_THEME = 4, PGE_UNSUPPORTED_DRAW = 5 };
+
+// ---- EF_META packing -------------------------------------------------------------------------------------
+constexpr uint32_t M_TYPE_MASK = 0x3ffu;
+constexpr int M_IMG_SHIFT = 10;   // 8 bits
+constexpr int M_THEME_SHIFT = 18; // 4 bits
+constexpr int M_Z_SHIFT = 22;     // 2 bits, render_z + 1
+constexpr uint32_t MF_WILL_ERASE = 1u << 24;
+constexpr uint32_t MF_COLLIDES = 1u << 25;
+constexpr uint32_t MF_REFLECTED = 1u << 26;
+constexpr uint32_t MF_ABS_COORDS = 1u << 27;
+constexpr uint32_t MF_SMART_STEP = 1u << 28;
+constexpr uint32_t MF_AVOIDS = 1u << 29;
+constexpr uint32_t MF_AUTO_ERASE = 1u << 30;
+
+PG_DEV uint32_t meta_make(int type, int image_type, int image_theme, int render_z, uint32_t flags) {
+    return ((uint32_t)type & M_TYPE_MASK) | (((uint32_t)image_type & 0xffu) << M_IMG_SHIFT) | (((uint32_t)image_theme & 0xfu) << M_THEME_SHIFT) |
+           (((uint32_t)(render_z + 1) & 3u) << M_Z_SHIFT) | flags;
+}
+PG_DEV int meta_type(uint32_t m) { return (int)(m & M_TYPE_MASK); }
+PG_DEV int meta_image_type(uint32_t m) { return (int)((m >> M_IMG_SHIFT) & 0xffu); }
+PG_DEV int meta_image_theme(uint32_t m) { return (int)((m >> M_THEME_SHIFT) & 0xfu); }
+PG_DEV int meta_render_z(uint32_t m) { return (int)((m >> M_Z_SHIFT) & 3u) - 1; }
+
+struct RectD {
+    double x, y, w, h;
+};
+
+PG_DEV RectD adjust_rect(RectD b, double ax, double ay, double aw, double ah) {  // reference src/qt-utils.h:12-19
+    RectD r;
+    r.x = b.x + b.w * ax;
+    r.y = b.y + b.h * ay;
+    r.w = b.w * aw;
+    r.h = b.h * ah;
+    return r;
+}
+
+PG_DEV int q_round(double d) {  // Qt 5.9 qRound(double)
+    return d >= 0.0 ? (int)(d + 0.5) : (int)(d - (double)((int)(d - 1)) + 0.5) + (int)(d - 1);
+}
+PG_DEV uint32_t byte_mul(uint32_t x, uint32_t a) {  // Qt BYTE_MUL (qdrawhelper_p.h)
+    uint32_t t = (x & 0xff00ffu) * a;
+    t = (t + ((t >> 8) & 0xff00ffu) + 0x800080u) >> 8;
+    t &= 0xff00ffu;
+    x = ((x >> 8) & 0xff00ffu) * a;
+    x = (x + ((x >> 8) & 0xff00ffu) + 0x800080u);
+    x &= 0xff00ff00u;
+    return x | t;
+}
+PG_DEV double sign_d(double x) { return x > 0 ? +1 : (x == 0 ? 0 : -1); }  // reference src/cpp-utils.h:43-45
+PG_DEV float clip_abs(float x, float y) {                                   // reference src/cpp-utils.h:47-53
+    if (x > y) return y;
+    if (x < -y) return -y;
+    return x;
+}
+
+// draw-command words kept in LDS for one batch of 64 drawables
+enum CmdWord : int { CW_GEOM = 0, CW_BASEX, CW_SRCY, CW_IX, CW_IY, CW_IMG, CW_COUNT };
+// CW_GEOM: tx1 | ty1<<7 | w<<14 | h<<21 (w == 0: nothing to draw);  CW_IMG: image index | mirrored<<12 | const_alpha(0..256)<<16
+
+// ---- LDS arena of one workgroup ---------------------------------------------------------------------------
+template <class Game, int CAP>
+struct Lds {
+    uint32_t fb[RES_W * RES_H];  // 0xffRRGGBB framebuffer; fb[0..1279] doubles as MT19937 scratch A/B before rendering
+    uint32_t ent[EF_COUNT * CAP];
+    uint32_t cmd[CW_COUNT][64];
+    uint32_t tmp[64];
+    typename Game::cell_t grid[Game::MAX_CELLS];
+};
+
+template <class Game, int CAP>
+struct Env {
+    using cell_t = typename Game::cell_t;
+    static constexpr int CAPACITY = CAP;
+    const DevCtx &d;
+    const int env;
+    Lds<Game, CAP> *s;
+    EnvHdr G;
+    // rand_gen bookkeeping: where the live 624-word state is (HBM home or LDS scratch)
+    uint32_t *rg_home;
+    uint32_t *rg_cur;
+    bool rg_in_lds;
+
+    PG_DEV Env(const DevCtx &d_, int env_, Lds<Game, CAP> *s_) : d(d_), env(env_), s(s_) {
+        rg_home = d.rng + (size_t)env * 2 * MT_STRIDE;
+        rg_cur = rg_home;
+        rg_in_lds = false;
+    }
+
+    // ======================================================================================================
+    // entity table accessors (LDS SoA)
+    PG_DEV float &ef(int field, int i) { return reinterpret_cast<float *>(s->ent)[field * CAP + i]; }
+    PG_DEV int &ei(int field, int i) { return reinterpret_cast<int *>(s->ent)[field * CAP + i]; }
+    PG_DEV uint32_t &meta(int i) { return s->ent[EF_META * CAP + i]; }
+    PG_DEV float &ex(int i) { return ef(EF_X, i); }
+    PG_DEV float &ey(int i) { return ef(EF_Y, i); }
+    PG_DEV float &evx(int i) { return ef(EF_VX, i); }
+    PG_DEV float &evy(int i) { return ef(EF_VY, i); }
+    PG_DEV float &erx(int i) { return ef(EF_RX, i); }
+    PG_DEV float &ery(int i) { return ef(EF_RY, i); }
+    PG_DEV int etype(int i) { return meta_type(meta(i)); }
+    PG_DEV bool eflag(int i, uint32_t f) { return (meta(i) & f) != 0; }
+    PG_DEV void set_flag(int i, uint32_t f, bool v) { meta(i) = v ? (meta(i) | f) : (meta(i) & ~f); }
+    PG_DEV void set_image_type(int i, int t) { meta(i) = (meta(i) & ~(0xffu << M_IMG_SHIFT)) | (((uint32_t)t & 0xffu) << M_IMG_SHIFT); }
+    PG_DEV void set_image_theme(int i, int t) { meta(i) = (meta(i) & ~(0xfu << M_THEME_SHIFT)) | (((uint32_t)t & 0xfu) << M_THEME_SHIFT); }
+    PG_DEV void set_render_z(int i, int z) { meta(i) = (meta(i) & ~(3u << M_Z_SHIFT)) | (((uint32_t)(z + 1) & 3u) << M_Z_SHIFT); }
+
+    PG_DEV void fail(int code) {
+        if (G.error == 0) G.error = code;
+    }
+
+    // Entity::Entity(x,y,vx,vy,rx,ry,type): reference src/entity.cpp:11-51
+    PG_DEV void ent_init(int i, float x, float y, float vx, float vy, float rx, float ry, int type) {
+        ex(i) = x; ey(i) = y; evx(i) = vx; evy(i) = vy; erx(i) = rx; ery(i) = ry;
+        meta(i) = meta_make(type, type, 0, 0, MF_AUTO_ERASE);
+        ei(EF_FIRE_TIME, i) = -1;
+        ei(EF_SPAWN_TIME, i) = -1;
+        ei(EF_LIFE_TIME, i) = 0;
+        ei(EF_EXPIRE_TIME, i) = type == EXPLOSION ? 4 : -1;
+        ef(EF_COLLISION_MARGIN, i) = 0.0f;
+        ef(EF_ROTATION, i) = 0.0f;
+        ef(EF_VROT, i) = 0.0f;
+        ef(EF_FRICTION, i) = 1.0f;
+        ef(EF_ALPHA, i) = 1.0f;
+        ef(EF_HEALTH, i) = 1.0f;
+        ef(EF_THETA, i) = -100.0f;
+        ef(EF_GROW_RATE, i) = type == EXPLOSION ? 1.4f : (type == TRAIL ? 1.05f : 1.0f);
+        ef(EF_ALPHA_DECAY, i) = type == TRAIL ? 0.8f : 1.0f;
+        ef(EF_CLIMBER_SPAWN_X, i) = 0.0f;
+    }
+
+    // entities.push_back(new Entity(...)) from wave-uniform code: BAG:566-576
+    PG_DEV int add_entity_rxy(float x, float y, float vx, float vy, float rx, float ry, int type) {
+        int i = G.n_ents;
+        if (i >= CAP - 1) {
+            fail(PGE_ENT_OVERFLOW);
+            return CAP - 2;
+        }
+        ent_init(i, x, y, vx, vy, rx, ry, type);
+        G.n_ents = i + 1;
+        return i;
+    }
+    PG_DEV int add_entity(float x, float y, float vx, float vy, float r, int type) { return add_entity_rxy(x, y, vx, vy, r, r, type); }
+
+    // Entity::step: reference src/entity.cpp:57-82 (callable from a lane section or from uniform code)
+    PG_DEV void ent_step(int i) {
+        uint32_t m = meta(i);
+        if (!(m & MF_SMART_STEP)) {
+            ex(i) += evx(i);
+            ey(i) += evy(i);
+        }
+        ef(EF_ROTATION, i) += ef(EF_VROT, i);
+        float fr = ef(EF_FRICTION, i);
+        evx(i) *= fr;
+        evy(i) *= fr;
+        int lt = ei(EF_LIFE_TIME, i) + 1;
+        ei(EF_LIFE_TIME, i) = lt;
+        int et = ei(EF_EXPIRE_TIME, i);
+        if (et > 0 && lt > et) m |= MF_WILL_ERASE;
+        if (meta_type(m) == EXPLOSION) {
+            int it = meta_image_type(m);
+            if (it < EXPLOSION5) m = (m & ~(0xffu << M_IMG_SHIFT)) | ((uint32_t)(it + 1) << M_IMG_SHIFT);
+        }
+        meta(i) = m;
+        float gr = ef(EF_GROW_RATE, i);
+        erx(i) *= gr;
+        ery(i) *= gr;
+        ef(EF_ALPHA, i) = ef(EF_ALPHA_DECAY, i) * ef(EF_ALPHA, i);
+    }
+
+    // ======================================================================================================
+    // grid (staged in LDS): reference src/grid.h, BAG:125-131,167-223
+    PG_DEV bool grid_contains(int x, int y) { return 0 <= y && y < G.main_height && 0 <= x && x < G.main_width; }
+    PG_DEV int get_obj(int x, int y) {  // BAG:180-185
+        if (!grid_contains(x, y)) return G.out_of_bounds_object;
+        return (int)s->grid[y * G.main_width + x];
+    }
+    PG_DEV void set_obj(int x, int y, int v) {  // grid.h:54-57 (fassert on out-of-range)
+        if (!grid_contains(x, y)) {
+            fail(PGE_GRID_OOB);
+            return;
+        }
+        s->grid[y * G.main_width + x] = (cell_t)v;
+        G.grid_dirty = 1;
+    }
+    PG_DEV int get_obj_from_floats(float i, float j) {  // BAG:167-174
+        if (i < 0) return G.out_of_bounds_object;
+        if (j < 0) return G.out_of_bounds_object;
+        return get_obj((int)pg_floor((double)i), (int)pg_floor((double)j));
+    }
+    // fill_elem BAG:125-131: rows are walked uniformly, lanes cover the columns
+    PG_DEV void fill_elem(int x, int y, int dx, int dy, int elem) {
+        if (dx <= 0 || dy <= 0) return;
+        if (x < 0 || y < 0 || x + dx > G.main_width || y + dy > G.main_height) {
+            fail(PGE_GRID_OOB);
+            return;
+        }
+        const int w = G.main_width;
+        for (int k = 0; k < dy; k++) {
+            PG_FOR_LANES(l) {
+                for (int j = l; j < dx; j += 64) s->grid[(y + k) * w + x + j] = (cell_t)elem;
+            }
+        }
+        G.grid_dirty = 1;
+        PG_SYNC();
+    }
+
+    // ======================================================================================================
+    // MT19937 (std::mt19937 as used by RandGen: reference src/randgen.cpp:6-31,90-98; libstdc++ random.tcc)
+    PG_DEV uint32_t *mt_a() { return s->fb; }
+    PG_DEV uint32_t *mt_b() { return s->fb + MT_STRIDE; }
+
+    // one twist of the whole state: src -> dst (distinct buffers, so lanes never read what others write)
+    PG_DEV void mt_twist(const uint32_t *src, uint32_t *dst) {
+        // k in [0,227): needs old[k], old[k+1], old[k+397]
+        for (int base = 0; base < 227; base += 64) {
+            PG_FOR_LANES(l) {
+                int k = base + l;
+                if (k < 227) {
+                    uint32_t y = (src[k] & 0x80000000u) | (src[k + 1] & 0x7fffffffu);
+                    dst[k] = src[k + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                }
+            }
+        }
+        PG_SYNC();
+        // k in [227,454): new[k-227] was produced by the previous phase
+        for (int base = 227; base < 454; base += 64) {
+            PG_FOR_LANES(l) {
+                int k = base + l;
+                if (k < 454) {
+                    uint32_t y = (src[k] & 0x80000000u) | (src[k + 1] & 0x7fffffffu);
+                    dst[k] = dst[k - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                }
+            }
+        }
+        PG_SYNC();
+        for (int base = 454; base < 623; base += 64) {
+            PG_FOR_LANES(l) {
+                int k = base + l;
+                if (k < 623) {
+                    uint32_t y = (src[k] & 0x80000000u) | (src[k + 1] & 0x7fffffffu);
+                    dst[k] = dst[k - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                }
+            }
+        }
+        PG_SYNC();
+        {
+            uint32_t y = (src[623] & 0x80000000u) | (dst[0] & 0x7fffffffu);
+            uint32_t v = dst[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            dst[623] = v;
+        }
+        PG_SYNC();
+    }
+    PG_DEV void mt_copy(const uint32_t *src, uint32_t *dst) {
+        for (int base = 0; base < MT_N; base += 64) {
+            PG_FOR_LANES(l) {
+                int k = base + l;
+                if (k < MT_N) dst[k] = src[k];
+            }
+        }
+        PG_SYNC();
+    }
+    PG_DEV static uint32_t mt_temper(uint32_t z) {
+        z ^= (z >> 11);
+        z ^= (z << 7) & 0x9d2c5680u;
+        z ^= (z << 15) & 0xefc60000u;
+        z ^= (z >> 18);
+        return z;
+    }
+    // rand_gen.seed(seed): state generated serially into LDS scratch A (the recurrence is a dependent chain)
+    PG_DEV void rand_seed(int seed) {
+        uint32_t *a = mt_a();
+        uint32_t x = (uint32_t)seed;
+        for (int i = 0; i < MT_N; i++) {
+            if (i > 0) x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+            a[i] = x;  // wave-uniform store (every lane writes the same word)
+        }
+        PG_SYNC();
+        rg_cur = a;
+        rg_in_lds = true;
+        G.rand_idx = MT_N;
+    }
+    PG_DEV uint32_t rand_u32() {
+        if (G.rand_idx >= MT_N) {
+            uint32_t *dst = (rg_cur == mt_a()) ? mt_b() : mt_a();
+            mt_twist(rg_cur, dst);
+            rg_cur = dst;
+            rg_in_lds = true;
+            G.rand_idx = 0;
+        }
+        uint32_t z = rg_cur[G.rand_idx];
+        G.rand_idx += 1;
+        return mt_temper(z);
+    }
+    // write the live rand_gen state back to its HBM home (before the scratch is reused as framebuffer)
+    PG_DEV void rand_flush() {
+        if (rg_in_lds) {
+            mt_copy(rg_cur, rg_home);
+            rg_cur = rg_home;
+            rg_in_lds = false;
+        }
+    }
+    PG_DEV int randint(int low, int high) {  // randgen.cpp:6-11
+        uint32_t x = rand_u32();
+        uint32_t range = (uint32_t)(high - low);
+        return (int)((uint32_t)low + (x % range));
+    }
+    PG_DEV int randn(int high) { return (int)(rand_u32() % (uint32_t)high); }             // randgen.cpp:13-17
+    PG_DEV float rand01() { return (float)((double)rand_u32() / 4294967296.0); }          // randgen.cpp:19-23
+    // one draw from level_seed_rand_gen (state stays in HBM; a twist goes through scratch A)
+    PG_DEV uint32_t level_seed_u32() {
+        uint32_t *home = rg_home + MT_STRIDE;
+        if (G.lvl_rand_idx >= MT_N) {
+            mt_twist(home, mt_a());
+            mt_copy(mt_a(), home);
+            G.lvl_rand_idx = 0;
+        }
+        uint32_t z = home[G.lvl_rand_idx];
+        G.lvl_rand_idx += 1;
+        return mt_temper(z);
+    }
+
+    // ======================================================================================================
+    // collision predicates: BAG:1068-1084,1126-1131,1145-1150
+    PG_DEV bool has_collision_idx(int a, int b, float margin) {
+        float tx = (erx(a) + erx(b)) + margin;
+        float ty = (ery(a) + ery(b)) + margin;
+        return (pg_fabsf(ex(a) - ex(b)) < tx) && (pg_fabsf(ey(a) - ey(b)) < ty);
+    }
+    PG_DEV bool is_out_of_bounds(int i) {
+        float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
+        if (x + rx < 0) return true;
+        if (y + ry < 0) return true;
+        if (x - rx > G.main_width) return true;
+        if (y - ry > G.main_height) return true;
+        return false;
+    }
+    PG_DEV bool has_agent_collision(int i) {
+        if (etype(i) == PLAYER) return false;
+        return has_collision_idx(i, G.agent, ef(EF_COLLISION_MARGIN, i));
+    }
+
+    // ======================================================================================================
+    // sub_step / push_obj: BAG:240-372.  The recursion (depth <= 5) is unrolled through the template depth.
+    template <int DEPTH>
+    PG_DEV void push_obj(int src, int target, bool is_horizontal) {  // BAG:240-268
+        float rsum = is_horizontal ? (erx(src) + erx(target)) : (ery(src) + ery(target));
+        float delx = ex(target) - ex(src);
+        float dely = ey(target) - ey(src);
+        float t_vx = 0, t_vy = 0;
+        if (is_horizontal) t_vx = (float)((double)ex(src) + sign_d((double)delx) * (double)rsum - (double)ex(target));
+        else t_vy = (float)((double)ey(src) + sign_d((double)dely) * (double)rsum - (double)ey(target));
+        if constexpr (DEPTH < 5) sub_step<DEPTH + 1>(target, t_vx, t_vy);
+        if (is_horizontal) evx(target) = 0;
+        else evy(target) = 0;
+    }
+
+    template <int DEPTH>
+    PG_DEV bool sub_step(int obj, float _vx, float _vy) {  // BAG:270-372
+        if (eflag(obj, MF_WILL_ERASE)) return false;
+        const int otype = etype(obj);
+        const float orx = erx(obj), ory = ery(obj);
+        float ny = ey(obj) + _vy;
+        float nx = ex(obj) + _vx;
+        const float margin = 0.98f;
+        const bool is_horizontal = _vx != 0;
+        bool block = false, reflect = false;
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++) {
+                int type2 = get_obj_from_floats(nx + orx * margin * (2 * i - 1), ny + ory * margin * (2 * j - 1));
+                block = block || Game::is_blocked(*this, otype, type2, is_horizontal);
+                reflect = reflect || Game::will_reflect(otype, type2);
+            }
+        if (reflect) {
+            if (is_horizontal) {
+                float delta;
+                if (_vx < 0) delta = (float)(pg_ceil((double)(nx - orx)) - (double)(nx - orx));
+                else delta = (float)(pg_floor((double)(nx + orx)) - (double)(nx + orx));
+                evx(obj) = -1 * evx(obj);
+                nx = nx + 2 * delta;
+            } else {
+                float delta;
+                if (_vy < 0) delta = (float)(pg_ceil((double)(ny - ory)) - (double)(ny - ory));
+                else delta = (float)(pg_floor((double)(ny + ory)) - (double)(ny + ory));
+                evy(obj) = -1 * evy(obj);
+                ny = ny + 2 * delta;
+            }
+        } else if (block) {
+            if (is_horizontal) {
+                if (G.grid_step) nx = ex(obj);
+                else nx = (float)(_vx > 0 ? (pg_floor((double)(nx + orx)) - (double)orx) : (pg_ceil((double)(nx - orx)) + (double)orx));
+            } else {
+                if (G.grid_step) ny = ey(obj);
+                else ny = (float)(_vy > 0 ? (pg_floor((double)(ny + ory)) - (double)ory) : (pg_ceil((double)(ny - ory)) + (double)ory));
+            }
+        }
+        ex(obj) = nx;
+        ey(obj) = ny;
+        PG_SYNC();
+
+        // reverse scan of the entity list (BAG:337-369): broad phase = one ballot per 64 entities, hits are
+        // visited from the highest index down; the ballot is re-evaluated only after a hit moved `obj`.
+        bool block2 = false;
+        const int n = G.n_ents;
+        for (int c = (n - 1) >> 6; c >= 0; c--) {
+            int limit = 64;  // lanes >= limit of this chunk have been visited
+            bool need_ballot = true;
+            uint64_t m = 0;
+            while (true) {
+                if (need_ballot) {
+                    const float cx = ex(obj), cy = ey(obj);
+                    m = PG_BALLOT(l, ({
+                                      const int idx = (c << 6) + l;
+                                      bool hit = false;
+                                      if (l < limit && idx < n && idx != obj) {
+                                          const uint32_t mm = meta(idx);
+                                          if (!(mm & MF_WILL_ERASE)) {
+                                              const float tx = (orx + erx(idx)) + POS_EPS;
+                                              const float ty = (ory + ery(idx)) + POS_EPS;
+                                              hit = (pg_fabsf(cx - ex(idx)) < tx) && (pg_fabsf(cy - ey(idx)) < ty);
+                                          }
+                                      }
+                                      hit;
+                                  }));
+                    need_ballot = false;
+                }
+                if (m == 0) break;
+                const int jl = pg_highest(m);
+                m &= ~(1ull << jl);
+                limit = jl;
+                const int j = (c << 6) + jl;
+                bool curr_block = false;
+                bool moved = false;
+                if (Game::is_blocked_ents(*this, obj, j, is_horizontal)) {
+                    curr_block = true;
+                } else if (Game::will_reflect(otype, etype(j))) {
+                    if (is_horizontal) {
+                        float delx = ex(j) - ex(obj);
+                        float rsum = erx(j) + orx;
+                        ex(obj) += _vx > 0 ? -2 * (rsum - delx) : 2 * (rsum + delx);
+                        evx(obj) = -1 * evx(obj);
+                    } else {
+                        float dely = ey(j) - ey(obj);
+                        float rsum = ery(j) + ory;
+                        ey(obj) += _vy > 0 ? -2 * (rsum - dely) : 2 * (rsum + dely);
+                        evy(obj) = -1 * evy(obj);
+                    }
+                    moved = true;
+                }
+                if (curr_block) {
+                    push_obj<DEPTH>(j, obj, is_horizontal);
+                    moved = true;
+                }
+                block2 = block2 || curr_block;
+                if (moved) {
+                    PG_SYNC();
+                    need_ballot = true;
+                }
+            }
+        }
+        return block || block2;
+    }
+
+    PG_DEV void basic_step_object(int obj) {  // BAG:593-656
+        if (eflag(obj, MF_WILL_ERASE)) return;
+        int num_sub_steps;
+        {
+            const float vx = evx(obj), vy = evy(obj);
+            if (G.grid_step) {
+                num_sub_steps = 1;
+            } else {
+                num_sub_steps = (int)(4 * pg_sqrt((double)(vx * vx + vy * vy)));  // double sqrt, see oracle note
+                if (num_sub_steps < 4) num_sub_steps = 4;
+            }
+        }
+        const float pct = (float)(1.0 / num_sub_steps);
+        const float cmp = pg_fabsf(evx(obj)) - pg_fabsf(evy(obj));
+        bool step_x_first = cmp == 0 ? (G.step_rand_int % 2 == 0) : (cmp > 0);
+        if (etype(obj) == PLAYER) {
+            if (G.action_vx != 0) step_x_first = true;
+            if (G.action_vy != 0) step_x_first = false;
+        }
+        float vx_pct = 0, vy_pct = 0;
+        for (int st = 0; st < num_sub_steps; st++) {
+            bool block_x = false, block_y = false;
+            for (int h = 0; h < 2; h++) {  // one call site for sub_step<0>
+                const bool xaxis = (h == 0) == step_x_first;
+                const float dvx = xaxis ? evx(obj) * pct : 0.0f;
+                const float dvy = xaxis ? 0.0f : evy(obj) * pct;
+                const bool b = sub_step<0>(obj, dvx, dvy);
+                if (xaxis) block_x = b;
+                else block_y = b;
+            }
+            if (!block_x) vx_pct += 1;
+            if (!block_y) vy_pct += 1;
+            if (block_x && block_y) break;
+        }
+        vx_pct = vx_pct / num_sub_steps;
+        vy_pct = vy_pct / num_sub_steps;
+        evx(obj) *= vx_pct;
+        evy(obj) *= vy_pct;
+    }
+
+    // step_entities BAG:1086-1098: reverse order; runs of non-smart entities are stepped lane-parallel,
+    // smart_step entities (agent, walkers) serially in their list position.
+    PG_DEV void step_entities() {
+        const int n0 = G.n_ents;
+        int hi = n0;  // entities [hi, n0) are done
+        while (hi > 0) {
+            // highest smart_step index below hi
+            int sidx = -1;
+            for (int c = (hi - 1) >> 6; c >= 0 && sidx < 0; c--) {
+                uint64_t m = PG_BALLOT(l, ({
+                                           const int idx = (c << 6) + l;
+                                           idx < hi && (meta(idx) & MF_SMART_STEP) != 0;
+                                       }));
+                if (m) sidx = (c << 6) + pg_highest(m);
+            }
+            const int lo = sidx + 1;  // [lo, hi) are non-smart
+            for (int base = lo & ~63; base < hi; base += 64) {
+                PG_FOR_LANES(l) {
+                    const int idx = base + l;
+                    if (idx >= lo && idx < hi) ent_step(idx);
+                }
+            }
+            PG_SYNC();
+            if (sidx < 0) break;
+            basic_step_object(sidx);
+            ent_step(sidx);
+            PG_SYNC();
+            hi = sidx;
+        }
+    }
+
+    PG_DEV void check_grid_collisions(int ent) {  // BAG:145-165
+        float ax = ex(ent), ay = ey(ent), arx = erx(ent), ary = ery(ent);
+        int min_x = (int)(ax - (arx + POS_EPS));
+        int max_x = (int)(ax + (arx + POS_EPS));
+        int min_y = (int)(ay - (ary + POS_EPS));
+        int max_y = (int)(ay + (ary + POS_EPS));
+        for (int x = min_x; x <= max_x; x++)
+            for (int y = min_y; y <= max_y; y++) {
+                int grid_type = get_obj_from_floats((float)x, (float)y);
+                if (grid_type != SPACE) Game::handle_grid_collision(*this, ent, grid_type, x, y);
+            }
+    }
+
+    // collision pass BAG:719-741.  Entities that need any work (agent overlap, collides_with_entities,
+    // smart_step) are found by ballot and visited from the highest index down; predicates are re-evaluated
+    // at visit time, and the ballot is refreshed after every handler (handlers may change geometry).
+    PG_DEV void collision_pass() {
+        int limit = G.n_ents;
+        while (limit > 0) {
+            const int n = G.n_ents;
+            int i = -1;
+            for (int c = (limit - 1) >> 6; c >= 0 && i < 0; c--) {
+                const int ag = G.agent;
+                const float agx = ex(ag), agy = ey(ag), agrx = erx(ag), agry = ery(ag);
+                uint64_t m = PG_BALLOT(l, ({
+                                           const int idx = (c << 6) + l;
+                                           bool w = false;
+                                           if (idx < limit && idx < n) {
+                                               const uint32_t mm = meta(idx);
+                                               w = (mm & (MF_COLLIDES | MF_SMART_STEP)) != 0;
+                                               if (!w && meta_type(mm) != PLAYER) {
+                                                   const float cm = ef(EF_COLLISION_MARGIN, idx);
+                                                   const float tx = (erx(idx) + agrx) + cm;
+                                                   const float ty = (ery(idx) + agry) + cm;
+                                                   w = (pg_fabsf(ex(idx) - agx) < tx) && (pg_fabsf(ey(idx) - agy) < ty);
+                                               }
+                                           }
+                                           w;
+                                       }));
+                if (m) i = (c << 6) + pg_highest(m);
+            }
+            if (i < 0) break;
+            if (has_agent_collision(i)) Game::handle_agent_collision(*this, i);
+            if (eflag(i, MF_COLLIDES)) {
+                if constexpr (Game::USES_ENTITY_COLLISIONS) {
+                    for (int j = G.n_ents - 1; j >= 0; j--) {
+                        if (i == j) continue;
+                        if (has_collision_idx(i, j, ef(EF_COLLISION_MARGIN, i)) && !eflag(i, MF_WILL_ERASE) && !eflag(j, MF_WILL_ERASE)) Game::handle_collision(*this, i, j);
+                    }
+                }
+            }
+            if (eflag(i, MF_SMART_STEP)) check_grid_collisions(i);
+            PG_SYNC();
+            limit = i;
+        }
+    }
+
+    // erase_if_needed BAG:748-756: stable compaction of the SoA table, field by field through LDS scratch.
+    PG_DEV void erase_if_needed() {
+        const int n = G.n_ents;
+        int kept = 0;
+        int new_agent = G.agent;
+        bool agent_erased = false;
+        const int nchunks = (n + 63) >> 6;
+        for (int c = 0; c < nchunks; c++) {
+            const uint64_t valid = PG_BALLOT(l, ((c << 6) + l) < n);
+            const uint64_t keep = PG_BALLOT(l, ({
+                                                const int idx = (c << 6) + l;
+                                                bool k = false;
+                                                if (idx < n) {
+                                                    const uint32_t mm = meta(idx);
+                                                    k = !((mm & MF_WILL_ERASE) || ((mm & MF_AUTO_ERASE) && is_out_of_bounds(idx)));
+                                                }
+                                                k;
+                                            }));
+            const int base = c << 6;
+            if (G.agent >= base && G.agent < base + 64) {
+                const int al = G.agent - base;
+                if (keep & (1ull << al)) new_agent = kept + pg_popc64(keep & pg_mask_lt(al));
+                else agent_erased = true;
+            }
+            if (agent_erased && G.agent >= base && G.agent < base + 64) {
+                // keep the detached agent readable in the reserved last slot (shared_ptr semantics, BAG:788-792)
+                const int src_i = G.agent;
+                PG_FOR_LANES(l) {
+                    if (l < EF_COUNT) s->tmp[l] = s->ent[l * CAP + src_i];
+                }
+                PG_SYNC();
+                PG_FOR_LANES(l) {
+                    if (l < EF_COUNT) s->ent[l * CAP + (CAP - 1)] = s->tmp[l];
+                }
+                PG_SYNC();
+                new_agent = CAP - 1;
+            }
+            if (keep != valid || kept != base) {
+                for (int f = 0; f < EF_COUNT; f++) {
+                    PG_FOR_LANES(l) { s->tmp[l] = s->ent[f * CAP + base + l]; }
+                    PG_SYNC();
+                    PG_FOR_LANES(l) {
+                        if (keep & (1ull << l)) s->ent[f * CAP + kept + pg_popc64(keep & pg_mask_lt(l))] = s->tmp[l];
+                    }
+                    PG_SYNC();
+                }
+            }
+            kept += pg_popc64(keep);
+        }
+        G.n_ents = kept;
+        G.agent = new_agent;
+    }
+
+    // BasicAbstractGame::game_step BAG:686-746
+    PG_DEV void bag_game_step() {
+        G.step_rand_int = randint(0, 1000000);
+        G.move_action = G.action % 9;
+        G.special_action = 0;
+        if (G.action >= 9) {
+            G.special_action = G.action - 8;
+            G.move_action = 4;
+        }
+        if (G.move_action != 4) G.last_move_action = G.move_action;
+        G.action_vrot = 0;
+        G.action_vx = 0;
+        G.action_vy = 0;
+        Game::set_action_xy(*this, G.move_action);
+        const int ag = G.agent;
+        if (G.grid_step) {
+            evx(ag) = G.action_vx;
+            evy(ag) = G.action_vy;
+        } else {
+            Game::update_agent_velocity(*this);
+            float vrot = MIXRATEROT * ef(EF_VROT, ag);
+            vrot += MIXRATEROT * MAXVTHETA * G.action_vrot;
+            ef(EF_VROT, ag) = vrot;
+        }
+        PG_SYNC();
+        step_entities();
+        collision_pass();
+        erase_if_needed();
+        G.done = G.done || is_out_of_bounds(G.agent);
+    }
+    // default BAG::update_agent_velocity BAG:669-684 (games may override)
+    PG_DEV void bag_update_agent_velocity(float v_scale) {
+        const int ag = G.agent;
+        float vx = (1 - G.mixrate) * evx(ag);
+        float vy = (1 - G.mixrate) * evy(ag);
+        vx += G.mixrate * G.maxspeed * G.action_vx * v_scale;
+        vy += G.mixrate * G.maxspeed * G.action_vy * v_scale;
+        evx(ag) = (float)(.9 * vx);
+        evy(ag) = (float)(.9 * vy);
+    }
+
+    // BasicAbstractGame::game_reset BAG:758-797
+    PG_DEV void bag_game_reset() {
+        if (!(G.main_width > 0 && G.main_height > 0)) fail(PGE_ASSERT);
+        G.bg_pct_x = rand01();
+        G.background_index = randn(d.assets->n_bg);
+        G.n_ents = 0;
+        float ax, ay;
+        const float a_r = 0.4f;
+        if (G.random_agent_start) {
+            ax = rand01() * (G.main_width - 2 * a_r) + a_r;
+            ay = rand01() * (G.main_height - 2 * a_r) + a_r;
+        } else {
+            ax = a_r;
+            ay = a_r;
+        }
+        const int ag = add_entity(ax, ay, 0, 0, a_r, PLAYER);
+        G.agent = ag;
+        set_flag(ag, MF_SMART_STEP, true);
+        set_render_z(ag, 1);
+        PG_SYNC();
+        erase_if_needed();
+        fill_elem(0, 0, G.main_width, G.main_height, SPACE);
+    }
+    PG_DEV void choose_random_theme(int i) {  // BAG:1038-1041
+        const int nt = d.assets->type_num_themes[meta_image_type(meta(i))];
+        if (nt <= 0) {
+            fail(PGE_THEME);
+            return;
+        }
+        set_image_theme(i, randn(nt));
+    }
+
+    // Game::reset reference src/game.cpp:93-118
+    PG_DEV void game_reset_full() {
+        if (G.episodes_remaining == 0) {
+            if (d.opt.use_sequential_levels && G.level_complete) {
+                G.current_level_seed = (int32_t)((uint32_t)G.current_level_seed + 997u);
+            } else {
+                const uint32_t x = level_seed_u32();
+                const uint32_t range = (uint32_t)(d.opt.level_seed_high - d.opt.level_seed_low);
+                G.current_level_seed = (int)((uint32_t)d.opt.level_seed_low + (x % range));
+            }
+            G.episodes_remaining = 1;
+        } else {
+            G.reward = 0;
+            G.done = 0;
+            G.level_complete = 0;
+        }
+        rand_seed(G.current_level_seed);
+        Game::game_reset(*this);
+        G.cur_time = 0;
+        G.total_reward = 0;
+        G.episodes_remaining -= 1;
+        G.action = G.default_action;
+    }
+
+    // Game::step reference src/game.cpp:120-155 (observe() = render(), done by the caller)
+    PG_DEV void game_step_full() {
+        G.cur_time += 1;
+        bool will_force_reset = false;
+        if (G.action == -1) {
+            G.action = G.default_action;
+            will_force_reset = true;
+        }
+        G.reward = 0;
+        G.done = 0;
+        G.level_complete = 0;
+        Game::game_step(*this);
+        G.done = G.done || will_force_reset || (G.cur_time >= G.timeout);
+        G.total_reward += G.reward;
+        if (G.reward != 0) {
+            G.last_reward_timer = 10;
+            G.last_reward = G.reward;
+        }
+        G.prev_level_seed = G.current_level_seed;
+        if (G.done) game_reset_full();
+        if (d.opt.use_sequential_levels && G.level_complete) G.done = 0;
+        G.episode_done = G.done;
+    }
+
+    // ======================================================================================================
+    // Rendering.  Replaces Game::render_to_buf + BasicAbstractGame::game_draw (reference src/game.cpp:77-91,
+    // BAG:799-1012) and the Qt 5.9 raster engine calls they make (drawImage(QRectF,QImage) without
+    // antialiasing/rotation = qt_scale_image_32: 16.16 fixed point nearest sampling + premultiplied SourceOver).
+    PG_DEV RectD get_screen_rect(float x, float y, float dx, float dy, float render_eps) {  // BAG:799-801
+        RectD r;
+        r.x = (double)((x - render_eps) * G.unit - G.x_off);
+        r.y = (double)((G.view_dim - y - render_eps) * G.unit + G.y_off);
+        r.w = (double)((dx + 2 * render_eps) * G.unit);
+        r.h = (double)((dy + 2 * render_eps) * G.unit);
+        return r;
+    }
+    PG_DEV void prepare_for_drawing(float rect_height) {  // BAG:819-838
+        G.center_x = (float)(G.main_width * .5);
+        G.center_y = (float)(G.main_height * .5);
+        if (d.opt.center_agent) {
+            Game::choose_center(*this, G.center_x, G.center_y);
+        } else {
+            G.visibility = (float)(G.main_width > G.main_height ? G.main_width : G.main_height);
+            if (G.visibility < G.min_visibility) G.visibility = G.min_visibility;
+        }
+        const float raw_unit = 64 / G.visibility;
+        G.unit = (float)((double)raw_unit * ((double)rect_height / 64.0));
+        G.view_dim = (float)(64.0 / (double)raw_unit);
+        G.x_off = G.unit * (G.center_x - G.view_dim / 2);
+        G.y_off = G.unit * (G.center_y - G.view_dim / 2);
+    }
+
+    // lane-local: turn (image, target rect, mirror, opacity) into one draw command in slot `slot` of s->cmd
+    PG_DEV void cmd_none(int slot) { s->cmd[CW_GEOM][slot] = 0; }
+    PG_DEV void cmd_image(int slot, int img_index, bool mirrored, RectD tr, float opacity) {
+        const ImgDesc im = d.assets->img[img_index];
+        const double sx = tr.w / (double)im.w;
+        const double sy = tr.h / (double)im.h;
+        const int ix = (int)(65536 / sx);
+        const int iy = (int)(65536 / sy);
+        int tx1 = q_round(tr.x), tx2 = q_round(tr.x + tr.w), ty1 = q_round(tr.y), ty2 = q_round(tr.y + tr.h);
+        if (tx1 < 0) tx1 = 0;
+        if (ty1 < 0) ty1 = 0;
+        if (tx2 > RES_W) tx2 = RES_W;
+        if (ty2 > RES_H) ty2 = RES_H;
+        int w = tx2 - tx1, h = ty2 - ty1;
+        if (w <= 0 || h <= 0) {
+            cmd_none(slot);
+            return;
+        }
+        // Qt 5.9: qCeil(...) - 1 (pinned with tests/tools/qt_drawimage_probe.py)
+        const uint32_t basex = (uint32_t)((int)pg_ceil((tx1 + 0.5 - tr.x) * ix) - 1);
+        const uint32_t srcy = (uint32_t)((int)pg_ceil((ty1 + 0.5 - tr.y) * iy) - 1);
+        const int yend = (int)((srcy + (uint32_t)iy * (uint32_t)(h - 1)) >> 16);
+        if (yend < 0 || yend >= (int)im.h) --h;
+        const int xend = (int)((basex + (uint32_t)ix * (uint32_t)(w - 1)) >> 16);
+        if (xend < 0 || xend >= (int)im.w) --w;
+        if (w <= 0 || h <= 0) {
+            cmd_none(slot);
+            return;
+        }
+        double o = (double)opacity;  // QPainter::setOpacity clamps to [0,1]; intOpacity = int(opacity * 256)
+        if (o < 0) o = 0;
+        if (o > 1) o = 1;
+        const int io = (int)(o * 256);
+        s->cmd[CW_GEOM][slot] = (uint32_t)tx1 | ((uint32_t)ty1 << 7) | ((uint32_t)w << 14) | ((uint32_t)h << 21);
+        s->cmd[CW_BASEX][slot] = basex;
+        s->cmd[CW_SRCY][slot] = srcy;
+        s->cmd[CW_IX][slot] = (uint32_t)ix;
+        s->cmd[CW_IY][slot] = (uint32_t)iy;
+        s->cmd[CW_IMG][slot] = (uint32_t)img_index | ((mirrored ? 1u : 0u) << 12) | ((uint32_t)io << 16);
+    }
+    // draw_image BAG:877-913 for one drawable (lane-local)
+    PG_DEV void cmd_draw_image(int slot, RectD base_rect, float rotation, bool is_reflected, int base_type, int theme, float alpha, float tile_ratio) {
+        const int img_type = Game::image_for_type(*this, base_type);
+        if (img_type < 0) {
+            cmd_none(slot);
+            return;
+        }
+        if (d.opt.use_monochrome_assets || img_type >= USE_ASSET_THRESHOLD) {
+            if (img_type != SPACE) fail(PGE_UNSUPPORTED_DRAW);  // colored grid squares: not on the default-option path yet
+            cmd_none(slot);
+            return;
+        }
+        const RectD adjusted = Game::adjusted_image_rect(img_type, base_rect);
+        int mt = theme;
+        if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;  // BAG:450-453
+        const int img = (mt >= 0 && mt < MAX_IMAGE_THEMES) ? (int)d.assets->type_theme_img[img_type][mt] : -1;
+        if (img < 0) {
+            fail(PGE_THEME);
+            cmd_none(slot);
+            return;
+        }
+        if (rotation != 0 || tile_ratio != 0) {
+            fail(PGE_UNSUPPORTED_DRAW);
+            cmd_none(slot);
+            return;
+        }
+        cmd_image(slot, img, is_reflected, adjusted, alpha);
+    }
+
+    // execute the valid commands of the current batch in slot order; lanes cover 8x8 pixel blocks
+    PG_DEV void run_cmd_batch(int count) {
+        PG_SYNC();
+        uint64_t valid = PG_BALLOT(l, l < count && ((s->cmd[CW_GEOM][l] >> 14) & 0x7fu) != 0);
+        while (valid) {
+            const int k = pg_ctz64(valid);
+            valid &= valid - 1;
+            const uint32_t geom = s->cmd[CW_GEOM][k];
+            const int tx1 = (int)(geom & 0x7fu), ty1 = (int)((geom >> 7) & 0x7fu), w = (int)((geom >> 14) & 0x7fu), h = (int)((geom >> 21) & 0x7fu);
+            const uint32_t basex = s->cmd[CW_BASEX][k], srcy0 = s->cmd[CW_SRCY][k];
+            const uint32_t ix = s->cmd[CW_IX][k], iy = s->cmd[CW_IY][k];
+            const uint32_t cimg = s->cmd[CW_IMG][k];
+            const ImgDesc im = d.assets->img[cimg & 0xfffu];
+            const bool mirrored = ((cimg >> 12) & 1u) != 0;
+            const int io = (int)(cimg >> 16);
+            const uint32_t ca = (uint32_t)((io * 255) >> 8);
+            const uint32_t *src = d.pixels + im.off;
+            for (int by = 0; by < h; by += 8) {
+                for (int bx = 0; bx < w; bx += 8) {
+                    PG_FOR_LANES(l) {
+                        const int px = bx + (l & 7), py = by + (l >> 3);
+                        if (px < w && py < h) {
+                            const int sxp = (int)((basex + (uint32_t)px * ix) >> 16);
+                            const int syp = (int)((srcy0 + (uint32_t)py * iy) >> 16);
+                            uint32_t sp = src[syp * (int)im.w + (mirrored ? ((int)im.w - 1 - sxp) : sxp)];
+                            if (io != 256) sp = byte_mul(sp, ca);
+                            uint32_t *dp = &s->fb[(ty1 + py) * RES_W + tx1 + px];
+                            *dp = sp + byte_mul(*dp, 255u - (sp >> 24));
+                        }
+                    }
+                }
+            }
+            PG_SYNC();
+        }
+    }
+
+    // draw_entities BAG:1052-1066 for one render_z layer, 64 entities per batch
+    PG_DEV void draw_entities(int render_z) {
+        const int n = G.n_ents;
+        for (int base = 0; base < n; base += 64) {
+            const uint64_t any = PG_BALLOT(l, (base + l) < n && meta_render_z(meta(base + l)) == render_z);
+            if (!any) continue;
+            PG_FOR_LANES(l) {
+                const int i = base + l;
+                if (i < n && meta_render_z(meta(i)) == render_z && Game::should_draw_entity(*this, i)) {
+                    const uint32_t mm = meta(i);
+                    RectD r1;  // get_object_rect BAG:811-817
+                    if (mm & MF_ABS_COORDS) {
+                        const float vd = G.view_dim;
+                        r1.x = (double)((vd * (ex(i) - erx(i))) * G.unit);
+                        r1.y = (double)((vd * (ey(i) + ery(i))) * G.unit);
+                        r1.w = (double)((2 * vd * erx(i)) * G.unit);
+                        r1.h = (double)((2 * vd * ery(i)) * G.unit);
+                    } else {
+                        r1 = get_screen_rect(ex(i) - erx(i), ey(i) + ery(i), 2 * erx(i), 2 * ery(i), 0);
+                    }
+                    cmd_draw_image(l, r1, ef(EF_ROTATION, i), (mm & MF_REFLECTED) != 0, meta_image_type(mm), meta_image_theme(mm), ef(EF_ALPHA, i),
+                                   Game::tile_aspect_ratio(*this, i));
+                } else {
+                    cmd_none(l);
+                }
+            }
+            run_cmd_batch(64);
+        }
+    }
+
+    // game_draw BAG:1009-1012 (draw_background BAG:979-1007 + draw_foreground BAG:921-970)
+    PG_DEV void render() {
+        for (int base = 0; base < RES_W * RES_H; base += 64) {
+            PG_FOR_LANES(l) { s->fb[base + l] = 0xff000000u; }  // p.fillRect(rect, QColor(0,0,0))
+        }
+        prepare_for_drawing((float)RES_H);
+        if (d.opt.use_backgrounds) {
+            const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);
+            const int bgi = (int)d.assets->bg_img[G.background_index];
+            if (G.bg_tile_ratio < 0) fail(PGE_UNSUPPORTED_DRAW);
+            const ImgDesc bim = d.assets->img[bgi];
+            const float bgw = (float)bim.w, bgh = (float)bim.h;
+            const float bg_ar = bgw / bgh;
+            const float world_ar = (float)(G.main_width * 1.0 / G.main_height);
+            const float extra_w = bg_ar - world_ar;
+            const float offset_x = G.bg_pct_x * extra_w;
+            const RectD bg_rect = adjust_rect(main_rect, (double)(-offset_x), 0, (double)(bg_ar / world_ar), 1);
+            PG_FOR_LANES(l) {
+                if (l == 0) cmd_image(0, bgi, false, bg_rect, 1.0f);
+            }
+            run_cmd_batch(1);
+        }
+        draw_entities(-1);
+        int low_x, high_x, low_y, high_y;
+        if (d.opt.center_agent) {
+            const float margin = (float)(G.visibility / 2.0 + 1);
+            low_x = (int)(G.center_x - margin);
+            high_x = (int)(G.center_x + margin);
+            low_y = (int)(G.center_y - margin);
+            high_y = (int)(G.center_y + margin);
+        } else {
+            low_x = 0;
+            high_x = G.main_width - 1;
+            low_y = 0;
+            high_y = G.main_height - 1;
+        }
+        const int ny = high_y - low_y + 1;
+        const int ncell = (high_x - low_x + 1) * ny;
+        for (int base = 0; base < ncell; base += 64) {  // x-major order of BAG:941-955
+            PG_FOR_LANES(l) {
+                const int cidx = base + l;
+                bool drawn = false;
+                if (cidx < ncell) {
+                    const int x = low_x + cidx / ny, y = low_y + cidx % ny;
+                    const int type = get_obj(x, y);
+                    if (type != INVALID_OBJ && type != SPACE) {
+                        const int theme = Game::theme_for_grid_obj(*this, type);
+                        const RectD r2 = get_screen_rect((float)x, (float)(y + 1), 1, 1, RENDER_EPS);
+                        cmd_draw_image(l, r2, 0, false, type, theme, 1.0f, 0.0f);
+                        drawn = true;
+                    }
+                }
+                if (!drawn) cmd_none(l);
+            }
+            run_cmd_batch(64);
+        }
+        draw_entities(0);
+        draw_entities(1);
+        if (G.has_useful_vel_info && d.opt.paint_vel_info) fail(PGE_UNSUPPORTED_DRAW);
+        PG_SYNC();
+    }
+
+    // bgr32_to_rgb888 + Game::observe (reference src/game.cpp:8-23,157-165): 4 pixels -> 3 dwords per lane,
+    // each wave-wide store covers 768 contiguous bytes of the observation buffer.
+    PG_DEV void store_observation() {
+        uint32_t *out = reinterpret_cast<uint32_t *>(d.obs + (size_t)env * OBS_BYTES);
+        for (int base = 0; base < RES_W * RES_H; base += 256) {
+            PG_FOR_LANES(l) {
+                const uint32_t *p = &s->fb[base + 4 * l];
+                const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+                // bytes: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3   (pixel word = 0xffRRGGBB)
+                const uint32_t r0 = (p0 >> 16) & 0xff, g0 = (p0 >> 8) & 0xff, b0 = p0 & 0xff;
+                const uint32_t r1 = (p1 >> 16) & 0xff, g1 = (p1 >> 8) & 0xff, b1 = p1 & 0xff;
+                const uint32_t r2 = (p2 >> 16) & 0xff, g2 = (p2 >> 8) & 0xff, b2 = p2 & 0xff;
+                const uint32_t r3 = (p3 >> 16) & 0xff, g3 = (p3 >> 8) & 0xff, b3 = p3 & 0xff;
+                uint32_t *o = out + (base / 4) * 3 + 3 * l;
+                o[0] = r0 | (g0 << 8) | (b0 << 16) | (r1 << 24);
+                o[1] = g1 | (b1 << 8) | (r2 << 16) | (g2 << 24);
+                o[2] = b2 | (r3 << 8) | (g3 << 16) | (b3 << 24);
+            }
+        }
+        PG_FOR_LANES(l) {
+            if (l == 0) {
+                d.rew[env] = G.reward;
+                d.first[env] = (uint8_t)G.done;
+                d.prev_level_seed[env] = G.prev_level_seed;
+                d.prev_level_complete[env] = (uint8_t)G.level_complete;
+                d.level_seed[env] = G.current_level_seed;
+            }
+        }
+    }
+
+    // ======================================================================================================
+    // HBM <-> LDS staging of one env
+    PG_DEV void load_env() {
+        {
+            const EnvHdr *h = d.hdr + env;  // wave-uniform address
+#define PG_X(type, name) G.name = h->name;
+            PG_HDR_FIELDS(PG_X)
+#undef PG_X
+        }
+        const int n = G.n_ents;
+        const uint32_t *ge = d.ents + (size_t)env * EF_COUNT * d.ent_cap;
+        for (int f = 0; f < EF_COUNT; f++) {
+            for (int base = 0; base < n; base += 64) {
+                PG_FOR_LANES(l) {
+                    if (base + l < n) s->ent[f * CAP + base + l] = ge[f * d.ent_cap + base + l];
+                }
+            }
+        }
+        const int cells = G.main_width * G.main_height;
+        const cell_t *gg = reinterpret_cast<const cell_t *>(d.grid + (size_t)env * d.grid_bytes);
+        for (int base = 0; base < cells; base += 64) {
+            PG_FOR_LANES(l) {
+                if (base + l < cells) s->grid[base + l] = gg[base + l];
+            }
+        }
+        G.grid_dirty = 0;
+        PG_SYNC();
+    }
+    PG_DEV void store_env() {
+        const int n = G.n_ents;
+        uint32_t *ge = d.ents + (size_t)env * EF_COUNT * d.ent_cap;
+        if (n > d.ent_cap - 1) fail(PGE_ENT_OVERFLOW);
+        for (int f = 0; f < EF_COUNT; f++) {
+            for (int base = 0; base < n; base += 64) {
+                PG_FOR_LANES(l) {
+                    if (base + l < n && base + l < d.ent_cap) ge[f * d.ent_cap + base + l] = s->ent[f * CAP + base + l];
+                }
+            }
+        }
+        if (G.agent < 0 || G.agent >= n) fail(PGE_ASSERT);  // a detached agent never outlives the step (reset follows)
+        if (G.grid_dirty) {
+            const int cells = G.main_width * G.main_height;
+            cell_t *gg = reinterpret_cast<cell_t *>(d.grid + (size_t)env * d.grid_bytes);
+            for (int base = 0; base < cells; base += 64) {
+                PG_FOR_LANES(l) {
+                    if (base + l < cells) gg[base + l] = s->grid[base + l];
+                }
+            }
+        }
+        G.big = Game::needs_big(n) ? 1 : 0;
+        {
+            EnvHdr *h = d.hdr + env;
+            PG_FOR_LANES(l) {
+                if (l == 0) {
+#define PG_X(type, name) h->name = G.name;
+                    PG_HDR_FIELDS(PG_X)
+#undef PG_X
+                }
+            }
+        }
+    }
+
+    // one libenv step (mode 1) or the initial reset + first observation (mode 0) of this env
+    PG_DEV void run(int mode) {
+        load_env();
+        if (mode != 0) G.action = d.action[env];  // reference src/vecgame.cpp:388
+        if (mode == 0) {
+            game_reset_full();
+            G.initial_reset_complete = 1;
+        } else {
+            game_step_full();
+        }
+        rand_flush();
+        render();
+        store_observation();
+        store_env();
+    }
+};
+
+}  // namespace pgamd

@@ -1,0 +1,69 @@
+// wave.h -- the execution model the kernels are written against: ONE 64-lane wavefront == ONE workgroup
+// == ONE environment.
+//
+// Kernel code is "wave-structured": control flow is wave-uniform (every lane takes the same branches on
+// the same values), and lane parallelism is expressed only through
+//   PG_FOR_LANES(l) { ... }      the body runs once per lane, `l` = lane id (0..63)
+//   PG_BALLOT(l, pred)           64-bit mask of lanes whose predicate holds
+//   PG_SYNC()                    orders LDS/global traffic between two lane sections
+// Rule: inside one PG_FOR_LANES section a lane may only read locations that no other lane writes in the
+// same section; cross-lane hand-offs go through LDS with a PG_SYNC() between the sections.
+//
+// On the GPU (hipcc, gfx950) PG_FOR_LANES is just "this lane", PG_BALLOT is v_cmp -> SGPR pair, and
+// PG_SYNC is an s_barrier-level fence for the single wave.  tests/emu builds the same sources with
+// PGAMD_WAVE_EMU, where a lane section is a 64-iteration loop on the host: a debugging harness for the
+// kernel logic (this container has no GPU); it is never part of libenv.so.
+#pragma once
+#include <stdint.h>
+
+#if defined(PGAMD_WAVE_EMU)
+
+#include <math.h>
+#include <string.h>
+#define PG_DEV inline
+#define PG_FOR_LANES(l) for (int l = 0; l < 64; ++l)
+#define PG_BALLOT(l, pred)                              \
+    ({                                                  \
+        uint64_t m_ = 0;                                \
+        for (int l = 0; l < 64; ++l)                    \
+            if (pred) m_ |= (1ull << l);                \
+        m_;                                             \
+    })
+#define PG_SYNC() ((void)0)
+#define PG_UNIFORM_I(x) (x)
+PG_DEV int pg_popc64(uint64_t m) { return __builtin_popcountll(m); }
+PG_DEV int pg_clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
+PG_DEV int pg_ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
+PG_DEV double pg_sqrt(double x) { return sqrt(x); }
+PG_DEV double pg_floor(double x) { return floor(x); }
+PG_DEV double pg_ceil(double x) { return ceil(x); }
+PG_DEV float pg_fabsf(float x) { return fabsf(x); }
+
+#else
+
+#include <hip/hip_runtime.h>
+#define PG_DEV __device__ __forceinline__
+#define PG_FOR_LANES(l) for (int l = (int)threadIdx.x, pg_once_ = 1; pg_once_; pg_once_ = 0)
+#define PG_BALLOT(l, pred)                              \
+    ({                                                  \
+        const int l = (int)threadIdx.x;                 \
+        (void)l;                                        \
+        (uint64_t)__ballot((pred) ? 1 : 0);             \
+    })
+#define PG_SYNC() __syncthreads()
+// value known to be wave-uniform: move it to an SGPR so branches on it are scalar branches
+#define PG_UNIFORM_I(x) __builtin_amdgcn_readfirstlane((int)(x))
+PG_DEV int pg_popc64(uint64_t m) { return __popcll(m); }
+PG_DEV int pg_clz64(uint64_t m) { return m ? __clzll((long long)m) : 64; }
+PG_DEV int pg_ctz64(uint64_t m) { return m ? (__ffsll((long long)m) - 1) : 64; }
+PG_DEV double pg_sqrt(double x) { return __builtin_sqrt(x); }   // IEEE correctly rounded (no fast-math)
+PG_DEV double pg_floor(double x) { return __builtin_floor(x); }
+PG_DEV double pg_ceil(double x) { return __builtin_ceil(x); }
+PG_DEV float pg_fabsf(float x) { return __builtin_fabsf(x); }
+
+#endif
+
+// mask of lanes strictly below / at-or-below lane l
+PG_DEV uint64_t pg_mask_lt(int l) { return l >= 64 ? ~0ull : ((1ull << l) - 1ull); }
+// index of the highest set bit (-1 if none)
+PG_DEV int pg_highest(uint64_t m) { return 63 - pg_clz64(m); }

@@ -1,0 +1,159 @@
+// tests/emu/emu_env.cpp -- TEST HARNESS ONLY.
+// Builds the kernel sources (procgen_amd/csrc/pg_env.h + game policies) with PGAMD_WAVE_EMU, i.e. with wave.h's
+// lane sections executed as 64-iteration host loops, so the wave-structured kernel logic can be compared with
+// the oracle in a container that has no GPU.  Nothing here is linked into libenv.so.
+#define PGAMD_WAVE_EMU 1
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "assets.h"
+#include "game_coinrun.h"
+#include "host_state.h"
+
+using namespace pgamd;
+
+namespace pgamd {
+template <class Game, int CAP>
+struct EnvCap : Env<Game, CAP> {};
+}  // namespace pgamd
+
+struct EmuVec {
+    int n, cap_small, cap_big;
+    DevCtx d;
+    std::vector<EnvHdr> hdr;
+    std::vector<uint32_t> rng, ents;
+    std::vector<uint8_t> grid, obs, first, plc;
+    std::vector<int32_t> action, pls, ls;
+    std::vector<float> rew;
+    HostAssets assets;
+    int use_small;
+};
+
+template <class Game, int CAP>
+static void run_env(EmuVec *v, int env, int mode) {
+    static Lds<Game, CAP> lds;  // one "workgroup" at a time
+    Env<Game, CAP> e(v->d, env, &lds);
+    e.run(mode);
+}
+
+template <class Game>
+static void run_all(EmuVec *v, int mode) {
+    for (int e = 0; e < v->n; e++) {
+        if (v->use_small && !v->hdr[e].big) run_env<Game, Game::ENT_CAP_SMALL>(v, e, mode);
+        else run_env<Game, Game::ENT_CAP_BIG>(v, e, mode);
+    }
+}
+
+extern "C" {
+
+void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, int num_levels, int start_level, int distribution_mode,
+               int center_agent, int use_backgrounds, int restrict_themes, int use_sequential_levels, int debug_mode, const char *resource_root,
+               const char *atlas_path, int use_small) {
+    EmuVec *v = new EmuVec();
+    v->n = num_envs;
+    v->use_small = use_small;
+    std::string err;
+    int gid = game_id_from_name(game);
+    if (gid != GAME_COINRUN) {
+        fprintf(stderr, "emu: game %s not implemented\n", game);
+        return nullptr;
+    }
+    if (!load_game_assets(gid, resource_root ? resource_root : "", atlas_path ? atlas_path : "", &v->assets, &err)) {
+        fprintf(stderr, "emu: %s\n", err.c_str());
+        return nullptr;
+    }
+    using Game = CoinRun;
+    const int ent_cap = Game::ENT_CAP_BIG;
+    v->hdr.resize(num_envs);
+    v->rng.assign((size_t)num_envs * 2 * MT_STRIDE, 0);
+    v->ents.assign((size_t)num_envs * EF_COUNT * ent_cap, 0);
+    const int grid_bytes = Game::MAX_CELLS * (int)sizeof(Game::cell_t);
+    v->grid.assign((size_t)num_envs * grid_bytes, 0);
+    v->obs.assign((size_t)num_envs * OBS_BYTES, 0);
+    v->first.assign(num_envs, 0);
+    v->plc.assign(num_envs, 0);
+    v->action.assign(num_envs, 0);
+    v->pls.assign(num_envs, 0);
+    v->ls.assign(num_envs, 0);
+    v->rew.assign(num_envs, 0);
+    init_env_state<Game>(num_envs, rand_seed, env_offset, v->hdr.data(), v->rng.data());
+    DevCtx &d = v->d;
+    memset(&d, 0, sizeof(d));
+    d.num_envs = num_envs;
+    d.opt = GameOptions{};
+    d.opt.use_backgrounds = use_backgrounds;
+    d.opt.center_agent = center_agent;
+    d.opt.restrict_themes = restrict_themes;
+    d.opt.distribution_mode = distribution_mode;
+    d.opt.use_sequential_levels = use_sequential_levels;
+    d.opt.debug_mode = debug_mode;
+    level_seed_range(num_levels, start_level, &d.opt.level_seed_low, &d.opt.level_seed_high);
+    d.hdr = v->hdr.data();
+    d.rng = v->rng.data();
+    d.ents = v->ents.data();
+    d.ent_cap = ent_cap;
+    d.grid = v->grid.data();
+    d.grid_bytes = grid_bytes;
+    d.action = v->action.data();
+    d.obs = v->obs.data();
+    d.rew = v->rew.data();
+    d.prev_level_seed = v->pls.data();
+    d.level_seed = v->ls.data();
+    d.first = v->first.data();
+    d.prev_level_complete = v->plc.data();
+    d.assets = &v->assets.table;
+    d.pixels = v->assets.pixels.data();
+    return v;
+}
+
+void emu_free(void *h) { delete (EmuVec *)h; }
+void emu_init(void *h) { run_all<CoinRun>((EmuVec *)h, 0); }
+void emu_step(void *h, const int32_t *actions) {
+    EmuVec *v = (EmuVec *)h;
+    memcpy(v->action.data(), actions, sizeof(int32_t) * v->n);
+    run_all<CoinRun>(v, 1);
+}
+void emu_observe(void *h, uint8_t *rgb, float *rew, uint8_t *first, int32_t *pls, uint8_t *plc, int32_t *ls) {
+    EmuVec *v = (EmuVec *)h;
+    memcpy(rgb, v->obs.data(), v->obs.size());
+    memcpy(rew, v->rew.data(), 4 * v->n);
+    memcpy(first, v->first.data(), v->n);
+    memcpy(pls, v->pls.data(), 4 * v->n);
+    memcpy(plc, v->plc.data(), v->n);
+    memcpy(ls, v->ls.data(), 4 * v->n);
+}
+int emu_error(void *h, int env) { return ((EmuVec *)h)->hdr[env].error; }
+int emu_num_entities(void *h, int env) { return ((EmuVec *)h)->hdr[env].n_ents; }
+int emu_is_big(void *h, int env) { return ((EmuVec *)h)->hdr[env].big; }
+// entity dump in the reference's serialization order (31 words, reference src/entity.cpp:90-137)
+void emu_dump_entities(void *h, int env, int32_t *out) {
+    EmuVec *v = (EmuVec *)h;
+    const int cap = v->d.ent_cap;
+    const uint32_t *e = v->ents.data() + (size_t)env * EF_COUNT * cap;
+    auto W = [&](int f, int i) { return (int32_t)e[f * cap + i]; };
+    for (int i = 0; i < v->hdr[env].n_ents; i++) {
+        int32_t *o = out + 31 * i;
+        const uint32_t m = e[EF_META * cap + i];
+        int k = 0;
+        o[k++] = W(EF_X, i); o[k++] = W(EF_Y, i); o[k++] = W(EF_VX, i); o[k++] = W(EF_VY, i); o[k++] = W(EF_RX, i); o[k++] = W(EF_RY, i);
+        o[k++] = meta_type(m); o[k++] = meta_image_type(m); o[k++] = meta_image_theme(m); o[k++] = meta_render_z(m);
+        o[k++] = (m & MF_WILL_ERASE) != 0; o[k++] = (m & MF_COLLIDES) != 0;
+        o[k++] = W(EF_COLLISION_MARGIN, i); o[k++] = W(EF_ROTATION, i); o[k++] = W(EF_VROT, i);
+        o[k++] = (m & MF_REFLECTED) != 0; o[k++] = W(EF_FIRE_TIME, i); o[k++] = W(EF_SPAWN_TIME, i); o[k++] = W(EF_LIFE_TIME, i);
+        o[k++] = W(EF_EXPIRE_TIME, i); o[k++] = (m & MF_ABS_COORDS) != 0;
+        o[k++] = W(EF_FRICTION, i); o[k++] = (m & MF_SMART_STEP) != 0; o[k++] = (m & MF_AVOIDS) != 0; o[k++] = (m & MF_AUTO_ERASE) != 0;
+        o[k++] = W(EF_ALPHA, i); o[k++] = W(EF_HEALTH, i); o[k++] = W(EF_THETA, i); o[k++] = W(EF_GROW_RATE, i); o[k++] = W(EF_ALPHA_DECAY, i);
+        o[k++] = W(EF_CLIMBER_SPAWN_X, i);
+    }
+}
+void emu_dump_grid(void *h, int env, int32_t *out, int *w, int *hh) {
+    EmuVec *v = (EmuVec *)h;
+    *w = v->hdr[env].main_width;
+    *hh = v->hdr[env].main_height;
+    const uint8_t *g = v->grid.data() + (size_t)env * v->d.grid_bytes;
+    for (int i = 0; i < (*w) * (*hh); i++) out[i] = g[i];
+}
+}
