@@ -1,0 +1,155 @@
+#!/usr/bin/env python
+"""
+bench.py -- env steps/sec of the MI355X stepper on BASELINE.json's metric.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one libenv_act + libenv_observe over every env of the workload (BASELINE.json configs[1]:
+coinrun, num_envs=65536 per GPU, uniform random actions from RandomState(0), rand_seed=23, default options).
+Observations stay resident in HBM (host_observations=0; rew/first/info are landed on the host every step, the
+4 B/env action upload is inside the timed region).  With N GPUs every rank steps its own 65536 envs of one
+logical vector of N*65536 (env_offset = rank*65536, no collective on the data path) -> weak scaling.
+
+Extra objects on the JSON line:
+  roofline     : algorithmic bytes (12306 B per env-step) / mean device time of one step's kernels
+                 (HIP events on the library's stream, procgen_amd_time_steps) against the 8 TB/s HBM peak.
+  cpu_baseline : the compiled reference (oracle/_ref, all host cores) or the plain-C oracle port (1 core) timed
+                 on a bounded sample of the same workload on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+
+ENVS_PER_GPU = 65536
+ALGO_BYTES_PER_ENV_STEP = 12288 + 4 + 1 + 9 + 4  # obs + reward + first + info + action
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(budget_s=15.0):
+    """Reported baseline, not the optimisation target."""
+    import ref_env
+
+    if ref_env.available():
+        cores = os.cpu_count() or 1
+        n = 1024
+        env = ref_env.make_ref_env(n, "coinrun", rand_seed=23, num_threads=cores)
+        kind, label = "reference", f"compiled reference C++/Qt (oracle/_ref), num_threads={cores}"
+    else:
+        import oracle_env
+
+        cores, n = 1, 256
+        env = oracle_env.OracleEnv(n, "coinrun", rand_seed=23)
+        kind, label = "port", "plain-C oracle port, single thread"
+    rng = np.random.RandomState(0)
+    env.observe()
+    for _ in range(5):
+        env.act(rng.randint(0, 15, size=(n,), dtype=np.int32))
+        env.observe()
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < budget_s:
+        env.act(rng.randint(0, 15, size=(n,), dtype=np.int32))
+        env.observe()
+        steps += 1
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"value": round(n * steps / dt, 1), "unit": "env steps/sec", "cores": cores, "kind": kind,
+            "sample": f"coinrun num_envs={n}, {steps} steps, random actions, {label}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--num-envs", type=int, default=ENVS_PER_GPU, help="envs per GPU (default = BASELINE configs[1])")
+    ap.add_argument("--game", default="coinrun")
+    ap.add_argument("--host-landed", action="store_true", help="also land observations on the host (PCIe-inclusive rate)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from procgen_amd import ProcgenGym3Env
+
+    n = args.num_envs
+    env = ProcgenGym3Env(n, args.game, rand_seed=23, extra_options={
+        "device_id": local_rank, "env_offset": rank * n, "host_observations": bool(args.host_landed)})
+    rng = np.random.RandomState(rank)
+    acts = rng.randint(0, 15, size=(args.warmup + args.steps, n), dtype=np.int32)
+    env.observe()
+    for t in range(args.warmup):
+        env.act(acts[t])
+        env.observe()
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, args.warmup + args.steps):
+        env.act(acts[t])
+        env.observe()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # dominant kernel: device time of one step's kernels, HIP events on the library's own stream
+    env._lib.procgen_amd_time_steps.restype = C.c_double
+    env._lib.procgen_amd_time_steps.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    k_steps = min(50, args.steps)
+    kacts = np.ascontiguousarray(acts[:k_steps])
+    kernel_ms = env._lib.procgen_amd_time_steps(env._handle, k_steps, kacts.ctypes.data)
+    env.close()
+
+    if rank == 0:
+        total_steps = n * world * args.steps
+        value = total_steps / dt
+        achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "env steps/sec (whole node), coinrun num_envs=65536 random actions",
+            "value": round(value, 1), "unit": "env steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32+i32 game state, u8 pixels", "data": "synthetic (uniform random actions, procedurally generated levels)",
+            "config": {"workload": f"{args.game} num_envs={n} per GPU x {world} GPU(s), random-action rollout, distribution_mode=hard, "
+                                   f"observations {'landed on host (PCIe inclusive)' if args.host_landed else 'resident in HBM'}",
+                       "num_envs_per_gpu": n, "sharding": f"env_offset shards x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms_per_step": round(kernel_ms, 4), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+/*
+ * procgen_amd.h -- extension entry points of the HIP libenv.so, next to the gym3 libenv ABI (libenv.h).
+ *
+ * The reference sanctions extra exported functions on the libenv handle: gym3's CEnv takes `c_func_defs`
+ * and calls them through `call_c_func` (reference procgen/env.py:128-136,145 -- that is how get_state /
+ * set_state are reached).  These hooks use the same mechanism; none of the seven libenv calls changes.
+ *
+ * Extension OPTIONS accepted by libenv_make (all optional; the reference library would reject them as
+ * "unused options", reference src/vecoptions.cpp:34-38, so only pass them to this library):
+ *   "device_id"          int32  HIP device ordinal (default: $LOCAL_RANK mod device count, else 0)
+ *   "env_offset"         int32  global index of env 0 of this handle; env n then reproduces env
+ *                               (env_offset + n) of a single big handle (seed derivation of reference
+ *                               src/vecgame.cpp:301-314 is per global index) -- used to shard one
+ *                               logical vector of envs over several GPUs / processes
+ *   "host_observations"  uint8  1 (default): libenv_observe lands `ob` in the caller's host buffers, as the
+ *                               ABI requires; 0: observations stay in HBM (read them through
+ *                               procgen_amd_device_buffers), rew/first/info are still landed on the host
+ */
+#ifndef PROCGEN_AMD_H
+#define PROCGEN_AMD_H
+
+#include "libenv.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Device-side (HBM) views of the boundary buffers.  Valid until libenv_close; contents are valid after
+ * libenv_observe returns (the producing stream has been joined) or after synchronizing `stream`. */
+struct procgen_amd_buffers {
+    int device_id;
+    int num_envs;
+    void *stream;                 /* hipStream_t the step kernels run on */
+    uint8_t *ob;                  /* [num_envs][64][64][3] RGB888 */
+    float *rew;                   /* [num_envs] */
+    uint8_t *first;               /* [num_envs] */
+    int32_t *prev_level_seed;     /* [num_envs] */
+    uint8_t *prev_level_complete; /* [num_envs] */
+    int32_t *level_seed;          /* [num_envs] */
+    int32_t *action;              /* [num_envs] actions of the step in flight (written by libenv_act) */
+};
+
+/* fills *out; returns 0 */
+LIBENV_API int procgen_amd_device_buffers(libenv_env *handle, struct procgen_amd_buffers *out);
+/* switch the D2H landing of observations on/off after construction (same meaning as the option) */
+LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable);
+/* Runs `steps` steps back to back entirely on the device (actions: [steps][num_envs] int32 on the HOST, or
+ * NULL to repeat the last actions) and returns the mean device time of one step's kernels in milliseconds,
+ * measured with HIP events on the library's own stream.  Used by bench.py for the roofline figure. */
+LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const int32_t *actions_or_null);
+
+/* reference src/vecgame.cpp:437-457 (declared to cffi by reference procgen/env.py:132-135) */
+LIBENV_API int get_state(libenv_env *handle, int env_idx, char *data, int length);
+LIBENV_API void set_state(libenv_env *handle, int env_idx, char *data, int length);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

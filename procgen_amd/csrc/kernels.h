@@ -1,0 +1,14 @@
+// kernels.h -- host-callable entry points of kernels.hip
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "host_state.h"
+#include "pg_defs.h"
+
+namespace pgamd {
+// mode 0: initial reset + first observation of every env; mode 1: one step
+hipError_t launch_step(int game_id, const DevCtx &d, int mode, hipStream_t stream);
+bool game_supported(int game_id);
+void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes);
+void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, EnvHdr *hdr, uint32_t *rng);
+}  // namespace pgamd

@@ -1,0 +1,74 @@
+// kernels.hip -- gfx950 kernels of the vectorized stepper.  One workgroup = one 64-lane wavefront = one env.
+//
+//   step_small<Game> : grid = num_envs; LDS arena sized for Game::ENT_CAP_SMALL entities (4 workgroups / CU);
+//                      skips envs routed to the large kernel.
+//   step_big<Game>   : fixed grid that walks the list of envs whose entity table may exceed the small arena
+//                      (LDS arena for Game::ENT_CAP_BIG entities).
+// Both run Env<Game,CAP>::run (pg_env.h): HBM -> LDS staging, Game::step / reset, rasterize, RGB888 store.
+#include <hip/hip_runtime.h>
+
+#include "game_coinrun.h"
+#include "kernels.h"
+
+namespace pgamd {
+
+template <class Game>
+__global__ __launch_bounds__(64) void step_small(DevCtx d, int mode) {
+    __shared__ Lds<Game, Game::ENT_CAP_SMALL> lds;
+    const int env = (int)blockIdx.x;
+    if (mode != 0 && d.hdr[env].big) return;
+    Env<Game, Game::ENT_CAP_SMALL> e(d, env, &lds);
+    e.run(mode);
+}
+
+template <class Game>
+__global__ __launch_bounds__(64) void step_big(DevCtx d, int mode) {
+    __shared__ Lds<Game, Game::ENT_CAP_BIG> lds;
+    const int count = *d.big_count;
+    for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+        const int env = d.big_list[k];
+        Env<Game, Game::ENT_CAP_BIG> e(d, env, &lds);
+        e.run(mode);
+        __syncthreads();
+    }
+}
+
+template <class Game>
+static hipError_t launch_game(const DevCtx &d, int mode, hipStream_t stream) {
+    hipLaunchKernelGGL(step_small<Game>, dim3(d.num_envs), dim3(64), 0, stream, d, mode);
+    if (mode != 0) {
+        int big_grid = d.num_envs < 512 ? d.num_envs : 512;
+        hipLaunchKernelGGL(step_big<Game>, dim3(big_grid), dim3(64), 0, stream, d, mode);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_step(int game_id, const DevCtx &d, int mode, hipStream_t stream) {
+    switch (game_id) {
+        case GAME_COINRUN: return launch_game<CoinRun>(d, mode, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+bool game_supported(int game_id) { return game_id == GAME_COINRUN; }
+
+void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes) {
+    switch (game_id) {
+        case GAME_COINRUN:
+            *ent_cap_hbm = CoinRun::ENT_CAP_BIG;
+            *grid_bytes = CoinRun::MAX_CELLS * (int)sizeof(CoinRun::cell_t);
+            break;
+        default:
+            *ent_cap_hbm = 0;
+            *grid_bytes = 0;
+    }
+}
+
+void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, EnvHdr *hdr, uint32_t *rng) {
+    switch (game_id) {
+        case GAME_COINRUN: init_env_state<CoinRun>(num_envs, rand_seed, env_offset, hdr, rng); break;
+        default: break;
+    }
+}
+
+}  // namespace pgamd

@@ -1,0 +1,493 @@
+// libenv_hip.cpp -- the drop-in boundary: the gym3 libenv C ABI (include/libenv.h) plus get_state / set_state
+// and the procgen_amd_* extension hooks (include/procgen_amd.h), implemented over the gfx950 kernels.
+//
+// Replaces the reference's VecGame (reference src/vecgame.cpp): the thread pool / work queue becomes one kernel
+// launch per libenv_act on a HIP stream, and libenv_observe is the stream join (+ the D2H landing of the
+// boundary buffers).  Option parsing follows reference src/vecoptions.cpp (consume by name and dtype; anything
+// left over is fatal), errors follow reference src/cpp-utils.cpp (message + exit(EXIT_FAILURE)).
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <stdarg.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/libenv.h"
+#include "../../include/procgen_amd.h"
+#include "assets.h"
+#include "kernels.h"
+
+using namespace pgamd;
+
+namespace {
+
+[[noreturn]] void fatal(const char *fmt, ...) {  // reference src/cpp-utils.cpp:8-19
+    printf("fatal: ");
+    va_list args;
+    va_start(args, fmt);
+    vprintf(fmt, args);
+    va_end(args);
+    fflush(stdout);
+    exit(EXIT_FAILURE);
+}
+
+#define HIP_CHECK(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) fatal("%s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- reference src/vecoptions.cpp ----------------------------------------------------------------------
+class VecOptions {
+  public:
+    explicit VecOptions(const struct libenv_options options) : m_options(options.items, options.items + options.count) {}
+    bool consume_string(const std::string &name, std::string *value) {
+        libenv_option opt;
+        if (!find_option(name, LIBENV_DTYPE_UINT8, &opt)) return false;
+        *value = std::string((char *)opt.data, opt.count);
+        return true;
+    }
+    bool consume_int(const std::string &name, int32_t *value) {
+        libenv_option opt;
+        if (!find_option(name, LIBENV_DTYPE_INT32, &opt)) return false;
+        *value = *(int32_t *)opt.data;
+        return true;
+    }
+    bool consume_bool(const std::string &name, bool *value) {
+        libenv_option opt;
+        if (!find_option(name, LIBENV_DTYPE_UINT8, &opt)) return false;
+        uint8_t v = *(uint8_t *)opt.data;
+        if (!(v == 0 || v == 1)) fatal("option %s is not a bool\n", name.c_str());
+        *value = (bool)v;
+        return true;
+    }
+    void ensure_empty() {
+        if (!m_options.empty()) fatal("unused options found, first unused option: %s\n", m_options[0].name);
+    }
+
+  private:
+    std::vector<libenv_option> m_options;
+    bool find_option(const std::string &name, enum libenv_dtype dtype, libenv_option *out) {
+        for (size_t idx = 0; idx < m_options.size(); idx++) {
+            const libenv_option &opt = m_options[idx];
+            if (name == std::string(opt.name, strnlen(opt.name, LIBENV_MAX_NAME_LEN))) {
+                if (opt.dtype != dtype) fatal("invalid dtype for option %s\n", name.c_str());
+                *out = opt;
+                m_options.erase(m_options.begin() + idx);
+                return true;
+            }
+        }
+        return false;
+    }
+};
+
+std::string this_library_dir() {
+    Dl_info info;
+    if (dladdr((void *)&this_library_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t k = p.find_last_of('/');
+        if (k != std::string::npos) return p.substr(0, k);
+    }
+    return ".";
+}
+
+template <class T>
+T *dev_alloc(size_t count) {
+    void *p = nullptr;
+    HIP_CHECK(hipMalloc(&p, count * sizeof(T) + 16));
+    HIP_CHECK(hipMemset(p, 0, count * sizeof(T) + 16));
+    return (T *)p;
+}
+
+struct VecGame {
+    int num_envs = 0;
+    int game_id = -1;
+    int device_id = 0;
+    bool host_observations = true;
+    std::vector<libenv_tensortype> observation_types, action_types, info_types;
+    hipStream_t stream = nullptr;
+    DevCtx d{};
+    HostAssets assets;
+    GameAssetsDev *d_assets = nullptr;
+    uint32_t *d_pixels = nullptr;
+    int32_t *d_action = nullptr;
+    uint8_t *d_small = nullptr;  // [rew f32 N | prev_level_seed i32 N | level_seed i32 N | first u8 N | prev_level_complete u8 N | error i32]
+    size_t small_bytes = 0;
+    int *d_big_list[2] = {nullptr, nullptr};
+    int *d_big_count[2] = {nullptr, nullptr};
+    uint64_t step_count = 0;
+    // host staging (pinned)
+    int32_t *h_action = nullptr;
+    uint8_t *h_small = nullptr;
+    uint8_t *h_obs_stage = nullptr;  // only when the caller's ob pointers are not one contiguous array
+    // caller buffers (libenv_set_buffers)
+    std::vector<void *> ob_ptr, ac_ptr, info_ptr[3];
+    float *rew_ptr = nullptr;
+    uint8_t *first_ptr = nullptr;
+    bool ob_contig = false, ac_contig = false;
+    bool buffers_set = false;
+    bool pending = false;
+    bool registered_obs = false;
+
+    VecGame(int nenvs, VecOptions opts);
+    ~VecGame();
+    void set_buffers(struct libenv_buffers *bufs);
+    void launch(int mode);
+    void act();
+    void observe();
+};
+
+VecGame::VecGame(int nenvs, VecOptions opts) {
+    num_envs = nenvs;
+    if (num_envs <= 0) fatal("num_envs must be positive\n");
+    std::string env_name, resource_root;
+    int num_levels = 0, start_level = -1, num_actions = -1, rand_seed = 0, num_threads = 4;
+    bool render_human = false;
+    // reference src/vecgame.cpp:183-190
+    opts.consume_string("env_name", &env_name);
+    opts.consume_int("num_levels", &num_levels);
+    opts.consume_int("start_level", &start_level);
+    opts.consume_int("num_actions", &num_actions);
+    opts.consume_int("rand_seed", &rand_seed);
+    opts.consume_int("num_threads", &num_threads);  // accepted, meaningless here: the GPU is the thread pool
+    opts.consume_string("resource_root", &resource_root);
+    opts.consume_bool("render_human", &render_human);
+    // extension options of this library (include/procgen_amd.h)
+    int env_offset = 0;
+    device_id = -1;
+    opts.consume_int("device_id", &device_id);
+    opts.consume_int("env_offset", &env_offset);
+    opts.consume_bool("host_observations", &host_observations);
+
+    if (env_name.empty()) fatal("fassert failed 'env_name != \"\"'\n");
+    if (!(num_actions > 0)) fatal("fassert failed 'num_actions > 0'\n");
+    if (!(num_levels >= 0)) fatal("fassert failed 'num_levels >= 0'\n");
+    if (!(start_level >= 0)) fatal("fassert failed 'start_level >= 0'\n");
+    if (render_human) fatal("render_human (512x512 antialiased info frame) is not provided by the HIP stepper\n");
+    if (env_name.find(',') != std::string::npos) fatal("joint games (comma separated env_name) are not provided by the HIP stepper yet\n");
+    game_id = game_id_from_name(env_name);
+    if (game_id < 0) fatal("unknown game %s\n", env_name.c_str());
+    if (!game_supported(game_id)) fatal("game %s is not implemented in the HIP stepper yet\n", env_name.c_str());
+
+    // reference src/game.cpp:42-75 (Game::parse_options)
+    GameOptions &o = d.opt;
+    memset(&o, 0, sizeof(o));
+    o.use_backgrounds = 1;
+    bool b;
+    bool use_easy_jump = false;
+    opts.consume_bool("use_easy_jump", &use_easy_jump);
+    if (opts.consume_bool("paint_vel_info", &b)) o.paint_vel_info = b;
+    if (opts.consume_bool("use_generated_assets", &b)) o.use_generated_assets = b;
+    if (opts.consume_bool("use_monochrome_assets", &b)) o.use_monochrome_assets = b;
+    if (opts.consume_bool("restrict_themes", &b)) o.restrict_themes = b;
+    if (opts.consume_bool("use_backgrounds", &b)) o.use_backgrounds = b;
+    if (opts.consume_bool("center_agent", &b)) o.center_agent = b;
+    if (opts.consume_bool("use_sequential_levels", &b)) o.use_sequential_levels = b;
+    int dist_mode = EasyMode;
+    opts.consume_int("distribution_mode", &dist_mode);
+    o.distribution_mode = dist_mode;
+    if (dist_mode == EasyMode || dist_mode == HardMode) {
+    } else if (dist_mode == ExtremeMode) {
+        if (!(env_name == "chaser" || env_name == "dodgeball" || env_name == "leaper" || env_name == "starpilot")) fatal("fassert failed: extreme mode unsupported for %s\n", env_name.c_str());
+    } else if (dist_mode == MemoryMode) {
+        if (!(env_name == "caveflyer" || env_name == "dodgeball" || env_name == "heist" || env_name == "jumper" || env_name == "maze" || env_name == "miner")) fatal("fassert failed: memory mode unsupported for %s\n", env_name.c_str());
+    } else {
+        fatal("invalid distribution_mode %d\n", dist_mode);
+    }
+    int plain_assets = 0, physics_mode = 0, game_type = 0;
+    opts.consume_int("plain_assets", &plain_assets);
+    opts.consume_int("physics_mode", &physics_mode);
+    opts.consume_int("debug_mode", &o.debug_mode);
+    opts.consume_int("game_type", &game_type);
+    opts.ensure_empty();
+    if (o.use_generated_assets) fatal("use_generated_assets is not provided by the HIP stepper\n");
+    if (o.use_monochrome_assets || o.paint_vel_info) fatal("use_monochrome_assets / paint_vel_info are not provided by the HIP stepper yet\n");
+    level_seed_range(num_levels, start_level, &o.level_seed_low, &o.level_seed_high);
+
+    // tensortypes: reference src/vecgame.cpp:212-268
+    {
+        libenv_tensortype s{};
+        strcpy(s.name, "rgb");
+        s.scalar_type = LIBENV_SCALAR_TYPE_DISCRETE;
+        s.dtype = LIBENV_DTYPE_UINT8;
+        s.shape[0] = RES_W;
+        s.shape[1] = RES_H;
+        s.shape[2] = 3;
+        s.ndim = 3;
+        s.low.uint8 = 0;
+        s.high.uint8 = 255;
+        observation_types.push_back(s);
+    }
+    {
+        libenv_tensortype s{};
+        strcpy(s.name, "action");
+        s.scalar_type = LIBENV_SCALAR_TYPE_DISCRETE;
+        s.dtype = LIBENV_DTYPE_INT32;
+        s.ndim = 0;
+        s.low.int32 = 0;
+        s.high.int32 = num_actions - 1;
+        action_types.push_back(s);
+    }
+    const char *info_names[3] = {"prev_level_seed", "prev_level_complete", "level_seed"};
+    for (int i = 0; i < 3; i++) {
+        libenv_tensortype s{};
+        strcpy(s.name, info_names[i]);
+        s.scalar_type = LIBENV_SCALAR_TYPE_DISCRETE;
+        s.ndim = 0;
+        if (i == 1) {
+            s.dtype = LIBENV_DTYPE_UINT8;
+            s.low.uint8 = 0;
+            s.high.uint8 = 1;
+        } else {
+            s.dtype = LIBENV_DTYPE_INT32;
+            s.low.int32 = 0;
+            s.high.int32 = INT32_MAX;
+        }
+        info_types.push_back(s);
+    }
+
+    // device
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        fatal("no HIP device available: the MI355X stepper cannot run (there is no CPU fallback)\n");
+    if (device_id < 0) {
+        const char *lr = getenv("LOCAL_RANK");
+        device_id = lr ? atoi(lr) % ndev : 0;
+    }
+    if (device_id >= ndev) fatal("device_id %d out of range (%d devices)\n", device_id, ndev);
+    HIP_CHECK(hipSetDevice(device_id));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+
+    // assets: baked pack next to the library (procgen_amd/data/<game>.atlas) or the PNG tree at resource_root
+    std::string data_dir = getenv("PROCGEN_AMD_DATA_DIR") ? getenv("PROCGEN_AMD_DATA_DIR") : this_library_dir() + "/../../data";
+    std::string err;
+    if (!load_game_assets(game_id, resource_root, data_dir + "/" + env_name + ".atlas", &assets, &err)) fatal("failed to load images %s\n", err.c_str());
+    d_assets = dev_alloc<GameAssetsDev>(1);
+    HIP_CHECK(hipMemcpy(d_assets, &assets.table, sizeof(GameAssetsDev), hipMemcpyHostToDevice));
+    d_pixels = dev_alloc<uint32_t>(assets.pixels.size());
+    HIP_CHECK(hipMemcpy(d_pixels, assets.pixels.data(), assets.pixels.size() * 4, hipMemcpyHostToDevice));
+
+    // per-env state in HBM
+    const size_t N = (size_t)num_envs;
+    game_limits(game_id, &d.ent_cap, &d.grid_bytes);
+    d.num_envs = num_envs;
+    d.hdr = dev_alloc<EnvHdr>(N);
+    d.rng = dev_alloc<uint32_t>(N * 2 * MT_STRIDE);
+    d.ents = dev_alloc<uint32_t>(N * EF_COUNT * d.ent_cap);
+    d.grid = dev_alloc<uint8_t>(N * d.grid_bytes);
+    {
+        std::vector<EnvHdr> hdr(N);
+        std::vector<uint32_t> rng(N * 2 * MT_STRIDE);
+        game_init_state(game_id, num_envs, rand_seed, env_offset, hdr.data(), rng.data());
+        HIP_CHECK(hipMemcpy(d.hdr, hdr.data(), N * sizeof(EnvHdr), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d.rng, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
+    }
+    d_action = dev_alloc<int32_t>(N);
+    d.action = d_action;
+    d.obs = dev_alloc<uint8_t>(N * OBS_BYTES);
+    small_bytes = N * 14 + 4;
+    d_small = dev_alloc<uint8_t>(small_bytes);
+    d.rew = (float *)d_small;
+    d.prev_level_seed = (int32_t *)(d_small + 4 * N);
+    d.level_seed = (int32_t *)(d_small + 8 * N);
+    d.first = d_small + 12 * N;
+    d.prev_level_complete = d_small + 13 * N;
+    d.error = (int *)(d_small + ((14 * N + 3) & ~(size_t)3));
+    small_bytes = ((14 * N + 3) & ~(size_t)3) + 4;
+    for (int k = 0; k < 2; k++) {
+        d_big_list[k] = dev_alloc<int>(N);
+        d_big_count[k] = dev_alloc<int>(1);
+    }
+    d.assets = d_assets;
+    d.pixels = d_pixels;
+    HIP_CHECK(hipHostMalloc((void **)&h_action, N * 4 + 16, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&h_small, small_bytes + 16, hipHostMallocDefault));
+}
+
+VecGame::~VecGame() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (registered_obs && !ob_ptr.empty()) (void)hipHostUnregister(ob_ptr[0]);
+    (void)hipFree(d_assets);
+    (void)hipFree(d_pixels);
+    (void)hipFree(d.hdr);
+    (void)hipFree(d.rng);
+    (void)hipFree(d.ents);
+    (void)hipFree(d.grid);
+    (void)hipFree(d_action);
+    (void)hipFree(d.obs);
+    (void)hipFree(d_small);
+    for (int k = 0; k < 2; k++) {
+        (void)hipFree(d_big_list[k]);
+        (void)hipFree(d_big_count[k]);
+    }
+    if (h_action) (void)hipHostFree(h_action);
+    if (h_small) (void)hipHostFree(h_small);
+    if (h_obs_stage) (void)hipHostFree(h_obs_stage);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecgame.cpp:30-40,74-83,333-361
+    const int N = num_envs;
+    ob_ptr.assign(bufs->ob, bufs->ob + N);  // one observation space
+    ac_ptr.assign(bufs->ac, bufs->ac + N);  // one action space
+    for (int s = 0; s < 3; s++) info_ptr[s].assign(bufs->info + (size_t)s * N, bufs->info + (size_t)(s + 1) * N);
+    rew_ptr = bufs->rew;
+    first_ptr = bufs->first;
+    ob_contig = true;
+    ac_contig = true;
+    for (int e = 0; e < N; e++) {
+        if ((uint8_t *)ob_ptr[e] != (uint8_t *)ob_ptr[0] + (size_t)e * OBS_BYTES) ob_contig = false;
+        if ((uint8_t *)ac_ptr[e] != (uint8_t *)ac_ptr[0] + (size_t)e * 4) ac_contig = false;
+    }
+    if (host_observations) {
+        if (ob_contig) {
+            // pin the caller's observation array so the D2H landing is a single DMA ("one pinned host buffer")
+            registered_obs = hipHostRegister(ob_ptr[0], (size_t)N * OBS_BYTES, hipHostRegisterDefault) == hipSuccess;
+            if (!registered_obs) (void)hipGetLastError();
+        } else {
+            HIP_CHECK(hipHostMalloc((void **)&h_obs_stage, (size_t)N * OBS_BYTES, hipHostMallocDefault));
+        }
+    }
+    buffers_set = true;
+    launch(0);  // initial reset + first frame (reference src/vecgame.cpp:346-357)
+}
+
+void VecGame::launch(int mode) {
+    const int cur = (int)(step_count & 1), nxt = cur ^ 1;
+    d.big_list = d_big_list[cur];
+    d.big_count = d_big_count[cur];
+    d.next_big_list = d_big_list[nxt];
+    d.next_big_count = d_big_count[nxt];
+    HIP_CHECK(hipMemsetAsync(d_big_count[nxt], 0, sizeof(int), stream));
+    HIP_CHECK(hipMemsetAsync(d.error, 0, sizeof(int), stream));
+    HIP_CHECK(launch_step(game_id, d, mode, stream));
+    step_count++;
+    HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
+    if (host_observations) {
+        void *dst = ob_contig ? ob_ptr[0] : (void *)h_obs_stage;
+        HIP_CHECK(hipMemcpyAsync(dst, d.obs, (size_t)num_envs * OBS_BYTES, hipMemcpyDeviceToHost, stream));
+    }
+    pending = true;
+}
+
+void VecGame::act() {  // reference src/vecgame.cpp:378-401
+    if (!buffers_set) fatal("libenv_act called before libenv_set_buffers\n");
+    observe();  // wait_for_stepping_threads()
+    const int N = num_envs;
+    // the action values are only valid for the duration of this call (reference src/vecgame.cpp:387-388)
+    if (ac_contig) memcpy(h_action, ac_ptr[0], (size_t)N * 4);
+    else
+        for (int e = 0; e < N; e++) h_action[e] = *(int32_t *)ac_ptr[e];
+    HIP_CHECK(hipMemcpyAsync(d_action, h_action, (size_t)N * 4, hipMemcpyHostToDevice, stream));
+    launch(1);
+}
+
+void VecGame::observe() {  // reference src/vecgame.cpp:363-376,416-435
+    if (!pending) return;
+    HIP_CHECK(hipStreamSynchronize(stream));
+    pending = false;
+    const size_t N = (size_t)num_envs;
+    const int err = *(const int *)(h_small + (small_bytes - 4));
+    if (err) fatal("device-side check failed (code %d: 1 entity table overflow, 2 grid index out of range, 3 fassert, 4 asset theme, 5 unsupported draw)\n", err);
+    memcpy(rew_ptr, h_small, 4 * N);
+    memcpy(first_ptr, h_small + 12 * N, N);
+    const int32_t *pls = (const int32_t *)(h_small + 4 * N), *ls = (const int32_t *)(h_small + 8 * N);
+    const uint8_t *plc = h_small + 13 * N;
+    for (size_t e = 0; e < N; e++) {
+        *(int32_t *)info_ptr[0][e] = pls[e];
+        *(uint8_t *)info_ptr[1][e] = plc[e];
+        *(int32_t *)info_ptr[2][e] = ls[e];
+    }
+    if (host_observations && !ob_contig)
+        for (size_t e = 0; e < N; e++) memcpy(ob_ptr[e], h_obs_stage + e * OBS_BYTES, OBS_BYTES);
+}
+
+}  // namespace
+
+extern "C" {
+
+LIBENV_API int libenv_version(void) { return LIBENV_VERSION; }
+
+LIBENV_API libenv_env *libenv_make(int num_envs, const struct libenv_options options) {
+    return (libenv_env *)new VecGame(num_envs, VecOptions(options));
+}
+
+LIBENV_API int libenv_get_tensortypes(libenv_env *handle, enum libenv_space_name name, struct libenv_tensortype *out_types) {
+    VecGame *v = (VecGame *)handle;
+    const std::vector<libenv_tensortype> *types;
+    if (name == LIBENV_SPACE_OBSERVATION) types = &v->observation_types;
+    else if (name == LIBENV_SPACE_ACTION) types = &v->action_types;
+    else if (name == LIBENV_SPACE_INFO) types = &v->info_types;
+    else return 0;
+    if (out_types != nullptr)
+        for (size_t i = 0; i < types->size(); i++) out_types[i] = (*types)[i];
+    return (int)types->size();
+}
+
+LIBENV_API void libenv_set_buffers(libenv_env *handle, struct libenv_buffers *bufs) { ((VecGame *)handle)->set_buffers(bufs); }
+LIBENV_API void libenv_observe(libenv_env *handle) { ((VecGame *)handle)->observe(); }
+LIBENV_API void libenv_act(libenv_env *handle) { ((VecGame *)handle)->act(); }
+LIBENV_API void libenv_close(libenv_env *handle) { delete (VecGame *)handle; }
+
+// reference src/vecgame.cpp:437-457 -- the reference's wire format is a "next" row.
+LIBENV_API int get_state(libenv_env *, int, char *, int) { fatal("get_state is not provided by the HIP stepper yet\n"); }
+LIBENV_API void set_state(libenv_env *, int, char *, int) { fatal("set_state is not provided by the HIP stepper yet\n"); }
+
+// ---- extension hooks (include/procgen_amd.h) -------------------------------------------------------------
+LIBENV_API int procgen_amd_device_buffers(libenv_env *handle, struct procgen_amd_buffers *out) {
+    VecGame *v = (VecGame *)handle;
+    out->device_id = v->device_id;
+    out->num_envs = v->num_envs;
+    out->stream = (void *)v->stream;
+    out->ob = v->d.obs;
+    out->rew = v->d.rew;
+    out->first = v->d.first;
+    out->prev_level_seed = v->d.prev_level_seed;
+    out->prev_level_complete = v->d.prev_level_complete;
+    out->level_seed = v->d.level_seed;
+    out->action = v->d_action;
+    return 0;
+}
+LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable) {
+    VecGame *v = (VecGame *)handle;
+    v->observe();
+    if (enable && !v->host_observations && v->buffers_set && !v->ob_contig && !v->h_obs_stage)
+        HIP_CHECK(hipHostMalloc((void **)&v->h_obs_stage, (size_t)v->num_envs * OBS_BYTES, hipHostMallocDefault));
+    v->host_observations = enable != 0;
+}
+// average device time of the step kernels over the given number of act/observe rounds (bench.py roofline leg)
+LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const int32_t *actions_or_null) {
+    VecGame *v = (VecGame *)handle;
+    v->observe();
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    float total_ms = 0.f;
+    for (int s = 0; s < steps; s++) {
+        if (actions_or_null) HIP_CHECK(hipMemcpyAsync(v->d_action, actions_or_null + (size_t)s * v->num_envs, (size_t)v->num_envs * 4, hipMemcpyHostToDevice, v->stream));
+        const int cur = (int)(v->step_count & 1), nxt = cur ^ 1;
+        v->d.big_list = v->d_big_list[cur];
+        v->d.big_count = v->d_big_count[cur];
+        v->d.next_big_list = v->d_big_list[nxt];
+        v->d.next_big_count = v->d_big_count[nxt];
+        HIP_CHECK(hipMemsetAsync(v->d_big_count[nxt], 0, sizeof(int), v->stream));
+        HIP_CHECK(hipEventRecord(e0, v->stream));
+        HIP_CHECK(launch_step(v->game_id, v->d, 1, v->stream));
+        HIP_CHECK(hipEventRecord(e1, v->stream));
+        v->step_count++;
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms;
+    }
+    HIP_CHECK(hipMemcpyAsync(v->h_small, v->d_small, v->small_bytes, hipMemcpyDeviceToHost, v->stream));
+    v->pending = true;
+    v->observe();
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return (double)total_ms / steps;
+}
+}

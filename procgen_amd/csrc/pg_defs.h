@@ -124,9 +124,13 @@ struct DevCtx {
     // assets
     const GameAssetsDev *assets;
     const uint32_t *pixels;
-    // routing between the small-LDS and large-LDS kernels
-    int *big_list;   // [num_envs] env ids routed to the large kernel
-    int *big_count;  // [1]
+    // routing between the small-LDS and large-LDS kernels: envs whose entity table may outgrow the small
+    // kernel's LDS capacity are listed for the large kernel of the NEXT step (double-buffered by step parity)
+    const int *big_list;   // [num_envs] env ids the large kernel handles this step
+    const int *big_count;  // [1]
+    int *next_big_list;    // [num_envs] filled during this step
+    int *next_big_count;   // [1] zeroed by the host before the step
+    int *error;            // [1] OR of the per-env error codes raised this step (0 = none)
 };
 
 }  // namespace pgamd

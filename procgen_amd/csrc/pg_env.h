@@ -1094,6 +1094,7 @@ struct Env {
             }
         }
         G.big = Game::needs_big(n) ? 1 : 0;
+        publish_routing();
         {
             EnvHdr *h = d.hdr + env;
             PG_FOR_LANES(l) {
@@ -1104,6 +1105,21 @@ struct Env {
                 }
             }
         }
+    }
+
+    // tell the next step which kernel owns this env, and surface error codes to the host
+    PG_DEV void publish_routing() {
+#if defined(PGAMD_WAVE_EMU)
+        if (G.error && d.error) *d.error |= G.error;
+#else
+        if (threadIdx.x == 0) {
+            if (G.big) {
+                const int slot = atomicAdd(d.next_big_count, 1);
+                d.next_big_list[slot] = env;
+            }
+            if (G.error) atomicOr(d.error, G.error);
+        }
+#endif
     }
 
     // one libenv step (mode 1) or the initial reset + first observation (mode 0) of this env

@@ -1,0 +1,50 @@
+"""
+CPU: the kernel sources themselves (procgen_amd/csrc/pg_env.h + game policies), built with wave.h's host lane-loop
+emulation (tests/emu), against the oracle: frames, rew/first/info, entity tables and grids, bit exact, including the
+routing between the small and the large LDS arena.
+"""
+import numpy as np
+import pytest
+
+import emu_harness
+import oracle_env
+from helpers import action_stream, assert_rollouts_equal, rollout
+
+
+@pytest.mark.parametrize("use_small", [True, False])
+def test_emulated_kernels_match_oracle(use_small):
+    n, steps = 24, 260
+    acts = action_stream(n, steps)
+    orc = oracle_env.OracleEnv(n, "coinrun", rand_seed=23)
+    emu = emu_harness.EmuEnv(n, "coinrun", rand_seed=23, use_small=use_small)
+    for t in range(steps + 1):
+        r1, o1, f1 = orc.observe()
+        r2, o2, f2 = emu.observe()
+        assert np.array_equal(r1, r2) and np.array_equal(f1, f2), f"step {t}"
+        assert np.array_equal(o1["rgb"], o2["rgb"]), f"frame at step {t}"
+        for k, v in orc.info_arrays().items():
+            assert np.array_equal(v, emu.info_arrays()[k]), f"{k} at step {t}"
+        if t % 20 == 0:
+            for e in range(n):
+                assert np.array_equal(orc.entities(e), emu.entities(e)), f"entities env {e} step {t}"
+                assert np.array_equal(orc.grid(e), emu.grid(e)), f"grid env {e} step {t}"
+        if t < steps:
+            orc.act(acts[t])
+            emu.act(acts[t])
+
+
+def test_emulated_shard_equals_slice_of_whole():
+    """env_offset sharding (include/procgen_amd.h): a shard reproduces the matching slice of one big vector."""
+    acts = action_stream(8, 60, seed=3)
+    whole = rollout(emu_harness.EmuEnv(8, "coinrun", rand_seed=5), acts)
+    shard = rollout(emu_harness.EmuEnv(4, "coinrun", rand_seed=5, env_offset=4), [a[4:] for a in acts])
+    for k in whole:
+        assert np.array_equal(whole[k][:, 4:], shard[k]), k
+
+
+def test_emulated_num_levels_and_easy_mode():
+    acts = action_stream(4, 80, seed=9)
+    for kw in (dict(num_levels=3, start_level=17), dict(distribution_mode=0), dict(use_backgrounds=False), dict(restrict_themes=True)):
+        a = rollout(oracle_env.OracleEnv(4, "coinrun", rand_seed=2, **kw), acts)
+        b = rollout(emu_harness.EmuEnv(4, "coinrun", rand_seed=2, **kw), acts)
+        assert_rollouts_equal(a, b, str(kw))
