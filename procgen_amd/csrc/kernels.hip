@@ -1,13 +1,17 @@
 // kernels.hip -- gfx950 kernels of the vectorized stepper.  One workgroup = one 64-lane wavefront = one env.
 //
-//   step_small<Game> : grid = num_envs; LDS arena sized for Game::ENT_CAP_SMALL entities (4 workgroups / CU);
-//                      skips envs routed to the large kernel.
+//   step_small<Game> : grid = num_envs; LDS arena sized for Game::ENT_CAP_SMALL entities; skips envs routed to
+//                      the large kernel.
 //   step_big<Game>   : fixed grid that walks the list of envs whose entity table may exceed the small arena
 //                      (LDS arena for Game::ENT_CAP_BIG entities).
-// Both run Env<Game,CAP>::run (pg_env.h): HBM -> LDS staging, Game::step / reset, rasterize, RGB888 store.
+//   render<Game>     : grid = num_envs, 256 threads: four band-waves per env rasterize 16 rows each into a 4 KB
+//                      LDS band and store the RGB888 observation (pg_render.h).
+// The step kernels run Env<Game,CAP>::run (pg_env.h): HBM -> LDS staging, Game::step / reset + level generation,
+// state write-back.
 #include <hip/hip_runtime.h>
 
 #include "game_coinrun.h"
+#include "pg_render.h"
 #include "kernels.h"
 
 namespace pgamd {
@@ -34,12 +38,21 @@ __global__ __launch_bounds__(64) void step_big(DevCtx d, int mode) {
 }
 
 template <class Game>
+__global__ __launch_bounds__(256) void render(DevCtx d) {
+    __shared__ uint32_t fb[NUM_BANDS][BAND_ROWS * RES_W];
+    const int band = (int)(threadIdx.x >> 6);
+    Renderer<Game> r(d, (int)blockIdx.x, band, fb[band]);
+    r.render_band();
+}
+
+template <class Game>
 static hipError_t launch_game(const DevCtx &d, int mode, hipStream_t stream) {
     hipLaunchKernelGGL(step_small<Game>, dim3(d.num_envs), dim3(64), 0, stream, d, mode);
     if (mode != 0) {
-        int big_grid = d.num_envs < 512 ? d.num_envs : 512;
+        int big_grid = d.num_envs < 2048 ? d.num_envs : 2048;
         hipLaunchKernelGGL(step_big<Game>, dim3(big_grid), dim3(64), 0, stream, d, mode);
     }
+    hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(256), 0, stream, d);
     return hipGetLastError();
 }
 

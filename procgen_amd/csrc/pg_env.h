@@ -80,18 +80,13 @@ PG_DEV float clip_abs(float x, float y) {                                   // r
     return x;
 }
 
-// draw-command words kept in LDS for one batch of 64 drawables
-enum CmdWord : int { CW_GEOM = 0, CW_BASEX, CW_SRCY, CW_IX, CW_IY, CW_IMG, CW_COUNT };
-// CW_GEOM: tx1 | ty1<<7 | w<<14 | h<<21 (w == 0: nothing to draw);  CW_IMG: image index | mirrored<<12 | const_alpha(0..256)<<16
-
 // ---- LDS arena of one workgroup ---------------------------------------------------------------------------
 template <class Game, int CAP>
 struct Lds {
-    uint32_t fb[RES_W * RES_H];  // 0xffRRGGBB framebuffer; fb[0..1279] doubles as MT19937 scratch A/B before rendering
+    uint32_t mt[2 * MT_STRIDE];  // MT19937 scratch A/B (seed / twist of rand_gen during a reset)
     uint32_t ent[EF_COUNT * CAP];
-    uint32_t cmd[CW_COUNT][64];
     uint32_t tmp[64];
-    typename Game::cell_t grid[Game::MAX_CELLS];
+    alignas(16) typename Game::cell_t grid[Game::MAX_CELLS];
 };
 
 template <class Game, int CAP>
@@ -233,8 +228,8 @@ struct Env {
 
     // ======================================================================================================
     // MT19937 (std::mt19937 as used by RandGen: reference src/randgen.cpp:6-31,90-98; libstdc++ random.tcc)
-    PG_DEV uint32_t *mt_a() { return s->fb; }
-    PG_DEV uint32_t *mt_b() { return s->fb + MT_STRIDE; }
+    PG_DEV uint32_t *mt_a() { return s->mt; }
+    PG_DEV uint32_t *mt_b() { return s->mt + MT_STRIDE; }
 
     // one twist of the whole state: src -> dst (distinct buffers, so lanes never read what others write)
     PG_DEV void mt_twist(const uint32_t *src, uint32_t *dst) {
@@ -336,13 +331,16 @@ struct Env {
     // one draw from level_seed_rand_gen (state stays in HBM; a twist goes through scratch A)
     PG_DEV uint32_t level_seed_u32() {
         uint32_t *home = rg_home + MT_STRIDE;
+        uint32_t z;
         if (G.lvl_rand_idx >= MT_N) {
             mt_twist(home, mt_a());
+            z = mt_a()[0];
             mt_copy(mt_a(), home);
-            G.lvl_rand_idx = 0;
+            G.lvl_rand_idx = 1;
+        } else {
+            z = home[G.lvl_rand_idx];
+            G.lvl_rand_idx += 1;
         }
-        uint32_t z = home[G.lvl_rand_idx];
-        G.lvl_rand_idx += 1;
         return mt_temper(z);
     }
 
@@ -790,17 +788,7 @@ struct Env {
     }
 
     // ======================================================================================================
-    // Rendering.  Replaces Game::render_to_buf + BasicAbstractGame::game_draw (reference src/game.cpp:77-91,
-    // BAG:799-1012) and the Qt 5.9 raster engine calls they make (drawImage(QRectF,QImage) without
-    // antialiasing/rotation = qt_scale_image_32: 16.16 fixed point nearest sampling + premultiplied SourceOver).
-    PG_DEV RectD get_screen_rect(float x, float y, float dx, float dy, float render_eps) {  // BAG:799-801
-        RectD r;
-        r.x = (double)((x - render_eps) * G.unit - G.x_off);
-        r.y = (double)((G.view_dim - y - render_eps) * G.unit + G.y_off);
-        r.w = (double)((dx + 2 * render_eps) * G.unit);
-        r.h = (double)((dy + 2 * render_eps) * G.unit);
-        return r;
-    }
+    // Camera scalars consumed by the render kernel (pg_render.h) and serialized by get_state: BAG:819-838
     PG_DEV void prepare_for_drawing(float rect_height) {  // BAG:819-838
         G.center_x = (float)(G.main_width * .5);
         G.center_y = (float)(G.main_height * .5);
@@ -817,222 +805,8 @@ struct Env {
         G.y_off = G.unit * (G.center_y - G.view_dim / 2);
     }
 
-    // lane-local: turn (image, target rect, mirror, opacity) into one draw command in slot `slot` of s->cmd
-    PG_DEV void cmd_none(int slot) { s->cmd[CW_GEOM][slot] = 0; }
-    PG_DEV void cmd_image(int slot, int img_index, bool mirrored, RectD tr, float opacity) {
-        const ImgDesc im = d.assets->img[img_index];
-        const double sx = tr.w / (double)im.w;
-        const double sy = tr.h / (double)im.h;
-        const int ix = (int)(65536 / sx);
-        const int iy = (int)(65536 / sy);
-        int tx1 = q_round(tr.x), tx2 = q_round(tr.x + tr.w), ty1 = q_round(tr.y), ty2 = q_round(tr.y + tr.h);
-        if (tx1 < 0) tx1 = 0;
-        if (ty1 < 0) ty1 = 0;
-        if (tx2 > RES_W) tx2 = RES_W;
-        if (ty2 > RES_H) ty2 = RES_H;
-        int w = tx2 - tx1, h = ty2 - ty1;
-        if (w <= 0 || h <= 0) {
-            cmd_none(slot);
-            return;
-        }
-        // Qt 5.9: qCeil(...) - 1 (pinned with tests/tools/qt_drawimage_probe.py)
-        const uint32_t basex = (uint32_t)((int)pg_ceil((tx1 + 0.5 - tr.x) * ix) - 1);
-        const uint32_t srcy = (uint32_t)((int)pg_ceil((ty1 + 0.5 - tr.y) * iy) - 1);
-        const int yend = (int)((srcy + (uint32_t)iy * (uint32_t)(h - 1)) >> 16);
-        if (yend < 0 || yend >= (int)im.h) --h;
-        const int xend = (int)((basex + (uint32_t)ix * (uint32_t)(w - 1)) >> 16);
-        if (xend < 0 || xend >= (int)im.w) --w;
-        if (w <= 0 || h <= 0) {
-            cmd_none(slot);
-            return;
-        }
-        double o = (double)opacity;  // QPainter::setOpacity clamps to [0,1]; intOpacity = int(opacity * 256)
-        if (o < 0) o = 0;
-        if (o > 1) o = 1;
-        const int io = (int)(o * 256);
-        s->cmd[CW_GEOM][slot] = (uint32_t)tx1 | ((uint32_t)ty1 << 7) | ((uint32_t)w << 14) | ((uint32_t)h << 21);
-        s->cmd[CW_BASEX][slot] = basex;
-        s->cmd[CW_SRCY][slot] = srcy;
-        s->cmd[CW_IX][slot] = (uint32_t)ix;
-        s->cmd[CW_IY][slot] = (uint32_t)iy;
-        s->cmd[CW_IMG][slot] = (uint32_t)img_index | ((mirrored ? 1u : 0u) << 12) | ((uint32_t)io << 16);
-    }
-    // draw_image BAG:877-913 for one drawable (lane-local)
-    PG_DEV void cmd_draw_image(int slot, RectD base_rect, float rotation, bool is_reflected, int base_type, int theme, float alpha, float tile_ratio) {
-        const int img_type = Game::image_for_type(*this, base_type);
-        if (img_type < 0) {
-            cmd_none(slot);
-            return;
-        }
-        if (d.opt.use_monochrome_assets || img_type >= USE_ASSET_THRESHOLD) {
-            if (img_type != SPACE) fail(PGE_UNSUPPORTED_DRAW);  // colored grid squares: not on the default-option path yet
-            cmd_none(slot);
-            return;
-        }
-        const RectD adjusted = Game::adjusted_image_rect(img_type, base_rect);
-        int mt = theme;
-        if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;  // BAG:450-453
-        const int img = (mt >= 0 && mt < MAX_IMAGE_THEMES) ? (int)d.assets->type_theme_img[img_type][mt] : -1;
-        if (img < 0) {
-            fail(PGE_THEME);
-            cmd_none(slot);
-            return;
-        }
-        if (rotation != 0 || tile_ratio != 0) {
-            fail(PGE_UNSUPPORTED_DRAW);
-            cmd_none(slot);
-            return;
-        }
-        cmd_image(slot, img, is_reflected, adjusted, alpha);
-    }
-
-    // execute the valid commands of the current batch in slot order; lanes cover 8x8 pixel blocks
-    PG_DEV void run_cmd_batch(int count) {
-        PG_SYNC();
-        uint64_t valid = PG_BALLOT(l, l < count && ((s->cmd[CW_GEOM][l] >> 14) & 0x7fu) != 0);
-        while (valid) {
-            const int k = pg_ctz64(valid);
-            valid &= valid - 1;
-            const uint32_t geom = s->cmd[CW_GEOM][k];
-            const int tx1 = (int)(geom & 0x7fu), ty1 = (int)((geom >> 7) & 0x7fu), w = (int)((geom >> 14) & 0x7fu), h = (int)((geom >> 21) & 0x7fu);
-            const uint32_t basex = s->cmd[CW_BASEX][k], srcy0 = s->cmd[CW_SRCY][k];
-            const uint32_t ix = s->cmd[CW_IX][k], iy = s->cmd[CW_IY][k];
-            const uint32_t cimg = s->cmd[CW_IMG][k];
-            const ImgDesc im = d.assets->img[cimg & 0xfffu];
-            const bool mirrored = ((cimg >> 12) & 1u) != 0;
-            const int io = (int)(cimg >> 16);
-            const uint32_t ca = (uint32_t)((io * 255) >> 8);
-            const uint32_t *src = d.pixels + im.off;
-            for (int by = 0; by < h; by += 8) {
-                for (int bx = 0; bx < w; bx += 8) {
-                    PG_FOR_LANES(l) {
-                        const int px = bx + (l & 7), py = by + (l >> 3);
-                        if (px < w && py < h) {
-                            const int sxp = (int)((basex + (uint32_t)px * ix) >> 16);
-                            const int syp = (int)((srcy0 + (uint32_t)py * iy) >> 16);
-                            uint32_t sp = src[syp * (int)im.w + (mirrored ? ((int)im.w - 1 - sxp) : sxp)];
-                            if (io != 256) sp = byte_mul(sp, ca);
-                            uint32_t *dp = &s->fb[(ty1 + py) * RES_W + tx1 + px];
-                            *dp = sp + byte_mul(*dp, 255u - (sp >> 24));
-                        }
-                    }
-                }
-            }
-            PG_SYNC();
-        }
-    }
-
-    // draw_entities BAG:1052-1066 for one render_z layer, 64 entities per batch
-    PG_DEV void draw_entities(int render_z) {
-        const int n = G.n_ents;
-        for (int base = 0; base < n; base += 64) {
-            const uint64_t any = PG_BALLOT(l, (base + l) < n && meta_render_z(meta(base + l)) == render_z);
-            if (!any) continue;
-            PG_FOR_LANES(l) {
-                const int i = base + l;
-                if (i < n && meta_render_z(meta(i)) == render_z && Game::should_draw_entity(*this, i)) {
-                    const uint32_t mm = meta(i);
-                    RectD r1;  // get_object_rect BAG:811-817
-                    if (mm & MF_ABS_COORDS) {
-                        const float vd = G.view_dim;
-                        r1.x = (double)((vd * (ex(i) - erx(i))) * G.unit);
-                        r1.y = (double)((vd * (ey(i) + ery(i))) * G.unit);
-                        r1.w = (double)((2 * vd * erx(i)) * G.unit);
-                        r1.h = (double)((2 * vd * ery(i)) * G.unit);
-                    } else {
-                        r1 = get_screen_rect(ex(i) - erx(i), ey(i) + ery(i), 2 * erx(i), 2 * ery(i), 0);
-                    }
-                    cmd_draw_image(l, r1, ef(EF_ROTATION, i), (mm & MF_REFLECTED) != 0, meta_image_type(mm), meta_image_theme(mm), ef(EF_ALPHA, i),
-                                   Game::tile_aspect_ratio(*this, i));
-                } else {
-                    cmd_none(l);
-                }
-            }
-            run_cmd_batch(64);
-        }
-    }
-
-    // game_draw BAG:1009-1012 (draw_background BAG:979-1007 + draw_foreground BAG:921-970)
-    PG_DEV void render() {
-        for (int base = 0; base < RES_W * RES_H; base += 64) {
-            PG_FOR_LANES(l) { s->fb[base + l] = 0xff000000u; }  // p.fillRect(rect, QColor(0,0,0))
-        }
-        prepare_for_drawing((float)RES_H);
-        if (d.opt.use_backgrounds) {
-            const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);
-            const int bgi = (int)d.assets->bg_img[G.background_index];
-            if (G.bg_tile_ratio < 0) fail(PGE_UNSUPPORTED_DRAW);
-            const ImgDesc bim = d.assets->img[bgi];
-            const float bgw = (float)bim.w, bgh = (float)bim.h;
-            const float bg_ar = bgw / bgh;
-            const float world_ar = (float)(G.main_width * 1.0 / G.main_height);
-            const float extra_w = bg_ar - world_ar;
-            const float offset_x = G.bg_pct_x * extra_w;
-            const RectD bg_rect = adjust_rect(main_rect, (double)(-offset_x), 0, (double)(bg_ar / world_ar), 1);
-            PG_FOR_LANES(l) {
-                if (l == 0) cmd_image(0, bgi, false, bg_rect, 1.0f);
-            }
-            run_cmd_batch(1);
-        }
-        draw_entities(-1);
-        int low_x, high_x, low_y, high_y;
-        if (d.opt.center_agent) {
-            const float margin = (float)(G.visibility / 2.0 + 1);
-            low_x = (int)(G.center_x - margin);
-            high_x = (int)(G.center_x + margin);
-            low_y = (int)(G.center_y - margin);
-            high_y = (int)(G.center_y + margin);
-        } else {
-            low_x = 0;
-            high_x = G.main_width - 1;
-            low_y = 0;
-            high_y = G.main_height - 1;
-        }
-        const int ny = high_y - low_y + 1;
-        const int ncell = (high_x - low_x + 1) * ny;
-        for (int base = 0; base < ncell; base += 64) {  // x-major order of BAG:941-955
-            PG_FOR_LANES(l) {
-                const int cidx = base + l;
-                bool drawn = false;
-                if (cidx < ncell) {
-                    const int x = low_x + cidx / ny, y = low_y + cidx % ny;
-                    const int type = get_obj(x, y);
-                    if (type != INVALID_OBJ && type != SPACE) {
-                        const int theme = Game::theme_for_grid_obj(*this, type);
-                        const RectD r2 = get_screen_rect((float)x, (float)(y + 1), 1, 1, RENDER_EPS);
-                        cmd_draw_image(l, r2, 0, false, type, theme, 1.0f, 0.0f);
-                        drawn = true;
-                    }
-                }
-                if (!drawn) cmd_none(l);
-            }
-            run_cmd_batch(64);
-        }
-        draw_entities(0);
-        draw_entities(1);
-        if (G.has_useful_vel_info && d.opt.paint_vel_info) fail(PGE_UNSUPPORTED_DRAW);
-        PG_SYNC();
-    }
-
-    // bgr32_to_rgb888 + Game::observe (reference src/game.cpp:8-23,157-165): 4 pixels -> 3 dwords per lane,
-    // each wave-wide store covers 768 contiguous bytes of the observation buffer.
-    PG_DEV void store_observation() {
-        uint32_t *out = reinterpret_cast<uint32_t *>(d.obs + (size_t)env * OBS_BYTES);
-        for (int base = 0; base < RES_W * RES_H; base += 256) {
-            PG_FOR_LANES(l) {
-                const uint32_t *p = &s->fb[base + 4 * l];
-                const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
-                // bytes: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3   (pixel word = 0xffRRGGBB)
-                const uint32_t r0 = (p0 >> 16) & 0xff, g0 = (p0 >> 8) & 0xff, b0 = p0 & 0xff;
-                const uint32_t r1 = (p1 >> 16) & 0xff, g1 = (p1 >> 8) & 0xff, b1 = p1 & 0xff;
-                const uint32_t r2 = (p2 >> 16) & 0xff, g2 = (p2 >> 8) & 0xff, b2 = p2 & 0xff;
-                const uint32_t r3 = (p3 >> 16) & 0xff, g3 = (p3 >> 8) & 0xff, b3 = p3 & 0xff;
-                uint32_t *o = out + (base / 4) * 3 + 3 * l;
-                o[0] = r0 | (g0 << 8) | (b0 << 16) | (r1 << 24);
-                o[1] = g1 | (b1 << 8) | (r2 << 16) | (g2 << 24);
-                o[2] = b2 | (r3 << 8) | (g3 << 16) | (b3 << 24);
-            }
-        }
+    // Game::observe minus the frame (reference src/game.cpp:160-164)
+    PG_DEV void store_outputs() {
         PG_FOR_LANES(l) {
             if (l == 0) {
                 d.rew[env] = G.reward;
@@ -1055,18 +829,23 @@ struct Env {
         }
         const int n = G.n_ents;
         const uint32_t *ge = d.ents + (size_t)env * EF_COUNT * d.ent_cap;
-        for (int f = 0; f < EF_COUNT; f++) {
-            for (int base = 0; base < n; base += 64) {
-                PG_FOR_LANES(l) {
-                    if (base + l < n) s->ent[f * CAP + base + l] = ge[f * d.ent_cap + base + l];
+        for (int base = 0; base < n; base += 64) {
+            PG_FOR_LANES(l) {
+                if (base + l < n) {
+                    uint32_t v[EF_COUNT];  // all field loads in flight before the first LDS store
+                    for (int f = 0; f < EF_COUNT; f++) v[f] = ge[f * d.ent_cap + base + l];
+                    for (int f = 0; f < EF_COUNT; f++) s->ent[f * CAP + base + l] = v[f];
                 }
             }
         }
-        const int cells = G.main_width * G.main_height;
-        const cell_t *gg = reinterpret_cast<const cell_t *>(d.grid + (size_t)env * d.grid_bytes);
-        for (int base = 0; base < cells; base += 64) {
-            PG_FOR_LANES(l) {
-                if (base + l < cells) s->grid[base + l] = gg[base + l];
+        {   // whole grid slab, 16 B per lane per access
+            constexpr int NV = (int)(sizeof(cell_t) * Game::MAX_CELLS / 16);
+            const pg_u4 *gg = reinterpret_cast<const pg_u4 *>(d.grid + (size_t)env * d.grid_bytes);
+            pg_u4 *lg = reinterpret_cast<pg_u4 *>(s->grid);
+            for (int base = 0; base < NV; base += 64) {
+                PG_FOR_LANES(l) {
+                    if (base + l < NV) lg[base + l] = gg[base + l];
+                }
             }
         }
         G.grid_dirty = 0;
@@ -1085,11 +864,12 @@ struct Env {
         }
         if (G.agent < 0 || G.agent >= n) fail(PGE_ASSERT);  // a detached agent never outlives the step (reset follows)
         if (G.grid_dirty) {
-            const int cells = G.main_width * G.main_height;
-            cell_t *gg = reinterpret_cast<cell_t *>(d.grid + (size_t)env * d.grid_bytes);
-            for (int base = 0; base < cells; base += 64) {
+            constexpr int NV = (int)(sizeof(cell_t) * Game::MAX_CELLS / 16);
+            pg_u4 *gg = reinterpret_cast<pg_u4 *>(d.grid + (size_t)env * d.grid_bytes);
+            const pg_u4 *lg = reinterpret_cast<const pg_u4 *>(s->grid);
+            for (int base = 0; base < NV; base += 64) {
                 PG_FOR_LANES(l) {
-                    if (base + l < cells) gg[base + l] = s->grid[base + l];
+                    if (base + l < NV) gg[base + l] = lg[base + l];
                 }
             }
         }
@@ -1112,7 +892,7 @@ struct Env {
 #if defined(PGAMD_WAVE_EMU)
         if (G.error && d.error) *d.error |= G.error;
 #else
-        if (threadIdx.x == 0) {
+        if (PG_LANE_ID() == 0) {
             if (G.big) {
                 const int slot = atomicAdd(d.next_big_count, 1);
                 d.next_big_list[slot] = env;
@@ -1133,8 +913,8 @@ struct Env {
             game_step_full();
         }
         rand_flush();
-        render();
-        store_observation();
+        prepare_for_drawing((float)RES_H);  // draw_background + draw_foreground both call it (BAG:922,982)
+        store_outputs();
         store_env();
     }
 };

@@ -6,11 +6,15 @@
 //   PG_FOR_LANES(l) { ... }      the body runs once per lane, `l` = lane id (0..63)
 //   PG_BALLOT(l, pred)           64-bit mask of lanes whose predicate holds
 //   PG_SYNC()                    orders LDS/global traffic between two lane sections
+//   PG_LANE_VAR(T, v) / PG_LV(v, l) / PG_READLANE(v, k)
+//                                a per-lane value that outlives a lane section, and its read from uniform
+//                                code (v_readlane on the GPU)
 // Rule: inside one PG_FOR_LANES section a lane may only read locations that no other lane writes in the
 // same section; cross-lane hand-offs go through LDS with a PG_SYNC() between the sections.
 //
 // On the GPU (hipcc, gfx950) PG_FOR_LANES is just "this lane", PG_BALLOT is v_cmp -> SGPR pair, and
-// PG_SYNC is an s_barrier-level fence for the single wave.  tests/emu builds the same sources with
+// PG_SYNC is a workgroup-scope memory fence for the wave (no s_barrier: waves of a multi-wave workgroup,
+// e.g. the 4 band-waves of the render kernel, never wait for each other).  tests/emu builds the same sources with
 // PGAMD_WAVE_EMU, where a lane section is a 64-iteration loop on the host: a debugging harness for the
 // kernel logic (this container has no GPU); it is never part of libenv.so.
 #pragma once
@@ -31,6 +35,11 @@
     })
 #define PG_SYNC() ((void)0)
 #define PG_UNIFORM_I(x) (x)
+#define PG_LANE_VAR(T, v) T v[64]
+#define PG_LV(v, l) v[l]
+#define PG_READLANE(v, k) v[k]
+#define PG_LANE_ARR(T, v, N) T v[N][64]
+#define PG_LA(v, j, l) v[j][l]
 PG_DEV int pg_popc64(uint64_t m) { return __builtin_popcountll(m); }
 PG_DEV int pg_clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
 PG_DEV int pg_ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
@@ -43,14 +52,24 @@ PG_DEV float pg_fabsf(float x) { return fabsf(x); }
 
 #include <hip/hip_runtime.h>
 #define PG_DEV __device__ __forceinline__
-#define PG_FOR_LANES(l) for (int l = (int)threadIdx.x, pg_once_ = 1; pg_once_; pg_once_ = 0)
+#define PG_LANE_ID() ((int)(threadIdx.x & 63u))
+#define PG_FOR_LANES(l) for (int l = PG_LANE_ID(), pg_once_ = 1; pg_once_; pg_once_ = 0)
 #define PG_BALLOT(l, pred)                              \
     ({                                                  \
-        const int l = (int)threadIdx.x;                 \
+        const int l = PG_LANE_ID();                     \
         (void)l;                                        \
         (uint64_t)__ballot((pred) ? 1 : 0);             \
     })
-#define PG_SYNC() __syncthreads()
+#define PG_SYNC()                                               \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
+#define PG_LANE_VAR(T, v) T v
+#define PG_LV(v, l) v
+#define PG_LANE_ARR(T, v, N) T v[N]
+#define PG_LA(v, j, l) v[j]
+#define PG_READLANE(v, k) ((decltype(v))__builtin_amdgcn_readlane((int)(v), (k)))
 // value known to be wave-uniform: move it to an SGPR so branches on it are scalar branches
 #define PG_UNIFORM_I(x) __builtin_amdgcn_readfirstlane((int)(x))
 PG_DEV int pg_popc64(uint64_t m) { return __popcll(m); }
@@ -62,6 +81,10 @@ PG_DEV double pg_ceil(double x) { return __builtin_ceil(x); }
 PG_DEV float pg_fabsf(float x) { return __builtin_fabsf(x); }
 
 #endif
+
+struct alignas(16) pg_u4 {  // 16-byte move unit for staging copies
+    uint32_t x, y, z, w;
+};
 
 // mask of lanes strictly below / at-or-below lane l
 PG_DEV uint64_t pg_mask_lt(int l) { return l >= 64 ? ~0ull : ((1ull << l) - 1ull); }

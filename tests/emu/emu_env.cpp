@@ -11,6 +11,7 @@
 
 #include "assets.h"
 #include "game_coinrun.h"
+#include "pg_render.h"
 #include "host_state.h"
 
 using namespace pgamd;
@@ -30,6 +31,7 @@ struct EmuVec {
     std::vector<float> rew;
     HostAssets assets;
     int use_small;
+    int dev_error = 0;
 };
 
 template <class Game, int CAP>
@@ -41,10 +43,16 @@ static void run_env(EmuVec *v, int env, int mode) {
 
 template <class Game>
 static void run_all(EmuVec *v, int mode) {
-    for (int e = 0; e < v->n; e++) {
+    for (int e = 0; e < v->n; e++) {  // "step kernels"
         if (v->use_small && !v->hdr[e].big) run_env<Game, Game::ENT_CAP_SMALL>(v, e, mode);
         else run_env<Game, Game::ENT_CAP_BIG>(v, e, mode);
     }
+    static uint32_t fb[NUM_BANDS][BAND_ROWS * RES_W];
+    for (int e = 0; e < v->n; e++)  // "render kernel": 4 band-waves per env
+        for (int b = 0; b < NUM_BANDS; b++) {
+            Renderer<Game> r(v->d, e, b, fb[b]);
+            r.render_band();
+        }
 }
 
 extern "C" {
@@ -106,6 +114,7 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.prev_level_complete = v->plc.data();
     d.assets = &v->assets.table;
     d.pixels = v->assets.pixels.data();
+    d.error = &v->dev_error;
     return v;
 }
 
@@ -125,7 +134,7 @@ void emu_observe(void *h, uint8_t *rgb, float *rew, uint8_t *first, int32_t *pls
     memcpy(plc, v->plc.data(), v->n);
     memcpy(ls, v->ls.data(), 4 * v->n);
 }
-int emu_error(void *h, int env) { return ((EmuVec *)h)->hdr[env].error; }
+int emu_error(void *h, int env) { return ((EmuVec *)h)->hdr[env].error | ((EmuVec *)h)->dev_error; }
 int emu_num_entities(void *h, int env) { return ((EmuVec *)h)->hdr[env].n_ents; }
 int emu_is_big(void *h, int env) { return ((EmuVec *)h)->hdr[env].big; }
 // entity dump in the reference's serialization order (31 words, reference src/entity.cpp:90-137)
