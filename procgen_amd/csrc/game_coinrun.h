@@ -82,6 +82,11 @@ struct CoinRun {
         }
         return is_blocked(e, e.etype(src), ttype, is_horizontal);  // BAG:494-496
     }
+    // superset of the (obj type, entity type) pairs for which is_blocked_ents or will_reflect can be true
+    template <class E>
+    PG_DEV static bool may_interact(E &e, int src_type, int target_type, bool is_horizontal) {
+        return (target_type == CRATE && !is_horizontal) || is_blocked(e, src_type, target_type, is_horizontal) || will_reflect(src_type, target_type);
+    }
     PG_DEV static bool will_reflect(int src, int target) {  // coinrun.cpp:140-142
         return src == ENEMY && (is_wall(target) || target == ENEMY_BARRIER);
     }

@@ -6,8 +6,12 @@
 #include "pg_defs.h"
 
 namespace pgamd {
+struct LaunchStreams {
+    hipStream_t main, side;   // side: large-arena step kernel, concurrent with the small-arena one
+    hipEvent_t fork, join;
+};
 // mode 0: initial reset + first observation of every env; mode 1: one step
-hipError_t launch_step(int game_id, const DevCtx &d, int mode, hipStream_t stream);
+hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStreams &ls);
 bool game_supported(int game_id);
 void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes);
 void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, EnvHdr *hdr, uint32_t *rng);

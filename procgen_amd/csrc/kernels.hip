@@ -45,20 +45,32 @@ __global__ __launch_bounds__(256) void render(DevCtx d) {
     r.render_band();
 }
 
+// The two step kernels touch disjoint envs, so the (few, slow, low-occupancy) large-arena envs run on a side
+// stream concurrently with the small-arena grid; the render kernel joins both.
 template <class Game>
-static hipError_t launch_game(const DevCtx &d, int mode, hipStream_t stream) {
-    hipLaunchKernelGGL(step_small<Game>, dim3(d.num_envs), dim3(64), 0, stream, d, mode);
+static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls) {
     if (mode != 0) {
-        int big_grid = d.num_envs < 2048 ? d.num_envs : 2048;
-        hipLaunchKernelGGL(step_big<Game>, dim3(big_grid), dim3(64), 0, stream, d, mode);
+        hipError_t e = hipEventRecord(ls.fork, ls.main);
+        if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(ls.side, ls.fork, 0);
+        if (e != hipSuccess) return e;
+        int big_grid = d.num_envs < 4096 ? d.num_envs : 4096;
+        hipLaunchKernelGGL(step_big<Game>, dim3(big_grid), dim3(64), 0, ls.side, d, mode);
+        e = hipEventRecord(ls.join, ls.side);
+        if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(step_small<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode);
+    if (mode != 0) {
+        hipError_t e = hipStreamWaitEvent(ls.main, ls.join, 0);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(256), 0, ls.main, d);
     return hipGetLastError();
 }
 
-hipError_t launch_step(int game_id, const DevCtx &d, int mode, hipStream_t stream) {
+hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStreams &ls) {
     switch (game_id) {
-        case GAME_COINRUN: return launch_game<CoinRun>(d, mode, stream);
+        case GAME_COINRUN: return launch_game<CoinRun>(d, mode, ls);
         default: return hipErrorInvalidValue;
     }
 }

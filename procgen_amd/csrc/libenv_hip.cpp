@@ -108,7 +108,9 @@ struct VecGame {
     int device_id = 0;
     bool host_observations = true;
     std::vector<libenv_tensortype> observation_types, action_types, info_types;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    LaunchStreams streams() const { return LaunchStreams{stream, side_stream, ev_fork, ev_join}; }
     DevCtx d{};
     HostAssets assets;
     GameAssetsDev *d_assets = nullptr;
@@ -260,6 +262,9 @@ VecGame::VecGame(int nenvs, VecOptions opts) {
     if (device_id >= ndev) fatal("device_id %d out of range (%d devices)\n", device_id, ndev);
     HIP_CHECK(hipSetDevice(device_id));
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
 
     // assets: baked pack next to the library (procgen_amd/data/<game>.atlas) or the PNG tree at resource_root
     std::string data_dir = getenv("PROCGEN_AMD_DATA_DIR") ? getenv("PROCGEN_AMD_DATA_DIR") : this_library_dir() + "/../../data";
@@ -326,6 +331,9 @@ VecGame::~VecGame() {
     if (h_action) (void)hipHostFree(h_action);
     if (h_small) (void)hipHostFree(h_small);
     if (h_obs_stage) (void)hipHostFree(h_obs_stage);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -363,7 +371,7 @@ void VecGame::launch(int mode) {
     d.next_big_count = d_big_count[nxt];
     HIP_CHECK(hipMemsetAsync(d_big_count[nxt], 0, sizeof(int), stream));
     HIP_CHECK(hipMemsetAsync(d.error, 0, sizeof(int), stream));
-    HIP_CHECK(launch_step(game_id, d, mode, stream));
+    HIP_CHECK(launch_step(game_id, d, mode, streams()));
     step_count++;
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
     if (host_observations) {
@@ -475,7 +483,7 @@ LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const in
         v->d.next_big_count = v->d_big_count[nxt];
         HIP_CHECK(hipMemsetAsync(v->d_big_count[nxt], 0, sizeof(int), v->stream));
         HIP_CHECK(hipEventRecord(e0, v->stream));
-        HIP_CHECK(launch_step(v->game_id, v->d, 1, v->stream));
+        HIP_CHECK(launch_step(v->game_id, v->d, 1, v->streams()));
         HIP_CHECK(hipEventRecord(e1, v->stream));
         v->step_count++;
         HIP_CHECK(hipEventSynchronize(e1));

@@ -438,7 +438,9 @@ struct Env {
                                       bool hit = false;
                                       if (l < limit && idx < n && idx != obj) {
                                           const uint32_t mm = meta(idx);
-                                          if (!(mm & MF_WILL_ERASE)) {
+                                          // only entities that can block or reflect `obj` need a visit (a hit with any
+                                          // other entity has no effect in BAG:346-366)
+                                          if (!(mm & MF_WILL_ERASE) && Game::may_interact(*this, otype, meta_type(mm), is_horizontal)) {
                                               const float tx = (orx + erx(idx)) + POS_EPS;
                                               const float ty = (ory + ery(idx)) + POS_EPS;
                                               hit = (pg_fabsf(cx - ex(idx)) < tx) && (pg_fabsf(cy - ey(idx)) < ty);
