@@ -17,8 +17,15 @@ struct CoinRun {
     // Worst-case entity count: 5 pit sections x 7 walking enemies x (1 + 9 live trails) + agent = 351.
     static constexpr int ENT_CAP_SMALL = 128;
     static constexpr int ENT_CAP_BIG = 384;
-    // Per step the list grows by at most one trail per ENEMY (<= n); a reset creates <= 42 entities.
-    PG_DEV static bool needs_big(int n_ents) { return 2 * n_ents + 2 > ENT_CAP_SMALL - 1; }
+    // Per step the list grows by at most one trail per ENEMY (enemies are only created by a reset); a reset
+    // creates <= 42 entities.  So the small arena is safe next step iff n + #ENEMY fits.
+    template <class E>
+    PG_DEV static bool needs_big(E &e) {
+        const int n = e.G.n_ents;
+        int enemies = 0;
+        for (int c = 0; c < ((n + 63) >> 6); c++) enemies += pg_popc64(PG_BALLOT(l, ((c << 6) + l) < n && e.etype((c << 6) + l) == ENEMY));
+        return n + enemies + 2 > ENT_CAP_SMALL - 1;
+    }
 
     // object ids coinrun.cpp:11-31
     static constexpr int GOAL = 1, SAW = 2, SAW2 = 3, ENEMY = 5, ENEMY1 = 6, ENEMY2 = 7;

@@ -875,7 +875,7 @@ struct Env {
                 }
             }
         }
-        G.big = Game::needs_big(n) ? 1 : 0;
+        G.big = Game::needs_big(*this) ? 1 : 0;
         publish_routing();
         {
             EnvHdr *h = d.hdr + env;

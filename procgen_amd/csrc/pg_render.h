@@ -239,8 +239,8 @@ struct Renderer {
                       PG_READLANE(r.img, k));
     }
     // executes the commands in lane order; runs of small commands go eight at a time
-    PG_DEV void run_batch(const CmdRegs &r) {
-        uint64_t valid = PG_BALLOT(l, PG_LV(r.geom, l) != 0);
+    PG_DEV void run_batch(const CmdRegs &r, uint64_t lane_mask = ~0ull) {
+        uint64_t valid = PG_BALLOT(l, PG_LV(r.geom, l) != 0) & lane_mask;
         const uint64_t small = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && ((PG_LV(r.geom, l) >> 14) & 0x7fu) <= 8u && ((PG_LV(r.geom, l) >> 21) & 0x7fu) <= 8u);
         while (valid) {
             const int k = pg_ctz64(valid);
@@ -267,35 +267,42 @@ struct Renderer {
         }
     }
 
-    // draw_entities BAG:1052-1066 for one render_z layer
-    PG_DEV void draw_entities(int render_z) {
+    // draw_entities BAG:1052-1066.  Commands of 64 entities are set up once (they do not depend on the layer) and
+    // then executed per render_z layer through a lane mask.
+    PG_DEV void setup_entities(int base, CmdRegs &r, uint64_t (&zmask)[3]) {
+        const int n = G.n_ents;
+        for (int z = 0; z < 3; z++) zmask[z] = PG_BALLOT(l, (base + l) < n && meta_render_z(meta(base + l)) == z - 1);
+        PG_FOR_LANES(l) {
+            const int i = base + l;
+            PG_LV(r.geom, l) = 0;
+            PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.img, l) = 0;
+            if (i < n && Game::should_draw_entity(*this, i)) {
+                const uint32_t mm = meta(i);
+                const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
+                RectD r1;  // get_object_rect BAG:811-817
+                if (mm & MF_ABS_COORDS) {
+                    const float vd = G.view_dim;
+                    r1.x = (double)((vd * (x - rx)) * G.unit);
+                    r1.y = (double)((vd * (y + ry)) * G.unit);
+                    r1.w = (double)((2 * vd * rx) * G.unit);
+                    r1.h = (double)((2 * vd * ry) * G.unit);
+                } else {
+                    r1 = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
+                }
+                const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), ef(EF_ROTATION, i), Game::tile_aspect_ratio(*this, i), r1);
+                if (im >= 0) cmd_image(im, (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.img, l));
+            }
+        }
+    }
+    PG_DEV void draw_entities(int render_z) {  // general path (more than 64 entities): one set-up per layer and chunk
         const int n = G.n_ents;
         for (int base = 0; base < n; base += 64) {
             const uint64_t any = PG_BALLOT(l, (base + l) < n && meta_render_z(meta(base + l)) == render_z);
             if (!any) continue;
             CmdRegs r;
-            PG_FOR_LANES(l) {
-                const int i = base + l;
-                PG_LV(r.geom, l) = 0;
-                PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.img, l) = 0;
-                if (i < n && (any & (1ull << l)) && Game::should_draw_entity(*this, i)) {
-                    const uint32_t mm = meta(i);
-                    const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
-                    RectD r1;  // get_object_rect BAG:811-817
-                    if (mm & MF_ABS_COORDS) {
-                        const float vd = G.view_dim;
-                        r1.x = (double)((vd * (x - rx)) * G.unit);
-                        r1.y = (double)((vd * (y + ry)) * G.unit);
-                        r1.w = (double)((2 * vd * rx) * G.unit);
-                        r1.h = (double)((2 * vd * ry) * G.unit);
-                    } else {
-                        r1 = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
-                    }
-                    const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), ef(EF_ROTATION, i), Game::tile_aspect_ratio(*this, i), r1);
-                    if (im >= 0) cmd_image(im, (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.img, l));
-                }
-            }
-            run_batch(r);
+            uint64_t zmask[3];
+            setup_entities(base, r, zmask);
+            run_batch(r, zmask[render_z + 1]);
         }
     }
 
@@ -326,7 +333,16 @@ struct Renderer {
             cmd_image(bgi, false, bg_rect, 1.0f, geom, basex, srcy, ix, iy, img);
             if (geom != 0) exec_large(unpack(geom, basex, srcy, ix, iy, img));
         }
-        draw_entities(-1);
+        // common case (<= 64 entities): their commands are built once and kept in registers across the tile pass
+        const bool one_chunk = G.n_ents <= 64;
+        CmdRegs er;
+        uint64_t ezmask[3] = {0, 0, 0};
+        if (one_chunk) {
+            setup_entities(0, er, ezmask);
+            if (ezmask[0]) run_batch(er, ezmask[0]);
+        } else {
+            draw_entities(-1);
+        }
         int low_x, high_x, low_y, high_y;
         if (d.opt.center_agent) {
             const float margin = (float)(G.visibility / 2.0 + 1);
@@ -352,6 +368,8 @@ struct Renderer {
         }
         const int ny = high_y - low_y + 1;
         const int ncell = ny > 0 ? (high_x - low_x + 1) * ny : 0;
+        const uint32_t ny_inv = ny > 0 ? (uint32_t)(((1u << 20) + (uint32_t)ny - 1u) / (uint32_t)ny) : 0u;
+        if (ncell > 4096) fail(PGE_ASSERT);
         for (int base = 0; base < ncell; base += 64) {
             CmdRegs r;
             PG_FOR_LANES(l) {
@@ -359,7 +377,8 @@ struct Renderer {
                 PG_LV(r.geom, l) = 0;
                 PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.img, l) = 0;
                 if (cidx < ncell) {
-                    const int x = low_x + cidx / ny, y = low_y + cidx % ny;
+                    const int cx = (int)(((uint32_t)cidx * ny_inv) >> 20);  // cidx / ny (exact for cidx < 4096)
+                    const int x = low_x + cx, y = low_y + (cidx - cx * ny);
                     const int type = get_obj(x, y);
                     if (type != INVALID_OBJ && type != SPACE) {
                         const int theme = Game::theme_for_grid_obj(*this, type);
@@ -371,8 +390,13 @@ struct Renderer {
             }
             run_batch(r);
         }
-        draw_entities(0);
-        draw_entities(1);
+        if (one_chunk) {
+            if (ezmask[1]) run_batch(er, ezmask[1]);
+            if (ezmask[2]) run_batch(er, ezmask[2]);
+        } else {
+            draw_entities(0);
+            draw_entities(1);
+        }
         if (G.has_useful_vel_info && d.opt.paint_vel_info) fail(PGE_UNSUPPORTED_DRAW);
         PG_SYNC();
         store_band();
