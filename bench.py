@@ -129,6 +129,12 @@ def main():
     env.close()
 
     if rank == 0:
+        traffic = None  # HBM bytes per launch (= one step) from the committed rocprofv3 PMC passes, same workload only
+        tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath) and args.game == "coinrun":
+            tj = json.load(open(tpath))
+            if tj.get("num_envs") == n:
+                traffic = round(tj["hbm_bytes_per_step_upper"])
         total_steps = n * world * args.steps
         value = total_steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
@@ -141,7 +147,9 @@ def main():
                                    f"observations {'landed on host (PCIe inclusive)' if args.host_landed else 'resident in HBM'}",
                        "num_envs_per_gpu": n, "sharding": f"env_offset shards x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "launch": "one step = step_small + step_big + render kernels over all envs of this GPU",
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "kernel_ms_per_step": round(kernel_ms, 4), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
         }
         if world == 1 and not args.no_cpu_baseline:
