@@ -7,7 +7,7 @@
  * literals promote, results narrow on assignment); build with -ffp-contract=off (no FMA), matching
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
- * Games restated so far: coinrun.
+ * Games restated so far: coinrun, bigfish.
  */
 #include "procgen_oracle.h"
 
@@ -37,7 +37,13 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_COINRUN = 5 };
+enum { GAME_BIGFISH = 0, GAME_COINRUN = 5 };
+
+/* bigfish ids: reference src/games/bigfish.cpp:8-18 */
+#define BF_FISH 2
+#define BF_FISH_MIN_R .25f
+#define BF_FISH_MAX_R 2.0f
+#define BF_FISH_QUOTA 30
 
 /* coinrun ids: reference src/games/coinrun.cpp:11-31 */
 #define CR_GOAL 1
@@ -294,6 +300,17 @@ static void assets_build(int game_id) {
         /* coinrun.cpp:60-62 load_background_images: platform_backgrounds */
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_BIGFISH) { /* bigfish.cpp:33-46 */
+        assets_type(a, PLAYER, "misc_assets/fishTile_072.png");
+        assets_type(a, BF_FISH, "misc_assets/fishTile_074.png");
+        assets_type(a, BF_FISH, "misc_assets/fishTile_078.png");
+        assets_type(a, BF_FISH, "misc_assets/fishTile_080.png");
+        /* water_backgrounds, reference src/resources.cpp:921-932 */
+        static const char *WATER[] = {"water_backgrounds/water1.png", "water_backgrounds/water2.png", "water_backgrounds/water3.png",
+                                      "water_backgrounds/water4.png", "water_backgrounds/underwater1.png", "water_backgrounds/underwater2.png",
+                                      "water_backgrounds/underwater3.png"};
+        a->n_bg = 7;
+        for (int i = 0; i < 7; i++) a->bg_img[i] = assets_add(a, WATER[i], 1);
     } else {
         fatal("game not restated in the oracle");
     }
@@ -301,6 +318,7 @@ static void assets_build(int game_id) {
 
 int pgo_game_id(const char *name) {
     if (strcmp(name, "coinrun") == 0) return GAME_COINRUN;
+    if (strcmp(name, "bigfish") == 0) return GAME_BIGFISH;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -365,6 +383,10 @@ typedef struct {
     float unit, view_dim, x_off, y_off, visibility, min_visibility;
     int grid_w, grid_h;
     int grid[MAX_GRID];
+    int center_agent; /* options.center_agent: some games overwrite it in game_reset (bigfish.cpp:64) */
+    /* BigFish: bigfish.cpp:22-23 */
+    int fish_eaten;
+    float r_inc;
     /* CoinRun */
     float last_agent_y;
     int wall_theme, has_support, facing_right, is_on_crate;
@@ -467,6 +489,19 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
     if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:123-131 */
         if (obj->type == CR_ENEMY) g->done = 1;
         else if (obj->type == CR_SAW) g->done = 1;
+    } else if (g->game_id == GAME_BIGFISH) { /* bigfish.cpp:48-62 */
+        Ent *agent = &g->pool[g->agent];
+        if (obj->type == BF_FISH) {
+            if (obj->rx > agent->rx) {
+                g->done = 1;
+            } else {
+                g->reward += 1.0f; /* POSITIVE_REWARD is an int constant 1 */
+                obj->will_erase = 1;
+                agent->rx += g->r_inc;
+                agent->ry += g->r_inc;
+                g->fish_eaten += 1;
+            }
+        }
     }
 }
 static void hook_handle_grid_collision(Game *g, Ent *obj, int type, int i, int j) {
@@ -732,7 +767,10 @@ static void bag_game_step(Game *g) {
     g->done = g->done || is_out_of_bounds(g, &g->pool[g->agent]);
 }
 
-/* ---- CoinRun::game_step: coinrun.cpp:474-498 ---- */
+static void choose_random_theme(Game *g, Ent *ent);
+static void match_aspect_ratio(Game *g, Ent *ent);
+
+/* ---- per-game game_step: coinrun.cpp:474-498, bigfish.cpp:80-107 ---- */
 static void game_step(Game *g) {
     bag_game_step(g);
     if (g->game_id == GAME_COINRUN) {
@@ -755,12 +793,39 @@ static void game_step(Game *g) {
             }
         }
         g->last_agent_y = agent->y;
+    } else if (g->game_id == GAME_BIGFISH) { /* bigfish.cpp:83-107 */
+        if (rng_randn(&g->rand_gen, 10) == 1) {
+            float ent_r = (float)((BF_FISH_MAX_R - BF_FISH_MIN_R) * pow((double)rng_rand01(&g->rand_gen), 1.4) + BF_FISH_MIN_R);
+            float ent_y = rng_rand01(&g->rand_gen) * (g->main_height - 2 * ent_r);
+            float moves_right = rng_rand01(&g->rand_gen) < .5;
+            float ent_vx = (float)((.15 + rng_rand01(&g->rand_gen) * .25) * (moves_right ? 1 : -1));
+            float ent_x = moves_right ? -1 * ent_r : g->main_width + ent_r;
+            Ent *ent = push_entity(g, ent_x, ent_y, ent_vx, 0, ent_r, ent_r, BF_FISH);
+            choose_random_theme(g, ent);
+            match_aspect_ratio(g, ent);
+            ent->is_reflected = !moves_right;
+        }
+        if (g->fish_eaten >= BF_FISH_QUOTA) {
+            g->done = 1;
+            g->reward += 10.0f; /* COMPLETION_BONUS */
+            g->level_complete = 1;
+        }
+        Ent *agent = &g->pool[g->agent];
+        if (g->action_vx > 0) agent->is_reflected = 0;
+        if (g->action_vx < 0) agent->is_reflected = 1;
     }
 }
 
 /* ---- level generation ---- */
 static void choose_random_theme(Game *g, Ent *ent) { /* BAG:1038-1041 */
     ent->image_theme = rng_randn(&g->rand_gen, g->assets->type_num_themes[ent->image_type]);
+}
+
+static void match_aspect_ratio(Game *g, Ent *ent) { /* BAG:1014-1023 (match_width = true), aspect from BAG:114 */
+    if (g->assets->type_num_themes[ent->image_type] <= ent->image_theme) fatal("asset theme out of range");
+    const Img *im = &g->assets->img[g->assets->type_theme_img[ent->image_type][ent->image_theme]];
+    float aspect = (float)(im->w * 1.0 / im->h);
+    ent->ry = ent->rx / aspect;
 }
 
 static void cr_fill_block_top(Game *g, int x, int y, int dx, int dy, int fill, int top) { /* coinrun.cpp:227-231 */
@@ -933,6 +998,16 @@ static void game_reset(Game *g) {
         fill_elem(g, g->main_width - 1, 0, 1, g->main_height, CR_WALL_MID);
         fill_elem(g, 0, g->main_height - 1, g->main_width, 1, CR_WALL_MID);
         cr_generate_coin_to_the_right(g);
+    } else if (g->game_id == GAME_BIGFISH) { /* bigfish.cpp:64-81 */
+        Ent *agent = &g->pool[g->agent];
+        g->center_agent = 0;
+        g->fish_eaten = 0;
+        float start_r = (float).5;
+        if (g->opt.distribution_mode == 0) start_r = 1;
+        g->r_inc = (BF_FISH_MAX_R - start_r) / BF_FISH_QUOTA;
+        agent->rx = start_r;
+        agent->ry = start_r;
+        agent->y = 1 + agent->ry;
     }
 }
 
@@ -1028,7 +1103,7 @@ static RectD adjust_rect(RectD b, RectD a) { /* src/qt-utils.h:12-19 */
 static void prepare_for_drawing(Game *g, float rect_height) { /* BAG:819-838 */
     g->center_x = (float)(g->main_width * .5);
     g->center_y = (float)(g->main_height * .5);
-    if (g->opt.center_agent) {
+    if (g->center_agent) {
         g->center_x = g->pool[g->agent].x; /* choose_center BAG:664-667 */
         g->center_y = g->pool[g->agent].y;
     } else {
@@ -1122,7 +1197,7 @@ static void game_draw(Game *g, uint32_t *dst) { /* BAG:979-1012,921-970 */
     prepare_for_drawing(g, (float)RES_H);
     draw_entities(g, dst, -1);
     int low_x, high_x, low_y, high_y;
-    if (g->opt.center_agent) {
+    if (g->center_agent) {
         float margin = (float)(g->visibility / 2.0 + 1);
         low_x = (int)(g->center_x - margin);
         high_x = (int)(g->center_x + margin);
@@ -1211,6 +1286,7 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
     g->game_id = game_id;
     g->assets = &g_assets[game_id];
     g->opt = *opt;
+    g->center_agent = opt->center_agent;
     /* Game::Game src/game.cpp:25-38 */
     g->timeout = 1000;
     g->last_reward = -1;
@@ -1235,6 +1311,10 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->main_width = 64;
         g->main_height = 64;
         g->out_of_bounds_object = CR_WALL_MID;
+    } else if (game_id == GAME_BIGFISH) { /* bigfish.cpp:25-31 */
+        g->timeout = 6000;
+        g->main_width = 20;
+        g->main_height = 20;
     }
 }
 

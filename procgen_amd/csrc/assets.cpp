@@ -78,6 +78,11 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(3, {"kenney/Enemies/sawHalf_move.png"});
         add_themes(20, {"kenney/Tiles/boxCrate.png", "kenney/Tiles/boxCrate_double.png", "kenney/Tiles/boxCrate_single.png", "kenney/Tiles/boxCrate_warning.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_BIGFISH) {  // reference src/games/bigfish.cpp:33-46, src/resources.cpp:921-932
+        add_themes(0, {"misc_assets/fishTile_072.png"});
+        add_themes(2, {"misc_assets/fishTile_074.png", "misc_assets/fishTile_078.png", "misc_assets/fishTile_080.png"});
+        for (const char *n : {"water1", "water2", "water3", "water4", "underwater1", "underwater2", "underwater3"})
+            backgrounds->push_back(std::string("water_backgrounds/") + n + ".png");
     } else {
         return false;
     }

@@ -42,6 +42,7 @@ struct CoinRun {
 #define CR_FACING_RIGHT(G) (G).gsi2
 #define CR_IS_ON_CRATE(G) (G).gsi3
 
+    PG_DEV static bool center_agent(const GameOptions &o) { return o.center_agent != 0; }  // left as passed
     PG_DEV static bool is_wall(int t) { return t == WALL_MID || t == WALL_TOP; }
     PG_DEV static bool is_lava(int t) { return t == LAVA_MID || t == LAVA_TOP; }
 

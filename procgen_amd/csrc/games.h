@@ -1,0 +1,6 @@
+// games.h -- the game policies compiled into the kernels (one kernel instantiation per game).
+#pragma once
+#include "game_bigfish.h"
+#include "game_coinrun.h"
+
+#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish)

@@ -10,7 +10,7 @@
 // state write-back.
 #include <hip/hip_runtime.h>
 
-#include "game_coinrun.h"
+#include "games.h"
 #include "pg_render.h"
 #include "kernels.h"
 
@@ -70,28 +70,45 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
 
 hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStreams &ls) {
     switch (game_id) {
-        case GAME_COINRUN: return launch_game<CoinRun>(d, mode, ls);
+#define PG_X(Game) \
+    case Game::GAME_ID: return launch_game<Game>(d, mode, ls);
+        PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
         default: return hipErrorInvalidValue;
     }
 }
 
-bool game_supported(int game_id) { return game_id == GAME_COINRUN; }
+bool game_supported(int game_id) {
+    switch (game_id) {
+#define PG_X(Game) \
+    case Game::GAME_ID: return true;
+        PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
+        default: return false;
+    }
+}
 
 void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes) {
+    *ent_cap_hbm = 0;
+    *grid_bytes = 0;
     switch (game_id) {
-        case GAME_COINRUN:
-            *ent_cap_hbm = CoinRun::ENT_CAP_BIG;
-            *grid_bytes = CoinRun::MAX_CELLS * (int)sizeof(CoinRun::cell_t);
-            break;
-        default:
-            *ent_cap_hbm = 0;
-            *grid_bytes = 0;
+#define PG_X(Game)                                                                        \
+    case Game::GAME_ID:                                                                   \
+        *ent_cap_hbm = Game::ENT_CAP_BIG;                                                 \
+        *grid_bytes = (int)((Game::MAX_CELLS * sizeof(Game::cell_t) + 15) & ~(size_t)15); \
+        break;
+        PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
+        default: break;
     }
 }
 
 void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, EnvHdr *hdr, uint32_t *rng) {
     switch (game_id) {
-        case GAME_COINRUN: init_env_state<CoinRun>(num_envs, rand_seed, env_offset, hdr, rng); break;
+#define PG_X(Game) \
+    case Game::GAME_ID: init_env_state<Game>(num_envs, rand_seed, env_offset, hdr, rng); break;
+        PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
         default: break;
     }
 }

@@ -86,7 +86,7 @@ struct Lds {
     uint32_t mt[2 * MT_STRIDE];  // MT19937 scratch A/B (seed / twist of rand_gen during a reset)
     uint32_t ent[EF_COUNT * CAP];
     uint32_t tmp[64];
-    alignas(16) typename Game::cell_t grid[Game::MAX_CELLS];
+    alignas(16) typename Game::cell_t grid[(Game::MAX_CELLS + 15) & ~15];
 };
 
 template <class Game, int CAP>
@@ -741,6 +741,18 @@ struct Env {
         set_image_theme(i, randn(nt));
     }
 
+    PG_DEV void match_aspect_ratio(int i) {  // BAG:1014-1023 (match_width), aspect ratio BAG:114
+        const uint32_t mm = meta(i);
+        const int img = (int)d.assets->type_theme_img[meta_image_type(mm)][meta_image_theme(mm)];
+        if (img < 0) {
+            fail(PGE_THEME);
+            return;
+        }
+        const ImgDesc im = d.assets->img[img];
+        const float aspect = (float)((double)im.w * 1.0 / (double)im.h);
+        ery(i) = erx(i) / aspect;
+    }
+
     // Game::reset reference src/game.cpp:93-118
     PG_DEV void game_reset_full() {
         if (G.episodes_remaining == 0) {
@@ -794,7 +806,7 @@ struct Env {
     PG_DEV void prepare_for_drawing(float rect_height) {  // BAG:819-838
         G.center_x = (float)(G.main_width * .5);
         G.center_y = (float)(G.main_height * .5);
-        if (d.opt.center_agent) {
+        if (Game::center_agent(d.opt)) {
             Game::choose_center(*this, G.center_x, G.center_y);
         } else {
             G.visibility = (float)(G.main_width > G.main_height ? G.main_width : G.main_height);
@@ -841,7 +853,7 @@ struct Env {
             }
         }
         {   // whole grid slab, 16 B per lane per access
-            constexpr int NV = (int)(sizeof(cell_t) * Game::MAX_CELLS / 16);
+            constexpr int NV = (int)((sizeof(cell_t) * Game::MAX_CELLS + 15) / 16);
             const pg_u4 *gg = reinterpret_cast<const pg_u4 *>(d.grid + (size_t)env * d.grid_bytes);
             pg_u4 *lg = reinterpret_cast<pg_u4 *>(s->grid);
             for (int base = 0; base < NV; base += 64) {
@@ -866,7 +878,7 @@ struct Env {
         }
         if (G.agent < 0 || G.agent >= n) fail(PGE_ASSERT);  // a detached agent never outlives the step (reset follows)
         if (G.grid_dirty) {
-            constexpr int NV = (int)(sizeof(cell_t) * Game::MAX_CELLS / 16);
+            constexpr int NV = (int)((sizeof(cell_t) * Game::MAX_CELLS + 15) / 16);
             pg_u4 *gg = reinterpret_cast<pg_u4 *>(d.grid + (size_t)env * d.grid_bytes);
             const pg_u4 *lg = reinterpret_cast<const pg_u4 *>(s->grid);
             for (int base = 0; base < NV; base += 64) {

@@ -344,7 +344,7 @@ struct Renderer {
             draw_entities(-1);
         }
         int low_x, high_x, low_y, high_y;
-        if (d.opt.center_agent) {
+        if (Game::center_agent(d.opt)) {
             const float margin = (float)(G.visibility / 2.0 + 1);
             low_x = (int)(G.center_x - margin);
             high_x = (int)(G.center_x + margin);

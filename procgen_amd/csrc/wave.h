@@ -47,6 +47,7 @@ PG_DEV double pg_sqrt(double x) { return sqrt(x); }
 PG_DEV double pg_floor(double x) { return floor(x); }
 PG_DEV double pg_ceil(double x) { return ceil(x); }
 PG_DEV float pg_fabsf(float x) { return fabsf(x); }
+PG_DEV double pg_pow(double x, double y) { return pow(x, y); }  // glibc, as the reference
 
 #else
 
@@ -79,6 +80,8 @@ PG_DEV double pg_sqrt(double x) { return __builtin_sqrt(x); }   // IEEE correctl
 PG_DEV double pg_floor(double x) { return __builtin_floor(x); }
 PG_DEV double pg_ceil(double x) { return __builtin_ceil(x); }
 PG_DEV float pg_fabsf(float x) { return __builtin_fabsf(x); }
+// ROCm device libm (OCML), < 1 ulp in double; callers narrow the result to float (bit-exactness notes)
+PG_DEV double pg_pow(double x, double y) { return pow(x, y); }
 
 #endif
 

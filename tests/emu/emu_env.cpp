@@ -10,7 +10,7 @@
 #include <vector>
 
 #include "assets.h"
-#include "game_coinrun.h"
+#include "games.h"
 #include "pg_render.h"
 #include "host_state.h"
 
@@ -32,6 +32,7 @@ struct EmuVec {
     HostAssets assets;
     int use_small;
     int dev_error = 0;
+    int game_id = -1;
 };
 
 template <class Game, int CAP>
@@ -65,20 +66,30 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     v->use_small = use_small;
     std::string err;
     int gid = game_id_from_name(game);
-    if (gid != GAME_COINRUN) {
+    bool known = false;
+#define PG_X(Game) known = known || gid == Game::GAME_ID;
+    PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
+    if (!known) {
         fprintf(stderr, "emu: game %s not implemented\n", game);
         return nullptr;
     }
+    v->game_id = gid;
     if (!load_game_assets(gid, resource_root ? resource_root : "", atlas_path ? atlas_path : "", &v->assets, &err)) {
         fprintf(stderr, "emu: %s\n", err.c_str());
         return nullptr;
     }
-    using Game = CoinRun;
-    const int ent_cap = Game::ENT_CAP_BIG;
+    int ent_cap = 0, grid_bytes = 0;
+#define PG_X(Game)                                                                            \
+    if (gid == Game::GAME_ID) {                                                               \
+        ent_cap = Game::ENT_CAP_BIG;                                                          \
+        grid_bytes = (int)((Game::MAX_CELLS * sizeof(Game::cell_t) + 15) & ~(size_t)15);      \
+    }
+    PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
     v->hdr.resize(num_envs);
     v->rng.assign((size_t)num_envs * 2 * MT_STRIDE, 0);
     v->ents.assign((size_t)num_envs * EF_COUNT * ent_cap, 0);
-    const int grid_bytes = Game::MAX_CELLS * (int)sizeof(Game::cell_t);
     v->grid.assign((size_t)num_envs * grid_bytes, 0);
     v->obs.assign((size_t)num_envs * OBS_BYTES, 0);
     v->first.assign(num_envs, 0);
@@ -87,7 +98,10 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     v->pls.assign(num_envs, 0);
     v->ls.assign(num_envs, 0);
     v->rew.assign(num_envs, 0);
-    init_env_state<Game>(num_envs, rand_seed, env_offset, v->hdr.data(), v->rng.data());
+#define PG_X(Game) \
+    if (gid == Game::GAME_ID) init_env_state<Game>(num_envs, rand_seed, env_offset, v->hdr.data(), v->rng.data());
+    PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
     DevCtx &d = v->d;
     memset(&d, 0, sizeof(d));
     d.num_envs = num_envs;
@@ -119,11 +133,17 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
 }
 
 void emu_free(void *h) { delete (EmuVec *)h; }
-void emu_init(void *h) { run_all<CoinRun>((EmuVec *)h, 0); }
+static void run_game(EmuVec *v, int mode) {
+#define PG_X(Game) \
+    if (v->game_id == Game::GAME_ID) run_all<Game>(v, mode);
+    PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
+}
+void emu_init(void *h) { run_game((EmuVec *)h, 0); }
 void emu_step(void *h, const int32_t *actions) {
     EmuVec *v = (EmuVec *)h;
     memcpy(v->action.data(), actions, sizeof(int32_t) * v->n);
-    run_all<CoinRun>(v, 1);
+    run_game(v, 1);
 }
 void emu_observe(void *h, uint8_t *rgb, float *rew, uint8_t *first, int32_t *pls, uint8_t *plc, int32_t *ls) {
     EmuVec *v = (EmuVec *)h;
@@ -162,7 +182,7 @@ void emu_dump_grid(void *h, int env, int32_t *out, int *w, int *hh) {
     EmuVec *v = (EmuVec *)h;
     *w = v->hdr[env].main_width;
     *hh = v->hdr[env].main_height;
-    const uint8_t *g = v->grid.data() + (size_t)env * v->d.grid_bytes;
+    const uint8_t *g = v->grid.data() + (size_t)env * v->d.grid_bytes;  // u8 cells (all games so far)
     for (int i = 0; i < (*w) * (*hh); i++) out[i] = g[i];
 }
 }

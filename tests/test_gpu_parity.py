@@ -14,12 +14,15 @@ from helpers import HIP_LIB, action_stream, assert_rollouts_equal, hip_memcpy_dt
 pytestmark = pytest.mark.gpu
 
 
-def make_env(n, **kw):
+GAMES = ["coinrun", "bigfish"]
+
+
+def make_env(n, game="coinrun", **kw):
     from procgen_amd import ProcgenGym3Env
 
     assert os.path.exists(HIP_LIB), "HIP libenv.so missing: run __graft_entry__.build() (there is no fallback path)"
     kw.setdefault("rand_seed", 23)
-    return ProcgenGym3Env(n, "coinrun", **kw)
+    return ProcgenGym3Env(n, game, **kw)
 
 
 def test_native_library_is_the_one_loaded():
@@ -30,31 +33,34 @@ def test_native_library_is_the_one_loaded():
     env.close()
 
 
-def test_golden_rollout_from_compiled_reference(golden_dir):
-    gold = np.load(os.path.join(golden_dir, "coinrun_rollout.npz"))
+@pytest.mark.parametrize("game", GAMES)
+def test_golden_rollout_from_compiled_reference(golden_dir, game):
+    gold = np.load(os.path.join(golden_dir, f"{game}_rollout.npz"))
     n = gold["actions"].shape[1]
-    got = rollout(make_env(n), list(gold["actions"][:-1]), keep_frames=True)
+    got = rollout(make_env(n, game), list(gold["actions"][:-1]), keep_frames=True)
     ref = {k: gold[k] for k in ("rew", "first", "prev_level_seed", "prev_level_complete", "level_seed", "crc")}
     assert_rollouts_equal(got, ref, "HIP vs compiled reference (golden)")
     for k, t in enumerate(gold["frame_t"]):
         assert np.array_equal(got["frames"][t][:4], gold["frames"][k])
 
 
-def test_parity_with_oracle_many_envs():
+@pytest.mark.parametrize("game", GAMES)
+def test_parity_with_oracle_many_envs(game):
     n, steps = 256, 400
     acts = action_stream(n, steps, seed=1)
-    a = rollout(oracle_env.OracleEnv(n, "coinrun", rand_seed=23), acts)
-    b = rollout(make_env(n), acts)
-    assert_rollouts_equal(a, b, "HIP vs oracle")
+    a = rollout(oracle_env.OracleEnv(n, game, rand_seed=23), acts)
+    b = rollout(make_env(n, game), acts)
+    assert_rollouts_equal(a, b, f"HIP vs oracle ({game})")
     assert a["first"][1:].sum() > 20  # resets / level generation on device were exercised
 
 
-def test_seeding_protocol(golden_dir):
+@pytest.mark.parametrize("game", GAMES)
+def test_seeding_protocol(golden_dir, game):
     """reference procgen/env_test.py:7-30"""
-    g = np.load(os.path.join(golden_dir, "coinrun_seeding.npz"))
+    g = np.load(os.path.join(golden_dir, f"{game}_seeding.npz"))
     frames = {}
     for lvl in (0, 1):
-        env = make_env(1, num_levels=1, start_level=lvl, rand_seed=5)
+        env = make_env(1, game, num_levels=1, start_level=lvl, rand_seed=5)
         env.act(np.zeros(1, np.int32))
         _, ob, _ = env.observe()
         frames[lvl] = ob["rgb"][0].copy()
@@ -63,11 +69,12 @@ def test_seeding_protocol(golden_dir):
     assert not np.array_equal(frames[0], frames[1])
 
 
-def test_determinism_protocol():
+@pytest.mark.parametrize("game", GAMES)
+def test_determinism_protocol(game):
     """reference procgen/env_test.py:33-52: two fresh runs give identical observation sequences."""
     acts = action_stream(2, 128)
-    a = rollout(make_env(2), acts, keep_frames=True)
-    b = rollout(make_env(2), acts, keep_frames=True)
+    a = rollout(make_env(2, game), acts, keep_frames=True)
+    b = rollout(make_env(2, game), acts, keep_frames=True)
     assert np.array_equal(a["frames"], b["frames"])
 
 
@@ -138,3 +145,13 @@ def test_entity_table_overflow_routing():
     a = rollout(oracle_env.OracleEnv(n, "coinrun", rand_seed=99), acts)
     b = rollout(make_env(n, rand_seed=99), acts)
     assert_rollouts_equal(a, b, "long rollout")
+
+
+def test_bigfish_full_size_prefix_matches_oracle():
+    """BASELINE configs[2] (bigfish, 65536 envs): the first 128 envs equal a 128-env oracle run."""
+    n, steps, m = 65536, 10, 128
+    acts = action_stream(n, steps, seed=5)
+    big = rollout(make_env(n, "bigfish", extra_options={"host_observations": True}), acts)
+    small = rollout(oracle_env.OracleEnv(m, "bigfish", rand_seed=23), [a[:m] for a in acts])
+    for k in small:
+        assert np.array_equal(big[k][:, :m], small[k]), k

@@ -11,12 +11,12 @@ import oracle_env
 from helpers import action_stream, assert_rollouts_equal, rollout
 
 
-@pytest.mark.parametrize("use_small", [True, False])
-def test_emulated_kernels_match_oracle(use_small):
+@pytest.mark.parametrize("game,use_small", [("coinrun", True), ("coinrun", False), ("bigfish", True)])
+def test_emulated_kernels_match_oracle(game, use_small):
     n, steps = 24, 260
     acts = action_stream(n, steps)
-    orc = oracle_env.OracleEnv(n, "coinrun", rand_seed=23)
-    emu = emu_harness.EmuEnv(n, "coinrun", rand_seed=23, use_small=use_small)
+    orc = oracle_env.OracleEnv(n, game, rand_seed=23)
+    emu = emu_harness.EmuEnv(n, game, rand_seed=23, use_small=use_small)
     for t in range(steps + 1):
         r1, o1, f1 = orc.observe()
         r2, o2, f2 = emu.observe()

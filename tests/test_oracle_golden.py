@@ -14,14 +14,19 @@ import oracle_env
 from helpers import assert_rollouts_equal, rollout
 
 
-@pytest.fixture(scope="module")
-def gold(golden_dir):
-    return np.load(os.path.join(golden_dir, "coinrun_rollout.npz"))
+GAMES = ["coinrun", "bigfish"]
+
+
+@pytest.fixture(scope="module", params=GAMES)
+def gold(request, golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, f"{request.param}_rollout.npz")))
+    g["game"] = request.param
+    return g
 
 
 def test_oracle_matches_reference_rollout(gold):
     n = gold["actions"].shape[1]
-    env = oracle_env.OracleEnv(n, "coinrun", rand_seed=23)
+    env = oracle_env.OracleEnv(n, gold["game"], rand_seed=23)
     actions = list(gold["actions"][:-1])
     got = rollout(env, actions, keep_frames=True)
     ref = {k: gold[k] for k in ("rew", "first", "prev_level_seed", "prev_level_complete", "level_seed", "crc")}
@@ -36,8 +41,8 @@ def test_oracle_matches_reference_rollout(gold):
 def test_oracle_entity_tables_match_reference_state(gold):
     """Entity table / grid parsed from the reference's get_state bytes at a few checkpoints."""
     n = gold["actions"].shape[1]
-    env = oracle_env.OracleEnv(n, "coinrun", rand_seed=23)
-    checkpoints = sorted({int(k.split("_")[0][5:]) for k in gold.files if k.startswith("state")})
+    env = oracle_env.OracleEnv(n, gold["game"], rand_seed=23)
+    checkpoints = sorted({int(k.split("_")[0][5:]) for k in gold if k.startswith("state")})
     t = 0
     for cp in checkpoints:
         while t < cp:
@@ -52,12 +57,13 @@ def test_oracle_entity_tables_match_reference_state(gold):
             assert mine[0] == sc[0] and mine[2] == sc[1] and mine[3] == sc[2] and mine[4] == sc[3], f"scalars of env {e} at step {cp}"
 
 
-def test_oracle_seeding_protocol(golden_dir):
+@pytest.mark.parametrize("game", GAMES)
+def test_oracle_seeding_protocol(golden_dir, game):
     """reference procgen/env_test.py:7-30: same start_level -> same frame, different level -> different frame."""
-    g = np.load(os.path.join(golden_dir, "coinrun_seeding.npz"))
+    g = np.load(os.path.join(golden_dir, f"{game}_seeding.npz"))
     frames = {}
     for lvl in (0, 1):
-        env = oracle_env.OracleEnv(1, "coinrun", num_levels=1, start_level=lvl, rand_seed=5)
+        env = oracle_env.OracleEnv(1, game, num_levels=1, start_level=lvl, rand_seed=5)
         env.act(np.zeros(1, np.int32))
         _, ob, _ = env.observe()
         frames[lvl] = ob["rgb"][0].copy()
