@@ -139,7 +139,7 @@ def main():
         value = total_steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
         line = {
-            "metric": "env steps/sec (whole node), coinrun num_envs=65536 random actions",
+            "metric": f"env steps/sec (whole node), {args.game} num_envs={n} random actions",
             "value": round(value, 1), "unit": "env steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+i32 game state, u8 pixels", "data": "synthetic (uniform random actions, procedurally generated levels)",

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(64) void step_big(DevCtx d, int mode) {
     const int count = *d.big_count;
     for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
         const int env = d.big_list[k];
+        if (!d.hdr[env].big) continue;  // set_state replaced this env with a small one after the list was built
         Env<Game, Game::ENT_CAP_BIG> e(d, env, &lds);
         e.run(mode);
         __syncthreads();
@@ -38,10 +39,10 @@ __global__ __launch_bounds__(64) void step_big(DevCtx d, int mode) {
 }
 
 template <class Game>
-__global__ __launch_bounds__(256) void render(DevCtx d) {
+__global__ __launch_bounds__(256) void render(DevCtx d, int env_base) {
     __shared__ uint32_t fb[NUM_BANDS][BAND_ROWS * RES_W];
     const int band = (int)(threadIdx.x >> 6);
-    Renderer<Game> r(d, (int)blockIdx.x, band, fb[band]);
+    Renderer<Game> r(d, env_base + (int)blockIdx.x, band, fb[band]);
     r.render_band();
 }
 
@@ -64,7 +65,7 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         hipError_t e = hipStreamWaitEvent(ls.main, ls.join, 0);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(256), 0, ls.main, d);
+    hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(256), 0, ls.main, d, 0);
     return hipGetLastError();
 }
 
@@ -78,6 +79,19 @@ hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStrea
     }
 }
 
+// re-renders one env (after set_state)
+hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream) {
+    switch (game_id) {
+#define PG_X(Game)                                                                       \
+    case Game::GAME_ID:                                                                  \
+        hipLaunchKernelGGL(render<Game>, dim3(1), dim3(256), 0, stream, d, env);         \
+        return hipGetLastError();
+        PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
+        default: return hipErrorInvalidValue;
+    }
+}
+
 bool game_supported(int game_id) {
     switch (game_id) {
 #define PG_X(Game) \
@@ -85,6 +99,16 @@ bool game_supported(int game_id) {
         PG_FOR_EACH_GAME(PG_X)
 #undef PG_X
         default: return false;
+    }
+}
+
+int game_small_cap(int game_id) {
+    switch (game_id) {
+#define PG_X(Game) \
+    case Game::GAME_ID: return Game::ENT_CAP_SMALL;
+        PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
+        default: return 0;
     }
 }
 

@@ -19,6 +19,7 @@
 #include "../../include/procgen_amd.h"
 #include "assets.h"
 #include "kernels.h"
+#include "state_io.h"
 
 using namespace pgamd;
 
@@ -140,6 +141,10 @@ struct VecGame {
     void launch(int mode);
     void act();
     void observe();
+    int get_state(int env_idx, char *data, int length);
+    void set_state(int env_idx, const char *data, int length);
+    void snapshot(int env_idx, EnvSnapshot *s);
+    int env_offset = 0;
 };
 
 VecGame::VecGame(int nenvs, VecOptions opts) {
@@ -158,7 +163,7 @@ VecGame::VecGame(int nenvs, VecOptions opts) {
     opts.consume_string("resource_root", &resource_root);
     opts.consume_bool("render_human", &render_human);
     // extension options of this library (include/procgen_amd.h)
-    int env_offset = 0;
+    env_offset = 0;
     device_id = -1;
     opts.consume_int("device_id", &device_id);
     opts.consume_int("env_offset", &env_offset);
@@ -413,6 +418,70 @@ void VecGame::observe() {  // reference src/vecgame.cpp:363-376,416-435
         for (size_t e = 0; e < N; e++) memcpy(ob_ptr[e], h_obs_stage + e * OBS_BYTES, OBS_BYTES);
 }
 
+void VecGame::snapshot(int e, EnvSnapshot *s) {
+    s->ent_cap = d.ent_cap;
+    s->ents.resize((size_t)EF_COUNT * d.ent_cap);
+    s->rng.resize(2 * MT_STRIDE);
+    s->grid.resize(d.grid_bytes);
+    HIP_CHECK(hipMemcpy(&s->hdr, d.hdr + e, sizeof(EnvHdr), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(s->ents.data(), d.ents + (size_t)e * EF_COUNT * d.ent_cap, s->ents.size() * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(s->rng.data(), d.rng + (size_t)e * 2 * MT_STRIDE, s->rng.size() * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(s->grid.data(), d.grid + (size_t)e * d.grid_bytes, s->grid.size(), hipMemcpyDeviceToHost));
+}
+
+int VecGame::get_state(int e, char *data, int length) {  // reference src/vecgame.cpp:438-445
+    if (!buffers_set) fatal("get_state called before libenv_set_buffers\n");
+    if (e < 0 || e >= num_envs) fatal("get_state: env index %d out of range\n", e);
+    observe();  // wait_for_stepping_threads()
+    EnvSnapshot s;
+    snapshot(e, &s);
+    int written = 0;
+    std::string err;
+    if (!serialize_state(game_id, d.opt, env_offset + e, s, data, length, &written, &err)) fatal("%s\n", err.c_str());
+    return written;
+}
+
+void VecGame::set_state(int e, const char *data, int length) {  // reference src/vecgame.cpp:447-456
+    if (!buffers_set) fatal("set_state called before libenv_set_buffers\n");
+    if (e < 0 || e >= num_envs) fatal("set_state: env index %d out of range\n", e);
+    observe();
+    EnvSnapshot s;
+    snapshot(e, &s);  // fields the wire format does not carry keep their current values
+    const int was_big = s.hdr.big;
+    std::string err;
+    if (!deserialize_state(game_id, d.opt, &s, data, length, &err)) fatal("%s\n", err.c_str());
+    // routing between the two step kernels: conservative bound (a step at most doubles the table)
+    s.hdr.big = (2 * s.hdr.n_ents + 2 > game_small_cap(game_id) - 1) ? 1 : 0;
+    HIP_CHECK(hipMemcpy(d.ents + (size_t)e * EF_COUNT * d.ent_cap, s.ents.data(), s.ents.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.rng + (size_t)e * 2 * MT_STRIDE, s.rng.data(), s.rng.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.grid + (size_t)e * d.grid_bytes, s.grid.data(), s.grid.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.hdr + e, &s.hdr, sizeof(EnvHdr), hipMemcpyHostToDevice));
+    if (s.hdr.big && !was_big) {  // append to the list the next step's large kernel will walk
+        const int cur = (int)(step_count & 1);
+        int count = 0;
+        HIP_CHECK(hipMemcpy(&count, d_big_count[cur], sizeof(int), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(d_big_list[cur] + count, &e, sizeof(int), hipMemcpyHostToDevice));
+        count++;
+        HIP_CHECK(hipMemcpy(d_big_count[cur], &count, sizeof(int), hipMemcpyHostToDevice));
+    }
+    // Game::observe(): refresh this env's observation / reward / first / info (reference src/vecgame.cpp:453-455)
+    const uint8_t first = (uint8_t)s.hdr.done, plc = (uint8_t)s.hdr.level_complete;
+    HIP_CHECK(hipMemcpy(d.rew + e, &s.hdr.reward, 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.first + e, &first, 1, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.prev_level_seed + e, &s.hdr.prev_level_seed, 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.prev_level_complete + e, &plc, 1, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.level_seed + e, &s.hdr.current_level_seed, 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemsetAsync(d.error, 0, sizeof(int), stream));
+    HIP_CHECK(launch_render_one(game_id, d, e, stream));
+    HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
+    if (host_observations) {
+        void *dst = ob_contig ? ob_ptr[0] : (void *)h_obs_stage;
+        HIP_CHECK(hipMemcpyAsync(dst, d.obs, (size_t)num_envs * OBS_BYTES, hipMemcpyDeviceToHost, stream));
+    }
+    pending = true;
+    observe();
+}
+
 }  // namespace
 
 extern "C" {
@@ -440,9 +509,9 @@ LIBENV_API void libenv_observe(libenv_env *handle) { ((VecGame *)handle)->observ
 LIBENV_API void libenv_act(libenv_env *handle) { ((VecGame *)handle)->act(); }
 LIBENV_API void libenv_close(libenv_env *handle) { delete (VecGame *)handle; }
 
-// reference src/vecgame.cpp:437-457 -- the reference's wire format is a "next" row.
-LIBENV_API int get_state(libenv_env *, int, char *, int) { fatal("get_state is not provided by the HIP stepper yet\n"); }
-LIBENV_API void set_state(libenv_env *, int, char *, int) { fatal("set_state is not provided by the HIP stepper yet\n"); }
+// reference src/vecgame.cpp:437-457 (wire format: state_io.cpp)
+LIBENV_API int get_state(libenv_env *handle, int env_idx, char *data, int length) { return ((VecGame *)handle)->get_state(env_idx, data, length); }
+LIBENV_API void set_state(libenv_env *handle, int env_idx, char *data, int length) { ((VecGame *)handle)->set_state(env_idx, data, length); }
 
 // ---- extension hooks (include/procgen_amd.h) -------------------------------------------------------------
 LIBENV_API int procgen_amd_device_buffers(libenv_env *handle, struct procgen_amd_buffers *out) {

@@ -1,0 +1,377 @@
+#include "state_io.h"
+
+#include <cstring>
+#include <sstream>
+
+#include "assets.h"
+#include "host_state.h"
+
+namespace pgamd {
+
+namespace {
+
+constexpr int32_t END_OF_BUFFER = (int32_t)0xCAFECAFE;  // reference src/vecgame.cpp:6
+
+// EF_META packing (pg_env.h)
+constexpr uint32_t M_TYPE_MASK = 0x3ffu;
+constexpr int M_IMG_SHIFT = 10, M_THEME_SHIFT = 18, M_Z_SHIFT = 22;
+constexpr uint32_t MF_WILL_ERASE = 1u << 24, MF_COLLIDES = 1u << 25, MF_REFLECTED = 1u << 26, MF_ABS_COORDS = 1u << 27, MF_SMART_STEP = 1u << 28,
+                   MF_AVOIDS = 1u << 29, MF_AUTO_ERASE = 1u << 30;
+
+struct Writer {  // reference src/buffer.h WriteBuffer
+    char *data;
+    size_t offset = 0, length;
+    bool ok = true;
+    void raw(const void *p, size_t n) {
+        if (offset + n > length) {
+            ok = false;
+            return;
+        }
+        memcpy(data + offset, p, n);
+        offset += n;
+    }
+    void i(int32_t v) { raw(&v, 4); }
+    void f(float v) { raw(&v, 4); }
+    void s(const std::string &v) {
+        i((int32_t)v.size());
+        raw(v.data(), v.size());
+    }
+};
+struct Reader {  // reference src/buffer.h ReadBuffer
+    const char *data;
+    size_t offset = 0, length;
+    bool ok = true;
+    void raw(void *p, size_t n) {
+        if (offset + n > length) {
+            ok = false;
+            memset(p, 0, n);
+            return;
+        }
+        memcpy(p, data + offset, n);
+        offset += n;
+    }
+    int32_t i() {
+        int32_t v;
+        raw(&v, 4);
+        return v;
+    }
+    float f() {
+        float v;
+        raw(&v, 4);
+        return v;
+    }
+    std::string s() {
+        int32_t n = i();
+        if (!ok || n < 0 || offset + (size_t)n > length) {
+            ok = false;
+            return std::string();
+        }
+        std::string v(data + offset, (size_t)n);
+        offset += (size_t)n;
+        return v;
+    }
+};
+
+uint32_t hash_str_uint32(const std::string &str) {  // reference src/vecgame.cpp:156-167
+    uint32_t hash = 0x811c9dc5u;
+    for (unsigned char c : str) {
+        hash ^= c;
+        hash *= 0x1000193u;
+    }
+    return hash;
+}
+
+// RandGen::serialize reference src/randgen.cpp:100-107: is_seeded, then the iostream text of std::mt19937
+// (libstdc++ operator<<: the 624 state words and the position, separated by single spaces)
+void write_rng(Writer &w, bool seeded, const uint32_t *mt, int idx) {
+    w.i(seeded ? 1 : 0);
+    std::string txt;
+    txt.reserve(MT_N * 11 + 8);
+    char buf[16];
+    for (int k = 0; k < MT_N; k++) {
+        int n = snprintf(buf, sizeof buf, "%u ", mt[k]);
+        txt.append(buf, (size_t)n);
+    }
+    int n = snprintf(buf, sizeof buf, "%d", idx);
+    txt.append(buf, (size_t)n);
+    w.s(txt);
+}
+bool read_rng(Reader &r, int *seeded, uint32_t *mt, int *idx) {
+    *seeded = r.i();
+    std::string txt = r.s();
+    if (!r.ok) return false;
+    std::istringstream is(txt);
+    for (int k = 0; k < MT_N; k++) {
+        unsigned long long v;
+        if (!(is >> v)) return false;
+        mt[k] = (uint32_t)v;
+    }
+    long long p;
+    if (!(is >> p)) return false;
+    *idx = (int)p;
+    return true;
+}
+
+bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h) {
+    if (game_id == GAME_BIGFISH) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64
+    return opt.center_agent != 0;
+}
+
+}  // namespace
+
+bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvSnapshot &s, char *data, int length, int *written, std::string *err) {
+    Writer w{data, 0, (size_t)(length < 0 ? 0 : length)};
+    const EnvHdr &h = s.hdr;
+    const std::string name = game_name_from_id(game_id);
+    // Game::serialize reference src/game.cpp:170-229
+    w.i(0);  // SERIALIZE_VERSION
+    w.s(name);
+    w.i(opt.paint_vel_info);
+    w.i(opt.use_generated_assets);
+    w.i(opt.use_monochrome_assets);
+    w.i(opt.restrict_themes);
+    w.i(opt.use_backgrounds);
+    w.i(effective_center_agent(game_id, opt, h) ? 1 : 0);
+    w.i(opt.debug_mode);
+    w.i(opt.distribution_mode);
+    w.i(opt.use_sequential_levels);
+    w.i(0);  // use_easy_jump
+    w.i(0);  // plain_assets
+    w.i(0);  // physics_mode
+    w.i(h.grid_step);
+    w.i(opt.level_seed_low);
+    w.i(opt.level_seed_high);
+    w.i(0);  // game_type
+    w.i(game_n);
+    write_rng(w, true, s.rng.data() + MT_STRIDE, h.lvl_rand_idx);  // level_seed_rand_gen
+    write_rng(w, h.initial_reset_complete != 0, s.rng.data(), h.rand_idx);
+    w.f(h.reward);
+    w.i(h.done);
+    w.i(h.level_complete);
+    w.i(h.action);
+    w.i(h.timeout);
+    w.i(h.current_level_seed);
+    w.i(h.prev_level_seed);
+    w.i(h.episodes_remaining);
+    w.i(h.episode_done);
+    w.i(h.last_reward_timer);
+    w.f(h.last_reward);
+    w.i(h.default_action);
+    w.i((int32_t)hash_str_uint32(name));  // fixed_asset_seed, reference src/vecgame.cpp:324-327
+    w.i(h.cur_time);
+    w.i(0);  // is_waiting_for_step
+    // BasicAbstractGame::serialize BAG:1169-1223
+    w.i(h.main_width * h.main_height);  // grid_size
+    w.i(h.n_ents);
+    const int cap = s.ent_cap;
+    auto W = [&](int f, int i) { return s.ents[(size_t)f * cap + i]; };
+    for (int i = 0; i < h.n_ents; i++) {  // Entity::serialize reference src/entity.cpp:90-137
+        const uint32_t m = W(EF_META, i);
+        auto wf = [&](int f) {
+            uint32_t v = W(f, i);
+            w.raw(&v, 4);
+        };
+        wf(EF_X); wf(EF_Y); wf(EF_VX); wf(EF_VY); wf(EF_RX); wf(EF_RY);
+        w.i((int32_t)(m & M_TYPE_MASK));
+        w.i((int32_t)((m >> M_IMG_SHIFT) & 0xffu));
+        w.i((int32_t)((m >> M_THEME_SHIFT) & 0xfu));
+        w.i((int32_t)((m >> M_Z_SHIFT) & 3u) - 1);
+        w.i((m & MF_WILL_ERASE) != 0);
+        w.i((m & MF_COLLIDES) != 0);
+        wf(EF_COLLISION_MARGIN); wf(EF_ROTATION); wf(EF_VROT);
+        w.i((m & MF_REFLECTED) != 0);
+        wf(EF_FIRE_TIME); wf(EF_SPAWN_TIME); wf(EF_LIFE_TIME); wf(EF_EXPIRE_TIME);
+        w.i((m & MF_ABS_COORDS) != 0);
+        wf(EF_FRICTION);
+        w.i((m & MF_SMART_STEP) != 0);
+        w.i((m & MF_AVOIDS) != 0);
+        w.i((m & MF_AUTO_ERASE) != 0);
+        wf(EF_ALPHA); wf(EF_HEALTH); wf(EF_THETA); wf(EF_GROW_RATE); wf(EF_ALPHA_DECAY); wf(EF_CLIMBER_SPAWN_X);
+    }
+    w.i(0);  // use_procgen_background
+    w.i(h.background_index);
+    w.f(h.bg_tile_ratio);
+    w.f(h.bg_pct_x);
+    w.f(5.0f);  // char_dim, BAG:24
+    w.i(h.last_move_action);
+    w.i(h.move_action);
+    w.i(h.special_action);
+    w.f(h.mixrate);
+    w.f(h.maxspeed);
+    w.f(h.max_jump);
+    w.f(h.action_vx);
+    w.f(h.action_vy);
+    w.f(h.action_vrot);
+    w.f(h.center_x);
+    w.f(h.center_y);
+    w.i(h.random_agent_start);
+    w.i(h.has_useful_vel_info);
+    w.i(h.step_rand_int);
+    {   // asset_rand_gen is never seeded on the PNG-asset path: is_seeded = 0 + the default-constructed mt19937 (seed 5489)
+        HostMT def;
+        def.seed(5489);
+        write_rng(w, false, def.mt, def.idx);
+    }
+    w.i(h.main_width);
+    w.i(h.main_height);
+    w.i(h.out_of_bounds_object);
+    w.f(h.unit);
+    w.f(h.view_dim);
+    w.f(h.x_off);
+    w.f(h.y_off);
+    w.f(h.visibility);
+    w.f(h.min_visibility);
+    w.i(h.main_width);  // Grid::serialize reference src/grid.h:69-73
+    w.i(h.main_height);
+    const int cells = h.main_width * h.main_height;
+    w.i(cells);
+    for (int c = 0; c < cells; c++) w.i((int32_t)s.grid[c]);
+    // game tails
+    if (game_id == GAME_COINRUN) {  // reference src/games/coinrun.cpp:500-509
+        w.f(h.gsf0);
+        w.i(h.gsi0);
+        w.i(h.gsi1 ? 1 : 0);
+        w.i(h.gsi2 ? 1 : 0);
+        w.i(h.gsi3 ? 1 : 0);
+        w.f(h.gsf1);
+        w.f(h.gsf2);
+    } else if (game_id == GAME_BIGFISH) {  // reference src/games/bigfish.cpp:109-113
+        w.i(h.gsi0);
+        w.f(h.gsf0);
+    }
+    w.i(END_OF_BUFFER);
+    if (!w.ok) {
+        if (err) *err = "fassert failed 'offset + sizeof(int) <= length' (state buffer too small)";
+        return false;
+    }
+    *written = (int)w.offset;
+    return true;
+}
+
+bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, const char *data, int length, std::string *err) {
+    Reader r{data, 0, (size_t)(length < 0 ? 0 : length)};
+    EnvHdr &h = s->hdr;
+    auto bad = [&](const char *what) {
+        if (err) *err = what;
+        return false;
+    };
+    if (r.i() != 0) return bad("fassert failed 'SERIALIZE_VERSION == b->read_int()'");
+    if (r.s() != game_name_from_id(game_id)) return bad("fassert failed 'game_name == b->read_string()'");
+    // options are per-handle here (one GameOptions for every env of a handle); a state saved under other options is refused
+    int o[9];
+    for (int k = 0; k < 9; k++) o[k] = r.i();
+    const bool cen = o[5] != 0;
+    if (o[0] != opt.paint_vel_info || o[1] != opt.use_generated_assets || o[2] != opt.use_monochrome_assets || o[3] != opt.restrict_themes ||
+        o[4] != opt.use_backgrounds || o[6] != opt.debug_mode || o[7] != opt.distribution_mode || o[8] != opt.use_sequential_levels)
+        return bad("set_state: the state was saved under different game options than this handle's");
+    (void)cen;
+    r.i();  // use_easy_jump
+    r.i();  // plain_assets
+    r.i();  // physics_mode
+    h.grid_step = r.i();
+    const int lo = r.i(), hi = r.i();
+    if (lo != opt.level_seed_low || hi != opt.level_seed_high) return bad("set_state: the state was saved under a different num_levels/start_level");
+    r.i();  // game_type
+    r.i();  // game_n
+    int seeded;
+    if (!read_rng(r, &seeded, s->rng.data() + MT_STRIDE, &h.lvl_rand_idx)) return bad("set_state: malformed level_seed_rand_gen");
+    if (!read_rng(r, &seeded, s->rng.data(), &h.rand_idx)) return bad("set_state: malformed rand_gen");
+    h.initial_reset_complete = 1;
+    h.reward = r.f();
+    h.done = r.i();
+    h.level_complete = r.i();
+    h.action = r.i();
+    h.timeout = r.i();
+    h.current_level_seed = r.i();
+    h.prev_level_seed = r.i();
+    h.episodes_remaining = r.i();
+    h.episode_done = r.i();
+    h.last_reward_timer = r.i();
+    h.last_reward = r.f();
+    h.default_action = r.i();
+    r.i();  // fixed_asset_seed
+    h.cur_time = r.i();
+    r.i();  // is_waiting_for_step
+    r.i();  // grid_size
+    const int n = r.i();
+    const int cap = s->ent_cap;
+    if (!r.ok || n < 0 || n > cap - 1) return bad("set_state: entity count exceeds the table capacity");
+    h.n_ents = n;
+    h.agent = -1;
+    auto W = [&](int f, int i) -> uint32_t & { return s->ents[(size_t)f * cap + i]; };
+    for (int i = 0; i < n; i++) {
+        auto rf = [&](int f) { r.raw(&W(f, i), 4); };
+        rf(EF_X); rf(EF_Y); rf(EF_VX); rf(EF_VY); rf(EF_RX); rf(EF_RY);
+        const int type = r.i(), image_type = r.i(), image_theme = r.i(), render_z = r.i();
+        uint32_t m = ((uint32_t)type & M_TYPE_MASK) | (((uint32_t)image_type & 0xffu) << M_IMG_SHIFT) | (((uint32_t)image_theme & 0xfu) << M_THEME_SHIFT) |
+                     (((uint32_t)(render_z + 1) & 3u) << M_Z_SHIFT);
+        if (r.i()) m |= MF_WILL_ERASE;
+        if (r.i()) m |= MF_COLLIDES;
+        rf(EF_COLLISION_MARGIN); rf(EF_ROTATION); rf(EF_VROT);
+        if (r.i()) m |= MF_REFLECTED;
+        rf(EF_FIRE_TIME); rf(EF_SPAWN_TIME); rf(EF_LIFE_TIME); rf(EF_EXPIRE_TIME);
+        if (r.i()) m |= MF_ABS_COORDS;
+        rf(EF_FRICTION);
+        if (r.i()) m |= MF_SMART_STEP;
+        if (r.i()) m |= MF_AVOIDS;
+        if (r.i()) m |= MF_AUTO_ERASE;
+        rf(EF_ALPHA); rf(EF_HEALTH); rf(EF_THETA); rf(EF_GROW_RATE); rf(EF_ALPHA_DECAY); rf(EF_CLIMBER_SPAWN_X);
+        W(EF_META, i) = m;
+        if (type == PLAYER) h.agent = i;  // find_entity_index returns the LAST match, BAG:1133-1143
+    }
+    if (h.agent < 0) return bad("fassert failed 'agent_idx >= 0'");
+    r.i();  // use_procgen_background
+    h.background_index = r.i();
+    h.bg_tile_ratio = r.f();
+    h.bg_pct_x = r.f();
+    r.f();  // char_dim
+    h.last_move_action = r.i();
+    h.move_action = r.i();
+    h.special_action = r.i();
+    h.mixrate = r.f();
+    h.maxspeed = r.f();
+    h.max_jump = r.f();
+    h.action_vx = r.f();
+    h.action_vy = r.f();
+    h.action_vrot = r.f();
+    h.center_x = r.f();
+    h.center_y = r.f();
+    h.random_agent_start = r.i();
+    h.has_useful_vel_info = r.i();
+    h.step_rand_int = r.i();
+    {
+        uint32_t tmp[MT_N];
+        int idx;
+        if (!read_rng(r, &seeded, tmp, &idx)) return bad("set_state: malformed asset_rand_gen");
+    }
+    h.main_width = r.i();
+    h.main_height = r.i();
+    h.out_of_bounds_object = r.i();
+    h.unit = r.f();
+    h.view_dim = r.f();
+    h.x_off = r.f();
+    h.y_off = r.f();
+    h.visibility = r.f();
+    h.min_visibility = r.f();
+    const int gw = r.i(), gh = r.i(), cnt = r.i();
+    if (!r.ok || gw != h.main_width || gh != h.main_height || cnt != gw * gh || (size_t)cnt > s->grid.size()) return bad("set_state: malformed grid");
+    for (int c = 0; c < cnt; c++) s->grid[c] = (uint8_t)r.i();
+    if (game_id == GAME_COINRUN) {
+        h.gsf0 = r.f();
+        h.gsi0 = r.i();
+        h.gsi1 = r.i() > 0;
+        h.gsi2 = r.i() > 0;
+        h.gsi3 = r.i() > 0;
+        h.gsf1 = r.f();
+        h.gsf2 = r.f();
+    } else if (game_id == GAME_BIGFISH) {
+        h.gsi0 = r.i();
+        h.gsf0 = r.f();
+    }
+    if (r.i() != END_OF_BUFFER || !r.ok) return bad("fassert failed 'b.read_int() == END_OF_BUFFER'");
+    h.error = 0;
+    h.grid_dirty = 0;
+    return true;
+}
+
+}  // namespace pgamd

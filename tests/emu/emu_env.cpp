@@ -13,6 +13,7 @@
 #include "games.h"
 #include "pg_render.h"
 #include "host_state.h"
+#include "state_io.h"
 
 using namespace pgamd;
 
@@ -153,6 +154,58 @@ void emu_observe(void *h, uint8_t *rgb, float *rew, uint8_t *first, int32_t *pls
     memcpy(pls, v->pls.data(), 4 * v->n);
     memcpy(plc, v->plc.data(), v->n);
     memcpy(ls, v->ls.data(), 4 * v->n);
+}
+static void emu_snapshot(EmuVec *v, int env, EnvSnapshot *s) {
+    const int cap = v->d.ent_cap;
+    s->hdr = v->hdr[env];
+    s->ent_cap = cap;
+    s->ents.assign(v->ents.begin() + (size_t)env * EF_COUNT * cap, v->ents.begin() + (size_t)(env + 1) * EF_COUNT * cap);
+    s->rng.assign(v->rng.begin() + (size_t)env * 2 * MT_STRIDE, v->rng.begin() + (size_t)(env + 1) * 2 * MT_STRIDE);
+    s->grid.assign(v->grid.begin() + (size_t)env * v->d.grid_bytes, v->grid.begin() + (size_t)(env + 1) * v->d.grid_bytes);
+}
+// the product's state_io.cpp on the emulated state: same wire format code as libenv.so's get_state / set_state
+int emu_get_state(void *h, int env, char *data, int length) {
+    EmuVec *v = (EmuVec *)h;
+    EnvSnapshot s;
+    emu_snapshot(v, env, &s);
+    int written = 0;
+    std::string err;
+    if (!serialize_state(v->game_id, v->d.opt, env, s, data, length, &written, &err)) {
+        fprintf(stderr, "emu_get_state: %s\n", err.c_str());
+        return -1;
+    }
+    return written;
+}
+int emu_set_state(void *h, int env, const char *data, int length) {
+    EmuVec *v = (EmuVec *)h;
+    EnvSnapshot s;
+    emu_snapshot(v, env, &s);
+    std::string err;
+    if (!deserialize_state(v->game_id, v->d.opt, &s, data, length, &err)) {
+        fprintf(stderr, "emu_set_state: %s\n", err.c_str());
+        return -1;
+    }
+    s.hdr.big = 1;  // the emulation picks the arena from this flag alone; the large arena is always safe
+    const int cap = v->d.ent_cap;
+    v->hdr[env] = s.hdr;
+    std::copy(s.ents.begin(), s.ents.end(), v->ents.begin() + (size_t)env * EF_COUNT * cap);
+    std::copy(s.rng.begin(), s.rng.end(), v->rng.begin() + (size_t)env * 2 * MT_STRIDE);
+    std::copy(s.grid.begin(), s.grid.end(), v->grid.begin() + (size_t)env * v->d.grid_bytes);
+    v->rew[env] = s.hdr.reward;
+    v->first[env] = (uint8_t)s.hdr.done;
+    v->pls[env] = s.hdr.prev_level_seed;
+    v->plc[env] = (uint8_t)s.hdr.level_complete;
+    v->ls[env] = s.hdr.current_level_seed;
+    static uint32_t fb[NUM_BANDS][BAND_ROWS * RES_W];
+#define PG_X(Game)                                    \
+    if (v->game_id == Game::GAME_ID)                  \
+        for (int b = 0; b < NUM_BANDS; b++) {         \
+            Renderer<Game> r(v->d, env, b, fb[b]);    \
+            r.render_band();                          \
+        }
+    PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
+    return 0;
 }
 int emu_error(void *h, int env) { return ((EmuVec *)h)->hdr[env].error | ((EmuVec *)h)->dev_error; }
 int emu_num_entities(void *h, int env) { return ((EmuVec *)h)->hdr[env].n_ents; }

@@ -15,7 +15,7 @@ CSRC = os.path.join(REPO, "procgen_amd", "csrc")
 
 
 def build(force=False):
-    srcs = [os.path.join(HERE, "emu_env.cpp"), os.path.join(CSRC, "assets.cpp"), os.path.join(CSRC, "image_io.cpp")]
+    srcs = [os.path.join(HERE, "emu_env.cpp"), os.path.join(CSRC, "assets.cpp"), os.path.join(CSRC, "image_io.cpp"), os.path.join(CSRC, "state_io.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return
@@ -39,6 +39,8 @@ def lib():
         L.emu_observe.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         for f in ("emu_error", "emu_num_entities", "emu_is_big"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_int]
+        L.emu_get_state.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+        L.emu_set_state.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
         L.emu_dump_entities.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_dump_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
@@ -94,6 +96,19 @@ class EmuEnv:
         w, h = C.c_int(), C.c_int()
         self.L.emu_dump_grid(self.h, env, out.ctypes.data, C.byref(w), C.byref(h))
         return out[: w.value * h.value].reshape(h.value, w.value)
+
+    def get_state(self):
+        buf = C.create_string_buffer(1 << 20)
+        out = []
+        for e in range(self.num):
+            n = self.L.emu_get_state(self.h, e, buf, 1 << 20)
+            assert n > 0
+            out.append(bytes(buf.raw[:n]))
+        return out
+
+    def set_state(self, states):
+        for e, st in enumerate(states):
+            assert self.L.emu_set_state(self.h, e, st, len(st)) == 0
 
     def is_big(self, env):
         return self.L.emu_is_big(self.h, env)

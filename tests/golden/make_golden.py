@@ -47,12 +47,18 @@ def rollout(game, n, t_steps, frame_every, state_at):
             frames.append(ob["rgb"][: min(n, 4)].copy())
             frame_t.append(t)
         if t in state_at:
-            sts = [state_parse.parse_state(s) for s in env.get_state()]
+            raw = env.get_state()
+            sts = [state_parse.parse_state(s) for s in raw]
             states[t] = sts
+            for e in range(min(n, 2)):
+                out.setdefault("_raw", {})[(t, e)] = np.frombuffer(raw[e], dtype=np.uint8).copy()
         ac = rng.randint(0, 15, size=(n,), dtype=np.int32)
         out["actions"].append(ac)
         env.act(ac)
+    raw_states = out.pop("_raw", {})
     res = {k: np.array(v) for k, v in out.items()}
+    for (t, e), b in raw_states.items():
+        res[f"state{t}_e{e}_bytes"] = b  # the reference's get_state byte stream, verbatim
     res["frames"] = np.array(frames)
     res["frame_t"] = np.array(frame_t)
     for t, sts in states.items():

@@ -155,3 +155,34 @@ def test_bigfish_full_size_prefix_matches_oracle():
     small = rollout(oracle_env.OracleEnv(m, "bigfish", rand_seed=23), [a[:m] for a in acts])
     for k in small:
         assert np.array_equal(big[k][:, :m], small[k]), k
+
+
+@pytest.mark.parametrize("game", GAMES)
+def test_state_protocol_through_the_c_abi(golden_dir, game):
+    """get_state / set_state of libenv.so: byte-identical to the reference's streams, and the reference's state restored
+    into an env with another rand_seed resumes the reference's rollout (reference procgen/state_test.py:71-124)."""
+    g = np.load(os.path.join(golden_dir, f"{game}_rollout.npz"))
+    n = g["actions"].shape[1]
+    env = make_env(n, game)
+    for t in range(100):
+        env.act(g["actions"][t])
+    sts = env.get_state()
+    for e in range(2):
+        assert sts[e] == bytes(g[f"state100_e{e}_bytes"]), f"env {e}"
+    env.close()
+    env2 = make_env(2, game, rand_seed=4242)
+    env2.set_state([bytes(g["state100_e0_bytes"]), bytes(g["state100_e1_bytes"])])
+    got = rollout(env2, [a[:2] for a in g["actions"][100:260]])
+    for k in ("rew", "first", "prev_level_seed", "prev_level_complete", "level_seed", "crc"):
+        assert np.array_equal(got[k], g[k][100:261, :2]), k
+    # save/restore every step is transparent
+    env3 = make_env(2, game, rand_seed=4242)
+    env3.set_state([bytes(g["state100_e0_bytes"]), bytes(g["state100_e1_bytes"])])
+    for t in range(100, 130):
+        st = env3.get_state()
+        env3.set_state(st)
+        env3.act(g["actions"][t][:2])
+    _, ob, _ = env3.observe()
+    import zlib
+
+    assert [zlib.crc32(ob["rgb"][e].tobytes()) for e in range(2)] == list(g["crc"][130, :2])
