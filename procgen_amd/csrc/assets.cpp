@@ -157,6 +157,13 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
         t.img[idx].off = (uint32_t)out->pixels.size();
         t.img[idx].w = (uint16_t)im.w;
         t.img[idx].h = (uint16_t)im.h;
+        bool opaque = true;
+        for (uint32_t px : im.px)
+            if ((px >> 24) != 0xffu) {
+                opaque = false;
+                break;
+            }
+        t.img[idx].opaque = opaque ? 1u : 0u;
         out->pixels.insert(out->pixels.end(), im.px.begin(), im.px.end());
         out->image_names.push_back(key);
         index[key] = idx;
@@ -170,6 +177,20 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
         }
         t.type_theme_img[s.type][s.theme] = (int16_t)idx;
         if (t.type_num_themes[s.type] < s.theme + 1) t.type_num_themes[s.type] = (uint8_t)(s.theme + 1);
+    }
+    {   // most common sprite size
+        std::map<std::pair<int, int>, int> hist;
+        for (auto &sp : sprites) {
+            const Image &im = imgs.images.at(sp.path);
+            hist[{im.w, im.h}]++;
+        }
+        int best = -1;
+        for (auto &kv : hist)
+            if (kv.second > best) {
+                best = kv.second;
+                t.ref_w = kv.first.first;
+                t.ref_h = kv.first.second;
+            }
     }
     t.n_bg = (int32_t)bgs.size();
     if (t.n_bg > MAX_BACKGROUNDS) {

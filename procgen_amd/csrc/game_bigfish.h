@@ -12,10 +12,9 @@ struct BigFish {
     typedef uint8_t cell_t;
     static constexpr int MAX_CELLS = 20 * 20;  // bigfish.cpp:29-30 (padded to a 16-byte multiple below)
     static constexpr bool USES_ENTITY_COLLISIONS = false;
-    static constexpr int ENT_CAP_SMALL = 64;   // <= 1 spawn per step; ~5-15 fish alive
-    static constexpr int ENT_CAP_BIG = 256;
+    static constexpr int ENT_CAP_T0 = 64, ENT_CAP_T1 = 128, ENT_CAP_T2 = 256;  // <= 1 spawn per step; ~5-15 fish alive
     template <class E>
-    PG_DEV static bool needs_big(E &e) { return e.G.n_ents + 1 + 2 > ENT_CAP_SMALL - 1; }
+    PG_DEV static int slots_needed_next_step(E &e) { return e.G.n_ents + 1 + 3; }
 
     static constexpr int FISH = 2;
     static constexpr float FISH_MIN_R = .25f, FISH_MAX_R = 2.0f;

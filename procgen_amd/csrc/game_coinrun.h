@@ -15,16 +15,18 @@ struct CoinRun {
     static constexpr int MAX_CELLS = 64 * 64;      // coinrun.cpp:54-55
     static constexpr bool USES_ENTITY_COLLISIONS = false;  // no entity sets collides_with_entities
     // Worst-case entity count: 5 pit sections x 7 walking enemies x (1 + 9 live trails) + agent = 351.
-    static constexpr int ENT_CAP_SMALL = 128;
-    static constexpr int ENT_CAP_BIG = 384;
+    // LDS entity-arena tiers of the step kernel (measured demand n + #ENEMY + 3: > 64 in 5.6 % of env-steps,
+    // > 128 in 0.5 %, max seen 154)
+    static constexpr int ENT_CAP_T0 = 64, ENT_CAP_T1 = 160, ENT_CAP_T2 = 384;
     // Per step the list grows by at most one trail per ENEMY (enemies are only created by a reset); a reset
-    // creates <= 42 entities.  So the small arena is safe next step iff n + #ENEMY fits.
+    // creates <= 42 entities.  One slot is reserved (detached agent).
     template <class E>
-    PG_DEV static bool needs_big(E &e) {
+    PG_DEV static int slots_needed_next_step(E &e) {
         const int n = e.G.n_ents;
         int enemies = 0;
         for (int c = 0; c < ((n + 63) >> 6); c++) enemies += pg_popc64(PG_BALLOT(l, ((c << 6) + l) < n && e.etype((c << 6) + l) == ENEMY));
-        return n + enemies + 2 > ENT_CAP_SMALL - 1;
+        const int need = n + enemies + 3;
+        return need < 46 ? 46 : need;
     }
 
     // object ids coinrun.cpp:11-31

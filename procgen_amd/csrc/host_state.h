@@ -35,7 +35,7 @@ struct HostMT {  // std::mt19937 (libstdc++ bits/random.tcc): seed, twist, tempe
     }
 };
 
-// Fills hdr[n] and rng[n][2][MT_STRIDE] for envs [env_offset, env_offset + num_envs) of the global index space.
+// Fills hdr[n] and rng[n][MT_SLOTS][MT_STRIDE] for envs [env_offset, env_offset + num_envs) of the global index space.
 template <class Game>
 inline void init_env_state(int num_envs, int rand_seed, int env_offset, EnvHdr *hdr, uint32_t *rng) {
     HostMT seedgen;
@@ -45,8 +45,8 @@ inline void init_env_state(int num_envs, int rand_seed, int env_offset, EnvHdr *
     Game::construct(proto);
     for (int n = 0; n < num_envs; n++) {
         hdr[n] = proto;
-        uint32_t *st = rng + (size_t)n * 2 * MT_STRIDE;
-        for (int k = 0; k < 2 * MT_STRIDE; k++) st[k] = 0;
+        uint32_t *st = rng + (size_t)n * MT_SLOTS * MT_STRIDE;
+        for (int k = 0; k < MT_SLOTS * MT_STRIDE; k++) st[k] = 0;
         HostMT lvl;
         lvl.seed((int)seedgen.next());  // games[n]->level_seed_rand_gen.seed(game_level_seed_gen.randint()), vecgame.cpp:314
         for (int k = 0; k < MT_N; k++) st[MT_STRIDE + k] = lvl.mt[k];

@@ -9,12 +9,15 @@ namespace pgamd {
 struct LaunchStreams {
     hipStream_t main, side;   // side: large-arena step kernel, concurrent with the small-arena one
     hipEvent_t fork, join;
+    hipStream_t lane[2];      // env chunks alternate between these two streams (step of chunk c+1 overlaps render of chunk c)
+    hipEvent_t lane_done[2];
+    int chunks;               // 1 = everything on `main`
 };
 // mode 0: initial reset + first observation of every env; mode 1: one step
 hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStreams &ls);
 hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream);
 bool game_supported(int game_id);
-int game_small_cap(int game_id);
+int game_tier_for(int game_id, int slots_needed);
 void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes);
 void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, EnvHdr *hdr, uint32_t *rng);
 }  // namespace pgamd

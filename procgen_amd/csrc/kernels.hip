@@ -1,11 +1,11 @@
 // kernels.hip -- gfx950 kernels of the vectorized stepper.  One workgroup = one 64-lane wavefront = one env.
 //
-//   step_small<Game> : grid = num_envs; LDS arena sized for Game::ENT_CAP_SMALL entities; skips envs routed to
-//                      the large kernel.
-//   step_big<Game>   : fixed grid that walks the list of envs whose entity table may exceed the small arena
-//                      (LDS arena for Game::ENT_CAP_BIG entities).
-//   render<Game>     : grid = num_envs, 256 threads: four band-waves per env rasterize 16 rows each into a 4 KB
-//                      LDS band and store the RGB888 observation (pg_render.h).
+//   step_tier0<Game> : grid = num_envs; LDS arena for Game::ENT_CAP_T0 entities (10 KB -> 16 workgroups / CU); skips
+//                      envs routed to a larger arena.
+//   step_list<Game,CAP,T> : fixed grids that walk the lists of envs whose entity table may outgrow the smaller
+//                      arenas (ENT_CAP_T1 / ENT_CAP_T2), on a side stream.
+//   render<Game>     : grid = num_envs, one wave per env: four passes of 16 rows through a 4 KB LDS band, RGB888
+//                      observation stores (pg_render.h).
 // The step kernels run Env<Game,CAP>::run (pg_env.h): HBM -> LDS staging, Game::step / reset + level generation,
 // state write-back.
 #include <hip/hip_runtime.h>
@@ -17,55 +17,78 @@
 namespace pgamd {
 
 template <class Game>
-__global__ __launch_bounds__(64) void step_small(DevCtx d, int mode) {
-    __shared__ Lds<Game, Game::ENT_CAP_SMALL> lds;
-    const int env = (int)blockIdx.x;
-    if (mode != 0 && d.hdr[env].big) return;
-    Env<Game, Game::ENT_CAP_SMALL> e(d, env, &lds);
+__global__ __launch_bounds__(64) void step_tier0(DevCtx d, int mode, int env_base) {
+    __shared__ Lds<Game, Game::ENT_CAP_T0> lds;
+    const int env = env_base + (int)blockIdx.x;
+    if (mode != 0 && d.hdr[env].big != 0) return;
+    Env<Game, Game::ENT_CAP_T0> e(d, env, &lds);
     e.run(mode);
 }
 
-template <class Game>
-__global__ __launch_bounds__(64) void step_big(DevCtx d, int mode) {
-    __shared__ Lds<Game, Game::ENT_CAP_BIG> lds;
-    const int count = *d.big_count;
+template <class Game, int CAP, int TIER>
+__global__ __launch_bounds__(64) void step_list(DevCtx d, int mode) {
+    __shared__ Lds<Game, CAP> lds;
+    const int count = d.big_count[TIER - 1];
+    const int *list = d.big_list + (size_t)(TIER - 1) * d.num_envs;
     for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
-        const int env = d.big_list[k];
-        if (!d.hdr[env].big) continue;  // set_state replaced this env with a small one after the list was built
-        Env<Game, Game::ENT_CAP_BIG> e(d, env, &lds);
+        const int env = list[k];
+        if (d.hdr[env].big != TIER) continue;  // set_state moved this env to another tier after the list was built
+        Env<Game, CAP> e(d, env, &lds);
         e.run(mode);
         __syncthreads();
     }
 }
 
 template <class Game>
-__global__ __launch_bounds__(256) void render(DevCtx d, int env_base) {
-    __shared__ uint32_t fb[NUM_BANDS][BAND_ROWS * RES_W];
-    const int band = (int)(threadIdx.x >> 6);
-    Renderer<Game> r(d, env_base + (int)blockIdx.x, band, fb[band]);
-    r.render_band();
+__global__ __launch_bounds__(64) void render(DevCtx d, int env_base) {
+    __shared__ uint32_t fb[BAND_ROWS * RES_W];
+    __shared__ uint32_t ax[128];
+    Renderer<Game> r(d, env_base + (int)blockIdx.x, fb, ax);
+    r.render_env();
 }
 
 // The two step kernels touch disjoint envs, so the (few, slow, low-occupancy) large-arena envs run on a side
-// stream concurrently with the small-arena grid; the render kernel joins both.
+// stream concurrently with the small-arena grid.  The env range is further cut into chunks that alternate between
+// two streams: the latency-bound step kernel of one chunk shares the CUs with the issue-bound render kernel of the
+// previous chunk instead of the two phases running back to back.
 template <class Game>
 static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls) {
+#define PG_TRY(x)                          \
+    do {                                   \
+        hipError_t e_ = (x);               \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+    PG_TRY(hipEventRecord(ls.fork, ls.main));
     if (mode != 0) {
-        hipError_t e = hipEventRecord(ls.fork, ls.main);
-        if (e != hipSuccess) return e;
-        e = hipStreamWaitEvent(ls.side, ls.fork, 0);
-        if (e != hipSuccess) return e;
-        int big_grid = d.num_envs < 4096 ? d.num_envs : 4096;
-        hipLaunchKernelGGL(step_big<Game>, dim3(big_grid), dim3(64), 0, ls.side, d, mode);
-        e = hipEventRecord(ls.join, ls.side);
-        if (e != hipSuccess) return e;
+        PG_TRY(hipStreamWaitEvent(ls.side, ls.fork, 0));
+        const int g1 = d.num_envs < 8192 ? d.num_envs : 8192, g2 = d.num_envs < 2048 ? d.num_envs : 2048;
+        // the two list kernels run on their own streams (lane[1] is otherwise idle when chunks == 1)
+        PG_TRY(hipStreamWaitEvent(ls.lane[1], ls.fork, 0));
+        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.side, d, mode);
+        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.lane[1], d, mode);
+        PG_TRY(hipEventRecord(ls.lane_done[1], ls.lane[1]));
+        PG_TRY(hipStreamWaitEvent(ls.side, ls.lane_done[1], 0));
+        PG_TRY(hipEventRecord(ls.join, ls.side));
     }
-    hipLaunchKernelGGL(step_small<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode);
-    if (mode != 0) {
-        hipError_t e = hipStreamWaitEvent(ls.main, ls.join, 0);
-        if (e != hipSuccess) return e;
+    const int nchunk = (ls.chunks > 1 && d.num_envs >= 4096) ? ls.chunks : 1;
+    const int per = (d.num_envs + nchunk - 1) / nchunk;
+    for (int c = 0; c < nchunk; c++) {
+        const int base = c * per;
+        const int count = (d.num_envs - base) < per ? (d.num_envs - base) : per;
+        if (count <= 0) break;
+        hipStream_t st = nchunk == 1 ? ls.main : ls.lane[c & 1];
+        if (nchunk > 1 && c < 2) PG_TRY(hipStreamWaitEvent(st, ls.fork, 0));
+        if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(count), dim3(64), 0, st, d, mode, base);
+        if (mode != 0) PG_TRY(hipStreamWaitEvent(st, ls.join, 0));
+        if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(count), dim3(64), 0, st, d, base);
     }
-    hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(256), 0, ls.main, d, 0);
+    if (nchunk > 1) {
+        for (int k = 0; k < 2; k++) {
+            PG_TRY(hipEventRecord(ls.lane_done[k], ls.lane[k]));
+            PG_TRY(hipStreamWaitEvent(ls.main, ls.lane_done[k], 0));
+        }
+    }
+#undef PG_TRY
     return hipGetLastError();
 }
 
@@ -84,7 +107,7 @@ hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t 
     switch (game_id) {
 #define PG_X(Game)                                                                       \
     case Game::GAME_ID:                                                                  \
-        hipLaunchKernelGGL(render<Game>, dim3(1), dim3(256), 0, stream, d, env);         \
+        hipLaunchKernelGGL(render<Game>, dim3(1), dim3(64), 0, stream, d, env);         \
         return hipGetLastError();
         PG_FOR_EACH_GAME(PG_X)
 #undef PG_X
@@ -102,10 +125,10 @@ bool game_supported(int game_id) {
     }
 }
 
-int game_small_cap(int game_id) {
+int game_tier_for(int game_id, int slots_needed) {
     switch (game_id) {
 #define PG_X(Game) \
-    case Game::GAME_ID: return Game::ENT_CAP_SMALL;
+    case Game::GAME_ID: return slots_needed <= Game::ENT_CAP_T0 ? 0 : (slots_needed <= Game::ENT_CAP_T1 ? 1 : 2);
         PG_FOR_EACH_GAME(PG_X)
 #undef PG_X
         default: return 0;
@@ -118,7 +141,7 @@ void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes) {
     switch (game_id) {
 #define PG_X(Game)                                                                        \
     case Game::GAME_ID:                                                                   \
-        *ent_cap_hbm = Game::ENT_CAP_BIG;                                                 \
+        *ent_cap_hbm = Game::ENT_CAP_T2;                                                  \
         *grid_bytes = (int)((Game::MAX_CELLS * sizeof(Game::cell_t) + 15) & ~(size_t)15); \
         break;
         PG_FOR_EACH_GAME(PG_X)

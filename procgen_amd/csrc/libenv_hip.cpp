@@ -111,7 +111,10 @@ struct VecGame {
     std::vector<libenv_tensortype> observation_types, action_types, info_types;
     hipStream_t stream = nullptr, side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    LaunchStreams streams() const { return LaunchStreams{stream, side_stream, ev_fork, ev_join}; }
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_lane[2] = {nullptr, nullptr};
+    int chunks = 1;  // PROCGEN_AMD_CHUNKS: measured no gain from chunked step/render overlap (both phases are issue-bound)
+    LaunchStreams streams() const { return LaunchStreams{stream, side_stream, ev_fork, ev_join, {lane_stream[0], lane_stream[1]}, {ev_lane[0], ev_lane[1]}, chunks}; }
     DevCtx d{};
     HostAssets assets;
     GameAssetsDev *d_assets = nullptr;
@@ -270,6 +273,11 @@ VecGame::VecGame(int nenvs, VecOptions opts) {
     HIP_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) {
+        HIP_CHECK(hipStreamCreateWithFlags(&lane_stream[k], hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_lane[k], hipEventDisableTiming));
+    }
+    if (const char *c = getenv("PROCGEN_AMD_CHUNKS")) chunks = atoi(c) > 0 ? atoi(c) : 1;
 
     // assets: baked pack next to the library (procgen_amd/data/<game>.atlas) or the PNG tree at resource_root
     std::string data_dir = getenv("PROCGEN_AMD_DATA_DIR") ? getenv("PROCGEN_AMD_DATA_DIR") : this_library_dir() + "/../../data";
@@ -285,12 +293,12 @@ VecGame::VecGame(int nenvs, VecOptions opts) {
     game_limits(game_id, &d.ent_cap, &d.grid_bytes);
     d.num_envs = num_envs;
     d.hdr = dev_alloc<EnvHdr>(N);
-    d.rng = dev_alloc<uint32_t>(N * 2 * MT_STRIDE);
+    d.rng = dev_alloc<uint32_t>(N * MT_SLOTS * MT_STRIDE);
     d.ents = dev_alloc<uint32_t>(N * EF_COUNT * d.ent_cap);
     d.grid = dev_alloc<uint8_t>(N * d.grid_bytes);
     {
         std::vector<EnvHdr> hdr(N);
-        std::vector<uint32_t> rng(N * 2 * MT_STRIDE);
+        std::vector<uint32_t> rng(N * MT_SLOTS * MT_STRIDE);
         game_init_state(game_id, num_envs, rand_seed, env_offset, hdr.data(), rng.data());
         HIP_CHECK(hipMemcpy(d.hdr, hdr.data(), N * sizeof(EnvHdr), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d.rng, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
@@ -308,11 +316,12 @@ VecGame::VecGame(int nenvs, VecOptions opts) {
     d.error = (int *)(d_small + ((14 * N + 3) & ~(size_t)3));
     small_bytes = ((14 * N + 3) & ~(size_t)3) + 4;
     for (int k = 0; k < 2; k++) {
-        d_big_list[k] = dev_alloc<int>(N);
-        d_big_count[k] = dev_alloc<int>(1);
+        d_big_list[k] = dev_alloc<int>(N * (NUM_TIERS - 1));
+        d_big_count[k] = dev_alloc<int>(NUM_TIERS - 1);
     }
     d.assets = d_assets;
     d.pixels = d_pixels;
+    d.debug_flags = getenv("PROCGEN_AMD_DEBUG") ? atoi(getenv("PROCGEN_AMD_DEBUG")) : 0;
     HIP_CHECK(hipHostMalloc((void **)&h_action, N * 4 + 16, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_small, small_bytes + 16, hipHostMallocDefault));
 }
@@ -336,6 +345,10 @@ VecGame::~VecGame() {
     if (h_action) (void)hipHostFree(h_action);
     if (h_small) (void)hipHostFree(h_small);
     if (h_obs_stage) (void)hipHostFree(h_obs_stage);
+    for (int k = 0; k < 2; k++) {
+        if (ev_lane[k]) (void)hipEventDestroy(ev_lane[k]);
+        if (lane_stream[k]) (void)hipStreamDestroy(lane_stream[k]);
+    }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (side_stream) (void)hipStreamDestroy(side_stream);
@@ -374,7 +387,7 @@ void VecGame::launch(int mode) {
     d.big_count = d_big_count[cur];
     d.next_big_list = d_big_list[nxt];
     d.next_big_count = d_big_count[nxt];
-    HIP_CHECK(hipMemsetAsync(d_big_count[nxt], 0, sizeof(int), stream));
+    HIP_CHECK(hipMemsetAsync(d_big_count[nxt], 0, sizeof(int) * (NUM_TIERS - 1), stream));
     HIP_CHECK(hipMemsetAsync(d.error, 0, sizeof(int), stream));
     HIP_CHECK(launch_step(game_id, d, mode, streams()));
     step_count++;
@@ -425,7 +438,7 @@ void VecGame::snapshot(int e, EnvSnapshot *s) {
     s->grid.resize(d.grid_bytes);
     HIP_CHECK(hipMemcpy(&s->hdr, d.hdr + e, sizeof(EnvHdr), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(s->ents.data(), d.ents + (size_t)e * EF_COUNT * d.ent_cap, s->ents.size() * 4, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(s->rng.data(), d.rng + (size_t)e * 2 * MT_STRIDE, s->rng.size() * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(s->rng.data(), d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, s->rng.size() * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(s->grid.data(), d.grid + (size_t)e * d.grid_bytes, s->grid.size(), hipMemcpyDeviceToHost));
 }
 
@@ -447,22 +460,22 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     observe();
     EnvSnapshot s;
     snapshot(e, &s);  // fields the wire format does not carry keep their current values
-    const int was_big = s.hdr.big;
+    const int was_tier = s.hdr.big;
     std::string err;
     if (!deserialize_state(game_id, d.opt, &s, data, length, &err)) fatal("%s\n", err.c_str());
-    // routing between the two step kernels: conservative bound (a step at most doubles the table)
-    s.hdr.big = (2 * s.hdr.n_ents + 2 > game_small_cap(game_id) - 1) ? 1 : 0;
+    // routing between the arena tiers of the step kernel: conservative bound (a step at most doubles the table)
+    s.hdr.big = game_tier_for(game_id, 2 * s.hdr.n_ents + 4);
     HIP_CHECK(hipMemcpy(d.ents + (size_t)e * EF_COUNT * d.ent_cap, s.ents.data(), s.ents.size() * 4, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(d.rng + (size_t)e * 2 * MT_STRIDE, s.rng.data(), s.rng.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, s.rng.data(), s.rng.size() * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.grid + (size_t)e * d.grid_bytes, s.grid.data(), s.grid.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.hdr + e, &s.hdr, sizeof(EnvHdr), hipMemcpyHostToDevice));
-    if (s.hdr.big && !was_big) {  // append to the list the next step's large kernel will walk
-        const int cur = (int)(step_count & 1);
+    if (s.hdr.big && s.hdr.big != was_tier) {  // append to the list the next step's tier kernel will walk
+        const int cur = (int)(step_count & 1), t = s.hdr.big - 1;
         int count = 0;
-        HIP_CHECK(hipMemcpy(&count, d_big_count[cur], sizeof(int), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(d_big_list[cur] + count, &e, sizeof(int), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(&count, d_big_count[cur] + t, sizeof(int), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(d_big_list[cur] + (size_t)t * num_envs + count, &e, sizeof(int), hipMemcpyHostToDevice));
         count++;
-        HIP_CHECK(hipMemcpy(d_big_count[cur], &count, sizeof(int), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_big_count[cur] + t, &count, sizeof(int), hipMemcpyHostToDevice));
     }
     // Game::observe(): refresh this env's observation / reward / first / info (reference src/vecgame.cpp:453-455)
     const uint8_t first = (uint8_t)s.hdr.done, plc = (uint8_t)s.hdr.level_complete;
@@ -550,7 +563,7 @@ LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const in
         v->d.big_count = v->d_big_count[cur];
         v->d.next_big_list = v->d_big_list[nxt];
         v->d.next_big_count = v->d_big_count[nxt];
-        HIP_CHECK(hipMemsetAsync(v->d_big_count[nxt], 0, sizeof(int), v->stream));
+        HIP_CHECK(hipMemsetAsync(v->d_big_count[nxt], 0, sizeof(int) * (NUM_TIERS - 1), v->stream));
         HIP_CHECK(hipEventRecord(e0, v->stream));
         HIP_CHECK(launch_step(v->game_id, v->d, 1, v->streams()));
         HIP_CHECK(hipEventRecord(e1, v->stream));

@@ -61,7 +61,7 @@ struct GameOptions {
     X(float, unit) X(float, view_dim) X(float, x_off) X(float, y_off) X(float, visibility) X(float, min_visibility) \
     /* bookkeeping of this implementation */                                                                      \
     X(int, error)      /* first failed reference fassert / capacity overflow (0 = none) -> host fatal() */        \
-    X(int, big)        /* 1: entity count may exceed the small-LDS kernel's capacity next step */                 \
+    X(int, big)        /* arena tier (0,1,2) that must step this env next: smallest LDS entity table that fits */      \
     X(int, grid_dirty)                                                                                            \
     /* game-specific scalars (meaning defined by the game policy, e.g. game_coinrun.h) */                         \
     X(int, gsi0) X(int, gsi1) X(int, gsi2) X(int, gsi3) X(int, gsi4) X(int, gsi5) X(int, gsi6) X(int, gsi7)       \
@@ -76,6 +76,8 @@ constexpr int ENV_HDR_WORDS = (int)(sizeof(EnvHdr) / 4);
 
 constexpr int MT_N = 624;
 constexpr int MT_STRIDE = 640;  // words per generator state in HBM (624 + pad, 128-B multiple)
+constexpr int MT_SLOTS = 4;     // per env: rand_gen, level_seed_rand_gen, two scratch states (seed / twist during a reset)
+constexpr int NUM_TIERS = 3;    // LDS entity-arena sizes of the step kernel (Game::ENT_CAP_T0 < T1 < T2)
 
 // ---- entity table: SoA [field][slot], one table per env in HBM, staged in LDS while an env steps ----
 // The 31 members of the reference Entity (reference src/entity.h:9-48) with the 4 small ints and 7 bools
@@ -93,6 +95,7 @@ enum EntField : int {
 struct ImgDesc {
     uint32_t off;  // first pixel (0xAARRGGBB words) in the atlas blob
     uint16_t w, h;
+    uint32_t opaque;  // 1: every pixel has alpha 255 (SourceOver degenerates to a copy)
 };
 constexpr int MAX_GAME_IMAGES = 256;
 constexpr int MAX_BACKGROUNDS = 128;
@@ -102,6 +105,7 @@ struct GameAssetsDev {
     uint8_t type_num_themes[MAX_ASSETS];
     int32_t n_bg;
     int16_t bg_img[MAX_BACKGROUNDS];
+    int32_t ref_w, ref_h;  // most common sprite size of the game (renderer's separable tile geometry)
 };
 
 // ---- everything a kernel launch needs ----
@@ -110,7 +114,7 @@ struct DevCtx {
     GameOptions opt;
     // per-env state
     EnvHdr *hdr;          // [num_envs]
-    uint32_t *rng;        // [num_envs][2][MT_STRIDE]  (0: rand_gen, 1: level_seed_rand_gen)
+    uint32_t *rng;        // [num_envs][MT_SLOTS][MT_STRIDE]  (0: rand_gen, 1: level_seed_rand_gen, 2-3: scratch)
     uint32_t *ents;       // [num_envs][EF_COUNT][ent_cap]
     int ent_cap;          // slots per env in HBM
     uint8_t *grid;        // [num_envs][grid_bytes]
@@ -124,13 +128,14 @@ struct DevCtx {
     // assets
     const GameAssetsDev *assets;
     const uint32_t *pixels;
-    // routing between the small-LDS and large-LDS kernels: envs whose entity table may outgrow the small
-    // kernel's LDS capacity are listed for the large kernel of the NEXT step (double-buffered by step parity)
-    const int *big_list;   // [num_envs] env ids the large kernel handles this step
-    const int *big_count;  // [1]
-    int *next_big_list;    // [num_envs] filled during this step
-    int *next_big_count;   // [1] zeroed by the host before the step
+    // routing between the arena tiers of the step kernel: envs whose entity table may outgrow tier 0's LDS arena
+    // are listed for the tier-1 / tier-2 kernels of the NEXT step (double-buffered by step parity)
+    const int *big_list;   // [NUM_TIERS-1][num_envs] env ids the tier-1 / tier-2 kernels handle this step
+    const int *big_count;  // [NUM_TIERS-1]
+    int *next_big_list;    // [NUM_TIERS-1][num_envs] filled during this step
+    int *next_big_count;   // [NUM_TIERS-1] zeroed by the host before the step
     int *error;            // [1] OR of the per-env error codes raised this step (0 = none)
+    int debug_flags;       // PROCGEN_AMD_DEBUG: phase ablation bits for profiling only (0 in normal operation)
 };
 
 }  // namespace pgamd

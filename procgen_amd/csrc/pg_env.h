@@ -83,7 +83,6 @@ PG_DEV float clip_abs(float x, float y) {                                   // r
 // ---- LDS arena of one workgroup ---------------------------------------------------------------------------
 template <class Game, int CAP>
 struct Lds {
-    uint32_t mt[2 * MT_STRIDE];  // MT19937 scratch A/B (seed / twist of rand_gen during a reset)
     uint32_t ent[EF_COUNT * CAP];
     uint32_t tmp[64];
     alignas(16) typename Game::cell_t grid[(Game::MAX_CELLS + 15) & ~15];
@@ -103,7 +102,7 @@ struct Env {
     bool rg_in_lds;
 
     PG_DEV Env(const DevCtx &d_, int env_, Lds<Game, CAP> *s_) : d(d_), env(env_), s(s_) {
-        rg_home = d.rng + (size_t)env * 2 * MT_STRIDE;
+        rg_home = d.rng + (size_t)env * MT_SLOTS * MT_STRIDE;
         rg_cur = rg_home;
         rg_in_lds = false;
     }
@@ -207,7 +206,7 @@ struct Env {
     PG_DEV int get_obj_from_floats(float i, float j) {  // BAG:167-174
         if (i < 0) return G.out_of_bounds_object;
         if (j < 0) return G.out_of_bounds_object;
-        return get_obj((int)pg_floor((double)i), (int)pg_floor((double)j));
+        return get_obj((int)pg_floorf(i), (int)pg_floorf(j));  // floor() of a float is the same number in float and double
     }
     // fill_elem BAG:125-131: rows are walked uniformly, lanes cover the columns
     PG_DEV void fill_elem(int x, int y, int dx, int dy, int elem) {
@@ -228,8 +227,9 @@ struct Env {
 
     // ======================================================================================================
     // MT19937 (std::mt19937 as used by RandGen: reference src/randgen.cpp:6-31,90-98; libstdc++ random.tcc)
-    PG_DEV uint32_t *mt_a() { return s->mt; }
-    PG_DEV uint32_t *mt_b() { return s->mt + MT_STRIDE; }
+    // scratch states live in HBM next to the generator's home (a reset is rare; LDS is kept for occupancy)
+    PG_DEV uint32_t *mt_a() { return rg_home + 2 * MT_STRIDE; }
+    PG_DEV uint32_t *mt_b() { return rg_home + 3 * MT_STRIDE; }
 
     // one twist of the whole state: src -> dst (distinct buffers, so lanes never read what others write)
     PG_DEV void mt_twist(const uint32_t *src, uint32_t *dst) {
@@ -268,7 +268,9 @@ struct Env {
         {
             uint32_t y = (src[623] & 0x80000000u) | (dst[0] & 0x7fffffffu);
             uint32_t v = dst[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            dst[623] = v;
+            PG_FOR_LANES(l) {
+                if (l == 0) dst[623] = v;
+            }
         }
         PG_SYNC();
     }
@@ -294,7 +296,9 @@ struct Env {
         uint32_t x = (uint32_t)seed;
         for (int i = 0; i < MT_N; i++) {
             if (i > 0) x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
-            a[i] = x;  // wave-uniform store (every lane writes the same word)
+            PG_FOR_LANES(l) {
+                if (l == 0) a[i] = x;
+            }
         }
         PG_SYNC();
         rg_cur = a;
@@ -367,20 +371,22 @@ struct Env {
     // ======================================================================================================
     // sub_step / push_obj: BAG:240-372.  The recursion (depth <= 5) is unrolled through the template depth.
     template <int DEPTH>
-    PG_DEV void push_obj(int src, int target, bool is_horizontal) {  // BAG:240-268
+    PG_DEV void push_obj(int src, int target, bool is_horizontal, int scan_axes) {  // BAG:240-268
         float rsum = is_horizontal ? (erx(src) + erx(target)) : (ery(src) + ery(target));
         float delx = ex(target) - ex(src);
         float dely = ey(target) - ey(src);
         float t_vx = 0, t_vy = 0;
         if (is_horizontal) t_vx = (float)((double)ex(src) + sign_d((double)delx) * (double)rsum - (double)ex(target));
         else t_vy = (float)((double)ey(src) + sign_d((double)dely) * (double)rsum - (double)ey(target));
-        if constexpr (DEPTH < 5) sub_step<DEPTH + 1>(target, t_vx, t_vy);
+        if constexpr (DEPTH < 5) sub_step<DEPTH + 1>(target, t_vx, t_vy, scan_axes);
         if (is_horizontal) evx(target) = 0;
         else evy(target) = 0;
     }
 
+    // scan_axes: bit 0 / bit 1 = some entity could block or reflect `obj` on a horizontal / vertical move
+    // (computed once per object by basic_step_object); when clear, the entity scan of BAG:337-369 is a no-op.
     template <int DEPTH>
-    PG_DEV bool sub_step(int obj, float _vx, float _vy) {  // BAG:270-372
+    PG_DEV bool sub_step(int obj, float _vx, float _vy, int scan_axes) {  // BAG:270-372
         if (eflag(obj, MF_WILL_ERASE)) return false;
         const int otype = etype(obj);
         const float orx = erx(obj), ory = ery(obj);
@@ -389,12 +395,26 @@ struct Env {
         const float margin = 0.98f;
         const bool is_horizontal = _vx != 0;
         bool block = false, reflect = false;
-        for (int i = 0; i < 2; i++)
-            for (int j = 0; j < 2; j++) {
-                int type2 = get_obj_from_floats(nx + orx * margin * (2 * i - 1), ny + ory * margin * (2 * j - 1));
-                block = block || Game::is_blocked(*this, otype, type2, is_horizontal);
-                reflect = reflect || Game::will_reflect(otype, type2);
+        {
+            // the four corner probes of BAG:284-290 share two x and two y coordinates: floor each once
+            const float mx = orx * margin, my = ory * margin;
+            const float px[2] = {nx + mx * -1, nx + mx * 1};
+            const float py[2] = {ny + my * -1, ny + my * 1};
+            int cxi[2], cyi[2];
+            bool xneg[2], yneg[2];
+            for (int k = 0; k < 2; k++) {
+                xneg[k] = px[k] < 0;
+                yneg[k] = py[k] < 0;
+                cxi[k] = (int)pg_floorf(px[k]);
+                cyi[k] = (int)pg_floorf(py[k]);
             }
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 2; j++) {
+                    const int type2 = (xneg[i] || yneg[j]) ? G.out_of_bounds_object : get_obj(cxi[i], cyi[j]);
+                    block = block || Game::is_blocked(*this, otype, type2, is_horizontal);
+                    reflect = reflect || Game::will_reflect(otype, type2);
+                }
+        }
         if (reflect) {
             if (is_horizontal) {
                 float delta;
@@ -425,7 +445,7 @@ struct Env {
         // reverse scan of the entity list (BAG:337-369): broad phase = one ballot per 64 entities, hits are
         // visited from the highest index down; the ballot is re-evaluated only after a hit moved `obj`.
         bool block2 = false;
-        const int n = G.n_ents;
+        const int n = ((scan_axes >> (is_horizontal ? 0 : 1)) & 1) ? G.n_ents : 0;
         for (int c = (n - 1) >> 6; c >= 0; c--) {
             int limit = 64;  // lanes >= limit of this chunk have been visited
             bool need_ballot = true;
@@ -474,7 +494,7 @@ struct Env {
                     moved = true;
                 }
                 if (curr_block) {
-                    push_obj<DEPTH>(j, obj, is_horizontal);
+                    push_obj<DEPTH>(j, obj, is_horizontal, scan_axes);
                     moved = true;
                 }
                 block2 = block2 || curr_block;
@@ -506,6 +526,17 @@ struct Env {
             if (G.action_vx != 0) step_x_first = true;
             if (G.action_vy != 0) step_x_first = false;
         }
+        // which axes need the entity scan at all for this object (entity types do not change while it steps)
+        int scan_axes = 0;
+        {
+            const int otype = etype(obj);
+            const int n = G.n_ents;
+            for (int c = 0; c < ((n + 63) >> 6) && scan_axes != 3; c++) {
+                const uint64_t mh = PG_BALLOT(l, ((c << 6) + l) < n && ((c << 6) + l) != obj && Game::may_interact(*this, otype, etype((c << 6) + l), true));
+                const uint64_t mv = PG_BALLOT(l, ((c << 6) + l) < n && ((c << 6) + l) != obj && Game::may_interact(*this, otype, etype((c << 6) + l), false));
+                scan_axes |= (mh ? 1 : 0) | (mv ? 2 : 0);
+            }
+        }
         float vx_pct = 0, vy_pct = 0;
         for (int st = 0; st < num_sub_steps; st++) {
             bool block_x = false, block_y = false;
@@ -513,7 +544,7 @@ struct Env {
                 const bool xaxis = (h == 0) == step_x_first;
                 const float dvx = xaxis ? evx(obj) * pct : 0.0f;
                 const float dvy = xaxis ? 0.0f : evy(obj) * pct;
-                const bool b = sub_step<0>(obj, dvx, dvy);
+                const bool b = sub_step<0>(obj, dvx, dvy, scan_axes);
                 if (xaxis) block_x = b;
                 else block_y = b;
             }
@@ -693,9 +724,9 @@ struct Env {
             ef(EF_VROT, ag) = vrot;
         }
         PG_SYNC();
-        step_entities();
-        collision_pass();
-        erase_if_needed();
+        if (!(d.debug_flags & 64)) step_entities();
+        if (!(d.debug_flags & 128)) collision_pass();
+        if (!(d.debug_flags & 256)) erase_if_needed();
         G.done = G.done || is_out_of_bounds(G.agent);
     }
     // default BAG::update_agent_velocity BAG:669-684 (games may override)
@@ -887,7 +918,11 @@ struct Env {
                 }
             }
         }
-        G.big = Game::needs_big(*this) ? 1 : 0;
+        {
+            const int need = Game::slots_needed_next_step(*this);  // entity slots incl. growth of one step + the reserved one
+            G.big = need <= Game::ENT_CAP_T0 ? 0 : (need <= Game::ENT_CAP_T1 ? 1 : 2);
+            if (need > Game::ENT_CAP_T2) fail(PGE_ENT_OVERFLOW);
+        }
         publish_routing();
         {
             EnvHdr *h = d.hdr + env;
@@ -908,8 +943,9 @@ struct Env {
 #else
         if (PG_LANE_ID() == 0) {
             if (G.big) {
-                const int slot = atomicAdd(d.next_big_count, 1);
-                d.next_big_list[slot] = env;
+                const int t = G.big - 1;
+                const int slot = atomicAdd(d.next_big_count + t, 1);
+                d.next_big_list[(size_t)t * d.num_envs + slot] = env;
             }
             if (G.error) atomicOr(d.error, G.error);
         }
@@ -920,7 +956,9 @@ struct Env {
     PG_DEV void run(int mode) {
         load_env();
         if (mode != 0) G.action = d.action[env];  // reference src/vecgame.cpp:388
-        if (mode == 0) {
+        if (d.debug_flags & 512) {
+            // ablation: staging only
+        } else if (mode == 0) {
             game_reset_full();
             G.initial_reset_complete = 1;
         } else {

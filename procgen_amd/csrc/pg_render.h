@@ -1,6 +1,8 @@
-// pg_render.h -- the 64x64x3 frame of one environment, produced by FOUR wavefronts (one 256-thread workgroup):
-// wave b rasterizes rows [16b, 16b+16) into its own 4 KB LDS band and writes that band of the RGB888 observation
-// with fully coalesced stores.  The waves never synchronize with each other.
+// pg_render.h -- the 64x64x3 frame of one environment, produced by ONE wavefront in four passes: pass b rasterizes
+// rows [16b, 16b+16) into a 4 KB LDS band and writes that band of the RGB888 observation with fully coalesced
+// stores.  The frame-level set-up (header, entity draw commands, per-column / per-row tile geometry, background
+// command) is done once and kept in registers / 0.5 KB of LDS across the passes, so a workgroup needs only 4.5 KB
+// of LDS and the CU runs at its 32-wave occupancy limit.
 //
 // Replaces Game::render_to_buf + BasicAbstractGame::game_draw (reference src/game.cpp:77-91, BAG:799-1012,
 // "BAG" = reference src/basic-abstract-game.cpp) and the Qt 5.9 raster engine calls they make: non-antialiased
@@ -17,33 +19,44 @@
 
 namespace pgamd {
 
-constexpr int BAND_ROWS = 16;
+#ifndef PG_BAND_ROWS
+#define PG_BAND_ROWS 16
+#endif
+constexpr int BAND_ROWS = PG_BAND_ROWS;  // rows per pass (64 / BAND_ROWS passes per frame)
 constexpr int NUM_BANDS = RES_H / BAND_ROWS;
 
 struct DrawCmd {  // uniform (scalar) view of one command
     int tx1, ty1, w, h;
     uint32_t basex, srcy0, ix, iy;
-    uint32_t img;  // image index | mirrored<<12 | const_alpha(0..256)<<16
+    uint32_t src;  // first pixel of the source image in the atlas blob
+    uint32_t aux;  // source width (13 bits) | mirrored<<13 | opaque<<14 | const_alpha(0..256)<<16
 };
+PG_DEV int cmd_src_w(uint32_t aux) { return (int)(aux & 0x1fffu); }
+PG_DEV bool cmd_mirrored(uint32_t aux) { return ((aux >> 13) & 1u) != 0; }
+PG_DEV bool cmd_opaque(uint32_t aux) { return ((aux >> 14) & 1u) != 0; }
+PG_DEV int cmd_alpha(uint32_t aux) { return (int)(aux >> 16); }
+PG_DEV uint32_t cmd_aux(int src_w, bool mirrored, bool opaque, int io) {
+    return (uint32_t)src_w | ((mirrored ? 1u : 0u) << 13) | (((opaque && io == 256) ? 1u : 0u) << 14) | ((uint32_t)io << 16);
+}
 
 template <class Game>
 struct Renderer {
     const DevCtx &d;
     const int env;
-    const int band;
-    uint32_t *fb;  // this wave's band: BAND_ROWS x 64 words of 0xffRRGGBB
+    uint32_t *fb;  // the band being rasterized: BAND_ROWS x 64 words of 0xffRRGGBB
+    uint32_t *ax;  // this wave's tile-axis scratch: 3 x 64 words (see setup_tile_axes)
     EnvHdr G;
     const uint32_t *ge;  // this env's entity table in HBM
     int ecap;
     const typename Game::cell_t *gg;
     int row0, row1;  // band rows [row0, row1)
 
-    PG_DEV Renderer(const DevCtx &d_, int env_, int band_, uint32_t *fb_) : d(d_), env(env_), band(band_), fb(fb_) {
+    PG_DEV Renderer(const DevCtx &d_, int env_, uint32_t *fb_, uint32_t *ax_) : d(d_), env(env_), fb(fb_), ax(ax_) {
         ge = d.ents + (size_t)env * EF_COUNT * d.ent_cap;
         ecap = d.ent_cap;
         gg = reinterpret_cast<const typename Game::cell_t *>(d.grid + (size_t)env * d.grid_bytes);
-        row0 = band * BAND_ROWS;
-        row1 = row0 + BAND_ROWS;
+        row0 = 0;
+        row1 = RES_H;
     }
 
     // entity accessors with the names the game policies use (HBM reads; the table was written by the step kernel)
@@ -76,9 +89,9 @@ struct Renderer {
     // ---- command set-up (lane-local) ----------------------------------------------------------------------
     // geom word: tx1 | ty1<<7 | w<<14 | h<<21, 0 = nothing to draw in this band
     PG_DEV void cmd_image(int img_index, bool mirrored, RectD tr, float opacity, uint32_t &geom, uint32_t &basex_o, uint32_t &srcy_o,
-                          uint32_t &ix_o, uint32_t &iy_o, uint32_t &img_o) const {
+                          uint32_t &ix_o, uint32_t &iy_o, uint32_t &src_o, uint32_t &aux_o) const {
         geom = 0;
-        basex_o = srcy_o = ix_o = iy_o = img_o = 0;
+        basex_o = srcy_o = ix_o = iy_o = src_o = aux_o = 0;
         const ImgDesc im = d.assets->img[img_index];
         const double sx = tr.w / (double)im.w;
         const double sy = tr.h / (double)im.h;
@@ -109,7 +122,8 @@ struct Renderer {
         srcy_o = srcy;
         ix_o = (uint32_t)ix;
         iy_o = (uint32_t)iy;
-        img_o = (uint32_t)img_index | ((mirrored ? 1u : 0u) << 12) | ((uint32_t)io << 16);
+        src_o = im.off;
+        aux_o = cmd_aux((int)im.w, mirrored, im.opaque != 0, io);
     }
     // draw_image BAG:877-913 for one drawable (lane-local); returns the image index or -1
     PG_DEV int resolve_image(int base_type, int theme, float rotation, float tile_ratio, RectD &rect) {
@@ -134,8 +148,60 @@ struct Renderer {
         return img;
     }
 
+    // ---- separable geometry of grid cells -------------------------------------------------------------------
+    // Every cell rect has the same size and an x that depends only on the cell column (y: only on the row), so for
+    // cells whose image has the reference dimensions (ref_w x ref_h, the game's common sprite size) the Qt
+    // stepping arithmetic is done once per column and once per row instead of once per cell:
+    //   lanes 0..ncol-1 : column c -> tx1 | w<<8 (valid bit 16), basex      lanes 32..32+nrow-1 : row r -> ty1 | h<<8, srcy
+    // (same formulas as cmd_image, evaluated on one axis).  ix / iy are wave-uniform.
+    PG_DEV void axis_params(double pos, double len, int src_len, int limit, uint32_t &packed, uint32_t &base, int &step_out) const {
+        const double sc = len / (double)src_len;
+        const int step = (int)(65536 / sc);
+        step_out = step;
+        int t1 = q_round(pos), t2 = q_round(pos + len);
+        if (t1 < 0) t1 = 0;
+        if (t2 > limit) t2 = limit;
+        int n = t2 - t1;
+        packed = 0;
+        base = 0;
+        if (n <= 0) return;
+        const uint32_t b = (uint32_t)((int)pg_ceil((t1 + 0.5 - pos) * step) - 1);
+        const int end = (int)((b + (uint32_t)step * (uint32_t)(n - 1)) >> 16);
+        if (end < 0 || end >= src_len) --n;
+        if (n <= 0) return;
+        packed = (uint32_t)t1 | ((uint32_t)n << 8) | (1u << 16);
+        base = b;
+    }
+    PG_DEV void setup_tile_axes(int low_x, int ncol, int low_y, int nrow, int ref_w, int ref_h, int &ix_out, int &iy_out) {
+        int ixu = 0, iyu = 0;
+        {
+            // wave-uniform steps (all cells share the rect size)
+            const RectD r0 = get_screen_rect(0.0f, 1.0f, 1, 1, RENDER_EPS);
+            ixu = (int)(65536 / (r0.w / (double)ref_w));
+            iyu = (int)(65536 / (r0.h / (double)ref_h));
+        }
+        PG_FOR_LANES(l) {
+            uint32_t packed = 0, base = 0;
+            int step = 0;
+            if (l < 32) {
+                if (l < ncol) {
+                    const RectD r = get_screen_rect((float)(low_x + l), 1.0f, 1, 1, RENDER_EPS);
+                    axis_params(r.x, r.w, ref_w, RES_W, packed, base, step);
+                }
+            } else if (l - 32 < nrow) {
+                const RectD r = get_screen_rect(0.0f, (float)(low_y + (l - 32) + 1), 1, 1, RENDER_EPS);
+                axis_params(r.y, r.h, ref_h, RES_H, packed, base, step);
+            }
+            ax[l] = packed;
+            ax[64 + l] = base;
+        }
+        PG_SYNC();
+        ix_out = ixu;
+        iy_out = iyu;
+    }
+
     // ---- command execution ----------------------------------------------------------------------------------
-    PG_DEV static DrawCmd unpack(uint32_t geom, uint32_t basex, uint32_t srcy0, uint32_t ix, uint32_t iy, uint32_t img) {
+    PG_DEV static DrawCmd unpack(uint32_t geom, uint32_t basex, uint32_t srcy0, uint32_t ix, uint32_t iy, uint32_t src, uint32_t aux) {
         DrawCmd c;
         c.tx1 = (int)(geom & 0x7fu);
         c.ty1 = (int)((geom >> 7) & 0x7fu);
@@ -145,44 +211,70 @@ struct Renderer {
         c.srcy0 = srcy0;
         c.ix = ix;
         c.iy = iy;
-        c.img = img;
+        c.src = src;
+        c.aux = aux;
         return c;
     }
     PG_DEV static uint32_t blend(uint32_t sp, uint32_t dst, int io, uint32_t ca) {
         if (io != 256) sp = byte_mul(sp, ca);
         return sp + byte_mul(dst, 255u - (sp >> 24));
     }
-    // one command of any size: every lane takes up to 8 pixels per round, all 8 texel fetches before the blends
+    // one command of any size: every lane takes up to 8 pixels per round, all 8 texel fetches before the blends.
+    // Wide commands (backgrounds) map lane -> column and walk 8 rows per round; narrower ones split a linear pixel
+    // index with a reciprocal multiply.
     PG_DEV void exec_large(const DrawCmd &c) {
-        const ImgDesc im = d.assets->img[c.img & 0xfffu];
-        const uint32_t *src = d.pixels + im.off;
-        const bool mirrored = ((c.img >> 12) & 1u) != 0;
-        const int io = (int)(c.img >> 16);
+        const uint32_t *src = d.pixels + c.src;
+        const int sw = cmd_src_w(c.aux);
+        const bool mirrored = cmd_mirrored(c.aux);
+        const bool opaque = cmd_opaque(c.aux);
+        const int io = cmd_alpha(c.aux);
         const uint32_t ca = (uint32_t)((io * 255) >> 8);
         const int y0 = c.ty1 > row0 ? c.ty1 : row0;
         const int y1 = (c.ty1 + c.h) < row1 ? (c.ty1 + c.h) : row1;
-        const int npix = c.w * (y1 - y0);
-        const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)c.w - 1u) / (uint32_t)c.w);  // p / w == (p * inv) >> 20 for p < 4096
-        for (int base = 0; base < npix; base += 512) {
-            PG_FOR_LANES(l) {
-                uint32_t tex[8];
-                int fbi[8];
-                _Pragma("unroll") for (int j = 0; j < 8; j++) {
-                    const int p = base + j * 64 + l;
-                    fbi[j] = -1;
-                    tex[j] = 0;
-                    if (p < npix) {
-                        const int pyb = (int)(((uint32_t)p * inv) >> 20);
-                        const int px = p - pyb * c.w;
-                        const int y = y0 + pyb;
-                        const int sxp = (int)((c.basex + (uint32_t)px * c.ix) >> 16);
-                        const int syp = (int)((c.srcy0 + (uint32_t)(y - c.ty1) * c.iy) >> 16);
-                        tex[j] = src[syp * (int)im.w + (mirrored ? ((int)im.w - 1 - sxp) : sxp)];
-                        fbi[j] = (y - row0) * RES_W + c.tx1 + px;
+        if (c.w > 32) {
+            for (int yb = y0; yb < y1; yb += 8) {
+                PG_FOR_LANES(l) {
+                    if (l < c.w) {
+                        const int sxp = (int)((c.basex + (uint32_t)l * c.ix) >> 16);
+                        const int scol = mirrored ? (sw - 1 - sxp) : sxp;
+                        uint32_t tex[8];
+                        _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                            tex[j] = 0;
+                            if (yb + j < y1) tex[j] = src[(int)((c.srcy0 + (uint32_t)(yb + j - c.ty1) * c.iy) >> 16) * sw + scol];
+                        }
+                        _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                            if (yb + j < y1) {
+                                uint32_t *dp = &fb[(yb + j - row0) * RES_W + c.tx1 + l];
+                                *dp = opaque ? tex[j] : blend(tex[j], *dp, io, ca);
+                            }
+                        }
                     }
                 }
-                _Pragma("unroll") for (int j = 0; j < 8; j++) {
-                    if (fbi[j] >= 0) fb[fbi[j]] = blend(tex[j], fb[fbi[j]], io, ca);
+            }
+        } else {
+            const int npix = c.w * (y1 - y0);
+            const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)c.w - 1u) / (uint32_t)c.w);  // p / w == (p * inv) >> 20 for p < 4096
+            for (int base = 0; base < npix; base += 512) {
+                PG_FOR_LANES(l) {
+                    uint32_t tex[8];
+                    int fbi[8];
+                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                        const int p = base + j * 64 + l;
+                        fbi[j] = -1;
+                        tex[j] = 0;
+                        if (p < npix) {
+                            const int pyb = (int)(((uint32_t)p * inv) >> 20);
+                            const int px = p - pyb * c.w;
+                            const int y = y0 + pyb;
+                            const int sxp = (int)((c.basex + (uint32_t)px * c.ix) >> 16);
+                            const int syp = (int)((c.srcy0 + (uint32_t)(y - c.ty1) * c.iy) >> 16);
+                            tex[j] = src[syp * sw + (mirrored ? (sw - 1 - sxp) : sxp)];
+                            fbi[j] = (y - row0) * RES_W + c.tx1 + px;
+                        }
+                    }
+                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                        if (fbi[j] >= 0) fb[fbi[j]] = opaque ? tex[j] : blend(tex[j], fb[fbi[j]], io, ca);
+                    }
                 }
             }
         }
@@ -202,11 +294,10 @@ struct Renderer {
                 if (g < count) {
                     const int y = c[g].ty1 + ly;
                     if (lx < c[g].w && ly < c[g].h && y >= row0 && y < row1) {
-                        const ImgDesc im = d.assets->img[c[g].img & 0xfffu];
+                        const int sw = cmd_src_w(c[g].aux);
                         const int sxp = (int)((c[g].basex + (uint32_t)lx * c[g].ix) >> 16);
                         const int syp = (int)((c[g].srcy0 + (uint32_t)ly * c[g].iy) >> 16);
-                        const bool mirrored = ((c[g].img >> 12) & 1u) != 0;
-                        PG_LA(tex, g, l) = d.pixels[im.off + (uint32_t)(syp * (int)im.w + (mirrored ? ((int)im.w - 1 - sxp) : sxp))];
+                        PG_LA(tex, g, l) = d.pixels[c[g].src + (uint32_t)(syp * sw + (cmd_mirrored(c[g].aux) ? (sw - 1 - sxp) : sxp))];
                         PG_LA(fbi, g, l) = (y - row0) * RES_W + c[g].tx1 + lx;
                     }
                 }
@@ -214,11 +305,12 @@ struct Renderer {
         }
         _Pragma("unroll") for (int g = 0; g < 8; g++) {
             if (g < count) {
-                const int io = (int)(c[g].img >> 16);
+                const int io = cmd_alpha(c[g].aux);
                 const uint32_t ca = (uint32_t)((io * 255) >> 8);
+                const bool opaque = cmd_opaque(c[g].aux);
                 PG_FOR_LANES(l) {
                     const int fi = PG_LA(fbi, g, l);
-                    if (fi >= 0) fb[fi] = blend(PG_LA(tex, g, l), fb[fi], io, ca);
+                    if (fi >= 0) fb[fi] = opaque ? PG_LA(tex, g, l) : blend(PG_LA(tex, g, l), fb[fi], io, ca);
                 }
             }
         }
@@ -232,15 +324,18 @@ struct Renderer {
         PG_LANE_VAR(uint32_t, srcy);
         PG_LANE_VAR(uint32_t, ix);
         PG_LANE_VAR(uint32_t, iy);
-        PG_LANE_VAR(uint32_t, img);
+        PG_LANE_VAR(uint32_t, src);
+        PG_LANE_VAR(uint32_t, aux);
     };
     PG_DEV static DrawCmd read_cmd(const CmdRegs &r, int k) {
         return unpack(PG_READLANE(r.geom, k), PG_READLANE(r.basex, k), PG_READLANE(r.srcy, k), PG_READLANE(r.ix, k), PG_READLANE(r.iy, k),
-                      PG_READLANE(r.img, k));
+                      PG_READLANE(r.src, k), PG_READLANE(r.aux, k));
     }
     // executes the commands in lane order; runs of small commands go eight at a time
     PG_DEV void run_batch(const CmdRegs &r, uint64_t lane_mask = ~0ull) {
-        uint64_t valid = PG_BALLOT(l, PG_LV(r.geom, l) != 0) & lane_mask;
+        // commands that exist, are selected by the caller, and touch the rows of the current pass
+        uint64_t valid = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && (int)((PG_LV(r.geom, l) >> 7) & 0x7fu) < row1 &&
+                                          (int)(((PG_LV(r.geom, l) >> 7) & 0x7fu) + ((PG_LV(r.geom, l) >> 21) & 0x7fu)) > row0) & lane_mask;
         const uint64_t small = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && ((PG_LV(r.geom, l) >> 14) & 0x7fu) <= 8u && ((PG_LV(r.geom, l) >> 21) & 0x7fu) <= 8u);
         while (valid) {
             const int k = pg_ctz64(valid);
@@ -275,7 +370,7 @@ struct Renderer {
         PG_FOR_LANES(l) {
             const int i = base + l;
             PG_LV(r.geom, l) = 0;
-            PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.img, l) = 0;
+            PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.src, l) = PG_LV(r.aux, l) = 0;
             if (i < n && Game::should_draw_entity(*this, i)) {
                 const uint32_t mm = meta(i);
                 const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
@@ -290,7 +385,7 @@ struct Renderer {
                     r1 = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
                 }
                 const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), ef(EF_ROTATION, i), Game::tile_aspect_ratio(*this, i), r1);
-                if (im >= 0) cmd_image(im, (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.img, l));
+                if (im >= 0) cmd_image(im, (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
             }
         }
     }
@@ -306,19 +401,19 @@ struct Renderer {
         }
     }
 
-    // game_draw BAG:1009-1012 (draw_background BAG:979-1007 + draw_foreground BAG:921-970), restricted to the band
-    PG_DEV void render_band() {
+    // game_draw BAG:1009-1012 (draw_background BAG:979-1007 + draw_foreground BAG:921-970)
+    PG_DEV void render_env() {
         {
             const EnvHdr *h = d.hdr + env;
 #define PG_X(type, name) G.name = h->name;
             PG_HDR_FIELDS(PG_X)
 #undef PG_X
         }
-        for (int base = 0; base < BAND_ROWS * RES_W; base += 64) {
-            PG_FOR_LANES(l) { fb[base + l] = 0xff000000u; }  // p.fillRect(rect, QColor(0,0,0))
-        }
-        PG_SYNC();
-        if (d.opt.use_backgrounds) {
+        // ---- frame-level set-up (rows [0, 64)) ------------------------------------------------------------------
+        row0 = 0;
+        row1 = RES_H;
+        uint32_t bg_geom = 0, bg_basex = 0, bg_srcy = 0, bg_ix = 0, bg_iy = 0, bg_src = 0, bg_aux = 0;  // wave-uniform command
+        if (d.opt.use_backgrounds && !(d.debug_flags & 1)) {
             const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);
             const int bgi = (int)d.assets->bg_img[G.background_index];
             if (G.bg_tile_ratio < 0) fail(PGE_UNSUPPORTED_DRAW);
@@ -329,77 +424,129 @@ struct Renderer {
             const float extra_w = bg_ar - world_ar;
             const float offset_x = G.bg_pct_x * extra_w;
             const RectD bg_rect = adjust_rect(main_rect, (double)(-offset_x), 0, (double)(bg_ar / world_ar), 1);
-            uint32_t geom, basex, srcy, ix, iy, img;  // wave-uniform: every lane computes the same command
-            cmd_image(bgi, false, bg_rect, 1.0f, geom, basex, srcy, ix, iy, img);
-            if (geom != 0) exec_large(unpack(geom, basex, srcy, ix, iy, img));
+            cmd_image(bgi, false, bg_rect, 1.0f, bg_geom, bg_basex, bg_srcy, bg_ix, bg_iy, bg_src, bg_aux);
         }
-        // common case (<= 64 entities): their commands are built once and kept in registers across the tile pass
+        // common case (<= 64 entities): their commands are built once and kept in registers for all passes
+        if (d.debug_flags & 4) G.n_ents = 0;
         const bool one_chunk = G.n_ents <= 64;
         CmdRegs er;
         uint64_t ezmask[3] = {0, 0, 0};
-        if (one_chunk) {
-            setup_entities(0, er, ezmask);
-            if (ezmask[0]) run_batch(er, ezmask[0]);
-        } else {
-            draw_entities(-1);
-        }
-        int low_x, high_x, low_y, high_y;
+        if (one_chunk) setup_entities(0, er, ezmask);
+        int win_lx, win_hx, win_ly, win_hy;  // BAG:926-939
         if (Game::center_agent(d.opt)) {
             const float margin = (float)(G.visibility / 2.0 + 1);
-            low_x = (int)(G.center_x - margin);
-            high_x = (int)(G.center_x + margin);
-            low_y = (int)(G.center_y - margin);
-            high_y = (int)(G.center_y + margin);
+            win_lx = (int)(G.center_x - margin);
+            win_hx = (int)(G.center_x + margin);
+            win_ly = (int)(G.center_y - margin);
+            win_hy = (int)(G.center_y + margin);
         } else {
-            low_x = 0;
-            high_x = G.main_width - 1;
-            low_y = 0;
-            high_y = G.main_height - 1;
+            win_lx = 0;
+            win_hx = G.main_width - 1;
+            win_ly = 0;
+            win_hy = G.main_height - 1;
         }
-        {
-            // only cell rows whose (inflated) rect can reach this band: screen y falls as cell y grows.
-            // Conservative by a full cell either side; cells outside the range draw nothing into the band, and
-            // dropping them keeps the x-major order of the rest (BAG:941-955).
-            const float inv_unit = 1.0f / G.unit;
-            const int cy_hi = (int)pg_ceil((double)(G.view_dim - ((float)row0 - G.y_off) * inv_unit)) + 1;
-            const int cy_lo = (int)pg_floor((double)(G.view_dim - ((float)row1 - G.y_off) * inv_unit)) - 2;
-            if (cy_lo > low_y) low_y = cy_lo;
-            if (cy_hi < high_y) high_y = cy_hi;
-        }
-        const int ny = high_y - low_y + 1;
-        const int ncell = ny > 0 ? (high_x - low_x + 1) * ny : 0;
-        const uint32_t ny_inv = ny > 0 ? (uint32_t)(((1u << 20) + (uint32_t)ny - 1u) / (uint32_t)ny) : 0u;
-        if (ncell > 4096) fail(PGE_ASSERT);
-        for (int base = 0; base < ncell; base += 64) {
-            CmdRegs r;
-            PG_FOR_LANES(l) {
-                const int cidx = base + l;
-                PG_LV(r.geom, l) = 0;
-                PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.img, l) = 0;
-                if (cidx < ncell) {
-                    const int cx = (int)(((uint32_t)cidx * ny_inv) >> 20);  // cidx / ny (exact for cidx < 4096)
-                    const int x = low_x + cx, y = low_y + (cidx - cx * ny);
-                    const int type = get_obj(x, y);
-                    if (type != INVALID_OBJ && type != SPACE) {
-                        const int theme = Game::theme_for_grid_obj(*this, type);
-                        RectD r2 = get_screen_rect((float)x, (float)(y + 1), 1, 1, RENDER_EPS);
-                        const int im = resolve_image(type, theme, 0.0f, 0.0f, r2);
-                        if (im >= 0) cmd_image(im, false, r2, 1.0f, PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.img, l));
+        const int nx = win_hx - win_lx + 1;
+        const int ny_full = win_hy - win_ly + 1;
+        const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
+        const bool use_axes = nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
+        int ix_ref = 0, iy_ref = 0;
+        if (use_axes) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);
+
+        // ---- passes -------------------------------------------------------------------------------------------------
+        for (int band = 0; band < NUM_BANDS; band++) {
+            row0 = band * BAND_ROWS;
+            row1 = row0 + BAND_ROWS;
+            for (int base = 0; base < BAND_ROWS * RES_W; base += 64) {
+                PG_FOR_LANES(l) { fb[base + l] = 0xff000000u; }  // p.fillRect(rect, QColor(0,0,0))
+            }
+            PG_SYNC();
+            if (bg_geom != 0) {
+                const DrawCmd bc = unpack(bg_geom, bg_basex, bg_srcy, bg_ix, bg_iy, bg_src, bg_aux);
+                if (bc.ty1 < row1 && bc.ty1 + bc.h > row0) exec_large(bc);
+            }
+            if (one_chunk) {
+                if (ezmask[0]) run_batch(er, ezmask[0]);
+            } else {
+                draw_entities(-1);
+            }
+            // only cell rows whose (inflated) rect can reach these rows: screen y falls as cell y grows.  Conservative
+            // by a full cell either side; cells outside the range draw nothing here, and dropping them keeps the
+            // x-major order of the rest (BAG:941-955).
+            int low_y = win_ly, high_y = win_hy;
+            {
+                const float inv_unit = 1.0f / G.unit;
+                const int cy_hi = (int)pg_ceil((double)(G.view_dim - ((float)row0 - G.y_off) * inv_unit)) + 1;
+                const int cy_lo = (int)pg_floor((double)(G.view_dim - ((float)row1 - G.y_off) * inv_unit)) - 2;
+                if (cy_lo > low_y) low_y = cy_lo;
+                if (cy_hi < high_y) high_y = cy_hi;
+            }
+            const int low_x = win_lx;
+            const int ny = high_y - low_y + 1;
+            const int ncell = (ny > 0 && nx > 0) ? nx * ny : 0;
+            const uint32_t ny_inv = ny > 0 ? (uint32_t)(((1u << 20) + (uint32_t)ny - 1u) / (uint32_t)ny) : 0u;
+            if (ncell > 4096) fail(PGE_ASSERT);
+            for (int base = 0; base < ((d.debug_flags & 2) ? 0 : ncell); base += 64) {
+                CmdRegs r;
+                PG_FOR_LANES(l) {
+                    const int cidx = base + l;
+                    PG_LV(r.geom, l) = 0;
+                    PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.src, l) = PG_LV(r.aux, l) = 0;
+                    if (cidx < ncell) {
+                        const int cx = (int)(((uint32_t)cidx * ny_inv) >> 20);  // cidx / ny (exact for cidx < 4096)
+                        const int cy = cidx - cx * ny;
+                        const int x = low_x + cx, y = low_y + cy;
+                        const int type = get_obj(x, y);
+                        if (type != INVALID_OBJ && type != SPACE) {
+                            const int theme = Game::theme_for_grid_obj(*this, type);
+                            RectD r2 = get_screen_rect((float)x, (float)(y + 1), 1, 1, RENDER_EPS);
+                            const RectD r2_in = r2;
+                            const int im = resolve_image(type, theme, 0.0f, 0.0f, r2);
+                            if (im >= 0) {
+                                const ImgDesc imd = d.assets->img[im];
+                                const bool same_rect = r2.x == r2_in.x && r2.y == r2_in.y && r2.w == r2_in.w && r2.h == r2_in.h;
+                                if (use_axes && same_rect && (int)imd.w == ref_w && (int)imd.h == ref_h) {
+                                    const int ry = y - win_ly;  // row index in the frame-level axis table
+                                    const uint32_t px = ax[cx], py = ax[32 + ry];
+                                    if ((px >> 16) && (py >> 16)) {
+                                        const int ty1 = (int)(py & 0xffu), h = (int)((py >> 8) & 0xffu);
+                                        if (!(ty1 >= row1 || ty1 + h <= row0)) {
+                                            PG_LV(r.geom, l) = (px & 0xffu) | ((uint32_t)ty1 << 7) | (((px >> 8) & 0xffu) << 14) | ((uint32_t)h << 21);
+                                            PG_LV(r.basex, l) = ax[64 + cx];
+                                            PG_LV(r.srcy, l) = ax[64 + 32 + ry];
+                                            PG_LV(r.ix, l) = (uint32_t)ix_ref;
+                                            PG_LV(r.iy, l) = (uint32_t)iy_ref;
+                                            PG_LV(r.src, l) = imd.off;
+                                            PG_LV(r.aux, l) = cmd_aux((int)imd.w, false, imd.opaque != 0, 256);
+                                        }
+                                    }
+                                } else {
+                                    cmd_image(im, false, r2, 1.0f, PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                                }
+                            }
+                        }
                     }
                 }
+                run_batch(r);
             }
-            run_batch(r);
+            if (one_chunk) {
+                if (ezmask[1]) run_batch(er, ezmask[1]);
+                if (ezmask[2]) run_batch(er, ezmask[2]);
+            } else {
+                draw_entities(0);
+                draw_entities(1);
+            }
+            if (G.has_useful_vel_info && d.opt.paint_vel_info) fail(PGE_UNSUPPORTED_DRAW);
+            PG_SYNC();
+            if (!(d.debug_flags & 8)) store_band();
+            PG_SYNC();
         }
-        if (one_chunk) {
-            if (ezmask[1]) run_batch(er, ezmask[1]);
-            if (ezmask[2]) run_batch(er, ezmask[2]);
-        } else {
-            draw_entities(0);
-            draw_entities(1);
+        if (G.error) {
+#if defined(PGAMD_WAVE_EMU)
+            if (d.error) *d.error |= G.error;
+#else
+            if (PG_LANE_ID() == 0) atomicOr(d.error, G.error);
+#endif
         }
-        if (G.has_useful_vel_info && d.opt.paint_vel_info) fail(PGE_UNSUPPORTED_DRAW);
-        PG_SYNC();
-        store_band();
     }
 
     // bgr32_to_rgb888 + the ob write of Game::observe (reference src/game.cpp:8-23,159): 4 pixels -> 3 dwords per
@@ -420,13 +567,6 @@ struct Renderer {
                 o[1] = g1 | (b1 << 8) | (r2 << 16) | (g2 << 24);
                 o[2] = b2 | (r3 << 8) | (g3 << 16) | (b3 << 24);
             }
-        }
-        if (G.error) {
-#if defined(PGAMD_WAVE_EMU)
-            if (d.error) *d.error |= G.error;
-#else
-            if (PG_LANE_ID() == 0) atomicOr(d.error, G.error);
-#endif
         }
     }
 };

@@ -45,6 +45,7 @@ PG_DEV int pg_clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
 PG_DEV int pg_ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
 PG_DEV double pg_sqrt(double x) { return sqrt(x); }
 PG_DEV double pg_floor(double x) { return floor(x); }
+PG_DEV float pg_floorf(float x) { return floorf(x); }
 PG_DEV double pg_ceil(double x) { return ceil(x); }
 PG_DEV float pg_fabsf(float x) { return fabsf(x); }
 PG_DEV double pg_pow(double x, double y) { return pow(x, y); }  // glibc, as the reference
@@ -78,6 +79,7 @@ PG_DEV int pg_clz64(uint64_t m) { return m ? __clzll((long long)m) : 64; }
 PG_DEV int pg_ctz64(uint64_t m) { return m ? (__ffsll((long long)m) - 1) : 64; }
 PG_DEV double pg_sqrt(double x) { return __builtin_sqrt(x); }   // IEEE correctly rounded (no fast-math)
 PG_DEV double pg_floor(double x) { return __builtin_floor(x); }
+PG_DEV float pg_floorf(float x) { return __builtin_floorf(x); }
 PG_DEV double pg_ceil(double x) { return __builtin_ceil(x); }
 PG_DEV float pg_fabsf(float x) { return __builtin_fabsf(x); }
 // ROCm device libm (OCML), < 1 ulp in double; callers narrow the result to float (bit-exactness notes)

@@ -16,7 +16,7 @@ import numpy as np
 from .libenv import CEnv
 
 SCRIPT_DIR = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB_DIR = os.path.join(SCRIPT_DIR, "csrc", "build")
+DEFAULT_LIB_DIR = os.environ.get("PROCGEN_AMD_LIB_DIR") or os.path.join(SCRIPT_DIR, "csrc", "build")
 
 MAX_STATE_SIZE = 2 ** 20
 

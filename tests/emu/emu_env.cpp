@@ -46,15 +46,17 @@ static void run_env(EmuVec *v, int env, int mode) {
 template <class Game>
 static void run_all(EmuVec *v, int mode) {
     for (int e = 0; e < v->n; e++) {  // "step kernels"
-        if (v->use_small && !v->hdr[e].big) run_env<Game, Game::ENT_CAP_SMALL>(v, e, mode);
-        else run_env<Game, Game::ENT_CAP_BIG>(v, e, mode);
+        const int tier = v->use_small ? v->hdr[e].big : 2;
+        if (tier == 0) run_env<Game, Game::ENT_CAP_T0>(v, e, mode);
+        else if (tier == 1) run_env<Game, Game::ENT_CAP_T1>(v, e, mode);
+        else run_env<Game, Game::ENT_CAP_T2>(v, e, mode);
     }
-    static uint32_t fb[NUM_BANDS][BAND_ROWS * RES_W];
-    for (int e = 0; e < v->n; e++)  // "render kernel": 4 band-waves per env
-        for (int b = 0; b < NUM_BANDS; b++) {
-            Renderer<Game> r(v->d, e, b, fb[b]);
-            r.render_band();
-        }
+    static uint32_t fb[BAND_ROWS * RES_W];
+    static uint32_t ax[128];
+    for (int e = 0; e < v->n; e++) {  // "render kernel": one wave per env
+        Renderer<Game> r(v->d, e, fb, ax);
+        r.render_env();
+    }
 }
 
 extern "C" {
@@ -83,13 +85,13 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     int ent_cap = 0, grid_bytes = 0;
 #define PG_X(Game)                                                                            \
     if (gid == Game::GAME_ID) {                                                               \
-        ent_cap = Game::ENT_CAP_BIG;                                                          \
+        ent_cap = Game::ENT_CAP_T2;                                                           \
         grid_bytes = (int)((Game::MAX_CELLS * sizeof(Game::cell_t) + 15) & ~(size_t)15);      \
     }
     PG_FOR_EACH_GAME(PG_X)
 #undef PG_X
     v->hdr.resize(num_envs);
-    v->rng.assign((size_t)num_envs * 2 * MT_STRIDE, 0);
+    v->rng.assign((size_t)num_envs * MT_SLOTS * MT_STRIDE, 0);
     v->ents.assign((size_t)num_envs * EF_COUNT * ent_cap, 0);
     v->grid.assign((size_t)num_envs * grid_bytes, 0);
     v->obs.assign((size_t)num_envs * OBS_BYTES, 0);
@@ -160,7 +162,7 @@ static void emu_snapshot(EmuVec *v, int env, EnvSnapshot *s) {
     s->hdr = v->hdr[env];
     s->ent_cap = cap;
     s->ents.assign(v->ents.begin() + (size_t)env * EF_COUNT * cap, v->ents.begin() + (size_t)(env + 1) * EF_COUNT * cap);
-    s->rng.assign(v->rng.begin() + (size_t)env * 2 * MT_STRIDE, v->rng.begin() + (size_t)(env + 1) * 2 * MT_STRIDE);
+    s->rng.assign(v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE, v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE + 2 * MT_STRIDE);
     s->grid.assign(v->grid.begin() + (size_t)env * v->d.grid_bytes, v->grid.begin() + (size_t)(env + 1) * v->d.grid_bytes);
 }
 // the product's state_io.cpp on the emulated state: same wire format code as libenv.so's get_state / set_state
@@ -185,24 +187,24 @@ int emu_set_state(void *h, int env, const char *data, int length) {
         fprintf(stderr, "emu_set_state: %s\n", err.c_str());
         return -1;
     }
-    s.hdr.big = 1;  // the emulation picks the arena from this flag alone; the large arena is always safe
+    s.hdr.big = 2;  // the emulation picks the arena from this field alone; the largest arena is always safe
     const int cap = v->d.ent_cap;
     v->hdr[env] = s.hdr;
     std::copy(s.ents.begin(), s.ents.end(), v->ents.begin() + (size_t)env * EF_COUNT * cap);
-    std::copy(s.rng.begin(), s.rng.end(), v->rng.begin() + (size_t)env * 2 * MT_STRIDE);
+    std::copy(s.rng.begin(), s.rng.end(), v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE);
     std::copy(s.grid.begin(), s.grid.end(), v->grid.begin() + (size_t)env * v->d.grid_bytes);
     v->rew[env] = s.hdr.reward;
     v->first[env] = (uint8_t)s.hdr.done;
     v->pls[env] = s.hdr.prev_level_seed;
     v->plc[env] = (uint8_t)s.hdr.level_complete;
     v->ls[env] = s.hdr.current_level_seed;
-    static uint32_t fb[NUM_BANDS][BAND_ROWS * RES_W];
-#define PG_X(Game)                                    \
-    if (v->game_id == Game::GAME_ID)                  \
-        for (int b = 0; b < NUM_BANDS; b++) {         \
-            Renderer<Game> r(v->d, env, b, fb[b]);    \
-            r.render_band();                          \
-        }
+    static uint32_t fb[BAND_ROWS * RES_W];
+    static uint32_t ax[128];
+#define PG_X(Game)                            \
+    if (v->game_id == Game::GAME_ID) {        \
+        Renderer<Game> r(v->d, env, fb, ax);  \
+        r.render_env();                       \
+    }
     PG_FOR_EACH_GAME(PG_X)
 #undef PG_X
     return 0;
