@@ -41,9 +41,8 @@ __global__ __launch_bounds__(64) void step_list(DevCtx d, int mode) {
 
 template <class Game>
 __global__ __launch_bounds__(64) void render(DevCtx d, int env_base) {
-    __shared__ uint32_t fb[BAND_ROWS * RES_W];
-    __shared__ uint32_t ax[128];
-    Renderer<Game> r(d, env_base + (int)blockIdx.x, fb, ax);
+    __shared__ RenderLds lds;
+    Renderer<Game> r(d, env_base + (int)blockIdx.x, &lds);
     r.render_env();
 }
 

@@ -39,19 +39,31 @@ PG_DEV uint32_t cmd_aux(int src_w, bool mirrored, bool opaque, int io) {
     return (uint32_t)src_w | ((mirrored ? 1u : 0u) << 13) | (((opaque && io == 256) ? 1u : 0u) << 14) | ((uint32_t)io << 16);
 }
 
+// LDS arena of one render workgroup (one wave)
+struct RenderLds {
+    uint32_t fb[BAND_ROWS * RES_W];  // the band being rasterized, 0xffRRGGBB
+    uint32_t ax[128];                // per-column / per-row tile geometry (setup_tile_axes)
+    uint32_t ci[2][64];              // screen column -> the (at most two) cell columns covering it
+    uint32_t ri[2][64];              // screen row    -> the (at most two) cell rows covering it
+    uint32_t seamcols[64];           // screen columns covered by two cell columns
+    uint32_t cellimg[1024];          // window cell -> source image (atlas offset | opaque<<31), CELL_NONE = nothing to draw
+};
+constexpr uint32_t CELL_NONE = 0xffffffffu;
+
 template <class Game>
 struct Renderer {
     const DevCtx &d;
     const int env;
+    RenderLds *lds;
     uint32_t *fb;  // the band being rasterized: BAND_ROWS x 64 words of 0xffRRGGBB
-    uint32_t *ax;  // this wave's tile-axis scratch: 3 x 64 words (see setup_tile_axes)
+    uint32_t *ax;  // tile-axis scratch (see setup_tile_axes)
     EnvHdr G;
     const uint32_t *ge;  // this env's entity table in HBM
     int ecap;
     const typename Game::cell_t *gg;
     int row0, row1;  // band rows [row0, row1)
 
-    PG_DEV Renderer(const DevCtx &d_, int env_, uint32_t *fb_, uint32_t *ax_) : d(d_), env(env_), fb(fb_), ax(ax_) {
+    PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(lds_->ax) {
         ge = d.ents + (size_t)env * EF_COUNT * d.ent_cap;
         ecap = d.ent_cap;
         gg = reinterpret_cast<const typename Game::cell_t *>(d.grid + (size_t)env * d.grid_bytes);
@@ -198,6 +210,156 @@ struct Renderer {
         PG_SYNC();
         ix_out = ixu;
         iy_out = iyu;
+    }
+
+    // ---- grid cells, pull form ---------------------------------------------------------------------------------
+    // When every drawn cell of the window uses an image of the reference size with an unadjusted rect (the normal
+    // case), the cells are not executed as ~150 separate 5x5 blits: each screen column knows the (at most two)
+    // cell columns covering it and the source column they sample, each screen row likewise, and a pixel composites
+    // its covering cells in the reference's x-major draw order: (c0,r0), (c0,r1), (c1,r0), (c1,r1).  Stage 1 does
+    // (c0,r0) for all pixels with lane = screen column; the seam stages touch only the doubly covered columns/rows.
+    // entry: valid<<31 | cell index<<12 | source coordinate
+    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, int ix_ref, int iy_ref, uint64_t &colseam, uint64_t &rowseam) {
+        PG_LANE_VAR(uint32_t, over);
+        PG_FOR_LANES(l) {
+            uint32_t s0 = 0, s1 = 0;
+            int cnt = 0;
+            for (int c = 0; c < nx; c++) {
+                const uint32_t pk = ax[c];
+                const int t1 = (int)(pk & 0xffu), n = (int)((pk >> 8) & 0xffu);
+                if ((pk >> 16) && l >= t1 && l < t1 + n) {
+                    const uint32_t e = (1u << 31) | ((uint32_t)c << 12) | ((ax[64 + c] + (uint32_t)(l - t1) * (uint32_t)ix_ref) >> 16);
+                    if (cnt == 0) s0 = e;
+                    else if (cnt == 1) s1 = e;
+                    cnt++;
+                }
+            }
+            lds->ci[0][l] = s0;
+            lds->ci[1][l] = s1;
+            uint32_t ov = cnt > 2;
+            s0 = 0;
+            s1 = 0;
+            cnt = 0;
+            for (int r = 0; r < ny_full; r++) {
+                const uint32_t pk = ax[32 + r];
+                const int t1 = (int)(pk & 0xffu), n = (int)((pk >> 8) & 0xffu);
+                if ((pk >> 16) && l >= t1 && l < t1 + n) {
+                    const uint32_t e = (1u << 31) | ((uint32_t)r << 12) | ((ax[96 + r] + (uint32_t)(l - t1) * (uint32_t)iy_ref) >> 16);
+                    if (cnt == 0) s0 = e;
+                    else if (cnt == 1) s1 = e;
+                    cnt++;
+                }
+            }
+            lds->ri[0][l] = s0;
+            lds->ri[1][l] = s1;
+            PG_LV(over, l) = ov | (cnt > 2);
+        }
+        PG_SYNC();
+        bool ok = PG_BALLOT(l, PG_LV(over, l) != 0) == 0;
+        colseam = PG_BALLOT(l, (lds->ci[1][l] >> 31) != 0);
+        rowseam = PG_BALLOT(l, (lds->ri[1][l] >> 31) != 0);
+        PG_FOR_LANES(l) {
+            if ((colseam >> l) & 1ull) lds->seamcols[pg_popc64(colseam & pg_mask_lt(l))] = (uint32_t)l;
+        }
+        // cell -> image
+        const int ncell = nx * ny_full;
+        const uint32_t ny_inv = (uint32_t)(((1u << 20) + (uint32_t)ny_full - 1u) / (uint32_t)ny_full);
+        const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
+        for (int base = 0; base < ncell; base += 64) {
+            PG_LANE_VAR(uint32_t, bad);
+            PG_FOR_LANES(l) {
+                const int cidx = base + l;
+                PG_LV(bad, l) = 0;
+                if (cidx < ncell) {
+                    const int cx = (int)(((uint32_t)cidx * ny_inv) >> 20);
+                    const int cy = cidx - cx * ny_full;
+                    const int type = get_obj(win_lx + cx, win_ly + cy);
+                    uint32_t v = CELL_NONE;
+                    if (type != INVALID_OBJ && type != SPACE) {
+                        const int theme = Game::theme_for_grid_obj(*this, type);
+                        RectD r2 = get_screen_rect((float)(win_lx + cx), (float)(win_ly + cy + 1), 1, 1, RENDER_EPS);
+                        const RectD r2_in = r2;
+                        const int im = resolve_image(type, theme, 0.0f, 0.0f, r2);
+                        if (im >= 0) {
+                            const ImgDesc imd = d.assets->img[im];
+                            const bool same_rect = r2.x == r2_in.x && r2.y == r2_in.y && r2.w == r2_in.w && r2.h == r2_in.h;
+                            if (same_rect && (int)imd.w == ref_w && (int)imd.h == ref_h && imd.off < 0x7fffffffu) v = imd.off | (imd.opaque ? (1u << 31) : 0u);
+                            else PG_LV(bad, l) = 1;
+                        }
+                    }
+                    lds->cellimg[cidx] = v;
+                }
+            }
+            ok = ok && PG_BALLOT(l, PG_LV(bad, l) != 0) == 0;
+        }
+        PG_SYNC();
+        return ok;
+    }
+    // composites cell (ce, re) onto pixel value `px` (lane-local)
+    PG_DEV bool pull_fetch(uint32_t ce, uint32_t re, int ny_full, int ref_w, uint32_t &tex, bool &opaque) const {
+        if (!((ce & re) >> 31)) return false;
+        const uint32_t cell = lds->cellimg[((ce >> 12) & 0x3fu) * (uint32_t)ny_full + ((re >> 12) & 0x3fu)];
+        if (cell == CELL_NONE) return false;
+        opaque = (cell >> 31) != 0;
+        tex = d.pixels[(cell & 0x7fffffffu) + (re & 0xfffu) * (uint32_t)ref_w + (ce & 0xfffu)];
+        return true;
+    }
+    PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam) {
+        const int ref_w = d.assets->ref_w;
+        const int nseam = pg_popc64(colseam);
+        // stage 1: (c0, r0), lane = screen column, 8 rows of fetches in flight; stage 2: (c0, r1) on doubly covered rows
+        for (int slot_r = 0; slot_r < 2; slot_r++) {
+            for (int yb = row0; yb < row1; yb += 8) {
+                if (slot_r == 1 && ((rowseam >> yb) & 0xffull) == 0) continue;
+                PG_FOR_LANES(l) {
+                    const uint32_t ce = lds->ci[0][l];
+                    uint32_t tex[8];
+                    bool hit[8], opq[8];
+                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                        opq[j] = false;
+                        tex[j] = 0;
+                        hit[j] = pull_fetch(ce, lds->ri[slot_r][yb + j], ny_full, ref_w, tex[j], opq[j]);
+                    }
+                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                        if (hit[j]) {
+                            uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];
+                            *dp = opq[j] ? tex[j] : blend(tex[j], *dp, 256, 255u);
+                        }
+                    }
+                }
+                PG_SYNC();
+            }
+        }
+        if (nseam == 0) return;
+        // stage 3: (c1, r0) and stage 4: (c1, r1): only the doubly covered columns; pixels (seam column k, row) are
+        // laid out linearly over the lanes
+        const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)nseam - 1u) / (uint32_t)nseam);
+        const int npx = nseam * BAND_ROWS;
+        for (int slot_r = 0; slot_r < 2; slot_r++) {
+            if (slot_r == 1 && ((rowseam >> row0) & ((1ull << BAND_ROWS) - 1ull)) == 0) continue;
+            for (int base = 0; base < npx; base += 512) {
+                PG_FOR_LANES(l) {
+                    uint32_t tex[8];
+                    int fbi[8];
+                    bool opq[8];
+                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                        const int p = base + j * 64 + l;
+                        fbi[j] = -1;
+                        tex[j] = 0;
+                        opq[j] = false;
+                        if (p < npx) {
+                            const int yl = (int)(((uint32_t)p * inv) >> 20);
+                            const int x = (int)lds->seamcols[p - yl * nseam];
+                            if (pull_fetch(lds->ci[1][x], lds->ri[slot_r][row0 + yl], ny_full, ref_w, tex[j], opq[j])) fbi[j] = yl * RES_W + x;
+                        }
+                    }
+                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                        if (fbi[j] >= 0) fb[fbi[j]] = opq[j] ? tex[j] : blend(tex[j], fb[fbi[j]], 256, 255u);
+                    }
+                }
+                PG_SYNC();
+            }
+        }
     }
 
     // ---- command execution ----------------------------------------------------------------------------------
@@ -451,6 +613,9 @@ struct Renderer {
         const bool use_axes = nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
         int ix_ref = 0, iy_ref = 0;
         if (use_axes) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);
+        uint64_t colseam = 0, rowseam = 0;
+        const bool pull = use_axes && nx * ny_full <= 1024 && !(d.debug_flags & 1024) &&
+                          build_pull_tables(win_lx, nx, win_ly, ny_full, ix_ref, iy_ref, colseam, rowseam);
 
         // ---- passes -------------------------------------------------------------------------------------------------
         for (int band = 0; band < NUM_BANDS; band++) {
@@ -485,7 +650,8 @@ struct Renderer {
             const int ncell = (ny > 0 && nx > 0) ? nx * ny : 0;
             const uint32_t ny_inv = ny > 0 ? (uint32_t)(((1u << 20) + (uint32_t)ny - 1u) / (uint32_t)ny) : 0u;
             if (ncell > 4096) fail(PGE_ASSERT);
-            for (int base = 0; base < ((d.debug_flags & 2) ? 0 : ncell); base += 64) {
+            if (pull && !(d.debug_flags & 2)) draw_tiles_pull(ny_full, colseam, rowseam);
+            for (int base = 0; base < ((pull || (d.debug_flags & 2)) ? 0 : ncell); base += 64) {
                 CmdRegs r;
                 PG_FOR_LANES(l) {
                     const int cidx = base + l;

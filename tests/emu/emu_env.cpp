@@ -51,10 +51,9 @@ static void run_all(EmuVec *v, int mode) {
         else if (tier == 1) run_env<Game, Game::ENT_CAP_T1>(v, e, mode);
         else run_env<Game, Game::ENT_CAP_T2>(v, e, mode);
     }
-    static uint32_t fb[BAND_ROWS * RES_W];
-    static uint32_t ax[128];
+    static RenderLds rlds;
     for (int e = 0; e < v->n; e++) {  // "render kernel": one wave per env
-        Renderer<Game> r(v->d, e, fb, ax);
+        Renderer<Game> r(v->d, e, &rlds);
         r.render_env();
     }
 }
@@ -198,11 +197,10 @@ int emu_set_state(void *h, int env, const char *data, int length) {
     v->pls[env] = s.hdr.prev_level_seed;
     v->plc[env] = (uint8_t)s.hdr.level_complete;
     v->ls[env] = s.hdr.current_level_seed;
-    static uint32_t fb[BAND_ROWS * RES_W];
-    static uint32_t ax[128];
+    static RenderLds rlds;
 #define PG_X(Game)                            \
     if (v->game_id == Game::GAME_ID) {        \
-        Renderer<Game> r(v->d, env, fb, ax);  \
+        Renderer<Game> r(v->d, env, &rlds);   \
         r.render_env();                       \
     }
     PG_FOR_EACH_GAME(PG_X)

@@ -44,7 +44,7 @@ def test_emulated_shard_equals_slice_of_whole():
 
 def test_emulated_num_levels_and_easy_mode():
     acts = action_stream(4, 80, seed=9)
-    for kw in (dict(num_levels=3, start_level=17), dict(distribution_mode=0), dict(use_backgrounds=False), dict(restrict_themes=True)):
+    for kw in (dict(num_levels=3, start_level=17), dict(distribution_mode=0), dict(use_backgrounds=False), dict(restrict_themes=True), dict(center_agent=False)):
         a = rollout(oracle_env.OracleEnv(4, "coinrun", rand_seed=2, **kw), acts)
         b = rollout(emu_harness.EmuEnv(4, "coinrun", rand_seed=2, **kw), acts)
         assert_rollouts_equal(a, b, str(kw))
