@@ -41,7 +41,7 @@ PG_DEV uint32_t cmd_aux(int src_w, bool mirrored, bool opaque, int io) {
 
 // LDS arena of one render workgroup (one wave)
 struct RenderLds {
-    uint32_t fb[BAND_ROWS * RES_W];  // the band being rasterized, 0xffRRGGBB
+    uint32_t fb[BAND_ROWS * RES_W + 64];  // the band being rasterized, 0xffRRGGBB (+ a dump row for masked-off lanes)
     uint32_t ax[128];                // per-column / per-row tile geometry (setup_tile_axes)
     uint32_t ci[2][64];              // screen column -> the (at most two) cell columns covering it
     uint32_t ri[2][64];              // screen row    -> the (at most two) cell rows covering it
@@ -295,14 +295,16 @@ struct Renderer {
         PG_SYNC();
         return ok;
     }
-    // composites cell (ce, re) onto pixel value `px` (lane-local)
+    // texel of cell (ce, re) for one pixel, branch-free: lanes without a cell fetch atlas word 0 and report no hit
+    // (per-lane `if`s around memory operations cost exec-mask juggling on the CU's single scalar unit)
     PG_DEV bool pull_fetch(uint32_t ce, uint32_t re, int ny_full, int ref_w, uint32_t &tex, bool &opaque) const {
-        if (!((ce & re) >> 31)) return false;
-        const uint32_t cell = lds->cellimg[((ce >> 12) & 0x3fu) * (uint32_t)ny_full + ((re >> 12) & 0x3fu)];
-        if (cell == CELL_NONE) return false;
+        const bool valid = ((ce & re) >> 31) != 0;
+        const uint32_t cell = lds->cellimg[((ce >> 12) & 0x1fu) * (uint32_t)ny_full + ((re >> 12) & 0x1fu)];
+        const bool hit = valid && cell != CELL_NONE;
         opaque = (cell >> 31) != 0;
-        tex = d.pixels[(cell & 0x7fffffffu) + (re & 0xfffu) * (uint32_t)ref_w + (ce & 0xfffu)];
-        return true;
+        const uint32_t addr = (cell & 0x7fffffffu) + (re & 0xfffu) * (uint32_t)ref_w + (ce & 0xfffu);
+        tex = d.pixels[hit ? addr : 0u];
+        return hit;
     }
     PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam) {
         const int ref_w = d.assets->ref_w;
@@ -321,10 +323,10 @@ struct Renderer {
                         hit[j] = pull_fetch(ce, lds->ri[slot_r][yb + j], ny_full, ref_w, tex[j], opq[j]);
                     }
                     _Pragma("unroll") for (int j = 0; j < 8; j++) {
-                        if (hit[j]) {
-                            uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];
-                            *dp = opq[j] ? tex[j] : blend(tex[j], *dp, 256, 255u);
-                        }
+                        uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];  // this lane owns the pixel
+                        const uint32_t old = *dp;
+                        const uint32_t over = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
+                        *dp = hit[j] ? over : old;
                     }
                 }
                 PG_SYNC();
@@ -344,17 +346,16 @@ struct Renderer {
                     bool opq[8];
                     _Pragma("unroll") for (int j = 0; j < 8; j++) {
                         const int p = base + j * 64 + l;
-                        fbi[j] = -1;
-                        tex[j] = 0;
-                        opq[j] = false;
-                        if (p < npx) {
-                            const int yl = (int)(((uint32_t)p * inv) >> 20);
-                            const int x = (int)lds->seamcols[p - yl * nseam];
-                            if (pull_fetch(lds->ci[1][x], lds->ri[slot_r][row0 + yl], ny_full, ref_w, tex[j], opq[j])) fbi[j] = yl * RES_W + x;
-                        }
+                        const bool in = p < npx;
+                        const int pc = in ? p : 0;
+                        const int yl = (int)(((uint32_t)pc * inv) >> 20);
+                        const int x = (int)lds->seamcols[pc - yl * nseam];
+                        const bool hit = pull_fetch(lds->ci[1][x], lds->ri[slot_r][row0 + yl], ny_full, ref_w, tex[j], opq[j]) && in;
+                        fbi[j] = hit ? yl * RES_W + x : BAND_ROWS * RES_W + l;  // masked-off lanes use the dump row
                     }
                     _Pragma("unroll") for (int j = 0; j < 8; j++) {
-                        if (fbi[j] >= 0) fb[fbi[j]] = opq[j] ? tex[j] : blend(tex[j], fb[fbi[j]], 256, 255u);
+                        const uint32_t old = fb[fbi[j]];
+                        fb[fbi[j]] = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
                     }
                 }
                 PG_SYNC();
@@ -395,21 +396,21 @@ struct Renderer {
         const int y1 = (c.ty1 + c.h) < row1 ? (c.ty1 + c.h) : row1;
         if (c.w > 32) {
             for (int yb = y0; yb < y1; yb += 8) {
+                const int last = y1 - 1;  // rows past the end re-sample the last row into the dump row (no per-row branches)
                 PG_FOR_LANES(l) {
-                    if (l < c.w) {
-                        const int sxp = (int)((c.basex + (uint32_t)l * c.ix) >> 16);
-                        const int scol = mirrored ? (sw - 1 - sxp) : sxp;
-                        uint32_t tex[8];
-                        _Pragma("unroll") for (int j = 0; j < 8; j++) {
-                            tex[j] = 0;
-                            if (yb + j < y1) tex[j] = src[(int)((c.srcy0 + (uint32_t)(yb + j - c.ty1) * c.iy) >> 16) * sw + scol];
-                        }
-                        _Pragma("unroll") for (int j = 0; j < 8; j++) {
-                            if (yb + j < y1) {
-                                uint32_t *dp = &fb[(yb + j - row0) * RES_W + c.tx1 + l];
-                                *dp = opaque ? tex[j] : blend(tex[j], *dp, io, ca);
-                            }
-                        }
+                    const bool in = l < c.w;
+                    const int lc = in ? l : 0;
+                    const int sxp = (int)((c.basex + (uint32_t)lc * c.ix) >> 16);
+                    const int scol = mirrored ? (sw - 1 - sxp) : sxp;
+                    uint32_t tex[8];
+                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                        const int y = (yb + j) < last ? (yb + j) : last;
+                        tex[j] = src[(int)((c.srcy0 + (uint32_t)(y - c.ty1) * c.iy) >> 16) * sw + scol];
+                    }
+                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                        const bool ok = in && (yb + j) <= last;
+                        uint32_t *dp = &fb[ok ? ((yb + j - row0) * RES_W + c.tx1 + l) : (BAND_ROWS * RES_W + l)];
+                        *dp = opaque ? tex[j] : blend(tex[j], *dp, io, ca);
                     }
                 }
             }
@@ -451,17 +452,17 @@ struct Renderer {
         PG_FOR_LANES(l) {
             const int lx = l & 7, ly = l >> 3;
             _Pragma("unroll") for (int g = 0; g < 8; g++) {
-                PG_LA(fbi, g, l) = -1;
+                PG_LA(fbi, g, l) = BAND_ROWS * RES_W + l;  // dump row
                 PG_LA(tex, g, l) = 0;
-                if (g < count) {
+                if (g < count) {  // wave-uniform
                     const int y = c[g].ty1 + ly;
-                    if (lx < c[g].w && ly < c[g].h && y >= row0 && y < row1) {
-                        const int sw = cmd_src_w(c[g].aux);
-                        const int sxp = (int)((c[g].basex + (uint32_t)lx * c[g].ix) >> 16);
-                        const int syp = (int)((c[g].srcy0 + (uint32_t)ly * c[g].iy) >> 16);
-                        PG_LA(tex, g, l) = d.pixels[c[g].src + (uint32_t)(syp * sw + (cmd_mirrored(c[g].aux) ? (sw - 1 - sxp) : sxp))];
-                        PG_LA(fbi, g, l) = (y - row0) * RES_W + c[g].tx1 + lx;
-                    }
+                    const bool in = lx < c[g].w && ly < c[g].h && y >= row0 && y < row1;
+                    const int sw = cmd_src_w(c[g].aux);
+                    const int sxp = (int)((c[g].basex + (uint32_t)lx * c[g].ix) >> 16);
+                    const int syp = (int)((c[g].srcy0 + (uint32_t)ly * c[g].iy) >> 16);
+                    const uint32_t addr = c[g].src + (uint32_t)(syp * sw + (cmd_mirrored(c[g].aux) ? (sw - 1 - sxp) : sxp));
+                    PG_LA(tex, g, l) = d.pixels[in ? addr : 0u];  // branch-free: masked-off lanes fetch word 0
+                    PG_LA(fbi, g, l) = in ? ((y - row0) * RES_W + c[g].tx1 + lx) : (BAND_ROWS * RES_W + l);
                 }
             }
         }
@@ -472,7 +473,7 @@ struct Renderer {
                 const bool opaque = cmd_opaque(c[g].aux);
                 PG_FOR_LANES(l) {
                     const int fi = PG_LA(fbi, g, l);
-                    if (fi >= 0) fb[fi] = opaque ? PG_LA(tex, g, l) : blend(PG_LA(tex, g, l), fb[fi], io, ca);
+                    fb[fi] = opaque ? PG_LA(tex, g, l) : blend(PG_LA(tex, g, l), fb[fi], io, ca);
                 }
             }
         }
