@@ -7,7 +7,7 @@
  * literals promote, results narrow on assignment); build with -ffp-contract=off (no FMA), matching
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
- * Games restated so far: coinrun, bigfish.
+ * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects).
  */
 #include "procgen_oracle.h"
 
@@ -37,7 +37,11 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_COINRUN = 5 };
+enum { GAME_BIGFISH = 0, GAME_COINRUN = 5, GAME_MAZE = 11 };
+
+/* maze ids: reference src/games/maze.cpp:8 */
+#define MZ_GOAL 2
+#define MAZE_OFFSET 1 /* src/mazegen.h:14 */
 
 /* bigfish ids: reference src/games/bigfish.cpp:8-18 */
 #define BF_FISH 2
@@ -311,6 +315,18 @@ static void assets_build(int game_id) {
                                       "water_backgrounds/underwater3.png"};
         a->n_bg = 7;
         for (int i = 0; i < 7; i++) a->bg_img[i] = assets_add(a, WATER[i], 1);
+    } else if (game_id == GAME_MAZE) { /* maze.cpp:26-38 */
+        assets_type(a, WALL_OBJ, "kenney/Ground/Sand/sandCenter.png");
+        assets_type(a, MZ_GOAL, "misc_assets/cheese.png");
+        assets_type(a, PLAYER, "kenney/Enemies/mouse_move.png");
+        /* topdown_backgrounds, reference src/resources.cpp:900-911 */
+        static const char *TOPDOWN[] = {"topdown_backgrounds/floortiles.png", "topdown_backgrounds/backgrounddetailed1.png",
+                                        "topdown_backgrounds/backgrounddetailed2.png", "topdown_backgrounds/backgrounddetailed3.png",
+                                        "topdown_backgrounds/backgrounddetailed4.png", "topdown_backgrounds/backgrounddetailed5.png",
+                                        "topdown_backgrounds/backgrounddetailed6.png", "topdown_backgrounds/backgrounddetailed7.png",
+                                        "topdown_backgrounds/backgrounddetailed8.png"};
+        a->n_bg = 9;
+        for (int i = 0; i < 9; i++) a->bg_img[i] = assets_add(a, TOPDOWN[i], 1);
     } else {
         fatal("game not restated in the oracle");
     }
@@ -319,6 +335,7 @@ static void assets_build(int game_id) {
 int pgo_game_id(const char *name) {
     if (strcmp(name, "coinrun") == 0) return GAME_COINRUN;
     if (strcmp(name, "bigfish") == 0) return GAME_BIGFISH;
+    if (strcmp(name, "maze") == 0) return GAME_MAZE;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -387,6 +404,8 @@ typedef struct {
     /* BigFish: bigfish.cpp:22-23 */
     int fish_eaten;
     float r_inc;
+    /* MazeGame: maze.cpp:12-14 */
+    int maze_dim, world_dim;
     /* CoinRun */
     float last_agent_y;
     int wall_theme, has_support, facing_right, is_on_crate;
@@ -692,6 +711,9 @@ static void hook_set_action_xy(Game *g, int move_act) {
         }
     } else {
         g->action_vrot = 0; /* BAG:658-662 */
+        if (g->game_id == GAME_MAZE) { /* maze.cpp:99-103 */
+            if (g->action_vx != 0) g->action_vy = 0;
+        }
     }
 }
 
@@ -813,6 +835,86 @@ static void game_step(Game *g) {
         Ent *agent = &g->pool[g->agent];
         if (g->action_vx > 0) agent->is_reflected = 0;
         if (g->action_vx < 0) agent->is_reflected = 1;
+    } else if (g->game_id == GAME_MAZE) { /* maze.cpp:105-124 */
+        Ent *agent = &g->pool[g->agent];
+        if (g->action_vx > 0) agent->is_reflected = 1;
+        if (g->action_vx < 0) agent->is_reflected = 0;
+        int ix = (int)agent->x, iy = (int)agent->y;
+        if (get_obj(g, ix, iy) == MZ_GOAL) {
+            set_obj(g, ix, iy, SPACE);
+            g->reward += 10.0f;
+            g->level_complete = 1;
+        }
+        g->done = g->reward > 0;
+    }
+}
+
+/* ---- MazeGen: reference src/mazegen.cpp (Kruskal over std::set cell sets) ----
+ * The std::set objects only carry connectivity, so they are restated as one label per cell; walls.erase keeps the
+ * vector order, restated with an order-preserving removal. */
+#define MG_MAX_DIM 33
+typedef struct {
+    int maze_dim, array_dim;
+    int grid[MG_MAX_DIM * MG_MAX_DIM]; /* Grid<int>, index y*array_dim+x */
+    int label[MG_MAX_DIM * MG_MAX_DIM]; /* cell_sets_idxs */
+    int is_free[MG_MAX_DIM * MG_MAX_DIM]; /* free_cell_set membership */
+    int free_cells[MG_MAX_DIM * MG_MAX_DIM];
+    int num_free_cells;
+} MazeGen;
+
+static void mg_set_free_cell(MazeGen *m, int x, int y) { /* mazegen.cpp:26-34 */
+    m->grid[(y + MAZE_OFFSET) * m->array_dim + x + MAZE_OFFSET] = SPACE;
+    int cell = m->maze_dim * y + x;
+    if (!m->is_free[cell]) {
+        m->free_cells[m->num_free_cells] = cell;
+        m->is_free[cell] = 1;
+        m->num_free_cells += 1;
+    }
+}
+
+static void mg_generate_maze(MazeGen *m, Rng *r) { /* mazegen.cpp:112-187 */
+    int md = m->maze_dim, ad = m->array_dim;
+    for (int i = 0; i < ad * ad; i++) m->grid[i] = WALL_OBJ;
+    m->grid[MAZE_OFFSET * ad + MAZE_OFFSET] = 0;
+    m->num_free_cells = 0;
+    memset(m->is_free, 0, sizeof(m->is_free));
+    for (int i = 0; i < md * md; i++) m->label[i] = i;
+    static int wx1[1024], wy1[1024], wx2[1024], wy2[1024];
+    int nw = 0;
+    for (int i = 1; i < md; i += 2)
+        for (int j = 0; j < md; j += 2)
+            if (i > 0 && i < md - 1) { wx1[nw] = i - 1; wy1[nw] = j; wx2[nw] = i + 1; wy2[nw] = j; nw++; }
+    for (int i = 0; i < md; i += 2)
+        for (int j = 1; j < md; j += 2)
+            if (j > 0 && j < md - 1) { wx1[nw] = i; wy1[nw] = j - 1; wx2[nw] = i; wy2[nw] = j + 1; nw++; }
+    while (nw > 0) {
+        int n = rng_randn(r, nw);
+        int x1 = wx1[n], y1 = wy1[n], x2 = wx2[n], y2 = wy2[n];
+        int s0_idx = m->label[md * y1 + x1];
+        int s1_idx = m->label[md * y2 + x2];
+        int x0 = (x1 + x2) / 2, y0 = (y1 + y2) / 2;
+        int center = md * y0 + x0;
+        int can_remove = (m->grid[(y0 + MAZE_OFFSET) * ad + x0 + MAZE_OFFSET] == WALL_OBJ) && (s0_idx != s1_idx);
+        if (can_remove) {
+            mg_set_free_cell(m, x1, y1);
+            mg_set_free_cell(m, x0, y0);
+            mg_set_free_cell(m, x2, y2);
+            for (int i = 0; i < md * md; i++)
+                if (m->label[i] == s0_idx) m->label[i] = s1_idx;
+            m->label[center] = s1_idx;
+        }
+        for (int k = n; k < nw - 1; k++) { wx1[k] = wx1[k + 1]; wy1[k] = wy1[k + 1]; wx2[k] = wx2[k + 1]; wy2[k] = wy2[k + 1]; }
+        nw--;
+    }
+}
+
+static void mg_place_objects(MazeGen *m, Rng *r, int start_obj, int num_objs) { /* mazegen.cpp:292-306 */
+    for (int j = 0; j < num_objs; j++) {
+        int k = rng_randn(r, m->num_free_cells);
+        while (m->free_cells[k] == -1 || m->free_cells[k] == 0) k = rng_randn(r, m->num_free_cells);
+        int coin_cell = m->free_cells[k];
+        m->free_cells[k] = -1;
+        m->grid[(coin_cell / m->maze_dim + MAZE_OFFSET) * m->array_dim + coin_cell % m->maze_dim + MAZE_OFFSET] = start_obj + j;
     }
 }
 
@@ -944,6 +1046,14 @@ static void cr_generate_coin_to_the_right(Game *g) { /* coinrun.cpp:265-414 */
 }
 
 static void bag_game_reset(Game *g) { /* BAG:758-797 */
+    if (g->game_id == GAME_MAZE) { /* choose_world_dim maze.cpp:40-53 */
+        int dm = g->opt.distribution_mode;
+        if (dm == 0) g->world_dim = 15;
+        else if (dm == 1) g->world_dim = 25;
+        else if (dm == 10) g->world_dim = 31;
+        g->main_width = g->world_dim;
+        g->main_height = g->world_dim;
+    }
     if (!(g->main_width > 0 && g->main_height > 0)) fatal("fassert main dims (BAG:760)");
     g->bg_pct_x = rng_rand01(&g->rand_gen);
     g->grid_w = g->main_width;
@@ -1008,6 +1118,32 @@ static void game_reset(Game *g) {
         agent->rx = start_r;
         agent->ry = start_r;
         agent->y = 1 + agent->ry;
+    } else if (g->game_id == GAME_MAZE) { /* maze.cpp:55-97 */
+        static MazeGen mg;
+        Ent *agent = &g->pool[g->agent];
+        g->grid_step = 1;
+        g->maze_dim = rng_randn(&g->rand_gen, (g->world_dim - 1) / 2) * 2 + 3;
+        int margin = (g->world_dim - g->maze_dim) / 2;
+        mg.maze_dim = g->maze_dim;
+        mg.array_dim = g->maze_dim + 2;
+        g->center_agent = g->opt.distribution_mode == 10;
+        agent->rx = (float).5;
+        agent->ry = (float).5;
+        agent->x = (float)(margin + .5);
+        agent->y = (float)(margin + .5);
+        mg_generate_maze(&mg, &g->rand_gen);
+        mg_place_objects(&mg, &g->rand_gen, MZ_GOAL, 1);
+        for (int i = 0; i < g->main_width * g->main_height; i++) g->grid[i] = WALL_OBJ;
+        for (int i = 0; i < g->maze_dim; i++)
+            for (int j = 0; j < g->maze_dim; j++) set_obj(g, margin + i, margin + j, mg.grid[(j + MAZE_OFFSET) * mg.array_dim + i + MAZE_OFFSET]);
+        if (margin > 0) {
+            for (int i = 0; i < g->maze_dim + 2; i++) {
+                set_obj(g, margin - 1, margin + i - 1, WALL_OBJ);
+                set_obj(g, margin + g->maze_dim, margin + i - 1, WALL_OBJ);
+                set_obj(g, margin + i - 1, margin - 1, WALL_OBJ);
+                set_obj(g, margin + i - 1, margin + g->maze_dim, WALL_OBJ);
+            }
+        }
     }
 }
 
@@ -1315,6 +1451,12 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->timeout = 6000;
         g->main_width = 20;
         g->main_height = 20;
+    } else if (game_id == GAME_MAZE) { /* maze.cpp:16-24 */
+        g->timeout = 500;
+        g->random_agent_start = 0;
+        g->has_useful_vel_info = 0;
+        g->out_of_bounds_object = WALL_OBJ;
+        g->visibility = 8.0f;
     }
 }
 

@@ -83,6 +83,12 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(2, {"misc_assets/fishTile_074.png", "misc_assets/fishTile_078.png", "misc_assets/fishTile_080.png"});
         for (const char *n : {"water1", "water2", "water3", "water4", "underwater1", "underwater2", "underwater3"})
             backgrounds->push_back(std::string("water_backgrounds/") + n + ".png");
+    } else if (game_id == GAME_MAZE) {  // reference src/games/maze.cpp:26-38, src/resources.cpp:900-911
+        add_themes(51, {"kenney/Ground/Sand/sandCenter.png"});
+        add_themes(2, {"misc_assets/cheese.png"});
+        add_themes(0, {"kenney/Enemies/mouse_move.png"});
+        backgrounds->push_back("topdown_backgrounds/floortiles.png");
+        for (int k = 1; k <= 8; k++) backgrounds->push_back("topdown_backgrounds/backgrounddetailed" + std::to_string(k) + ".png");
     } else {
         return false;
     }

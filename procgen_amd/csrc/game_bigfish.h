@@ -47,6 +47,9 @@ struct BigFish {
         G.lvl_rand_idx = MT_N;
     }
 
+    template <class E>
+    PG_DEV static void choose_world_dim(E &) {}  // BAG:377-378
+
     // ---- physics hooks: all BasicAbstractGame defaults -------------------------------------------------------
     template <class E>
     PG_DEV static bool is_blocked(E &e, int, int target, bool) {  // BAG:485-492

@@ -71,6 +71,9 @@ struct CoinRun {
         G.lvl_rand_idx = MT_N;
     }
 
+    template <class E>
+    PG_DEV static void choose_world_dim(E &) {}  // BAG:377-378
+
     // ---- physics hooks -----------------------------------------------------------------------------------
     template <class E>
     PG_DEV static bool is_blocked(E &e, int src_type, int target, bool) {  // BAG:485-492 + coinrun.cpp:204-211

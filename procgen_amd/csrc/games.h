@@ -2,5 +2,6 @@
 #pragma once
 #include "game_bigfish.h"
 #include "game_coinrun.h"
+#include "game_maze.h"
 
-#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish)
+#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze)

@@ -81,11 +81,24 @@ PG_DEV float clip_abs(float x, float y) {                                   // r
 }
 
 // ---- LDS arena of one workgroup ---------------------------------------------------------------------------
+struct NoScratch {};
+
+// a game may declare `typedef X Scratch;` for LDS it needs during level generation (e.g. MazeScratch)
+template <class Game, class = void>
+struct GameScratch {
+    typedef NoScratch type;
+};
+template <class Game>
+struct GameScratch<Game, decltype((void)sizeof(typename Game::Scratch))> {
+    typedef typename Game::Scratch type;
+};
+
 template <class Game, int CAP>
 struct Lds {
     uint32_t ent[EF_COUNT * CAP];
     uint32_t tmp[64];
     alignas(16) typename Game::cell_t grid[(Game::MAX_CELLS + 15) & ~15];
+    typename GameScratch<Game>::type scratch;
 };
 
 template <class Game, int CAP>
@@ -742,6 +755,7 @@ struct Env {
 
     // BasicAbstractGame::game_reset BAG:758-797
     PG_DEV void bag_game_reset() {
+        Game::choose_world_dim(*this);
         if (!(G.main_width > 0 && G.main_height > 0)) fail(PGE_ASSERT);
         G.bg_pct_x = rand01();
         G.background_index = randn(d.assets->n_bg);

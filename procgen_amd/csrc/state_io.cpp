@@ -114,6 +114,7 @@ bool read_rng(Reader &r, int *seeded, uint32_t *mt, int *idx) {
 
 bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h) {
     if (game_id == GAME_BIGFISH) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64
+    if (game_id == GAME_MAZE) return h.initial_reset_complete ? opt.distribution_mode == MemoryMode : opt.center_agent != 0;  // maze.cpp:66
     return opt.center_agent != 0;
 }
 
@@ -238,6 +239,9 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
     } else if (game_id == GAME_BIGFISH) {  // reference src/games/bigfish.cpp:109-113
         w.i(h.gsi0);
         w.f(h.gsf0);
+    } else if (game_id == GAME_MAZE) {  // reference src/games/maze.cpp:126-130
+        w.i(h.gsi0);
+        w.i(h.gsi1);
     }
     w.i(END_OF_BUFFER);
     if (!w.ok) {
@@ -367,6 +371,9 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
     } else if (game_id == GAME_BIGFISH) {
         h.gsi0 = r.i();
         h.gsf0 = r.f();
+    } else if (game_id == GAME_MAZE) {
+        h.gsi0 = r.i();
+        h.gsi1 = r.i();
     }
     if (r.i() != END_OF_BUFFER || !r.ok) return bad("fassert failed 'b.read_int() == END_OF_BUFFER'");
     h.error = 0;

@@ -11,7 +11,7 @@ import pytest
 import emu_harness
 from helpers import rollout
 
-GAMES = ["coinrun", "bigfish"]
+GAMES = ["coinrun", "bigfish", "maze"]
 
 
 @pytest.mark.parametrize("game", GAMES)
