@@ -7,7 +7,7 @@
  * literals promote, results narrow on assignment); build with -ffp-contract=off (no FMA), matching
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
- * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects).
+ * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber.
  */
 #include "procgen_oracle.h"
 
@@ -37,7 +37,20 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_COINRUN = 5, GAME_MAZE = 11 };
+enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_MAZE = 11 };
+
+/* climber ids: reference src/games/climber.cpp:12-28 */
+#define CL_COIN 1
+#define CL_ENEMY 5
+#define CL_ENEMY1 6
+#define CL_ENEMY2 7
+#define CL_PLAYER_JUMP 9
+#define CL_PLAYER_RIGHT1 12
+#define CL_PLAYER_RIGHT2 13
+#define CL_WALL_MID 15
+#define CL_WALL_TOP 16
+#define CL_ENEMY_BARRIER 19
+#define CL_PATROL_RANGE 4.0f
 
 /* maze ids: reference src/games/maze.cpp:8 */
 #define MZ_GOAL 2
@@ -315,6 +328,28 @@ static void assets_build(int game_id) {
                                       "water_backgrounds/underwater3.png"};
         a->n_bg = 7;
         for (int i = 0; i < 7; i++) a->bg_img[i] = assets_add(a, WATER[i], 1);
+    } else if (game_id == GAME_CLIMBER) { /* climber.cpp:42-88 */
+        static const char *PCOL[] = {"Blue", "Green", "Grey", "Red"};
+        static const int ptypes[4] = {PLAYER, CL_PLAYER_JUMP, CL_PLAYER_RIGHT1, CL_PLAYER_RIGHT2};
+        static const char *pnames[4] = {"stand", "walk4", "walk1", "walk2"};
+        for (int k = 0; k < 4; k++)
+            for (int c = 0; c < 4; c++) {
+                snprintf(buf, sizeof buf, "platformer/player%s_%s.png", PCOL[c], pnames[k]);
+                assets_type(a, ptypes[k], buf);
+            }
+        assets_type(a, CL_WALL_TOP, "platformer/tileBlue_05.png");
+        assets_type(a, CL_WALL_TOP, "platformer/tileGreen_05.png");
+        assets_type(a, CL_WALL_TOP, "platformer/tileYellow_06.png");
+        assets_type(a, CL_WALL_TOP, "platformer/tileBrown_06.png");
+        assets_type(a, CL_WALL_MID, "platformer/tileBlue_08.png");
+        assets_type(a, CL_WALL_MID, "platformer/tileGreen_08.png");
+        assets_type(a, CL_WALL_MID, "platformer/tileYellow_09.png");
+        assets_type(a, CL_WALL_MID, "platformer/tileBrown_09.png");
+        assets_type(a, CL_ENEMY1, "platformer/enemySwimming_1.png");
+        assets_type(a, CL_ENEMY2, "platformer/enemySwimming_2.png");
+        assets_type(a, CL_COIN, "platformer/yellowCrystal.png");
+        a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
+        for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
     } else if (game_id == GAME_MAZE) { /* maze.cpp:26-38 */
         assets_type(a, WALL_OBJ, "kenney/Ground/Sand/sandCenter.png");
         assets_type(a, MZ_GOAL, "misc_assets/cheese.png");
@@ -336,6 +371,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "coinrun") == 0) return GAME_COINRUN;
     if (strcmp(name, "bigfish") == 0) return GAME_BIGFISH;
     if (strcmp(name, "maze") == 0) return GAME_MAZE;
+    if (strcmp(name, "climber") == 0) return GAME_CLIMBER;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -404,6 +440,8 @@ typedef struct {
     /* BigFish: bigfish.cpp:22-23 */
     int fish_eaten;
     float r_inc;
+    /* Climber: climber.cpp:32-38 (has_support, facing_right, wall_theme, gravity, air_control shared with CoinRun below) */
+    int coin_quota, coins_collected;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
     /* CoinRun */
@@ -481,7 +519,7 @@ static int hook_is_blocked(const Game *g, const Ent *src, int target, int is_hor
     (void)is_horizontal;
     if (target == WALL_OBJ) return 1; /* BAG:485-492 */
     if (target == g->out_of_bounds_object) return 1;
-    if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:204-211 */
+    if (g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) { /* coinrun.cpp:204-211, climber.cpp:136-143 */
         if (src->type == PLAYER && cr_is_wall(target)) return 1;
     }
     return 0;
@@ -500,7 +538,7 @@ static int hook_is_blocked_ents(Game *g, const Ent *src, const Ent *target, int 
     return hook_is_blocked(g, src, target->type, is_horizontal); /* BAG:494-496 */
 }
 static int hook_will_reflect(const Game *g, int src, int target) {
-    if (g->game_id == GAME_COINRUN) /* coinrun.cpp:140-142 */
+    if (g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) /* coinrun.cpp:140-142, climber.cpp:110-112 (same ids) */
         return (src == CR_ENEMY && (cr_is_wall(target) || target == CR_ENEMY_BARRIER));
     return 0; /* BAG:498-500 */
 }
@@ -508,6 +546,14 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
     if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:123-131 */
         if (obj->type == CR_ENEMY) g->done = 1;
         else if (obj->type == CR_SAW) g->done = 1;
+    } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:90-100 */
+        if (obj->type == CL_ENEMY) {
+            g->done = 1;
+        } else if (obj->type == CL_COIN) {
+            g->reward += 1.0f;
+            g->coins_collected += 1;
+            obj->will_erase = 1;
+        }
     } else if (g->game_id == GAME_BIGFISH) { /* bigfish.cpp:48-62 */
         Ent *agent = &g->pool[g->agent];
         if (obj->type == BF_FISH) {
@@ -709,6 +755,18 @@ static void hook_set_action_xy(Game *g, int move_act) {
         if (g->action_vy == 1) {
             if (!g->has_support) g->action_vy = 0;
         }
+    } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:268-288 */
+        Ent *agent = &g->pool[g->agent];
+        if (g->action_vy < 0) g->action_vy = 0;
+        if (g->action_vx > 0) g->facing_right = 1;
+        if (g->action_vx < 0) g->facing_right = 0;
+        int obj_below_1 = get_obj_from_floats(g, (float)(agent->x - (agent->rx - .01)), (float)(agent->y - (agent->ry + .01)));
+        int obj_below_2 = get_obj_from_floats(g, (float)(agent->x + (agent->rx - .01)), (float)(agent->y - (agent->ry + .01)));
+        int s1 = cr_is_wall(obj_below_1) || obj_below_1 == g->out_of_bounds_object;
+        int s2 = cr_is_wall(obj_below_2) || obj_below_2 == g->out_of_bounds_object;
+        g->has_support = s1 || s2;
+        if (g->has_support && g->action_vy == 1) g->action_vy = 1;
+        else g->action_vy = 0;
     } else {
         g->action_vrot = 0; /* BAG:658-662 */
         if (g->game_id == GAME_MAZE) { /* maze.cpp:99-103 */
@@ -731,6 +789,13 @@ static void hook_update_agent_velocity(Game *g) {
         if (!(g->has_support && g->action_vy > 0)) {
             agent->vy -= g->gravity;
             agent->vy = clip_abs(agent->vy, g->max_jump);
+        }
+    } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:114-126 */
+        float mixrate_x = g->has_support ? g->mixrate : (g->mixrate * g->air_control);
+        agent->vx = (1 - mixrate_x) * agent->vx + mixrate_x * g->maxspeed * g->action_vx;
+        if (g->action_vy > 0) agent->vy = g->max_jump;
+        if (!g->has_support) {
+            if (agent->vy > -2) agent->vy -= g->gravity;
         }
     } else { /* BAG:669-684 */
         float v_scale = 1.0f;
@@ -835,6 +900,24 @@ static void game_step(Game *g) {
         Ent *agent = &g->pool[g->agent];
         if (g->action_vx > 0) agent->is_reflected = 0;
         if (g->action_vx < 0) agent->is_reflected = 1;
+    } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:290-316 */
+        Ent *agent = &g->pool[g->agent];
+        if (g->action_vx > 0) agent->is_reflected = 0;
+        if (g->action_vx < 0) agent->is_reflected = 1;
+        for (int i = g->n_ents - 1; i >= 0; i--) {
+            Ent *ent = &g->pool[g->ents[i]];
+            if (ent->type == CL_ENEMY) {
+                if (ent->x > ent->climber_spawn_x + CL_PATROL_RANGE) ent->vx = (float)(-1 * fabs((double)ent->vx));
+                else if (ent->x < ent->climber_spawn_x - CL_PATROL_RANGE) ent->vx = (float)fabs((double)ent->vx);
+                ent->image_type = g->cur_time / 5 % 2 == 0 ? CL_ENEMY1 : CL_ENEMY2;
+                ent->is_reflected = ent->vx < 0;
+            }
+        }
+        if (g->coin_quota == g->coins_collected) {
+            g->done = 1;
+            g->reward += 10.0f;
+            g->level_complete = 1;
+        }
     } else if (g->game_id == GAME_MAZE) { /* maze.cpp:105-124 */
         Ent *agent = &g->pool[g->agent];
         if (g->action_vx > 0) agent->is_reflected = 1;
@@ -1045,7 +1128,62 @@ static void cr_generate_coin_to_the_right(Game *g) { /* coinrun.cpp:265-414 */
     fill_elem(g, curr_x + 1, 0, g->main_width - curr_x - 1, g->main_height, CR_WALL_MID);
 }
 
+static void cl_generate_platforms(Game *g) { /* climber.cpp:171-228 */
+    Rng *r = &g->rand_gen;
+    int difficulty = rng_randn(r, 3);
+    int min_platforms = difficulty * difficulty + 1;
+    int max_platforms = (difficulty + 1) * (difficulty + 1) + 1;
+    int num_platforms = rng_randn(r, max_platforms - min_platforms + 1) + min_platforms;
+    g->coin_quota = 0;
+    g->coins_collected = 0;
+    int curr_x = rng_randn(r, g->main_width - 4) + 2;
+    int curr_y = 0;
+    int margin_x = 3;
+    float enemy_prob = g->opt.distribution_mode == 0 ? (float).2 : (float).5;
+    for (int i = 0; i < num_platforms; i++) {
+        int max_dy = (int)(g->max_jump * g->max_jump / (2 * g->gravity)); /* choose_delta_y climber.cpp:164-169 */
+        int min_dy = 3;
+        int delta_y = rng_randn(r, max_dy - min_dy + 1) + min_dy;
+        int can_spawn_enemy = (curr_x >= margin_x) && (curr_x <= g->main_width - margin_x);
+        if (can_spawn_enemy && (rng_rand01(r) < enemy_prob)) {
+            /* the two draws sit in different arguments of one call: g++ (x86-64) evaluates them right to left,
+             * i.e. the velocity sign first (pinned against the compiled reference) */
+            float evx = (float)(.15 * (rng_randn(r, 2) * 2 - 1));
+            float ey = (float)(curr_y + rng_randn(r, 2) + 2 + .5);
+            Ent *ent = push_entity(g, (float)(curr_x + .5), ey, evx, 0, (float).5, (float).5, CL_ENEMY);
+            ent->image_type = CL_ENEMY1;
+            ent->smart_step = 1;
+            ent->climber_spawn_x = (float)(curr_x + .5);
+            match_aspect_ratio(g, ent);
+        }
+        curr_y += delta_y;
+        int plat_len = 2 + rng_randn(r, 10);
+        int vx = rng_randn(r, 2) * 2 - 1;
+        if (curr_x < margin_x) vx = 1;
+        if (curr_x > g->main_width - margin_x) vx = -1;
+        int candidates[16], nc = 0;
+        for (int j = 0; j < plat_len; j++) {
+            int nx = curr_x + (j + 1) * vx;
+            if (nx <= 0 || nx >= g->main_width - 1) break;
+            candidates[nc++] = nx;
+            set_obj(g, nx, curr_y, CL_WALL_TOP);
+        }
+        if (rng_rand01(r) < .5 || i == num_platforms - 1) {
+            if (nc <= 0) fatal("fassert elems.size() > 0 (randgen.cpp:43)");
+            int coin_x = candidates[rng_randn(r, nc)];
+            push_entity(g, (float)(coin_x + .5), (float)(curr_y + 1.5), 0, 0, 0.3f, 0.3f, CL_COIN);
+            g->coin_quota += 1;
+        }
+        if (nc <= 0) fatal("fassert elems.size() > 0 (randgen.cpp:43)");
+        curr_x = candidates[rng_randn(r, nc)];
+    }
+}
+
 static void bag_game_reset(Game *g) { /* BAG:758-797 */
+    if (g->game_id == GAME_CLIMBER) { /* choose_world_dim climber.cpp:230-233 */
+        g->main_width = g->opt.distribution_mode == 0 ? 16 : 20;
+        g->main_height = 64;
+    }
     if (g->game_id == GAME_MAZE) { /* choose_world_dim maze.cpp:40-53 */
         int dm = g->opt.distribution_mode;
         if (dm == 0) g->world_dim = 15;
@@ -1118,6 +1256,25 @@ static void game_reset(Game *g) {
         agent->rx = start_r;
         agent->ry = start_r;
         agent->y = 1 + agent->ry;
+    } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:235-255 */
+        Ent *agent = &g->pool[g->agent];
+        g->gravity = 0.2f;
+        g->max_jump = 1.5;
+        g->air_control = 0.15f;
+        g->maxspeed = (float).5;
+        g->has_support = 0;
+        g->facing_right = 1;
+        agent->rx = (float).5;
+        agent->ry = (float).5;
+        agent->x = 1 + agent->rx;
+        agent->y = 1 + agent->ry;
+        choose_random_theme(g, agent);
+        g->wall_theme = rng_randn(&g->rand_gen, 4);
+        fill_elem(g, 0, 0, g->main_width, 1, CL_WALL_TOP);
+        fill_elem(g, 0, 0, 1, g->main_height, CL_WALL_MID);
+        fill_elem(g, g->main_width - 1, 0, 1, g->main_height, CL_WALL_MID);
+        fill_elem(g, 0, g->main_height - 1, g->main_width, 1, CL_WALL_MID);
+        cl_generate_platforms(g);
     } else if (g->game_id == GAME_MAZE) { /* maze.cpp:55-97 */
         static MazeGen mg;
         Ent *agent = &g->pool[g->agent];
@@ -1239,7 +1396,11 @@ static RectD adjust_rect(RectD b, RectD a) { /* src/qt-utils.h:12-19 */
 static void prepare_for_drawing(Game *g, float rect_height) { /* BAG:819-838 */
     g->center_x = (float)(g->main_width * .5);
     g->center_y = (float)(g->main_height * .5);
-    if (g->center_agent) {
+    if (g->center_agent && g->game_id == GAME_CLIMBER) { /* choose_center climber.cpp:261-265 */
+        g->center_x = (float)(g->main_width / 2.0);
+        g->center_y = (float)(g->pool[g->agent].y + g->main_width / 2.0 - 5 * g->pool[g->agent].ry);
+        g->visibility = (float)g->main_width;
+    } else if (g->center_agent) {
         g->center_x = g->pool[g->agent].x; /* choose_center BAG:664-667 */
         g->center_y = g->pool[g->agent].y;
     } else {
@@ -1254,6 +1415,16 @@ static void prepare_for_drawing(Game *g, float rect_height) { /* BAG:819-838 */
 }
 
 static int hook_image_for_type(const Game *g, int type) {
+    if (g->game_id == GAME_CLIMBER) { /* climber.cpp:145-159 */
+        if (type == PLAYER) {
+            const Ent *agent = &g->pool[g->agent];
+            if (!g->has_support) return CL_PLAYER_JUMP;
+            if (fabs((double)agent->vx) < .01 && g->action_vx == 0 && g->has_support) return PLAYER;
+            return (g->cur_time / 5 % 2 == 0 || !g->has_support) ? CL_PLAYER_RIGHT1 : CL_PLAYER_RIGHT2;
+        } else if (type == CL_ENEMY_BARRIER) {
+            return -1;
+        }
+    }
     if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:213-225 */
         if (type == PLAYER) {
             const Ent *agent = &g->pool[g->agent];
@@ -1266,7 +1437,7 @@ static int hook_image_for_type(const Game *g, int type) {
     return abs(type); /* BAG:438-440 */
 }
 static int hook_theme_for_grid_obj(const Game *g, int type) {
-    if (g->game_id == GAME_COINRUN && cr_is_wall(type)) return g->wall_theme; /* coinrun.cpp:133-138 */
+    if ((g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) && cr_is_wall(type)) return g->wall_theme; /* coinrun.cpp:133-138, climber.cpp:102-107 */
     return 0;
 }
 static RectD hook_adjusted_image_rect(const Game *g, int type, RectD rect) {
@@ -1451,6 +1622,8 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->timeout = 6000;
         g->main_width = 20;
         g->main_height = 20;
+    } else if (game_id == GAME_CLIMBER) { /* climber.cpp:40-42 */
+        g->out_of_bounds_object = CL_WALL_MID;
     } else if (game_id == GAME_MAZE) { /* maze.cpp:16-24 */
         g->timeout = 500;
         g->random_agent_start = 0;

@@ -83,6 +83,21 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(2, {"misc_assets/fishTile_074.png", "misc_assets/fishTile_078.png", "misc_assets/fishTile_080.png"});
         for (const char *n : {"water1", "water2", "water3", "water4", "underwater1", "underwater2", "underwater3"})
             backgrounds->push_back(std::string("water_backgrounds/") + n + ".png");
+    } else if (game_id == GAME_CLIMBER) {  // reference src/games/climber.cpp:42-88
+        const char *pcol[4] = {"Blue", "Green", "Grey", "Red"};
+        const int ptypes[4] = {0, 9, 12, 13};
+        const char *pnames[4] = {"stand", "walk4", "walk1", "walk2"};
+        for (int k = 0; k < 4; k++) {
+            std::vector<std::string> v;
+            for (auto c : pcol) v.push_back(std::string("platformer/player") + c + "_" + pnames[k] + ".png");
+            add_themes(ptypes[k], v);
+        }
+        add_themes(16, {"platformer/tileBlue_05.png", "platformer/tileGreen_05.png", "platformer/tileYellow_06.png", "platformer/tileBrown_06.png"});
+        add_themes(15, {"platformer/tileBlue_08.png", "platformer/tileGreen_08.png", "platformer/tileYellow_09.png", "platformer/tileBrown_09.png"});
+        add_themes(6, {"platformer/enemySwimming_1.png"});
+        add_themes(7, {"platformer/enemySwimming_2.png"});
+        add_themes(1, {"platformer/yellowCrystal.png"});
+        platform_backgrounds(backgrounds);
     } else if (game_id == GAME_MAZE) {  // reference src/games/maze.cpp:26-38, src/resources.cpp:900-911
         add_themes(51, {"kenney/Ground/Sand/sandCenter.png"});
         add_themes(2, {"misc_assets/cheese.png"});
@@ -184,7 +199,13 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
         t.type_theme_img[s.type][s.theme] = (int16_t)idx;
         if (t.type_num_themes[s.type] < s.theme + 1) t.type_num_themes[s.type] = (uint8_t)(s.theme + 1);
     }
-    {   // most common sprite size
+    int ref_type = -1;  // the game's wall tile, when it has one: its size is the renderer's reference cell-image size
+    if (game_id == GAME_COINRUN || game_id == GAME_CLIMBER) ref_type = 15;
+    if (game_id == GAME_MAZE) ref_type = 51;
+    if (ref_type >= 0 && t.type_theme_img[ref_type][0] >= 0) {
+        t.ref_w = t.img[t.type_theme_img[ref_type][0]].w;
+        t.ref_h = t.img[t.type_theme_img[ref_type][0]].h;
+    } else {   // most common sprite size
         std::map<std::pair<int, int>, int> hist;
         for (auto &sp : sprites) {
             const Image &im = imgs.images.at(sp.path);

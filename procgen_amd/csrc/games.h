@@ -1,7 +1,8 @@
 // games.h -- the game policies compiled into the kernels (one kernel instantiation per game).
 #pragma once
 #include "game_bigfish.h"
+#include "game_climber.h"
 #include "game_coinrun.h"
 #include "game_maze.h"
 
-#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze)
+#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber)

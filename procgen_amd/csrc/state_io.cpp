@@ -242,6 +242,14 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
     } else if (game_id == GAME_MAZE) {  // reference src/games/maze.cpp:126-130
         w.i(h.gsi0);
         w.i(h.gsi1);
+    } else if (game_id == GAME_CLIMBER) {  // reference src/games/climber.cpp:318-327
+        w.i(h.gsi1 ? 1 : 0);
+        w.i(h.gsi2 ? 1 : 0);
+        w.i(h.gsi3);
+        w.i(h.gsi4);
+        w.i(h.gsi0);
+        w.f(h.gsf1);
+        w.f(h.gsf2);
     }
     w.i(END_OF_BUFFER);
     if (!w.ok) {
@@ -374,6 +382,14 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
     } else if (game_id == GAME_MAZE) {
         h.gsi0 = r.i();
         h.gsi1 = r.i();
+    } else if (game_id == GAME_CLIMBER) {
+        h.gsi1 = r.i() > 0;
+        h.gsi2 = r.i() > 0;
+        h.gsi3 = r.i();
+        h.gsi4 = r.i();
+        h.gsi0 = r.i();
+        h.gsf1 = r.f();
+        h.gsf2 = r.f();
     }
     if (r.i() != END_OF_BUFFER || !r.ok) return bad("fassert failed 'b.read_int() == END_OF_BUFFER'");
     h.error = 0;
