@@ -7,7 +7,7 @@
  * literals promote, results narrow on assignment); build with -ffp-contract=off (no FMA), matching
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
- * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber.
+ * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner.
  */
 #include "procgen_oracle.h"
 
@@ -37,7 +37,17 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_MAZE = 11 };
+enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_MAZE = 11, GAME_MINER = 12 };
+
+/* miner ids: reference src/games/miner.cpp:11-19 */
+#define MN_BOULDER 1
+#define MN_DIAMOND 2
+#define MN_MOVING_BOULDER 3
+#define MN_MOVING_DIAMOND 4
+#define MN_ENEMY 5
+#define MN_EXIT 6
+#define MN_DIRT 9
+#define MN_OOB_WALL 10
 
 /* climber ids: reference src/games/climber.cpp:12-28 */
 #define CL_COIN 1
@@ -350,6 +360,15 @@ static void assets_build(int game_id) {
         assets_type(a, CL_COIN, "platformer/yellowCrystal.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_MINER) { /* miner.cpp:41-55 */
+        assets_type(a, PLAYER, "misc_assets/robot_greenDrive1.png");
+        assets_type(a, MN_BOULDER, "misc_assets/elementStone007.png");
+        assets_type(a, MN_DIAMOND, "misc_assets/gemBlue.png");
+        assets_type(a, MN_EXIT, "misc_assets/window.png");
+        assets_type(a, MN_DIRT, "misc_assets/dirt.png");
+        assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
+        a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
+        for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
     } else if (game_id == GAME_MAZE) { /* maze.cpp:26-38 */
         assets_type(a, WALL_OBJ, "kenney/Ground/Sand/sandCenter.png");
         assets_type(a, MZ_GOAL, "misc_assets/cheese.png");
@@ -372,6 +391,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "bigfish") == 0) return GAME_BIGFISH;
     if (strcmp(name, "maze") == 0) return GAME_MAZE;
     if (strcmp(name, "climber") == 0) return GAME_CLIMBER;
+    if (strcmp(name, "miner") == 0) return GAME_MINER;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -442,6 +462,8 @@ typedef struct {
     float r_inc;
     /* Climber: climber.cpp:32-38 (has_support, facing_right, wall_theme, gravity, air_control shared with CoinRun below) */
     int coin_quota, coins_collected;
+    /* MinerGame: miner.cpp:23 */
+    int diamonds_remaining;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
     /* CoinRun */
@@ -522,6 +544,9 @@ static int hook_is_blocked(const Game *g, const Ent *src, int target, int is_hor
     if (g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) { /* coinrun.cpp:204-211, climber.cpp:136-143 */
         if (src->type == PLAYER && cr_is_wall(target)) return 1;
     }
+    if (g->game_id == GAME_MINER) { /* miner.cpp:57-64 */
+        if (src->type == PLAYER && (target == MN_BOULDER || target == MN_MOVING_BOULDER || target == MN_OOB_WALL)) return 1;
+    }
     return 0;
 }
 static int hook_is_blocked_ents(Game *g, const Ent *src, const Ent *target, int is_horizontal) {
@@ -540,12 +565,24 @@ static int hook_is_blocked_ents(Game *g, const Ent *src, const Ent *target, int 
 static int hook_will_reflect(const Game *g, int src, int target) {
     if (g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) /* coinrun.cpp:140-142, climber.cpp:110-112 (same ids) */
         return (src == CR_ENEMY && (cr_is_wall(target) || target == CR_ENEMY_BARRIER));
+    if (g->game_id == GAME_MINER) /* miner.cpp:66-68 */
+        return (src == MN_ENEMY && (target == MN_BOULDER || target == MN_DIAMOND || target == MN_MOVING_BOULDER || target == MN_MOVING_DIAMOND || target == g->out_of_bounds_object));
     return 0; /* BAG:498-500 */
 }
 static void hook_handle_agent_collision(Game *g, Ent *obj) {
     if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:123-131 */
         if (obj->type == CR_ENEMY) g->done = 1;
         else if (obj->type == CR_SAW) g->done = 1;
+    } else if (g->game_id == GAME_MINER) { /* miner.cpp:70-82 */
+        if (obj->type == MN_ENEMY) {
+            g->done = 1;
+        } else if (obj->type == MN_EXIT) {
+            if (g->diamonds_remaining == 0) {
+                g->reward += 10.0f;
+                g->level_complete = 1;
+                g->done = 1;
+            }
+        }
     } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:90-100 */
         if (obj->type == CL_ENEMY) {
             g->done = 1;
@@ -769,7 +806,7 @@ static void hook_set_action_xy(Game *g, int move_act) {
         else g->action_vy = 0;
     } else {
         g->action_vrot = 0; /* BAG:658-662 */
-        if (g->game_id == GAME_MAZE) { /* maze.cpp:99-103 */
+        if (g->game_id == GAME_MAZE || g->game_id == GAME_MINER) { /* maze.cpp:99-103, miner.cpp:98-102 */
             if (g->action_vx != 0) g->action_vy = 0;
         }
     }
@@ -856,6 +893,7 @@ static void bag_game_step(Game *g) {
 
 static void choose_random_theme(Game *g, Ent *ent);
 static void match_aspect_ratio(Game *g, Ent *ent);
+static void mn_game_step_tail(Game *g);
 
 /* ---- per-game game_step: coinrun.cpp:474-498, bigfish.cpp:80-107 ---- */
 static void game_step(Game *g) {
@@ -900,6 +938,8 @@ static void game_step(Game *g) {
         Ent *agent = &g->pool[g->agent];
         if (g->action_vx > 0) agent->is_reflected = 0;
         if (g->action_vx < 0) agent->is_reflected = 1;
+    } else if (g->game_id == GAME_MINER) {
+        mn_game_step_tail(g);
     } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:290-316 */
         Ent *agent = &g->pool[g->agent];
         if (g->action_vx > 0) agent->is_reflected = 0;
@@ -930,6 +970,73 @@ static void game_step(Game *g) {
         }
         g->done = g->reward > 0;
     }
+}
+
+/* ---- miner helpers: index-based grid access BAG:198-203,217-219, miner.cpp:94-96,207-245 ---- */
+static int get_obj_idx(const Game *g, int idx) {
+    if (!(0 <= idx && idx < g->grid_w * g->grid_h)) return g->out_of_bounds_object;
+    return g->grid[idx];
+}
+static void set_obj_idx(Game *g, int idx, int v) {
+    if (!(idx < g->grid_w * g->grid_h) || idx < 0) fatal("fassert index < w * h (grid.h:60)");
+    g->grid[idx] = v;
+}
+static int mn_agent_index(const Game *g) { return (int)g->pool[g->agent].y * g->main_width + (int)g->pool[g->agent].x; }
+static int mn_is_free(const Game *g, int idx) { return get_obj_idx(g, idx) == SPACE && (mn_agent_index(g) != idx); }
+static int mn_is_round(int t) { return t == MN_BOULDER || t == MN_MOVING_BOULDER || t == MN_DIAMOND || t == MN_MOVING_DIAMOND; }
+static int mn_stationary(int t) { return t == MN_MOVING_DIAMOND ? MN_DIAMOND : (t == MN_MOVING_BOULDER ? MN_BOULDER : t); }
+static int mn_moving(int t) { return t == MN_DIAMOND ? MN_MOVING_DIAMOND : (t == MN_BOULDER ? MN_MOVING_BOULDER : t); }
+
+static void mn_game_step_tail(Game *g) { /* miner.cpp:247-307 */
+    Ent *agent = &g->pool[g->agent];
+    if (g->action_vx > 0) agent->is_reflected = 0;
+    if (g->action_vx < 0) agent->is_reflected = 1;
+    { /* handle_push miner.cpp:232-245 */
+        int agent_idx = mn_agent_index(g);
+        int agentx = agent_idx % g->main_width;
+        if (g->action_vx == 1 && (agent->vx == 0) && (agentx < g->main_width - 2) && get_obj_idx(g, agent_idx + 1) == MN_BOULDER && get_obj_idx(g, agent_idx + 2) == SPACE) {
+            set_obj_idx(g, agent_idx + 1, SPACE);
+            set_obj_idx(g, agent_idx + 2, MN_BOULDER);
+            agent->x += 1;
+        } else if (g->action_vx == -1 && (agent->vx == 0) && (agentx > 1) && get_obj_idx(g, agent_idx - 1) == MN_BOULDER && get_obj_idx(g, agent_idx - 2) == SPACE) {
+            set_obj_idx(g, agent_idx - 1, SPACE);
+            set_obj_idx(g, agent_idx - 2, MN_BOULDER);
+            agent->x -= 1;
+        }
+    }
+    int agent_obj = get_obj(g, (int)agent->x, (int)agent->y);
+    if (agent_obj == MN_DIAMOND) g->reward += 1.0f; /* DIAMOND_REWARD is an int constant 1 */
+    if (agent_obj == MN_DIRT || agent_obj == MN_DIAMOND) set_obj(g, (int)agent->x, (int)agent->y, SPACE);
+    int main_area = g->main_width * g->main_height;
+    int diamonds_count = 0;
+    for (int idx = 0; idx < main_area; idx++) {
+        int obj = get_obj_idx(g, idx);
+        int obj_x = idx % g->main_width;
+        int agent_idx = (int)((agent->y - .5) * g->main_width + (agent->x - .5));
+        int stat_type = mn_stationary(obj);
+        if (stat_type == MN_DIAMOND) diamonds_count++;
+        if (obj == MN_BOULDER || obj == MN_MOVING_BOULDER || obj == MN_DIAMOND || obj == MN_MOVING_DIAMOND) {
+            int below_idx = idx - g->main_width;
+            int obj2 = get_obj_idx(g, below_idx);
+            int agent_is_below = agent_idx == below_idx;
+            if (obj2 == SPACE && !agent_is_below) {
+                set_obj_idx(g, idx, SPACE);
+                set_obj_idx(g, below_idx, mn_moving(obj));
+            } else if (agent_is_below && (obj == MN_MOVING_BOULDER || obj == MN_MOVING_DIAMOND)) {
+                g->done = 1;
+            } else if (mn_is_round(obj2) && obj_x > 0 && mn_is_free(g, idx - 1) && mn_is_free(g, idx - g->main_width - 1)) {
+                set_obj_idx(g, idx, SPACE);
+                set_obj_idx(g, idx - 1, mn_stationary(obj));
+            } else if (mn_is_round(obj2) && obj_x < g->main_width - 1 && mn_is_free(g, idx + 1) && mn_is_free(g, idx - g->main_width + 1)) {
+                set_obj_idx(g, idx, SPACE);
+                set_obj_idx(g, idx + 1, stat_type);
+            } else {
+                set_obj_idx(g, idx, stat_type);
+            }
+        }
+    }
+    g->diamonds_remaining = diamonds_count;
+    /* the ENEMY loop of miner.cpp:299-305 never runs: no ENEMY entity is ever created */
 }
 
 /* ---- MazeGen: reference src/mazegen.cpp (Kruskal over std::set cell sets) ----
@@ -1180,6 +1287,12 @@ static void cl_generate_platforms(Game *g) { /* climber.cpp:171-228 */
 }
 
 static void bag_game_reset(Game *g) { /* BAG:758-797 */
+    if (g->game_id == GAME_MINER) { /* choose_world_dim miner.cpp:116-129 */
+        int dm = g->opt.distribution_mode;
+        if (dm == 0) g->main_width = g->main_height = 10;
+        else if (dm == 1) g->main_width = g->main_height = 20;
+        else if (dm == 10) g->main_width = g->main_height = 35;
+    }
     if (g->game_id == GAME_CLIMBER) { /* choose_world_dim climber.cpp:230-233 */
         g->main_width = g->opt.distribution_mode == 0 ? 16 : 20;
         g->main_height = 64;
@@ -1256,6 +1369,54 @@ static void game_reset(Game *g) {
         agent->rx = start_r;
         agent->ry = start_r;
         agent->y = 1 + agent->ry;
+    } else if (g->game_id == GAME_MINER) { /* miner.cpp:131-205 */
+        Ent *agent = &g->pool[g->agent];
+        agent->rx = (float).5;
+        agent->ry = (float).5;
+        int main_area = g->main_height * g->main_width;
+        g->center_agent = g->opt.distribution_mode == 10;
+        g->grid_step = 1;
+        float diamond_pct = 12 / 400.0f;
+        float boulder_pct = 80 / 400.0f;
+        int num_diamonds = (int)(diamond_pct * main_area);
+        int num_boulders = (int)(boulder_pct * main_area);
+        int k = num_diamonds + num_boulders + 1;
+        static int obj_idxs[2048];
+        static unsigned char used[2048];
+        memset(used, 0, sizeof(used));
+        for (int i = 0; i < k; i++) { /* RandGen::simple_choose randgen.cpp:70-88 */
+            int next = rng_randn(&g->rand_gen, main_area);
+            while (used[next]) next = rng_randn(&g->rand_gen, main_area);
+            obj_idxs[i] = next;
+            used[next] = 1;
+        }
+        int agent_x = obj_idxs[0] % g->main_width;
+        int agent_y = obj_idxs[0] / g->main_width;
+        agent->x = (float)(agent_x + .5);
+        agent->y = (float)(agent_y + .5);
+        for (int i = 0; i < main_area; i++) set_obj_idx(g, i, MN_DIRT);
+        for (int i = 0; i < num_diamonds; i++) set_obj_idx(g, obj_idxs[i + 1], MN_DIAMOND);
+        for (int i = 0; i < num_boulders; i++) set_obj_idx(g, obj_idxs[i + 1 + num_diamonds], MN_BOULDER);
+        static unsigned char was_dirt[2048]; /* get_cells_with_type(DIRT) snapshot */
+        for (int i = 0; i < main_area; i++) was_dirt[i] = g->grid[i] == MN_DIRT;
+        set_obj(g, (int)agent->x, (int)agent->y, SPACE);
+        for (int i = -1; i <= 1; i++)
+            for (int j = -1; j <= 1; j++) {
+                int ox = agent_x + i, oy = agent_y + j;
+                if (get_obj(g, ox, oy) == MN_BOULDER) set_obj(g, ox, oy, MN_DIRT);
+            }
+        int ncand = 0;
+        static int cand[2048];
+        for (int cell = 0; cell < main_area; cell++) {
+            if (!was_dirt[cell]) continue;
+            int above_obj = get_obj_idx(g, cell + g->main_width);
+            if (above_obj == MN_DIRT || above_obj == g->out_of_bounds_object) cand[ncand++] = cell;
+        }
+        if (ncand <= 0) fatal("fassert exit_candidates.size() > 0 (miner.cpp:196)");
+        int exit_cell = cand[rng_randn(&g->rand_gen, ncand)];
+        set_obj_idx(g, exit_cell, SPACE);
+        Ent *ex = push_entity(g, (float)((exit_cell % g->main_width) + .5), (float)((exit_cell / g->main_width) + .5), 0, 0, (float).5, (float).5, MN_EXIT);
+        ex->render_z = -1;
     } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:235-255 */
         Ent *agent = &g->pool[g->agent];
         g->gravity = 0.2f;
@@ -1415,6 +1576,10 @@ static void prepare_for_drawing(Game *g, float rect_height) { /* BAG:819-838 */
 }
 
 static int hook_image_for_type(const Game *g, int type) {
+    if (g->game_id == GAME_MINER) { /* miner.cpp:84-92 */
+        if (type == MN_MOVING_BOULDER) return MN_BOULDER;
+        if (type == MN_MOVING_DIAMOND) return MN_DIAMOND;
+    }
     if (g->game_id == GAME_CLIMBER) { /* climber.cpp:145-159 */
         if (type == PLAYER) {
             const Ent *agent = &g->pool[g->agent];
@@ -1622,6 +1787,14 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->timeout = 6000;
         g->main_width = 20;
         g->main_height = 20;
+    } else if (game_id == GAME_MINER) { /* miner.cpp:25-35 */
+        g->main_width = 20;
+        g->main_height = 20;
+        g->mixrate = (float).5;
+        g->maxspeed = (float).5;
+        g->has_useful_vel_info = 0;
+        g->out_of_bounds_object = MN_OOB_WALL;
+        g->visibility = 8.0f;
     } else if (game_id == GAME_CLIMBER) { /* climber.cpp:40-42 */
         g->out_of_bounds_object = CL_WALL_MID;
     } else if (game_id == GAME_MAZE) { /* maze.cpp:16-24 */

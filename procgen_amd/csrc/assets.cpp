@@ -98,6 +98,14 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(7, {"platformer/enemySwimming_2.png"});
         add_themes(1, {"platformer/yellowCrystal.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:37-55
+        add_themes(0, {"misc_assets/robot_greenDrive1.png"});
+        add_themes(1, {"misc_assets/elementStone007.png"});
+        add_themes(2, {"misc_assets/gemBlue.png"});
+        add_themes(6, {"misc_assets/window.png"});
+        add_themes(9, {"misc_assets/dirt.png"});
+        add_themes(10, {"misc_assets/tile_bricksGrey.png"});
+        platform_backgrounds(backgrounds);
     } else if (game_id == GAME_MAZE) {  // reference src/games/maze.cpp:26-38, src/resources.cpp:900-911
         add_themes(51, {"kenney/Ground/Sand/sandCenter.png"});
         add_themes(2, {"misc_assets/cheese.png"});
@@ -202,6 +210,7 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
     int ref_type = -1;  // the game's wall tile, when it has one: its size is the renderer's reference cell-image size
     if (game_id == GAME_COINRUN || game_id == GAME_CLIMBER) ref_type = 15;
     if (game_id == GAME_MAZE) ref_type = 51;
+    if (game_id == GAME_MINER) ref_type = 9;
     if (ref_type >= 0 && t.type_theme_img[ref_type][0] >= 0) {
         t.ref_w = t.img[t.type_theme_img[ref_type][0]].w;
         t.ref_h = t.img[t.type_theme_img[ref_type][0]].h;

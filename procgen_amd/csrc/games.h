@@ -4,5 +4,6 @@
 #include "game_climber.h"
 #include "game_coinrun.h"
 #include "game_maze.h"
+#include "game_miner.h"
 
-#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber)
+#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner)

@@ -114,7 +114,8 @@ bool read_rng(Reader &r, int *seeded, uint32_t *mt, int *idx) {
 
 bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h) {
     if (game_id == GAME_BIGFISH) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64
-    if (game_id == GAME_MAZE) return h.initial_reset_complete ? opt.distribution_mode == MemoryMode : opt.center_agent != 0;  // maze.cpp:66
+    if (game_id == GAME_MAZE || game_id == GAME_MINER)  // maze.cpp:66, miner.cpp:140
+        return h.initial_reset_complete ? opt.distribution_mode == MemoryMode : opt.center_agent != 0;
     return opt.center_agent != 0;
 }
 
@@ -242,6 +243,8 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
     } else if (game_id == GAME_MAZE) {  // reference src/games/maze.cpp:126-130
         w.i(h.gsi0);
         w.i(h.gsi1);
+    } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:309-312
+        w.i(h.gsi0);
     } else if (game_id == GAME_CLIMBER) {  // reference src/games/climber.cpp:318-327
         w.i(h.gsi1 ? 1 : 0);
         w.i(h.gsi2 ? 1 : 0);
@@ -382,6 +385,8 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
     } else if (game_id == GAME_MAZE) {
         h.gsi0 = r.i();
         h.gsi1 = r.i();
+    } else if (game_id == GAME_MINER) {
+        h.gsi0 = r.i();
     } else if (game_id == GAME_CLIMBER) {
         h.gsi1 = r.i() > 0;
         h.gsi2 = r.i() > 0;
