@@ -7,7 +7,8 @@
  * literals promote, results narrow on assignment); build with -ffp-contract=off (no FMA), matching
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
- * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner.
+ * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner,
+ * starpilot.
  */
 #include "procgen_oracle.h"
 
@@ -37,7 +38,23 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_MAZE = 11, GAME_MINER = 12 };
+enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_MAZE = 11, GAME_MINER = 12, GAME_STARPILOT = 15 };
+
+/* starpilot.cpp:6-27 */
+#define SP_V_SCALE (2.0f / 5.0f)
+#define SP_BULLET_PLAYER 1
+#define SP_BULLET2 2
+#define SP_BULLET3 3
+#define SP_FLYER 4
+#define SP_METEOR 5
+#define SP_CLOUD 6
+#define SP_TURRET 7
+#define SP_FAST_FLYER 8
+#define SP_FINISH_LINE 9
+#define SP_SHOOTER_WIN_TIME 500
+#define SP_NUM_BASIC_OBJECTS 9
+#define SP_NUM_SHIP_THEMES 7
+#define SP_MAX_SPAWNERS 256
 
 /* miner ids: reference src/games/miner.cpp:11-19 */
 #define MN_BOULDER 1
@@ -369,6 +386,38 @@ static void assets_build(int game_id) {
         assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_STARPILOT) { /* starpilot.cpp:59-106 */
+        assets_type(a, PLAYER, "misc_assets/playerShip2_blue.png");
+        assets_type(a, SP_BULLET_PLAYER, "misc_assets/towerDefense_tile295.png");
+        assets_type(a, SP_BULLET2, "misc_assets/towerDefense_tile296.png");
+        assets_type(a, SP_BULLET3, "misc_assets/towerDefense_tile297.png");
+        for (int t = 0; t < 2; t++)
+            for (int i = 1; i <= 7; i++) {
+                snprintf(buf, sizeof buf, "misc_assets/spaceShips_00%d.png", i);
+                assets_type(a, t == 0 ? SP_FLYER : SP_FAST_FLYER, buf);
+            }
+        for (int i = 1; i <= 4; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/spaceMeteors_00%d.png", i);
+            assets_type(a, SP_METEOR, buf);
+        }
+        for (int i = 1; i <= 4; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/meteorGrey_big%d.png", i);
+            assets_type(a, SP_METEOR, buf);
+        }
+        for (int i = 1; i <= 9; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/spaceEffect%d.png", i);
+            assets_type(a, SP_CLOUD, buf);
+        }
+        assets_type(a, SP_TURRET, "misc_assets/spaceStation_018.png");
+        assets_type(a, SP_TURRET, "misc_assets/spaceStation_019.png");
+        for (int i = 1; i <= 4; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/spaceRockets_00%d.png", i);
+            assets_type(a, SP_FINISH_LINE, buf);
+        }
+        /* starpilot.cpp:55-57 load_background_images: space_backgrounds (resources.cpp:829-845) */
+        int n_platform = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0])) - 13;
+        a->n_bg = 13;
+        for (int i = 0; i < 13; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[n_platform + i], 1);
     } else if (game_id == GAME_MAZE) { /* maze.cpp:26-38 */
         assets_type(a, WALL_OBJ, "kenney/Ground/Sand/sandCenter.png");
         assets_type(a, MZ_GOAL, "misc_assets/cheese.png");
@@ -392,6 +441,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "maze") == 0) return GAME_MAZE;
     if (strcmp(name, "climber") == 0) return GAME_CLIMBER;
     if (strcmp(name, "miner") == 0) return GAME_MINER;
+    if (strcmp(name, "starpilot") == 0) return GAME_STARPILOT;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -466,6 +516,14 @@ typedef struct {
     int diamonds_remaining;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
+    /* StarPilotGame: starpilot.cpp:34-50 */
+    Ent spawners[SP_MAX_SPAWNERS];
+    int n_spawners;
+    float hp_vs[SP_NUM_BASIC_OBJECTS], hp_healths[SP_NUM_BASIC_OBJECTS], hp_bullet_r[SP_NUM_BASIC_OBJECTS];
+    float hp_object_r[SP_NUM_BASIC_OBJECTS], hp_object_prob_weight[SP_NUM_BASIC_OBJECTS];
+    float total_prob_weight, hp_slow_v, hp_weapon_bullet_dist, hp_spawn_right_threshold;
+    int hp_min_enemy_delta_t, hp_max_group_size, hp_max_enemy_delta_t;
+    float char_dim; /* BAG:24 */
     /* CoinRun */
     float last_agent_y;
     int wall_theme, has_support, facing_right, is_on_crate;
@@ -569,6 +627,12 @@ static int hook_will_reflect(const Game *g, int src, int target) {
         return (src == MN_ENEMY && (target == MN_BOULDER || target == MN_DIAMOND || target == MN_MOVING_BOULDER || target == MN_MOVING_DIAMOND || target == g->out_of_bounds_object));
     return 0; /* BAG:498-500 */
 }
+static int sp_is_lethal(int type) { /* starpilot.cpp:341-345 */
+    return type == SP_FLYER || type == SP_FAST_FLYER || type == SP_BULLET2 || type == SP_BULLET3 || type == SP_TURRET || type == SP_METEOR;
+}
+static int sp_is_destructible(int type) { /* starpilot.cpp:347-349 */
+    return type == SP_FLYER || type == SP_FAST_FLYER || type == SP_TURRET || type == SP_METEOR;
+}
 static void hook_handle_agent_collision(Game *g, Ent *obj) {
     if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:123-131 */
         if (obj->type == CR_ENEMY) g->done = 1;
@@ -590,6 +654,14 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
             g->reward += 1.0f;
             g->coins_collected += 1;
             obj->will_erase = 1;
+        }
+    } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:126-136 */
+        if (obj->type == SP_FINISH_LINE) {
+            g->done = 1;
+            g->reward += 10.0f;
+            g->level_complete = 1;
+        } else if (sp_is_lethal(obj->type)) {
+            g->done = 1;
         }
     } else if (g->game_id == GAME_BIGFISH) { /* bigfish.cpp:48-62 */
         Ent *agent = &g->pool[g->agent];
@@ -620,7 +692,16 @@ static void hook_handle_grid_collision(Game *g, Ent *obj, int type, int i, int j
         }
     }
 }
-static void hook_handle_collision(Game *g, Ent *src, Ent *target) { (void)g; (void)src; (void)target; } /* BAG:398 */
+static void hook_handle_collision(Game *g, Ent *src, Ent *target) { /* BAG:398 */
+    if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:138-146 */
+        if (src->type == SP_BULLET_PLAYER && target->type != SP_CLOUD && sp_is_destructible(target->type)) {
+            src->will_erase = 1;
+            target->health -= 1;
+            float sx = src->x, sy = src->y, tvx = target->vx, tvy = target->vy, r = (float)(.5 * src->rx);
+            push_entity(g, sx, sy, tvx, tvy, r, r, EXPLOSION); /* add_entity BAG:571-575; pool slots never move */
+        }
+    }
+}
 
 /* ---- physics: BAG:240-372 ---- */
 static int sub_step(Game *g, Ent *obj, float _vx, float _vy, int depth);
@@ -894,6 +975,7 @@ static void bag_game_step(Game *g) {
 static void choose_random_theme(Game *g, Ent *ent);
 static void match_aspect_ratio(Game *g, Ent *ent);
 static void mn_game_step_tail(Game *g);
+static void sp_game_step_tail(Game *g);
 
 /* ---- per-game game_step: coinrun.cpp:474-498, bigfish.cpp:80-107 ---- */
 static void game_step(Game *g) {
@@ -940,6 +1022,8 @@ static void game_step(Game *g) {
         if (g->action_vx < 0) agent->is_reflected = 1;
     } else if (g->game_id == GAME_MINER) {
         mn_game_step_tail(g);
+    } else if (g->game_id == GAME_STARPILOT) {
+        sp_game_step_tail(g);
     } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:290-316 */
         Ent *agent = &g->pool[g->agent];
         if (g->action_vx > 0) agent->is_reflected = 0;
@@ -1118,6 +1202,286 @@ static void match_aspect_ratio(Game *g, Ent *ent) { /* BAG:1014-1023 (match_widt
     const Img *im = &g->assets->img[g->assets->type_theme_img[ent->image_type][ent->image_theme]];
     float aspect = (float)(im->w * 1.0 / im->h);
     ent->ry = ent->rx / aspect;
+}
+
+static void match_aspect_ratio_h(Game *g, Ent *ent) { /* BAG:1014-1023 (match_width = false) */
+    if (g->assets->type_num_themes[ent->image_type] <= ent->image_theme) fatal("asset theme out of range");
+    const Img *im = &g->assets->img[g->assets->type_theme_img[ent->image_type][ent->image_theme]];
+    float aspect = (float)(im->w * 1.0 / im->h);
+    ent->rx = ent->ry * aspect;
+}
+
+static float rand_pos(Game *g, float r, float min, float max) { /* BAG:1100-1108 */
+    if (!(min <= max)) fatal("fassert min <= max (BAG:1101)");
+    if (max - min <= 2 * r) return (max + min) / 2;
+    float range = max - min;
+    return (range - 2 * r) * rng_rand01(&g->rand_gen) + r + min;
+}
+
+static void face_direction(Ent *e, float dx, float dy, float rotation_offset) { /* entity.cpp:84-88; atan2f by overload */
+    if (dx != 0 || dy != 0) e->rotation = -1 * atan2f(dy, dx) + rotation_offset;
+}
+
+/* ---- StarPilot: starpilot.cpp:148-443 ---- */
+static void sp_init_hps(Game *g) { /* starpilot.cpp:148-227 */
+    float scale = 1;
+    for (int i = 0; i < SP_NUM_BASIC_OBJECTS; i++) {
+        g->hp_vs[i] = 1;
+        g->hp_healths[i] = 0;
+        g->hp_object_prob_weight[i] = 1;
+        g->hp_object_r[i] = scale / 2;
+    }
+    float default_bullet_r = (float)(scale / 2.5);
+    int dm = g->opt.distribution_mode;
+    if (dm == 0) {
+        g->hp_object_prob_weight[SP_METEOR] = 0;
+        g->hp_object_prob_weight[SP_CLOUD] = 0;
+        g->hp_object_prob_weight[SP_TURRET] = 0;
+        g->hp_object_prob_weight[SP_FAST_FLYER] = 0;
+        g->hp_vs[SP_FLYER] = (float).75;
+        g->hp_vs[SP_BULLET2] = (float)1.25;
+        g->hp_healths[SP_TURRET] = 5;
+        g->hp_healths[SP_FLYER] = 2;
+        g->hp_healths[SP_FAST_FLYER] = 1;
+        g->maxspeed = (float)0.75;
+    } else if (dm == 1) {
+        g->hp_vs[SP_BULLET2] = 2;
+        g->hp_healths[SP_TURRET] = 5;
+        g->hp_healths[SP_FLYER] = 2;
+        g->hp_healths[SP_FAST_FLYER] = 1;
+        g->maxspeed = (float)0.75;
+    } else if (dm == 2) {
+        g->hp_vs[SP_BULLET2] = 2;
+        g->hp_healths[SP_TURRET] = 10;
+        g->hp_healths[SP_FLYER] = 5;
+        g->hp_healths[SP_FAST_FLYER] = 2;
+        g->maxspeed = (float)0.5;
+        default_bullet_r = scale / 5;
+    } else {
+        fatal("fassert(false) starpilot.cpp:188");
+    }
+    for (int i = 0; i < SP_NUM_BASIC_OBJECTS; i++) g->hp_bullet_r[i] = default_bullet_r;
+    g->hp_healths[SP_METEOR] = 500;
+    g->hp_vs[SP_FAST_FLYER] = (float)1.5;
+    g->hp_vs[SP_BULLET_PLAYER] = 2;
+    g->hp_vs[SP_BULLET3] = 2;
+    g->hp_object_r[SP_TURRET] = scale * 2;
+    g->hp_object_r[SP_METEOR] = scale * 2;
+    g->hp_object_r[SP_CLOUD] = scale * 2;
+    g->hp_object_prob_weight[SP_FLYER] = 3;
+    g->hp_slow_v = (float).5;
+    g->hp_max_group_size = 5;
+    g->hp_weapon_bullet_dist = 3;
+    g->hp_min_enemy_delta_t = 10;
+    g->hp_max_enemy_delta_t = g->hp_min_enemy_delta_t + 20;
+    g->hp_spawn_right_threshold = 0.9f;
+    g->hp_object_prob_weight[SP_BULLET_PLAYER] = 0;
+    g->hp_object_prob_weight[SP_BULLET2] = 0;
+    g->hp_object_prob_weight[SP_BULLET3] = 0;
+    g->total_prob_weight = 0;
+    for (int i = 2; i < SP_NUM_BASIC_OBJECTS; i++) g->total_prob_weight += g->hp_object_prob_weight[i];
+}
+
+static void sp_choose_random_theme_ent(Game *g, Ent *ent) { ent->image_theme = rng_randn(&g->rand_gen, g->assets->type_num_themes[ent->image_type]); }
+
+static void sp_add_spawners(Game *g) { /* starpilot.cpp:229-325 */
+    int t = 1 + rng_randint(&g->rand_gen, g->hp_min_enemy_delta_t, g->hp_max_enemy_delta_t);
+    int can_spawn_left = g->opt.distribution_mode != 0;
+    for (int i = 0; t <= SP_SHOOTER_WIN_TIME; i++) {
+        int group_size = 1;
+        float start_weight = rng_rand01(&g->rand_gen) * g->total_prob_weight;
+        float curr_weight = start_weight;
+        int type;
+        for (type = 2; type < SP_NUM_BASIC_OBJECTS; type++) {
+            curr_weight -= g->hp_object_prob_weight[type];
+            if (curr_weight <= 0) break;
+        }
+        if (type >= SP_NUM_BASIC_OBJECTS) type = SP_NUM_BASIC_OBJECTS - 1;
+        float r = g->hp_object_r[type];
+        int flyer_theme = 0;
+        if (type == SP_FLYER || type == SP_FAST_FLYER) {
+            group_size = rng_randint(&g->rand_gen, 0, g->hp_max_group_size) + 1;
+            flyer_theme = rng_randn(&g->rand_gen, SP_NUM_SHIP_THEMES);
+        }
+        float y_pos = rand_pos(g, r, 0, (float)g->main_height);
+        for (int j = 0; j < group_size; j++) {
+            int spawn_time = t + j * 5;
+            int fire_time = rng_randint(&g->rand_gen, 10, 100);
+            float k = 2 * PI_F / 4;
+            float theta = (float)((rng_rand01(&g->rand_gen) - .5) * k);
+            float v_scale = g->hp_vs[type];
+            if (rng_randint(&g->rand_gen, 0, 2) == 1) theta = 0;
+            float health = g->hp_healths[type];
+            if (type == SP_METEOR || type == SP_CLOUD) {
+                theta = 0;
+                v_scale = g->hp_slow_v;
+                fire_time = -1;
+            } else if (type == SP_TURRET) {
+                theta = 0;
+                v_scale = g->hp_slow_v;
+                fire_time = rng_randint(&g->rand_gen, 20, 30);
+            }
+            v_scale *= SP_V_SCALE;
+            float vx = (float)(-1 * cos((double)theta) * v_scale);
+            float vy = (float)(sin((double)theta) * v_scale);
+            int spawn_right = 1;
+            float x_pos;
+            if (type == SP_FLYER || type == SP_FAST_FLYER) {
+                if (rng_rand01(&g->rand_gen) > g->hp_spawn_right_threshold && can_spawn_left) spawn_right = 0;
+            }
+            if (spawn_right) {
+                x_pos = g->main_width + r;
+            } else {
+                x_pos = -r;
+                vx *= -1;
+            }
+            if (g->n_spawners >= SP_MAX_SPAWNERS) fatal("spawner list overflow");
+            Ent *sp = &g->spawners[g->n_spawners++];
+            ent_init(sp, x_pos, y_pos, vx, vy, r, r, type);
+            sp->fire_time = fire_time;
+            sp->spawn_time = spawn_time;
+            sp->health = health;
+            if (type == SP_CLOUD) {
+                sp->render_z = 1;
+                sp_choose_random_theme_ent(g, sp);
+            } else if (type == SP_METEOR) {
+                sp_choose_random_theme_ent(g, sp);
+            } else if (type == SP_FLYER || type == SP_FAST_FLYER) {
+                sp->image_theme = flyer_theme;
+                sp->rotation = ((vx > 0) ? -1 : 1) * PI_F / 2;
+            } else if (type == SP_TURRET) {
+                sp_choose_random_theme_ent(g, sp);
+                match_aspect_ratio(g, sp);
+            }
+        }
+        t += rng_randint(&g->rand_gen, g->hp_min_enemy_delta_t, g->hp_max_enemy_delta_t);
+    }
+}
+
+/* std::sort(spawners.begin(), spawners.end(), spawn_cmp) -- starpilot.cpp:334, spawn_cmp :29-31.
+ * Third-party algorithm restated: libstdc++ (GCC 11) bits/stl_algo.h std::__sort = introsort
+ * (median-of-3 to first, unguarded partition, threshold 16) + final insertion sort.  The order of
+ * equal spawn_times depends on it.  The heapsort fallback (depth limit 2*floor(log2 n)) is not
+ * restated; the oracle stops if it would be taken. */
+static int sp_cmp(const Ent *x, const Ent *y) { return x->spawn_time > y->spawn_time; }
+static void sp_swap(Ent *a, Ent *b) { Ent t = *a; *a = *b; *b = t; }
+static void sp_unguarded_linear_insert(Ent *base, int last) {
+    Ent val = base[last];
+    int next = last - 1;
+    while (sp_cmp(&val, &base[next])) {
+        base[last] = base[next];
+        last = next;
+        next--;
+    }
+    base[last] = val;
+}
+static void sp_insertion_sort(Ent *base, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; i++) {
+        if (sp_cmp(&base[i], &base[first])) {
+            Ent val = base[i];
+            for (int k = i; k > first; k--) base[k] = base[k - 1];
+            base[first] = val;
+        } else {
+            sp_unguarded_linear_insert(base, i);
+        }
+    }
+}
+static void sp_introsort_loop(Ent *base, int first, int last, int depth_limit) {
+    while (last - first > 16) {
+        if (depth_limit == 0) fatal("std::sort heapsort fallback not restated");
+        --depth_limit;
+        int mid = first + (last - first) / 2;
+        int a = first + 1, b = mid, c = last - 1, result = first;
+        if (sp_cmp(&base[a], &base[b])) {
+            if (sp_cmp(&base[b], &base[c])) sp_swap(&base[result], &base[b]);
+            else if (sp_cmp(&base[a], &base[c])) sp_swap(&base[result], &base[c]);
+            else sp_swap(&base[result], &base[a]);
+        } else if (sp_cmp(&base[a], &base[c])) sp_swap(&base[result], &base[a]);
+        else if (sp_cmp(&base[b], &base[c])) sp_swap(&base[result], &base[c]);
+        else sp_swap(&base[result], &base[b]);
+        int lo = first + 1, hi = last;
+        for (;;) {
+            while (sp_cmp(&base[lo], &base[first])) ++lo;
+            --hi;
+            while (sp_cmp(&base[first], &base[hi])) --hi;
+            if (!(lo < hi)) break;
+            sp_swap(&base[lo], &base[hi]);
+            ++lo;
+        }
+        sp_introsort_loop(base, lo, last, depth_limit);
+        last = lo;
+    }
+}
+static void sp_sort_spawners(Game *g) {
+    int n = g->n_spawners;
+    if (n == 0) return;
+    int lg = 0;
+    while ((1 << (lg + 1)) <= n) lg++;
+    sp_introsort_loop(g->spawners, 0, n, lg * 2);
+    if (n > 16) {
+        sp_insertion_sort(g->spawners, 0, 16);
+        for (int i = 16; i != n; i++) sp_unguarded_linear_insert(g->spawners, i);
+    } else {
+        sp_insertion_sort(g->spawners, 0, n);
+    }
+}
+
+static void sp_game_step_tail(Game *g) { /* starpilot.cpp:363-430 */
+    int is_firing = g->special_action != 0;
+    for (int i = g->n_ents - 1; i >= 0; i--) {
+        Ent *m = &g->pool[g->ents[i]];
+        if (m->type == PLAYER) continue;
+        int should_fire = 0; /* starpilot.cpp:351-361 */
+        if (m->fire_time > 0) {
+            if (m->type == SP_TURRET) should_fire = (g->cur_time - m->spawn_time) % m->fire_time == 0;
+            else should_fire = g->cur_time - m->spawn_time == m->fire_time;
+        }
+        if (should_fire) {
+            const Ent *agent = &g->pool[g->agent];
+            int bullet_type = m->type == SP_TURRET ? SP_BULLET3 : SP_BULLET2;
+            float bullet_r = g->hp_bullet_r[m->type];
+            float b_vx = agent->x - m->x;
+            float b_vy = agent->y - m->y;
+            float bv_scale = (float)(g->hp_vs[bullet_type] * SP_V_SCALE / sqrt((double)(b_vx * b_vx + b_vy * b_vy)));
+            b_vx = b_vx * bv_scale;
+            b_vy = b_vy * bv_scale;
+            Ent *nb = push_entity(g, m->x, m->y, b_vx, b_vy, bullet_r, bullet_r, bullet_type);
+            face_direction(nb, b_vx, b_vy, -1 * PI_F / 2);
+        }
+        if (m->health <= 0 && sp_is_destructible(m->type) && !m->will_erase) {
+            float r = (float)(.5 * m->rx);
+            push_entity(g, m->x, m->y, m->vx, m->vy, r, r, EXPLOSION); /* spawn_child BAG:225-231 */
+            g->reward += 1.0f;
+            m->will_erase = 1;
+        }
+    }
+    while (g->n_spawners > 0 && g->cur_time == g->spawners[g->n_spawners - 1].spawn_time) {
+        int id = pool_alloc(g);
+        g->pool[id] = g->spawners[g->n_spawners - 1];
+        if (g->n_ents >= MAX_ENTS) fatal("entity list overflow");
+        g->ents[g->n_ents++] = id;
+        g->n_spawners--;
+    }
+    float bullet_r = g->hp_bullet_r[PLAYER];
+    if (is_firing) {
+        const Ent *agent = &g->pool[g->agent];
+        float theta = g->special_action == 2 ? PI_F : 0;
+        float v_scale = g->hp_vs[SP_BULLET_PLAYER] * SP_V_SCALE;
+        float vx = (float)(cos((double)theta) * v_scale);
+        float vy = (float)(sin((double)theta) * v_scale);
+        float x_off = (float)(agent->rx * cos((double)theta));
+        Ent *bullet = push_entity(g, agent->x + x_off, agent->y, vx, vy, bullet_r, bullet_r, SP_BULLET_PLAYER);
+        bullet->collides_with_entities = 1;
+        face_direction(bullet, vx, vy, 0);
+        bullet->rotation -= PI_F / 2;
+    }
+    if (g->cur_time == SP_SHOOTER_WIN_TIME) {
+        Ent *finish = push_entity(g, (float)g->main_width, (float)(g->main_height / 2), -1 * g->hp_slow_v * SP_V_SCALE, 0, 2, (float)(g->main_height / 2), SP_FINISH_LINE);
+        choose_random_theme(g, finish);
+        match_aspect_ratio_h(g, finish);
+        finish->x = g->main_width + finish->rx;
+    }
 }
 
 static void cr_fill_block_top(Game *g, int x, int y, int dx, int dy, int fill, int top) { /* coinrun.cpp:227-231 */
@@ -1359,6 +1723,15 @@ static void game_reset(Game *g) {
         fill_elem(g, g->main_width - 1, 0, 1, g->main_height, CR_WALL_MID);
         fill_elem(g, 0, g->main_height - 1, g->main_width, 1, CR_WALL_MID);
         cr_generate_coin_to_the_right(g);
+    } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:327-339 */
+        g->center_agent = 0;
+        sp_init_hps(g);
+        g->n_spawners = 0;
+        sp_add_spawners(g);
+        sp_sort_spawners(g);
+        Ent *agent = &g->pool[g->agent];
+        agent->rotation = PI_F / 2;
+        choose_random_theme(g, agent);
     } else if (g->game_id == GAME_BIGFISH) { /* bigfish.cpp:64-81 */
         Ent *agent = &g->pool[g->agent];
         g->center_agent = 0;
@@ -1497,30 +1870,50 @@ static void fill_rect(uint32_t *dst, RectD r, uint32_t color) {
         for (int x = x1; x < x2; x++) dst[y * RES_W + x] = color;
 }
 
+static void blend_px(uint32_t *d, uint32_t s, int io, uint32_t ca) { /* Blend_ARGB32_on_ARGB32_Source(AndConst)Alpha */
+    if (io != 256) s = byte_mul(s, ca);
+    *d = s + byte_mul(*d, 255u - (s >> 24));
+}
+static int opacity_to_io(float opacity) { /* QRasterPaintEngine: intOpacity = int(opacity * 256), opacity clamped by QPainter::setOpacity */
+    double o = opacity;
+    if (o < 0) o = 0;
+    if (o > 1) o = 1;
+    return (int)(o * 256);
+}
+
+/* qt_scale_image_32bit (qblendfunctions_p.h, Qt 5.9.7).  tr.w / tr.h may be negative (a 180 degree
+ * rotation reaches this function as a negative scale through qt_mapRect_non_normalizing). */
 static void draw_image_scaled(uint32_t *dst, const Img *src, int mirrored, RectD tr, float opacity) {
     if (!src->px) fatal("image not provided to the oracle");
     double sx = tr.w / (double)src->w;
     double sy = tr.h / (double)src->h;
     int ix = (int)(65536 / sx);
     int iy = (int)(65536 / sy);
-    int tx1 = q_round(tr.x), tx2 = q_round(tr.x + tr.w), ty1 = q_round(tr.y), ty2 = q_round(tr.y + tr.h);
+    double right = tr.x + tr.w, bottom = tr.y + tr.h;
+    int tx1 = q_round(tr.x), tx2 = q_round(right), ty1 = q_round(tr.y), ty2 = q_round(bottom);
+    if (tx2 < tx1) { int t = tx1; tx1 = tx2; tx2 = t; }
+    if (ty2 < ty1) { int t = ty1; ty1 = ty2; ty2 = t; }
     if (tx1 < 0) tx1 = 0;
     if (ty1 < 0) ty1 = 0;
     if (tx2 > RES_W) tx2 = RES_W;
     if (ty2 > RES_H) ty2 = RES_H;
     int w = tx2 - tx1, h = ty2 - ty1;
     if (w <= 0 || h <= 0) return;
-    /* Qt 5.9: qCeil(..) - 1 (newer Qt uses qFloor(..) + 1; pinned with tests/tools/qt_drawimage_probe.py) */
-    uint32_t basex = (uint32_t)((int)ceil((tx1 + 0.5 - tr.x) * ix) - 1);
-    uint32_t srcy = (uint32_t)((int)ceil((ty1 + 0.5 - tr.y) * iy) - 1);
+    /* Qt 5.9: qCeil(..) - 1 for positive scales (newer Qt uses qFloor(..) + 1; pinned with
+     * tests/tools/qt_drawimage_probe.py); qFloor(..) + 1 from the far edge for negative scales
+     * (pinned with tests/tools/qt_rotate_probe.py). */
+    uint32_t basex, srcy;
+    if (sx < 0) basex = (uint32_t)src->w * 65536u + (uint32_t)((int)floor((tx1 + 0.5 - right) * ix) + 1);
+    else basex = (uint32_t)((int)ceil((tx1 + 0.5 - tr.x) * ix) - 1);
+    if (sy < 0) srcy = (uint32_t)src->h * 65536u + (uint32_t)((int)floor((ty1 + 0.5 - bottom) * iy) + 1);
+    else srcy = (uint32_t)((int)ceil((ty1 + 0.5 - tr.y) * iy) - 1);
+    if ((int)(srcy >> 16) >= src->h && iy < 0) { srcy += (uint32_t)iy; --h; }
+    if ((int)(basex >> 16) >= src->w && ix < 0) { basex += (uint32_t)ix; --w; }
     int yend = (int)((srcy + (uint32_t)iy * (uint32_t)(h - 1)) >> 16);
     if (yend < 0 || yend >= src->h) --h;
     int xend = (int)((basex + (uint32_t)ix * (uint32_t)(w - 1)) >> 16);
     if (xend < 0 || xend >= src->w) --w;
-    double o = opacity;
-    if (o < 0) o = 0;
-    if (o > 1) o = 1;
-    int io = (int)(o * 256);
+    int io = opacity_to_io(opacity);
     uint32_t ca = (uint32_t)((io * 255) >> 8);
     for (int y = 0; y < h; y++) {
         const uint32_t *srow = src->px + (size_t)(srcy >> 16) * src->w;
@@ -1528,12 +1921,176 @@ static void draw_image_scaled(uint32_t *dst, const Img *src, int mirrored, RectD
         uint32_t *drow = dst + (ty1 + y) * RES_W + tx1;
         for (int x = 0; x < w; x++) {
             int sxp = (int)(srcx >> 16);
-            uint32_t s = srow[mirrored ? (src->w - 1 - sxp) : sxp];
-            if (io != 256) s = byte_mul(s, ca);
-            drow[x] = s + byte_mul(drow[x], 255u - (s >> 24));
+            blend_px(&drow[x], srow[mirrored ? (src->w - 1 - sxp) : sxp], io, ca);
             srcx += (uint32_t)ix;
         }
         srcy += (uint32_t)iy;
+    }
+}
+
+/* qt_transform_image + qt_transform_image_rasterize (qblendfunctions_p.h, Qt 5.9.7): the path
+ * drawImage takes when the painter matrix has a rotation (QTransform::type() > TxScale).
+ * Vertices: x,y in device space, u,v in source pixels. */
+typedef struct { double x, y, u, v; } TVert;
+typedef struct {
+    uint32_t *dst;
+    const Img *src;
+    int mirrored, io;
+    uint32_t ca;
+    int dudx, dvdx, dudy, dvdy, u0, v0;
+} TRast;
+static void transform_rasterize(const TRast *t, TVert tl, TVert bl, TVert tr, TVert br, double top_y, double bottom_y) {
+    int from_y = q_round(top_y), to_y = q_round(bottom_y);
+    if (from_y < 0) from_y = 0;
+    if (to_y > RES_H) to_y = RES_H;
+    if (from_y >= to_y) return;
+    double left_slope = (bl.x - tl.x) / (bl.y - tl.y);
+    double right_slope = (br.x - tr.x) / (br.y - tr.y);
+    int dx_l = (int)(left_slope * 0x10000);
+    int dx_r = (int)(right_slope * 0x10000);
+    int x_l = (int)((tl.x + (0.5 + from_y - tl.y) * left_slope + 0.5) * 0x10000);
+    int x_r = (int)((tr.x + (0.5 + from_y - tr.y) * right_slope + 0.5) * 0x10000);
+    const Img *src = t->src;
+    for (int y = from_y; y < to_y; y++) {
+        int from_x = x_l >> 16, to_x = x_r >> 16;
+        if (from_x < 0) from_x = 0;
+        if (to_x > RES_W) to_x = RES_W;
+        for (int x = from_x; x < to_x; x++) {
+            int uu = (x * t->dudx + y * t->dudy + t->u0) >> 16;
+            int vv = (x * t->dvdx + y * t->dvdy + t->v0) >> 16;
+            if (uu < 0) uu = 0; /* out-of-range source coordinates are clamped to the source rect */
+            if (uu > src->w - 1) uu = src->w - 1;
+            if (vv < 0) vv = 0;
+            if (vv > src->h - 1) vv = src->h - 1;
+            blend_px(&t->dst[y * RES_W + x], src->px[(size_t)vv * src->w + (t->mirrored ? (src->w - 1 - uu) : uu)], t->io, t->ca);
+        }
+        x_l += dx_l;
+        x_r += dx_r;
+    }
+}
+static void draw_image_transformed(uint32_t *dst, const Img *src, int mirrored, RectD r, double m11, double m12, double m21, double m22, double dx, double dy, float opacity) {
+    if (!src->px) fatal("image not provided to the oracle");
+    TVert v[4];
+    double L = r.x, T = r.y, R = r.x + r.w, B = r.y + r.h;
+    double px[4] = {L, R, R, L}, py[4] = {T, T, B, B};
+    double pu[4] = {0, (double)src->w, (double)src->w, 0}, pv[4] = {0, 0, (double)src->h, (double)src->h};
+    for (int i = 0; i < 4; i++) {
+        v[i].x = m11 * px[i] + m21 * py[i] + dx;
+        v[i].y = m12 * px[i] + m22 * py[i] + dy;
+        v[i].u = pu[i];
+        v[i].v = pv[i];
+    }
+    int topmost = 0;
+    for (int i = 1; i < 4; i++)
+        if (v[i].y < v[topmost].y) topmost = i;
+    TVert q[4];
+    for (int i = 0; i < 4; i++) q[i] = v[(topmost + i) & 3];
+    double dx1 = q[1].x - q[0].x, dy1 = q[1].y - q[0].y, dx2 = q[3].x - q[0].x, dy2 = q[3].y - q[0].y;
+    if (dx1 * dy2 - dx2 * dy1 > 0) { TVert t = q[1]; q[1] = q[3]; q[3] = t; }
+    TVert u = {q[1].x - q[0].x, q[1].y - q[0].y, q[1].u - q[0].u, q[1].v - q[0].v};
+    TVert w = {q[2].x - q[0].x, q[2].y - q[0].y, q[2].u - q[0].u, q[2].v - q[0].v};
+    double det = u.x * w.y - u.y * w.x;
+    if (det == 0) return;
+    double det_inv = 1 / det;
+    double i11 = (u.u * w.y - u.y * w.u) * det_inv;
+    double i12 = (u.x * w.u - u.u * w.x) * det_inv;
+    double i21 = (u.v * w.y - u.y * w.v) * det_inv;
+    double i22 = (u.x * w.v - u.v * w.x) * det_inv;
+    double mdx = q[0].u - i11 * q[0].x - i12 * q[0].y;
+    double mdy = q[0].v - i21 * q[0].x - i22 * q[0].y;
+    TRast t;
+    t.dst = dst;
+    t.src = src;
+    t.mirrored = mirrored;
+    t.io = opacity_to_io(opacity);
+    t.ca = (uint32_t)((t.io * 255) >> 8);
+    t.dudx = (int)(i11 * 0x10000);
+    t.dvdx = (int)(i21 * 0x10000);
+    t.dudy = (int)(i12 * 0x10000);
+    t.dvdy = (int)(i22 * 0x10000);
+    t.u0 = (int)ceil((0.5 * i11 + 0.5 * i12 + mdx) * 0x10000) - 1;
+    t.v0 = (int)ceil((0.5 * i21 + 0.5 * i22 + mdy) * 0x10000) - 1;
+    if (q[1].y < q[3].y) {
+        transform_rasterize(&t, q[0], q[1], q[0], q[3], q[0].y, q[1].y);
+        transform_rasterize(&t, q[1], q[2], q[0], q[3], q[1].y, q[3].y);
+        transform_rasterize(&t, q[1], q[2], q[3], q[2], q[3].y, q[2].y);
+    } else {
+        transform_rasterize(&t, q[0], q[1], q[0], q[3], q[0].y, q[3].y);
+        transform_rasterize(&t, q[0], q[1], q[3], q[2], q[3].y, q[1].y);
+        transform_rasterize(&t, q[1], q[2], q[3], q[2], q[1].y, q[2].y);
+    }
+}
+
+/* BAG:902-906: p.translate(cx, cy); p.rotate(rotation * 180 / PI); p.drawImage(QRectF(-w/2, -h/2, w, h), img).
+ * QTransform::rotate special-cases 90/180/270 degrees, otherwise sin/cos of deg2rad*a (qtransform.cpp);
+ * QTransform::type() decides between the transform path and the (possibly negative) scale path. */
+static int q_fuzzy_is_null(double d) { return fabs(d) <= 0.000000000001; }
+static void draw_image_rotated(uint32_t *dst, const Img *src, int mirrored, RectD adjusted, float rotation, float opacity) {
+    double cx = adjusted.x + adjusted.w / 2, cy = adjusted.y + adjusted.h / 2;
+    double a = (double)(rotation * 180 / PI_F);
+    RectD r = {-adjusted.w / 2, -adjusted.h / 2, adjusted.w, adjusted.h};
+    double sina = 0, cosa = 0;
+    if (a == 0) cosa = 1; /* rotate(0) returns early: identity */
+    else if (a == 90. || a == -270.) sina = 1.;
+    else if (a == 270. || a == -90.) sina = -1.;
+    else if (a == 180.) cosa = -1.;
+    else {
+        double b = 0.017453292519943295769 * a;
+        sina = sin(b);
+        cosa = cos(b);
+    }
+    double m11 = cosa, m12 = sina, m21 = -sina, m22 = cosa;
+    if (!q_fuzzy_is_null(m12) || !q_fuzzy_is_null(m21)) {
+        draw_image_transformed(dst, src, mirrored, r, m11, m12, m21, m22, cx, cy, opacity);
+        return;
+    }
+    /* TxScale or below: drawImage maps the rect with qt_mapRect_non_normalizing and scales */
+    double x1, y1, x2, y2;
+    if (!q_fuzzy_is_null(m11 - 1) || !q_fuzzy_is_null(m22 - 1)) { /* TxScale */
+        x1 = m11 * r.x + cx;
+        y1 = m22 * r.y + cy;
+        x2 = m11 * (r.x + r.w) + cx;
+        y2 = m22 * (r.y + r.h) + cy;
+    } else if (!q_fuzzy_is_null(cx) || !q_fuzzy_is_null(cy)) { /* TxTranslate */
+        x1 = r.x + cx;
+        y1 = r.y + cy;
+        x2 = (r.x + r.w) + cx;
+        y2 = (r.y + r.h) + cy;
+    } else {
+        x1 = r.x;
+        y1 = r.y;
+        x2 = r.x + r.w;
+        y2 = r.y + r.h;
+    }
+    RectD tr = {x1, y1, x2 - x1, y2 - y1};
+    draw_image_scaled(dst, src, mirrored, tr, opacity);
+}
+
+/* BAG:840-869 */
+static void tile_image(uint32_t *dst, const Img *img, int mirrored, RectD rect, float tile_ratio, float opacity) {
+    if (tile_ratio != 0) {
+        if (tile_ratio < 0) {
+            tile_ratio = -1 * tile_ratio;
+            int num_tiles = (int)(rect.h / (rect.w * tile_ratio));
+            if (num_tiles < 1) num_tiles = 1;
+            float tile_height = (float)(rect.h / num_tiles);
+            float tile_width = (float)rect.w;
+            for (int i = 0; i < num_tiles; i++) {
+                RectD tr = {rect.x, rect.y + tile_height * i, tile_width, tile_height};
+                draw_image_scaled(dst, img, mirrored, tr, opacity);
+            }
+        } else {
+            int num_tiles = (int)(rect.w / (rect.h * tile_ratio));
+            if (num_tiles < 1) num_tiles = 1;
+            float tile_width = (float)(rect.w / num_tiles);
+            float tile_height = (float)rect.h;
+            for (int i = 0; i < num_tiles; i++) {
+                RectD tr = {rect.x + tile_width * i, rect.y, tile_width, tile_height};
+                draw_image_scaled(dst, img, mirrored, tr, opacity);
+            }
+        }
+    } else {
+        draw_image_scaled(dst, img, mirrored, rect, opacity);
     }
 }
 
@@ -1628,9 +2185,8 @@ static void draw_image(Game *g, uint32_t *dst, RectD base_rect, float rotation, 
     if (g->opt.restrict_themes) mt = 0;
     if (g->assets->type_num_themes[img_type] <= mt) fatal("asset theme out of range");
     const Img *img = &g->assets->img[g->assets->type_theme_img[img_type][mt]];
-    if (rotation != 0) fatal("rotated drawImage not restated yet");
-    if (tile_ratio != 0) fatal("tiled drawImage not restated yet");
-    draw_image_scaled(dst, img, is_reflected, adjusted, alpha);
+    if (rotation == 0) tile_image(dst, img, is_reflected, adjusted, tile_ratio, alpha);
+    else draw_image_rotated(dst, img, is_reflected, adjusted, rotation, alpha);
 }
 
 static void draw_entities(Game *g, uint32_t *dst, int render_z) { /* BAG:1052-1066 */
@@ -1653,18 +2209,32 @@ static void draw_entities(Game *g, uint32_t *dst, int render_z) { /* BAG:1052-10
 
 static void game_draw(Game *g, uint32_t *dst) { /* BAG:979-1012,921-970 */
     for (int i = 0; i < RES_W * RES_H; i++) dst[i] = 0xff000000u; /* fillRect black */
+    if (g->game_id == GAME_STARPILOT) { /* game_draw override starpilot.cpp:108-124 */
+        if (g->opt.use_backgrounds) {
+            float scale = (float)(RES_H / g->main_height);
+            float bg_k = 3;
+            float t = (float)g->cur_time;
+            float x_off = -t * scale * g->hp_slow_v * 2 / g->char_dim;
+            RectD r_bg = {x_off, -RES_H * (bg_k - 1) / 2, RES_H * bg_k * 18.0f, RES_H * bg_k};
+            tile_image(dst, &g->assets->img[g->assets->bg_img[g->background_index]], 0, r_bg, 1, 1.0f);
+        }
+    } else {
     prepare_for_drawing(g, (float)RES_H);
     if (g->opt.use_backgrounds) {
         RectD main_rect = get_screen_rect(g, 0, (float)g->main_height, (float)g->main_width, (float)g->main_height, 0);
         const Img *bg = &g->assets->img[g->assets->bg_img[g->background_index]];
-        if (g->bg_tile_ratio < 0) fatal("tiled backgrounds not restated yet");
-        float bgw = (float)bg->w, bgh = (float)bg->h;
-        float bg_ar = bgw / bgh;
-        float world_ar = (float)(g->main_width * 1.0 / g->main_height);
-        float extra_w = bg_ar - world_ar;
-        float offset_x = g->bg_pct_x * extra_w;
-        RectD a = {-offset_x, 0, bg_ar / world_ar, 1};
-        draw_image_scaled(dst, bg, 0, adjust_rect(main_rect, a), 1.0f);
+        if (g->bg_tile_ratio < 0) {
+            tile_image(dst, bg, 0, main_rect, g->bg_tile_ratio, 1.0f);
+        } else {
+            float bgw = (float)bg->w, bgh = (float)bg->h;
+            float bg_ar = bgw / bgh;
+            float world_ar = (float)(g->main_width * 1.0 / g->main_height);
+            float extra_w = bg_ar - world_ar;
+            float offset_x = g->bg_pct_x * extra_w;
+            RectD a = {-offset_x, 0, bg_ar / world_ar, 1};
+            draw_image_scaled(dst, bg, 0, adjust_rect(main_rect, a), 1.0f);
+        }
+    }
     }
     prepare_for_drawing(g, (float)RES_H);
     draw_entities(g, dst, -1);
@@ -1773,6 +2343,7 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
     g->default_action = 4;
     g->last_move_action = 7;
     g->bg_tile_ratio = 0;
+    g->char_dim = 5;
     g->out_of_bounds_object = INVALID_OBJ;
     g->has_useful_vel_info = 1;
     g->random_agent_start = 1; /* basic-abstract-game.h:144 */
@@ -1783,6 +2354,9 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->main_width = 64;
         g->main_height = 64;
         g->out_of_bounds_object = CR_WALL_MID;
+    } else if (game_id == GAME_STARPILOT) { /* starpilot.cpp:50-53 */
+        g->main_width = 16;
+        g->main_height = 16;
     } else if (game_id == GAME_BIGFISH) { /* bigfish.cpp:25-31 */
         g->timeout = 6000;
         g->main_width = 20;

@@ -106,6 +106,31 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(9, {"misc_assets/dirt.png"});
         add_themes(10, {"misc_assets/tile_bricksGrey.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_STARPILOT) {  // reference src/games/starpilot.cpp:55-106, src/resources.cpp:828-845
+        auto numbered = [](const std::string &stem, int from, int to, int width) {
+            std::vector<std::string> v;
+            for (int i = from; i <= to; i++) {
+                std::string n = std::to_string(i);
+                while ((int)n.size() < width) n = "0" + n;
+                v.push_back("misc_assets/" + stem + n + ".png");
+            }
+            return v;
+        };
+        add_themes(0, {"misc_assets/playerShip2_blue.png"});
+        add_themes(1, {"misc_assets/towerDefense_tile295.png"});
+        add_themes(2, {"misc_assets/towerDefense_tile296.png"});
+        add_themes(3, {"misc_assets/towerDefense_tile297.png"});
+        add_themes(4, numbered("spaceShips_", 1, 7, 3));
+        add_themes(8, numbered("spaceShips_", 1, 7, 3));
+        {
+            std::vector<std::string> m = numbered("spaceMeteors_", 1, 4, 3), g = numbered("meteorGrey_big", 1, 4, 1);
+            m.insert(m.end(), g.begin(), g.end());
+            add_themes(5, m);
+        }
+        add_themes(6, numbered("spaceEffect", 1, 9, 1));
+        add_themes(7, {"misc_assets/spaceStation_018.png", "misc_assets/spaceStation_019.png"});
+        add_themes(9, numbered("spaceRockets_", 1, 4, 3));
+        for (const char *n : SPACE_BGS) backgrounds->push_back(std::string("space_backgrounds/") + n + ".png");
     } else if (game_id == GAME_MAZE) {  // reference src/games/maze.cpp:26-38, src/resources.cpp:900-911
         add_themes(51, {"kenney/Ground/Sand/sandCenter.png"});
         add_themes(2, {"misc_assets/cheese.png"});

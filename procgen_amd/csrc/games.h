@@ -5,5 +5,6 @@
 #include "game_coinrun.h"
 #include "game_maze.h"
 #include "game_miner.h"
+#include "game_starpilot.h"
 
-#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner)
+#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot)

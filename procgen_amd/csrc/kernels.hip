@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void step_list(DevCtx d, int mode) {
 
 template <class Game>
 __global__ __launch_bounds__(64) void render(DevCtx d, int env_base) {
-    __shared__ RenderLds lds;
+    __shared__ RenderLdsT<Game> lds;
     Renderer<Game> r(d, env_base + (int)blockIdx.x, &lds);
     r.render_env();
 }
@@ -141,7 +141,7 @@ void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes) {
 #define PG_X(Game)                                                                        \
     case Game::GAME_ID:                                                                   \
         *ent_cap_hbm = Game::ENT_CAP_T2;                                                  \
-        *grid_bytes = (int)((Game::MAX_CELLS * sizeof(Game::cell_t) + 15) & ~(size_t)15); \
+        *grid_bytes = game_grid_bytes<Game>();                                            \
         break;
         PG_FOR_EACH_GAME(PG_X)
 #undef PG_X

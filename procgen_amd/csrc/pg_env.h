@@ -93,6 +93,25 @@ struct GameScratch<Game, decltype((void)sizeof(typename Game::Scratch))> {
     typedef typename Game::Scratch type;
 };
 
+// a game may declare `static constexpr int AUX_WORDS` for per-env HBM storage behind its grid cells (the slab
+// d.grid + env * d.grid_bytes holds the padded cells, then AUX_WORDS 32-bit words; not staged in LDS)
+template <class Game, class = void>
+struct GameAux {
+    static constexpr int WORDS = 0;
+};
+template <class Game>
+struct GameAux<Game, decltype((void)Game::AUX_WORDS)> {
+    static constexpr int WORDS = Game::AUX_WORDS;
+};
+template <class Game>
+constexpr int game_cell_bytes() {
+    return (int)((sizeof(typename Game::cell_t) * Game::MAX_CELLS + 15) & ~(size_t)15);
+}
+template <class Game>
+constexpr int game_grid_bytes() {
+    return game_cell_bytes<Game>() + GameAux<Game>::WORDS * 4;
+}
+
 template <class Game, int CAP>
 struct Lds {
     uint32_t ent[EF_COUNT * CAP];
@@ -141,6 +160,8 @@ struct Env {
     PG_DEV void fail(int code) {
         if (G.error == 0) G.error = code;
     }
+    // the game's aux words of this env in HBM (see GameAux)
+    PG_DEV uint32_t *aux() { return reinterpret_cast<uint32_t *>(d.grid + (size_t)env * d.grid_bytes + game_cell_bytes<Game>()); }
 
     // Entity::Entity(x,y,vx,vy,rx,ry,type): reference src/entity.cpp:11-51
     PG_DEV void ent_init(int i, float x, float y, float vx, float vy, float rx, float ry, int type) {
@@ -796,6 +817,18 @@ struct Env {
         const ImgDesc im = d.assets->img[img];
         const float aspect = (float)((double)im.w * 1.0 / (double)im.h);
         ery(i) = erx(i) / aspect;
+    }
+
+    PG_DEV void match_aspect_ratio_h(int i) {  // BAG:1014-1023 (match_width = false)
+        const uint32_t mm = meta(i);
+        const int img = (int)d.assets->type_theme_img[meta_image_type(mm)][meta_image_theme(mm)];
+        if (img < 0) {
+            fail(PGE_THEME);
+            return;
+        }
+        const ImgDesc im = d.assets->img[img];
+        const float aspect = (float)((double)im.w * 1.0 / (double)im.h);
+        erx(i) = ery(i) * aspect;
     }
 
     // Game::reset reference src/game.cpp:93-118

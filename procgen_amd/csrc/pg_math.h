@@ -1,0 +1,106 @@
+// pg_math.h -- libm functions of the reference's state path, restated so that the device reproduces the host bits.
+//
+// atan2f: Entity::face_direction (reference src/entity.cpp:84-88) stores -atan2f(dy, dx) + offset in the entity's
+// rotation, which is part of the serialized state, so the float result must match glibc's bit for bit.  glibc 2.35
+// (the libm the compiled reference links here and on the GPU box) implements atan2f/atanf with the fdlibm single
+// precision algorithm (sysdeps/ieee754/flt-32/e_atan2f.c, s_atanf.c): argument reduction to one of four intervals,
+// an odd/even split degree-11 polynomial in float arithmetic, hi/lo constants for atan(0.5), atan(1), atan(1.5),
+// pi/2.  Restated here from the published algorithm; tests/test_device_math.py checks it against the host libm on
+// a few million inputs.  Plain float operations only -- compile with -ffp-contract=off.
+#pragma once
+#include "wave.h"
+
+namespace pgamd {
+
+PG_DEV float pg_atanf(float x) {
+    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                          6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+    const int32_t hx = __builtin_bit_cast(int32_t, x);
+    const int32_t ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {  // |x| >= 2^25 (or NaN)
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) {  // |x| < 0.4375
+        if (ix < 0x31000000) return x;  // |x| < 2^-29
+        id = -1;
+    } else {
+        x = __builtin_fabsf(x);
+        if (ix < 0x3f980000) {      // |x| < 1.1875
+            if (ix < 0x3f300000) {  // 7/16 <= |x| < 11/16
+                id = 0;
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else {  // 11/16 <= |x| < 19/16
+                id = 1;
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else {
+            if (ix < 0x401c0000) {  // |x| < 2.4375
+                id = 2;
+                x = (x - 1.5f) / (1.0f + 1.5f * x);
+            } else {  // 2.4375 <= |x| < 2^25
+                id = 3;
+                x = -1.0f / x;
+            }
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return hx < 0 ? -r : r;
+}
+
+PG_DEV float pg_atan2f(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = __builtin_bit_cast(int32_t, x), hy = __builtin_bit_cast(int32_t, y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;  // NaN
+    if (hx == 0x3f800000) return pg_atanf(y);              // x = 1.0
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);     // 2*sign(x) + sign(y)
+    if (iy == 0) {
+        switch (m) {
+            case 0:
+            case 1: return y;
+            case 2: return pi + tiny;
+            default: return -pi - tiny;
+        }
+    }
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+                case 0: return pi_o_4 + tiny;
+                case 1: return -pi_o_4 - tiny;
+                case 2: return 3.0f * pi_o_4 + tiny;
+                default: return -3.0f * pi_o_4 - tiny;
+            }
+        } else {
+            switch (m) {
+                case 0: return 0.0f;
+                case 1: return -0.0f;
+                case 2: return pi + tiny;
+                default: return -pi - tiny;
+            }
+        }
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = pg_atanf(__builtin_fabsf(y / x));
+    switch (m) {
+        case 0: return z;
+        case 1: return -z;
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+
+}  // namespace pgamd

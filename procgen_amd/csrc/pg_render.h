@@ -29,31 +29,71 @@ struct DrawCmd {  // uniform (scalar) view of one command
     int tx1, ty1, w, h;
     uint32_t basex, srcy0, ix, iy;
     uint32_t src;  // first pixel of the source image in the atlas blob
-    uint32_t aux;  // source width (13 bits) | mirrored<<13 | opaque<<14 | const_alpha(0..256)<<16
+    uint32_t aux;  // source width (13 bits) | mirrored<<13 | opaque<<14 | rotated<<15 | const_alpha(0..256)<<16
 };
+// A rotated command (aux bit 15) keeps its bounding box in geom, its source height in iy, the index of its
+// parameter record (RenderLds::rot) in basex; srcy0 / ix are unused.
 PG_DEV int cmd_src_w(uint32_t aux) { return (int)(aux & 0x1fffu); }
 PG_DEV bool cmd_mirrored(uint32_t aux) { return ((aux >> 13) & 1u) != 0; }
 PG_DEV bool cmd_opaque(uint32_t aux) { return ((aux >> 14) & 1u) != 0; }
+PG_DEV bool cmd_rotated(uint32_t aux) { return ((aux >> 15) & 1u) != 0; }
 PG_DEV int cmd_alpha(uint32_t aux) { return (int)(aux >> 16); }
 PG_DEV uint32_t cmd_aux(int src_w, bool mirrored, bool opaque, int io) {
     return (uint32_t)src_w | ((mirrored ? 1u : 0u) << 13) | (((opaque && io == 256) ? 1u : 0u) << 14) | ((uint32_t)io << 16);
 }
 
+// optional policy constants (defaults when a game does not declare them)
+template <class Game, class = void>
+struct GameUsesRotation {
+    static constexpr bool value = false;
+};
+template <class Game>
+struct GameUsesRotation<Game, decltype((void)Game::USES_ROTATION)> {
+    static constexpr bool value = Game::USES_ROTATION;
+};
+template <class Game, class = void>
+struct GameDrawsGrid {
+    static constexpr bool value = true;
+};
+template <class Game>
+struct GameDrawsGrid<Game, decltype((void)Game::DRAWS_GRID)> {
+    static constexpr bool value = Game::DRAWS_GRID;
+};
+template <class Game, class = void>
+struct GameCustomBackground {
+    static constexpr bool value = false;
+};
+template <class Game>
+struct GameCustomBackground<Game, decltype((void)Game::CUSTOM_BACKGROUND)> {
+    static constexpr bool value = Game::CUSTOM_BACKGROUND;
+};
+
+// parameter record of one rotated command (qt_transform_image): inverse mapping + three trapezoids
+constexpr int ROT_WORDS = 24;  // u0 v0 dudx dudy dvdx dvdy | 3 x (from_y to_y x_l dx_l x_r dx_r)
+
 // LDS arena of one render workgroup (one wave)
-struct RenderLds {
+template <class Game>
+struct RenderLdsT {
     uint32_t fb[BAND_ROWS * RES_W + 64];  // the band being rasterized, 0xffRRGGBB (+ a dump row for masked-off lanes)
     uint32_t ax[128];                // per-column / per-row tile geometry (setup_tile_axes)
     uint32_t ci[2][64];              // screen column -> the (at most two) cell columns covering it
     uint32_t ri[2][64];              // screen row    -> the (at most two) cell rows covering it
     uint32_t seamcols[64];           // screen columns covered by two cell columns
-    uint32_t cellimg[1024];          // window cell -> source image (atlas offset | opaque<<31), CELL_NONE = nothing to draw
+    uint32_t cellimg[GameDrawsGrid<Game>::value ? 1024 : 1];  // window cell -> source image (atlas offset | opaque<<31), CELL_NONE = nothing to draw
+    uint32_t rot[GameUsesRotation<Game>::value ? 64 * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane
 };
 constexpr uint32_t CELL_NONE = 0xffffffffu;
+
+// x86 double -> int32 conversion (cvttsd2si): out-of-range and NaN give INT_MIN.  Qt's edge walkers convert
+// unbounded slopes this way; the GPU's conversion saturates instead.
+PG_DEV int d2i_x86(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (int)0x80000000; }
+PG_DEV bool q_fuzzy_is_null(double v) { return (v < 0 ? -v : v) <= 0.000000000001; }
 
 template <class Game>
 struct Renderer {
     const DevCtx &d;
     const int env;
+    typedef RenderLdsT<Game> RenderLds;
     RenderLds *lds;
     uint32_t *fb;  // the band being rasterized: BAND_ROWS x 64 words of 0xffRRGGBB
     uint32_t *ax;  // tile-axis scratch (see setup_tile_axes)
@@ -100,6 +140,13 @@ struct Renderer {
 
     // ---- command set-up (lane-local) ----------------------------------------------------------------------
     // geom word: tx1 | ty1<<7 | w<<14 | h<<21, 0 = nothing to draw in this band
+    PG_DEV static int opacity_to_io(float opacity) {  // QPainter::setOpacity clamps to [0,1]; intOpacity = int(opacity * 256)
+        double o = (double)opacity;
+        if (o < 0) o = 0;
+        if (o > 1) o = 1;
+        return (int)(o * 256);
+    }
+    // qt_scale_image_32bit.  tr.w / tr.h may be negative (a 180 degree rotation arrives as a negative scale).
     PG_DEV void cmd_image(int img_index, bool mirrored, RectD tr, float opacity, uint32_t &geom, uint32_t &basex_o, uint32_t &srcy_o,
                           uint32_t &ix_o, uint32_t &iy_o, uint32_t &src_o, uint32_t &aux_o) const {
         geom = 0;
@@ -109,26 +156,32 @@ struct Renderer {
         const double sy = tr.h / (double)im.h;
         const int ix = (int)(65536 / sx);
         const int iy = (int)(65536 / sy);
-        int tx1 = q_round(tr.x), tx2 = q_round(tr.x + tr.w), ty1 = q_round(tr.y), ty2 = q_round(tr.y + tr.h);
+        const double right = tr.x + tr.w, bottom = tr.y + tr.h;
+        int tx1 = q_round(tr.x), tx2 = q_round(right), ty1 = q_round(tr.y), ty2 = q_round(bottom);
+        if (tx2 < tx1) { const int t = tx1; tx1 = tx2; tx2 = t; }
+        if (ty2 < ty1) { const int t = ty1; ty1 = ty2; ty2 = t; }
         if (tx1 < 0) tx1 = 0;
         if (ty1 < 0) ty1 = 0;
         if (tx2 > RES_W) tx2 = RES_W;
         if (ty2 > RES_H) ty2 = RES_H;
         int w = tx2 - tx1, h = ty2 - ty1;
         if (w <= 0 || h <= 0) return;
-        // Qt 5.9: qCeil(...) - 1 (pinned with tests/tools/qt_drawimage_probe.py)
-        const uint32_t basex = (uint32_t)((int)pg_ceil((tx1 + 0.5 - tr.x) * ix) - 1);
-        const uint32_t srcy = (uint32_t)((int)pg_ceil((ty1 + 0.5 - tr.y) * iy) - 1);
+        // Qt 5.9: qCeil(...) - 1 for positive scales (pinned with tests/tools/qt_drawimage_probe.py), qFloor(...) + 1
+        // from the far edge for negative ones (tests/tools/qt_rotate_probe.py)
+        uint32_t basex, srcy;
+        if (sx < 0) basex = (uint32_t)im.w * 65536u + (uint32_t)((int)pg_floor((tx1 + 0.5 - right) * ix) + 1);
+        else basex = (uint32_t)((int)pg_ceil((tx1 + 0.5 - tr.x) * ix) - 1);
+        if (sy < 0) srcy = (uint32_t)im.h * 65536u + (uint32_t)((int)pg_floor((ty1 + 0.5 - bottom) * iy) + 1);
+        else srcy = (uint32_t)((int)pg_ceil((ty1 + 0.5 - tr.y) * iy) - 1);
+        if ((int)(srcy >> 16) >= (int)im.h && iy < 0) { srcy += (uint32_t)iy; --h; }
+        if ((int)(basex >> 16) >= (int)im.w && ix < 0) { basex += (uint32_t)ix; --w; }
         const int yend = (int)((srcy + (uint32_t)iy * (uint32_t)(h - 1)) >> 16);
         if (yend < 0 || yend >= (int)im.h) --h;
         const int xend = (int)((basex + (uint32_t)ix * (uint32_t)(w - 1)) >> 16);
         if (xend < 0 || xend >= (int)im.w) --w;
         if (w <= 0 || h <= 0) return;
         if (ty1 >= row1 || ty1 + h <= row0) return;  // does not touch this wave's band
-        double o = (double)opacity;  // QPainter::setOpacity clamps to [0,1]; intOpacity = int(opacity * 256)
-        if (o < 0) o = 0;
-        if (o > 1) o = 1;
-        const int io = (int)(o * 256);
+        const int io = opacity_to_io(opacity);
         geom = (uint32_t)tx1 | ((uint32_t)ty1 << 7) | ((uint32_t)w << 14) | ((uint32_t)h << 21);
         basex_o = basex;
         srcy_o = srcy;
@@ -136,6 +189,156 @@ struct Renderer {
         iy_o = (uint32_t)iy;
         src_o = im.off;
         aux_o = cmd_aux((int)im.w, mirrored, im.opaque != 0, io);
+    }
+
+    // BAG:902-906: p.translate(cx, cy); p.rotate(rotation * 180 / PI); p.drawImage(QRectF(-w/2, -h/2, w, h), img).
+    // QTransform::rotate special-cases 90 / 180 / 270 degrees; QTransform::type() then routes the draw to the
+    // scale path (sine fuzzy-null: a 180 degree turn is a negative scale) or to qt_transform_image, whose set-up
+    // (inverse 16.16 mapping, three trapezoids with 16.16 edge walkers) is written to the lane's LDS record.
+    PG_DEV void cmd_image_rotated(int lane, int img_index, bool mirrored, RectD adjusted, float rotation, float opacity, uint32_t &geom,
+                                  uint32_t &basex_o, uint32_t &srcy_o, uint32_t &ix_o, uint32_t &iy_o, uint32_t &src_o, uint32_t &aux_o) {
+        geom = 0;
+        basex_o = srcy_o = ix_o = iy_o = src_o = aux_o = 0;
+        const double cx = adjusted.x + adjusted.w / 2, cy = adjusted.y + adjusted.h / 2;
+        const double a = (double)(rotation * 180 / PG_PI);
+        const RectD r = {-adjusted.w / 2, -adjusted.h / 2, adjusted.w, adjusted.h};
+        double sina = 0, cosa = 0;
+        if (a == 0) cosa = 1;
+        else if (a == 90. || a == -270.) sina = 1.;
+        else if (a == 270. || a == -90.) sina = -1.;
+        else if (a == 180.) cosa = -1.;
+        else {
+            const double b = 0.017453292519943295769 * a;
+            sina = pg_sin(b);
+            cosa = pg_cos(b);
+        }
+        const double m11 = cosa, m12 = sina, m21 = -sina, m22 = cosa;
+        if (q_fuzzy_is_null(m12) && q_fuzzy_is_null(m21)) {  // TxScale or below: qt_mapRect_non_normalizing + scale path
+            double x1, y1, x2, y2;
+            if (!q_fuzzy_is_null(m11 - 1) || !q_fuzzy_is_null(m22 - 1)) {
+                x1 = m11 * r.x + cx;
+                y1 = m22 * r.y + cy;
+                x2 = m11 * (r.x + r.w) + cx;
+                y2 = m22 * (r.y + r.h) + cy;
+            } else if (!q_fuzzy_is_null(cx) || !q_fuzzy_is_null(cy)) {
+                x1 = r.x + cx;
+                y1 = r.y + cy;
+                x2 = (r.x + r.w) + cx;
+                y2 = (r.y + r.h) + cy;
+            } else {
+                x1 = r.x;
+                y1 = r.y;
+                x2 = r.x + r.w;
+                y2 = r.y + r.h;
+            }
+            const RectD tr = {x1, y1, x2 - x1, y2 - y1};
+            cmd_image(img_index, mirrored, tr, opacity, geom, basex_o, srcy_o, ix_o, iy_o, src_o, aux_o);
+            return;
+        }
+        if constexpr (!GameUsesRotation<Game>::value) {
+            fail(PGE_UNSUPPORTED_DRAW);
+            return;
+        } else {
+            const ImgDesc im = d.assets->img[img_index];
+            double vx[4], vy[4], vu[4], vv[4];
+            {
+                const double L = r.x, T = r.y, R = r.x + r.w, B = r.y + r.h;
+                const double px[4] = {L, R, R, L}, py[4] = {T, T, B, B};
+                const double pu[4] = {0, (double)im.w, (double)im.w, 0}, pv[4] = {0, 0, (double)im.h, (double)im.h};
+                int topmost = 0;
+                double tx[4], ty[4];
+                for (int i = 0; i < 4; i++) {
+                    tx[i] = m11 * px[i] + m21 * py[i] + cx;
+                    ty[i] = m12 * px[i] + m22 * py[i] + cy;
+                }
+                for (int i = 1; i < 4; i++)
+                    if (ty[i] < ty[topmost]) topmost = i;
+                for (int i = 0; i < 4; i++) {
+                    const int k = (topmost + i) & 3;
+                    vx[i] = tx[k];
+                    vy[i] = ty[k];
+                    vu[i] = pu[k];
+                    vv[i] = pv[k];
+                }
+            }
+            {
+                const double dx1 = vx[1] - vx[0], dy1 = vy[1] - vy[0], dx2 = vx[3] - vx[0], dy2 = vy[3] - vy[0];
+                if (dx1 * dy2 - dx2 * dy1 > 0) {
+                    double t;
+                    t = vx[1]; vx[1] = vx[3]; vx[3] = t;
+                    t = vy[1]; vy[1] = vy[3]; vy[3] = t;
+                    t = vu[1]; vu[1] = vu[3]; vu[3] = t;
+                    t = vv[1]; vv[1] = vv[3]; vv[3] = t;
+                }
+            }
+            const double ux = vx[1] - vx[0], uy = vy[1] - vy[0], uu = vu[1] - vu[0], uv = vv[1] - vv[0];
+            const double wx = vx[2] - vx[0], wy = vy[2] - vy[0], wu = vu[2] - vu[0], wv = vv[2] - vv[0];
+            const double det = ux * wy - uy * wx;
+            if (det == 0) return;
+            const double det_inv = 1 / det;
+            const double i11 = (uu * wy - uy * wu) * det_inv;
+            const double i12 = (ux * wu - uu * wx) * det_inv;
+            const double i21 = (uv * wy - uy * wv) * det_inv;
+            const double i22 = (ux * wv - uv * wx) * det_inv;
+            const double mdx = vu[0] - i11 * vx[0] - i12 * vy[0];
+            const double mdy = vv[0] - i21 * vx[0] - i22 * vy[0];
+            uint32_t *rp = &lds->rot[lane * ROT_WORDS];
+            rp[0] = (uint32_t)(d2i_x86(pg_ceil((0.5 * i11 + 0.5 * i12 + mdx) * 0x10000)) - 1);  // u0
+            rp[1] = (uint32_t)(d2i_x86(pg_ceil((0.5 * i21 + 0.5 * i22 + mdy) * 0x10000)) - 1);  // v0
+            rp[2] = (uint32_t)d2i_x86(i11 * 0x10000);                                            // dudx
+            rp[3] = (uint32_t)d2i_x86(i12 * 0x10000);                                            // dudy
+            rp[4] = (uint32_t)d2i_x86(i21 * 0x10000);                                            // dvdx
+            rp[5] = (uint32_t)d2i_x86(i22 * 0x10000);                                            // dvdy
+            // trapezoids: (top-left, bottom-left, top-right, bottom-right, top y, bottom y) as vertex indices
+            int tl[3], bl[3], tr_[3], br[3], yt[3], yb[3];
+            if (vy[1] < vy[3]) {
+                tl[0] = 0; bl[0] = 1; tr_[0] = 0; br[0] = 3; yt[0] = 0; yb[0] = 1;
+                tl[1] = 1; bl[1] = 2; tr_[1] = 0; br[1] = 3; yt[1] = 1; yb[1] = 3;
+                tl[2] = 1; bl[2] = 2; tr_[2] = 3; br[2] = 2; yt[2] = 3; yb[2] = 2;
+            } else {
+                tl[0] = 0; bl[0] = 1; tr_[0] = 0; br[0] = 3; yt[0] = 0; yb[0] = 3;
+                tl[1] = 0; bl[1] = 1; tr_[1] = 3; br[1] = 2; yt[1] = 3; yb[1] = 1;
+                tl[2] = 1; bl[2] = 2; tr_[2] = 3; br[2] = 2; yt[2] = 1; yb[2] = 2;
+            }
+            int ymin = RES_H, ymax = 0;
+            for (int t = 0; t < 3; t++) {
+                int from_y = q_round(vy[yt[t]]), to_y = q_round(vy[yb[t]]);
+                if (from_y < 0) from_y = 0;
+                if (to_y > RES_H) to_y = RES_H;
+                uint32_t *tp = rp + 6 + 6 * t;
+                if (from_y >= to_y) {
+                    tp[0] = tp[1] = tp[2] = tp[3] = tp[4] = tp[5] = 0;
+                    continue;
+                }
+                const double left_slope = (vx[bl[t]] - vx[tl[t]]) / (vy[bl[t]] - vy[tl[t]]);
+                const double right_slope = (vx[br[t]] - vx[tr_[t]]) / (vy[br[t]] - vy[tr_[t]]);
+                tp[0] = (uint32_t)from_y;
+                tp[1] = (uint32_t)to_y;
+                tp[2] = (uint32_t)d2i_x86((vx[tl[t]] + (0.5 + from_y - vy[tl[t]]) * left_slope + 0.5) * 0x10000);
+                tp[3] = (uint32_t)d2i_x86(left_slope * 0x10000);
+                tp[4] = (uint32_t)d2i_x86((vx[tr_[t]] + (0.5 + from_y - vy[tr_[t]]) * right_slope + 0.5) * 0x10000);
+                tp[5] = (uint32_t)d2i_x86(right_slope * 0x10000);
+                if (from_y < ymin) ymin = from_y;
+                if (to_y > ymax) ymax = to_y;
+            }
+            if (ymin >= ymax) return;
+            // bounding columns (conservative; the per-row spans decide coverage)
+            double xmin = vx[0], xmax = vx[0];
+            for (int i = 1; i < 4; i++) {
+                if (vx[i] < xmin) xmin = vx[i];
+                if (vx[i] > xmax) xmax = vx[i];
+            }
+            int bx1 = xmin < 1.0 ? 0 : (xmin > 63.0 ? 63 : (int)xmin - 1);
+            int bx2 = xmax > 62.0 ? RES_W : (xmax < 0.0 ? 1 : (int)xmax + 2);
+            if (bx1 < 0) bx1 = 0;
+            if (bx2 > RES_W) bx2 = RES_W;
+            if (ymin >= row1 || ymax <= row0) return;
+            geom = (uint32_t)bx1 | ((uint32_t)ymin << 7) | ((uint32_t)(bx2 - bx1) << 14) | ((uint32_t)(ymax - ymin) << 21);
+            basex_o = (uint32_t)lane;
+            iy_o = (uint32_t)im.h;
+            src_o = im.off;
+            aux_o = cmd_aux((int)im.w, mirrored, false, opacity_to_io(opacity)) | (1u << 15);
+        }
     }
     // draw_image BAG:877-913 for one drawable (lane-local); returns the image index or -1
     PG_DEV int resolve_image(int base_type, int theme, float rotation, float tile_ratio, RectD &rect) {
@@ -153,7 +356,8 @@ struct Renderer {
             fail(PGE_THEME);
             return -1;
         }
-        if (rotation != 0 || tile_ratio != 0) {
+        (void)rotation;
+        if (tile_ratio != 0) {
             fail(PGE_UNSUPPORTED_DRAW);
             return -1;
         }
@@ -443,6 +647,67 @@ struct Renderer {
         }
         PG_SYNC();
     }
+    // one rotated command (qt_transform_image_rasterize): the pixels of its bounding box are laid out linearly
+    // over the lanes; a pixel is covered when its row falls into one of the three trapezoids and its column into
+    // that row's span [x_l >> 16, x_r >> 16); its texel is the clamped inverse mapping of the pixel position.
+    PG_DEV void exec_rotated(const DrawCmd &c) {
+        if constexpr (GameUsesRotation<Game>::value) {
+            const uint32_t *rp = &lds->rot[(c.basex & 63u) * ROT_WORDS];
+            const uint32_t *src = d.pixels + c.src;
+            const int sw = cmd_src_w(c.aux), sh = (int)c.iy;
+            const bool mirrored = cmd_mirrored(c.aux);
+            const int io = cmd_alpha(c.aux);
+            const uint32_t ca = (uint32_t)((io * 255) >> 8);
+            const uint32_t u0 = rp[0], v0 = rp[1], dudx = rp[2], dudy = rp[3], dvdx = rp[4], dvdy = rp[5];
+            uint32_t tf[3], tt[3], txl[3], tdl[3], txr[3], tdr[3];
+            for (int t = 0; t < 3; t++) {
+                tf[t] = rp[6 + 6 * t];
+                tt[t] = rp[7 + 6 * t];
+                txl[t] = rp[8 + 6 * t];
+                tdl[t] = rp[9 + 6 * t];
+                txr[t] = rp[10 + 6 * t];
+                tdr[t] = rp[11 + 6 * t];
+            }
+            const int y0 = c.ty1 > row0 ? c.ty1 : row0;
+            const int y1 = (c.ty1 + c.h) < row1 ? (c.ty1 + c.h) : row1;
+            const int npix = c.w * (y1 - y0);
+            const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)c.w - 1u) / (uint32_t)c.w);
+            for (int base = 0; base < npix; base += 512) {
+                PG_FOR_LANES(l) {
+                    uint32_t tex[8];
+                    int fbi[8];
+                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                        const int p = base + j * 64 + l;
+                        const int pc = p < npix ? p : 0;
+                        const int pyb = (int)(((uint32_t)pc * inv) >> 20);
+                        const int X = c.tx1 + (pc - pyb * c.w);
+                        const int Y = y0 + pyb;
+                        // the trapezoids cover disjoint row ranges
+                        const bool s0 = (uint32_t)Y >= tf[0] && (uint32_t)Y < tt[0];
+                        const bool s1 = (uint32_t)Y >= tf[1] && (uint32_t)Y < tt[1];
+                        const bool s2 = (uint32_t)Y >= tf[2] && (uint32_t)Y < tt[2];
+                        const bool in_rows = s0 || s1 || s2;
+                        const uint32_t k = (uint32_t)Y - (s0 ? tf[0] : (s1 ? tf[1] : tf[2]));
+                        int from_x = (int)((s0 ? txl[0] : (s1 ? txl[1] : txl[2])) + k * (s0 ? tdl[0] : (s1 ? tdl[1] : tdl[2]))) >> 16;
+                        int to_x = (int)((s0 ? txr[0] : (s1 ? txr[1] : txr[2])) + k * (s0 ? tdr[0] : (s1 ? tdr[1] : tdr[2]))) >> 16;
+                        if (from_x < 0) from_x = 0;
+                        if (to_x > RES_W) to_x = RES_W;
+                        const bool in = p < npix && in_rows && X >= from_x && X < to_x;
+                        int uu = (int)((uint32_t)X * dudx + (uint32_t)Y * dudy + u0) >> 16;
+                        int vv = (int)((uint32_t)X * dvdx + (uint32_t)Y * dvdy + v0) >> 16;
+                        uu = uu < 0 ? 0 : (uu > sw - 1 ? sw - 1 : uu);
+                        vv = vv < 0 ? 0 : (vv > sh - 1 ? sh - 1 : vv);
+                        tex[j] = src[in ? (vv * sw + (mirrored ? (sw - 1 - uu) : uu)) : 0];
+                        fbi[j] = in ? ((Y - row0) * RES_W + X) : (BAND_ROWS * RES_W + l);  // masked-off lanes use the dump row
+                    }
+                    _Pragma("unroll") for (int j = 0; j < 8; j++) { fb[fbi[j]] = blend(tex[j], fb[fbi[j]], io, ca); }
+                }
+            }
+            PG_SYNC();
+        } else {
+            (void)c;
+        }
+    }
     // up to 8 commands of at most 8x8 pixels each: lane = (row, column) of the footprint; the 8 texel fetches are
     // issued together, the blends then run command by command (two commands may touch the same pixel from
     // different lanes, so each blend is its own lane section)
@@ -499,7 +764,8 @@ struct Renderer {
         // commands that exist, are selected by the caller, and touch the rows of the current pass
         uint64_t valid = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && (int)((PG_LV(r.geom, l) >> 7) & 0x7fu) < row1 &&
                                           (int)(((PG_LV(r.geom, l) >> 7) & 0x7fu) + ((PG_LV(r.geom, l) >> 21) & 0x7fu)) > row0) & lane_mask;
-        const uint64_t small = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && ((PG_LV(r.geom, l) >> 14) & 0x7fu) <= 8u && ((PG_LV(r.geom, l) >> 21) & 0x7fu) <= 8u);
+        const uint64_t small = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && ((PG_LV(r.geom, l) >> 14) & 0x7fu) <= 8u && ((PG_LV(r.geom, l) >> 21) & 0x7fu) <= 8u &&
+                                                !cmd_rotated(PG_LV(r.aux, l)));
         while (valid) {
             const int k = pg_ctz64(valid);
             if ((small >> k) & 1ull) {
@@ -520,7 +786,9 @@ struct Renderer {
                 exec_small_group(c, count);
             } else {
                 valid &= valid - 1;
-                exec_large(read_cmd(r, k));
+                const DrawCmd c = read_cmd(r, k);
+                if (cmd_rotated(c.aux)) exec_rotated(c);
+                else exec_large(c);
             }
         }
     }
@@ -547,10 +815,15 @@ struct Renderer {
                 } else {
                     r1 = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
                 }
-                const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), ef(EF_ROTATION, i), Game::tile_aspect_ratio(*this, i), r1);
-                if (im >= 0) cmd_image(im, (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, Game::tile_aspect_ratio(*this, i), r1);
+                const float rotation = ef(EF_ROTATION, i);
+                if (im >= 0) {
+                    if (rotation == 0) cmd_image(im, (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                    else cmd_image_rotated(l, im, (mm & MF_REFLECTED) != 0, r1, rotation, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                }
             }
         }
+        if constexpr (GameUsesRotation<Game>::value) PG_SYNC();  // the rotated commands' LDS records are read by every lane
     }
     PG_DEV void draw_entities(int render_z) {  // general path (more than 64 entities): one set-up per layer and chunk
         const int n = G.n_ents;
@@ -575,8 +848,28 @@ struct Renderer {
         // ---- frame-level set-up (rows [0, 64)) ------------------------------------------------------------------
         row0 = 0;
         row1 = RES_H;
-        uint32_t bg_geom = 0, bg_basex = 0, bg_srcy = 0, bg_ix = 0, bg_iy = 0, bg_src = 0, bg_aux = 0;  // wave-uniform command
-        if (d.opt.use_backgrounds && !(d.debug_flags & 1)) {
+        // wave-uniform background commands (one scaled image, or the visible tiles of a game's own background)
+        uint32_t bg_geom[2] = {0, 0}, bg_basex[2] = {0, 0}, bg_srcy[2] = {0, 0}, bg_ix[2] = {0, 0}, bg_iy[2] = {0, 0}, bg_src[2] = {0, 0}, bg_aux[2] = {0, 0};
+        int nbg = 0;
+        if constexpr (GameCustomBackground<Game>::value) {
+            if (d.opt.use_backgrounds && !(d.debug_flags & 1)) {
+                RectD rects[4];
+                const int nr = Game::background_rects(*this, rects);
+                const int bgi = (int)d.assets->bg_img[G.background_index];
+                for (int k = 0; k < nr; k++) {
+                    uint32_t g, bx, sy, ix, iy, sr, au;
+                    cmd_image(bgi, false, rects[k], 1.0f, g, bx, sy, ix, iy, sr, au);
+                    if (g != 0) {
+                        if (nbg >= 2) {
+                            fail(PGE_UNSUPPORTED_DRAW);
+                            break;
+                        }
+                        bg_geom[nbg] = g; bg_basex[nbg] = bx; bg_srcy[nbg] = sy; bg_ix[nbg] = ix; bg_iy[nbg] = iy; bg_src[nbg] = sr; bg_aux[nbg] = au;
+                        nbg++;
+                    }
+                }
+            }
+        } else if (d.opt.use_backgrounds && !(d.debug_flags & 1)) {
             const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);
             const int bgi = (int)d.assets->bg_img[G.background_index];
             if (G.bg_tile_ratio < 0) fail(PGE_UNSUPPORTED_DRAW);
@@ -587,7 +880,8 @@ struct Renderer {
             const float extra_w = bg_ar - world_ar;
             const float offset_x = G.bg_pct_x * extra_w;
             const RectD bg_rect = adjust_rect(main_rect, (double)(-offset_x), 0, (double)(bg_ar / world_ar), 1);
-            cmd_image(bgi, false, bg_rect, 1.0f, bg_geom, bg_basex, bg_srcy, bg_ix, bg_iy, bg_src, bg_aux);
+            cmd_image(bgi, false, bg_rect, 1.0f, bg_geom[0], bg_basex[0], bg_srcy[0], bg_ix[0], bg_iy[0], bg_src[0], bg_aux[0]);
+            nbg = bg_geom[0] != 0 ? 1 : 0;
         }
         // common case (<= 64 entities): their commands are built once and kept in registers for all passes
         if (d.debug_flags & 4) G.n_ents = 0;
@@ -611,12 +905,13 @@ struct Renderer {
         const int nx = win_hx - win_lx + 1;
         const int ny_full = win_hy - win_ly + 1;
         const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
-        const bool use_axes = nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
+        const bool use_axes = GameDrawsGrid<Game>::value && nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
         int ix_ref = 0, iy_ref = 0;
         if (use_axes) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);
         uint64_t colseam = 0, rowseam = 0;
-        const bool pull = use_axes && nx * ny_full <= 1024 && !(d.debug_flags & 1024) &&
-                          build_pull_tables(win_lx, nx, win_ly, ny_full, ix_ref, iy_ref, colseam, rowseam);
+        bool pull = false;
+        if constexpr (GameDrawsGrid<Game>::value)
+            pull = use_axes && nx * ny_full <= 1024 && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, ix_ref, iy_ref, colseam, rowseam);
 
         // ---- passes -------------------------------------------------------------------------------------------------
         for (int band = 0; band < NUM_BANDS; band++) {
@@ -626,8 +921,8 @@ struct Renderer {
                 PG_FOR_LANES(l) { fb[base + l] = 0xff000000u; }  // p.fillRect(rect, QColor(0,0,0))
             }
             PG_SYNC();
-            if (bg_geom != 0) {
-                const DrawCmd bc = unpack(bg_geom, bg_basex, bg_srcy, bg_ix, bg_iy, bg_src, bg_aux);
+            for (int k = 0; k < nbg; k++) {
+                const DrawCmd bc = unpack(bg_geom[k], bg_basex[k], bg_srcy[k], bg_ix[k], bg_iy[k], bg_src[k], bg_aux[k]);
                 if (bc.ty1 < row1 && bc.ty1 + bc.h > row0) exec_large(bc);
             }
             if (one_chunk) {
@@ -648,10 +943,11 @@ struct Renderer {
             }
             const int low_x = win_lx;
             const int ny = high_y - low_y + 1;
-            const int ncell = (ny > 0 && nx > 0) ? nx * ny : 0;
+            const int ncell = (GameDrawsGrid<Game>::value && ny > 0 && nx > 0) ? nx * ny : 0;
             const uint32_t ny_inv = ny > 0 ? (uint32_t)(((1u << 20) + (uint32_t)ny - 1u) / (uint32_t)ny) : 0u;
             if (ncell > 4096) fail(PGE_ASSERT);
-            if (pull && !(d.debug_flags & 2)) draw_tiles_pull(ny_full, colseam, rowseam);
+            if constexpr (GameDrawsGrid<Game>::value)
+                if (pull && !(d.debug_flags & 2)) draw_tiles_pull(ny_full, colseam, rowseam);
             for (int base = 0; base < ((pull || (d.debug_flags & 2)) ? 0 : ncell); base += 64) {
                 CmdRegs r;
                 PG_FOR_LANES(l) {

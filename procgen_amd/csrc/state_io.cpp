@@ -113,7 +113,7 @@ bool read_rng(Reader &r, int *seeded, uint32_t *mt, int *idx) {
 }
 
 bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h) {
-    if (game_id == GAME_BIGFISH) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64
+    if (game_id == GAME_BIGFISH || game_id == GAME_STARPILOT) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64, starpilot.cpp:330
     if (game_id == GAME_MAZE || game_id == GAME_MINER)  // maze.cpp:66, miner.cpp:140
         return h.initial_reset_complete ? opt.distribution_mode == MemoryMode : opt.center_agent != 0;
     return opt.center_agent != 0;
@@ -165,9 +165,9 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
     // BasicAbstractGame::serialize BAG:1169-1223
     w.i(h.main_width * h.main_height);  // grid_size
     w.i(h.n_ents);
-    const int cap = s.ent_cap;
-    auto W = [&](int f, int i) { return s.ents[(size_t)f * cap + i]; };
-    for (int i = 0; i < h.n_ents; i++) {  // Entity::serialize reference src/entity.cpp:90-137
+    auto write_entities = [&](const uint32_t *tab, int cap, int count) {
+    auto W = [&](int f, int i) { return tab[(size_t)f * cap + i]; };
+    for (int i = 0; i < count; i++) {  // Entity::serialize reference src/entity.cpp:90-137
         const uint32_t m = W(EF_META, i);
         auto wf = [&](int f) {
             uint32_t v = W(f, i);
@@ -190,6 +190,8 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
         w.i((m & MF_AUTO_ERASE) != 0);
         wf(EF_ALPHA); wf(EF_HEALTH); wf(EF_THETA); wf(EF_GROW_RATE); wf(EF_ALPHA_DECAY); wf(EF_CLIMBER_SPAWN_X);
     }
+    };
+    write_entities(s.ents.data(), s.ent_cap, h.n_ents);
     w.i(0);  // use_procgen_background
     w.i(h.background_index);
     w.f(h.bg_tile_ratio);
@@ -245,6 +247,16 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
         w.i(h.gsi1);
     } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:309-312
         w.i(h.gsi0);
+    } else if (game_id == GAME_STARPILOT) {  // reference src/games/starpilot.cpp:432-435: write_entities(spawners)
+        const int cell_bytes = (16 * 16 + 15) & ~15;
+        const int spawn_cap = 256;
+        const uint32_t *tab = reinterpret_cast<const uint32_t *>(s.grid.data() + cell_bytes);
+        if ((size_t)cell_bytes + (size_t)EF_COUNT * spawn_cap * 4 > s.grid.size() || h.gsi0 < 0 || h.gsi0 > spawn_cap) {
+            if (err) *err = "starpilot: malformed spawner table";
+            return false;
+        }
+        w.i(h.gsi0);
+        write_entities(tab, spawn_cap, h.gsi0);
     } else if (game_id == GAME_CLIMBER) {  // reference src/games/climber.cpp:318-327
         w.i(h.gsi1 ? 1 : 0);
         w.i(h.gsi2 ? 1 : 0);
@@ -313,7 +325,9 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
     if (!r.ok || n < 0 || n > cap - 1) return bad("set_state: entity count exceeds the table capacity");
     h.n_ents = n;
     h.agent = -1;
-    auto W = [&](int f, int i) -> uint32_t & { return s->ents[(size_t)f * cap + i]; };
+    int last_player = -1;
+    auto read_entities = [&](uint32_t *tab, int cap, int n) {
+    auto W = [&](int f, int i) -> uint32_t & { return tab[(size_t)f * cap + i]; };
     for (int i = 0; i < n; i++) {
         auto rf = [&](int f) { r.raw(&W(f, i), 4); };
         rf(EF_X); rf(EF_Y); rf(EF_VX); rf(EF_VY); rf(EF_RX); rf(EF_RY);
@@ -332,8 +346,11 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         if (r.i()) m |= MF_AUTO_ERASE;
         rf(EF_ALPHA); rf(EF_HEALTH); rf(EF_THETA); rf(EF_GROW_RATE); rf(EF_ALPHA_DECAY); rf(EF_CLIMBER_SPAWN_X);
         W(EF_META, i) = m;
-        if (type == PLAYER) h.agent = i;  // find_entity_index returns the LAST match, BAG:1133-1143
+        if (type == PLAYER) last_player = i;
     }
+    };
+    read_entities(s->ents.data(), cap, n);
+    h.agent = last_player;  // find_entity_index returns the LAST match, BAG:1133-1143
     if (h.agent < 0) return bad("fassert failed 'agent_idx >= 0'");
     r.i();  // use_procgen_background
     h.background_index = r.i();
@@ -387,6 +404,16 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         h.gsi1 = r.i();
     } else if (game_id == GAME_MINER) {
         h.gsi0 = r.i();
+    } else if (game_id == GAME_STARPILOT) {  // read_entities(spawners), starpilot.cpp:437-442
+        const int cell_bytes = (16 * 16 + 15) & ~15;
+        const int spawn_cap = 256;
+        const int ns = r.i();
+        if (!r.ok || ns < 0 || ns > spawn_cap || (size_t)cell_bytes + (size_t)EF_COUNT * spawn_cap * 4 > s->grid.size())
+            return bad("set_state: spawner count exceeds the table capacity");
+        uint32_t *tab = reinterpret_cast<uint32_t *>(s->grid.data() + cell_bytes);
+        read_entities(tab, spawn_cap, ns);
+        h.gsi0 = ns;
+        h.gsi1 = ns > 0 ? (int)tab[(size_t)EF_SPAWN_TIME * spawn_cap + (ns - 1)] : -1;
     } else if (game_id == GAME_CLIMBER) {
         h.gsi1 = r.i() > 0;
         h.gsi2 = r.i() > 0;

@@ -11,6 +11,7 @@
 
 #include "assets.h"
 #include "games.h"
+#include "pg_math.h"
 #include "pg_render.h"
 #include "host_state.h"
 #include "state_io.h"
@@ -51,7 +52,7 @@ static void run_all(EmuVec *v, int mode) {
         else if (tier == 1) run_env<Game, Game::ENT_CAP_T1>(v, e, mode);
         else run_env<Game, Game::ENT_CAP_T2>(v, e, mode);
     }
-    static RenderLds rlds;
+    static RenderLdsT<Game> rlds;
     for (int e = 0; e < v->n; e++) {  // "render kernel": one wave per env
         Renderer<Game> r(v->d, e, &rlds);
         r.render_env();
@@ -85,7 +86,7 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
 #define PG_X(Game)                                                                            \
     if (gid == Game::GAME_ID) {                                                               \
         ent_cap = Game::ENT_CAP_T2;                                                           \
-        grid_bytes = (int)((Game::MAX_CELLS * sizeof(Game::cell_t) + 15) & ~(size_t)15);      \
+        grid_bytes = game_grid_bytes<Game>();                                                 \
     }
     PG_FOR_EACH_GAME(PG_X)
 #undef PG_X
@@ -197,15 +198,19 @@ int emu_set_state(void *h, int env, const char *data, int length) {
     v->pls[env] = s.hdr.prev_level_seed;
     v->plc[env] = (uint8_t)s.hdr.level_complete;
     v->ls[env] = s.hdr.current_level_seed;
-    static RenderLds rlds;
 #define PG_X(Game)                            \
     if (v->game_id == Game::GAME_ID) {        \
+        static RenderLdsT<Game> rlds;         \
         Renderer<Game> r(v->d, env, &rlds);   \
         r.render_env();                       \
     }
     PG_FOR_EACH_GAME(PG_X)
 #undef PG_X
     return 0;
+}
+// pg_math.h restatements, exposed for tests/test_device_math.py
+void emu_atan2f_array(const float *y, const float *x, float *out, int n) {
+    for (int i = 0; i < n; i++) out[i] = pg_atan2f(y[i], x[i]);
 }
 int emu_error(void *h, int env) { return ((EmuVec *)h)->hdr[env].error | ((EmuVec *)h)->dev_error; }
 int emu_num_entities(void *h, int env) { return ((EmuVec *)h)->hdr[env].n_ents; }

@@ -1,0 +1,41 @@
+"""
+pg_math.h (the libm functions of the reference's STATE path, restated for the device) against the host libm --
+the library the compiled reference links.  Runs the host build of the same header (tests/emu).
+"""
+import ctypes as C
+import ctypes.util
+
+import numpy as np
+
+from emu import emu_harness
+
+
+def _libm_atan2f(y, x):
+    libm = C.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    libm.atan2f.restype = C.c_float
+    libm.atan2f.argtypes = [C.c_float, C.c_float]
+    return np.array([libm.atan2f(float(a), float(b)) for a, b in zip(y, x)], dtype=np.float32)
+
+
+def test_atan2f_matches_host_libm_bit_for_bit():
+    L = emu_harness.lib()
+    L.emu_atan2f_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.RandomState(7)
+    parts = [
+        (rng.uniform(-20, 20, 60000), rng.uniform(-20, 20, 60000)),            # entity-to-agent offsets in world units
+        (rng.uniform(-1, 1, 20000) * 1e-3, rng.uniform(-1, 1, 20000)),          # nearly horizontal
+        (rng.uniform(-1, 1, 20000), rng.uniform(-1, 1, 20000) * 1e-3),          # nearly vertical
+    ]
+    bits = rng.randint(0, 2 ** 32, size=(2, 40000), dtype=np.uint64).astype(np.uint32)  # arbitrary bit patterns (inf, nan, denormals)
+    parts.append((bits[0].view(np.float32), bits[1].view(np.float32)))
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, 0.8, -0.8, -6.99382e-8, 1e-30], dtype=np.float32)
+    sy, sx = np.meshgrid(special, special)
+    parts.append((sy.ravel(), sx.ravel()))
+    y = np.concatenate([np.asarray(p[0], dtype=np.float32) for p in parts])
+    x = np.concatenate([np.asarray(p[1], dtype=np.float32) for p in parts])
+    out = np.zeros_like(y)
+    L.emu_atan2f_array(y.ctypes.data, x.ctypes.data, out.ctypes.data, len(y))
+    ref = _libm_atan2f(y, x)
+    both_nan = np.isnan(out) & np.isnan(ref)
+    same = (out.view(np.uint32) == ref.view(np.uint32)) | both_nan
+    assert same.all(), f"{(~same).sum()} of {len(y)} differ, first: y={y[~same][0]!r} x={x[~same][0]!r}"
