@@ -35,20 +35,20 @@ ALGO_BYTES_PER_ENV_STEP = 12288 + 4 + 1 + 9 + 4  # obs + reward + first + info +
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(budget_s=15.0):
+def cpu_baseline(game="coinrun", budget_s=15.0):
     """Reported baseline, not the optimisation target."""
     import ref_env
 
     if ref_env.available():
         cores = os.cpu_count() or 1
         n = 1024
-        env = ref_env.make_ref_env(n, "coinrun", rand_seed=23, num_threads=cores)
+        env = ref_env.make_ref_env(n, game, rand_seed=23, num_threads=cores)
         kind, label = "reference", f"compiled reference C++/Qt (oracle/_ref), num_threads={cores}"
     else:
         import oracle_env
 
         cores, n = 1, 256
-        env = oracle_env.OracleEnv(n, "coinrun", rand_seed=23)
+        env = oracle_env.OracleEnv(n, game, rand_seed=23)
         kind, label = "port", "plain-C oracle port, single thread"
     rng = np.random.RandomState(0)
     env.observe()
@@ -64,7 +64,7 @@ def cpu_baseline(budget_s=15.0):
     dt = time.perf_counter() - t0
     env.close()
     return {"value": round(n * steps / dt, 1), "unit": "env steps/sec", "cores": cores, "kind": kind,
-            "sample": f"coinrun num_envs={n}, {steps} steps, random actions, {label}"}
+            "sample": f"{game} num_envs={n}, {steps} steps, random actions, {label}"}
 
 
 def main():
@@ -153,7 +153,7 @@ def main():
                          "kernel_ms_per_step": round(kernel_ms, 4), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(args.game)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -11,6 +11,7 @@ struct LaunchStreams {
     hipEvent_t fork, join;
     hipStream_t lane[2];      // env chunks alternate between these two streams (step of chunk c+1 overlaps render of chunk c)
     hipEvent_t lane_done[2];
+    hipEvent_t tier2_done;    // the tier-2 list kernel runs on lane[1] ahead of that lane's chunk
     int chunks;               // 1 = everything on `main`
 };
 // mode 0: initial reset + first observation of every env; mode 1: one step

@@ -20,7 +20,7 @@ template <class Game>
 __global__ __launch_bounds__(64) void step_tier0(DevCtx d, int mode, int env_base) {
     __shared__ Lds<Game, Game::ENT_CAP_T0> lds;
     const int env = env_base + (int)blockIdx.x;
-    if (mode != 0 && d.hdr[env].big != 0) return;
+    if (mode != 0 && d.route[env] != 0) return;  // owned by a larger arena this step
     Env<Game, Game::ENT_CAP_T0> e(d, env, &lds);
     e.run(mode);
 }
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64) void step_list(DevCtx d, int mode) {
     const int *list = d.big_list + (size_t)(TIER - 1) * d.num_envs;
     for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
         const int env = list[k];
-        if (d.hdr[env].big != TIER) continue;  // set_state moved this env to another tier after the list was built
+        if (d.route[env] != TIER) continue;  // set_state moved this env to another tier after the list was built
         Env<Game, CAP> e(d, env, &lds);
         e.run(mode);
         __syncthreads();
@@ -65,8 +65,8 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         PG_TRY(hipStreamWaitEvent(ls.lane[1], ls.fork, 0));
         hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.side, d, mode);
         hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.lane[1], d, mode);
-        PG_TRY(hipEventRecord(ls.lane_done[1], ls.lane[1]));
-        PG_TRY(hipStreamWaitEvent(ls.side, ls.lane_done[1], 0));
+        PG_TRY(hipEventRecord(ls.tier2_done, ls.lane[1]));
+        PG_TRY(hipStreamWaitEvent(ls.side, ls.tier2_done, 0));
         PG_TRY(hipEventRecord(ls.join, ls.side));
     }
     const int nchunk = (ls.chunks > 1 && d.num_envs >= 4096) ? ls.chunks : 1;

@@ -110,11 +110,11 @@ struct VecGame {
     bool host_observations = true;
     std::vector<libenv_tensortype> observation_types, action_types, info_types;
     hipStream_t stream = nullptr, side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tier2 = nullptr;
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_lane[2] = {nullptr, nullptr};
     int chunks = 2;  // PROCGEN_AMD_CHUNKS: env range cut in 2 so one chunk's step kernel overlaps the other's render kernel (+6 % measured)
-    LaunchStreams streams() const { return LaunchStreams{stream, side_stream, ev_fork, ev_join, {lane_stream[0], lane_stream[1]}, {ev_lane[0], ev_lane[1]}, chunks}; }
+    LaunchStreams streams() const { return LaunchStreams{stream, side_stream, ev_fork, ev_join, {lane_stream[0], lane_stream[1]}, {ev_lane[0], ev_lane[1]}, ev_tier2, chunks}; }
     DevCtx d{};
     HostAssets assets;
     GameAssetsDev *d_assets = nullptr;
@@ -124,6 +124,16 @@ struct VecGame {
     size_t small_bytes = 0;
     int *d_big_list[2] = {nullptr, nullptr};
     int *d_big_count[2] = {nullptr, nullptr};
+    uint8_t *d_route[2] = {nullptr, nullptr};
+    void bind_routing() {  // double-buffered by step parity: this step reads [cur], fills [nxt]
+        const int cur = (int)(step_count & 1), nxt = cur ^ 1;
+        d.big_list = d_big_list[cur];
+        d.big_count = d_big_count[cur];
+        d.next_big_list = d_big_list[nxt];
+        d.next_big_count = d_big_count[nxt];
+        d.route = d_route[cur];
+        d.next_route = d_route[nxt];
+    }
     uint64_t step_count = 0;
     // host staging (pinned)
     int32_t *h_action = nullptr;
@@ -273,6 +283,7 @@ VecGame::VecGame(int nenvs, VecOptions opts) {
     HIP_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_tier2, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) {
         HIP_CHECK(hipStreamCreateWithFlags(&lane_stream[k], hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ev_lane[k], hipEventDisableTiming));
@@ -318,6 +329,7 @@ VecGame::VecGame(int nenvs, VecOptions opts) {
     for (int k = 0; k < 2; k++) {
         d_big_list[k] = dev_alloc<int>(N * (NUM_TIERS - 1));
         d_big_count[k] = dev_alloc<int>(NUM_TIERS - 1);
+        d_route[k] = dev_alloc<uint8_t>(N);
     }
     d.assets = d_assets;
     d.pixels = d_pixels;
@@ -341,6 +353,7 @@ VecGame::~VecGame() {
     for (int k = 0; k < 2; k++) {
         (void)hipFree(d_big_list[k]);
         (void)hipFree(d_big_count[k]);
+        (void)hipFree(d_route[k]);
     }
     if (h_action) (void)hipHostFree(h_action);
     if (h_small) (void)hipHostFree(h_small);
@@ -351,6 +364,7 @@ VecGame::~VecGame() {
     }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_tier2) (void)hipEventDestroy(ev_tier2);
     if (side_stream) (void)hipStreamDestroy(side_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -382,12 +396,8 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
 }
 
 void VecGame::launch(int mode) {
-    const int cur = (int)(step_count & 1), nxt = cur ^ 1;
-    d.big_list = d_big_list[cur];
-    d.big_count = d_big_count[cur];
-    d.next_big_list = d_big_list[nxt];
-    d.next_big_count = d_big_count[nxt];
-    HIP_CHECK(hipMemsetAsync(d_big_count[nxt], 0, sizeof(int) * (NUM_TIERS - 1), stream));
+    bind_routing();
+    HIP_CHECK(hipMemsetAsync(d.next_big_count, 0, sizeof(int) * (NUM_TIERS - 1), stream));
     HIP_CHECK(hipMemsetAsync(d.error, 0, sizeof(int), stream));
     HIP_CHECK(launch_step(game_id, d, mode, streams()));
     step_count++;
@@ -469,6 +479,10 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     HIP_CHECK(hipMemcpy(d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, s.rng.data(), s.rng.size() * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.grid + (size_t)e * d.grid_bytes, s.grid.data(), s.grid.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.hdr + e, &s.hdr, sizeof(EnvHdr), hipMemcpyHostToDevice));
+    {
+        const uint8_t tier = (uint8_t)s.hdr.big;  // the route table the next step reads
+        HIP_CHECK(hipMemcpy(d_route[step_count & 1] + e, &tier, 1, hipMemcpyHostToDevice));
+    }
     if (s.hdr.big && s.hdr.big != was_tier) {  // append to the list the next step's tier kernel will walk
         const int cur = (int)(step_count & 1), t = s.hdr.big - 1;
         int count = 0;
@@ -558,12 +572,8 @@ LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const in
     float total_ms = 0.f;
     for (int s = 0; s < steps; s++) {
         if (actions_or_null) HIP_CHECK(hipMemcpyAsync(v->d_action, actions_or_null + (size_t)s * v->num_envs, (size_t)v->num_envs * 4, hipMemcpyHostToDevice, v->stream));
-        const int cur = (int)(v->step_count & 1), nxt = cur ^ 1;
-        v->d.big_list = v->d_big_list[cur];
-        v->d.big_count = v->d_big_count[cur];
-        v->d.next_big_list = v->d_big_list[nxt];
-        v->d.next_big_count = v->d_big_count[nxt];
-        HIP_CHECK(hipMemsetAsync(v->d_big_count[nxt], 0, sizeof(int) * (NUM_TIERS - 1), v->stream));
+        v->bind_routing();
+        HIP_CHECK(hipMemsetAsync(v->d.next_big_count, 0, sizeof(int) * (NUM_TIERS - 1), v->stream));
         HIP_CHECK(hipEventRecord(e0, v->stream));
         HIP_CHECK(launch_step(v->game_id, v->d, 1, v->streams()));
         HIP_CHECK(hipEventRecord(e1, v->stream));

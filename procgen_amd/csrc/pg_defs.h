@@ -134,6 +134,10 @@ struct DevCtx {
     const int *big_count;  // [NUM_TIERS-1]
     int *next_big_list;    // [NUM_TIERS-1][num_envs] filled during this step
     int *next_big_count;   // [NUM_TIERS-1] zeroed by the host before the step
+    // tier that owns each env THIS step (written during the previous step, so it is stable while the step kernels of
+    // the three tiers run concurrently: an env re-routed by a fast kernel is not picked up again by a slower one)
+    const uint8_t *route;  // [num_envs]
+    uint8_t *next_route;   // [num_envs] written by every env's store_env
     int *error;            // [1] OR of the per-env error codes raised this step (0 = none)
     int debug_flags;       // PROCGEN_AMD_DEBUG: phase ablation bits for profiling only (0 in normal operation)
 };

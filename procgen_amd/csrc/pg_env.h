@@ -989,6 +989,7 @@ struct Env {
         if (G.error && d.error) *d.error |= G.error;
 #else
         if (PG_LANE_ID() == 0) {
+            if (d.next_route) d.next_route[env] = (uint8_t)G.big;
             if (G.big) {
                 const int t = G.big - 1;
                 const int slot = atomicAdd(d.next_big_count + t, 1);

@@ -147,6 +147,25 @@ def test_entity_table_overflow_routing():
     assert_rollouts_equal(a, b, "long rollout")
 
 
+def test_arena_tiers_run_concurrently_without_double_stepping(monkeypatch):
+    """The three arena-tier step kernels and the two env chunks share the GPU on separate streams.  An env that a
+    fast large-arena kernel hands back to tier 0 must not be stepped again by a tier-0 block that starts later:
+    200 steps at 16384 envs (enough for coinrun trails to push envs across tiers) give the same observations with
+    and without the chunk overlap, run after run, and the first 192 envs equal an oracle run."""
+    n, steps, m = 16384, 200, 192
+    acts = action_stream(n, steps, seed=11)
+    runs = []
+    for chunks in ("2", "2", "1"):
+        monkeypatch.setenv("PROCGEN_AMD_CHUNKS", chunks)
+        runs.append(rollout(make_env(n), acts))
+    for other in runs[1:]:
+        for k in runs[0]:
+            assert np.array_equal(runs[0][k], other[k]), k
+    small = rollout(oracle_env.OracleEnv(m, "coinrun", rand_seed=23), [a[:m] for a in acts])
+    for k in small:
+        assert np.array_equal(runs[0][k][:, :m], small[k]), k
+
+
 def test_bigfish_full_size_prefix_matches_oracle():
     """BASELINE configs[2] (bigfish, 65536 envs): the first 128 envs equal a 128-env oracle run."""
     n, steps, m = 65536, 10, 128
