@@ -8,7 +8,7 @@
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
  * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner,
- * starpilot.
+ * starpilot, fruitbot.
  */
 #include "procgen_oracle.h"
 
@@ -38,7 +38,19 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_MAZE = 11, GAME_MINER = 12, GAME_STARPILOT = 15 };
+enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_FRUITBOT = 7, GAME_MAZE = 11, GAME_MINER = 12, GAME_STARPILOT = 15 };
+
+/* fruitbot.cpp:8-24 */
+#define FB_BARRIER 1
+#define FB_OUT_OF_BOUNDS_WALL 2
+#define FB_PLAYER_BULLET 3
+#define FB_BAD_OBJ 4
+#define FB_GOOD_OBJ 7
+#define FB_LOCKED_DOOR 10
+#define FB_LOCK 11
+#define FB_PRESENT 12
+#define FB_KEY_DURATION 8
+#define FB_DOOR_ASPECT_RATIO 3.25f
 
 /* starpilot.cpp:6-27 */
 #define SP_V_SCALE (2.0f / 5.0f)
@@ -291,6 +303,16 @@ static void lower_copy(char *dst, const char *src) {
     *dst = 0;
 }
 
+static void assets_topdown_backgrounds(GameAssets *a) { /* topdown_backgrounds, reference src/resources.cpp:900-911 */
+    static const char *TOPDOWN[] = {"topdown_backgrounds/floortiles.png", "topdown_backgrounds/backgrounddetailed1.png",
+                                    "topdown_backgrounds/backgrounddetailed2.png", "topdown_backgrounds/backgrounddetailed3.png",
+                                    "topdown_backgrounds/backgrounddetailed4.png", "topdown_backgrounds/backgrounddetailed5.png",
+                                    "topdown_backgrounds/backgrounddetailed6.png", "topdown_backgrounds/backgrounddetailed7.png",
+                                    "topdown_backgrounds/backgrounddetailed8.png"};
+    a->n_bg = 9;
+    for (int i = 0; i < 9; i++) a->bg_img[i] = assets_add(a, TOPDOWN[i], 1);
+}
+
 static void assets_build(int game_id) {
     GameAssets *a = &g_assets[game_id];
     if (a->built) return;
@@ -386,6 +408,26 @@ static void assets_build(int game_id) {
         assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_FRUITBOT) { /* fruitbot.cpp:42-78 */
+        assets_type(a, PLAYER, "misc_assets/robot_3Dblue.png");
+        assets_type(a, FB_BARRIER, "misc_assets/tileStone_slope.png");
+        assets_type(a, FB_OUT_OF_BOUNDS_WALL, "misc_assets/tileStone_slope.png");
+        assets_type(a, FB_PLAYER_BULLET, "misc_assets/keyRed2.png");
+        for (int i = 1; i <= 6; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/food%d.png", i);
+            assets_type(a, FB_BAD_OBJ, buf);
+        }
+        for (int i = 1; i <= 6; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/fruit%d.png", i);
+            assets_type(a, FB_GOOD_OBJ, buf);
+        }
+        assets_type(a, FB_LOCKED_DOOR, "misc_assets/fenceYellow.png");
+        assets_type(a, FB_LOCK, "misc_assets/lockRed2.png");
+        for (int i = 1; i <= 3; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/present%d.png", i);
+            assets_type(a, FB_PRESENT, buf);
+        }
+        assets_topdown_backgrounds(a);
     } else if (game_id == GAME_STARPILOT) { /* starpilot.cpp:59-106 */
         assets_type(a, PLAYER, "misc_assets/playerShip2_blue.png");
         assets_type(a, SP_BULLET_PLAYER, "misc_assets/towerDefense_tile295.png");
@@ -422,14 +464,7 @@ static void assets_build(int game_id) {
         assets_type(a, WALL_OBJ, "kenney/Ground/Sand/sandCenter.png");
         assets_type(a, MZ_GOAL, "misc_assets/cheese.png");
         assets_type(a, PLAYER, "kenney/Enemies/mouse_move.png");
-        /* topdown_backgrounds, reference src/resources.cpp:900-911 */
-        static const char *TOPDOWN[] = {"topdown_backgrounds/floortiles.png", "topdown_backgrounds/backgrounddetailed1.png",
-                                        "topdown_backgrounds/backgrounddetailed2.png", "topdown_backgrounds/backgrounddetailed3.png",
-                                        "topdown_backgrounds/backgrounddetailed4.png", "topdown_backgrounds/backgrounddetailed5.png",
-                                        "topdown_backgrounds/backgrounddetailed6.png", "topdown_backgrounds/backgrounddetailed7.png",
-                                        "topdown_backgrounds/backgrounddetailed8.png"};
-        a->n_bg = 9;
-        for (int i = 0; i < 9; i++) a->bg_img[i] = assets_add(a, TOPDOWN[i], 1);
+        assets_topdown_backgrounds(a);
     } else {
         fatal("game not restated in the oracle");
     }
@@ -442,6 +477,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "climber") == 0) return GAME_CLIMBER;
     if (strcmp(name, "miner") == 0) return GAME_MINER;
     if (strcmp(name, "starpilot") == 0) return GAME_STARPILOT;
+    if (strcmp(name, "fruitbot") == 0) return GAME_FRUITBOT;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -516,6 +552,9 @@ typedef struct {
     int diamonds_remaining;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
+    /* FruitBotGame: fruitbot.cpp:28-30 */
+    float min_dim, bullet_vscale;
+    int last_fire_time;
     /* StarPilotGame: starpilot.cpp:34-50 */
     Ent spawners[SP_MAX_SPAWNERS];
     int n_spawners;
@@ -602,6 +641,9 @@ static int hook_is_blocked(const Game *g, const Ent *src, int target, int is_hor
     if (g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) { /* coinrun.cpp:204-211, climber.cpp:136-143 */
         if (src->type == PLAYER && cr_is_wall(target)) return 1;
     }
+    if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:84-86 */
+        if (src->type == PLAYER && target == FB_OUT_OF_BOUNDS_WALL) return 1;
+    }
     if (g->game_id == GAME_MINER) { /* miner.cpp:57-64 */
         if (src->type == PLAYER && (target == MN_BOULDER || target == MN_MOVING_BOULDER || target == MN_OOB_WALL)) return 1;
     }
@@ -623,6 +665,8 @@ static int hook_is_blocked_ents(Game *g, const Ent *src, const Ent *target, int 
 static int hook_will_reflect(const Game *g, int src, int target) {
     if (g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) /* coinrun.cpp:140-142, climber.cpp:110-112 (same ids) */
         return (src == CR_ENEMY && (cr_is_wall(target) || target == CR_ENEMY_BARRIER));
+    if (g->game_id == GAME_FRUITBOT) /* fruitbot.cpp:80-82 */
+        return (src == FB_BAD_OBJ && (target == FB_BARRIER || target == WALL_OBJ));
     if (g->game_id == GAME_MINER) /* miner.cpp:66-68 */
         return (src == MN_ENEMY && (target == MN_BOULDER || target == MN_DIAMOND || target == MN_MOVING_BOULDER || target == MN_MOVING_DIAMOND || target == g->out_of_bounds_object));
     return 0; /* BAG:498-500 */
@@ -654,6 +698,22 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
             g->reward += 1.0f;
             g->coins_collected += 1;
             obj->will_erase = 1;
+        }
+    } else if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:96-118 */
+        if (obj->type == FB_BARRIER) {
+            g->done = 1;
+        } else if (obj->type == FB_BAD_OBJ) {
+            g->reward += -4.0f;
+            obj->will_erase = 1;
+        } else if (obj->type == FB_LOCKED_DOOR) {
+            g->done = 1;
+        } else if (obj->type == FB_GOOD_OBJ) {
+            g->reward += 1.0f;
+            obj->will_erase = 1;
+        } else if (obj->type == FB_PRESENT) {
+            g->reward += 10.0f;
+            g->done = 1;
+            g->level_complete = 1;
         }
     } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:126-136 */
         if (obj->type == SP_FINISH_LINE) {
@@ -693,6 +753,23 @@ static void hook_handle_grid_collision(Game *g, Ent *obj, int type, int i, int j
     }
 }
 static void hook_handle_collision(Game *g, Ent *src, Ent *target) { /* BAG:398 */
+    if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:120-138 */
+        if (src->type == FB_PLAYER_BULLET) {
+            if (target->type == FB_BARRIER) {
+                src->will_erase = 1;
+            } else if (target->type == FB_LOCK) {
+                src->will_erase = 1;
+                target->will_erase = 1;
+                for (int k = 0; k < g->n_ents; k++) {
+                    Ent *ent = &g->pool[g->ents[k]];
+                    if (ent->type == FB_LOCKED_DOOR && fabs((double)(ent->y - target->y)) < 1) {
+                        ent->will_erase = 1;
+                        break;
+                    }
+                }
+            }
+        }
+    }
     if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:138-146 */
         if (src->type == SP_BULLET_PLAYER && target->type != SP_CLOUD && sp_is_destructible(target->type)) {
             src->will_erase = 1;
@@ -885,6 +962,9 @@ static void hook_set_action_xy(Game *g, int move_act) {
         g->has_support = s1 || s2;
         if (g->has_support && g->action_vy == 1) g->action_vy = 1;
         else g->action_vy = 0;
+    } else if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:162-166 */
+        g->action_vy = 0.2f;
+        g->action_vrot = 0;
     } else {
         g->action_vrot = 0; /* BAG:658-662 */
         if (g->game_id == GAME_MAZE || g->game_id == GAME_MINER) { /* maze.cpp:99-103, miner.cpp:98-102 */
@@ -1024,6 +1104,15 @@ static void game_step(Game *g) {
         mn_game_step_tail(g);
     } else if (g->game_id == GAME_STARPILOT) {
         sp_game_step_tail(g);
+    } else if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:251-262 */
+        if (g->special_action == 1 && (g->cur_time - g->last_fire_time) >= FB_KEY_DURATION) {
+            const Ent *agent = &g->pool[g->agent];
+            float vx = 0, vy = 1;
+            Ent *nb = push_entity(g, agent->x, agent->y, vx * g->bullet_vscale, vy * g->bullet_vscale, (float).25, (float).25, FB_PLAYER_BULLET);
+            nb->expire_time = FB_KEY_DURATION;
+            nb->collides_with_entities = 1;
+            g->last_fire_time = g->cur_time;
+        }
     } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:290-316 */
         Ent *agent = &g->pool[g->agent];
         if (g->action_vx > 0) agent->is_reflected = 0;
@@ -1220,6 +1309,112 @@ static float rand_pos(Game *g, float r, float min, float max) { /* BAG:1100-1108
 
 static void face_direction(Ent *e, float dx, float dy, float rotation_offset) { /* entity.cpp:84-88; atan2f by overload */
     if (dx != 0 || dy != 0) e->rotation = -1 * atan2f(dy, dx) + rotation_offset;
+}
+
+static int has_any_collision(const Game *g, const Ent *e1, float margin) { /* BAG:1114-1124 */
+    for (int i = g->n_ents - 1; i >= 0; i--) {
+        const Ent *ent = &g->pool[g->ents[i]];
+        if (!ent->avoids_collisions && has_collision(e1, ent, margin)) return 1;
+    }
+    return 0;
+}
+static void reposition(Game *g, Ent *ent, float x, float y, float w, float h, int check_collisions) { /* BAG:541-560 */
+    float rx = ent->rx, ry = ent->ry;
+    ent->x = rand_pos(g, rx, x, x + w);
+    ent->y = rand_pos(g, ry, y, y + h);
+    int count = 0;
+    while ((has_agent_collision(g, ent) || (check_collisions && has_any_collision(g, ent, 0))) && (count < 100)) {
+        ent->x = rand_pos(g, rx, x, x + w);
+        ent->y = rand_pos(g, ry, y, y + h);
+        count++;
+    }
+}
+static Ent *spawn_entity_rxy(Game *g, float rx, float ry, int type, float x, float y, float w, float h, int check_collisions) { /* BAG:511-519 */
+    int id = pool_alloc(g);
+    Ent *ent = &g->pool[id];
+    ent_init(ent, 0, 0, 0, 0, rx, ry, type);
+    reposition(g, ent, x, y, w, h, check_collisions);
+    if (g->n_ents >= MAX_ENTS) fatal("entity list overflow");
+    g->ents[g->n_ents++] = id;
+    return ent;
+}
+static void spawn_entities(Game *g, int num, float r, int type, float x, float y, float w, float h) { /* BAG:585-589 */
+    for (int i = 0; i < num; i++) spawn_entity_rxy(g, r, r, type, x, y, w, h, 1);
+}
+static void fit_aspect_ratio(Game *g, Ent *ent) { /* BAG:1025-1036 */
+    if (g->assets->type_num_themes[ent->image_type] <= ent->image_theme) fatal("asset theme out of range");
+    const Img *im = &g->assets->img[g->assets->type_theme_img[ent->image_type][ent->image_theme]];
+    float ar = (float)(im->w * 1.0 / im->h);
+    if (ar > 1) ent->ry = ent->rx / ar;
+    else ent->rx = ent->ry * ar;
+}
+
+/* ---- FruitBot: fruitbot.cpp:168-249 ---- */
+static void fb_add_walls(Game *g, float ry, int use_door, float min_pct) { /* fruitbot.cpp:168-201 */
+    float rw = (float)g->main_width;
+    float wall_ry = 0.3f;
+    float lock_rx = (float).25;
+    float lock_ry = 0.45f;
+    float pct = (float)(min_pct + .2 * rng_rand01(&g->rand_gen));
+    if (use_door) {
+        pct += 0.1f;
+        float lock_pct_w = 2 * lock_rx / g->main_width;
+        float door_pct_w = (wall_ry * 2 * FB_DOOR_ASPECT_RATIO) / g->main_width;
+        int num_doors = (int)ceil((double)((pct - 2 * lock_pct_w) / door_pct_w));
+        pct = 2 * lock_pct_w + door_pct_w * num_doors;
+    }
+    float gapw = pct * rw;
+    float w1 = rng_rand01(&g->rand_gen) * (rw - gapw);
+    float w2 = rw - w1 - gapw;
+    push_entity(g, w1 / 2, ry, 0, 0, w1 / 2, wall_ry, FB_BARRIER);
+    push_entity(g, rw - w2 / 2, ry, 0, 0, w2 / 2, wall_ry, FB_BARRIER);
+    if (use_door) {
+        int is_on_right = rng_randn(&g->rand_gen, 2);
+        float lock_x = w1 + lock_rx + is_on_right * (gapw - 2 * lock_rx);
+        float door_x = w1 + gapw / 2 - (is_on_right * 2 - 1) * lock_rx;
+        push_entity(g, door_x, ry, 0, 0, gapw / 2 - lock_rx, wall_ry, FB_LOCKED_DOOR);
+        push_entity(g, lock_x, ry - lock_ry + wall_ry, 0, 0, lock_rx, lock_ry, FB_LOCK);
+    }
+}
+static void fb_game_reset(Game *g) { /* fruitbot.cpp:203-249 */
+    g->last_fire_time = 0;
+    int min_sep = 4, num_walls = 10, object_group_size = 6, buf_h = 4;
+    float door_prob = (float).125;
+    float min_pct = (float).1;
+    if (g->opt.distribution_mode == 0) {
+        num_walls = 5;
+        object_group_size = 2;
+        door_prob = 0;
+        min_pct = (float).2;
+    }
+    int partition[16] = {0}; /* RandGen::partition randgen.cpp:33-41 */
+    int px = g->main_height - min_sep * num_walls - buf_h;
+    for (int i = 0; i < px; i++) partition[rng_randn(&g->rand_gen, num_walls)] += 1;
+    int curr_h = 0;
+    for (int k = 0; k < num_walls; k++) {
+        int dy = min_sep + partition[k];
+        curr_h += dy;
+        int use_door = (dy > 5) && rng_rand01(&g->rand_gen) < door_prob;
+        fb_add_walls(g, (float)curr_h, use_door, min_pct);
+    }
+    Ent *agent = &g->pool[g->agent];
+    agent->y = agent->ry;
+    int num_good = rng_randn(&g->rand_gen, 10) + 10;
+    int num_bad = rng_randn(&g->rand_gen, 10) + 10;
+    for (int i = 0; i < g->main_width; i++) {
+        Ent *present = push_entity(g, (float)(i + .5), (float)(g->main_height - .5), 0, 0, (float).5, (float).5, FB_PRESENT);
+        choose_random_theme(g, present);
+    }
+    spawn_entities(g, num_good, (float).5, FB_GOOD_OBJ, 0, 0, (float)g->main_width, (float)g->main_height);
+    spawn_entities(g, num_bad, (float).5, FB_BAD_OBJ, 0, 0, (float)g->main_width, (float)g->main_height);
+    for (int k = 0; k < g->n_ents; k++) {
+        Ent *ent = &g->pool[g->ents[k]];
+        if (ent->type == FB_GOOD_OBJ || ent->type == FB_BAD_OBJ) {
+            ent->image_theme = rng_randn(&g->rand_gen, object_group_size);
+            fit_aspect_ratio(g, ent);
+        }
+    }
+    g->pool[g->agent].rotation = -1 * PI_F / 2;
 }
 
 /* ---- StarPilot: starpilot.cpp:148-443 ---- */
@@ -1657,6 +1852,10 @@ static void bag_game_reset(Game *g) { /* BAG:758-797 */
         else if (dm == 1) g->main_width = g->main_height = 20;
         else if (dm == 10) g->main_width = g->main_height = 35;
     }
+    if (g->game_id == GAME_FRUITBOT) { /* choose_world_dim fruitbot.cpp:152-160 */
+        g->main_width = g->opt.distribution_mode == 0 ? 10 : 20;
+        g->main_height = 60;
+    }
     if (g->game_id == GAME_CLIMBER) { /* choose_world_dim climber.cpp:230-233 */
         g->main_width = g->opt.distribution_mode == 0 ? 16 : 20;
         g->main_height = 64;
@@ -1723,6 +1922,8 @@ static void game_reset(Game *g) {
         fill_elem(g, g->main_width - 1, 0, 1, g->main_height, CR_WALL_MID);
         fill_elem(g, 0, g->main_height - 1, g->main_width, 1, CR_WALL_MID);
         cr_generate_coin_to_the_right(g);
+    } else if (g->game_id == GAME_FRUITBOT) {
+        fb_game_reset(g);
     } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:327-339 */
         g->center_agent = 0;
         sp_init_hps(g);
@@ -2118,6 +2319,10 @@ static void prepare_for_drawing(Game *g, float rect_height) { /* BAG:819-838 */
         g->center_x = (float)(g->main_width / 2.0);
         g->center_y = (float)(g->pool[g->agent].y + g->main_width / 2.0 - 5 * g->pool[g->agent].ry);
         g->visibility = (float)g->main_width;
+    } else if (g->center_agent && g->game_id == GAME_FRUITBOT) { /* choose_center fruitbot.cpp:146-150 */
+        g->center_x = (float)(g->main_width / 2.0);
+        g->center_y = (float)(g->pool[g->agent].y + g->main_width / 2.0 - 2 * g->pool[g->agent].ry);
+        g->visibility = (float)g->main_width;
     } else if (g->center_agent) {
         g->center_x = g->pool[g->agent].x; /* choose_center BAG:664-667 */
         g->center_y = g->pool[g->agent].y;
@@ -2203,7 +2408,12 @@ static void draw_entities(Game *g, uint32_t *dst, int render_z) { /* BAG:1052-10
         } else {
             r1 = get_screen_rect(g, m->x - m->rx, m->y + m->ry, 2 * m->rx, 2 * m->ry, 0);
         }
-        draw_image(g, dst, r1, m->rotation, m->is_reflected, m->image_type, m->image_theme, m->alpha, 0);
+        float tile_ratio = 0; /* get_tile_aspect_ratio BAG:409-411 */
+        if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:87-94 */
+            if (m->type == FB_BARRIER) tile_ratio = 1;
+            else if (m->type == FB_LOCKED_DOOR) tile_ratio = FB_DOOR_ASPECT_RATIO;
+        }
+        draw_image(g, dst, r1, m->rotation, m->is_reflected, m->image_type, m->image_theme, m->alpha, tile_ratio);
     }
 }
 
@@ -2354,6 +2564,13 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->main_width = 64;
         g->main_height = 64;
         g->out_of_bounds_object = CR_WALL_MID;
+    } else if (game_id == GAME_FRUITBOT) { /* fruitbot.cpp:32-42 */
+        g->mixrate = (float).5;
+        g->maxspeed = 0.85f;
+        g->min_dim = 5;
+        g->bullet_vscale = (float).5;
+        g->bg_tile_ratio = -1;
+        g->out_of_bounds_object = FB_OUT_OF_BOUNDS_WALL;
     } else if (game_id == GAME_STARPILOT) { /* starpilot.cpp:50-53 */
         g->main_width = 16;
         g->main_height = 16;

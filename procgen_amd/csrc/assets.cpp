@@ -40,6 +40,11 @@ static void platform_backgrounds(std::vector<std::string> *out) {
     for (const char *n : SPACE_BGS) out->push_back(std::string("space_backgrounds/") + n + ".png");  // resources.cpp:950-953
 }
 
+static void topdown_backgrounds(std::vector<std::string> *out) {  // reference src/resources.cpp:900-911
+    out->push_back("topdown_backgrounds/floortiles.png");
+    for (int k = 1; k <= 8; k++) out->push_back("topdown_backgrounds/backgrounddetailed" + std::to_string(k) + ".png");
+}
+
 static void reserved_assets(std::vector<SpriteName> *s) {  // reference BAG:416-430
     for (int k = 0; k < 5; k++) s->push_back({EXPLOSION + k, 0, "misc_assets/explosion" + std::to_string(k + 1) + ".png"});
     s->push_back({TRAIL, 0, "misc_assets/iconCircle_white.png"});
@@ -106,6 +111,22 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(9, {"misc_assets/dirt.png"});
         add_themes(10, {"misc_assets/tile_bricksGrey.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_FRUITBOT) {  // reference src/games/fruitbot.cpp:42-78
+        auto series = [](const std::string &stem, int n) {
+            std::vector<std::string> v;
+            for (int i = 1; i <= n; i++) v.push_back("misc_assets/" + stem + std::to_string(i) + ".png");
+            return v;
+        };
+        add_themes(0, {"misc_assets/robot_3Dblue.png"});
+        add_themes(1, {"misc_assets/tileStone_slope.png"});
+        add_themes(2, {"misc_assets/tileStone_slope.png"});
+        add_themes(3, {"misc_assets/keyRed2.png"});
+        add_themes(4, series("food", 6));
+        add_themes(7, series("fruit", 6));
+        add_themes(10, {"misc_assets/fenceYellow.png"});
+        add_themes(11, {"misc_assets/lockRed2.png"});
+        add_themes(12, series("present", 3));
+        topdown_backgrounds(backgrounds);
     } else if (game_id == GAME_STARPILOT) {  // reference src/games/starpilot.cpp:55-106, src/resources.cpp:828-845
         auto numbered = [](const std::string &stem, int from, int to, int width) {
             std::vector<std::string> v;
@@ -135,8 +156,7 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(51, {"kenney/Ground/Sand/sandCenter.png"});
         add_themes(2, {"misc_assets/cheese.png"});
         add_themes(0, {"kenney/Enemies/mouse_move.png"});
-        backgrounds->push_back("topdown_backgrounds/floortiles.png");
-        for (int k = 1; k <= 8; k++) backgrounds->push_back("topdown_backgrounds/backgrounddetailed" + std::to_string(k) + ".png");
+        topdown_backgrounds(backgrounds);
     } else {
         return false;
     }
@@ -236,6 +256,7 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
     if (game_id == GAME_COINRUN || game_id == GAME_CLIMBER) ref_type = 15;
     if (game_id == GAME_MAZE) ref_type = 51;
     if (game_id == GAME_MINER) ref_type = 9;
+    if (game_id == GAME_FRUITBOT) ref_type = 2;
     if (ref_type >= 0 && t.type_theme_img[ref_type][0] >= 0) {
         t.ref_w = t.img[t.type_theme_img[ref_type][0]].w;
         t.ref_h = t.img[t.type_theme_img[ref_type][0]].h;

@@ -819,6 +819,76 @@ struct Env {
         ery(i) = erx(i) / aspect;
     }
 
+    PG_DEV void fit_aspect_ratio(int i) {  // BAG:1025-1036
+        const uint32_t mm = meta(i);
+        const int img = (int)d.assets->type_theme_img[meta_image_type(mm)][meta_image_theme(mm)];
+        if (img < 0) {
+            fail(PGE_THEME);
+            return;
+        }
+        const ImgDesc im = d.assets->img[img];
+        const float ar = (float)((double)im.w * 1.0 / (double)im.h);
+        if (ar > 1) ery(i) = erx(i) / ar;
+        else erx(i) = ery(i) * ar;
+    }
+    PG_DEV float rand_pos(float r, float min, float max) {  // BAG:1100-1108
+        if (!(min <= max)) fail(PGE_ASSERT);
+        if (max - min <= 2 * r) return (max + min) / 2;
+        const float range = max - min;
+        return (range - 2 * r) * rand01() + r + min;
+    }
+    // has_any_collision BAG:1114-1124 for the entity in table slot i (it need not be in the list yet)
+    PG_DEV bool has_any_collision(int i, float margin) {
+        const int n = G.n_ents;
+        const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
+        for (int c = 0; c < ((n + 63) >> 6); c++) {
+            const uint64_t m = PG_BALLOT(l, ({
+                                             const int idx = (c << 6) + l;
+                                             bool hit = false;
+                                             if (idx < n && !(meta(idx) & MF_AVOIDS)) {
+                                                 const float tx = (rx + erx(idx)) + margin;
+                                                 const float ty = (ry + ery(idx)) + margin;
+                                                 hit = (pg_fabsf(x - ex(idx)) < tx) && (pg_fabsf(y - ey(idx)) < ty);
+                                             }
+                                             hit;
+                                         }));
+            if (m) return true;
+        }
+        return false;
+    }
+    PG_DEV void reposition(int i, float x, float y, float w, float h, bool check_collisions) {  // BAG:541-560
+        const float rx = erx(i), ry = ery(i);
+        ex(i) = rand_pos(rx, x, x + w);
+        ey(i) = rand_pos(ry, y, y + h);
+        PG_SYNC();
+        int count = 0;
+        while ((has_agent_collision(i) || (check_collisions && has_any_collision(i, 0))) && (count < 100)) {
+            ex(i) = rand_pos(rx, x, x + w);
+            ey(i) = rand_pos(ry, y, y + h);
+            PG_SYNC();
+            count++;
+        }
+    }
+    // spawn_entity_rxy BAG:511-519: the entity is placed before it joins the list
+    PG_DEV int spawn_entity_rxy(float rx, float ry, int type, float x, float y, float w, float h, bool check_collisions = true) {
+        const int i = G.n_ents;
+        if (i >= CAP - 1) {
+            fail(PGE_ENT_OVERFLOW);
+            return CAP - 2;
+        }
+        ent_init(i, 0, 0, 0, 0, rx, ry, type);
+        PG_SYNC();
+        reposition(i, x, y, w, h, check_collisions);
+        G.n_ents = i + 1;
+        return i;
+    }
+    PG_DEV int spawn_entity(float r, int type, float x, float y, float w, float h, bool check_collisions = true) {
+        return spawn_entity_rxy(r, r, type, x, y, w, h, check_collisions);
+    }
+    PG_DEV void spawn_entities(int num, float r, int type, float x, float y, float w, float h) {  // BAG:585-589
+        for (int k = 0; k < num; k++) spawn_entity(r, type, x, y, w, h);
+    }
+
     PG_DEV void match_aspect_ratio_h(int i) {  // BAG:1014-1023 (match_width = false)
         const uint32_t mm = meta(i);
         const int img = (int)d.assets->type_theme_img[meta_image_type(mm)][meta_image_theme(mm)];

@@ -33,10 +33,13 @@ struct DrawCmd {  // uniform (scalar) view of one command
 };
 // A rotated command (aux bit 15) keeps its bounding box in geom, its source height in iy, the index of its
 // parameter record (RenderLds::rot) in basex; srcy0 / ix are unused.
+// A tiled command (aux bit 25) keeps the bounding box of the entity's rect in geom and the entity's lane in basex;
+// its tiles are generated when it is executed (exec_tiled).
 PG_DEV int cmd_src_w(uint32_t aux) { return (int)(aux & 0x1fffu); }
 PG_DEV bool cmd_mirrored(uint32_t aux) { return ((aux >> 13) & 1u) != 0; }
 PG_DEV bool cmd_opaque(uint32_t aux) { return ((aux >> 14) & 1u) != 0; }
 PG_DEV bool cmd_rotated(uint32_t aux) { return ((aux >> 15) & 1u) != 0; }
+PG_DEV bool cmd_tiled(uint32_t aux) { return ((aux >> 25) & 1u) != 0; }  // entity drawn as a row / column of tiles (tile_image BAG:840-865)
 PG_DEV int cmd_alpha(uint32_t aux) { return (int)(aux >> 16); }
 PG_DEV uint32_t cmd_aux(int src_w, bool mirrored, bool opaque, int io) {
     return (uint32_t)src_w | ((mirrored ? 1u : 0u) << 13) | (((opaque && io == 256) ? 1u : 0u) << 14) | ((uint32_t)io << 16);
@@ -58,6 +61,14 @@ struct GameDrawsGrid {
 template <class Game>
 struct GameDrawsGrid<Game, decltype((void)Game::DRAWS_GRID)> {
     static constexpr bool value = Game::DRAWS_GRID;
+};
+template <class Game, class = void>
+struct GameUsesTiledEntities {
+    static constexpr bool value = false;
+};
+template <class Game>
+struct GameUsesTiledEntities<Game, decltype((void)Game::USES_TILED_ENTITIES)> {
+    static constexpr bool value = Game::USES_TILED_ENTITIES;
 };
 template <class Game, class = void>
 struct GameCustomBackground {
@@ -102,6 +113,7 @@ struct Renderer {
     int ecap;
     const typename Game::cell_t *gg;
     int row0, row1;  // band rows [row0, row1)
+    int ent_base = 0;  // first entity of the chunk whose commands run_batch is executing (tiled commands look their entity up)
 
     PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(lds_->ax) {
         ge = d.ents + (size_t)env * EF_COUNT * d.ent_cap;
@@ -760,12 +772,13 @@ struct Renderer {
                       PG_READLANE(r.src, k), PG_READLANE(r.aux, k));
     }
     // executes the commands in lane order; runs of small commands go eight at a time
+    template <bool NESTED = false>
     PG_DEV void run_batch(const CmdRegs &r, uint64_t lane_mask = ~0ull) {
         // commands that exist, are selected by the caller, and touch the rows of the current pass
         uint64_t valid = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && (int)((PG_LV(r.geom, l) >> 7) & 0x7fu) < row1 &&
                                           (int)(((PG_LV(r.geom, l) >> 7) & 0x7fu) + ((PG_LV(r.geom, l) >> 21) & 0x7fu)) > row0) & lane_mask;
         const uint64_t small = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && ((PG_LV(r.geom, l) >> 14) & 0x7fu) <= 8u && ((PG_LV(r.geom, l) >> 21) & 0x7fu) <= 8u &&
-                                                !cmd_rotated(PG_LV(r.aux, l)));
+                                                !cmd_rotated(PG_LV(r.aux, l)) && !cmd_tiled(PG_LV(r.aux, l)));
         while (valid) {
             const int k = pg_ctz64(valid);
             if ((small >> k) & 1ull) {
@@ -787,9 +800,62 @@ struct Renderer {
             } else {
                 valid &= valid - 1;
                 const DrawCmd c = read_cmd(r, k);
-                if (cmd_rotated(c.aux)) exec_rotated(c);
+                if (cmd_tiled(c.aux)) {
+                    if constexpr (NESTED || !GameUsesTiledEntities<Game>::value) fail(PGE_ASSERT);
+                    else exec_tiled(ent_base + (int)(c.basex & 63u));
+                } else if (cmd_rotated(c.aux)) exec_rotated(c);
                 else exec_large(c);
             }
+        }
+    }
+
+    // tile_image BAG:840-865 for entity i: a row (tile_ratio > 0) or column (< 0) of equally sized tiles, each its
+    // own drawImage with its own rounding.  Lanes set up 64 tiles at a time.
+    PG_DEV void exec_tiled(int i) {
+        const uint32_t mm = meta(i);
+        const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
+        RectD rect;
+        if (mm & MF_ABS_COORDS) {
+            const float vd = G.view_dim;
+            rect.x = (double)((vd * (x - rx)) * G.unit);
+            rect.y = (double)((vd * (y + ry)) * G.unit);
+            rect.w = (double)((2 * vd * rx) * G.unit);
+            rect.h = (double)((2 * vd * ry) * G.unit);
+        } else {
+            rect = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
+        }
+        const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, 0.0f, rect);
+        if (im < 0) return;
+        float tile_ratio = Game::tile_aspect_ratio(*this, i);
+        const bool vertical = tile_ratio < 0;
+        if (vertical) tile_ratio = -1 * tile_ratio;
+        int num_tiles = vertical ? (int)(rect.h / (rect.w * (double)tile_ratio)) : (int)(rect.w / (rect.h * (double)tile_ratio));
+        if (num_tiles < 1) num_tiles = 1;
+        const float tile_width = vertical ? (float)rect.w : (float)(rect.w / num_tiles);
+        const float tile_height = vertical ? (float)(rect.h / num_tiles) : (float)rect.h;
+        const float alpha = ef(EF_ALPHA, i);
+        const bool mirrored = (mm & MF_REFLECTED) != 0;
+        for (int base = 0; base < num_tiles; base += 64) {
+            CmdRegs r;
+            PG_FOR_LANES(l) {
+                PG_LV(r.geom, l) = 0;
+                PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.src, l) = PG_LV(r.aux, l) = 0;
+                const int t = base + l;
+                if (t < num_tiles) {
+                    RectD tr;
+                    if (vertical) {
+                        tr.x = rect.x;
+                        tr.y = rect.y + (double)(tile_height * t);
+                    } else {
+                        tr.x = rect.x + (double)(tile_width * t);
+                        tr.y = rect.y;
+                    }
+                    tr.w = (double)tile_width;
+                    tr.h = (double)tile_height;
+                    cmd_image(im, mirrored, tr, alpha, PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                }
+            }
+            run_batch<true>(r);
         }
     }
 
@@ -815,10 +881,25 @@ struct Renderer {
                 } else {
                     r1 = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
                 }
-                const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, Game::tile_aspect_ratio(*this, i), r1);
+                const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, 0.0f, r1);
                 const float rotation = ef(EF_ROTATION, i);
+                const float tile_ratio = Game::tile_aspect_ratio(*this, i);
                 if (im >= 0) {
-                    if (rotation == 0) cmd_image(im, (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                    if (rotation == 0 && tile_ratio != 0 && !GameUsesTiledEntities<Game>::value) {
+                        fail(PGE_UNSUPPORTED_DRAW);
+                    } else if (rotation == 0 && tile_ratio != 0) {
+                        // bounding box of all tiles (each tile is rounded on its own: one pixel of slack either side)
+                        int bx1 = q_round(r1.x) - 1, bx2 = q_round(r1.x + r1.w) + 1, by1 = q_round(r1.y) - 1, by2 = q_round(r1.y + r1.h) + 1;
+                        if (bx1 < 0) bx1 = 0;
+                        if (by1 < 0) by1 = 0;
+                        if (bx2 > RES_W) bx2 = RES_W;
+                        if (by2 > RES_H) by2 = RES_H;
+                        if (bx2 > bx1 && by2 > by1) {
+                            PG_LV(r.geom, l) = (uint32_t)bx1 | ((uint32_t)by1 << 7) | ((uint32_t)(bx2 - bx1) << 14) | ((uint32_t)(by2 - by1) << 21);
+                            PG_LV(r.basex, l) = (uint32_t)l;
+                            PG_LV(r.aux, l) = 1u << 25;
+                        }
+                    } else if (rotation == 0) cmd_image(im, (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                     else cmd_image_rotated(l, im, (mm & MF_REFLECTED) != 0, r1, rotation, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                 }
             }
@@ -833,6 +914,7 @@ struct Renderer {
             CmdRegs r;
             uint64_t zmask[3];
             setup_entities(base, r, zmask);
+            ent_base = base;
             run_batch(r, zmask[render_z + 1]);
         }
     }
@@ -849,30 +931,45 @@ struct Renderer {
         row0 = 0;
         row1 = RES_H;
         // wave-uniform background commands (one scaled image, or the visible tiles of a game's own background)
-        uint32_t bg_geom[2] = {0, 0}, bg_basex[2] = {0, 0}, bg_srcy[2] = {0, 0}, bg_ix[2] = {0, 0}, bg_iy[2] = {0, 0}, bg_src[2] = {0, 0}, bg_aux[2] = {0, 0};
+        constexpr int MAXBG = 3;
+        uint32_t bg_geom[MAXBG] = {0, 0, 0}, bg_basex[MAXBG] = {0, 0, 0}, bg_srcy[MAXBG] = {0, 0, 0}, bg_ix[MAXBG] = {0, 0, 0}, bg_iy[MAXBG] = {0, 0, 0}, bg_src[MAXBG] = {0, 0, 0},
+                 bg_aux[MAXBG] = {0, 0, 0};
         int nbg = 0;
+        auto add_bg = [&](int bgi, const RectD &rc) {
+            uint32_t g, bx, sy, ix, iy, sr, au;
+            cmd_image(bgi, false, rc, 1.0f, g, bx, sy, ix, iy, sr, au);
+            if (g != 0) {
+                if (nbg >= MAXBG) {
+                    fail(PGE_UNSUPPORTED_DRAW);
+                    return;
+                }
+                bg_geom[nbg] = g; bg_basex[nbg] = bx; bg_srcy[nbg] = sy; bg_ix[nbg] = ix; bg_iy[nbg] = iy; bg_src[nbg] = sr; bg_aux[nbg] = au;
+                nbg++;
+            }
+        };
         if constexpr (GameCustomBackground<Game>::value) {
             if (d.opt.use_backgrounds && !(d.debug_flags & 1)) {
                 RectD rects[4];
                 const int nr = Game::background_rects(*this, rects);
                 const int bgi = (int)d.assets->bg_img[G.background_index];
-                for (int k = 0; k < nr; k++) {
-                    uint32_t g, bx, sy, ix, iy, sr, au;
-                    cmd_image(bgi, false, rects[k], 1.0f, g, bx, sy, ix, iy, sr, au);
-                    if (g != 0) {
-                        if (nbg >= 2) {
-                            fail(PGE_UNSUPPORTED_DRAW);
-                            break;
-                        }
-                        bg_geom[nbg] = g; bg_basex[nbg] = bx; bg_srcy[nbg] = sy; bg_ix[nbg] = ix; bg_iy[nbg] = iy; bg_src[nbg] = sr; bg_aux[nbg] = au;
-                        nbg++;
-                    }
-                }
+                for (int k = 0; k < nr; k++) add_bg(bgi, rects[k]);
             }
         } else if (d.opt.use_backgrounds && !(d.debug_flags & 1)) {
             const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);
             const int bgi = (int)d.assets->bg_img[G.background_index];
-            if (G.bg_tile_ratio < 0) fail(PGE_UNSUPPORTED_DRAW);
+            if (G.bg_tile_ratio < 0) {  // tile_image(main_rect, bg_tile_ratio) BAG:842-853: a column of tiles; only the ones on screen
+                const float tile_ratio = -1 * G.bg_tile_ratio;
+                int num_tiles = (int)(main_rect.h / (main_rect.w * (double)tile_ratio));
+                if (num_tiles < 1) num_tiles = 1;
+                const float tile_height = (float)(main_rect.h / num_tiles);
+                const float tile_width = (float)main_rect.w;
+                const int i0 = (int)pg_floor(-main_rect.y / (double)tile_height) - 1;
+                for (int i = i0; i < i0 + 4; i++) {
+                    if (i < 0 || i >= num_tiles) continue;
+                    const RectD tr = {main_rect.x, main_rect.y + (double)(tile_height * i), (double)tile_width, (double)tile_height};
+                    add_bg(bgi, tr);
+                }
+            } else {
             const ImgDesc bim = d.assets->img[bgi];
             const float bgw = (float)bim.w, bgh = (float)bim.h;
             const float bg_ar = bgw / bgh;
@@ -880,8 +977,8 @@ struct Renderer {
             const float extra_w = bg_ar - world_ar;
             const float offset_x = G.bg_pct_x * extra_w;
             const RectD bg_rect = adjust_rect(main_rect, (double)(-offset_x), 0, (double)(bg_ar / world_ar), 1);
-            cmd_image(bgi, false, bg_rect, 1.0f, bg_geom[0], bg_basex[0], bg_srcy[0], bg_ix[0], bg_iy[0], bg_src[0], bg_aux[0]);
-            nbg = bg_geom[0] != 0 ? 1 : 0;
+            add_bg(bgi, bg_rect);
+            }
         }
         // common case (<= 64 entities): their commands are built once and kept in registers for all passes
         if (d.debug_flags & 4) G.n_ents = 0;

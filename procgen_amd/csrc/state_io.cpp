@@ -247,6 +247,10 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
         w.i(h.gsi1);
     } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:309-312
         w.i(h.gsi0);
+    } else if (game_id == GAME_FRUITBOT) {  // reference src/games/fruitbot.cpp:264-269
+        w.f(h.gsf0);
+        w.f(h.gsf1);
+        w.i(h.gsi0);
     } else if (game_id == GAME_STARPILOT) {  // reference src/games/starpilot.cpp:432-435: write_entities(spawners)
         const int cell_bytes = (16 * 16 + 15) & ~15;
         const int spawn_cap = 256;
@@ -403,6 +407,10 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         h.gsi0 = r.i();
         h.gsi1 = r.i();
     } else if (game_id == GAME_MINER) {
+        h.gsi0 = r.i();
+    } else if (game_id == GAME_FRUITBOT) {
+        h.gsf0 = r.f();
+        h.gsf1 = r.f();
         h.gsi0 = r.i();
     } else if (game_id == GAME_STARPILOT) {  // read_entities(spawners), starpilot.cpp:437-442
         const int cell_bytes = (16 * 16 + 15) & ~15;
