@@ -8,7 +8,7 @@
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
  * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner,
- * starpilot, fruitbot.
+ * starpilot, fruitbot, leaper.
  */
 #include "procgen_oracle.h"
 
@@ -38,7 +38,19 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_FRUITBOT = 7, GAME_MAZE = 11, GAME_MINER = 12, GAME_STARPILOT = 15 };
+enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_FRUITBOT = 7, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_STARPILOT = 15 };
+
+/* leaper.cpp:6-21 */
+#define LP_LOG 1
+#define LP_ROAD 2
+#define LP_WATER 3
+#define LP_CAR 4
+#define LP_FINISH_LINE 5
+#define LP_MONSTER_RADIUS 0.25f
+#define LP_LOG_RADIUS 0.45f
+#define LP_NSTEP 5
+static const float LP_MAX_SPEED = (float)(2 / (LP_NSTEP - 1.0));
+#define LP_VEL_DECAY (LP_MAX_SPEED / LP_NSTEP)
 
 /* fruitbot.cpp:8-24 */
 #define FB_BARRIER 1
@@ -408,6 +420,22 @@ static void assets_build(int game_id) {
         assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_LEAPER) { /* leaper.cpp:40-66 */
+        assets_type(a, LP_ROAD, "misc_assets/roadTile6b.png");
+        assets_type(a, LP_WATER, "misc_assets/terrainTile6.png");
+        assets_type(a, LP_CAR, "misc_assets/car_yellow_5.png");
+        assets_type(a, LP_CAR, "misc_assets/car_black_1.png");
+        assets_type(a, LP_CAR, "misc_assets/car_blue_2.png");
+        assets_type(a, LP_CAR, "misc_assets/car_green_3.png");
+        assets_type(a, LP_CAR, "misc_assets/car_red_4.png");
+        assets_type(a, LP_LOG, "misc_assets/elementWood044.png");
+        assets_type(a, PLAYER, "misc_assets/frog1.png");
+        assets_type(a, PLAYER, "misc_assets/frog2.png");
+        assets_type(a, PLAYER, "misc_assets/frog4.png");
+        assets_type(a, PLAYER, "misc_assets/frog6.png");
+        assets_type(a, PLAYER, "misc_assets/frog7.png");
+        assets_type(a, LP_FINISH_LINE, "misc_assets/finish2.png");
+        assets_topdown_backgrounds(a);
     } else if (game_id == GAME_FRUITBOT) { /* fruitbot.cpp:42-78 */
         assets_type(a, PLAYER, "misc_assets/robot_3Dblue.png");
         assets_type(a, FB_BARRIER, "misc_assets/tileStone_slope.png");
@@ -478,6 +506,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "miner") == 0) return GAME_MINER;
     if (strcmp(name, "starpilot") == 0) return GAME_STARPILOT;
     if (strcmp(name, "fruitbot") == 0) return GAME_FRUITBOT;
+    if (strcmp(name, "leaper") == 0) return GAME_LEAPER;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -552,6 +581,9 @@ typedef struct {
     int diamonds_remaining;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
+    /* LeaperGame: leaper.cpp:29-33 */
+    int bottom_road_y, bottom_water_y, goal_y, n_road_lanes, n_water_lanes;
+    float road_lane_speeds[8], water_lane_speeds[8];
     /* FruitBotGame: fruitbot.cpp:28-30 */
     float min_dim, bullet_vscale;
     int last_fire_time;
@@ -698,6 +730,15 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
             g->reward += 1.0f;
             g->coins_collected += 1;
             obj->will_erase = 1;
+        }
+    } else if (g->game_id == GAME_LEAPER) { /* leaper.cpp:77-85 */
+        const Ent *agent = &g->pool[g->agent];
+        if (obj->type == LP_CAR) {
+            g->done = 1;
+        } else if (obj->type == LP_FINISH_LINE && agent->vx == 0 && agent->vy == 0) {
+            g->reward += 10.0f;
+            g->done = 1;
+            g->level_complete = 1;
         }
     } else if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:96-118 */
         if (obj->type == FB_BARRIER) {
@@ -973,6 +1014,13 @@ static void hook_set_action_xy(Game *g, int move_act) {
     }
 }
 
+static void lp_decay_vel(float *vel) { /* leaper.cpp:208-214, sign() :23-25 */
+    float x = (float)(1.0 * *vel);
+    float vel_sign = x > 0 ? +1 : (x == 0 ? 0 : -1);
+    *vel = (float)(fabs((double)*vel) - LP_VEL_DECAY);
+    if (*vel < 0) *vel = 0;
+    *vel = *vel * vel_sign;
+}
 static void hook_update_agent_velocity(Game *g) {
     Ent *agent = &g->pool[g->agent];
     if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:156-173 */
@@ -995,6 +1043,20 @@ static void hook_update_agent_velocity(Game *g) {
         if (!g->has_support) {
             if (agent->vy > -2) agent->vy -= g->gravity;
         }
+    } else if (g->game_id == GAME_LEAPER) { /* leaper.cpp:216-231 */
+        if (agent->vx == 0 && agent->vy == 0) {
+            if (g->action_vx != 0) {
+                agent->vx = g->maxspeed * g->action_vx;
+                agent->image_theme = 1;
+                agent->rotation = (agent->vx > 0 ? 1 : -1) * PI_F / 2;
+            } else if (g->action_vy != 0) {
+                agent->vy = g->maxspeed * g->action_vy;
+                agent->image_theme = 1;
+                agent->rotation = agent->vy > 0 ? 0 : PI_F;
+            }
+        }
+        lp_decay_vel(&agent->vx);
+        lp_decay_vel(&agent->vy);
     } else { /* BAG:669-684 */
         float v_scale = 1.0f;
         agent->vx = (1 - g->mixrate) * agent->vx;
@@ -1003,6 +1065,15 @@ static void hook_update_agent_velocity(Game *g) {
         agent->vy += g->mixrate * g->maxspeed * g->action_vy * v_scale;
         agent->vx = (float)(.9 * agent->vx);
         agent->vy = (float)(.9 * agent->vy);
+    }
+}
+
+static void step_entities(Game *g) { /* BAG:1086-1098 (count captured before the loop) */
+    int entities_count = g->n_ents;
+    for (int i = entities_count - 1; i >= 0; i--) {
+        Ent *ent = &g->pool[g->ents[i]];
+        if (ent->smart_step) basic_step_object(g, ent);
+        ent_step(ent);
     }
 }
 
@@ -1029,13 +1100,7 @@ static void bag_game_step(Game *g) {
         agent->vrot = MIXRATEROT * agent->vrot;
         agent->vrot += MIXRATEROT * MAXVTHETA * g->action_vrot;
     }
-    /* step_entities BAG:1086-1098 (count captured before the loop) */
-    int entities_count = g->n_ents;
-    for (int i = entities_count - 1; i >= 0; i--) {
-        Ent *ent = &g->pool[g->ents[i]];
-        if (ent->smart_step) basic_step_object(g, ent);
-        ent_step(ent);
-    }
+    step_entities(g);
     for (int i = g->n_ents - 1; i >= 0; i--) { /* BAG:719-741 */
         Ent *ent = &g->pool[g->ents[i]];
         if (has_agent_collision(g, ent)) hook_handle_agent_collision(g, ent);
@@ -1056,9 +1121,14 @@ static void choose_random_theme(Game *g, Ent *ent);
 static void match_aspect_ratio(Game *g, Ent *ent);
 static void mn_game_step_tail(Game *g);
 static void sp_game_step_tail(Game *g);
+static void lp_spawn_entities(Game *g);
 
 /* ---- per-game game_step: coinrun.cpp:474-498, bigfish.cpp:80-107 ---- */
 static void game_step(Game *g) {
+    if (g->game_id == GAME_LEAPER) { /* leaper.cpp:241-244 */
+        Ent *agent = &g->pool[g->agent];
+        if (agent->image_theme >= 1) agent->image_theme = (agent->image_theme + 1) % LP_NSTEP;
+    }
     bag_game_step(g);
     if (g->game_id == GAME_COINRUN) {
         Ent *agent = &g->pool[g->agent];
@@ -1104,6 +1174,24 @@ static void game_step(Game *g) {
         mn_game_step_tail(g);
     } else if (g->game_id == GAME_STARPILOT) {
         sp_game_step_tail(g);
+    } else if (g->game_id == GAME_LEAPER) { /* leaper.cpp:246-275 */
+        lp_spawn_entities(g);
+        Ent *agent = &g->pool[g->agent];
+        int standing_on_log = 0;
+        float log_vx = 0.0;
+        float margin = -1 * agent->rx;
+        for (int k = 0; k < g->n_ents; k++) {
+            const Ent *m = &g->pool[g->ents[k]];
+            if (m->type == LP_LOG && has_collision(agent, m, margin)) {
+                standing_on_log = 1;
+                log_vx = m->vx;
+            }
+        }
+        if (get_obj(g, (int)agent->x, (int)agent->y) == LP_WATER) {
+            if (!standing_on_log && agent->vx == 0 && agent->vy == 0) g->done = 1;
+        }
+        if (standing_on_log) agent->x += log_vx;
+        if (is_out_of_bounds(g, agent)) g->done = 1;
     } else if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:251-262 */
         if (g->special_action == 1 && (g->cur_time - g->last_fire_time) >= FB_KEY_DURATION) {
             const Ent *agent = &g->pool[g->agent];
@@ -1347,6 +1435,83 @@ static void fit_aspect_ratio(Game *g, Ent *ent) { /* BAG:1025-1036 */
     float ar = (float)(im->w * 1.0 / im->h);
     if (ar > 1) ent->ry = ent->rx / ar;
     else ent->rx = ent->ry * ar;
+}
+
+/* ---- Leaper: leaper.cpp:100-206 ---- */
+static void lp_spawn_entities(Game *g) { /* leaper.cpp:177-206 */
+    for (int lane = 0; lane < g->n_road_lanes; lane++) {
+        float speed = g->road_lane_speeds[lane];
+        float spawn_prob = (float)(fabs((double)speed) / 6.0);
+        if (rng_rand01(&g->rand_gen) < spawn_prob) {
+            float x = speed > 0 ? (-1 * LP_MONSTER_RADIUS) : (g->main_width + LP_MONSTER_RADIUS);
+            Ent m;
+            ent_init(&m, x, (float)(g->bottom_road_y + lane + 0.5), speed, 0, 2 * LP_MONSTER_RADIUS, LP_MONSTER_RADIUS, LP_CAR);
+            choose_random_theme(g, &m);
+            if (speed < 0) m.rotation = PI_F;
+            if (!has_any_collision(g, &m, 0)) {
+                int id = pool_alloc(g);
+                g->pool[id] = m;
+                g->ents[g->n_ents++] = id;
+            }
+        }
+    }
+    for (int lane = 0; lane < g->n_water_lanes; lane++) {
+        float speed = g->water_lane_speeds[lane];
+        float spawn_prob = (float)(fabs((double)speed) / 2.0);
+        if (rng_rand01(&g->rand_gen) < spawn_prob) {
+            float x = speed > 0 ? (-1 * LP_LOG_RADIUS) : (g->main_width + LP_LOG_RADIUS);
+            Ent m;
+            ent_init(&m, x, (float)(g->bottom_water_y + lane + 0.5), speed, 0, LP_LOG_RADIUS, LP_LOG_RADIUS, LP_LOG);
+            if (!has_any_collision(g, &m, 0)) {
+                int id = pool_alloc(g);
+                g->pool[id] = m;
+                g->ents[g->n_ents++] = id;
+            }
+        }
+    }
+}
+static float lp_rand_sign(Game *g) { return rng_rand01(&g->rand_gen) < 0.5 ? 1.0f : -1.0f; } /* leaper.cpp:95-101 */
+static float rng_randrange(Rng *r, float low, float high) { return rng_rand01(r) * (high - low) + low; } /* randgen.cpp:29-31 */
+static int lp_choose_extra_space(Game *g) { return g->opt.distribution_mode == 0 ? 0 : rng_randn(&g->rand_gen, 2); } /* leaper.cpp:118-120 */
+static void lp_game_reset(Game *g) { /* leaper.cpp:122-175 */
+    g->center_agent = 0;
+    Ent *agent = &g->pool[g->agent];
+    agent->y = agent->ry;
+    float min_car_speed = 0.05f, max_car_speed = 0.2f, min_log_speed = 0.05f, max_log_speed = 0.1f;
+    if (g->opt.distribution_mode == 0) {
+        min_car_speed = 0.03f; max_car_speed = 0.12f; min_log_speed = 0.025f; max_log_speed = 0.075f;
+    } else if (g->opt.distribution_mode == 2) {
+        min_car_speed = 0.1f; max_car_speed = 0.3f; min_log_speed = 0.1f; max_log_speed = 0.2f;
+    }
+    g->bottom_road_y = lp_choose_extra_space(g) + 1;
+    int max_diff = g->opt.distribution_mode == 0 ? 3 : 4;
+    int difficulty = rng_randn(&g->rand_gen, max_diff + 1);
+    int extra_lane_option = g->opt.distribution_mode == 0 ? 0 : rng_randn(&g->rand_gen, 4);
+    int num_road_lanes = difficulty + (extra_lane_option == 2 ? 1 : 0);
+    g->n_road_lanes = 0;
+    for (int lane = 0; lane < num_road_lanes; lane++) {
+        /* rand_sign() * randrange(): both operands draw; the reference build evaluates the left operand first (checked against oracle/_ref) */
+        float sgn = lp_rand_sign(g);
+        float mag = rng_randrange(&g->rand_gen, min_car_speed, max_car_speed);
+        g->road_lane_speeds[g->n_road_lanes++] = sgn * mag;
+        fill_elem(g, 0, g->bottom_road_y + lane, g->main_width, 1, LP_ROAD);
+    }
+    g->bottom_water_y = g->bottom_road_y + num_road_lanes + lp_choose_extra_space(g) + 1;
+    g->n_water_lanes = 0;
+    int num_water_lanes = difficulty + (extra_lane_option == 3 ? 1 : 0);
+    int curr_sign = (int)lp_rand_sign(g);
+    for (int lane = 0; lane < num_water_lanes; lane++) {
+        g->water_lane_speeds[g->n_water_lanes++] = curr_sign * rng_randrange(&g->rand_gen, min_log_speed, max_log_speed);
+        curr_sign *= -1;
+        fill_elem(g, 0, g->bottom_water_y + lane, g->main_width, 1, LP_WATER);
+    }
+    g->goal_y = g->bottom_water_y + num_water_lanes + 1;
+    float lim = g->main_width / (min_car_speed < min_log_speed ? min_car_speed : min_log_speed);
+    for (int i = 0; i < lim; i++) {
+        lp_spawn_entities(g);
+        step_entities(g);
+    }
+    push_entity(g, (float)(g->main_width / 2.0), (float)(g->goal_y - .5), 0, 0, (float)(g->main_width / 2.0), (float).5, LP_FINISH_LINE);
 }
 
 /* ---- FruitBot: fruitbot.cpp:168-249 ---- */
@@ -1852,6 +2017,12 @@ static void bag_game_reset(Game *g) { /* BAG:758-797 */
         else if (dm == 1) g->main_width = g->main_height = 20;
         else if (dm == 10) g->main_width = g->main_height = 35;
     }
+    if (g->game_id == GAME_LEAPER) { /* choose_world_dim leaper.cpp:103-116 */
+        int wd = 20;
+        if (g->opt.distribution_mode == 0) wd = 9;
+        else if (g->opt.distribution_mode == 1) wd = 15;
+        g->main_width = g->main_height = wd;
+    }
     if (g->game_id == GAME_FRUITBOT) { /* choose_world_dim fruitbot.cpp:152-160 */
         g->main_width = g->opt.distribution_mode == 0 ? 10 : 20;
         g->main_height = 60;
@@ -1924,6 +2095,8 @@ static void game_reset(Game *g) {
         cr_generate_coin_to_the_right(g);
     } else if (g->game_id == GAME_FRUITBOT) {
         fb_game_reset(g);
+    } else if (g->game_id == GAME_LEAPER) {
+        lp_game_reset(g);
     } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:327-339 */
         g->center_agent = 0;
         sp_init_hps(g);
@@ -2368,6 +2541,10 @@ static int hook_theme_for_grid_obj(const Game *g, int type) {
     return 0;
 }
 static RectD hook_adjusted_image_rect(const Game *g, int type, RectD rect) {
+    if (g->game_id == GAME_LEAPER && type == PLAYER) { /* leaper.cpp:233-239 */
+        RectD a = {0, -.275, 1, 1.55};
+        return adjust_rect(rect, a);
+    }
     if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:64-70 */
         if (type == PLAYER || type == CR_PLAYER_JUMP || type == CR_PLAYER_RIGHT1 || type == CR_PLAYER_RIGHT2) {
             RectD a = {0, -.7415, 1, 1.7415};
@@ -2387,7 +2564,7 @@ static void draw_image(Game *g, uint32_t *dst, RectD base_rect, float rotation, 
     if (theme >= MAX_IMAGE_THEMES) fatal("fassert theme < MAX_IMAGE_THEMES (BAG:888)");
     RectD adjusted = hook_adjusted_image_rect(g, img_type, base_rect);
     int mt = theme; /* mask_theme_if_necessary BAG:450-453 (restrict_themes) */
-    if (g->opt.restrict_themes) mt = 0;
+    if (g->opt.restrict_themes && !(g->game_id == GAME_LEAPER && img_type == PLAYER)) mt = 0; /* should_preserve_type_themes leaper.cpp:91-93 */
     if (g->assets->type_num_themes[img_type] <= mt) fatal("asset theme out of range");
     const Img *img = &g->assets->img[g->assets->type_theme_img[img_type][mt]];
     if (rotation == 0) tile_image(dst, img, is_reflected, adjusted, tile_ratio, alpha);
@@ -2409,6 +2586,7 @@ static void draw_entities(Game *g, uint32_t *dst, int render_z) { /* BAG:1052-10
             r1 = get_screen_rect(g, m->x - m->rx, m->y + m->ry, 2 * m->rx, 2 * m->ry, 0);
         }
         float tile_ratio = 0; /* get_tile_aspect_ratio BAG:409-411 */
+        if (g->game_id == GAME_LEAPER && m->type == LP_FINISH_LINE) tile_ratio = 1; /* leaper.cpp:69-75 */
         if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:87-94 */
             if (m->type == FB_BARRIER) tile_ratio = 1;
             else if (m->type == FB_LOCKED_DOOR) tile_ratio = FB_DOOR_ASPECT_RATIO;
@@ -2564,6 +2742,9 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->main_width = 64;
         g->main_height = 64;
         g->out_of_bounds_object = CR_WALL_MID;
+    } else if (game_id == GAME_LEAPER) { /* leaper.cpp:35-38 */
+        g->maxspeed = LP_MAX_SPEED;
+        g->timeout = 500;
     } else if (game_id == GAME_FRUITBOT) { /* fruitbot.cpp:32-42 */
         g->mixrate = (float).5;
         g->maxspeed = 0.85f;

@@ -111,6 +111,14 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(9, {"misc_assets/dirt.png"});
         add_themes(10, {"misc_assets/tile_bricksGrey.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_LEAPER) {  // reference src/games/leaper.cpp:40-66
+        add_themes(2, {"misc_assets/roadTile6b.png"});
+        add_themes(3, {"misc_assets/terrainTile6.png"});
+        add_themes(4, {"misc_assets/car_yellow_5.png", "misc_assets/car_black_1.png", "misc_assets/car_blue_2.png", "misc_assets/car_green_3.png", "misc_assets/car_red_4.png"});
+        add_themes(1, {"misc_assets/elementWood044.png"});
+        add_themes(0, {"misc_assets/frog1.png", "misc_assets/frog2.png", "misc_assets/frog4.png", "misc_assets/frog6.png", "misc_assets/frog7.png"});
+        add_themes(5, {"misc_assets/finish2.png"});
+        topdown_backgrounds(backgrounds);
     } else if (game_id == GAME_FRUITBOT) {  // reference src/games/fruitbot.cpp:42-78
         auto series = [](const std::string &stem, int n) {
             std::vector<std::string> v;
@@ -257,6 +265,7 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
     if (game_id == GAME_MAZE) ref_type = 51;
     if (game_id == GAME_MINER) ref_type = 9;
     if (game_id == GAME_FRUITBOT) ref_type = 2;
+    if (game_id == GAME_LEAPER) ref_type = 2;
     if (ref_type >= 0 && t.type_theme_img[ref_type][0] >= 0) {
         t.ref_w = t.img[t.type_theme_img[ref_type][0]].w;
         t.ref_h = t.img[t.type_theme_img[ref_type][0]].h;

@@ -113,7 +113,7 @@ bool read_rng(Reader &r, int *seeded, uint32_t *mt, int *idx) {
 }
 
 bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h) {
-    if (game_id == GAME_BIGFISH || game_id == GAME_STARPILOT) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64, starpilot.cpp:330
+    if (game_id == GAME_BIGFISH || game_id == GAME_STARPILOT || game_id == GAME_LEAPER) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64, starpilot.cpp:330
     if (game_id == GAME_MAZE || game_id == GAME_MINER)  // maze.cpp:66, miner.cpp:140
         return h.initial_reset_complete ? opt.distribution_mode == MemoryMode : opt.center_agent != 0;
     return opt.center_agent != 0;
@@ -247,6 +247,22 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
         w.i(h.gsi1);
     } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:309-312
         w.i(h.gsi0);
+    } else if (game_id == GAME_LEAPER) {  // reference src/games/leaper.cpp:277-284 (write_vector_float = count + values)
+        const float road[5] = {h.gsf0, h.gsf1, h.gsf2, h.gsf3, h.gsf4};
+        float water[5] = {h.gsf5, h.gsf6, h.gsf7, 0, 0};
+        memcpy(&water[3], &h.gsi5, 4);
+        memcpy(&water[4], &h.gsi6, 4);
+        if (h.gsi1 < 0 || h.gsi1 > 5 || h.gsi3 < 0 || h.gsi3 > 5) {
+            if (err) *err = "leaper: malformed lane tables";
+            return false;
+        }
+        w.i(h.gsi0);
+        w.i(h.gsi1);
+        for (int k = 0; k < h.gsi1; k++) w.f(road[k]);
+        w.i(h.gsi2);
+        w.i(h.gsi3);
+        for (int k = 0; k < h.gsi3; k++) w.f(water[k]);
+        w.i(h.gsi4);
     } else if (game_id == GAME_FRUITBOT) {  // reference src/games/fruitbot.cpp:264-269
         w.f(h.gsf0);
         w.f(h.gsf1);
@@ -408,6 +424,21 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         h.gsi1 = r.i();
     } else if (game_id == GAME_MINER) {
         h.gsi0 = r.i();
+    } else if (game_id == GAME_LEAPER) {
+        float road[5] = {0, 0, 0, 0, 0}, water[5] = {0, 0, 0, 0, 0};
+        h.gsi0 = r.i();
+        h.gsi1 = r.i();
+        if (!r.ok || h.gsi1 < 0 || h.gsi1 > 5) return bad("set_state: leaper road lane count");
+        for (int k = 0; k < h.gsi1; k++) road[k] = r.f();
+        h.gsi2 = r.i();
+        h.gsi3 = r.i();
+        if (!r.ok || h.gsi3 < 0 || h.gsi3 > 5) return bad("set_state: leaper water lane count");
+        for (int k = 0; k < h.gsi3; k++) water[k] = r.f();
+        h.gsi4 = r.i();
+        h.gsf0 = road[0]; h.gsf1 = road[1]; h.gsf2 = road[2]; h.gsf3 = road[3]; h.gsf4 = road[4];
+        h.gsf5 = water[0]; h.gsf6 = water[1]; h.gsf7 = water[2];
+        memcpy(&h.gsi5, &water[3], 4);
+        memcpy(&h.gsi6, &water[4], 4);
     } else if (game_id == GAME_FRUITBOT) {
         h.gsf0 = r.f();
         h.gsf1 = r.f();
