@@ -8,7 +8,7 @@
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
  * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner,
- * starpilot, fruitbot, leaper.
+ * starpilot, fruitbot, leaper, plunder.
  */
 #include "procgen_oracle.h"
 
@@ -38,7 +38,14 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_FRUITBOT = 7, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_STARPILOT = 15 };
+enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_FRUITBOT = 7, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+
+/* plunder.cpp:8-15 */
+#define PL_PLAYER_BULLET 1
+#define PL_TARGET_LEGEND 2
+#define PL_TARGET_BACKGROUND 3
+#define PL_PANEL 6
+#define PL_SHIP 7
 
 /* leaper.cpp:6-21 */
 #define LP_LOG 1
@@ -420,6 +427,18 @@ static void assets_build(int game_id) {
         assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_PLUNDER) { /* plunder.cpp:45-63 */
+        for (int i = 1; i <= 6; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/ship_%d.png", i);
+            assets_type(a, PL_SHIP, buf);
+        }
+        assets_type(a, PL_PLAYER_BULLET, "misc_assets/cannonBall.png");
+        assets_type(a, PL_PANEL, "misc_assets/panel_wood.png");
+        assets_type(a, PL_TARGET_BACKGROUND, "misc_assets/target_red2.png");
+        /* water_surface_backgrounds, reference src/resources.cpp:933-940 */
+        static const char *WS[] = {"water_backgrounds/water1.png", "water_backgrounds/water2.png", "water_backgrounds/water3.png", "water_backgrounds/water4.png"};
+        a->n_bg = 4;
+        for (int i = 0; i < 4; i++) a->bg_img[i] = assets_add(a, WS[i], 1);
     } else if (game_id == GAME_LEAPER) { /* leaper.cpp:40-66 */
         assets_type(a, LP_ROAD, "misc_assets/roadTile6b.png");
         assets_type(a, LP_WATER, "misc_assets/terrainTile6.png");
@@ -507,6 +526,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "starpilot") == 0) return GAME_STARPILOT;
     if (strcmp(name, "fruitbot") == 0) return GAME_FRUITBOT;
     if (strcmp(name, "leaper") == 0) return GAME_LEAPER;
+    if (strcmp(name, "plunder") == 0) return GAME_PLUNDER;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -581,6 +601,11 @@ typedef struct {
     int diamonds_remaining;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
+    /* PlunderGame: plunder.cpp:19-31 (last_fire_time shared with FruitBot below) */
+    int lane_directions[5], target_bools[6], image_permutation[6];
+    float lane_vels[5];
+    int num_lanes, num_current_ship_types, targets_hit, target_quota;
+    float juice_left, r_scale, spawn_prob, legend_r, min_agent_x;
     /* LeaperGame: leaper.cpp:29-33 */
     int bottom_road_y, bottom_water_y, goal_y, n_road_lanes, n_water_lanes;
     float road_lane_speeds[8], water_lane_speeds[8];
@@ -794,6 +819,27 @@ static void hook_handle_grid_collision(Game *g, Ent *obj, int type, int i, int j
     }
 }
 static void hook_handle_collision(Game *g, Ent *src, Ent *target) { /* BAG:398 */
+    if (g->game_id == GAME_PLUNDER) { /* plunder.cpp:87-109 */
+        if (src->type == PL_PLAYER_BULLET) {
+            if (target->type == PL_SHIP) {
+                target->will_erase = 1;
+                src->will_erase = 1;
+                if (g->target_bools[target->image_theme]) {
+                    g->targets_hit += 1;
+                    g->reward += 1.0f;
+                    g->juice_left += 0.1f;
+                } else {
+                    g->juice_left -= 0.1f;
+                }
+            } else if (target->type == PL_PANEL) {
+                src->will_erase = 1;
+            }
+            if (target->will_erase) {
+                float r = (float)(.5 * target->rx);
+                push_entity(g, target->x, target->y, target->vx / 2, target->vy / 2, r, r, EXPLOSION);
+            }
+        }
+    }
     if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:120-138 */
         if (src->type == FB_PLAYER_BULLET) {
             if (target->type == FB_BARRIER) {
@@ -1003,6 +1049,9 @@ static void hook_set_action_xy(Game *g, int move_act) {
         g->has_support = s1 || s2;
         if (g->has_support && g->action_vy == 1) g->action_vy = 1;
         else g->action_vy = 0;
+    } else if (g->game_id == GAME_PLUNDER) { /* plunder.cpp:111-115 */
+        g->action_vy = 0;
+        g->action_vrot = 0;
     } else if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:162-166 */
         g->action_vy = 0.2f;
         g->action_vrot = 0;
@@ -1121,6 +1170,7 @@ static void choose_random_theme(Game *g, Ent *ent);
 static void match_aspect_ratio(Game *g, Ent *ent);
 static void mn_game_step_tail(Game *g);
 static void sp_game_step_tail(Game *g);
+static int has_any_collision(const Game *g, const Ent *e1, float margin);
 static void lp_spawn_entities(Game *g);
 
 /* ---- per-game game_step: coinrun.cpp:474-498, bigfish.cpp:80-107 ---- */
@@ -1174,6 +1224,43 @@ static void game_step(Game *g) {
         mn_game_step_tail(g);
     } else if (g->game_id == GAME_STARPILOT) {
         sp_game_step_tail(g);
+    } else if (g->game_id == GAME_PLUNDER) { /* plunder.cpp:186-239 */
+        g->juice_left -= 0.0015f;
+        if (rng_rand01(&g->rand_gen) < g->spawn_prob) {
+            float ent_r = g->r_scale;
+            int lane = rng_randn(&g->rand_gen, g->num_lanes);
+            float ent_y = (float)((lane * .11 + .4) * (g->main_height / 2 - ent_r) + g->main_height / 2);
+            float moves_right = (float)g->lane_directions[lane];
+            float ent_vx = g->lane_vels[lane] * (moves_right ? 1 : -1);
+            Ent m;
+            ent_init(&m, 0, ent_y, ent_vx, 0, ent_r, ent_r, PL_SHIP);
+            m.image_type = PL_SHIP;
+            m.image_theme = g->image_permutation[rng_randn(&g->rand_gen, g->num_current_ship_types)];
+            match_aspect_ratio(g, &m);
+            m.x = moves_right ? -1 * ent_r : (g->main_width + ent_r);
+            m.is_reflected = !moves_right;
+            if (!has_any_collision(g, &m, 0)) {
+                int id = pool_alloc(g);
+                g->pool[id] = m;
+                g->ents[g->n_ents++] = id;
+            }
+        }
+        Ent *agent = &g->pool[g->agent];
+        if (g->special_action == 1 && (g->cur_time - g->last_fire_time) >= 3) {
+            Ent *nb = push_entity(g, agent->x, agent->y, 0, 1, (float).25, (float).25, PL_PLAYER_BULLET);
+            nb->collides_with_entities = 1;
+            nb->expire_time = 50;
+            g->last_fire_time = g->cur_time;
+            g->juice_left -= 0.02f;
+        }
+        if (g->juice_left <= 0) g->done = 1;
+        else if (g->juice_left >= 1) g->juice_left = 1;
+        if (g->targets_hit >= g->target_quota) {
+            g->done = 1;
+            g->reward += 10.0f;
+            g->level_complete = 1;
+        }
+        if (agent->x < g->min_agent_x) agent->x = g->min_agent_x;
     } else if (g->game_id == GAME_LEAPER) { /* leaper.cpp:246-275 */
         lp_spawn_entities(g);
         Ent *agent = &g->pool[g->agent];
@@ -1435,6 +1522,71 @@ static void fit_aspect_ratio(Game *g, Ent *ent) { /* BAG:1025-1036 */
     float ar = (float)(im->w * 1.0 / im->h);
     if (ar > 1) ent->ry = ent->rx / ar;
     else ent->rx = ent->ry * ar;
+}
+
+/* ---- Plunder: plunder.cpp:117-184 ---- */
+static void reposition_agent(Game *g) { /* BAG:521-539 */
+    Ent *agent = &g->pool[g->agent];
+    int count = 0, coll;
+    do {
+        agent->x = rng_rand01(&g->rand_gen) * (g->main_width - 2 * agent->rx) + agent->rx;
+        agent->y = rng_rand01(&g->rand_gen) * (g->main_height - 2 * agent->ry) + agent->ry;
+        count++;
+        coll = 0;
+        for (int k = 0; k < g->n_ents && !coll; k++) coll = has_agent_collision(g, &g->pool[g->ents[k]]);
+    } while (coll && (count < 100));
+}
+static void pl_game_reset(Game *g) {
+    Ent *agent = &g->pool[g->agent];
+    agent->image_type = PL_SHIP;
+    g->juice_left = 1;
+    g->targets_hit = 0;
+    g->target_quota = 20;
+    g->spawn_prob = 0.06f;
+    g->r_scale = g->opt.distribution_mode == 0 ? 1.5f : 1.0f;
+    int num_total_ship_types = 6;
+    g->num_lanes = 5;
+    { /* RandGen::choose_n randgen.cpp:49-69 with n == elems.size() */
+        int rem[6], nrem = 6, nch = 0;
+        for (int i = 0; i < 6; i++) rem[i] = i;
+        while (nch < num_total_ship_types) {
+            int idx = rng_randn(&g->rand_gen, nrem);
+            g->image_permutation[nch++] = rem[idx];
+            for (int k = idx; k < nrem - 1; k++) rem[k] = rem[k + 1];
+            nrem--;
+        }
+    }
+    g->num_current_ship_types = 2;
+    for (int i = 0; i < num_total_ship_types; i++) g->target_bools[i] = 0;
+    for (int i = 0; i < g->num_current_ship_types / 2; i++) g->target_bools[g->image_permutation[i]] = 1;
+    for (int i = 0; i < g->num_lanes; i++) {
+        g->lane_directions[i] = rng_rand01(&g->rand_gen) < .5;
+        g->lane_vels[i] = (float)(.15 + .1 * rng_rand01(&g->rand_gen));
+    }
+    int num_panels = g->opt.distribution_mode == 0 ? 0 : rng_randn(&g->rand_gen, 4);
+    float panel_width = 1.2f;
+    for (int i = 0; i < num_panels; i++)
+        spawn_entity_rxy(g, panel_width, (float).5, PL_PANEL, 0, (float)(.25 * g->main_height), (float)g->main_width, (float)(.25 * g->main_height), 1);
+    float key_scale = 1.5;
+    g->legend_r = 2;
+    push_entity(g, g->legend_r, g->legend_r, 0, 0, g->legend_r, g->legend_r, PL_TARGET_BACKGROUND);
+    float lr = g->r_scale * key_scale;
+    Ent *ent = push_entity(g, g->legend_r, g->legend_r, 0, 0, lr, lr, PL_TARGET_LEGEND);
+    ent->image_theme = g->image_permutation[0];
+    ent->image_type = PL_SHIP;
+    match_aspect_ratio(g, ent);
+    ent->rotation = PI_F / 2;
+    g->last_fire_time = 0;
+    g->center_agent = 0;
+    agent = &g->pool[g->agent];
+    agent->rx = g->r_scale;
+    agent->rotation = -1 * PI_F / 2;
+    agent->image_theme = g->image_permutation[rng_randn(&g->rand_gen, g->num_current_ship_types / 2) + g->num_current_ship_types / 2];
+    match_aspect_ratio(g, agent);
+    reposition_agent(g);
+    agent->y = 1 + agent->ry;
+    g->min_agent_x = 2 * g->legend_r + agent->rx;
+    if (agent->x < g->min_agent_x) agent->x = g->min_agent_x;
 }
 
 /* ---- Leaper: leaper.cpp:100-206 ---- */
@@ -2097,6 +2249,8 @@ static void game_reset(Game *g) {
         fb_game_reset(g);
     } else if (g->game_id == GAME_LEAPER) {
         lp_game_reset(g);
+    } else if (g->game_id == GAME_PLUNDER) {
+        pl_game_reset(g);
     } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:327-339 */
         g->center_agent = 0;
         sp_init_hps(g);
@@ -2236,6 +2390,8 @@ typedef struct { double x, y, w, h; } RectD;
 
 static void fill_rect(uint32_t *dst, RectD r, uint32_t color) {
     int x1 = q_round(r.x), x2 = q_round(r.x + r.w), y1 = q_round(r.y), y2 = q_round(r.y + r.h);
+    if (x2 < x1) { int t = x1; x1 = x2; x2 = t; } /* toNormalizedFillRect (qpaintengine_raster.cpp) */
+    if (y2 < y1) { int t = y1; y1 = y2; y2 = t; }
     if (x1 < 0) x1 = 0;
     if (y1 < 0) y1 = 0;
     if (x2 > RES_W) x2 = RES_W;
@@ -2564,7 +2720,7 @@ static void draw_image(Game *g, uint32_t *dst, RectD base_rect, float rotation, 
     if (theme >= MAX_IMAGE_THEMES) fatal("fassert theme < MAX_IMAGE_THEMES (BAG:888)");
     RectD adjusted = hook_adjusted_image_rect(g, img_type, base_rect);
     int mt = theme; /* mask_theme_if_necessary BAG:450-453 (restrict_themes) */
-    if (g->opt.restrict_themes && !(g->game_id == GAME_LEAPER && img_type == PLAYER)) mt = 0; /* should_preserve_type_themes leaper.cpp:91-93 */
+    if (g->opt.restrict_themes && !(g->game_id == GAME_LEAPER && img_type == PLAYER) && !(g->game_id == GAME_PLUNDER && img_type == PL_SHIP)) mt = 0; /* should_preserve_type_themes leaper.cpp:91-93 */
     if (g->assets->type_num_themes[img_type] <= mt) fatal("asset theme out of range");
     const Img *img = &g->assets->img[g->assets->type_theme_img[img_type][mt]];
     if (rotation == 0) tile_image(dst, img, is_reflected, adjusted, tile_ratio, alpha);
@@ -2662,6 +2818,14 @@ static void game_draw(Game *g, uint32_t *dst) { /* BAG:979-1012,921-970 */
         fill_rect(dst, d2, 0xff000000u | ((uint32_t)s1 << 16) | ((uint32_t)s1 << 8) | (uint32_t)s1);
         fill_rect(dst, d3, 0xff000000u | ((uint32_t)s2 << 16) | ((uint32_t)s2 << 8) | (uint32_t)s2);
     }
+    if (g->game_id == GAME_PLUNDER) { /* game_draw override plunder.cpp:65-77; get_abs_rect BAG:803-805 */
+        float w1 = g->main_width * g->juice_left;
+        float w2 = (float)(g->main_width * (g->targets_hit * 1.0 / g->target_quota));
+        RectD r1 = {(float).25 * g->unit, (float).25 * g->unit, w1 * g->unit, (float).5 * g->unit};
+        RectD r2 = {(float).25 * g->unit, (float).75 * g->unit, w2 * g->unit, (float).5 * g->unit};
+        fill_rect(dst, r1, 0xff42f587u);
+        fill_rect(dst, r2, 0xfff54290u);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -2742,6 +2906,13 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->main_width = 64;
         g->main_height = 64;
         g->out_of_bounds_object = CR_WALL_MID;
+    } else if (game_id == GAME_PLUNDER) { /* plunder.cpp:33-43 */
+        g->timeout = 4000;
+        g->main_width = 20;
+        g->main_height = 20;
+        g->mixrate = (float).5;
+        g->maxspeed = 0.85f;
+        g->has_useful_vel_info = 0;
     } else if (game_id == GAME_LEAPER) { /* leaper.cpp:35-38 */
         g->maxspeed = LP_MAX_SPEED;
         g->timeout = 500;

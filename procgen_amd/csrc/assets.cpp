@@ -111,6 +111,12 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(9, {"misc_assets/dirt.png"});
         add_themes(10, {"misc_assets/tile_bricksGrey.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_PLUNDER) {  // reference src/games/plunder.cpp:45-63, src/resources.cpp:933-940
+        add_themes(7, {"misc_assets/ship_1.png", "misc_assets/ship_2.png", "misc_assets/ship_3.png", "misc_assets/ship_4.png", "misc_assets/ship_5.png", "misc_assets/ship_6.png"});
+        add_themes(1, {"misc_assets/cannonBall.png"});
+        add_themes(6, {"misc_assets/panel_wood.png"});
+        add_themes(3, {"misc_assets/target_red2.png"});
+        for (int k = 1; k <= 4; k++) backgrounds->push_back("water_backgrounds/water" + std::to_string(k) + ".png");
     } else if (game_id == GAME_LEAPER) {  // reference src/games/leaper.cpp:40-66
         add_themes(2, {"misc_assets/roadTile6b.png"});
         add_themes(3, {"misc_assets/terrainTile6.png"});

@@ -71,6 +71,14 @@ struct GameUsesTiledEntities<Game, decltype((void)Game::USES_TILED_ENTITIES)> {
     static constexpr bool value = Game::USES_TILED_ENTITIES;
 };
 template <class Game, class = void>
+struct GameHasOverlay {
+    static constexpr bool value = false;
+};
+template <class Game>
+struct GameHasOverlay<Game, decltype((void)Game::HAS_OVERLAY)> {
+    static constexpr bool value = Game::HAS_OVERLAY;
+};
+template <class Game, class = void>
 struct GameCustomBackground {
     static constexpr bool value = false;
 };
@@ -659,6 +667,32 @@ struct Renderer {
         }
         PG_SYNC();
     }
+    // QPainter::fillRect(QRectF, QColor) without antialiasing: [qRound(left), qRound(right)) x [qRound(top), qRound(bottom)),
+    // normalized, opaque colour (used by the games' HUD overlays)
+    PG_DEV void exec_fill(RectD r, uint32_t color) {
+        int x1 = q_round(r.x), x2 = q_round(r.x + r.w), y1 = q_round(r.y), y2 = q_round(r.y + r.h);
+        if (x2 < x1) { const int t = x1; x1 = x2; x2 = t; }
+        if (y2 < y1) { const int t = y1; y1 = y2; y2 = t; }
+        if (x1 < 0) x1 = 0;
+        if (x2 > RES_W) x2 = RES_W;
+        if (y1 < row0) y1 = row0;
+        if (y2 > row1) y2 = row1;
+        if (x1 >= x2 || y1 >= y2) return;
+        for (int y = y1; y < y2; y++) {
+            PG_FOR_LANES(l) {
+                if (l >= x1 && l < x2) fb[(y - row0) * RES_W + l] = color;
+            }
+        }
+        PG_SYNC();
+    }
+    PG_DEV RectD get_abs_rect(float x, float y, float dx, float dy) const {  // BAG:803-805
+        RectD r;
+        r.x = (double)(x * G.unit);
+        r.y = (double)(y * G.unit);
+        r.w = (double)(dx * G.unit);
+        r.h = (double)(dy * G.unit);
+        return r;
+    }
     // one rotated command (qt_transform_image_rasterize): the pixels of its bounding box are laid out linearly
     // over the lanes; a pixel is covered when its row falls into one of the three trapezoids and its column into
     // that row's span [x_l >> 16, x_r >> 16); its texel is the clamped inverse mapping of the pixel position.
@@ -1096,6 +1130,7 @@ struct Renderer {
                 draw_entities(1);
             }
             if (G.has_useful_vel_info && d.opt.paint_vel_info) fail(PGE_UNSUPPORTED_DRAW);
+            if constexpr (GameHasOverlay<Game>::value) Game::draw_overlay(*this);  // game_draw overrides that paint after the base frame
             PG_SYNC();
             if (!(d.debug_flags & 8)) store_band();
             PG_SYNC();

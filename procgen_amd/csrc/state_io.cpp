@@ -113,7 +113,7 @@ bool read_rng(Reader &r, int *seeded, uint32_t *mt, int *idx) {
 }
 
 bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h) {
-    if (game_id == GAME_BIGFISH || game_id == GAME_STARPILOT || game_id == GAME_LEAPER) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64, starpilot.cpp:330
+    if (game_id == GAME_BIGFISH || game_id == GAME_STARPILOT || game_id == GAME_LEAPER || game_id == GAME_PLUNDER) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64, starpilot.cpp:330
     if (game_id == GAME_MAZE || game_id == GAME_MINER)  // maze.cpp:66, miner.cpp:140
         return h.initial_reset_complete ? opt.distribution_mode == MemoryMode : opt.center_agent != 0;
     return opt.center_agent != 0;
@@ -247,6 +247,26 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
         w.i(h.gsi1);
     } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:309-312
         w.i(h.gsi0);
+    } else if (game_id == GAME_PLUNDER) {  // reference src/games/plunder.cpp:241-257 (vectors = count + values, bools as ints)
+        const float vels[5] = {h.gsf0, h.gsf1, h.gsf2, h.gsf3, h.gsf4};
+        w.i(h.gsi0);
+        w.i(5);
+        for (int k = 0; k < 5; k++) w.i((h.gsi2 >> k) & 1);
+        w.i(6);
+        for (int k = 0; k < 6; k++) w.i((h.gsi3 >> k) & 1);
+        w.i(6);
+        for (int k = 0; k < 6; k++) w.i((h.gsi4 >> (3 * k)) & 7);
+        w.i(5);
+        for (int k = 0; k < 5; k++) w.f(vels[k]);
+        w.i(5);   // num_lanes
+        w.i(2);   // num_current_ship_types
+        w.i(h.gsi1);
+        w.i(20);  // target_quota
+        w.f(h.gsf5);
+        w.f(opt.distribution_mode == EasyMode ? 1.5f : 1.0f);  // r_scale
+        w.f(0.06f);                                             // spawn_prob
+        w.f(2.0f);                                              // legend_r
+        w.f(h.gsf6);
     } else if (game_id == GAME_LEAPER) {  // reference src/games/leaper.cpp:277-284 (write_vector_float = count + values)
         const float road[5] = {h.gsf0, h.gsf1, h.gsf2, h.gsf3, h.gsf4};
         float water[5] = {h.gsf5, h.gsf6, h.gsf7, 0, 0};
@@ -424,6 +444,30 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         h.gsi1 = r.i();
     } else if (game_id == GAME_MINER) {
         h.gsi0 = r.i();
+    } else if (game_id == GAME_PLUNDER) {
+        h.gsi0 = r.i();
+        if (r.i() != 5) return bad("set_state: plunder lane_directions");
+        h.gsi2 = 0;
+        for (int k = 0; k < 5; k++) h.gsi2 |= (r.i() ? 1 : 0) << k;
+        if (r.i() != 6) return bad("set_state: plunder target_bools");
+        h.gsi3 = 0;
+        for (int k = 0; k < 6; k++) h.gsi3 |= (r.i() ? 1 : 0) << k;
+        if (r.i() != 6) return bad("set_state: plunder image_permutation");
+        h.gsi4 = 0;
+        for (int k = 0; k < 6; k++) h.gsi4 |= (r.i() & 7) << (3 * k);
+        if (r.i() != 5) return bad("set_state: plunder lane_vels");
+        float vels[5];
+        for (int k = 0; k < 5; k++) vels[k] = r.f();
+        h.gsf0 = vels[0]; h.gsf1 = vels[1]; h.gsf2 = vels[2]; h.gsf3 = vels[3]; h.gsf4 = vels[4];
+        r.i();  // num_lanes
+        r.i();  // num_current_ship_types
+        h.gsi1 = r.i();
+        r.i();  // target_quota
+        h.gsf5 = r.f();
+        r.f();  // r_scale
+        r.f();  // spawn_prob
+        r.f();  // legend_r
+        h.gsf6 = r.f();
     } else if (game_id == GAME_LEAPER) {
         float road[5] = {0, 0, 0, 0, 0}, water[5] = {0, 0, 0, 0, 0};
         h.gsi0 = r.i();

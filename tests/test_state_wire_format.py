@@ -11,7 +11,7 @@ import pytest
 import emu_harness
 from helpers import rollout
 
-GAMES = ["coinrun", "bigfish", "maze", "climber", "miner", "starpilot", "fruitbot", "leaper"]
+GAMES = ["coinrun", "bigfish", "maze", "climber", "miner", "starpilot", "fruitbot", "leaper", "plunder"]
 
 
 @pytest.mark.parametrize("game", GAMES)
