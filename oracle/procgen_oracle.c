@@ -8,7 +8,7 @@
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
  * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner,
- * starpilot, fruitbot, leaper, plunder.
+ * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors).
  */
 #include "procgen_oracle.h"
 
@@ -38,7 +38,17 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_FRUITBOT = 7, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+
+/* heist.cpp:10-15, object-ids.h */
+#define HS_LOCKED_DOOR 1
+#define HS_KEY 2
+#define HS_EXIT 9
+#define HS_KEY_ON_RING 11
+#define EXIT_OBJ 52
+#define AGENT_OBJ 53
+#define DOOR_OBJ 200
+#define KEY_OBJ 300
 
 /* plunder.cpp:8-15 */
 #define PL_PLAYER_BULLET 1
@@ -427,6 +437,17 @@ static void assets_build(int game_id) {
         assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_HEIST) { /* heist.cpp:41-57 */
+        assets_type(a, WALL_OBJ, "kenney/Ground/Dirt/dirtCenter.png");
+        assets_type(a, HS_EXIT, "misc_assets/gemYellow.png");
+        assets_type(a, PLAYER, "misc_assets/spaceAstronauts_008.png");
+        assets_type(a, HS_KEY, "misc_assets/keyBlue.png");
+        assets_type(a, HS_KEY, "misc_assets/keyGreen.png");
+        assets_type(a, HS_KEY, "misc_assets/keyRed.png");
+        assets_type(a, HS_LOCKED_DOOR, "misc_assets/lock_blue.png");
+        assets_type(a, HS_LOCKED_DOOR, "misc_assets/lock_green.png");
+        assets_type(a, HS_LOCKED_DOOR, "misc_assets/lock_red.png");
+        assets_topdown_backgrounds(a);
     } else if (game_id == GAME_PLUNDER) { /* plunder.cpp:45-63 */
         for (int i = 1; i <= 6; i++) {
             snprintf(buf, sizeof buf, "misc_assets/ship_%d.png", i);
@@ -527,6 +548,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "fruitbot") == 0) return GAME_FRUITBOT;
     if (strcmp(name, "leaper") == 0) return GAME_LEAPER;
     if (strcmp(name, "plunder") == 0) return GAME_PLUNDER;
+    if (strcmp(name, "heist") == 0) return GAME_HEIST;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -601,6 +623,8 @@ typedef struct {
     int diamonds_remaining;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
+    /* HeistGame: heist.cpp:19-22 (world_dim shared with MazeGame below) */
+    int num_keys, has_keys[4];
     /* PlunderGame: plunder.cpp:19-31 (last_fire_time shared with FruitBot below) */
     int lane_directions[5], target_bools[6], image_permutation[6];
     float lane_vels[5];
@@ -707,6 +731,7 @@ static int hook_is_blocked(const Game *g, const Ent *src, int target, int is_hor
     return 0;
 }
 static int hook_is_blocked_ents(Game *g, const Ent *src, const Ent *target, int is_horizontal) {
+    if (g->game_id == GAME_HEIST && target->type == HS_LOCKED_DOOR) return !g->has_keys[target->image_theme]; /* heist.cpp:63-68 */
     if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:187-202 */
         if (target->type == CR_CRATE && !is_horizontal) {
             const Ent *agent = &g->pool[g->agent];
@@ -755,6 +780,17 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
             g->reward += 1.0f;
             g->coins_collected += 1;
             obj->will_erase = 1;
+        }
+    } else if (g->game_id == GAME_HEIST) { /* heist.cpp:77-93 */
+        if (obj->type == HS_EXIT) {
+            g->done = 1;
+            g->reward = 10.0f;
+            g->level_complete = 1;
+        } else if (obj->type == HS_KEY) {
+            obj->will_erase = 1;
+            g->has_keys[obj->image_theme] = 1;
+        } else if (obj->type == HS_LOCKED_DOOR) {
+            if (g->has_keys[obj->image_theme]) obj->will_erase = 1;
         }
     } else if (g->game_id == GAME_LEAPER) { /* leaper.cpp:77-85 */
         const Ent *agent = &g->pool[g->agent];
@@ -1170,6 +1206,7 @@ static void choose_random_theme(Game *g, Ent *ent);
 static void match_aspect_ratio(Game *g, Ent *ent);
 static void mn_game_step_tail(Game *g);
 static void sp_game_step_tail(Game *g);
+static void face_direction(Ent *e, float dx, float dy, float rotation_offset);
 static int has_any_collision(const Game *g, const Ent *e1, float margin);
 static void lp_spawn_entities(Game *g);
 
@@ -1224,6 +1261,8 @@ static void game_step(Game *g) {
         mn_game_step_tail(g);
     } else if (g->game_id == GAME_STARPILOT) {
         sp_game_step_tail(g);
+    } else if (g->game_id == GAME_HEIST) { /* heist.cpp:196-200 */
+        face_direction(&g->pool[g->agent], g->action_vx, g->action_vy, 0);
     } else if (g->game_id == GAME_PLUNDER) { /* plunder.cpp:186-239 */
         g->juice_left -= 0.0015f;
         if (rng_rand01(&g->rand_gen) < g->spawn_prob) {
@@ -1456,6 +1495,105 @@ static void mg_place_objects(MazeGen *m, Rng *r, int start_obj, int num_objs) { 
     }
 }
 
+static int mg_get_obj(const MazeGen *m, int idx) { /* mazegen.cpp:36-46 */
+    int x = idx % m->array_dim, y = idx / m->array_dim;
+    if (x <= 0 || x >= m->array_dim - 1) return INVALID_OBJ;
+    if (y <= 0 || y >= m->array_dim - 1) return INVALID_OBJ;
+    return m->grid[y * m->array_dim + x];
+}
+static int mg_get_neighbors(const MazeGen *m, int idx, int type, int *out) { /* mazegen.cpp:48-66: order (-1,0) (0,-1) (0,1) (1,0) */
+    int x = idx % m->array_dim, y = idx / m->array_dim, n = 0;
+    static const int DX[4] = {-1, 0, 0, 1}, DY[4] = {0, -1, 1, 0};
+    for (int k = 0; k < 4; k++) {
+        int n_idx = (y + DY[k]) * m->array_dim + (x + DX[k]);
+        if (mg_get_obj(m, n_idx) == type) out[n++] = n_idx;
+    }
+    return n;
+}
+/* std::set<int> restated as membership flags; iteration in ascending cell order == the set's order */
+static int mg_expand_to_type(const MazeGen *m, const unsigned char *s0, unsigned char *s1, int type) { /* mazegen.cpp:68-99 */
+    int nc = m->array_dim * m->array_dim;
+    static unsigned char curr[MG_MAX_DIM * MG_MAX_DIM], next[MG_MAX_DIM * MG_MAX_DIM];
+    memcpy(curr, s0, (size_t)nc);
+    for (;;) {
+        int any = 0;
+        for (int i = 0; i < nc; i++) any |= curr[i];
+        if (!any) break;
+        memset(next, 0, (size_t)nc);
+        for (int elem = 0; elem < nc; elem++) {
+            if (!curr[elem]) continue;
+            int tgt[4], adj[4];
+            int nt = mg_get_neighbors(m, elem, type, tgt);
+            int na = mg_get_neighbors(m, elem, SPACE, adj);
+            for (int k = 0; k < na; k++) {
+                int j = adj[k];
+                if (!s0[j] && !s1[j]) {
+                    next[j] = 1;
+                    s1[j] = 1;
+                }
+            }
+            if (nt > 0) return tgt[0];
+        }
+        memcpy(curr, next, (size_t)nc);
+    }
+    return -1;
+}
+static void mg_generate_maze_with_doors(MazeGen *m, Rng *r, int num_doors) { /* mazegen.cpp:211-290 */
+    mg_generate_maze(m, r);
+    int nc = m->array_dim * m->array_dim;
+    static int forks[MG_MAX_DIM * MG_MAX_DIM], chosen[MG_MAX_DIM * MG_MAX_DIM], space_cells[MG_MAX_DIM * MG_MAX_DIM];
+    int nforks = 0, tmp[4];
+    for (int i = 0; i < nc; i++)
+        if (mg_get_obj(m, i) == SPACE && mg_get_neighbors(m, i, SPACE, tmp) > 2) forks[nforks++] = i;
+    int nchosen = 0;
+    if (num_doors > nforks) { /* RandGen::choose_n randgen.cpp:49-69 */
+        for (int i = 0; i < nforks; i++) chosen[nchosen++] = forks[i];
+    } else {
+        int nrem = nforks;
+        while (nchosen < num_doors) {
+            int idx = rng_randn(r, nrem);
+            chosen[nchosen++] = forks[idx];
+            for (int k = idx; k < nrem - 1; k++) forks[k] = forks[k + 1];
+            nrem--;
+        }
+    }
+    num_doors = nchosen;
+    for (int i = 0; i < nchosen; i++) m->grid[chosen[i]] = DOOR_OBJ;
+    int agent_cell;
+    {
+        int ns = 0;
+        for (int i = 0; i < nc; i++)
+            if (mg_get_obj(m, i) == SPACE) space_cells[ns++] = i;
+        if (ns <= 0) fatal("fassert elems.size() > 0 (randgen.cpp:44)");
+        do {
+            agent_cell = space_cells[rng_randn(r, ns)];
+        } while (mg_get_neighbors(m, agent_cell, DOOR_OBJ, tmp) > 0);
+        m->grid[agent_cell] = AGENT_OBJ;
+    }
+    static unsigned char s0[MG_MAX_DIM * MG_MAX_DIM], s1[MG_MAX_DIM * MG_MAX_DIM];
+    memset(s0, 0, (size_t)nc);
+    s0[agent_cell] = 1;
+    for (int door_num = 0; door_num < num_doors + 1; door_num++) {
+        memset(s1, 0, (size_t)nc);
+        int found_door = -1;
+        if (door_num < num_doors) {
+            found_door = mg_expand_to_type(m, s0, s1, DOOR_OBJ);
+            if (found_door < 0) fatal("grid.set_index(-1) (mazegen.cpp:262)");
+            m->grid[found_door] = DOOR_OBJ + door_num + 1;
+            for (int i = 0; i < nc; i++) s0[i] |= s1[i];
+        }
+        mg_expand_to_type(m, s0, s1, -999);
+        int ns = 0;
+        for (int i = 0; i < nc; i++)
+            if (s1[i]) space_cells[ns++] = i;
+        if (ns <= 0) fatal("fassert space_cells.size() > 0 (mazegen.cpp:275)");
+        int key_cell = space_cells[rng_randn(r, ns)];
+        m->grid[key_cell] = door_num == num_doors ? EXIT_OBJ : (KEY_OBJ + door_num + 1);
+        for (int i = 0; i < nc; i++) s0[i] |= s1[i];
+        if (found_door >= 0) s0[found_door] = 1;
+    }
+}
+
 /* ---- level generation ---- */
 static void choose_random_theme(Game *g, Ent *ent) { /* BAG:1038-1041 */
     ent->image_theme = rng_randn(&g->rand_gen, g->assets->type_num_themes[ent->image_type]);
@@ -1522,6 +1660,69 @@ static void fit_aspect_ratio(Game *g, Ent *ent) { /* BAG:1025-1036 */
     float ar = (float)(im->w * 1.0 / im->h);
     if (ar > 1) ent->ry = ent->rx / ar;
     else ent->rx = ent->ry * ar;
+}
+
+/* ---- Heist: heist.cpp:112-194 ---- */
+static Ent *spawn_entity_rxy(Game *g, float rx, float ry, int type, float x, float y, float w, float h, int check_collisions);
+static void hs_game_reset(Game *g) {
+    static MazeGen mg;
+    int min_maze_dim = 5;
+    int max_diff = (g->world_dim - min_maze_dim) / 2;
+    int difficulty = rng_randn(&g->rand_gen, max_diff + 1);
+    g->center_agent = g->opt.distribution_mode == 10;
+    if (g->opt.distribution_mode == 10) g->num_keys = rng_randn(&g->rand_gen, 4);
+    else g->num_keys = difficulty + rng_randn(&g->rand_gen, 2);
+    if (g->num_keys > 3) g->num_keys = 3;
+    for (int i = 0; i < 4; i++) g->has_keys[i] = 0;
+    int maze_dim = difficulty * 2 + min_maze_dim;
+    float maze_scale = (float)(g->main_height / (g->world_dim * 1.0));
+    Ent *agent = &g->pool[g->agent];
+    agent->rx = (float)(.375 * maze_scale);
+    agent->ry = (float)(.375 * maze_scale);
+    float r_ent = maze_scale / 2;
+    mg.maze_dim = maze_dim;
+    mg.array_dim = maze_dim + 2;
+    mg_generate_maze_with_doors(&mg, &g->rand_gen, g->num_keys);
+    agent->x = -1;
+    agent->y = -1;
+    int off_x = rng_randn(&g->rand_gen, g->world_dim - maze_dim + 1);
+    int off_y = rng_randn(&g->rand_gen, g->world_dim - maze_dim + 1);
+    for (int i = 0; i < g->grid_w * g->grid_h; i++) g->grid[i] = WALL_OBJ;
+    for (int i = 0; i < maze_dim; i++) {
+        for (int j = 0; j < maze_dim; j++) {
+            int x = off_x + i, y = off_y + j;
+            int obj = mg.grid[(j + MAZE_OFFSET) * mg.array_dim + i + MAZE_OFFSET];
+            float obj_x = (float)((x + .5) * maze_scale);
+            float obj_y = (float)((y + .5) * maze_scale);
+            if (obj != WALL_OBJ) set_obj(g, x, y, SPACE);
+            if (obj >= KEY_OBJ) {
+                float r = (float)(.375 * maze_scale);
+                Ent *ent = spawn_entity_rxy(g, r, r, HS_KEY, maze_scale * x, maze_scale * y, maze_scale, maze_scale, 1);
+                ent->image_theme = obj - KEY_OBJ - 1;
+                match_aspect_ratio(g, ent);
+            } else if (obj >= DOOR_OBJ) {
+                Ent *ent = push_entity(g, obj_x, obj_y, 0, 0, r_ent, r_ent, HS_LOCKED_DOOR);
+                ent->image_theme = obj - DOOR_OBJ - 1;
+            } else if (obj == EXIT_OBJ) {
+                float r = (float)(.375 * maze_scale);
+                Ent *ent = spawn_entity_rxy(g, r, r, HS_EXIT, maze_scale * x, maze_scale * y, maze_scale, maze_scale, 1);
+                match_aspect_ratio(g, ent);
+            } else if (obj == AGENT_OBJ) {
+                g->pool[g->agent].x = obj_x;
+                g->pool[g->agent].y = obj_y;
+            }
+        }
+    }
+    float ring_key_r = 0.03f;
+    for (int i = 0; i < g->num_keys; i++) {
+        Ent *ent = push_entity(g, (float)(1 - ring_key_r * (2 * i + 1.25)), (float)(ring_key_r * .75), 0, 0, ring_key_r, ring_key_r, HS_KEY_ON_RING);
+        ent->image_theme = i;
+        ent->image_type = HS_KEY;
+        ent->rotation = PI_F / 2;
+        ent->render_z = 1;
+        ent->use_abs_coords = 1;
+        match_aspect_ratio(g, ent);
+    }
 }
 
 /* ---- Plunder: plunder.cpp:117-184 ---- */
@@ -2169,6 +2370,14 @@ static void bag_game_reset(Game *g) { /* BAG:758-797 */
         else if (dm == 1) g->main_width = g->main_height = 20;
         else if (dm == 10) g->main_width = g->main_height = 35;
     }
+    if (g->game_id == GAME_HEIST) { /* choose_world_dim heist.cpp:95-110 */
+        int dm = g->opt.distribution_mode;
+        if (dm == 0) g->world_dim = 9;
+        else if (dm == 1) g->world_dim = 13;
+        else if (dm == 10) g->world_dim = 23;
+        g->maxspeed = (float).75;
+        g->main_width = g->main_height = g->world_dim;
+    }
     if (g->game_id == GAME_LEAPER) { /* choose_world_dim leaper.cpp:103-116 */
         int wd = 20;
         if (g->opt.distribution_mode == 0) wd = 9;
@@ -2251,6 +2460,8 @@ static void game_reset(Game *g) {
         lp_game_reset(g);
     } else if (g->game_id == GAME_PLUNDER) {
         pl_game_reset(g);
+    } else if (g->game_id == GAME_HEIST) {
+        hs_game_reset(g);
     } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:327-339 */
         g->center_agent = 0;
         sp_init_hps(g);
@@ -2720,7 +2931,9 @@ static void draw_image(Game *g, uint32_t *dst, RectD base_rect, float rotation, 
     if (theme >= MAX_IMAGE_THEMES) fatal("fassert theme < MAX_IMAGE_THEMES (BAG:888)");
     RectD adjusted = hook_adjusted_image_rect(g, img_type, base_rect);
     int mt = theme; /* mask_theme_if_necessary BAG:450-453 (restrict_themes) */
-    if (g->opt.restrict_themes && !(g->game_id == GAME_LEAPER && img_type == PLAYER) && !(g->game_id == GAME_PLUNDER && img_type == PL_SHIP)) mt = 0; /* should_preserve_type_themes leaper.cpp:91-93 */
+    if (g->opt.restrict_themes && !(g->game_id == GAME_LEAPER && img_type == PLAYER) && !(g->game_id == GAME_PLUNDER && img_type == PL_SHIP) &&
+        !(g->game_id == GAME_HEIST && (img_type == HS_KEY || img_type == HS_LOCKED_DOOR)))
+        mt = 0; /* should_preserve_type_themes leaper.cpp:91-93 */
     if (g->assets->type_num_themes[img_type] <= mt) fatal("asset theme out of range");
     const Img *img = &g->assets->img[g->assets->type_theme_img[img_type][mt]];
     if (rotation == 0) tile_image(dst, img, is_reflected, adjusted, tile_ratio, alpha);
@@ -2731,6 +2944,7 @@ static void draw_entities(Game *g, uint32_t *dst, int render_z) { /* BAG:1052-10
     for (int i = 0; i < g->n_ents; i++) {
         const Ent *m = &g->pool[g->ents[i]];
         if (m->render_z != render_z) continue;
+        if (g->game_id == GAME_HEIST && m->type == HS_KEY_ON_RING && !g->has_keys[m->image_theme]) continue; /* should_draw_entity heist.cpp:70-75, BAG:1055 */
         RectD r1; /* get_object_rect BAG:811-817 */
         if (m->use_abs_coords) {
             float vd = g->view_dim;
@@ -2906,6 +3120,12 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->main_width = 64;
         g->main_height = 64;
         g->out_of_bounds_object = CR_WALL_MID;
+    } else if (game_id == GAME_HEIST) { /* heist.cpp:24-34 */
+        g->has_useful_vel_info = 0;
+        g->main_width = 20;
+        g->main_height = 20;
+        g->out_of_bounds_object = WALL_OBJ;
+        g->visibility = 8.0;
     } else if (game_id == GAME_PLUNDER) { /* plunder.cpp:33-43 */
         g->timeout = 4000;
         g->main_width = 20;

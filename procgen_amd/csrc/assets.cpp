@@ -111,6 +111,13 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(9, {"misc_assets/dirt.png"});
         add_themes(10, {"misc_assets/tile_bricksGrey.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_HEIST) {  // reference src/games/heist.cpp:41-57
+        add_themes(51, {"kenney/Ground/Dirt/dirtCenter.png"});
+        add_themes(9, {"misc_assets/gemYellow.png"});
+        add_themes(0, {"misc_assets/spaceAstronauts_008.png"});
+        add_themes(2, {"misc_assets/keyBlue.png", "misc_assets/keyGreen.png", "misc_assets/keyRed.png"});
+        add_themes(1, {"misc_assets/lock_blue.png", "misc_assets/lock_green.png", "misc_assets/lock_red.png"});
+        topdown_backgrounds(backgrounds);
     } else if (game_id == GAME_PLUNDER) {  // reference src/games/plunder.cpp:45-63, src/resources.cpp:933-940
         add_themes(7, {"misc_assets/ship_1.png", "misc_assets/ship_2.png", "misc_assets/ship_3.png", "misc_assets/ship_4.png", "misc_assets/ship_5.png", "misc_assets/ship_6.png"});
         add_themes(1, {"misc_assets/cannonBall.png"});
@@ -268,7 +275,7 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
     }
     int ref_type = -1;  // the game's wall tile, when it has one: its size is the renderer's reference cell-image size
     if (game_id == GAME_COINRUN || game_id == GAME_CLIMBER) ref_type = 15;
-    if (game_id == GAME_MAZE) ref_type = 51;
+    if (game_id == GAME_MAZE || game_id == GAME_HEIST) ref_type = 51;
     if (game_id == GAME_MINER) ref_type = 9;
     if (game_id == GAME_FRUITBOT) ref_type = 2;
     if (game_id == GAME_LEAPER) ref_type = 2;

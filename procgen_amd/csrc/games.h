@@ -4,10 +4,11 @@
 #include "game_climber.h"
 #include "game_coinrun.h"
 #include "game_fruitbot.h"
+#include "game_heist.h"
 #include "game_leaper.h"
 #include "game_maze.h"
 #include "game_miner.h"
 #include "game_plunder.h"
 #include "game_starpilot.h"
 
-#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder)
+#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist)

@@ -16,8 +16,9 @@ struct MazeScratch {
     uint16_t label[1024];       // cell_sets_idxs (cell = maze_dim * y + x)
     uint16_t free_cells[1024];  // 0xffff = taken (-1 in the reference)
     uint32_t walls[512];        // x1 | y1<<5 | x2<<10 | y2<<15
-    uint8_t mgrid[MG_MAX_DIM * MG_MAX_DIM + 7];  // MazeGen::grid (index y * array_dim + x), values < 256
+    uint16_t mgrid[MG_MAX_DIM * MG_MAX_DIM + 3];  // MazeGen::grid (index y * array_dim + x); door / key ids exceed 255
 };
+constexpr int MG_EXIT_OBJ = 52, MG_AGENT_OBJ = 53, MG_DOOR_OBJ = 200, MG_KEY_OBJ = 300;  // reference src/object-ids.h
 
 template <class E>
 struct MazeGenDev {
@@ -31,11 +32,11 @@ struct MazeGenDev {
 
     PG_DEV void set_free_cell(int x, int y) {  // mazegen.cpp:26-34 (membership in free_cell_set == the cell already being SPACE)
         const int gi = (y + MAZE_OFFSET) * array_dim + x + MAZE_OFFSET;
-        const bool was_free = m.mgrid[gi] == (uint8_t)SPACE;
+        const bool was_free = m.mgrid[gi] == (uint16_t)SPACE;
         const int cell = maze_dim * y + x;
         PG_FOR_LANES(l) {
             if (l == 0) {
-                m.mgrid[gi] = (uint8_t)SPACE;
+                m.mgrid[gi] = (uint16_t)SPACE;
                 if (!was_free) m.free_cells[num_free_cells] = (uint16_t)cell;
             }
         }
@@ -47,7 +48,7 @@ struct MazeGenDev {
         const int md = maze_dim, ad = array_dim;
         for (int base = 0; base < ad * ad; base += 64) {
             PG_FOR_LANES(l) {
-                if (base + l < ad * ad) m.mgrid[base + l] = (uint8_t)WALL_OBJ;
+                if (base + l < ad * ad) m.mgrid[base + l] = (uint16_t)WALL_OBJ;
             }
         }
         for (int base = 0; base < md * md; base += 64) {
@@ -134,6 +135,195 @@ struct MazeGenDev {
         }
     }
 
+    // ---- variants that post-process the spanning tree (mazegen.cpp:36-111,189-290) ------------------------------------
+    // The reference's std::set<int> objects are membership flags here (ascending cell order == the set's iteration
+    // order); the scratch arrays of generate_maze are free by then and are reused: label -> s0 | s1 | curr flags,
+    // free_cells -> next flags, walls -> cell lists.  Serial wave-uniform code: a reset-time cost of a few thousand
+    // LDS operations.
+    PG_DEV uint8_t *flags_s0() { return reinterpret_cast<uint8_t *>(m.label); }
+    PG_DEV uint8_t *flags_s1() { return reinterpret_cast<uint8_t *>(m.label) + 640; }
+    PG_DEV uint8_t *flags_curr() { return reinterpret_cast<uint8_t *>(m.label) + 1280; }
+    PG_DEV uint8_t *flags_next() { return reinterpret_cast<uint8_t *>(m.free_cells); }
+    PG_DEV uint16_t *cell_list() { return reinterpret_cast<uint16_t *>(m.walls); }
+
+    PG_DEV int get_obj(int idx) const {  // mazegen.cpp:36-46
+        const int x = idx % array_dim, y = idx / array_dim;
+        if (x <= 0 || x >= array_dim - 1) return INVALID_OBJ;
+        if (y <= 0 || y >= array_dim - 1) return INVALID_OBJ;
+        return PG_UNIFORM_I(m.mgrid[idx]);
+    }
+    // get_neighbors mazegen.cpp:48-66 for an interior cell: order (-1,0) (0,-1) (0,1) (1,0)
+    PG_DEV int get_neighbors(int idx, int type, int (&out)[4]) const {
+        const int cand[4] = {idx - 1, idx - array_dim, idx + array_dim, idx + 1};
+        int n = 0;
+        for (int k = 0; k < 4; k++)
+            if (get_obj(cand[k]) == type) out[n++] = cand[k];
+        return n;
+    }
+    PG_DEV int count_neighbors(int idx, int type) const {
+        return (get_obj(idx - 1) == type) + (get_obj(idx - array_dim) == type) + (get_obj(idx + array_dim) == type) + (get_obj(idx + 1) == type);
+    }
+    PG_DEV void clear_flags(uint8_t *f, int nc) {
+        for (int base = 0; base < nc; base += 64) {
+            PG_FOR_LANES(l) {
+                if (base + l < nc) f[base + l] = 0;
+            }
+        }
+        PG_SYNC();
+    }
+    PG_DEV void or_flags(uint8_t *dst, const uint8_t *src, int nc) {
+        for (int base = 0; base < nc; base += 64) {
+            PG_FOR_LANES(l) {
+                if (base + l < nc) dst[base + l] = dst[base + l] | src[base + l];
+            }
+        }
+        PG_SYNC();
+    }
+    PG_DEV int expand_to_type(int type) {  // mazegen.cpp:68-99 on (s0, s1)
+        const int nc = array_dim * array_dim;
+        uint8_t *s0 = flags_s0(), *s1 = flags_s1(), *curr = flags_curr(), *next = flags_next();
+        for (int base = 0; base < nc; base += 64) {
+            PG_FOR_LANES(l) {
+                if (base + l < nc) curr[base + l] = s0[base + l];
+            }
+        }
+        PG_SYNC();
+        for (;;) {
+            bool any = false;
+            for (int base = 0; base < nc; base += 64) any = any || PG_BALLOT(l, (base + l) < nc && curr[base + l] != 0) != 0;
+            if (!any) break;
+            clear_flags(next, nc);
+            for (int base = 0; base < nc; base += 64) {
+                uint64_t todo = PG_BALLOT(l, (base + l) < nc && curr[base + l] != 0);
+                while (todo) {  // ascending order
+                    const int elem = base + pg_ctz64(todo);
+                    todo &= todo - 1;
+                    int adj[4];
+                    const int na = get_neighbors(elem, SPACE, adj);
+                    for (int k = 0; k < 4; k++) {
+                        if (k < na) {
+                            const int j = adj[k];
+                            if (!PG_UNIFORM_I(s0[j]) && !PG_UNIFORM_I(s1[j])) {
+                                next[j] = 1;
+                                s1[j] = 1;
+                            }
+                        }
+                    }
+                    int tgt[4];
+                    if (get_neighbors(elem, type, tgt) > 0) return tgt[0];
+                }
+            }
+            PG_SYNC();
+            for (int base = 0; base < nc; base += 64) {
+                PG_FOR_LANES(l) {
+                    if (base + l < nc) curr[base + l] = next[base + l];
+                }
+            }
+            PG_SYNC();
+        }
+        return -1;
+    }
+    // collects the cells with flag / predicate into cell_list() in ascending order; returns the count
+    template <class Pred>
+    PG_DEV int collect_cells(Pred pred) {
+        const int nc = array_dim * array_dim;
+        uint16_t *list = cell_list();
+        int n = 0;
+        for (int base = 0; base < nc; base += 64) {
+            const uint64_t mask = PG_BALLOT(l, (base + l) < nc && pred(base + l));
+            PG_FOR_LANES(l) {
+                if ((mask >> l) & 1ull) list[n + pg_popc64(mask & pg_mask_lt(l))] = (uint16_t)(base + l);
+            }
+            n += pg_popc64(mask);
+        }
+        PG_SYNC();
+        return n;
+    }
+
+    PG_DEV void generate_maze_with_doors(int num_doors) {  // mazegen.cpp:211-290
+        generate_maze();
+        const int nc = array_dim * array_dim;
+        uint16_t *list = cell_list();
+        // forks: SPACE cells with more than two SPACE neighbours
+        int nforks = collect_cells([&](int i) { return get_obj(i) == SPACE && count_neighbors(i, SPACE) > 2; });
+        // RandGen::choose_n (reference src/randgen.cpp:49-69): chosen cells become doors right away (order is irrelevant)
+        if (num_doors > nforks) {
+            for (int i = 0; i < nforks; i++) m.mgrid[PG_UNIFORM_I(list[i])] = (uint16_t)MG_DOOR_OBJ;
+            num_doors = nforks;
+        } else {
+            int nrem = nforks;
+            for (int c = 0; c < num_doors; c++) {
+                const int idx = e.randn(nrem);
+                const int cell = PG_UNIFORM_I(list[idx]);
+                PG_SYNC();
+                {   // rem_elems.erase(begin + idx): shift the tail down by one (all reads before the writes)
+                    PG_LANE_ARR(uint16_t, v, 10);
+                    PG_FOR_LANES(l) {
+                        for (int q = 0; q < 10; q++) {
+                            const int k = idx + l + 64 * q;
+                            PG_LA(v, q, l) = k < nrem - 1 ? list[k + 1] : (uint16_t)0;
+                        }
+                    }
+                    PG_SYNC();
+                    PG_FOR_LANES(l) {
+                        for (int q = 0; q < 10; q++) {
+                            const int k = idx + l + 64 * q;
+                            if (k < nrem - 1) list[k] = PG_LA(v, q, l);
+                        }
+                    }
+                }
+                PG_SYNC();
+                nrem--;
+                m.mgrid[cell] = (uint16_t)MG_DOOR_OBJ;
+            }
+        }
+        PG_SYNC();
+        int agent_cell;
+        {
+            const int ns = collect_cells([&](int i) { return get_obj(i) == SPACE; });
+            if (ns <= 0) {
+                e.fail(PGE_ASSERT);
+                return;
+            }
+            do {
+                agent_cell = PG_UNIFORM_I(list[e.randn(ns)]);
+            } while (count_neighbors(agent_cell, MG_DOOR_OBJ) > 0);
+            m.mgrid[agent_cell] = (uint16_t)MG_AGENT_OBJ;
+        }
+        PG_SYNC();
+        uint8_t *s0 = flags_s0(), *s1 = flags_s1();
+        clear_flags(s0, nc);
+        s0[agent_cell] = 1;
+        PG_SYNC();
+        for (int door_num = 0; door_num < num_doors + 1; door_num++) {
+            clear_flags(s1, nc);
+            int found_door = -1;
+            if (door_num < num_doors) {
+                found_door = expand_to_type(MG_DOOR_OBJ);
+                if (found_door < 0) {
+                    e.fail(PGE_ASSERT);
+                    return;
+                }
+                m.mgrid[found_door] = (uint16_t)(MG_DOOR_OBJ + door_num + 1);
+                PG_SYNC();
+                or_flags(s0, s1, nc);
+            }
+            expand_to_type(-999);
+            PG_SYNC();
+            const int ns = collect_cells([&](int i) { return s1[i] != 0; });
+            if (ns <= 0) {
+                e.fail(PGE_ASSERT);
+                return;
+            }
+            const int key_cell = PG_UNIFORM_I(list[e.randn(ns)]);
+            m.mgrid[key_cell] = (uint16_t)(door_num == num_doors ? MG_EXIT_OBJ : (MG_KEY_OBJ + door_num + 1));
+            PG_SYNC();
+            or_flags(s0, s1, nc);
+            if (found_door >= 0) s0[found_door] = 1;
+            PG_SYNC();
+        }
+    }
+
     PG_DEV void place_objects(int start_obj, int num_objs) {  // mazegen.cpp:292-306
         for (int j = 0; j < num_objs; j++) {
             int k = e.randn(num_free_cells);
@@ -142,7 +332,7 @@ struct MazeGenDev {
             PG_FOR_LANES(l) {
                 if (l == 0) {
                     m.free_cells[k] = 0xffffu;
-                    m.mgrid[(coin_cell / maze_dim + MAZE_OFFSET) * array_dim + coin_cell % maze_dim + MAZE_OFFSET] = (uint8_t)(start_obj + j);
+                    m.mgrid[(coin_cell / maze_dim + MAZE_OFFSET) * array_dim + coin_cell % maze_dim + MAZE_OFFSET] = (uint16_t)(start_obj + j);
                 }
             }
             PG_SYNC();

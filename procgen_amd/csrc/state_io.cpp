@@ -114,7 +114,7 @@ bool read_rng(Reader &r, int *seeded, uint32_t *mt, int *idx) {
 
 bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h) {
     if (game_id == GAME_BIGFISH || game_id == GAME_STARPILOT || game_id == GAME_LEAPER || game_id == GAME_PLUNDER) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64, starpilot.cpp:330
-    if (game_id == GAME_MAZE || game_id == GAME_MINER)  // maze.cpp:66, miner.cpp:140
+    if (game_id == GAME_MAZE || game_id == GAME_MINER || game_id == GAME_HEIST)  // maze.cpp:66, miner.cpp:140, heist.cpp:119
         return h.initial_reset_complete ? opt.distribution_mode == MemoryMode : opt.center_agent != 0;
     return opt.center_agent != 0;
 }
@@ -247,6 +247,11 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
         w.i(h.gsi1);
     } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:309-312
         w.i(h.gsi0);
+    } else if (game_id == GAME_HEIST) {  // reference src/games/heist.cpp:202-207
+        w.i(h.gsi0);
+        w.i(h.gsi1);
+        w.i(h.gsi0);  // has_keys.size() == num_keys
+        for (int k = 0; k < h.gsi0; k++) w.i((h.gsi2 >> k) & 1);
     } else if (game_id == GAME_PLUNDER) {  // reference src/games/plunder.cpp:241-257 (vectors = count + values, bools as ints)
         const float vels[5] = {h.gsf0, h.gsf1, h.gsf2, h.gsf3, h.gsf4};
         w.i(h.gsi0);
@@ -444,6 +449,13 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         h.gsi1 = r.i();
     } else if (game_id == GAME_MINER) {
         h.gsi0 = r.i();
+    } else if (game_id == GAME_HEIST) {
+        h.gsi0 = r.i();
+        h.gsi1 = r.i();
+        const int nk = r.i();
+        if (!r.ok || nk < 0 || nk > 3) return bad("set_state: heist has_keys");
+        h.gsi2 = 0;
+        for (int k = 0; k < nk; k++) h.gsi2 |= (r.i() ? 1 : 0) << k;
     } else if (game_id == GAME_PLUNDER) {
         h.gsi0 = r.i();
         if (r.i() != 5) return bad("set_state: plunder lane_directions");
