@@ -8,7 +8,7 @@
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
  * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner,
- * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors).
+ * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors), ninja.
  */
 #include "procgen_oracle.h"
 
@@ -38,7 +38,17 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_NINJA = 13, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+
+/* ninja.cpp:9-21 */
+#define NJ_GOAL 1
+#define NJ_BOMB 6
+#define NJ_THROWING_STAR 7
+#define NJ_PLAYER_JUMP 9
+#define NJ_PLAYER_RIGHT1 12
+#define NJ_PLAYER_RIGHT2 13
+#define NJ_FIRE 14
+#define NJ_WALL_MID 20
 
 /* heist.cpp:10-15, object-ids.h */
 #define HS_LOCKED_DOOR 1
@@ -437,6 +447,23 @@ static void assets_build(int game_id) {
         assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_NINJA) { /* ninja.cpp:45-75 */
+        assets_type(a, NJ_WALL_MID, "misc_assets/tile_bricksGrey.png");
+        assets_type(a, NJ_WALL_MID, "misc_assets/tile_bricksGrown.png");
+        assets_type(a, NJ_WALL_MID, "misc_assets/tile_bricksRed.png");
+        for (int i = 1; i <= 6; i++) {
+            snprintf(buf, sizeof buf, "platformer/shroom%d.png", i);
+            assets_type(a, NJ_GOAL, buf);
+        }
+        assets_type(a, PLAYER, "platformer/zombie_idle.png");
+        assets_type(a, NJ_PLAYER_JUMP, "platformer/zombie_jump.png");
+        assets_type(a, NJ_PLAYER_RIGHT1, "platformer/zombie_walk1.png");
+        assets_type(a, NJ_PLAYER_RIGHT2, "platformer/zombie_walk2.png");
+        assets_type(a, NJ_BOMB, "misc_assets/bomb.png");
+        assets_type(a, NJ_THROWING_STAR, "misc_assets/saw.png");
+        assets_type(a, NJ_FIRE, "misc_assets/bomb.png");
+        a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
+        for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
     } else if (game_id == GAME_HEIST) { /* heist.cpp:41-57 */
         assets_type(a, WALL_OBJ, "kenney/Ground/Dirt/dirtCenter.png");
         assets_type(a, HS_EXIT, "misc_assets/gemYellow.png");
@@ -549,6 +576,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "leaper") == 0) return GAME_LEAPER;
     if (strcmp(name, "plunder") == 0) return GAME_PLUNDER;
     if (strcmp(name, "heist") == 0) return GAME_HEIST;
+    if (strcmp(name, "ninja") == 0) return GAME_NINJA;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -623,6 +651,8 @@ typedef struct {
     int diamonds_remaining;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
+    /* Ninja: ninja.cpp:25-32 (has_support, facing_right, last_fire_time, wall_theme, gravity, air_control shared) */
+    float jump_charge, jump_charge_inc;
     /* HeistGame: heist.cpp:19-22 (world_dim shared with MazeGame below) */
     int num_keys, has_keys[4];
     /* PlunderGame: plunder.cpp:19-31 (last_fire_time shared with FruitBot below) */
@@ -717,6 +747,14 @@ static int cr_is_lava(int t) { return t == CR_LAVA_MID || t == CR_LAVA_TOP; }
 
 static int hook_is_blocked(const Game *g, const Ent *src, int target, int is_horizontal) {
     (void)is_horizontal;
+    if (g->game_id == GAME_NINJA && target == NJ_WALL_MID) { /* ninja.cpp:142-156 */
+        if (src->type == PLAYER) return 1;
+        if (src->type == NJ_THROWING_STAR) { /* throwing stars stick to walls */
+            ((Ent *)src)->vx = 0;
+            ((Ent *)src)->vy = 0;
+            return 1;
+        }
+    }
     if (target == WALL_OBJ) return 1; /* BAG:485-492 */
     if (target == g->out_of_bounds_object) return 1;
     if (g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) { /* coinrun.cpp:204-211, climber.cpp:136-143 */
@@ -781,6 +819,14 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
             g->coins_collected += 1;
             obj->will_erase = 1;
         }
+    } else if (g->game_id == GAME_NINJA) { /* ninja.cpp:77-87 */
+        if (obj->type == EXPLOSION) {
+            g->done = 1;
+        } else if (obj->type == NJ_GOAL) {
+            g->reward += 10.0f;
+            g->level_complete = 1;
+            g->done = 1;
+        }
     } else if (g->game_id == GAME_HEIST) { /* heist.cpp:77-93 */
         if (obj->type == HS_EXIT) {
             g->done = 1;
@@ -841,7 +887,19 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
     }
 }
 static void hook_handle_grid_collision(Game *g, Ent *obj, int type, int i, int j) {
-    (void)i; (void)j;
+    if (g->game_id == GAME_NINJA) { /* ninja.cpp:89-107 */
+        if (obj->type == PLAYER) {
+            if (type == NJ_FIRE) g->done = 1;
+            else if (type == NJ_BOMB) g->done = 1;
+        } else if (obj->type == NJ_THROWING_STAR) {
+            if (type == NJ_BOMB) {
+                obj->will_erase = 1;
+                set_obj(g, i, j, SPACE);
+                push_entity(g, (float)(i + .5), (float)(j + .5), 0, 0, (float).5, (float).5, EXPLOSION);
+            }
+            if (type == NJ_WALL_MID) obj->will_erase = 1;
+        }
+    }
     if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:144-154 */
         if (obj->type == PLAYER) {
             if (type == CR_GOAL) {
@@ -1073,6 +1131,24 @@ static void hook_set_action_xy(Game *g, int move_act) {
         if (g->action_vy == 1) {
             if (!g->has_support) g->action_vy = 0;
         }
+    } else if (g->game_id == GAME_NINJA) { /* ninja.cpp:318-347 */
+        Ent *agent = &g->pool[g->agent];
+        if (g->action_vy < 0) g->action_vy = 0;
+        if (g->action_vx > 0) g->facing_right = 1;
+        if (g->action_vx < 0) g->facing_right = 0;
+        int obj_below_1 = get_obj_from_floats(g, (float)(agent->x - (agent->rx - .01)), (float)(agent->y - (agent->ry + .01)));
+        int obj_below_2 = get_obj_from_floats(g, (float)(agent->x + (agent->rx - .01)), (float)(agent->y - (agent->ry + .01)));
+        int s1 = obj_below_1 == NJ_WALL_MID || obj_below_1 == g->out_of_bounds_object;
+        int s2 = obj_below_2 == NJ_WALL_MID || obj_below_2 == g->out_of_bounds_object;
+        g->has_support = s1 || s2;
+        if (g->has_support && g->action_vy == 1) {
+            g->action_vy = 1;
+            g->jump_charge += g->jump_charge_inc;
+            if (g->jump_charge > 1) g->jump_charge = 1;
+        } else {
+            g->action_vy = 0;
+        }
+        if (!g->has_support) g->jump_charge = 0;
     } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:268-288 */
         Ent *agent = &g->pool[g->agent];
         if (g->action_vy < 0) g->action_vy = 0;
@@ -1120,6 +1196,16 @@ static void hook_update_agent_velocity(Game *g) {
         if (!(g->has_support && g->action_vy > 0)) {
             agent->vy -= g->gravity;
             agent->vy = clip_abs(agent->vy, g->max_jump);
+        }
+    } else if (g->game_id == GAME_NINJA) { /* ninja.cpp:109-124 */
+        float mixrate_x = g->has_support ? g->mixrate : (g->mixrate * g->air_control);
+        agent->vx = (1 - mixrate_x) * agent->vx + mixrate_x * g->maxspeed * g->action_vx;
+        if (g->action_vy < 1 && g->jump_charge > 0) {
+            agent->vy = g->jump_charge * g->max_jump;
+            g->jump_charge = 0;
+        }
+        if (!g->has_support) {
+            if (agent->vy > -2) agent->vy -= g->gravity;
         }
     } else if (g->game_id == GAME_CLIMBER) { /* climber.cpp:114-126 */
         float mixrate_x = g->has_support ? g->mixrate : (g->mixrate * g->air_control);
@@ -1261,6 +1347,24 @@ static void game_step(Game *g) {
         mn_game_step_tail(g);
     } else if (g->game_id == GAME_STARPILOT) {
         sp_game_step_tail(g);
+    } else if (g->game_id == GAME_NINJA) { /* ninja.cpp:349-383 */
+        Ent *agent = &g->pool[g->agent];
+        if (g->action_vx > 0) agent->is_reflected = 0;
+        if (g->action_vx < 0) agent->is_reflected = 1;
+        if (g->special_action > 0 && (g->cur_time - g->last_fire_time) >= 3) {
+            float theta = 0;
+            float bullet_vel = 1;
+            if (g->special_action == 1) theta = 0;
+            else if (g->special_action == 2) theta = PI_F / 4;
+            else if (g->special_action == 3) theta = PI_F / 2;
+            else if (g->special_action == 4) theta = -1 * PI_F / 4;
+            if (agent->is_reflected) theta = PI_F - theta;
+            Ent *nb = push_entity(g, agent->x, agent->y, (float)(bullet_vel * cos((double)theta)), (float)(bullet_vel * sin((double)theta)), (float).25, (float).25, NJ_THROWING_STAR);
+            nb->collides_with_entities = 1;
+            nb->expire_time = 15;
+            nb->smart_step = 1;
+            g->last_fire_time = g->cur_time;
+        }
     } else if (g->game_id == GAME_HEIST) { /* heist.cpp:196-200 */
         face_direction(&g->pool[g->agent], g->action_vx, g->action_vy, 0);
     } else if (g->game_id == GAME_PLUNDER) { /* plunder.cpp:186-239 */
@@ -1660,6 +1764,106 @@ static void fit_aspect_ratio(Game *g, Ent *ent) { /* BAG:1025-1036 */
     float ar = (float)(im->w * 1.0 / im->h);
     if (ar > 1) ent->ry = ent->rx / ar;
     else ent->rx = ent->ry * ar;
+}
+
+/* ---- Ninja: ninja.cpp:179-316 ---- */
+static void nj_fill_ground_block(Game *g, int x, int y, int dx, int dy) { /* fill_block_top ninja.cpp:179-188 with fill == top */
+    if (dy <= 0) return;
+    fill_elem(g, x, y, dx, dy - 1, NJ_WALL_MID);
+    fill_elem(g, x, y + dy - 1, dx, 1, NJ_WALL_MID);
+}
+static void nj_generate_coin_to_the_right(Game *g, int difficulty) { /* ninja.cpp:197-285 */
+    int min_gap = difficulty - 1;
+    int min_plat_w = 1;
+    int inc_dy = 4;
+    if (g->opt.distribution_mode == 0) {
+        min_gap -= 1;
+        if (min_gap < 0) min_gap = 0;
+        min_plat_w = 3;
+        inc_dy = 2;
+    }
+    float bomb_prob = (float)(.25 * (difficulty - 1));
+    int max_gap_inc = difficulty == 1 ? 1 : 2;
+    int num_sections = rng_randn(&g->rand_gen, difficulty) + difficulty;
+    int start_x = 5;
+    int curr_x = start_x;
+    int curr_y = g->main_height / 2;
+    int min_y = curr_y;
+    int w = g->main_width;
+    float _max_dy = g->max_jump * g->max_jump / (2 * g->gravity);
+    int max_dy = (int)(_max_dy - .5);
+    int prev_x, prev_y;
+    nj_fill_ground_block(g, 0, 0, start_x, curr_y);
+    fill_elem(g, 0, curr_y + 8, start_x, g->main_height - curr_y - 8, NJ_WALL_MID);
+    for (int i = 0; i < num_sections; i++) {
+        prev_x = curr_x;
+        prev_y = curr_y;
+        int num_edges = rng_randn(&g->rand_gen, 2) + 1;
+        int max_y = -1;
+        int last_edge_y = -1;
+        for (int j = 0; j < num_edges; j++) {
+            curr_x = prev_x + j;
+            if (curr_x + 15 >= w) break;
+            curr_y = prev_y;
+            int dy = rng_randn(&g->rand_gen, inc_dy) + 1 + (int)(difficulty / 3);
+            if (dy > max_dy) dy = max_dy;
+            if (curr_y >= g->main_height - 15) dy *= -1;
+            else if (curr_y >= 5 && rng_rand01(&g->rand_gen) < .4) dy *= -1;
+            curr_y += dy;
+            if (curr_y < 3) curr_y = 3;
+            if (abs(curr_y - last_edge_y) <= 1) curr_y = last_edge_y + 2;
+            int dx = min_plat_w + rng_randn(&g->rand_gen, 3);
+            nj_fill_ground_block(g, curr_x, curr_y - 1, dx, 1);
+            curr_x += dx;
+            curr_x += min_gap + rng_randn(&g->rand_gen, max_gap_inc + 1);
+            if (curr_y > max_y) max_y = curr_y;
+            if (curr_y < min_y) min_y = curr_y;
+            last_edge_y = curr_y;
+        }
+        if (rng_rand01(&g->rand_gen) < bomb_prob) set_obj(g, rng_randn(&g->rand_gen, curr_x - prev_x + 1) + prev_x, max_y + 2, NJ_BOMB);
+        int ceiling_height = 11;
+        int ceiling_start = max_y - 1 + ceiling_height;
+        nj_fill_ground_block(g, prev_x, ceiling_start, curr_x - prev_x, g->main_height - ceiling_start);
+    }
+    Ent *ent = push_entity(g, (float)(curr_x + .5), (float)(curr_y + .5), 0, 0, (float).5, (float).5, NJ_GOAL);
+    choose_random_theme(g, ent);
+    nj_fill_ground_block(g, curr_x, curr_y - 1, 1, 1);
+    fill_elem(g, curr_x, curr_y + 6, 1, g->main_height - curr_y - 6, NJ_WALL_MID);
+    int fire_y = min_y - 2;
+    if (fire_y < 1) fire_y = 1;
+    nj_fill_ground_block(g, start_x, 0, g->main_width - start_x, fire_y);
+    fill_elem(g, start_x, fire_y, g->main_width - start_x, 1, NJ_FIRE);
+    fill_elem(g, curr_x + 1, 0, g->main_width - curr_x - 1, g->main_height, NJ_WALL_MID);
+}
+static void nj_game_reset(Game *g) { /* ninja.cpp:287-316 */
+    Ent *agent = &g->pool[g->agent];
+    g->gravity = 0.2f;
+    g->max_jump = 1.5;
+    g->air_control = 0.15f;
+    g->maxspeed = (float).5;
+    g->has_support = 0;
+    g->facing_right = 1;
+    g->jump_charge = 0;
+    g->jump_charge_inc = (float).25;
+    g->visibility = 16;
+    agent->rx = (float).5;
+    agent->ry = (float).5;
+    agent->x = 1 + agent->rx;
+    agent->y = g->main_height / 2 + agent->ry;
+    if (g->opt.distribution_mode == 0) {
+        g->max_jump = (float)1.25;
+        g->jump_charge_inc = 1;
+        g->visibility = 10;
+    }
+    int max_difficulty = 3;
+    int difficulty = rng_randn(&g->rand_gen, max_difficulty) + 1;
+    g->last_fire_time = 0;
+    g->wall_theme = rng_randn(&g->rand_gen, 3);
+    fill_elem(g, 0, 0, g->main_width, 1, NJ_WALL_MID); /* init_floor_and_walls ninja.cpp:190-195 */
+    fill_elem(g, 0, 0, 1, g->main_height, NJ_WALL_MID);
+    fill_elem(g, g->main_width - 1, 0, 1, g->main_height, NJ_WALL_MID);
+    fill_elem(g, 0, g->main_height - 1, g->main_width, 1, NJ_WALL_MID);
+    nj_generate_coin_to_the_right(g, difficulty);
 }
 
 /* ---- Heist: heist.cpp:112-194 ---- */
@@ -2462,6 +2666,8 @@ static void game_reset(Game *g) {
         pl_game_reset(g);
     } else if (g->game_id == GAME_HEIST) {
         hs_game_reset(g);
+    } else if (g->game_id == GAME_NINJA) {
+        nj_game_reset(g);
     } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:327-339 */
         g->center_agent = 0;
         sp_init_hps(g);
@@ -2882,6 +3088,11 @@ static int hook_image_for_type(const Game *g, int type) {
         if (type == MN_MOVING_BOULDER) return MN_BOULDER;
         if (type == MN_MOVING_DIAMOND) return MN_DIAMOND;
     }
+    if (g->game_id == GAME_NINJA && type == PLAYER) { /* ninja.cpp:158-168 */
+        const Ent *agent = &g->pool[g->agent];
+        if (fabs((double)agent->vx) < .01 && g->action_vx == 0 && g->has_support) return PLAYER;
+        return (g->cur_time / 5 % 2 == 0 || !g->has_support) ? NJ_PLAYER_RIGHT1 : NJ_PLAYER_RIGHT2;
+    }
     if (g->game_id == GAME_CLIMBER) { /* climber.cpp:145-159 */
         if (type == PLAYER) {
             const Ent *agent = &g->pool[g->agent];
@@ -2904,6 +3115,7 @@ static int hook_image_for_type(const Game *g, int type) {
     return abs(type); /* BAG:438-440 */
 }
 static int hook_theme_for_grid_obj(const Game *g, int type) {
+    if (g->game_id == GAME_NINJA && type == NJ_WALL_MID) return g->wall_theme; /* ninja.cpp:130-135 */
     if ((g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) && cr_is_wall(type)) return g->wall_theme; /* coinrun.cpp:133-138, climber.cpp:102-107 */
     return 0;
 }
@@ -3032,6 +3244,11 @@ static void game_draw(Game *g, uint32_t *dst) { /* BAG:979-1012,921-970 */
         fill_rect(dst, d2, 0xff000000u | ((uint32_t)s1 << 16) | ((uint32_t)s1 << 8) | (uint32_t)s1);
         fill_rect(dst, d3, 0xff000000u | ((uint32_t)s2 << 16) | ((uint32_t)s2 << 8) | (uint32_t)s2);
     }
+    if (g->game_id == GAME_NINJA) { /* game_draw override ninja.cpp:170-177 */
+        float bar_height = 3 * g->jump_charge;
+        RectD r = {(float).25 * g->unit, (float)(g->visibility - .5 - bar_height) * g->unit, (float).5 * g->unit, bar_height * g->unit};
+        fill_rect(dst, r, 0xff42f587u);
+    }
     if (g->game_id == GAME_PLUNDER) { /* game_draw override plunder.cpp:65-77; get_abs_rect BAG:803-805 */
         float w1 = g->main_width * g->juice_left;
         float w2 = (float)(g->main_width * (g->targets_hit * 1.0 / g->target_quota));
@@ -3120,6 +3337,10 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->main_width = 64;
         g->main_height = 64;
         g->out_of_bounds_object = CR_WALL_MID;
+    } else if (game_id == GAME_NINJA) { /* ninja.cpp:34-40 */
+        g->main_width = 64;
+        g->main_height = 64;
+        g->out_of_bounds_object = NJ_WALL_MID;
     } else if (game_id == GAME_HEIST) { /* heist.cpp:24-34 */
         g->has_useful_vel_info = 0;
         g->main_width = 20;

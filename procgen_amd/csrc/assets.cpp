@@ -111,6 +111,17 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(9, {"misc_assets/dirt.png"});
         add_themes(10, {"misc_assets/tile_bricksGrey.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_NINJA) {  // reference src/games/ninja.cpp:45-75
+        add_themes(20, {"misc_assets/tile_bricksGrey.png", "misc_assets/tile_bricksGrown.png", "misc_assets/tile_bricksRed.png"});
+        add_themes(1, {"platformer/shroom1.png", "platformer/shroom2.png", "platformer/shroom3.png", "platformer/shroom4.png", "platformer/shroom5.png", "platformer/shroom6.png"});
+        add_themes(0, {"platformer/zombie_idle.png"});
+        add_themes(9, {"platformer/zombie_jump.png"});
+        add_themes(12, {"platformer/zombie_walk1.png"});
+        add_themes(13, {"platformer/zombie_walk2.png"});
+        add_themes(6, {"misc_assets/bomb.png"});
+        add_themes(7, {"misc_assets/saw.png"});
+        add_themes(14, {"misc_assets/bomb.png"});
+        platform_backgrounds(backgrounds);
     } else if (game_id == GAME_HEIST) {  // reference src/games/heist.cpp:41-57
         add_themes(51, {"kenney/Ground/Dirt/dirtCenter.png"});
         add_themes(9, {"misc_assets/gemYellow.png"});
@@ -279,6 +290,7 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
     if (game_id == GAME_MINER) ref_type = 9;
     if (game_id == GAME_FRUITBOT) ref_type = 2;
     if (game_id == GAME_LEAPER) ref_type = 2;
+    if (game_id == GAME_NINJA) ref_type = 20;
     if (ref_type >= 0 && t.type_theme_img[ref_type][0] >= 0) {
         t.ref_w = t.img[t.type_theme_img[ref_type][0]].w;
         t.ref_h = t.img[t.type_theme_img[ref_type][0]].h;

@@ -8,7 +8,8 @@
 #include "game_leaper.h"
 #include "game_maze.h"
 #include "game_miner.h"
+#include "game_ninja.h"
 #include "game_plunder.h"
 #include "game_starpilot.h"
 
-#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist)
+#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist) X(Ninja)

@@ -112,6 +112,17 @@ constexpr int game_grid_bytes() {
     return game_cell_bytes<Game>() + GameAux<Game>::WORDS * 4;
 }
 
+// a game whose is_blocked has a side effect on the moving entity (ninja's throwing stars stick to walls) declares
+// HAS_BLOCK_HOOK and on_grid_block(e, obj): called when the corner probes of sub_step found a blocking cell
+template <class Game, class = void>
+struct GameHasBlockHook {
+    static constexpr bool value = false;
+};
+template <class Game>
+struct GameHasBlockHook<Game, decltype((void)Game::HAS_BLOCK_HOOK)> {
+    static constexpr bool value = Game::HAS_BLOCK_HOOK;
+};
+
 template <class Game, int CAP>
 struct Lds {
     uint32_t ent[EF_COUNT * CAP];
@@ -448,6 +459,9 @@ struct Env {
                     block = block || Game::is_blocked(*this, otype, type2, is_horizontal);
                     reflect = reflect || Game::will_reflect(otype, type2);
                 }
+        }
+        if constexpr (GameHasBlockHook<Game>::value) {
+            if (block) Game::on_grid_block(*this, obj);
         }
         if (reflect) {
             if (is_horizontal) {

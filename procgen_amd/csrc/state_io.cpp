@@ -247,6 +247,15 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
         w.i(h.gsi1);
     } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:309-312
         w.i(h.gsi0);
+    } else if (game_id == GAME_NINJA) {  // reference src/games/ninja.cpp:385-395
+        w.i(h.gsi0 ? 1 : 0);
+        w.i(h.gsi1 ? 1 : 0);
+        w.i(h.gsi2);
+        w.i(h.gsi3);
+        w.f(h.gsf0);
+        w.f(h.gsf1);
+        w.f(h.gsf2);
+        w.f(h.gsf3);
     } else if (game_id == GAME_HEIST) {  // reference src/games/heist.cpp:202-207
         w.i(h.gsi0);
         w.i(h.gsi1);
@@ -449,6 +458,15 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         h.gsi1 = r.i();
     } else if (game_id == GAME_MINER) {
         h.gsi0 = r.i();
+    } else if (game_id == GAME_NINJA) {
+        h.gsi0 = r.i() > 0;
+        h.gsi1 = r.i() > 0;
+        h.gsi2 = r.i();
+        h.gsi3 = r.i();
+        h.gsf0 = r.f();
+        h.gsf1 = r.f();
+        h.gsf2 = r.f();
+        h.gsf3 = r.f();
     } else if (game_id == GAME_HEIST) {
         h.gsi0 = r.i();
         h.gsi1 = r.i();
