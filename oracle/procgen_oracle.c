@@ -8,7 +8,7 @@
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
  * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner,
- * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors), ninja.
+ * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors), ninja, dodgeball.
  */
 #include "procgen_oracle.h"
 
@@ -38,7 +38,19 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_NINJA = 13, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_DODGEBALL = 6, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_NINJA = 13, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+
+/* dodgeball.cpp:8-25 */
+#define DB_LAVA_WALL 1
+#define DB_PLAYER_BALL 3
+#define DB_ENEMY 4
+#define DB_DOOR 5
+#define DB_ENEMY_BALL 6
+#define DB_DOOR_OPEN 7
+#define DB_DUST_CLOUD 8
+#define DB_OOB_WALL 10
+#define DB_ENEMY_VEL 0.05f
+#define DB_BALL_V_ROT (PI_F * 0.23f)
 
 /* ninja.cpp:9-21 */
 #define NJ_GOAL 1
@@ -307,7 +319,8 @@ static int assets_add(GameAssets *a, const char *name, int is_bg) {
 
 static void assets_type(GameAssets *a, int type, const char *name) {
     int t = a->type_num_themes[type];
-    a->type_theme_img[type][t] = assets_add(a, name, 0);
+    /* names beyond MAX_IMAGE_THEMES count towards asset_num_themes (BAG:114-116) but can never be drawn (fassert BAG:888) */
+    if (t < MAX_IMAGE_THEMES) a->type_theme_img[type][t] = assets_add(a, name, 0);
     a->type_num_themes[type] = t + 1;
 }
 
@@ -447,6 +460,23 @@ static void assets_build(int game_id) {
         assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_DODGEBALL) { /* dodgeball.cpp:49-88 */
+        assets_type(a, PLAYER, "misc_assets/character12.png");
+        assets_type(a, DB_PLAYER_BALL, "misc_assets/ball_soccer1.png");
+        for (int i = 1; i <= 11; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/character%d.png", i);
+            assets_type(a, DB_ENEMY, buf);
+        }
+        assets_type(a, DB_DOOR, "misc_assets/blockRed.png");
+        assets_type(a, DB_ENEMY_BALL, "misc_assets/ball_soccer2.png");
+        assets_type(a, DB_DOOR_OPEN, "misc_assets/blockGreen.png");
+        assets_type(a, DB_LAVA_WALL, "misc_assets/tileStone_slope2.png");
+        assets_type(a, DB_OOB_WALL, "misc_assets/tileStone_slope2.png");
+        for (int i = 1; i <= 9; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/spaceEffect%d.png", i);
+            assets_type(a, DB_DUST_CLOUD, buf);
+        }
+        assets_topdown_backgrounds(a);
     } else if (game_id == GAME_NINJA) { /* ninja.cpp:45-75 */
         assets_type(a, NJ_WALL_MID, "misc_assets/tile_bricksGrey.png");
         assets_type(a, NJ_WALL_MID, "misc_assets/tile_bricksGrown.png");
@@ -577,6 +607,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "plunder") == 0) return GAME_PLUNDER;
     if (strcmp(name, "heist") == 0) return GAME_HEIST;
     if (strcmp(name, "ninja") == 0) return GAME_NINJA;
+    if (strcmp(name, "dodgeball") == 0) return GAME_DODGEBALL;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -651,6 +682,9 @@ typedef struct {
     int diamonds_remaining;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
+    /* DodgeballGame: dodgeball.cpp:29-36 (min_dim, last_fire_time shared with FruitBot) */
+    float hard_min_dim, ball_vscale, ball_r;
+    int num_enemies, enemy_fire_delay;
     /* Ninja: ninja.cpp:25-32 (has_support, facing_right, last_fire_time, wall_theme, gravity, air_control shared) */
     float jump_charge, jump_charge_inc;
     /* HeistGame: heist.cpp:19-22 (world_dim shared with MazeGame below) */
@@ -785,6 +819,8 @@ static int hook_is_blocked_ents(Game *g, const Ent *src, const Ent *target, int 
 static int hook_will_reflect(const Game *g, int src, int target) {
     if (g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) /* coinrun.cpp:140-142, climber.cpp:110-112 (same ids) */
         return (src == CR_ENEMY && (cr_is_wall(target) || target == CR_ENEMY_BARRIER));
+    if (g->game_id == GAME_DODGEBALL) /* dodgeball.cpp:98-100 */
+        return (src == DB_ENEMY && (target == DB_LAVA_WALL || target == g->out_of_bounds_object));
     if (g->game_id == GAME_FRUITBOT) /* fruitbot.cpp:80-82 */
         return (src == FB_BAD_OBJ && (target == FB_BARRIER || target == WALL_OBJ));
     if (g->game_id == GAME_MINER) /* miner.cpp:66-68 */
@@ -818,6 +854,20 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
             g->reward += 1.0f;
             g->coins_collected += 1;
             obj->will_erase = 1;
+        }
+    } else if (g->game_id == GAME_DODGEBALL) { /* dodgeball.cpp:102-118 */
+        if (obj->type == DB_ENEMY) {
+            g->done = 1;
+        } else if (obj->type == DB_ENEMY_BALL) {
+            g->done = 1;
+        } else if (obj->type == DB_DOOR) {
+            if (g->num_enemies == 0) {
+                g->done = 1;
+                g->reward += 10.0f;
+                g->level_complete = 1;
+            }
+        } else if (obj->type == DB_LAVA_WALL) {
+            g->done = 1;
         }
     } else if (g->game_id == GAME_NINJA) { /* ninja.cpp:77-87 */
         if (obj->type == EXPLOSION) {
@@ -913,6 +963,28 @@ static void hook_handle_grid_collision(Game *g, Ent *obj, int type, int i, int j
     }
 }
 static void hook_handle_collision(Game *g, Ent *src, Ent *target) { /* BAG:398 */
+    if (g->game_id == GAME_DODGEBALL) { /* dodgeball.cpp:120-151 */
+        if (target->type == DB_PLAYER_BALL) {
+            if (src->type == DB_LAVA_WALL) {
+                target->will_erase = 1;
+            } else if (src->type == DB_ENEMY) {
+                src->health -= 1;
+                target->will_erase = 1;
+                if (src->health <= 0 && !src->will_erase) {
+                    src->will_erase = 1;
+                    g->reward += 2.0f;
+                    Ent *ent = push_entity(g, src->x, src->y, 0, 0, src->rx, src->rx, DB_DUST_CLOUD); /* spawn_child BAG:225-231, match_vel = false */
+                    ent->vrot = PI_F / 0.3f;
+                    ent->grow_rate = 1.0f / 1.2f;
+                    ent->expire_time = 4;
+                    ent->alpha_decay = 0.9f;
+                    ent->image_theme = g->step_rand_int % g->assets->type_num_themes[ent->image_type]; /* choose_step_random_theme BAG:1043-1046 */
+                }
+            }
+        } else if (target->type == DB_ENEMY_BALL) {
+            if (src->type == DB_LAVA_WALL) target->will_erase = 1;
+        }
+    }
     if (g->game_id == GAME_PLUNDER) { /* plunder.cpp:87-109 */
         if (src->type == PL_PLAYER_BULLET) {
             if (target->type == PL_SHIP) {
@@ -1292,6 +1364,7 @@ static void choose_random_theme(Game *g, Ent *ent);
 static void match_aspect_ratio(Game *g, Ent *ent);
 static void mn_game_step_tail(Game *g);
 static void sp_game_step_tail(Game *g);
+static void db_game_step_tail(Game *g);
 static void face_direction(Ent *e, float dx, float dy, float rotation_offset);
 static int has_any_collision(const Game *g, const Ent *e1, float margin);
 static void lp_spawn_entities(Game *g);
@@ -1347,6 +1420,8 @@ static void game_step(Game *g) {
         mn_game_step_tail(g);
     } else if (g->game_id == GAME_STARPILOT) {
         sp_game_step_tail(g);
+    } else if (g->game_id == GAME_DODGEBALL) {
+        db_game_step_tail(g);
     } else if (g->game_id == GAME_NINJA) { /* ninja.cpp:349-383 */
         Ent *agent = &g->pool[g->agent];
         if (g->action_vx > 0) agent->is_reflected = 0;
@@ -1764,6 +1839,196 @@ static void fit_aspect_ratio(Game *g, Ent *ent) { /* BAG:1025-1036 */
     float ar = (float)(im->w * 1.0 / im->h);
     if (ar > 1) ent->ry = ent->rx / ar;
     else ent->rx = ent->ry * ar;
+}
+
+/* ---- Dodgeball: dodgeball.cpp:157-448 ---- */
+typedef struct { float x, y, w, h; } DbRoom; /* QRectF built from float expressions: the doubles hold float values */
+static DbRoom db_rooms[64];
+static int db_nrooms;
+static void db_add_room(Game *g, float x, float y, float w, float h) { /* dodgeball.cpp:157-164 */
+    float rw = w, rh = h;
+    if ((rw >= g->min_dim || rh >= g->min_dim) && (rw >= g->hard_min_dim) && (rh >= g->hard_min_dim)) {
+        if (db_nrooms >= 64) fatal("room list overflow");
+        DbRoom r = {x, y, w, h};
+        db_rooms[db_nrooms++] = r;
+    }
+}
+static void db_split_room(Game *g, DbRoom room, float thickness) { /* dodgeball.cpp:166-225 */
+    int will_split_width = rng_rand01(&g->rand_gen) < .5;
+    int choice2 = rng_rand01(&g->rand_gen) < .5;
+    if (room.w < g->min_dim) will_split_width = 0;
+    if (room.h < g->min_dim) will_split_width = 1;
+    float rx = room.x, ry = room.y, rw = room.w, rh = room.h;
+    float gap = (float)(.25 * (rng_randn(&g->rand_gen, 3) + 1));
+    float pct = 1 - gap;
+    if (!will_split_width) {
+        float wy, wh, remy;
+        if (choice2) {
+            wy = ry;
+            remy = ry + pct * rh;
+            wh = pct * rh;
+        } else {
+            wy = ry + (1 - pct) * rh;
+            remy = ry;
+            wh = pct * rh;
+        }
+        push_entity(g, rx + rw / 2, wy + wh / 2, 0, 0, thickness, wh / 2, DB_LAVA_WALL);
+        float nextw = rw / 2 - thickness;
+        db_add_room(g, rx, wy, nextw, wh);
+        db_add_room(g, rx + rw / 2 + thickness, wy, nextw, wh);
+        db_add_room(g, rx, remy, rw, rh - wh);
+    } else {
+        float wx, ww, remx;
+        if (choice2) {
+            wx = rx;
+            remx = rx + pct * rw;
+            ww = pct * rw;
+        } else {
+            wx = rx + (1 - pct) * rw;
+            remx = rx;
+            ww = pct * rw;
+        }
+        push_entity(g, wx + ww / 2, ry + rh / 2, 0, 0, ww / 2, thickness, DB_LAVA_WALL);
+        float nexth = rh / 2 - thickness;
+        db_add_room(g, wx, ry, ww, nexth);
+        db_add_room(g, wx, ry + rh / 2 + thickness, ww, nexth);
+        db_add_room(g, remx, ry, rw - ww, rh);
+    }
+}
+static void db_choose_vel(Game *g, Ent *ent) { /* dodgeball.cpp:227-239 */
+    float vel = DB_ENEMY_VEL * (rng_randn(&g->rand_gen, 2) * 2 - 1);
+    if (rng_randn(&g->rand_gen, 2) == 0) {
+        ent->vx = vel;
+        ent->vy = 0;
+    } else {
+        ent->vy = vel;
+        ent->vx = 0;
+    }
+    ent->spawn_time = rng_randn(&g->rand_gen, 50) + 25;
+}
+static void reposition_agent(Game *g);
+static void db_game_reset(Game *g) { /* dodgeball.cpp:261-371 */
+    g->center_agent = g->opt.distribution_mode == 10;
+    g->last_fire_time = 0;
+    db_nrooms = 0;
+    DbRoom all = {0, 0, (float)g->main_width, (float)g->main_height};
+    db_rooms[db_nrooms++] = all;
+    int dm = g->opt.distribution_mode;
+    Ent *agent = &g->pool[g->agent];
+    float thickness = 0.3f, enemy_r = (float).5, exit_r = (float).75;
+    g->ball_r = (float).25;
+    g->ball_vscale = (float).25;
+    int num_iterations = 0, max_extra_enemies = 3;
+    if (dm == 0) {
+        num_iterations = 2;
+        thickness *= 2; enemy_r *= 2; g->ball_r *= 2; g->ball_vscale *= 2;
+        g->maxspeed = (float).75;
+        agent->rx = 1; agent->ry = 1;
+        exit_r *= 2;
+    } else if (dm == 1) {
+        num_iterations = 4;
+        thickness = (float)(thickness * 1.5); enemy_r = (float)(enemy_r * 1.5); g->ball_r = (float)(g->ball_r * 1.5); g->ball_vscale = (float)(g->ball_vscale * 1.5);
+        g->maxspeed = (float).5;
+        agent->rx = (float).75; agent->ry = (float).75;
+    } else if (dm == 2) {
+        num_iterations = 8;
+        g->maxspeed = (float).25;
+    } else if (dm == 10) {
+        num_iterations = 16;
+        thickness = (float)(thickness * 1.5); enemy_r = (float)(enemy_r * 1.5); g->ball_r = (float)(g->ball_r * 1.5); g->ball_vscale = (float)(g->ball_vscale * 1.5);
+        g->maxspeed = (float).5;
+        agent->rx = (float).75; agent->ry = (float).75;
+        max_extra_enemies = 16;
+    } else {
+        fatal("fassert(false) dodgeball.cpp:310");
+    }
+    g->hard_min_dim = (float)(4 * agent->rx + 2 * thickness + .5);
+    g->min_dim = (float)(agent->rx * 8 + .5);
+    for (int it = 0; it < num_iterations; it++) {
+        if (db_nrooms == 0) break;
+        int idx = rng_randn(&g->rand_gen, db_nrooms);
+        DbRoom room = db_rooms[idx];
+        for (int k = idx; k < db_nrooms - 1; k++) db_rooms[k] = db_rooms[k + 1];
+        db_nrooms--;
+        db_split_room(g, room, thickness);
+    }
+    float border_r = 0;
+    float doorlen = 2 * exit_r;
+    int exit_wall_choice = rng_randn(&g->rand_gen, 4);
+    float mw = (float)g->main_width, mh = (float)g->main_height;
+    if (exit_wall_choice == 0) spawn_entity_rxy(g, doorlen / 2, exit_r, DB_DOOR, 2 * border_r, 2 * border_r, mw - 4 * border_r, 2 * exit_r, 1);
+    else if (exit_wall_choice == 1) spawn_entity_rxy(g, doorlen / 2, exit_r, DB_DOOR, 2 * border_r, mh - 2 * border_r - 2 * exit_r, mw - 4 * border_r, 2 * exit_r, 1);
+    else if (exit_wall_choice == 2) spawn_entity_rxy(g, exit_r, doorlen / 2, DB_DOOR, 2 * border_r, 2 * border_r, 2 * exit_r, mh - 4 * border_r, 1);
+    else if (exit_wall_choice == 3) spawn_entity_rxy(g, exit_r, doorlen / 2, DB_DOOR, mw - 2 * border_r - 2 * exit_r, 2 * border_r, 2 * exit_r, mh - 4 * border_r, 1);
+    reposition_agent(g);
+    g->num_enemies = rng_randn(&g->rand_gen, max_extra_enemies + 1) + 3;
+    spawn_entities(g, g->num_enemies, enemy_r, DB_ENEMY, 0, 0, mw, mh);
+    int enemy_theme = rng_randn(&g->rand_gen, 7);
+    for (int k = 0; k < g->n_ents; k++) {
+        Ent *ent = &g->pool[g->ents[k]];
+        if (ent->type == DB_ENEMY) {
+            ent->image_theme = enemy_theme;
+            ent->health = 1;
+            ent->spawn_time = 0;
+            ent->fire_time = 10;
+            ent->collides_with_entities = 1;
+            ent->smart_step = 1;
+            db_choose_vel(g, ent);
+            face_direction(ent, ent->vx, ent->vy, 0);
+        } else if (ent->type == DB_LAVA_WALL) {
+            ent->collides_with_entities = 1;
+        }
+    }
+    face_direction(&g->pool[g->agent], 1, 0, 0);
+}
+static void db_fire_ball(Game *g, Ent *ent, float vx, float vy) { /* dodgeball.cpp:373-378 */
+    Ent *nb = push_entity(g, ent->x, ent->y, vx * g->ball_vscale, vy * g->ball_vscale, g->ball_r, g->ball_r, DB_ENEMY_BALL);
+    ent->fire_time = g->cur_time + rng_randn(&g->rand_gen, 4);
+    nb->vrot = DB_BALL_V_ROT;
+    nb->expire_time = 50;
+}
+static void db_game_step_tail(Game *g) { /* dodgeball.cpp:380-448 */
+    Ent *agent = &g->pool[g->agent];
+    float vx = (float)(g->last_move_action / 3 - 1);
+    float vy = (float)(g->last_move_action % 3 - 1);
+    face_direction(agent, vx, vy, 0);
+    if (g->special_action == 1 && (g->cur_time - g->last_fire_time) >= 7) {
+        Ent *nb = push_entity(g, agent->x, agent->y, vx * g->ball_vscale, vy * g->ball_vscale, g->ball_r, g->ball_r, DB_PLAYER_BALL);
+        nb->collides_with_entities = 1;
+        nb->expire_time = 50;
+        nb->vrot = DB_BALL_V_ROT;
+        g->last_fire_time = g->cur_time;
+    }
+    g->num_enemies = 0;
+    for (int i = g->n_ents - 1; i >= 0; i--) {
+        Ent *ent = &g->pool[g->ents[i]];
+        if (ent->type == DB_ENEMY) {
+            g->num_enemies++;
+            if (ent->spawn_time == 0) db_choose_vel(g, ent);
+            else ent->spawn_time -= 1;
+            int can_fire = (g->cur_time - ent->fire_time) >= g->enemy_fire_delay;
+            if (can_fire) {
+                float dx = ent->x - agent->x;
+                float dy = ent->y - agent->y;
+                float bvelx = (float)(ent->x < agent->x ? 1 : -1);
+                float bvely = (float)(ent->y < agent->y ? 1 : -1);
+                if (fabs((double)dx) < 1) {
+                    db_fire_ball(g, ent, 0, bvely);
+                    ent->vx = 0;
+                    ent->vy = bvely * DB_ENEMY_VEL;
+                } else if (fabs((double)dy) < 1) {
+                    db_fire_ball(g, ent, bvelx, 0);
+                    ent->vx = bvelx * DB_ENEMY_VEL;
+                    ent->vy = 0;
+                }
+            }
+            face_direction(ent, ent->vx, ent->vy, 0);
+        } else if (ent->type == DB_PLAYER_BALL || ent->type == DB_ENEMY_BALL) {
+            if (ent->x < ent->rx || ent->x > (g->main_width - ent->rx)) ent->will_erase = 1;
+            else if (ent->y < ent->ry || ent->y > (g->main_height - ent->ry)) ent->will_erase = 1;
+        }
+    }
+    erase_if_needed(g);
 }
 
 /* ---- Ninja: ninja.cpp:179-316 ---- */
@@ -2574,6 +2839,10 @@ static void bag_game_reset(Game *g) { /* BAG:758-797 */
         else if (dm == 1) g->main_width = g->main_height = 20;
         else if (dm == 10) g->main_width = g->main_height = 35;
     }
+    if (g->game_id == GAME_DODGEBALL) { /* choose_world_dim dodgeball.cpp:250-259 */
+        int wd = g->opt.distribution_mode == 10 ? 40 : 20;
+        g->main_width = g->main_height = wd;
+    }
     if (g->game_id == GAME_HEIST) { /* choose_world_dim heist.cpp:95-110 */
         int dm = g->opt.distribution_mode;
         if (dm == 0) g->world_dim = 9;
@@ -2668,6 +2937,8 @@ static void game_reset(Game *g) {
         hs_game_reset(g);
     } else if (g->game_id == GAME_NINJA) {
         nj_game_reset(g);
+    } else if (g->game_id == GAME_DODGEBALL) {
+        db_game_reset(g);
     } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:327-339 */
         g->center_agent = 0;
         sp_init_hps(g);
@@ -3088,6 +3359,7 @@ static int hook_image_for_type(const Game *g, int type) {
         if (type == MN_MOVING_BOULDER) return MN_BOULDER;
         if (type == MN_MOVING_DIAMOND) return MN_DIAMOND;
     }
+    if (g->game_id == GAME_DODGEBALL && type == DB_DOOR) return g->num_enemies == 0 ? DB_DOOR_OPEN : DB_DOOR; /* dodgeball.cpp:90-96 */
     if (g->game_id == GAME_NINJA && type == PLAYER) { /* ninja.cpp:158-168 */
         const Ent *agent = &g->pool[g->agent];
         if (fabs((double)agent->vx) < .01 && g->action_vx == 0 && g->has_support) return PLAYER;
@@ -3169,6 +3441,7 @@ static void draw_entities(Game *g, uint32_t *dst, int render_z) { /* BAG:1052-10
         }
         float tile_ratio = 0; /* get_tile_aspect_ratio BAG:409-411 */
         if (g->game_id == GAME_LEAPER && m->type == LP_FINISH_LINE) tile_ratio = 1; /* leaper.cpp:69-75 */
+        if (g->game_id == GAME_DODGEBALL && m->type == DB_LAVA_WALL) tile_ratio = (float)(m->rx > m->ry ? 1 : -1); /* dodgeball.cpp:241-248 */
         if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:87-94 */
             if (m->type == FB_BARRIER) tile_ratio = 1;
             else if (m->type == FB_LOCKED_DOOR) tile_ratio = FB_DOOR_ASPECT_RATIO;
@@ -3337,6 +3610,10 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->main_width = 64;
         g->main_height = 64;
         g->out_of_bounds_object = CR_WALL_MID;
+    } else if (game_id == GAME_DODGEBALL) { /* dodgeball.cpp:38-45 */
+        g->mixrate = (float).5;
+        g->enemy_fire_delay = 50;
+        g->out_of_bounds_object = DB_OOB_WALL;
     } else if (game_id == GAME_NINJA) { /* ninja.cpp:34-40 */
         g->main_width = 64;
         g->main_height = 64;

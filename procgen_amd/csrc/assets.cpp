@@ -111,6 +111,22 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(9, {"misc_assets/dirt.png"});
         add_themes(10, {"misc_assets/tile_bricksGrey.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_DODGEBALL) {  // reference src/games/dodgeball.cpp:49-88
+        auto series = [](const std::string &stem, int n) {
+            std::vector<std::string> v;
+            for (int i = 1; i <= n; i++) v.push_back("misc_assets/" + stem + std::to_string(i) + ".png");
+            return v;
+        };
+        add_themes(0, {"misc_assets/character12.png"});
+        add_themes(3, {"misc_assets/ball_soccer1.png"});
+        add_themes(4, series("character", 11));
+        add_themes(5, {"misc_assets/blockRed.png"});
+        add_themes(6, {"misc_assets/ball_soccer2.png"});
+        add_themes(7, {"misc_assets/blockGreen.png"});
+        add_themes(1, {"misc_assets/tileStone_slope2.png"});
+        add_themes(10, {"misc_assets/tileStone_slope2.png"});
+        add_themes(8, series("spaceEffect", 9));
+        topdown_backgrounds(backgrounds);
     } else if (game_id == GAME_NINJA) {  // reference src/games/ninja.cpp:45-75
         add_themes(20, {"misc_assets/tile_bricksGrey.png", "misc_assets/tile_bricksGrown.png", "misc_assets/tile_bricksRed.png"});
         add_themes(1, {"platformer/shroom1.png", "platformer/shroom2.png", "platformer/shroom3.png", "platformer/shroom4.png", "platformer/shroom5.png", "platformer/shroom6.png"});
@@ -225,7 +241,7 @@ static bool gather_images(int game_id, const std::string &resource_root, const A
         return true;
     };
     for (auto &s : *sprites)
-        if (!fetch(s.path, IMG_ARGB32_PM)) return false;
+        if (s.theme < MAX_IMAGE_THEMES && !fetch(s.path, IMG_ARGB32_PM)) return false;
     for (auto &b : *bgs)
         if (!fetch(b, IMG_RGB32)) return false;
     return true;
@@ -276,8 +292,16 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
         return idx;
     };
     for (auto &s : sprites) {
+        if (s.type < 0 || s.type >= MAX_ASSETS) {
+            if (err) *err = "asset table overflow";
+            return false;
+        }
+        if (s.theme >= MAX_IMAGE_THEMES) {  // counted in asset_num_themes (BAG:114-116) but never drawable (fassert BAG:888)
+            if (t.type_num_themes[s.type] < s.theme + 1) t.type_num_themes[s.type] = (uint8_t)(s.theme + 1);
+            continue;
+        }
         const int idx = place(s.path);
-        if (idx < 0 || s.type < 0 || s.type >= MAX_ASSETS || s.theme >= MAX_IMAGE_THEMES) {
+        if (idx < 0) {
             if (err) *err = "asset table overflow";
             return false;
         }
@@ -291,12 +315,14 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
     if (game_id == GAME_FRUITBOT) ref_type = 2;
     if (game_id == GAME_LEAPER) ref_type = 2;
     if (game_id == GAME_NINJA) ref_type = 20;
+    if (game_id == GAME_DODGEBALL) ref_type = 10;
     if (ref_type >= 0 && t.type_theme_img[ref_type][0] >= 0) {
         t.ref_w = t.img[t.type_theme_img[ref_type][0]].w;
         t.ref_h = t.img[t.type_theme_img[ref_type][0]].h;
     } else {   // most common sprite size
         std::map<std::pair<int, int>, int> hist;
         for (auto &sp : sprites) {
+            if (sp.theme >= MAX_IMAGE_THEMES) continue;
             const Image &im = imgs.images.at(sp.path);
             hist[{im.w, im.h}]++;
         }

@@ -3,6 +3,7 @@
 #include "game_bigfish.h"
 #include "game_climber.h"
 #include "game_coinrun.h"
+#include "game_dodgeball.h"
 #include "game_fruitbot.h"
 #include "game_heist.h"
 #include "game_leaper.h"
@@ -12,4 +13,4 @@
 #include "game_plunder.h"
 #include "game_starpilot.h"
 
-#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist) X(Ninja)
+#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist) X(Ninja) X(Dodgeball)

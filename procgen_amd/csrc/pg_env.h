@@ -682,9 +682,31 @@ struct Env {
             if (has_agent_collision(i)) Game::handle_agent_collision(*this, i);
             if (eflag(i, MF_COLLIDES)) {
                 if constexpr (Game::USES_ENTITY_COLLISIONS) {
-                    for (int j = G.n_ents - 1; j >= 0; j--) {
-                        if (i == j) continue;
-                        if (has_collision_idx(i, j, ef(EF_COLLISION_MARGIN, i)) && !eflag(i, MF_WILL_ERASE) && !eflag(j, MF_WILL_ERASE)) Game::handle_collision(*this, i, j);
+                    // reverse j loop of BAG:727-735: overlaps found by ballot (handlers do not move entities), visited
+                    // from the highest index down; will_erase is re-read at visit time (handlers set it); entities a
+                    // handler appends are not part of this loop (its bound is the size at entry)
+                    const int nj = G.n_ents;
+                    const float cm = ef(EF_COLLISION_MARGIN, i);
+                    const float ix = ex(i), iy = ey(i), irx = erx(i), iry = ery(i);
+                    for (int cj = (nj - 1) >> 6; cj >= 0; cj--) {
+                        uint64_t hits = PG_BALLOT(l, ({
+                                                      const int j = (cj << 6) + l;
+                                                      bool h = false;
+                                                      if (j < nj && j != i) {
+                                                          const float tx = (irx + erx(j)) + cm;
+                                                          const float ty = (iry + ery(j)) + cm;
+                                                          h = (pg_fabsf(ix - ex(j)) < tx) && (pg_fabsf(iy - ey(j)) < ty);
+                                                      }
+                                                      h;
+                                                  }));
+                        while (hits) {
+                            const int j = (cj << 6) + pg_highest(hits);
+                            hits &= ~(1ull << (j & 63));
+                            if (!eflag(i, MF_WILL_ERASE) && !eflag(j, MF_WILL_ERASE)) {
+                                Game::handle_collision(*this, i, j);
+                                PG_SYNC();
+                            }
+                        }
                     }
                 }
             }
@@ -882,6 +904,22 @@ struct Env {
             PG_SYNC();
             count++;
         }
+    }
+    PG_DEV bool agent_has_collision() {  // BAG:521-529
+        const int n = G.n_ents;
+        for (int c = 0; c < ((n + 63) >> 6); c++)
+            if (PG_BALLOT(l, ((c << 6) + l) < n && has_agent_collision((c << 6) + l))) return true;
+        return false;
+    }
+    PG_DEV void reposition_agent() {  // BAG:531-539
+        const int ag = G.agent;
+        int count = 0;
+        do {
+            ex(ag) = rand01() * (G.main_width - 2 * erx(ag)) + erx(ag);
+            ey(ag) = rand01() * (G.main_height - 2 * ery(ag)) + ery(ag);
+            PG_SYNC();
+            count++;
+        } while (agent_has_collision() && (count < 100));
     }
     // spawn_entity_rxy BAG:511-519: the entity is placed before it joins the list
     PG_DEV int spawn_entity_rxy(float rx, float ry, int type, float x, float y, float w, float h, bool check_collisions = true) {

@@ -114,7 +114,7 @@ bool read_rng(Reader &r, int *seeded, uint32_t *mt, int *idx) {
 
 bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h) {
     if (game_id == GAME_BIGFISH || game_id == GAME_STARPILOT || game_id == GAME_LEAPER || game_id == GAME_PLUNDER) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64, starpilot.cpp:330
-    if (game_id == GAME_MAZE || game_id == GAME_MINER || game_id == GAME_HEIST)  // maze.cpp:66, miner.cpp:140, heist.cpp:119
+    if (game_id == GAME_MAZE || game_id == GAME_MINER || game_id == GAME_HEIST || game_id == GAME_DODGEBALL)  // maze.cpp:66, miner.cpp:140, heist.cpp:119
         return h.initial_reset_complete ? opt.distribution_mode == MemoryMode : opt.center_agent != 0;
     return opt.center_agent != 0;
 }
@@ -247,6 +247,14 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
         w.i(h.gsi1);
     } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:309-312
         w.i(h.gsi0);
+    } else if (game_id == GAME_DODGEBALL) {  // reference src/games/dodgeball.cpp:450-459
+        w.f(h.gsf0);
+        w.f(h.gsf1);
+        w.f(h.gsf2);
+        w.f(h.gsf3);
+        w.i(h.gsi0);
+        w.i(h.gsi1);
+        w.i(h.gsi2);
     } else if (game_id == GAME_NINJA) {  // reference src/games/ninja.cpp:385-395
         w.i(h.gsi0 ? 1 : 0);
         w.i(h.gsi1 ? 1 : 0);
@@ -458,6 +466,14 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         h.gsi1 = r.i();
     } else if (game_id == GAME_MINER) {
         h.gsi0 = r.i();
+    } else if (game_id == GAME_DODGEBALL) {
+        h.gsf0 = r.f();
+        h.gsf1 = r.f();
+        h.gsf2 = r.f();
+        h.gsf3 = r.f();
+        h.gsi0 = r.i();
+        h.gsi1 = r.i();
+        h.gsi2 = r.i();
     } else if (game_id == GAME_NINJA) {
         h.gsi0 = r.i() > 0;
         h.gsi1 = r.i() > 0;
