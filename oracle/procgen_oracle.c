@@ -8,7 +8,7 @@
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
  * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner,
- * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors), ninja, dodgeball.
+ * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors), ninja, dodgeball, bossfight.
  */
 #include "procgen_oracle.h"
 
@@ -38,7 +38,20 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_DODGEBALL = 6, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_NINJA = 13, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+enum { GAME_BIGFISH = 0, GAME_BOSSFIGHT = 1, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_DODGEBALL = 6, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_NINJA = 13, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+
+/* bossfight.cpp:8-31 */
+#define BF2_PLAYER_BULLET 1
+#define BF2_BOSS 2
+#define BF2_SHIELDS 3
+#define BF2_ENEMY_BULLET 4
+#define BF2_LASER_TRAIL 5
+#define BF2_REFLECTED_BULLET 6
+#define BF2_BARRIER 7
+#define BF2_BOSS_R 3.0f
+#define BF2_BOTTOM_MARGIN 6
+#define BF2_BOSS_VEL_TIMEOUT 20
+#define BF2_BOSS_DAMAGED_TIMEOUT 40
 
 /* dodgeball.cpp:8-25 */
 #define DB_LAVA_WALL 1
@@ -460,6 +473,33 @@ static void assets_build(int game_id) {
         assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_BOSSFIGHT) { /* bossfight.cpp:77-107 */
+        assets_type(a, PLAYER, "misc_assets/playerShip1_blue.png");
+        assets_type(a, PLAYER, "misc_assets/playerShip1_green.png");
+        assets_type(a, PLAYER, "misc_assets/playerShip2_orange.png");
+        assets_type(a, PLAYER, "misc_assets/playerShip3_red.png");
+        assets_type(a, BF2_BOSS, "misc_assets/enemyShipBlack1.png");
+        assets_type(a, BF2_BOSS, "misc_assets/enemyShipBlue2.png");
+        assets_type(a, BF2_BOSS, "misc_assets/enemyShipGreen3.png");
+        assets_type(a, BF2_BOSS, "misc_assets/enemyShipRed4.png");
+        for (int t = 0; t < 2; t++) {
+            int ty = t == 0 ? BF2_ENEMY_BULLET : BF2_PLAYER_BULLET;
+            assets_type(a, ty, "misc_assets/laserGreen14.png");
+            assets_type(a, ty, "misc_assets/laserRed11.png");
+            assets_type(a, ty, "misc_assets/laserBlue09.png");
+        }
+        assets_type(a, BF2_SHIELDS, "misc_assets/shield2.png");
+        for (int i = 1; i <= 4; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/spaceMeteors_00%d.png", i);
+            assets_type(a, BF2_BARRIER, buf);
+        }
+        for (int i = 1; i <= 4; i++) {
+            snprintf(buf, sizeof buf, "misc_assets/meteorGrey_big%d.png", i);
+            assets_type(a, BF2_BARRIER, buf);
+        }
+        int n_platform = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0])) - 13; /* space_backgrounds */
+        a->n_bg = 13;
+        for (int i = 0; i < 13; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[n_platform + i], 1);
     } else if (game_id == GAME_DODGEBALL) { /* dodgeball.cpp:49-88 */
         assets_type(a, PLAYER, "misc_assets/character12.png");
         assets_type(a, DB_PLAYER_BALL, "misc_assets/ball_soccer1.png");
@@ -608,6 +648,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "heist") == 0) return GAME_HEIST;
     if (strcmp(name, "ninja") == 0) return GAME_NINJA;
     if (strcmp(name, "dodgeball") == 0) return GAME_DODGEBALL;
+    if (strcmp(name, "bossfight") == 0) return GAME_BOSSFIGHT;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -682,6 +723,13 @@ typedef struct {
     int diamonds_remaining;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
+    /* BossfightGame: bossfight.cpp:35-61 (last_fire_time shared) */
+    int boss, shields; /* pool ids */
+    int attack_modes[8], n_attack_modes;
+    int time_to_swap, invulnerable_duration, vulnerable_duration, num_rounds, round_num, round_health;
+    int boss_vel_timeout, curr_vel_timeout, attack_mode, player_laser_theme, boss_laser_theme, damaged_until_time;
+    int shields_are_up, barriers_moves_right;
+    float base_fire_prob, boss_bullet_vel, barrier_vel, barrier_spawn_prob, rand_pct, rand_fire_pct, rand_pct_x, rand_pct_y;
     /* DodgeballGame: dodgeball.cpp:29-36 (min_dim, last_fire_time shared with FruitBot) */
     float hard_min_dim, ball_vscale, ball_r;
     int num_enemies, enemy_fire_delay;
@@ -855,6 +903,10 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
             g->coins_collected += 1;
             obj->will_erase = 1;
         }
+    } else if (g->game_id == GAME_BOSSFIGHT) { /* bossfight.cpp:109-120 */
+        if (obj->type == BF2_BOSS) g->done = 1;
+        else if (obj->type == BF2_BARRIER) g->done = 1;
+        if (obj->type == BF2_ENEMY_BULLET) g->done = 1;
     } else if (g->game_id == GAME_DODGEBALL) { /* dodgeball.cpp:102-118 */
         if (obj->type == DB_ENEMY) {
             g->done = 1;
@@ -962,7 +1014,74 @@ static void hook_handle_grid_collision(Game *g, Ent *obj, int type, int i, int j
         }
     }
 }
+static void bf2_prepare_boss(Game *g) { /* bossfight.cpp:194-201 */
+    g->shields_are_up = 1;
+    g->curr_vel_timeout = g->boss_vel_timeout;
+    g->time_to_swap = g->invulnerable_duration;
+    g->attack_mode = g->attack_modes[g->round_num % g->n_attack_modes];
+    g->pool[g->boss].vx = 0;
+    g->pool[g->boss].vy = 0;
+}
 static void hook_handle_collision(Game *g, Ent *src, Ent *target) { /* BAG:398 */
+    if (g->game_id == GAME_BOSSFIGHT) { /* bossfight.cpp:129-192 */
+        if (src->type == BF2_PLAYER_BULLET) {
+            int will_erase = 0;
+            if (target->type == BF2_SHIELDS) {
+                if (g->shields_are_up) {
+                    src->type = BF2_REFLECTED_BULLET;
+                    float theta = (float)(PI_F * (1.25 + .5 * g->rand_pct));
+                    src->vy = (float)(1 * sin((double)theta) * .5);
+                    src->vx = (float)(1 * cos((double)theta) * .5);
+                    src->expire_time = 4;
+                    src->life_time = 0;
+                    src->alpha_decay = 0.8f;
+                }
+            } else if (target->type == BF2_BOSS) {
+                if (!g->shields_are_up) {
+                    target->health -= 1;
+                    will_erase = 1;
+                    if ((int)target->health % g->round_health == 0) {
+                        g->reward += 1.0f;
+                        if (target->health == 0) {
+                            g->done = 1;
+                            g->reward += 10.0f;
+                            g->level_complete = 1;
+                        } else {
+                            g->round_num++;
+                            bf2_prepare_boss(g);
+                            g->curr_vel_timeout = BF2_BOSS_DAMAGED_TIMEOUT;
+                            g->damaged_until_time = g->cur_time + BF2_BOSS_DAMAGED_TIMEOUT;
+                        }
+                    }
+                }
+            }
+            if (will_erase && !src->will_erase) {
+                src->will_erase = 1;
+                float r = (float)(.5 * src->rx);
+                float tvx = target->vx, tvy = target->vy;
+                Ent *ex = push_entity(g, src->x, src->y, 0, 0, r, r, EXPLOSION);
+                ex->vx = tvx;
+                ex->vy = tvy;
+            }
+        } else if (src->type == BF2_BARRIER) {
+            if (target->type == BF2_ENEMY_BULLET || target->type == BF2_PLAYER_BULLET) {
+                target->will_erase = 1;
+                float r = (float)(.5 * target->rx);
+                push_entity(g, target->x, target->y, 0, 0, r, r, EXPLOSION);
+            } else if (target->type == BF2_LASER_TRAIL) {
+                target->will_erase = 1;
+            }
+            if (src->health <= 0) {
+                if (!src->will_erase) {
+                    float r = (float)(.5 * src->rx);
+                    Ent *ex = push_entity(g, src->x, src->y, 0, 0, r, r, EXPLOSION);
+                    ex->vx = src->vx;
+                    ex->vy = src->vy;
+                }
+                src->will_erase = 1;
+            }
+        }
+    }
     if (g->game_id == GAME_DODGEBALL) { /* dodgeball.cpp:120-151 */
         if (target->type == DB_PLAYER_BALL) {
             if (src->type == DB_LAVA_WALL) {
@@ -1365,6 +1484,7 @@ static void match_aspect_ratio(Game *g, Ent *ent);
 static void mn_game_step_tail(Game *g);
 static void sp_game_step_tail(Game *g);
 static void db_game_step_tail(Game *g);
+static void bf2_game_step_tail(Game *g);
 static void face_direction(Ent *e, float dx, float dy, float rotation_offset);
 static int has_any_collision(const Game *g, const Ent *e1, float margin);
 static void lp_spawn_entities(Game *g);
@@ -1422,6 +1542,8 @@ static void game_step(Game *g) {
         sp_game_step_tail(g);
     } else if (g->game_id == GAME_DODGEBALL) {
         db_game_step_tail(g);
+    } else if (g->game_id == GAME_BOSSFIGHT) {
+        bf2_game_step_tail(g);
     } else if (g->game_id == GAME_NINJA) { /* ninja.cpp:349-383 */
         Ent *agent = &g->pool[g->agent];
         if (g->action_vx > 0) agent->is_reflected = 0;
@@ -1839,6 +1961,152 @@ static void fit_aspect_ratio(Game *g, Ent *ent) { /* BAG:1025-1036 */
     float ar = (float)(im->w * 1.0 / im->h);
     if (ar > 1) ent->ry = ent->rx / ar;
     else ent->rx = ent->ry * ar;
+}
+
+/* ---- Bossfight: bossfight.cpp:203-414 ---- */
+static void reposition_agent(Game *g);
+static void bf2_spawn_barriers(Game *g) { /* bossfight.cpp:318-336 */
+    int num_barriers = rng_randn(&g->rand_gen, 3) + 1;
+    for (int i = 0; i < num_barriers; i++) {
+        const Ent *agent = &g->pool[g->agent];
+        float barrier_r = 0.6f;
+        float min_barrier_y = (float)(2 * agent->ry + barrier_r + .5);
+        float ent_y = rng_rand01(&g->rand_gen) * (BF2_BOTTOM_MARGIN - min_barrier_y - barrier_r) + min_barrier_y;
+        float ent_x = rng_rand01(&g->rand_gen) * (g->main_width - 2 * barrier_r) + barrier_r;
+        Ent m;
+        ent_init(&m, ent_x, ent_y, 0, 0, barrier_r, barrier_r, BF2_BARRIER);
+        choose_random_theme(g, &m);
+        match_aspect_ratio(g, &m);
+        m.health = 3;
+        m.collides_with_entities = 1;
+        if (!has_any_collision(g, &m, 0)) {
+            int id = pool_alloc(g);
+            g->pool[id] = m;
+            g->ents[g->n_ents++] = id;
+        }
+    }
+}
+static void bf2_game_reset(Game *g) { /* bossfight.cpp:203-262 */
+    g->damaged_until_time = 0;
+    g->last_fire_time = 0;
+    g->boss_bullet_vel = g->opt.distribution_mode == 0 ? (float).5 : (float).75;
+    int max_extra_invulnerable = g->opt.distribution_mode == 0 ? 1 : 3;
+    g->center_agent = 0;
+    Ent *boss = push_entity(g, (float)(g->main_width / 2), (float)(g->main_height / 2), 0, 0, BF2_BOSS_R, BF2_BOSS_R, BF2_BOSS);
+    g->boss = g->ents[g->n_ents - 1];
+    choose_random_theme(g, boss);
+    match_aspect_ratio(g, boss);
+    push_entity(g, boss->x, boss->y, 0, 0, (float)(1.2 * boss->rx), (float)(1.2 * boss->ry), BF2_SHIELDS);
+    g->shields = g->ents[g->n_ents - 1];
+    g->boss_vel_timeout = BF2_BOSS_VEL_TIMEOUT;
+    g->base_fire_prob = 0.1f;
+    g->round_health = rng_randn(&g->rand_gen, 9) + 1;
+    g->num_rounds = 1 + rng_randn(&g->rand_gen, 5);
+    g->invulnerable_duration = 2 + rng_randn(&g->rand_gen, max_extra_invulnerable + 1);
+    g->vulnerable_duration = 500;
+    boss->health = (float)(g->round_health * g->num_rounds);
+    choose_random_theme(g, &g->pool[g->agent]);
+    g->player_laser_theme = rng_randn(&g->rand_gen, 3);
+    g->boss_laser_theme = rng_randn(&g->rand_gen, 3);
+    g->n_attack_modes = 0;
+    for (int i = 0; i < g->num_rounds; i++) g->attack_modes[g->n_attack_modes++] = rng_randn(&g->rand_gen, 4);
+    g->round_num = 0;
+    bf2_prepare_boss(g);
+    Ent *agent = &g->pool[g->agent];
+    agent->rx = (float).75;
+    match_aspect_ratio(g, agent);
+    reposition_agent(g);
+    agent->y = agent->ry;
+    g->barrier_vel = 0.1f;
+    g->barriers_moves_right = rng_rand01(&g->rand_gen) > .5; /* randbool randgen.cpp:25-27 */
+    g->barrier_spawn_prob = 0.025f;
+    bf2_spawn_barriers(g);
+}
+static void bf2_boss_fire(Game *g, float bullet_r, float vel, float theta) { /* bossfight.cpp:264-269 */
+    const Ent *boss = &g->pool[g->boss];
+    Ent *nb = push_entity(g, boss->x, boss->y, (float)(vel * cos((double)theta)), (float)(vel * sin((double)theta)), bullet_r, bullet_r, BF2_ENEMY_BULLET);
+    nb->image_theme = g->boss_laser_theme;
+    nb->expire_time = 50;
+    nb->vrot = PI_F / 8;
+}
+static void bf2_game_step_tail(Game *g) { /* bossfight.cpp:338-414 */
+    Ent *boss = &g->pool[g->boss], *shields = &g->pool[g->shields], *agent = &g->pool[g->agent];
+    shields->x = boss->x;
+    shields->y = boss->y;
+    g->rand_pct = rng_rand01(&g->rand_gen);
+    g->rand_fire_pct = rng_rand01(&g->rand_gen);
+    g->rand_pct_x = rng_rand01(&g->rand_gen);
+    g->rand_pct_y = rng_rand01(&g->rand_gen);
+    if (g->curr_vel_timeout <= 0) {
+        float dest_x = g->rand_pct_x * (g->main_width - 2 * BF2_BOSS_R) + BF2_BOSS_R;
+        float dest_y = g->rand_pct_y * (g->main_height - 2 * BF2_BOSS_R - BF2_BOTTOM_MARGIN) + BF2_BOSS_R + BF2_BOTTOM_MARGIN;
+        boss->vx = (dest_x - boss->x) / g->boss_vel_timeout;
+        boss->vy = (dest_y - boss->y) / g->boss_vel_timeout;
+        g->curr_vel_timeout = g->boss_vel_timeout;
+        if (g->time_to_swap > 0) {
+            g->time_to_swap -= 1;
+        } else {
+            if (g->shields_are_up) g->time_to_swap = g->vulnerable_duration;
+            else g->time_to_swap = g->invulnerable_duration;
+            g->shields_are_up = !g->shields_are_up;
+        }
+    } else {
+        g->curr_vel_timeout -= 1;
+    }
+    if (g->special_action == 1 && (g->cur_time - g->last_fire_time) >= 3) {
+        Ent *nb = push_entity(g, agent->x, agent->y, 0, 1, (float).25, (float).25, BF2_PLAYER_BULLET);
+        nb->image_theme = g->player_laser_theme;
+        nb->collides_with_entities = 1;
+        nb->expire_time = 25;
+        g->last_fire_time = g->cur_time;
+    }
+    int ct = g->cur_time;
+    float bv = g->boss_bullet_vel;
+    if (g->damaged_until_time >= ct) { /* damaged_mode :309-315 */
+        if (ct % 3 == 0) {
+            float pos_x = boss->x + (2 * g->rand_pct_x - 1) * boss->rx;
+            float pos_y = boss->y + (2 * g->rand_pct_y - 1) * boss->ry;
+            push_entity(g, pos_x, pos_y, 0, 0, (float).75, (float).75, EXPLOSION);
+        }
+    } else if (g->shields_are_up) { /* active_attack :317-327 */
+        if (g->attack_mode == 0) {
+            if (ct % 8 == 0)
+                for (int i = 0; i < 5; i++) bf2_boss_fire(g, (float).5, bv, (float)(PI_F * 1.5 + (i - 2) * PI_F / 8));
+        } else if (g->attack_mode == 1) {
+            int dt = 5;
+            if (ct % dt == 0) {
+                int k = ct / dt;
+                k = abs(8 - (k % 16));
+                for (int i = 0; i < 4; i++) bf2_boss_fire(g, (float).5, bv, (float)(PI_F * (1.25 + .5 * k / 8.0) + i * PI_F / 2));
+            }
+        } else if (g->attack_mode == 2) {
+            if (ct % 10 == 0) {
+                int num_bullets = 8;
+                float offset = g->rand_pct * 2 * PI_F;
+                for (int i = 0; i < num_bullets; i++) {
+                    float theta = 2 * PI_F / num_bullets * i + offset;
+                    bf2_boss_fire(g, (float).5, bv, theta);
+                }
+            }
+        } else if (g->attack_mode == 3) {
+            if (ct % 4 == 0) bf2_boss_fire(g, (float).5, bv, PI_F * (1 + g->rand_pct));
+        }
+    } else { /* passive_attack_mode :271-275 */
+        if (g->rand_fire_pct < g->base_fire_prob) bf2_boss_fire(g, (float).5, bv, PI_F * (1 + g->rand_pct));
+    }
+    for (int i = g->n_ents - 1; i >= 0; i--) {
+        Ent *ent = &g->pool[g->ents[i]];
+        if (ent->type == BF2_ENEMY_BULLET) {
+            float v_trail = (float).5;
+            Ent *trail = push_entity(g, ent->x, ent->y, ent->vx * v_trail, ent->vy * v_trail, ent->rx, ent->ry, BF2_LASER_TRAIL);
+            trail->alpha_decay = 0.7f;
+            trail->image_type = BF2_ENEMY_BULLET;
+            trail->image_theme = g->boss_laser_theme;
+            trail->vrot = ent->vrot;
+            trail->rotation = ent->rotation;
+            trail->expire_time = 8;
+        }
+    }
 }
 
 /* ---- Dodgeball: dodgeball.cpp:157-448 ---- */
@@ -2939,6 +3207,8 @@ static void game_reset(Game *g) {
         nj_game_reset(g);
     } else if (g->game_id == GAME_DODGEBALL) {
         db_game_reset(g);
+    } else if (g->game_id == GAME_BOSSFIGHT) {
+        bf2_game_reset(g);
     } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:327-339 */
         g->center_agent = 0;
         sp_init_hps(g);
@@ -3428,6 +3698,7 @@ static void draw_entities(Game *g, uint32_t *dst, int render_z) { /* BAG:1052-10
     for (int i = 0; i < g->n_ents; i++) {
         const Ent *m = &g->pool[g->ents[i]];
         if (m->render_z != render_z) continue;
+        if (g->game_id == GAME_BOSSFIGHT && m->type == BF2_SHIELDS && !g->shields_are_up) continue; /* bossfight.cpp:122-127 */
         if (g->game_id == GAME_HEIST && m->type == HS_KEY_ON_RING && !g->has_keys[m->image_theme]) continue; /* should_draw_entity heist.cpp:70-75, BAG:1055 */
         RectD r1; /* get_object_rect BAG:811-817 */
         if (m->use_abs_coords) {
@@ -3610,6 +3881,12 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->main_width = 64;
         g->main_height = 64;
         g->out_of_bounds_object = CR_WALL_MID;
+    } else if (game_id == GAME_BOSSFIGHT) { /* bossfight.cpp:63-71 */
+        g->timeout = 4000;
+        g->main_width = 20;
+        g->main_height = 20;
+        g->mixrate = (float).5;
+        g->maxspeed = 0.85f;
     } else if (game_id == GAME_DODGEBALL) { /* dodgeball.cpp:38-45 */
         g->mixrate = (float).5;
         g->enemy_fire_delay = 50;

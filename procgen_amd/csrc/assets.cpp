@@ -111,6 +111,15 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(9, {"misc_assets/dirt.png"});
         add_themes(10, {"misc_assets/tile_bricksGrey.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_BOSSFIGHT) {  // reference src/games/bossfight.cpp:73-107
+        add_themes(0, {"misc_assets/playerShip1_blue.png", "misc_assets/playerShip1_green.png", "misc_assets/playerShip2_orange.png", "misc_assets/playerShip3_red.png"});
+        add_themes(2, {"misc_assets/enemyShipBlack1.png", "misc_assets/enemyShipBlue2.png", "misc_assets/enemyShipGreen3.png", "misc_assets/enemyShipRed4.png"});
+        add_themes(4, {"misc_assets/laserGreen14.png", "misc_assets/laserRed11.png", "misc_assets/laserBlue09.png"});
+        add_themes(1, {"misc_assets/laserGreen14.png", "misc_assets/laserRed11.png", "misc_assets/laserBlue09.png"});
+        add_themes(3, {"misc_assets/shield2.png"});
+        add_themes(7, {"misc_assets/spaceMeteors_001.png", "misc_assets/spaceMeteors_002.png", "misc_assets/spaceMeteors_003.png", "misc_assets/spaceMeteors_004.png",
+                       "misc_assets/meteorGrey_big1.png", "misc_assets/meteorGrey_big2.png", "misc_assets/meteorGrey_big3.png", "misc_assets/meteorGrey_big4.png"});
+        for (const char *n : SPACE_BGS) backgrounds->push_back(std::string("space_backgrounds/") + n + ".png");
     } else if (game_id == GAME_DODGEBALL) {  // reference src/games/dodgeball.cpp:49-88
         auto series = [](const std::string &stem, int n) {
             std::vector<std::string> v;

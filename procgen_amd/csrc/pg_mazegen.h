@@ -150,14 +150,15 @@ struct MazeGenDev {
         const int x = idx % array_dim, y = idx / array_dim;
         if (x <= 0 || x >= array_dim - 1) return INVALID_OBJ;
         if (y <= 0 || y >= array_dim - 1) return INVALID_OBJ;
-        return PG_UNIFORM_I(m.mgrid[idx]);
+        return (int)m.mgrid[idx];
     }
-    // get_neighbors mazegen.cpp:48-66 for an interior cell: order (-1,0) (0,-1) (0,1) (1,0)
+    PG_DEV int get_obj_u(int idx) const { return PG_UNIFORM_I(get_obj(idx)); }  // wave-uniform idx only
+    // get_neighbors mazegen.cpp:48-66 for an interior cell (wave-uniform idx): order (-1,0) (0,-1) (0,1) (1,0)
     PG_DEV int get_neighbors(int idx, int type, int (&out)[4]) const {
         const int cand[4] = {idx - 1, idx - array_dim, idx + array_dim, idx + 1};
         int n = 0;
         for (int k = 0; k < 4; k++)
-            if (get_obj(cand[k]) == type) out[n++] = cand[k];
+            if (get_obj_u(cand[k]) == type) out[n++] = cand[k];
         return n;
     }
     PG_DEV int count_neighbors(int idx, int type) const {

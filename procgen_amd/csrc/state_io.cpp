@@ -113,7 +113,7 @@ bool read_rng(Reader &r, int *seeded, uint32_t *mt, int *idx) {
 }
 
 bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h) {
-    if (game_id == GAME_BIGFISH || game_id == GAME_STARPILOT || game_id == GAME_LEAPER || game_id == GAME_PLUNDER) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64, starpilot.cpp:330
+    if (game_id == GAME_BIGFISH || game_id == GAME_STARPILOT || game_id == GAME_LEAPER || game_id == GAME_PLUNDER || game_id == GAME_BOSSFIGHT) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64, starpilot.cpp:330
     if (game_id == GAME_MAZE || game_id == GAME_MINER || game_id == GAME_HEIST || game_id == GAME_DODGEBALL)  // maze.cpp:66, miner.cpp:140, heist.cpp:119
         return h.initial_reset_complete ? opt.distribution_mode == MemoryMode : opt.center_agent != 0;
     return opt.center_agent != 0;
@@ -247,6 +247,33 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
         w.i(h.gsi1);
     } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:309-312
         w.i(h.gsi0);
+    } else if (game_id == GAME_BOSSFIGHT) {  // reference src/games/bossfight.cpp:416-441
+        const int p = h.gsi5, nr = (p >> 10) & 7;
+        w.i(nr);
+        for (int k = 0; k < nr; k++) w.i((p >> (2 * k)) & 3);
+        w.i(h.gsi0);              // last_fire_time
+        w.i(h.gsi1);              // time_to_swap
+        w.i((p >> 17) & 7);       // invulnerable_duration
+        w.i(500);                 // vulnerable_duration
+        w.i(nr);                  // num_rounds
+        w.i(h.gsi4);              // round_num
+        w.i((p >> 13) & 15);      // round_health
+        w.i(20);                  // boss_vel_timeout
+        w.i(h.gsi2);              // curr_vel_timeout
+        w.i(h.gsi7);              // attack_mode
+        w.i((p >> 20) & 3);       // player_laser_theme
+        w.i((p >> 22) & 3);       // boss_laser_theme
+        w.i(h.gsi3);              // damaged_until_time
+        w.i(h.gsi6 ? 1 : 0);      // shields_are_up
+        w.i((p >> 24) & 1);       // barriers_moves_right
+        w.f(0.1f);                // base_fire_prob
+        w.f(opt.distribution_mode == EasyMode ? .5f : .75f);  // boss_bullet_vel
+        w.f(0.1f);                // barrier_vel
+        w.f(0.025f);              // barrier_spawn_prob
+        w.f(h.gsf0);
+        w.f(h.gsf1);
+        w.f(h.gsf2);
+        w.f(h.gsf3);
     } else if (game_id == GAME_DODGEBALL) {  // reference src/games/dodgeball.cpp:450-459
         w.f(h.gsf0);
         w.f(h.gsf1);
@@ -466,6 +493,32 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         h.gsi1 = r.i();
     } else if (game_id == GAME_MINER) {
         h.gsi0 = r.i();
+    } else if (game_id == GAME_BOSSFIGHT) {
+        const int nm = r.i();
+        if (!r.ok || nm < 0 || nm > 5) return bad("set_state: bossfight attack_modes");
+        uint32_t p = 0;
+        for (int k = 0; k < nm; k++) p |= ((uint32_t)r.i() & 3u) << (2 * k);
+        h.gsi0 = r.i();
+        h.gsi1 = r.i();
+        p |= ((uint32_t)r.i() & 7u) << 17;   // invulnerable_duration
+        r.i();                                // vulnerable_duration
+        p |= ((uint32_t)r.i() & 7u) << 10;   // num_rounds
+        h.gsi4 = r.i();
+        p |= ((uint32_t)r.i() & 15u) << 13;  // round_health
+        r.i();                                // boss_vel_timeout
+        h.gsi2 = r.i();
+        h.gsi7 = r.i();
+        p |= ((uint32_t)r.i() & 3u) << 20;
+        p |= ((uint32_t)r.i() & 3u) << 22;
+        h.gsi3 = r.i();
+        h.gsi6 = r.i() > 0;
+        p |= (r.i() > 0 ? 1u : 0u) << 24;
+        h.gsi5 = (int)p;
+        r.f(); r.f(); r.f(); r.f();
+        h.gsf0 = r.f();
+        h.gsf1 = r.f();
+        h.gsf2 = r.f();
+        h.gsf3 = r.f();
     } else if (game_id == GAME_DODGEBALL) {
         h.gsf0 = r.f();
         h.gsf1 = r.f();

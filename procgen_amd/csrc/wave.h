@@ -25,16 +25,39 @@
 #include <math.h>
 #include <string.h>
 #define PG_DEV inline
-#define PG_FOR_LANES(l) for (int l = 0; l < 64; ++l)
+// the lane a lane section is currently executing (-1: wave-uniform code); lets the emulation give
+// PG_UNIFORM_I its GPU meaning (the value of the first lane) so that a readfirstlane on a lane-varying value is
+// caught by the CPU tests instead of only on the device
+inline int &pg_emu_lane() {
+    static thread_local int lane = -1;
+    return lane;
+}
+struct PgEmuLaneScope {
+    int saved;
+    PgEmuLaneScope() : saved(pg_emu_lane()) {}
+    ~PgEmuLaneScope() { pg_emu_lane() = saved; }
+};
+#define PG_FOR_LANES(l) \
+    if (PgEmuLaneScope pg_scope_{}; true) \
+        for (int l = 0; l < 64 && ((pg_emu_lane() = l), true); ++l)
 #define PG_BALLOT(l, pred)                              \
     ({                                                  \
         uint64_t m_ = 0;                                \
-        for (int l = 0; l < 64; ++l)                    \
+        PgEmuLaneScope pg_bscope_{};                    \
+        for (int l = 0; l < 64; ++l) {                  \
+            pg_emu_lane() = l;                          \
             if (pred) m_ |= (1ull << l);                \
+        }                                               \
         m_;                                             \
     })
 #define PG_SYNC() ((void)0)
-#define PG_UNIFORM_I(x) (x)
+#define PG_UNIFORM_I(x)                                 \
+    ({                                                  \
+        static thread_local int pg_first_;              \
+        const int v_ = (int)(x);                        \
+        if (pg_emu_lane() <= 0) pg_first_ = v_;         \
+        pg_emu_lane() > 0 ? pg_first_ : v_;             \
+    })
 #define PG_LANE_VAR(T, v) T v[64]
 #define PG_LV(v, l) v[l]
 #define PG_READLANE(v, k) v[k]
