@@ -8,7 +8,7 @@
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
  * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner,
- * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors), ninja, dodgeball, bossfight.
+ * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors), ninja, dodgeball, bossfight, chaser (with MazeGen::generate_maze_no_dead_ends).
  */
 #include "procgen_oracle.h"
 
@@ -38,7 +38,21 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_BOSSFIGHT = 1, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_DODGEBALL = 6, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_NINJA = 13, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+enum { GAME_BIGFISH = 0, GAME_BOSSFIGHT = 1, GAME_CHASER = 3, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_DODGEBALL = 6, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_NINJA = 13, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+
+/* chaser.cpp:10-23 */
+#define CH_LARGE_ORB 2
+#define CH_ENEMY_WEAK 3
+#define CH_ENEMY_EGG 4
+#define CH_MAZE_WALL 5
+#define CH_ENEMY 6
+#define CH_ENEMY2 7
+#define CH_ENEMY3 8
+#define CH_MARKER 1001
+#define CH_ORB 1002
+#define CH_ORB_REWARD 0.04f
+#define CH_ORB_DIM 0.3f
+#define INVALID_IDX (-2)
 
 /* bossfight.cpp:8-31 */
 #define BF2_PLAYER_BULLET 1
@@ -473,6 +487,17 @@ static void assets_build(int game_id) {
         assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_CHASER) { /* chaser.cpp:51-73 */
+        assets_type(a, PLAYER, "misc_assets/enemyFloating_1b.png");
+        assets_type(a, CH_ENEMY, "misc_assets/enemyFlying_1.png");
+        assets_type(a, CH_ENEMY2, "misc_assets/enemyFlying_2.png");
+        assets_type(a, CH_ENEMY3, "misc_assets/enemyFlying_3.png");
+        assets_type(a, CH_LARGE_ORB, "misc_assets/yellowCrystal.png");
+        assets_type(a, CH_ENEMY_WEAK, "misc_assets/enemyWalking_1b.png");
+        assets_type(a, CH_ENEMY_EGG, "misc_assets/enemySpikey_1b.png");
+        assets_type(a, CH_MAZE_WALL, "misc_assets/tileStone_slope.png");
+        a->n_bg = 1; /* topdown_simple_backgrounds, reference src/resources.cpp:913-918 */
+        a->bg_img[0] = assets_add(a, "topdown_backgrounds/floortiles.png", 1);
     } else if (game_id == GAME_BOSSFIGHT) { /* bossfight.cpp:77-107 */
         assets_type(a, PLAYER, "misc_assets/playerShip1_blue.png");
         assets_type(a, PLAYER, "misc_assets/playerShip1_green.png");
@@ -649,6 +674,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "ninja") == 0) return GAME_NINJA;
     if (strcmp(name, "dodgeball") == 0) return GAME_DODGEBALL;
     if (strcmp(name, "bossfight") == 0) return GAME_BOSSFIGHT;
+    if (strcmp(name, "chaser") == 0) return GAME_CHASER;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -723,6 +749,8 @@ typedef struct {
     int diamonds_remaining;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
+    /* ChaserGame: chaser.cpp:27-36 (maze_dim shared with MazeGame; free_cells / is_space_vec follow from the grid) */
+    int eat_timeout, egg_timeout, eat_time, total_enemies, total_orbs, orbs_collected;
     /* BossfightGame: bossfight.cpp:35-61 (last_fire_time shared) */
     int boss, shields; /* pool ids */
     int attack_modes[8], n_attack_modes;
@@ -842,6 +870,7 @@ static int hook_is_blocked(const Game *g, const Ent *src, int target, int is_hor
     if (g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) { /* coinrun.cpp:204-211, climber.cpp:136-143 */
         if (src->type == PLAYER && cr_is_wall(target)) return 1;
     }
+    if (g->game_id == GAME_CHASER && target == CH_MAZE_WALL) return 1; /* chaser.cpp:90-95 */
     if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:84-86 */
         if (src->type == PLAYER && target == FB_OUT_OF_BOUNDS_WALL) return 1;
     }
@@ -902,6 +931,15 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
             g->reward += 1.0f;
             g->coins_collected += 1;
             obj->will_erase = 1;
+        }
+    } else if (g->game_id == GAME_CHASER) { /* chaser.cpp:121-135 */
+        if (obj->type == CH_LARGE_ORB) {
+            g->eat_time = g->cur_time;
+            g->reward += CH_ORB_REWARD;
+            obj->will_erase = 1;
+        } else if (obj->type == CH_ENEMY) {
+            if (g->cur_time - g->eat_time < g->eat_timeout) obj->will_erase = 1;
+            else g->done = 1;
         }
     } else if (g->game_id == GAME_BOSSFIGHT) { /* bossfight.cpp:109-120 */
         if (obj->type == BF2_BOSS) g->done = 1;
@@ -1388,6 +1426,11 @@ static void hook_update_agent_velocity(Game *g) {
             agent->vy -= g->gravity;
             agent->vy = clip_abs(agent->vy, g->max_jump);
         }
+    } else if (g->game_id == GAME_CHASER) { /* chaser.cpp:79-88 */
+        if (g->action_vx != 0) agent->vx = g->maxspeed * g->action_vx;
+        if (g->action_vy != 0) agent->vy = g->maxspeed * g->action_vy;
+        agent->vx = (float)(sign_d(agent->vx) * g->maxspeed);
+        agent->vy = (float)(sign_d(agent->vy) * g->maxspeed);
     } else if (g->game_id == GAME_NINJA) { /* ninja.cpp:109-124 */
         float mixrate_x = g->has_support ? g->mixrate : (g->mixrate * g->air_control);
         agent->vx = (1 - mixrate_x) * agent->vx + mixrate_x * g->maxspeed * g->action_vx;
@@ -1485,6 +1528,7 @@ static void mn_game_step_tail(Game *g);
 static void sp_game_step_tail(Game *g);
 static void db_game_step_tail(Game *g);
 static void bf2_game_step_tail(Game *g);
+static void ch_game_step_tail(Game *g);
 static void face_direction(Ent *e, float dx, float dy, float rotation_offset);
 static int has_any_collision(const Game *g, const Ent *e1, float margin);
 static void lp_spawn_entities(Game *g);
@@ -1544,6 +1588,8 @@ static void game_step(Game *g) {
         db_game_step_tail(g);
     } else if (g->game_id == GAME_BOSSFIGHT) {
         bf2_game_step_tail(g);
+    } else if (g->game_id == GAME_CHASER) {
+        ch_game_step_tail(g);
     } else if (g->game_id == GAME_NINJA) { /* ninja.cpp:349-383 */
         Ent *agent = &g->pool[g->agent];
         if (g->action_vx > 0) agent->is_reflected = 0;
@@ -1839,6 +1885,18 @@ static int mg_expand_to_type(const MazeGen *m, const unsigned char *s0, unsigned
     }
     return -1;
 }
+static void mg_generate_maze_no_dead_ends(MazeGen *m, Rng *r) { /* mazegen.cpp:189-209 */
+    mg_generate_maze(m, r);
+    int nc = m->array_dim * m->array_dim, adj[4], wl[4];
+    for (int i = 0; i < nc; i++) {
+        if (mg_get_obj(m, i) == SPACE) {
+            if (mg_get_neighbors(m, i, SPACE, adj) == 1) {
+                int nw = mg_get_neighbors(m, i, WALL_OBJ, wl);
+                if (nw > 0) m->grid[wl[rng_randn(r, nw)]] = SPACE;
+            }
+        }
+    }
+}
 static void mg_generate_maze_with_doors(MazeGen *m, Rng *r, int num_doors) { /* mazegen.cpp:211-290 */
     mg_generate_maze(m, r);
     int nc = m->array_dim * m->array_dim;
@@ -1961,6 +2019,178 @@ static void fit_aspect_ratio(Game *g, Ent *ent) { /* BAG:1025-1036 */
     float ar = (float)(im->w * 1.0 / im->h);
     if (ar > 1) ent->ry = ent->rx / ar;
     else ent->rx = ent->ry * ar;
+}
+
+/* ---- Chaser: chaser.cpp:137-390 ---- */
+static int to_grid_idx(const Game *g, int x, int y) { /* BAG:187-192 */
+    if (!grid_contains(g, x, y)) return INVALID_IDX;
+    return y * g->grid_w + x;
+}
+static void ch_spawn_egg(Game *g, int enemy_cell) { /* chaser.cpp:270-273 */
+    Ent *egg = push_entity(g, (float)((enemy_cell % g->maze_dim) + .5), (float)((enemy_cell / g->maze_dim) + .5), 0, 0, (float).5, (float).5, CH_ENEMY_EGG);
+    egg->health = (float)g->egg_timeout;
+}
+/* RandGen::simple_choose randgen.cpp:71-88 */
+static void rng_simple_choose(Rng *r, int n, int k, int *chosen) {
+    if (!(k <= n)) fatal("fassert k <= n (randgen.cpp:75)");
+    for (int i = 0; i < k; i++) {
+        int next = rng_randn(r, n), dup;
+        do {
+            dup = 0;
+            for (int q = 0; q < i; q++) dup |= chosen[q] == next;
+            if (dup) next = rng_randn(r, n);
+        } while (dup);
+        chosen[i] = next;
+    }
+}
+static void ch_pre_reset(Game *g) { /* chaser.cpp:141-160: sets maze_dim before BasicAbstractGame::game_reset */
+    int dm = g->opt.distribution_mode;
+    if (dm == 0) { g->maze_dim = 11; g->total_enemies = 3; }
+    else if (dm == 1) { g->maze_dim = 13; g->total_enemies = 3; }
+    else if (dm == 2) { g->maze_dim = 19; g->total_enemies = 5; }
+    else fatal("fassert(false) chaser.cpp:156");
+}
+static void ch_game_reset(Game *g) { /* chaser.cpp:137-264 */
+    static MazeGen mg;
+    int dm = g->opt.distribution_mode;
+    int extra_orb_sign = dm == 0 ? 0 : (dm == 1 ? -1 : 1);
+    g->center_agent = 0;
+    Ent *agent = &g->pool[g->agent];
+    agent->rx = (float).5;
+    agent->ry = (float).5;
+    g->eat_time = -1 * g->eat_timeout;
+    fill_elem(g, 0, 0, g->main_width, g->main_height, CH_MAZE_WALL);
+    mg.maze_dim = g->maze_dim;
+    mg.array_dim = g->maze_dim + 2;
+    mg_generate_maze_no_dead_ends(&mg, &g->rand_gen);
+    static int quadrants[4][MAX_GRID], free_cells[MAX_GRID], sel[16];
+    int nq[4] = {0, 0, 0, 0}, orbs_for_quadrant[4];
+    int extra_quad = rng_randn(&g->rand_gen, 4);
+    for (int i = 0; i < 4; i++) orbs_for_quadrant[i] = 1 + (i == extra_quad ? extra_orb_sign : 0);
+    int md = g->maze_dim;
+    for (int i = 0; i < md; i++)
+        for (int j = 0; j < md; j++) {
+            int obj = mg.grid[(j + MAZE_OFFSET) * mg.array_dim + i + MAZE_OFFSET];
+            set_obj(g, i, j, obj == WALL_OBJ ? CH_MAZE_WALL : obj);
+            if (obj == SPACE) {
+                int idx = j * md + i;
+                int quad_idx = (i >= md / 2.0 ? 1 : 0) * 2 + (j >= md / 2.0 ? 1 : 0);
+                quadrants[quad_idx][nq[quad_idx]++] = idx;
+            }
+        }
+    for (int i = 0; i < 4; i++) {
+        rng_simple_choose(&g->rand_gen, nq[i], orbs_for_quadrant[i], sel);
+        for (int k = 0; k < orbs_for_quadrant[i]; k++) {
+            int cell = quadrants[i][sel[k]];
+            push_entity(g, (float)((cell % g->main_width) + .5), (float)((cell / g->main_width) + .5), 0, 0, 0.4f, 0.4f, CH_LARGE_ORB); /* spawn_entity_at_idx BAG:577-583 */
+            g->grid[cell] = CH_MARKER;
+        }
+    }
+    int nfree = 0;
+    for (int i = 0; i < g->grid_w * g->grid_h; i++)
+        if (g->grid[i] == SPACE) free_cells[nfree++] = i;
+    rng_simple_choose(&g->rand_gen, nfree, 1 + g->total_enemies, sel);
+    int start = free_cells[sel[0]];
+    agent = &g->pool[g->agent];
+    agent->x = (float)((start % md) + .5);
+    agent->y = (float)((start / md) + .5);
+    for (int i = 0; i < g->total_enemies; i++) {
+        int cell = free_cells[sel[i + 1]];
+        g->grid[cell] = CH_MARKER;
+        ch_spawn_egg(g, cell);
+    }
+    for (int k = 0; k < nfree; k++) g->grid[free_cells[k]] = CH_ORB;
+    g->total_orbs = nfree;
+    g->orbs_collected = 0;
+    for (int i = 0; i < g->grid_w * g->grid_h; i++)
+        if (g->grid[i] == CH_MARKER) g->grid[i] = SPACE;
+}
+static void ch_game_step_tail(Game *g) { /* chaser.cpp:301-390 */
+    int num_enemies = 0;
+    Ent *agent = &g->pool[g->agent];
+    int can_eat = g->cur_time - g->eat_time < g->eat_timeout;
+    float default_enemy_speed = (float).5;
+    float vscale = can_eat ? (float)(default_enemy_speed * .5) : default_enemy_speed;
+    int mw = g->main_width;
+    for (int j = g->n_ents - 1; j >= 0; j--) {
+        Ent *ent = &g->pool[g->ents[j]];
+        if (ent->type == CH_ENEMY_EGG) {
+            num_enemies++;
+            ent->health -= 1;
+            if (ent->health == 0) {
+                ent->will_erase = 1;
+                Ent *enemy = push_entity(g, ent->x, ent->y, 0, 0, (float).5, (float).5, CH_ENEMY); /* spawn_child BAG:225-231 */
+                enemy->smart_step = 1;
+            }
+        } else if (ent->type == CH_ENEMY) {
+            num_enemies++;
+            float x = (float)(ent->x - .5);
+            float y = (float)(ent->y - .5);
+            int dist_scale = can_eat ? -1 : 1;
+            int enemy_idx = to_grid_idx(g, (int)x, (int)y);
+            int agent_idx = to_grid_idx(g, (int)agent->x, (int)agent->y);
+            int is_at_junction = fabsf(x - roundf(x)) + fabsf(y - roundf(y)) < .01;
+            int be_agressive = g->step_rand_int % 2 == 0;
+            if ((ent->vx == 0 && ent->vy == 0) || is_at_junction) {
+                int adj_elems[4], na = 0, space_neighbors[4], ns = 0;
+                int prev_idx = to_grid_idx(g, (int)(x - sign_d(ent->vx)), (int)(y - sign_d(ent->vy)));
+                { /* get_adjacent chaser.cpp:280-299: order (-1,0) (0,-1) (0,1) (1,0) */
+                    int ex_ = enemy_idx % mw, ey_ = enemy_idx / mw;
+                    static const int DI[4] = {-1, 0, 0, 1}, DJ[4] = {0, -1, 1, 0};
+                    for (int k = 0; k < 4; k++) {
+                        int nb = to_grid_idx(g, ex_ + DI[k], ey_ + DJ[k]);
+                        if (nb != INVALID_IDX) adj_elems[na++] = nb;
+                    }
+                }
+                int min_dist = 2 * mw;
+                for (int k = 0; k < na; k++) {
+                    int adj = adj_elems[k];
+                    if (g->grid[adj] != CH_MAZE_WALL && adj != prev_idx) {
+                        int md_ = (abs((adj % mw) - (agent_idx % mw)) + abs((adj / mw) - (agent_idx / mw))) * dist_scale;
+                        if (be_agressive) {
+                            if (md_ < min_dist) {
+                                min_dist = md_;
+                                ns = 0;
+                                space_neighbors[ns++] = adj;
+                            } else if (md_ == min_dist) {
+                                space_neighbors[ns++] = adj;
+                            }
+                        } else {
+                            space_neighbors[ns++] = adj;
+                        }
+                    }
+                }
+                if (ns == 0) fatal("chaser: modulo by zero (no free neighbour)");
+                int neighbor = space_neighbors[(unsigned)g->step_rand_int % (unsigned)ns];
+                int nx = neighbor % mw, ny = neighbor / mw;
+                ent->vx = (nx - x) * vscale;
+                ent->vy = (ny - y) * vscale;
+            }
+        }
+    }
+    if (num_enemies < g->total_enemies) {
+        int nfree = 0;
+        for (int i = 0; i < g->grid_w * g->grid_h; i++) nfree += g->grid[i] != CH_MAZE_WALL;
+        int selected_idx = (int)((unsigned)g->step_rand_int % (unsigned)nfree), cell = -1;
+        for (int i = 0, k = 0; i < g->grid_w * g->grid_h; i++)
+            if (g->grid[i] != CH_MAZE_WALL) {
+                if (k == selected_idx) { cell = i; break; }
+                k++;
+            }
+        ch_spawn_egg(g, cell);
+    }
+    agent = &g->pool[g->agent];
+    int agent_idx = (int)agent->y * g->main_width + (int)agent->x; /* get_agent_index BAG:176-178 */
+    if (get_obj_idx(g, agent_idx) == CH_ORB) {
+        set_obj_idx(g, agent_idx, SPACE);
+        g->reward += CH_ORB_REWARD;
+        g->orbs_collected += 1;
+    }
+    if (g->orbs_collected == g->total_orbs) {
+        g->reward += 10.0f;
+        g->level_complete = 1;
+        g->done = 1;
+    }
 }
 
 /* ---- Bossfight: bossfight.cpp:203-414 ---- */
@@ -3107,6 +3337,7 @@ static void bag_game_reset(Game *g) { /* BAG:758-797 */
         else if (dm == 1) g->main_width = g->main_height = 20;
         else if (dm == 10) g->main_width = g->main_height = 35;
     }
+    if (g->game_id == GAME_CHASER) g->main_width = g->main_height = g->maze_dim; /* choose_world_dim chaser.cpp:132-135 */
     if (g->game_id == GAME_DODGEBALL) { /* choose_world_dim dodgeball.cpp:250-259 */
         int wd = g->opt.distribution_mode == 10 ? 40 : 20;
         g->main_width = g->main_height = wd;
@@ -3166,6 +3397,7 @@ static void bag_game_reset(Game *g) { /* BAG:758-797 */
 }
 
 static void game_reset(Game *g) {
+    if (g->game_id == GAME_CHASER) ch_pre_reset(g);
     bag_game_reset(g);
     if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:416-445 */
         Ent *agent = &g->pool[g->agent];
@@ -3209,6 +3441,8 @@ static void game_reset(Game *g) {
         db_game_reset(g);
     } else if (g->game_id == GAME_BOSSFIGHT) {
         bf2_game_reset(g);
+    } else if (g->game_id == GAME_CHASER) {
+        ch_game_reset(g);
     } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:327-339 */
         g->center_agent = 0;
         sp_init_hps(g);
@@ -3629,6 +3863,12 @@ static int hook_image_for_type(const Game *g, int type) {
         if (type == MN_MOVING_BOULDER) return MN_BOULDER;
         if (type == MN_MOVING_DIAMOND) return MN_DIAMOND;
     }
+    if (g->game_id == GAME_CHASER && type == CH_ENEMY) { /* chaser.cpp:97-110 */
+        if (g->cur_time - g->eat_time < g->eat_timeout) return CH_ENEMY_WEAK;
+        int rem = (g->cur_time / 2) % 4;
+        if (rem == 3) rem = 1;
+        return CH_ENEMY + rem;
+    }
     if (g->game_id == GAME_DODGEBALL && type == DB_DOOR) return g->num_enemies == 0 ? DB_DOOR_OPEN : DB_DOOR; /* dodgeball.cpp:90-96 */
     if (g->game_id == GAME_NINJA && type == PLAYER) { /* ninja.cpp:158-168 */
         const Ent *agent = &g->pool[g->agent];
@@ -3679,6 +3919,11 @@ static void draw_image(Game *g, uint32_t *dst, RectD base_rect, float rotation, 
     int img_type = hook_image_for_type(g, base_type);
     if (img_type < 0) return;
     if (g->opt.use_monochrome_assets || img_type >= USE_ASSET_THRESHOLD) {
+        if (g->game_id == GAME_CHASER && img_type == CH_ORB) { /* draw_grid_obj override chaser.cpp:112-119 */
+            RectD o = {base_rect.x + base_rect.w * (1 - CH_ORB_DIM) / 2, base_rect.y + base_rect.h * (1 - CH_ORB_DIM) / 2, base_rect.w * CH_ORB_DIM, base_rect.h * CH_ORB_DIM};
+            fill_rect(dst, o, 0xff00ff00u);
+            return;
+        }
         if (img_type == SPACE) return; /* draw_grid_obj BAG:915-919 */
         fatal("monochrome / colored grid objects not restated yet");
     }
@@ -3881,6 +4126,12 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->main_width = 64;
         g->main_height = 64;
         g->out_of_bounds_object = CR_WALL_MID;
+    } else if (game_id == GAME_CHASER) { /* chaser.cpp:38-49 */
+        g->mixrate = 1;
+        g->maxspeed = (float).5;
+        g->eat_timeout = 75;
+        g->egg_timeout = 50;
+        g->has_useful_vel_info = 0;
     } else if (game_id == GAME_BOSSFIGHT) { /* bossfight.cpp:63-71 */
         g->timeout = 4000;
         g->main_width = 20;

@@ -111,6 +111,16 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(9, {"misc_assets/dirt.png"});
         add_themes(10, {"misc_assets/tile_bricksGrey.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_CHASER) {  // reference src/games/chaser.cpp:51-73, src/resources.cpp:913-918
+        add_themes(0, {"misc_assets/enemyFloating_1b.png"});
+        add_themes(6, {"misc_assets/enemyFlying_1.png"});
+        add_themes(7, {"misc_assets/enemyFlying_2.png"});
+        add_themes(8, {"misc_assets/enemyFlying_3.png"});
+        add_themes(2, {"misc_assets/yellowCrystal.png"});
+        add_themes(3, {"misc_assets/enemyWalking_1b.png"});
+        add_themes(4, {"misc_assets/enemySpikey_1b.png"});
+        add_themes(5, {"misc_assets/tileStone_slope.png"});
+        backgrounds->push_back("topdown_backgrounds/floortiles.png");
     } else if (game_id == GAME_BOSSFIGHT) {  // reference src/games/bossfight.cpp:73-107
         add_themes(0, {"misc_assets/playerShip1_blue.png", "misc_assets/playerShip1_green.png", "misc_assets/playerShip2_orange.png", "misc_assets/playerShip3_red.png"});
         add_themes(2, {"misc_assets/enemyShipBlack1.png", "misc_assets/enemyShipBlue2.png", "misc_assets/enemyShipGreen3.png", "misc_assets/enemyShipRed4.png"});
@@ -325,6 +335,7 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
     if (game_id == GAME_LEAPER) ref_type = 2;
     if (game_id == GAME_NINJA) ref_type = 20;
     if (game_id == GAME_DODGEBALL) ref_type = 10;
+    if (game_id == GAME_CHASER) ref_type = 5;
     if (ref_type >= 0 && t.type_theme_img[ref_type][0] >= 0) {
         t.ref_w = t.img[t.type_theme_img[ref_type][0]].w;
         t.ref_h = t.img[t.type_theme_img[ref_type][0]].h;

@@ -241,6 +241,25 @@ struct MazeGenDev {
         return n;
     }
 
+    PG_DEV void generate_maze_no_dead_ends() {  // mazegen.cpp:189-209: sequential (each opened wall changes later neighbour counts)
+        generate_maze();
+        const int nc = array_dim * array_dim;
+        for (int i = 0; i < nc; i++) {
+            if (get_obj_u(i) != SPACE) continue;
+            int adj[4];
+            if (get_neighbors(i, SPACE, adj) == 1) {
+                int wl[4];
+                const int nw = get_neighbors(i, WALL_OBJ, wl);
+                if (nw > 0) {
+                    const int n = e.randn(nw);
+                    const int cell = n == 0 ? wl[0] : (n == 1 ? wl[1] : (n == 2 ? wl[2] : wl[3]));
+                    m.mgrid[cell] = (uint16_t)SPACE;
+                    PG_SYNC();
+                }
+            }
+        }
+    }
+
     PG_DEV void generate_maze_with_doors(int num_doors) {  // mazegen.cpp:211-290
         generate_maze();
         const int nc = array_dim * array_dim;

@@ -39,7 +39,8 @@ PG_DEV int cmd_src_w(uint32_t aux) { return (int)(aux & 0x1fffu); }
 PG_DEV bool cmd_mirrored(uint32_t aux) { return ((aux >> 13) & 1u) != 0; }
 PG_DEV bool cmd_opaque(uint32_t aux) { return ((aux >> 14) & 1u) != 0; }
 PG_DEV bool cmd_rotated(uint32_t aux) { return ((aux >> 15) & 1u) != 0; }
-PG_DEV bool cmd_tiled(uint32_t aux) { return ((aux >> 25) & 1u) != 0; }  // entity drawn as a row / column of tiles (tile_image BAG:840-865)
+PG_DEV bool cmd_tiled(uint32_t aux) { return ((aux >> 25) & 1u) != 0; }
+PG_DEV bool cmd_fill(uint32_t aux) { return ((aux >> 26) & 1u) != 0; }  // solid colour (draw_grid_obj): src holds the colour, no texture  // entity drawn as a row / column of tiles (tile_image BAG:840-865)
 PG_DEV int cmd_alpha(uint32_t aux) { return (int)(aux >> 16); }
 PG_DEV uint32_t cmd_aux(int src_w, bool mirrored, bool opaque, int io) {
     return (uint32_t)src_w | ((mirrored ? 1u : 0u) << 13) | (((opaque && io == 256) ? 1u : 0u) << 14) | ((uint32_t)io << 16);
@@ -69,6 +70,14 @@ struct GameUsesTiledEntities {
 template <class Game>
 struct GameUsesTiledEntities<Game, decltype((void)Game::USES_TILED_ENTITIES)> {
     static constexpr bool value = Game::USES_TILED_ENTITIES;
+};
+template <class Game, class = void>
+struct GameHasGridFills {
+    static constexpr bool value = false;
+};
+template <class Game>
+struct GameHasGridFills<Game, decltype((void)Game::HAS_GRID_FILLS)> {
+    static constexpr bool value = Game::HAS_GRID_FILLS;
 };
 template <class Game, class = void>
 struct GameHasOverlay {
@@ -499,7 +508,11 @@ struct Renderer {
                     const int cy = cidx - cx * ny_full;
                     const int type = get_obj(win_lx + cx, win_ly + cy);
                     uint32_t v = CELL_NONE;
-                    if (type != INVALID_OBJ && type != SPACE) {
+                    bool is_fill = false;
+                    if constexpr (GameHasGridFills<Game>::value) is_fill = Game::is_grid_fill(*this, type);
+                    if (is_fill) {
+                        PG_LV(bad, l) = 1;  // solid squares are not part of the pull form: per-cell commands for this frame
+                    } else if (type != INVALID_OBJ && type != SPACE) {
                         const int theme = Game::theme_for_grid_obj(*this, type);
                         RectD r2 = get_screen_rect((float)(win_lx + cx), (float)(win_ly + cy + 1), 1, 1, RENDER_EPS);
                         const RectD r2_in = r2;
@@ -610,6 +623,11 @@ struct Renderer {
     // Wide commands (backgrounds) map lane -> column and walk 8 rows per round; narrower ones split a linear pixel
     // index with a reciprocal multiply.
     PG_DEV void exec_large(const DrawCmd &c) {
+        if (cmd_fill(c.aux)) {
+            RectD r = {(double)c.tx1, (double)c.ty1, (double)c.w, (double)c.h};
+            exec_fill(r, c.src);
+            return;
+        }
         const uint32_t *src = d.pixels + c.src;
         const int sw = cmd_src_w(c.aux);
         const bool mirrored = cmd_mirrored(c.aux);
@@ -771,8 +789,8 @@ struct Renderer {
                     const int sw = cmd_src_w(c[g].aux);
                     const int sxp = (int)((c[g].basex + (uint32_t)lx * c[g].ix) >> 16);
                     const int syp = (int)((c[g].srcy0 + (uint32_t)ly * c[g].iy) >> 16);
-                    const uint32_t addr = c[g].src + (uint32_t)(syp * sw + (cmd_mirrored(c[g].aux) ? (sw - 1 - sxp) : sxp));
-                    PG_LA(tex, g, l) = d.pixels[in ? addr : 0u];  // branch-free: masked-off lanes fetch word 0
+                    const uint32_t addr = cmd_fill(c[g].aux) ? 0u : c[g].src + (uint32_t)(syp * sw + (cmd_mirrored(c[g].aux) ? (sw - 1 - sxp) : sxp));
+                    PG_LA(tex, g, l) = cmd_fill(c[g].aux) ? c[g].src : d.pixels[in ? addr : 0u];  // branch-free: masked-off lanes fetch word 0
                     PG_LA(fbi, g, l) = in ? ((y - row0) * RES_W + c[g].tx1 + lx) : (BAND_ROWS * RES_W + l);
                 }
             }
@@ -1090,7 +1108,28 @@ struct Renderer {
                         const int cy = cidx - cx * ny;
                         const int x = low_x + cx, y = low_y + cy;
                         const int type = get_obj(x, y);
-                        if (type != INVALID_OBJ && type != SPACE) {
+                        bool is_fill = false;
+                        if constexpr (GameHasGridFills<Game>::value) is_fill = Game::is_grid_fill(*this, type);
+                        if (is_fill) {
+                            if constexpr (GameHasGridFills<Game>::value) {  // draw_grid_obj override: p.fillRect(QRectF, QColor)
+                                const RectD cell = get_screen_rect((float)x, (float)(y + 1), 1, 1, RENDER_EPS);
+                                RectD fr;
+                                uint32_t color;
+                                Game::grid_fill(*this, type, cell, fr, color);
+                                int x1 = q_round(fr.x), x2 = q_round(fr.x + fr.w), y1 = q_round(fr.y), y2 = q_round(fr.y + fr.h);
+                                if (x2 < x1) { const int t = x1; x1 = x2; x2 = t; }
+                                if (y2 < y1) { const int t = y1; y1 = y2; y2 = t; }
+                                if (x1 < 0) x1 = 0;
+                                if (y1 < 0) y1 = 0;
+                                if (x2 > RES_W) x2 = RES_W;
+                                if (y2 > RES_H) y2 = RES_H;
+                                if (x2 > x1 && y2 > y1 && !(y1 >= row1 || y2 <= row0)) {
+                                    PG_LV(r.geom, l) = (uint32_t)x1 | ((uint32_t)y1 << 7) | ((uint32_t)(x2 - x1) << 14) | ((uint32_t)(y2 - y1) << 21);
+                                    PG_LV(r.src, l) = color;
+                                    PG_LV(r.aux, l) = cmd_aux(1, false, true, 256) | (1u << 26);
+                                }
+                            }
+                        } else if (type != INVALID_OBJ && type != SPACE) {
                             const int theme = Game::theme_for_grid_obj(*this, type);
                             RectD r2 = get_screen_rect((float)x, (float)(y + 1), 1, 1, RENDER_EPS);
                             const RectD r2_in = r2;

@@ -113,7 +113,7 @@ bool read_rng(Reader &r, int *seeded, uint32_t *mt, int *idx) {
 }
 
 bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h) {
-    if (game_id == GAME_BIGFISH || game_id == GAME_STARPILOT || game_id == GAME_LEAPER || game_id == GAME_PLUNDER || game_id == GAME_BOSSFIGHT) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64, starpilot.cpp:330
+    if (game_id == GAME_BIGFISH || game_id == GAME_STARPILOT || game_id == GAME_LEAPER || game_id == GAME_PLUNDER || game_id == GAME_BOSSFIGHT || game_id == GAME_CHASER) return h.initial_reset_complete ? false : opt.center_agent != 0;  // bigfish.cpp:64, starpilot.cpp:330
     if (game_id == GAME_MAZE || game_id == GAME_MINER || game_id == GAME_HEIST || game_id == GAME_DODGEBALL)  // maze.cpp:66, miner.cpp:140, heist.cpp:119
         return h.initial_reset_complete ? opt.distribution_mode == MemoryMode : opt.center_agent != 0;
     return opt.center_agent != 0;
@@ -229,7 +229,13 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
     w.i(h.main_height);
     const int cells = h.main_width * h.main_height;
     w.i(cells);
-    for (int c = 0; c < cells; c++) w.i((int32_t)s.grid[c]);
+    const bool wide_cells = game_id == GAME_CHASER;  // u16 cells (object ids above 255)
+    if ((size_t)cells * (wide_cells ? 2 : 1) > s.grid.size()) {
+        if (err) *err = "grid larger than the snapshot";
+        return false;
+    }
+    auto cell_at = [&](int c) -> int { return wide_cells ? (int)reinterpret_cast<const uint16_t *>(s.grid.data())[c] : (int)s.grid[c]; };
+    for (int c = 0; c < cells; c++) w.i((int32_t)cell_at(c));
     // game tails
     if (game_id == GAME_COINRUN) {  // reference src/games/coinrun.cpp:500-509
         w.f(h.gsf0);
@@ -247,6 +253,22 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
         w.i(h.gsi1);
     } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:309-312
         w.i(h.gsi0);
+    } else if (game_id == GAME_CHASER) {  // reference src/games/chaser.cpp:392-403: free_cells / is_space_vec follow from the walls
+        const int MAZE_WALL = 5;
+        int nfree = 0;
+        for (int c = 0; c < cells; c++) nfree += cell_at(c) != MAZE_WALL;
+        w.i(nfree);
+        for (int c = 0; c < cells; c++)
+            if (cell_at(c) != MAZE_WALL) w.i(c);
+        w.i(cells);
+        for (int c = 0; c < cells; c++) w.i(cell_at(c) != MAZE_WALL ? 1 : 0);
+        w.i(75);       // eat_timeout
+        w.i(50);       // egg_timeout
+        w.i(h.gsi0);   // eat_time
+        w.i(h.gsi4);   // total_enemies
+        w.i(h.gsi1);   // total_orbs
+        w.i(h.gsi2);   // orbs_collected
+        w.i(h.gsi3);   // maze_dim
     } else if (game_id == GAME_BOSSFIGHT) {  // reference src/games/bossfight.cpp:416-441
         const int p = h.gsi5, nr = (p >> 10) & 7;
         w.i(nr);
@@ -475,8 +497,12 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
     h.visibility = r.f();
     h.min_visibility = r.f();
     const int gw = r.i(), gh = r.i(), cnt = r.i();
-    if (!r.ok || gw != h.main_width || gh != h.main_height || cnt != gw * gh || (size_t)cnt > s->grid.size()) return bad("set_state: malformed grid");
-    for (int c = 0; c < cnt; c++) s->grid[c] = (uint8_t)r.i();
+    const bool wide_cells = game_id == GAME_CHASER;
+    if (!r.ok || gw != h.main_width || gh != h.main_height || cnt != gw * gh || (size_t)cnt * (wide_cells ? 2 : 1) > s->grid.size()) return bad("set_state: malformed grid");
+    for (int c = 0; c < cnt; c++) {
+        if (wide_cells) reinterpret_cast<uint16_t *>(s->grid.data())[c] = (uint16_t)r.i();
+        else s->grid[c] = (uint8_t)r.i();
+    }
     if (game_id == GAME_COINRUN) {
         h.gsf0 = r.f();
         h.gsi0 = r.i();
@@ -493,6 +519,21 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         h.gsi1 = r.i();
     } else if (game_id == GAME_MINER) {
         h.gsi0 = r.i();
+    } else if (game_id == GAME_CHASER) {
+        const int nf = r.i();
+        if (!r.ok || nf < 0 || nf > cnt) return bad("set_state: chaser free_cells");
+        for (int k = 0; k < nf; k++) r.i();
+        const int nsv = r.i();
+        if (!r.ok || nsv != cnt) return bad("set_state: chaser is_space_vec");
+        for (int k = 0; k < nsv; k++) r.i();
+        r.i();  // eat_timeout
+        r.i();  // egg_timeout
+        h.gsi0 = r.i();
+        h.gsi4 = r.i();
+        h.gsi1 = r.i();
+        h.gsi2 = r.i();
+        h.gsi3 = r.i();
+        h.gsi5 = nf;
     } else if (game_id == GAME_BOSSFIGHT) {
         const int nm = r.i();
         if (!r.ok || nm < 0 || nm > 5) return bad("set_state: bossfight attack_modes");

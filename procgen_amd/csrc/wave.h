@@ -71,6 +71,7 @@ PG_DEV double pg_floor(double x) { return floor(x); }
 PG_DEV float pg_floorf(float x) { return floorf(x); }
 PG_DEV double pg_ceil(double x) { return ceil(x); }
 PG_DEV float pg_fabsf(float x) { return fabsf(x); }
+PG_DEV float pg_roundf(float x) { return roundf(x); }
 PG_DEV double pg_fabs(double x) { return fabs(x); }
 PG_DEV double pg_pow(double x, double y) { return pow(x, y); }  // glibc, as the reference
 PG_DEV double pg_sin(double x) { return sin(x); }
@@ -108,6 +109,7 @@ PG_DEV double pg_floor(double x) { return __builtin_floor(x); }
 PG_DEV float pg_floorf(float x) { return __builtin_floorf(x); }
 PG_DEV double pg_ceil(double x) { return __builtin_ceil(x); }
 PG_DEV float pg_fabsf(float x) { return __builtin_fabsf(x); }
+PG_DEV float pg_roundf(float x) { return __builtin_roundf(x); }  // half away from zero, as C roundf
 PG_DEV double pg_fabs(double x) { return __builtin_fabs(x); }
 // ROCm device libm (OCML), < 1 ulp in double; callers narrow the result to float (bit-exactness notes)
 PG_DEV double pg_pow(double x, double y) { return pow(x, y); }

@@ -240,7 +240,8 @@ void emu_dump_grid(void *h, int env, int32_t *out, int *w, int *hh) {
     EmuVec *v = (EmuVec *)h;
     *w = v->hdr[env].main_width;
     *hh = v->hdr[env].main_height;
-    const uint8_t *g = v->grid.data() + (size_t)env * v->d.grid_bytes;  // u8 cells (all games so far)
-    for (int i = 0; i < (*w) * (*hh); i++) out[i] = g[i];
+    const uint8_t *g = v->grid.data() + (size_t)env * v->d.grid_bytes;
+    const bool wide = v->game_id == GAME_CHASER;  // u16 cells
+    for (int i = 0; i < (*w) * (*hh); i++) out[i] = wide ? (int32_t) reinterpret_cast<const uint16_t *>(g)[i] : (int32_t)g[i];
 }
 }
