@@ -8,7 +8,7 @@
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
  * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner,
- * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors), ninja, dodgeball, bossfight, chaser (with MazeGen::generate_maze_no_dead_ends).
+ * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors), ninja, dodgeball, bossfight, chaser (with MazeGen::generate_maze_no_dead_ends), caveflyer (with RoomGenerator).
  */
 #include "procgen_oracle.h"
 
@@ -38,7 +38,17 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_BOSSFIGHT = 1, GAME_CHASER = 3, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_DODGEBALL = 6, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_NINJA = 13, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+enum { GAME_BIGFISH = 0, GAME_BOSSFIGHT = 1, GAME_CAVEFLYER = 2, GAME_CHASER = 3, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_DODGEBALL = 6, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_NINJA = 13, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+
+/* caveflyer.cpp:9-21 */
+#define CF_GOAL 1
+#define CF_OBSTACLE 2
+#define CF_TARGET 3
+#define CF_PLAYER_BULLET 4
+#define CF_ENEMY 5
+#define CF_CAVEWALL 8
+#define CF_EXHAUST 9
+#define CF_MARKER 1003
 
 /* chaser.cpp:10-23 */
 #define CH_LARGE_ORB 2
@@ -487,6 +497,18 @@ static void assets_build(int game_id) {
         assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:35-53 */
+        assets_type(a, CF_GOAL, "misc_assets/ufoGreen2.png");
+        assets_type(a, CF_OBSTACLE, "misc_assets/meteorBrown_big1.png");
+        assets_type(a, CF_TARGET, "misc_assets/ufoRed2.png");
+        assets_type(a, CF_PLAYER_BULLET, "misc_assets/laserBlue02.png");
+        assets_type(a, CF_ENEMY, "misc_assets/enemyShipBlue4.png");
+        assets_type(a, PLAYER, "misc_assets/playerShip1_red.png");
+        assets_type(a, CF_CAVEWALL, "misc_assets/groundA.png");
+        assets_type(a, CF_EXHAUST, "misc_assets/towerDefense_tile295.png");
+        int n_platform = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0])) - 13; /* space_backgrounds */
+        a->n_bg = 13;
+        for (int i = 0; i < 13; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[n_platform + i], 1);
     } else if (game_id == GAME_CHASER) { /* chaser.cpp:51-73 */
         assets_type(a, PLAYER, "misc_assets/enemyFloating_1b.png");
         assets_type(a, CH_ENEMY, "misc_assets/enemyFlying_1.png");
@@ -675,6 +697,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "dodgeball") == 0) return GAME_DODGEBALL;
     if (strcmp(name, "bossfight") == 0) return GAME_BOSSFIGHT;
     if (strcmp(name, "chaser") == 0) return GAME_CHASER;
+    if (strcmp(name, "caveflyer") == 0) return GAME_CAVEFLYER;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -871,6 +894,7 @@ static int hook_is_blocked(const Game *g, const Ent *src, int target, int is_hor
         if (src->type == PLAYER && cr_is_wall(target)) return 1;
     }
     if (g->game_id == GAME_CHASER && target == CH_MAZE_WALL) return 1; /* chaser.cpp:90-95 */
+    if (g->game_id == GAME_CAVEFLYER && src->type == PLAYER && target == CF_CAVEWALL) return 1; /* caveflyer.cpp:87-94 */
     if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:84-86 */
         if (src->type == PLAYER && target == FB_OUT_OF_BOUNDS_WALL) return 1;
     }
@@ -896,6 +920,8 @@ static int hook_is_blocked_ents(Game *g, const Ent *src, const Ent *target, int 
 static int hook_will_reflect(const Game *g, int src, int target) {
     if (g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) /* coinrun.cpp:140-142, climber.cpp:110-112 (same ids) */
         return (src == CR_ENEMY && (cr_is_wall(target) || target == CR_ENEMY_BARRIER));
+    if (g->game_id == GAME_CAVEFLYER) /* caveflyer.cpp:127-129 */
+        return (src == CF_ENEMY && (target == CF_CAVEWALL || target == g->out_of_bounds_object));
     if (g->game_id == GAME_DODGEBALL) /* dodgeball.cpp:98-100 */
         return (src == DB_ENEMY && (target == DB_LAVA_WALL || target == g->out_of_bounds_object));
     if (g->game_id == GAME_FRUITBOT) /* fruitbot.cpp:80-82 */
@@ -931,6 +957,14 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
             g->reward += 1.0f;
             g->coins_collected += 1;
             obj->will_erase = 1;
+        }
+    } else if (g->game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:55-69 */
+        if (obj->type == CF_GOAL) {
+            g->reward += 10.0f;
+            g->level_complete = 1;
+            g->done = 1;
+        } else if (obj->type == CF_OBSTACLE || obj->type == CF_ENEMY || obj->type == CF_TARGET) {
+            g->done = 1;
         }
     } else if (g->game_id == GAME_CHASER) { /* chaser.cpp:121-135 */
         if (obj->type == CH_LARGE_ORB) {
@@ -1061,6 +1095,30 @@ static void bf2_prepare_boss(Game *g) { /* bossfight.cpp:194-201 */
     g->pool[g->boss].vy = 0;
 }
 static void hook_handle_collision(Game *g, Ent *src, Ent *target) { /* BAG:398 */
+    if (g->game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:96-125 */
+        if (target->type == CF_PLAYER_BULLET) {
+            int erase_bullet = 0;
+            if (src->type == CF_TARGET) {
+                src->health -= 1;
+                erase_bullet = 1;
+                if (src->health <= 0 && !src->will_erase) {
+                    float r = (float)(.5 * src->rx);
+                    push_entity(g, src->x, src->y, 0, 0, r, r, EXPLOSION);
+                    src->will_erase = 1;
+                    g->reward += 3.0f;
+                }
+            } else if (src->type == CF_OBSTACLE || src->type == CF_ENEMY || src->type == CF_GOAL) {
+                erase_bullet = 1;
+            }
+            if (erase_bullet && !target->will_erase) {
+                target->will_erase = 1;
+                float r = (float)(.5 * target->rx);
+                Ent *ex = push_entity(g, target->x, target->y, 0, 0, r, r, EXPLOSION);
+                ex->vx = src->vx;
+                ex->vy = src->vy;
+            }
+        }
+    }
     if (g->game_id == GAME_BOSSFIGHT) { /* bossfight.cpp:129-192 */
         if (src->type == BF2_PLAYER_BULLET) {
             int will_erase = 0;
@@ -1390,6 +1448,23 @@ static void hook_set_action_xy(Game *g, int move_act) {
         g->has_support = s1 || s2;
         if (g->has_support && g->action_vy == 1) g->action_vy = 1;
         else g->action_vy = 0;
+    } else if (g->game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:264-285 */
+        const Ent *agent = &g->pool[g->agent];
+        float acceleration = (float)(move_act % 3 - 1);
+        if (acceleration < 0) acceleration *= 0.33f;
+        float theta = -1 * agent->rotation + PI_F / 2;
+        if (acceleration > 0) {
+            float ax = agent->x, ay = agent->y, arx = agent->rx, ary = agent->ry;
+            float r = (float)(.5 * arx);
+            Ent *exhaust = push_entity(g, (float)(ax - arx * cos((double)theta)), (float)(ay - ary * sin((double)theta)), 0, 0, r, r, CF_EXHAUST);
+            exhaust->expire_time = 4;
+            exhaust->rotation = -1 * theta - PI_F / 2;
+            exhaust->grow_rate = (float)1.25;
+            exhaust->alpha_decay = 0.8f;
+        }
+        g->action_vy = (float)(acceleration * sin((double)theta));
+        g->action_vx = (float)(acceleration * cos((double)theta));
+        g->action_vrot = (float)(move_act / 3 - 1);
     } else if (g->game_id == GAME_PLUNDER) { /* plunder.cpp:111-115 */
         g->action_vy = 0;
         g->action_vrot = 0;
@@ -1426,6 +1501,12 @@ static void hook_update_agent_velocity(Game *g) {
             agent->vy -= g->gravity;
             agent->vy = clip_abs(agent->vy, g->max_jump);
         }
+    } else if (g->game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:71-78, BAG:502-504,681-684 */
+        float v_scale = 1.0;
+        agent->vx = (float)(agent->vx + g->mixrate * g->maxspeed * g->action_vx * v_scale * .2);
+        agent->vy = (float)(agent->vy + g->mixrate * g->maxspeed * g->action_vy * v_scale * .2);
+        agent->vx = (float)(.9 * agent->vx);
+        agent->vy = (float)(.9 * agent->vy);
     } else if (g->game_id == GAME_CHASER) { /* chaser.cpp:79-88 */
         if (g->action_vx != 0) agent->vx = g->maxspeed * g->action_vx;
         if (g->action_vy != 0) agent->vy = g->maxspeed * g->action_vy;
@@ -1590,6 +1671,34 @@ static void game_step(Game *g) {
         bf2_game_step_tail(g);
     } else if (g->game_id == GAME_CHASER) {
         ch_game_step_tail(g);
+    } else if (g->game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:287-324 */
+        if (g->special_action == 1) {
+            const Ent *agent = &g->pool[g->agent];
+            float theta = -1 * agent->rotation + PI_F / 2;
+            float vx = (float)cos((double)theta);
+            float vy = (float)sin((double)theta);
+            float rot = agent->rotation;
+            Ent *nb = push_entity(g, agent->x, agent->y, vx, vy, 0.1f, 0.25f, CF_PLAYER_BULLET);
+            nb->expire_time = 10;
+            nb->rotation = rot;
+        }
+        for (int k = g->n_ents - 1; k >= 0; k--) {
+            Ent *ent = &g->pool[g->ents[k]];
+            if (ent->type == CF_ENEMY) face_direction(ent, ent->vx, ent->vy, -1 * PI_F / 2);
+            if (ent->type != CF_PLAYER_BULLET) continue;
+            int found_wall = 0;
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 2; j++) {
+                    int type2 = get_obj_from_floats(g, ent->x + ent->rx * (2 * i - 1), ent->y + ent->ry * (2 * j - 1));
+                    found_wall = found_wall || type2 == CF_CAVEWALL;
+                }
+            if (found_wall) {
+                ent->will_erase = 1;
+                float r = (float)(.5 * ent->rx);
+                push_entity(g, ent->x, ent->y, 0, 0, r, r, EXPLOSION);
+            }
+        }
+        erase_if_needed(g);
     } else if (g->game_id == GAME_NINJA) { /* ninja.cpp:349-383 */
         Ent *agent = &g->pool[g->agent];
         if (g->action_vx > 0) agent->is_reflected = 0;
@@ -2019,6 +2128,187 @@ static void fit_aspect_ratio(Game *g, Ent *ent) { /* BAG:1025-1036 */
     float ar = (float)(im->w * 1.0 / im->h);
     if (ar > 1) ent->ry = ent->rx / ar;
     else ent->rx = ent->ry * ar;
+}
+
+/* ---- RoomGenerator: reference src/roomgen.cpp (std::set<int> = membership flags, ascending iteration) ---- */
+static int rg_to_grid_idx(const Game *g, int x, int y) { return grid_contains(g, x, y) ? y * g->grid_w + x : -2; } /* BAG:187-192 */
+static int rg_get_obj_idx(const Game *g, int idx) { return (0 <= idx && idx < g->grid_w * g->grid_h) ? g->grid[idx] : g->out_of_bounds_object; } /* BAG:198-203 */
+static void rg_update(Game *g) { /* roomgen.cpp:22-37; count_neighbors :3-20 (3x3 block incl. the cell) */
+    static int next_cells[MAX_GRID];
+    int n = g->grid_w * g->grid_h;
+    for (int idx = 0; idx < n; idx++) {
+        int x = idx % g->grid_w, y = idx / g->grid_w, cnt = 0;
+        for (int i = -1; i <= 1; i++)
+            for (int j = -1; j <= 1; j++) cnt += get_obj(g, x + i, y + j) == WALL_OBJ;
+        next_cells[idx] = cnt >= 5 ? WALL_OBJ : SPACE;
+    }
+    for (int idx = 0; idx < n; idx++) g->grid[idx] = next_cells[idx];
+}
+static int rg_build_room(const Game *g, int idx, unsigned char *room) { /* roomgen.cpp:39-70; returns the room's size */
+    static int queue[4 * MAX_GRID];
+    int head = 0, tail = 0, size = 0;
+    if (rg_get_obj_idx(g, idx) != SPACE) return 0;
+    queue[tail++] = idx;
+    while (head < tail) {
+        int curr = queue[head++];
+        if (rg_get_obj_idx(g, curr) != SPACE) continue;
+        int x = curr % g->grid_w, y = curr / g->grid_w;
+        static const int DI[4] = {-1, 0, 0, 1}, DJ[4] = {0, -1, 1, 0};
+        for (int k = 0; k < 4; k++) {
+            int next = rg_to_grid_idx(g, x + DI[k], y + DJ[k]);
+            if (next >= 0 && !room[next] && g->grid[next] == SPACE) {
+                queue[tail++] = next;
+                room[next] = 1;
+                size++;
+            }
+        }
+    }
+    return size;
+}
+static int rg_find_path(const Game *g, int src, int dst, int *path) { /* roomgen.cpp:72-126; returns the path length */
+    static unsigned char covered[MAX_GRID];
+    static int expanded[2 * MAX_GRID], parents[2 * MAX_GRID], tmp[2 * MAX_GRID];
+    int n = g->grid_w * g->grid_h, ne = 0, np = 0;
+    memset(covered, 0, (size_t)n);
+    if (rg_get_obj_idx(g, src) != SPACE) return 0;
+    expanded[ne] = src;
+    parents[ne++] = -1;
+    int search_idx = 0;
+    while (search_idx < ne) {
+        int curr = expanded[search_idx];
+        if (curr == dst) break;
+        int x = curr % g->grid_w, y = curr / g->grid_w;
+        static const int DI[4] = {-1, 0, 0, 1}, DJ[4] = {0, -1, 1, 0};
+        for (int k = 0; k < 4; k++) {
+            int next = rg_to_grid_idx(g, x + DI[k], y + DJ[k]);
+            if (next >= 0 && !covered[next] && g->grid[next] == SPACE) {
+                expanded[ne] = next;
+                parents[ne++] = search_idx;
+                covered[next] = 1;
+            }
+        }
+        search_idx++;
+    }
+    if (search_idx < ne && expanded[search_idx] == dst) {
+        int nt = 0;
+        while (search_idx >= 0) {
+            tmp[nt++] = expanded[search_idx];
+            search_idx = parents[search_idx];
+        }
+        for (int j = nt - 1; j >= 0; j--) path[np++] = tmp[j];
+    }
+    return np;
+}
+static void rg_expand_room(const Game *g, unsigned char *set, int n_loops) { /* roomgen.cpp:150-182 */
+    static unsigned char curr[MAX_GRID], next[MAX_GRID];
+    int n = g->grid_w * g->grid_h;
+    memcpy(curr, set, (size_t)n);
+    for (int loop = 0; loop < n_loops; loop++) {
+        memset(next, 0, (size_t)n);
+        for (int c = 0; c < n; c++) {
+            if (!curr[c]) continue;
+            if (g->grid[c] != SPACE) continue;
+            int x = c % g->grid_w, y = c / g->grid_w;
+            for (int i = -1; i <= 1; i++)
+                for (int j = -1; j <= 1; j++)
+                    if (i != 0 || j != 0) {
+                        int nx = rg_to_grid_idx(g, x + i, y + j);
+                        if (nx >= 0 && !set[nx] && g->grid[nx] == SPACE) {
+                            set[nx] = 1;
+                            next[nx] = 1;
+                        }
+                    }
+        }
+        memcpy(curr, next, (size_t)n);
+    }
+}
+
+/* ---- CaveFlyer: caveflyer.cpp:131-262 ---- */
+static void rng_simple_choose(Rng *r, int n, int k, int *chosen);
+static void cf_game_reset(Game *g) {
+    int n = g->grid_w * g->grid_h;
+    g->out_of_bounds_object = WALL_OBJ;
+    for (int i = 0; i < n; i++) g->grid[i] = rng_rand01(&g->rand_gen) < .5 ? WALL_OBJ : SPACE;
+    for (int it = 0; it < 4; it++) rg_update(g);
+    static unsigned char best_room[MAX_GRID], all_rooms[MAX_GRID], next_room[MAX_GRID], wide_path[MAX_GRID];
+    static int free_cells[MAX_GRID], goal_path[2 * MAX_GRID], sel[MAX_GRID];
+    { /* find_best_room roomgen.cpp:128-148 */
+        memset(all_rooms, 0, (size_t)n);
+        memset(best_room, 0, (size_t)n);
+        int best_size = -1;
+        for (int i = 0; i < n; i++)
+            if (g->grid[i] == SPACE && !all_rooms[i]) {
+                memset(next_room, 0, (size_t)n);
+                int sz = rg_build_room(g, i, next_room);
+                for (int c = 0; c < n; c++) all_rooms[c] |= next_room[c];
+                if (sz > best_size) {
+                    best_size = sz;
+                    memcpy(best_room, next_room, (size_t)n);
+                }
+            }
+        if (best_size <= 0) fatal("fassert best_room.size() > 0 (caveflyer.cpp:160)");
+    }
+    int nfree = 0;
+    for (int i = 0; i < n; i++) {
+        g->grid[i] = WALL_OBJ;
+    }
+    for (int i = 0; i < n; i++)
+        if (best_room[i]) {
+            g->grid[i] = SPACE;
+            free_cells[nfree++] = i;
+        }
+    rng_simple_choose(&g->rand_gen, nfree, 2, sel);
+    int agent_cell = free_cells[sel[0]], goal_cell = free_cells[sel[1]];
+    Ent *agent = &g->pool[g->agent];
+    agent->x = (float)((agent_cell % g->main_width) + .5);
+    agent->y = (float)((agent_cell / g->main_width) + .5);
+    Ent *goal = push_entity(g, (float)((goal_cell % g->main_width) + .5), (float)((goal_cell / g->main_width) + .5), 0, 0, (float).5, (float).5, CF_GOAL);
+    goal->collides_with_entities = 1;
+    int npath = rg_find_path(g, agent_cell, goal_cell, goal_path);
+    if (g->opt.distribution_mode != 10) {
+        memset(wide_path, 0, (size_t)n);
+        for (int k = 0; k < npath; k++) wide_path[goal_path[k]] = 1;
+        rg_expand_room(g, wide_path, 4);
+        for (int i = 0; i < n; i++) g->grid[i] = wide_path[i] ? SPACE : WALL_OBJ;
+    }
+    for (int it = 0; it < 4; it++) {
+        rg_update(g);
+        for (int k = 0; k < npath; k++) g->grid[goal_path[k]] = SPACE;
+    }
+    for (int k = 0; k < npath; k++) g->grid[goal_path[k]] = CF_MARKER;
+    nfree = 0;
+    for (int i = 0; i < n; i++) {
+        if (g->grid[i] == SPACE) free_cells[nfree++] = i;
+        else if (g->grid[i] == WALL_OBJ) g->grid[i] = CF_CAVEWALL;
+    }
+    int chunk_size = nfree / 80;
+    int num_objs = 3 * chunk_size;
+    rng_simple_choose(&g->rand_gen, nfree, num_objs, sel);
+    for (int i = 0; i < num_objs; i++) {
+        int val = free_cells[sel[i]];
+        float ex_ = (float)((val % g->main_width) + .5), ey_ = (float)((val / g->main_width) + .5);
+        if (i < chunk_size) {
+            Ent *e = push_entity(g, ex_, ey_, 0, 0, (float).5, (float).5, CF_OBSTACLE);
+            e->collides_with_entities = 1;
+        } else if (i < 2 * chunk_size) {
+            Ent *e = push_entity(g, ex_, ey_, 0, 0, (float).5, (float).5, CF_TARGET);
+            e->health = 5;
+            e->collides_with_entities = 1;
+        } else {
+            Ent *e = push_entity(g, ex_, ey_, 0, 0, (float).5, (float).5, CF_ENEMY);
+            double mag = .1 * rng_rand01(&g->rand_gen) + .1; /* left operand of the product draws first (checked against oracle/_ref) */
+            int sgn = rng_randn(&g->rand_gen, 2) * 2 - 1;
+            float vel = (float)(mag * sgn);
+            if (rng_rand01(&g->rand_gen) < .5) e->vx = vel;
+            else e->vy = vel;
+            e->smart_step = 1;
+            e->collides_with_entities = 1;
+        }
+    }
+    for (int i = 0; i < n; i++)
+        if (g->grid[i] == CF_MARKER) g->grid[i] = SPACE;
+    g->out_of_bounds_object = CF_CAVEWALL;
+    g->visibility = g->opt.distribution_mode == 0 ? 10.0f : 16.0f;
 }
 
 /* ---- Chaser: chaser.cpp:137-390 ---- */
@@ -3338,6 +3628,11 @@ static void bag_game_reset(Game *g) { /* BAG:758-797 */
         else if (dm == 10) g->main_width = g->main_height = 35;
     }
     if (g->game_id == GAME_CHASER) g->main_width = g->main_height = g->maze_dim; /* choose_world_dim chaser.cpp:132-135 */
+    if (g->game_id == GAME_CAVEFLYER) { /* choose_world_dim caveflyer.cpp:131-146 */
+        int dm = g->opt.distribution_mode;
+        int wd = dm == 0 ? 30 : (dm == 1 ? 40 : (dm == 10 ? 60 : 20));
+        g->main_width = g->main_height = wd;
+    }
     if (g->game_id == GAME_DODGEBALL) { /* choose_world_dim dodgeball.cpp:250-259 */
         int wd = g->opt.distribution_mode == 10 ? 40 : 20;
         g->main_width = g->main_height = wd;
@@ -3443,6 +3738,8 @@ static void game_reset(Game *g) {
         bf2_game_reset(g);
     } else if (g->game_id == GAME_CHASER) {
         ch_game_reset(g);
+    } else if (g->game_id == GAME_CAVEFLYER) {
+        cf_game_reset(g);
     } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:327-339 */
         g->center_agent = 0;
         sp_init_hps(g);
@@ -4126,6 +4423,8 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
         g->main_width = 64;
         g->main_height = 64;
         g->out_of_bounds_object = CR_WALL_MID;
+    } else if (game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:27-30 */
+        g->mixrate = 0.9f;
     } else if (game_id == GAME_CHASER) { /* chaser.cpp:38-49 */
         g->mixrate = 1;
         g->maxspeed = (float).5;

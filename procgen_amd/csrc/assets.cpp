@@ -111,6 +111,16 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(9, {"misc_assets/dirt.png"});
         add_themes(10, {"misc_assets/tile_bricksGrey.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_CAVEFLYER) {  // reference src/games/caveflyer.cpp:31-53
+        add_themes(1, {"misc_assets/ufoGreen2.png"});
+        add_themes(2, {"misc_assets/meteorBrown_big1.png"});
+        add_themes(3, {"misc_assets/ufoRed2.png"});
+        add_themes(4, {"misc_assets/laserBlue02.png"});
+        add_themes(5, {"misc_assets/enemyShipBlue4.png"});
+        add_themes(0, {"misc_assets/playerShip1_red.png"});
+        add_themes(8, {"misc_assets/groundA.png"});
+        add_themes(9, {"misc_assets/towerDefense_tile295.png"});
+        for (const char *n : SPACE_BGS) backgrounds->push_back(std::string("space_backgrounds/") + n + ".png");
     } else if (game_id == GAME_CHASER) {  // reference src/games/chaser.cpp:51-73, src/resources.cpp:913-918
         add_themes(0, {"misc_assets/enemyFloating_1b.png"});
         add_themes(6, {"misc_assets/enemyFlying_1.png"});
@@ -336,6 +346,7 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
     if (game_id == GAME_NINJA) ref_type = 20;
     if (game_id == GAME_DODGEBALL) ref_type = 10;
     if (game_id == GAME_CHASER) ref_type = 5;
+    if (game_id == GAME_CAVEFLYER) ref_type = 8;
     if (ref_type >= 0 && t.type_theme_img[ref_type][0] >= 0) {
         t.ref_w = t.img[t.type_theme_img[ref_type][0]].w;
         t.ref_h = t.img[t.type_theme_img[ref_type][0]].h;

@@ -2,6 +2,7 @@
 #pragma once
 #include "game_bigfish.h"
 #include "game_bossfight.h"
+#include "game_caveflyer.h"
 #include "game_chaser.h"
 #include "game_climber.h"
 #include "game_coinrun.h"
@@ -15,4 +16,4 @@
 #include "game_plunder.h"
 #include "game_starpilot.h"
 
-#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist) X(Ninja) X(Dodgeball) X(BossFight) X(Chaser)
+#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist) X(Ninja) X(Dodgeball) X(BossFight) X(Chaser) X(CaveFlyer)

@@ -905,6 +905,42 @@ struct Env {
             count++;
         }
     }
+    // k-th grid cell (ascending index) whose value satisfies pred (-1 if there are fewer), and their count
+    template <class Pred>
+    PG_DEV int nth_cell(int k, Pred pred) {
+        const int nc = G.main_width * G.main_height;
+        for (int base = 0; base < nc; base += 64) {
+            uint64_t m = PG_BALLOT(l, (base + l) < nc && pred((int)s->grid[base + l]));
+            const int c = pg_popc64(m);
+            if (k < c) {
+                for (int q = 0; q < k; q++) m &= m - 1;
+                return base + pg_ctz64(m);
+            }
+            k -= c;
+        }
+        return -1;
+    }
+    template <class Pred>
+    PG_DEV int count_cells(Pred pred) {
+        const int nc = G.main_width * G.main_height;
+        int n = 0;
+        for (int base = 0; base < nc; base += 64) n += pg_popc64(PG_BALLOT(l, (base + l) < nc && pred((int)s->grid[base + l])));
+        return n;
+    }
+    // RandGen::simple_choose (reference src/randgen.cpp:71-88): k <= 64 distinct draws below n, kept in s->tmp[0..k)
+    PG_DEV void simple_choose(int n, int k) {
+        if (!(k <= n) || k > 64) {
+            fail(PGE_ASSERT);
+            return;
+        }
+        for (int i = 0; i < k; i++) {
+            int next = randn(n);
+            while (PG_BALLOT(l, l < i && (int)s->tmp[l] == next) != 0) next = randn(n);
+            s->tmp[i] = (uint32_t)next;
+            PG_SYNC();
+        }
+    }
+
     PG_DEV bool agent_has_collision() {  // BAG:521-529
         const int n = G.n_ents;
         for (int c = 0; c < ((n + 63) >> 6); c++)

@@ -1,0 +1,216 @@
+// pg_roomgen.h -- RoomGenerator (reference src/roomgen.cpp) on one wave, over the env's grid in LDS.
+//
+// The cellular-automaton update and expand_room do not depend on a visiting order and run lane-parallel; build_room
+// (what lands in a room depends on the start cell only, but the quirk that the start cell joins only through a
+// neighbour is kept by walking the same queue) and find_path (the path IS the visiting order) walk their queues in
+// wave-uniform code.  std::set<int> objects are byte flags (ascending cell index == the set's iteration order).
+#pragma once
+#include "pg_env.h"
+
+namespace pgamd {
+
+template <int CELLS>
+struct RoomScratch {
+    uint8_t f0[CELLS], f1[CELLS], f2[CELLS], f3[CELLS];  // flag / cell buffers
+    uint16_t queue[CELLS + 64];                           // BFS queue / find_path's `expanded`
+    uint16_t parents[CELLS + 64];                         // find_path's `parents` (0xffff = -1)
+};
+
+template <class E, int CELLS>
+struct RoomGenDev {
+    E &e;
+    RoomScratch<CELLS> &m;
+    PG_DEV RoomGenDev(E &e_, RoomScratch<CELLS> &m_) : e(e_), m(m_) {}
+
+    PG_DEV int ncells() const { return e.G.main_width * e.G.main_height; }
+    PG_DEV int to_grid_idx(int x, int y) const { return (0 <= y && y < e.G.main_height && 0 <= x && x < e.G.main_width) ? y * e.G.main_width + x : -2; }
+    PG_DEV void clear(uint8_t *f) {
+        const int n = ncells();
+        for (int base = 0; base < n; base += 64) {
+            PG_FOR_LANES(l) {
+                if (base + l < n) f[base + l] = 0;
+            }
+        }
+        PG_SYNC();
+    }
+    PG_DEV void copy(uint8_t *dst, const uint8_t *src) {
+        const int n = ncells();
+        for (int base = 0; base < n; base += 64) {
+            PG_FOR_LANES(l) {
+                if (base + l < n) dst[base + l] = src[base + l];
+            }
+        }
+        PG_SYNC();
+    }
+
+    // update roomgen.cpp:22-37 (count_neighbors :3-20: the 3x3 block including the cell, out-of-range = out_of_bounds_object)
+    PG_DEV void update() {
+        const int n = ncells(), w = e.G.main_width, h = e.G.main_height;
+        const int oob_is_wall = e.G.out_of_bounds_object == WALL_OBJ ? 1 : 0;
+        for (int base = 0; base < n; base += 64) {
+            PG_FOR_LANES(l) {
+                const int idx = base + l;
+                if (idx < n) {
+                    const int x = idx % w, y = idx / w;
+                    int cnt = 0;
+                    for (int i = -1; i <= 1; i++)
+                        for (int j = -1; j <= 1; j++) {
+                            const int xx = x + i, yy = y + j;
+                            if (xx < 0 || xx >= w || yy < 0 || yy >= h) cnt += oob_is_wall;
+                            else cnt += (int)e.s->grid[yy * w + xx] == WALL_OBJ;
+                        }
+                    m.f0[idx] = (uint8_t)(cnt >= 5 ? WALL_OBJ : SPACE);
+                }
+            }
+        }
+        PG_SYNC();
+        for (int base = 0; base < n; base += 64) {
+            PG_FOR_LANES(l) {
+                if (base + l < n) e.s->grid[base + l] = (typename E::cell_t)m.f0[base + l];
+            }
+        }
+        PG_SYNC();
+    }
+
+    // build_room roomgen.cpp:39-70 into `room` (flags); returns the number of cells inserted
+    PG_DEV int build_room(int idx, uint8_t *room) {
+        const int w = e.G.main_width;
+        if ((int)e.s->grid[idx] != SPACE) return 0;
+        int head = 0, tail = 0, size = 0;
+        m.queue[tail++] = (uint16_t)idx;
+        while (head < tail) {
+            const int curr = PG_UNIFORM_I(m.queue[head]);
+            head++;
+            const int x = curr % w, y = curr / w;
+            const int nb[4] = {to_grid_idx(x - 1, y), to_grid_idx(x, y - 1), to_grid_idx(x, y + 1), to_grid_idx(x + 1, y)};
+            for (int k = 0; k < 4; k++) {
+                const int nx = nb[k];
+                if (nx >= 0 && !PG_UNIFORM_I(room[nx]) && PG_UNIFORM_I((int)e.s->grid[nx]) == SPACE) {
+                    m.queue[tail++] = (uint16_t)nx;
+                    room[nx] = 1;
+                    size++;
+                }
+            }
+        }
+        PG_SYNC();
+        return size;
+    }
+
+    // find_best_room roomgen.cpp:128-148 -> best room flags in f2 (all_rooms f0, candidate f1); returns its size
+    PG_DEV int find_best_room() {
+        const int n = ncells();
+        clear(m.f0);
+        clear(m.f2);
+        int best_size = -1;
+        for (int base = 0; base < n; base += 64) {
+            // cells of this chunk that are SPACE and in no room yet (rooms found while walking the chunk are re-checked)
+            uint64_t cand = PG_BALLOT(l, (base + l) < n && (int)e.s->grid[base + l] == SPACE);
+            while (cand) {
+                const int i = base + pg_ctz64(cand);
+                cand &= cand - 1;
+                if (PG_UNIFORM_I(m.f0[i])) continue;
+                clear(m.f1);
+                const int sz = build_room(i, m.f1);
+                for (int b2 = 0; b2 < n; b2 += 64) {
+                    PG_FOR_LANES(l) {
+                        if (b2 + l < n) m.f0[b2 + l] = m.f0[b2 + l] | m.f1[b2 + l];
+                    }
+                }
+                PG_SYNC();
+                if (sz > best_size) {
+                    best_size = sz;
+                    copy(m.f2, m.f1);
+                }
+            }
+        }
+        return best_size;
+    }
+
+    // find_path roomgen.cpp:72-126 -> path membership flags in `path`; returns the path length
+    PG_DEV int find_path(int src, int dst, uint8_t *path, uint8_t *covered) {
+        const int w = e.G.main_width;
+        clear(covered);
+        clear(path);
+        if ((int)e.s->grid[src] != SPACE) return 0;
+        int ne = 0;
+        m.queue[0] = (uint16_t)src;
+        m.parents[0] = 0xffffu;
+        ne = 1;
+        int search_idx = 0;
+        bool found = false;
+        while (search_idx < ne) {
+            const int curr = PG_UNIFORM_I(m.queue[search_idx]);
+            if (curr == dst) {
+                found = true;
+                break;
+            }
+            const int x = curr % w, y = curr / w;
+            const int nb[4] = {to_grid_idx(x - 1, y), to_grid_idx(x, y - 1), to_grid_idx(x, y + 1), to_grid_idx(x + 1, y)};
+            for (int k = 0; k < 4; k++) {
+                const int nx = nb[k];
+                if (nx >= 0 && !PG_UNIFORM_I(covered[nx]) && PG_UNIFORM_I((int)e.s->grid[nx]) == SPACE) {
+                    if (ne >= CELLS + 64) {
+                        e.fail(PGE_ASSERT);
+                        return 0;
+                    }
+                    m.queue[ne] = (uint16_t)nx;
+                    m.parents[ne] = (uint16_t)search_idx;
+                    ne++;
+                    covered[nx] = 1;
+                }
+            }
+            search_idx++;
+        }
+        int len = 0;
+        if (found) {
+            int k = search_idx;
+            while (k != 0xffff) {
+                path[PG_UNIFORM_I(m.queue[k])] = 1;
+                len++;
+                k = PG_UNIFORM_I(m.parents[k]);
+            }
+        }
+        PG_SYNC();
+        return len;
+    }
+
+    // expand_room roomgen.cpp:150-182: `set` grows by n_loops rings of 8-connected SPACE cells (curr / next: scratch flags)
+    PG_DEV void expand_room(uint8_t *set, int n_loops, uint8_t *curr, uint8_t *next) {
+        const int n = ncells(), w = e.G.main_width, h = e.G.main_height;
+        copy(curr, set);
+        for (int loop = 0; loop < n_loops; loop++) {
+            for (int base = 0; base < n; base += 64) {
+                PG_FOR_LANES(l) {
+                    const int idx = base + l;
+                    if (idx < n) {
+                        bool add = false;
+                        if (!set[idx] && (int)e.s->grid[idx] == SPACE) {
+                            const int x = idx % w, y = idx / w;
+                            for (int i = -1; i <= 1; i++)
+                                for (int j = -1; j <= 1; j++) {
+                                    const int xx = x + i, yy = y + j;
+                                    if ((i != 0 || j != 0) && xx >= 0 && xx < w && yy >= 0 && yy < h) {
+                                        const int c = yy * w + xx;
+                                        add = add || (curr[c] && (int)e.s->grid[c] == SPACE);
+                                    }
+                                }
+                        }
+                        next[idx] = add ? 1 : 0;
+                    }
+                }
+            }
+            PG_SYNC();
+            for (int base = 0; base < n; base += 64) {
+                PG_FOR_LANES(l) {
+                    if (base + l < n) {
+                        set[base + l] = set[base + l] | next[base + l];
+                        curr[base + l] = next[base + l];
+                    }
+                }
+            }
+            PG_SYNC();
+        }
+    }
+};
+
+}  // namespace pgamd
