@@ -8,7 +8,7 @@
  * the reference's PyPI-wheel flags (-march=ivybridge, reference procgen/CMakeLists.txt:28-31).
  *
  * Games restated so far: coinrun, bigfish, maze (with MazeGen::generate_maze / place_objects), climber, miner,
- * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors), ninja, dodgeball, bossfight, chaser (with MazeGen::generate_maze_no_dead_ends), caveflyer (with RoomGenerator).
+ * starpilot, fruitbot, leaper, plunder, heist (with MazeGen::generate_maze_with_doors), ninja, dodgeball, bossfight, chaser (with MazeGen::generate_maze_no_dead_ends), caveflyer (with RoomGenerator), jumper (compass drawn with Qt's midpoint ellipse and cosmetic line).
  */
 #include "procgen_oracle.h"
 
@@ -38,7 +38,20 @@ static const float PI_F = 3.14159265358979323846264338327950288f; /* src/cpp-uti
 static const float POS_EPS = -0.001f;   /* BAG:10 */
 static const float RENDER_EPS = 0.02f;  /* BAG:14 */
 
-enum { GAME_BIGFISH = 0, GAME_BOSSFIGHT = 1, GAME_CAVEFLYER = 2, GAME_CHASER = 3, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_DODGEBALL = 6, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_NINJA = 13, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+enum { GAME_BIGFISH = 0, GAME_BOSSFIGHT = 1, GAME_CAVEFLYER = 2, GAME_CHASER = 3, GAME_CLIMBER = 4, GAME_COINRUN = 5, GAME_DODGEBALL = 6, GAME_FRUITBOT = 7, GAME_HEIST = 8, GAME_JUMPER = 9, GAME_LEAPER = 10, GAME_MAZE = 11, GAME_MINER = 12, GAME_NINJA = 13, GAME_PLUNDER = 14, GAME_STARPILOT = 15 };
+
+/* jumper.cpp:11-27 */
+#define JP_GOAL 1
+#define JP_SPIKE 2
+#define JP_CAVEWALL 6
+#define JP_CAVEWALL_TOP 7
+#define JP_PLAYER_JUMP 9
+#define JP_PLAYER_LEFT1 10
+#define JP_PLAYER_LEFT2 11
+#define JP_PLAYER_RIGHT1 12
+#define JP_PLAYER_RIGHT2 13
+#define JP_MAZE_SCALE 3
+#define JP_JUMP_COOLDOWN 3
 
 /* caveflyer.cpp:9-21 */
 #define CF_GOAL 1
@@ -497,6 +510,25 @@ static void assets_build(int game_id) {
         assets_type(a, MN_OOB_WALL, "misc_assets/tile_bricksGrey.png");
         a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
         for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
+    } else if (game_id == GAME_JUMPER) { /* jumper.cpp:50-80 */
+        assets_type(a, PLAYER, "misc_assets/bunny2_ready.png");
+        assets_type(a, JP_SPIKE, "misc_assets/spikeMan_stand.png");
+        assets_type(a, JP_GOAL, "misc_assets/carrot.png");
+        assets_type(a, JP_PLAYER_JUMP, "misc_assets/bunny2_jump.png");
+        assets_type(a, JP_PLAYER_RIGHT1, "misc_assets/bunny2_walk1.png");
+        assets_type(a, JP_PLAYER_RIGHT2, "misc_assets/bunny2_walk2.png");
+        assets_type(a, JP_PLAYER_LEFT1, "misc_assets/bunny2_walk1.png");
+        assets_type(a, JP_PLAYER_LEFT2, "misc_assets/bunny2_walk2.png");
+        assets_type(a, JP_CAVEWALL_TOP, "platformer/tileBlue_05.png");
+        assets_type(a, JP_CAVEWALL_TOP, "platformer/tileGreen_05.png");
+        assets_type(a, JP_CAVEWALL_TOP, "platformer/tileYellow_06.png");
+        assets_type(a, JP_CAVEWALL_TOP, "platformer/tileBrown_06.png");
+        assets_type(a, JP_CAVEWALL, "platformer/tileBlue_08.png");
+        assets_type(a, JP_CAVEWALL, "platformer/tileGreen_08.png");
+        assets_type(a, JP_CAVEWALL, "platformer/tileYellow_09.png");
+        assets_type(a, JP_CAVEWALL, "platformer/tileBrown_09.png");
+        a->n_bg = (int)(sizeof(PLATFORM_BGS) / sizeof(PLATFORM_BGS[0]));
+        for (int i = 0; i < a->n_bg; i++) a->bg_img[i] = assets_add(a, PLATFORM_BGS[i], 1);
     } else if (game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:35-53 */
         assets_type(a, CF_GOAL, "misc_assets/ufoGreen2.png");
         assets_type(a, CF_OBSTACLE, "misc_assets/meteorBrown_big1.png");
@@ -698,6 +730,7 @@ int pgo_game_id(const char *name) {
     if (strcmp(name, "bossfight") == 0) return GAME_BOSSFIGHT;
     if (strcmp(name, "chaser") == 0) return GAME_CHASER;
     if (strcmp(name, "caveflyer") == 0) return GAME_CAVEFLYER;
+    if (strcmp(name, "jumper") == 0) return GAME_JUMPER;
     return -1;
 }
 int pgo_num_images(int game_id) {
@@ -772,6 +805,10 @@ typedef struct {
     int diamonds_remaining;
     /* MazeGame: maze.cpp:12-14 */
     int maze_dim, world_dim;
+    /* Jumper: jumper.cpp:31-39 (has_support, facing_right, wall_theme shared) */
+    int goal; /* pool id */
+    int jump_count, jump_delta, jump_time;
+    float compass_dim;
     /* ChaserGame: chaser.cpp:27-36 (maze_dim shared with MazeGame; free_cells / is_space_vec follow from the grid) */
     int eat_timeout, egg_timeout, eat_time, total_enemies, total_orbs, orbs_collected;
     /* BossfightGame: bossfight.cpp:35-61 (last_fire_time shared) */
@@ -895,6 +932,7 @@ static int hook_is_blocked(const Game *g, const Ent *src, int target, int is_hor
     }
     if (g->game_id == GAME_CHASER && target == CH_MAZE_WALL) return 1; /* chaser.cpp:90-95 */
     if (g->game_id == GAME_CAVEFLYER && src->type == PLAYER && target == CF_CAVEWALL) return 1; /* caveflyer.cpp:87-94 */
+    if (g->game_id == GAME_JUMPER && src->type == PLAYER && (target == JP_CAVEWALL || target == JP_CAVEWALL_TOP)) return 1; /* jumper.cpp:108-115 */
     if (g->game_id == GAME_FRUITBOT) { /* fruitbot.cpp:84-86 */
         if (src->type == PLAYER && target == FB_OUT_OF_BOUNDS_WALL) return 1;
     }
@@ -957,6 +995,14 @@ static void hook_handle_agent_collision(Game *g, Ent *obj) {
             g->reward += 1.0f;
             g->coins_collected += 1;
             obj->will_erase = 1;
+        }
+    } else if (g->game_id == GAME_JUMPER) { /* jumper.cpp:82-92 */
+        if (obj->type == JP_GOAL) {
+            g->reward += 10.0f;
+            g->level_complete = 1;
+            g->done = 1;
+        } else if (obj->type == JP_SPIKE) {
+            g->done = 1;
         }
     } else if (g->game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:55-69 */
         if (obj->type == CF_GOAL) {
@@ -1448,6 +1494,26 @@ static void hook_set_action_xy(Game *g, int move_act) {
         g->has_support = s1 || s2;
         if (g->has_support && g->action_vy == 1) g->action_vy = 1;
         else g->action_vy = 0;
+    } else if (g->game_id == GAME_JUMPER) { /* jumper.cpp:398-430 */
+        Ent *agent = &g->pool[g->agent];
+        if (g->action_vy < 0) g->action_vy = 0;
+        if (g->action_vx > 0) g->facing_right = 1;
+        if (g->action_vx < 0) g->facing_right = 0;
+        int obj_below_1 = get_obj_from_floats(g, (float)(agent->x - (agent->rx - .01)), (float)(agent->y - (agent->ry + .01)));
+        int obj_below_2 = get_obj_from_floats(g, (float)(agent->x + (agent->rx - .01)), (float)(agent->y - (agent->ry + .01)));
+        g->jump_delta = 0;
+        int s1 = obj_below_1 == JP_CAVEWALL || obj_below_1 == JP_CAVEWALL_TOP || obj_below_1 == g->out_of_bounds_object;
+        int s2 = obj_below_2 == JP_CAVEWALL || obj_below_2 == JP_CAVEWALL_TOP || obj_below_2 == g->out_of_bounds_object;
+        g->has_support = s1 || s2;
+        if (g->has_support) g->jump_count = 2;
+        if (g->action_vy == 1 && g->jump_count > 0 && (g->cur_time - g->jump_time > JP_JUMP_COOLDOWN)) {
+            g->jump_count -= 1;
+            g->jump_delta = -1;
+        } else {
+            g->action_vy = 0;
+        }
+        if (g->action_vy > 0) g->jump_time = g->cur_time;
+        g->action_vrot = 0;
     } else if (g->game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:264-285 */
         const Ent *agent = &g->pool[g->agent];
         float acceleration = (float)(move_act % 3 - 1);
@@ -1501,6 +1567,10 @@ static void hook_update_agent_velocity(Game *g) {
             agent->vy -= g->gravity;
             agent->vy = clip_abs(agent->vy, g->max_jump);
         }
+    } else if (g->game_id == GAME_JUMPER) { /* jumper.cpp:94-100 */
+        float v_scale = 1.0;
+        agent->vx = (1 - g->mixrate) * agent->vx + g->mixrate * g->maxspeed * g->action_vx * v_scale;
+        if (g->action_vy != 0) agent->vy = g->maxspeed * g->action_vy * 2;
     } else if (g->game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:71-78, BAG:502-504,681-684 */
         float v_scale = 1.0;
         agent->vx = (float)(agent->vx + g->mixrate * g->maxspeed * g->action_vx * v_scale * .2);
@@ -1671,6 +1741,17 @@ static void game_step(Game *g) {
         bf2_game_step_tail(g);
     } else if (g->game_id == GAME_CHASER) {
         ch_game_step_tail(g);
+    } else if (g->game_id == GAME_JUMPER) { /* jumper.cpp:432-449 */
+        Ent *agent = &g->pool[g->agent];
+        if (g->action_vx > 0) agent->is_reflected = 0;
+        if (g->action_vx < 0) agent->is_reflected = 1;
+        if (fabs((double)agent->vx) + fabs((double)agent->vy) > .05) {
+            Ent *trail = push_entity(g, agent->x, (float)(agent->y - agent->ry * .5), 0, 0.01f, 0.3f, 0.2f, TRAIL);
+            trail->expire_time = 8;
+            trail->alpha = (float).5;
+        }
+        agent = &g->pool[g->agent];
+        if (agent->vy > -2) agent->vy -= 0.15f;
     } else if (g->game_id == GAME_CAVEFLYER) { /* caveflyer.cpp:287-324 */
         if (g->special_action == 1) {
             const Ent *agent = &g->pool[g->agent];
@@ -2221,6 +2302,124 @@ static void rg_expand_room(const Game *g, unsigned char *set, int n_loops) { /* 
         }
         memcpy(curr, next, (size_t)n);
     }
+}
+
+/* ---- Jumper: jumper.cpp:180-396 ---- */
+static int jp_is_space_on_ground(const Game *g, int x, int y) { /* jumper.cpp:180-187 */
+    if (get_obj(g, x, y) != SPACE) return 0;
+    if (get_obj(g, x, y + 1) != SPACE) return 0;
+    int below_obj = get_obj(g, x, y - 1);
+    return below_obj == JP_CAVEWALL || below_obj == g->out_of_bounds_object;
+}
+static int jp_is_left_wall(const Game *g, int x, int y) { return get_obj(g, x, y) == JP_CAVEWALL && get_obj(g, x + 1, y) == SPACE; }  /* :193-195 */
+static int jp_is_right_wall(const Game *g, int x, int y) { return get_obj(g, x, y) == JP_CAVEWALL && get_obj(g, x - 1, y) == SPACE; } /* :197-199 */
+static void jp_pre_reset(Game *g) { /* jumper.cpp:219-231: before BasicAbstractGame::game_reset */
+    if (g->opt.distribution_mode == 0) {
+        g->visibility = 12;
+        g->compass_dim = 3;
+    } else {
+        g->visibility = 16;
+        g->compass_dim = 2;
+    }
+    if (g->opt.distribution_mode == 10) g->timeout = 2000;
+}
+static void jp_game_reset(Game *g) { /* jumper.cpp:233-388 */
+    static MazeGen mg;
+    int n = g->grid_w * g->grid_h, mw = g->main_width;
+    g->out_of_bounds_object = WALL_OBJ;
+    g->wall_theme = rng_randn(&g->rand_gen, 4);
+    g->jump_count = 0;
+    g->jump_delta = 0;
+    g->jump_time = 0;
+    g->has_support = 0;
+    g->facing_right = 1;
+    int maze_dim = g->main_width / JP_MAZE_SCALE;
+    mg.maze_dim = maze_dim;
+    mg.array_dim = maze_dim + 2;
+    mg_generate_maze_no_dead_ends(&mg, &g->rand_gen);
+    for (int i = 0; i < n; i++) {
+        int obj = mg.grid[((i / mw) / JP_MAZE_SCALE + 1) * mg.array_dim + (i % mw) / JP_MAZE_SCALE + 1];
+        float prob = obj == WALL_OBJ ? (float).8 : (float).2;
+        g->grid[i] = rng_rand01(&g->rand_gen) < prob ? WALL_OBJ : SPACE;
+    }
+    for (int it = 0; it < 2; it++) rg_update(g);
+    for (int i = 0; i < g->main_width; i++) {
+        set_obj(g, i, 0, JP_CAVEWALL);
+        set_obj(g, i, g->main_height - 1, JP_CAVEWALL);
+    }
+    for (int i = 0; i < g->main_height; i++) {
+        set_obj(g, 0, i, JP_CAVEWALL);
+        set_obj(g, g->main_width - 1, i, JP_CAVEWALL);
+    }
+    static unsigned char best_room[MAX_GRID], all_rooms[MAX_GRID], next_room[MAX_GRID], wide_path[MAX_GRID];
+    static int cells[MAX_GRID], goal_path[2 * MAX_GRID];
+    {
+        memset(all_rooms, 0, (size_t)n);
+        memset(best_room, 0, (size_t)n);
+        int best_size = -1;
+        for (int i = 0; i < n; i++)
+            if (g->grid[i] == SPACE && !all_rooms[i]) {
+                memset(next_room, 0, (size_t)n);
+                int sz = rg_build_room(g, i, next_room);
+                for (int c = 0; c < n; c++) all_rooms[c] |= next_room[c];
+                if (sz > best_size) {
+                    best_size = sz;
+                    memcpy(best_room, next_room, (size_t)n);
+                }
+            }
+        if (best_size <= 0) fatal("fassert best_room.size() > 0 (jumper.cpp:275)");
+    }
+    int nc = 0;
+    for (int i = 0; i < n; i++) g->grid[i] = JP_CAVEWALL;
+    for (int i = 0; i < n; i++)
+        if (best_room[i]) {
+            g->grid[i] = SPACE;
+            cells[nc++] = i;
+        }
+    int goal_cell = cells[rng_randn(&g->rand_gen, nc)];
+    nc = 0;
+    for (int i = 0; i < n; i++)
+        if (jp_is_space_on_ground(g, i % mw, i / mw)) cells[nc++] = i;
+    if (nc <= 0) fatal("fassert elems.size() > 0 (randgen.cpp:44)");
+    int agent_cell = cells[rng_randn(&g->rand_gen, nc)];
+    int npath = rg_find_path(g, agent_cell, goal_cell, goal_path);
+    if (g->opt.distribution_mode != 10) {
+        memset(wide_path, 0, (size_t)n);
+        for (int k = 0; k < npath; k++) wide_path[goal_path[k]] = 1;
+        rg_expand_room(g, wide_path, 4);
+        for (int i = 0; i < n; i++) g->grid[i] = wide_path[i] ? SPACE : JP_CAVEWALL;
+    }
+    push_entity(g, (float)((goal_cell % mw) + .5), (float)((goal_cell / mw) + .5), 0, 0, (float).5, (float).5, JP_GOAL);
+    g->goal = g->ents[g->n_ents - 1];
+    float spike_prob = g->opt.distribution_mode == 10 ? 0 : (float).2;
+    for (int i = 0; i < n; i++) {
+        int x = i % mw, y = i / mw;
+        if (jp_is_space_on_ground(g, x, y) && (jp_is_space_on_ground(g, x - 1, y) && jp_is_space_on_ground(g, x + 1, y))) {
+            if (rng_rand01(&g->rand_gen) < spike_prob) set_obj(g, x, y, JP_SPIKE);
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        int x = i % mw, y = i / mw;
+        if (jp_is_left_wall(g, x, y) && jp_is_left_wall(g, x, y + 1) && jp_is_left_wall(g, x, y + 2)) set_obj(g, x, y + rng_randn(&g->rand_gen, 3), SPACE);
+        if (jp_is_right_wall(g, x, y) && jp_is_right_wall(g, x, y + 1) && jp_is_right_wall(g, x, y + 2)) set_obj(g, x, y + rng_randn(&g->rand_gen, 3), SPACE);
+    }
+    Ent *agent = &g->pool[g->agent];
+    agent->x = (float)((agent_cell % mw) + .5);
+    agent->y = (agent_cell / mw) + agent->ry;
+    for (int i = 0; i < n; i++)
+        if (g->grid[i] == JP_SPIKE) {
+            g->grid[i] = SPACE;
+            float spike_ry = 0.4f, spike_rx = 0.23f;
+            push_entity(g, (float)((i % mw) + .5), (i / mw) + spike_ry, 0, 0, spike_rx, spike_ry, JP_SPIKE);
+        }
+    for (int i = 0; i < n; i++) {
+        int x = i % mw, y = i / mw;
+        if (get_obj(g, x, y) == JP_CAVEWALL && get_obj(g, x, y + 1) == SPACE) set_obj(g, x, y, JP_CAVEWALL_TOP); /* is_top_wall :189-191 */
+    }
+    agent = &g->pool[g->agent];
+    agent->rx = 0.254f;
+    agent->ry = 0.4f;
+    g->out_of_bounds_object = JP_CAVEWALL;
 }
 
 /* ---- CaveFlyer: caveflyer.cpp:131-262 ---- */
@@ -3628,6 +3827,11 @@ static void bag_game_reset(Game *g) { /* BAG:758-797 */
         else if (dm == 10) g->main_width = g->main_height = 35;
     }
     if (g->game_id == GAME_CHASER) g->main_width = g->main_height = g->maze_dim; /* choose_world_dim chaser.cpp:132-135 */
+    if (g->game_id == GAME_JUMPER) { /* choose_world_dim jumper.cpp:201-217 */
+        int dm = g->opt.distribution_mode;
+        int wd = dm == 1 ? 40 : (dm == 10 ? 45 : 20);
+        g->main_width = g->main_height = wd;
+    }
     if (g->game_id == GAME_CAVEFLYER) { /* choose_world_dim caveflyer.cpp:131-146 */
         int dm = g->opt.distribution_mode;
         int wd = dm == 0 ? 30 : (dm == 1 ? 40 : (dm == 10 ? 60 : 20));
@@ -3693,6 +3897,7 @@ static void bag_game_reset(Game *g) { /* BAG:758-797 */
 
 static void game_reset(Game *g) {
     if (g->game_id == GAME_CHASER) ch_pre_reset(g);
+    if (g->game_id == GAME_JUMPER) jp_pre_reset(g);
     bag_game_reset(g);
     if (g->game_id == GAME_COINRUN) { /* coinrun.cpp:416-445 */
         Ent *agent = &g->pool[g->agent];
@@ -3740,6 +3945,8 @@ static void game_reset(Game *g) {
         ch_game_reset(g);
     } else if (g->game_id == GAME_CAVEFLYER) {
         cf_game_reset(g);
+    } else if (g->game_id == GAME_JUMPER) {
+        jp_game_reset(g);
     } else if (g->game_id == GAME_STARPILOT) { /* starpilot.cpp:327-339 */
         g->center_agent = 0;
         sp_init_hps(g);
@@ -4160,6 +4367,12 @@ static int hook_image_for_type(const Game *g, int type) {
         if (type == MN_MOVING_BOULDER) return MN_BOULDER;
         if (type == MN_MOVING_DIAMOND) return MN_DIAMOND;
     }
+    if (g->game_id == GAME_JUMPER && type == PLAYER) { /* jumper.cpp:117-132 */
+        const Ent *agent = &g->pool[g->agent];
+        if (fabs((double)agent->vx) < .01 && g->action_vx == 0 && g->has_support) return PLAYER;
+        if (g->facing_right) return (g->cur_time / 5 % 2 == 0 || !g->has_support) ? JP_PLAYER_RIGHT1 : JP_PLAYER_RIGHT2;
+        return (g->cur_time / 5 % 2 == 0 || !g->has_support) ? JP_PLAYER_LEFT1 : JP_PLAYER_LEFT2;
+    }
     if (g->game_id == GAME_CHASER && type == CH_ENEMY) { /* chaser.cpp:97-110 */
         if (g->cur_time - g->eat_time < g->eat_timeout) return CH_ENEMY_WEAK;
         int rem = (g->cur_time / 2) % 4;
@@ -4195,6 +4408,7 @@ static int hook_image_for_type(const Game *g, int type) {
 }
 static int hook_theme_for_grid_obj(const Game *g, int type) {
     if (g->game_id == GAME_NINJA && type == NJ_WALL_MID) return g->wall_theme; /* ninja.cpp:130-135 */
+    if (g->game_id == GAME_JUMPER && (type == JP_CAVEWALL || type == JP_CAVEWALL_TOP)) return g->wall_theme; /* jumper.cpp:102-107 */
     if ((g->game_id == GAME_COINRUN || g->game_id == GAME_CLIMBER) && cr_is_wall(type)) return g->wall_theme; /* coinrun.cpp:133-138, climber.cpp:102-107 */
     return 0;
 }
@@ -4260,6 +4474,133 @@ static void draw_entities(Game *g, uint32_t *dst, int render_z) { /* BAG:1052-10
             else if (m->type == FB_LOCKED_DOOR) tile_ratio = FB_DOOR_ASPECT_RATIO;
         }
         draw_image(g, dst, r1, m->rotation, m->is_reflected, m->image_type, m->image_theme, m->alpha, tile_ratio);
+    }
+}
+
+/* QRasterPaintEngine::drawEllipse on an integer-aligned rect without antialiasing: drawEllipse_midpoint_i +
+ * drawEllipsePoints (qpaintengine_raster.cpp, Qt 5.9.7), pen of width <= 1 (outline spans) and/or brush (fill spans).
+ * Third-party algorithm restated; pinned with tests/tools/qt_compass_probe.py. */
+typedef struct { uint32_t *dst; int rx, ry, rw, rh, pen; uint32_t pen_px, brush_px; } EllipseCtx;
+static void ell_span(const EllipseCtx *c, int sx, int sy, int len, uint32_t px) {
+    if (sy < 0 || sy >= RES_H) return;
+    for (int x = sx; x < sx + len; x++)
+        if (x >= 0 && x < RES_W) c->dst[sy * RES_W + x] = px + byte_mul(c->dst[sy * RES_W + x], 255u - (px >> 24));
+}
+static void ell_points(const EllipseCtx *c, int px, int py, int length) {
+    if (length == 0) return;
+    int midx = c->rx + (c->rw + 1) / 2, midy = c->ry + (c->rh + 1) / 2;
+    int x = px + midx, y = midy - py;
+    int o0x = midx + midx - x - (length - 1) - (c->rw & 1);
+    int o0len = length < x - o0x ? length : x - o0x;
+    int o2y = midy + midy - y - (c->rh & 1);
+    if (o0x + o0len < x) {
+        int f0x = o0x + o0len - 1, f0len = x - f0x > 0 ? x - f0x : 0;
+        ell_span(c, f0x, y, f0len, c->brush_px);
+        if (!(y >= o2y)) ell_span(c, f0x, o2y, f0len, c->brush_px);
+    }
+    if (c->pen) {
+        ell_span(c, o0x, y, o0len, c->pen_px);
+        ell_span(c, x, y, length, c->pen_px);
+        if (!(y >= o2y)) {
+            ell_span(c, o0x, o2y, o0len, c->pen_px);
+            ell_span(c, x, o2y, length, c->pen_px);
+        }
+    }
+}
+static void draw_ellipse_i(uint32_t *dst, int rx, int ry, int rw, int rh, int pen, uint32_t pen_px, uint32_t brush_px) {
+    if (rw <= 0 || rh <= 0) return;
+    EllipseCtx c = {dst, rx, ry, rw, rh, pen, pen_px, brush_px};
+    double a = rw / 2.0, b = rh / 2.0;
+    double d = b * b - (a * a * b) + 0.25 * a * a;
+    int x = 0, y = (rh + 1) / 2, startx = x;
+    while (a * a * (2 * y - 1) > 2 * b * b * (x + 1)) {
+        if (d < 0) {
+            d += b * b * (2 * x + 3);
+            ++x;
+        } else {
+            d += b * b * (2 * x + 3) + a * a * (-2 * y + 2);
+            ell_points(&c, startx, y, x - startx + 1);
+            startx = ++x;
+            --y;
+        }
+    }
+    ell_points(&c, startx, y, x - startx + 1);
+    d = b * b * (x + 0.5) * (x + 0.5) + a * a * ((y - 1) * (y - 1) - b * b);
+    int miny = rh & 1;
+    while (y > miny) {
+        if (d < 0) {
+            d += b * b * (2 * x + 2) + a * a * (-2 * y + 3);
+            ++x;
+        } else {
+            d += a * a * (-2 * y + 3);
+        }
+        --y;
+        ell_points(&c, x, y, 1);
+    }
+}
+/* QCosmeticStroker::drawLine (qcosmeticstroker.cpp, Qt 5.9.7) for a solid width-0 pen with square caps and integer
+ * end points: 26.6 end points, 16.16 minor-axis walker, half-pixel cap extension at both ends. */
+static int tdiv_i64(long long a, long long b) { return (int)(a / b); }
+static void draw_line_cosmetic(uint32_t *dst, int X1, int Y1, int X2, int Y2, uint32_t px) {
+#define PUT(xx, yy) do { if ((xx) >= 0 && (xx) < RES_W && (yy) >= 0 && (yy) < RES_H) dst[(yy) * RES_W + (xx)] = px; } while (0)
+    if (X1 == X2 && Y1 == Y2) { /* QPainter::drawLine of a point with caps: one pixel */
+        PUT(X1, Y1);
+        return;
+    }
+    int x1 = X1 * 64, y1 = Y1 * 64, x2 = X2 * 64, y2 = Y2 * 64;
+    int dx = abs(x2 - x1), dy = abs(y2 - y1);
+    if (dx < dy) {
+        if (y1 > y2) { int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t; }
+        int xinc = tdiv_i64((long long)(x2 - x1) * 65536, y2 - y1);
+        int x = x1 * 1024;
+        y1 -= 32; x -= xinc >> 1; y2 += 32;
+        int y = (y1 + 32) >> 6, ys = (y2 + 32) >> 6, rnd = xinc > 0 ? 32 : 0;
+        if (y != ys) {
+            x += (int)(((long long)((y * 64) + rnd - y1) * xinc) >> 6);
+            do {
+                PUT(x >> 16, y);
+                x += xinc;
+            } while (++y < ys);
+        }
+    } else {
+        if (!dx) return;
+        if (x1 > x2) { int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t; }
+        int yinc = tdiv_i64((long long)(y2 - y1) * 65536, x2 - x1);
+        int y = y1 * 1024;
+        x1 -= 32; y -= yinc >> 1; x2 += 32;
+        int x = (x1 + 32) >> 6, xs = (x2 + 32) >> 6, rnd = yinc > 0 ? 32 : 0;
+        if (x != xs) {
+            y += (int)(((long long)((x * 64) + rnd - x1) * yinc) >> 6);
+            do {
+                PUT(x, y >> 16);
+                y += yinc;
+            } while (++x < xs);
+        }
+    }
+#undef PUT
+}
+static void jp_draw_compass(Game *g, uint32_t *dst) { /* jumper.cpp:134-169 */
+    const Ent *agent = &g->pool[g->agent], *goal = &g->pool[g->goal];
+    float cxf = (float)(g->view_dim - g->compass_dim - .25), cyf = (float).25;
+    RectD cr_ = {cxf * g->unit, cyf * g->unit, g->compass_dim * g->unit, g->compass_dim * g->unit}; /* get_abs_rect BAG:803-805 */
+    int bx = (int)cr_.x, by = (int)cr_.y, bw = (int)cr_.w, bh = (int)cr_.h;
+    if ((double)bx != cr_.x || (double)by != cr_.y || (double)bw != cr_.w || (double)bh != cr_.h)
+        fatal("jumper compass on a non-integer rect (QPaintEngineEx path) is not restated");
+    draw_ellipse_i(dst, bx, by, bw, bh, 1, 0xffa8a69eu, 0xffa8a69eu);
+    float cx = (float)(cr_.x + cr_.w / 2);
+    float cy = (float)(cr_.y + cr_.h / 2);
+    float cr = (float)(cr_.w / 2 * .95);
+    float theta = (float)atan2((double)(goal->y - agent->y), (double)(goal->x - agent->x)); /* get_theta BAG:233-238 */
+    draw_line_cosmetic(dst, (int)cx, (int)cy, (int)(cx + cr * cos((double)theta)), (int)(cy - cr * sin((double)theta)), 0xfffcba03u);
+    float ddx = agent->x - goal->x, ddy = agent->y - goal->y;
+    float dist = (float)sqrt((double)(ddx * ddx + ddy * ddy)); /* get_distance BAG:133-143 */
+    float dist_pct = (float)(dist / (g->main_width * sqrt(2.0)));
+    float bar_thickness = g->compass_dim / 8;
+    RectD dr = {cxf * g->unit, (float)(.25 + g->compass_dim) * g->unit, (g->compass_dim * dist_pct) * g->unit, bar_thickness * g->unit};
+    fill_rect(dst, dr, 0xfffcba03u);
+    if (g->jump_delta < 0 && !g->has_support) {
+        RectD r1 = get_screen_rect(g, agent->x - agent->rx, agent->y + agent->ry, 2 * agent->rx, 2 * agent->ry, 0);
+        draw_ellipse_i(dst, (int)r1.x, (int)(r1.y + r1.h * (5.0 / 6)), (int)r1.w, (int)(r1.h / 3), 0, 0, 0x78787878u); /* QColor(255,255,255,120) premultiplied */
     }
 }
 
@@ -4330,6 +4671,7 @@ static void game_draw(Game *g, uint32_t *dst) { /* BAG:979-1012,921-970 */
         fill_rect(dst, d2, 0xff000000u | ((uint32_t)s1 << 16) | ((uint32_t)s1 << 8) | (uint32_t)s1);
         fill_rect(dst, d3, 0xff000000u | ((uint32_t)s2 << 16) | ((uint32_t)s2 << 8) | (uint32_t)s2);
     }
+    if (g->game_id == GAME_JUMPER && g->opt.distribution_mode != 10) jp_draw_compass(g, dst); /* jumper.cpp:171-178 */
     if (g->game_id == GAME_NINJA) { /* game_draw override ninja.cpp:170-177 */
         float bar_height = 3 * g->jump_charge;
         RectD r = {(float).25 * g->unit, (float)(g->visibility - .5 - bar_height) * g->unit, (float).5 * g->unit, bar_height * g->unit};

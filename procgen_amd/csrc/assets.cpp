@@ -111,6 +111,18 @@ bool game_asset_names(int game_id, std::vector<SpriteName> *sprites, std::vector
         add_themes(9, {"misc_assets/dirt.png"});
         add_themes(10, {"misc_assets/tile_bricksGrey.png"});
         platform_backgrounds(backgrounds);
+    } else if (game_id == GAME_JUMPER) {  // reference src/games/jumper.cpp:46-80
+        add_themes(0, {"misc_assets/bunny2_ready.png"});
+        add_themes(2, {"misc_assets/spikeMan_stand.png"});
+        add_themes(1, {"misc_assets/carrot.png"});
+        add_themes(9, {"misc_assets/bunny2_jump.png"});
+        add_themes(12, {"misc_assets/bunny2_walk1.png"});
+        add_themes(13, {"misc_assets/bunny2_walk2.png"});
+        add_themes(10, {"misc_assets/bunny2_walk1.png"});
+        add_themes(11, {"misc_assets/bunny2_walk2.png"});
+        add_themes(7, {"platformer/tileBlue_05.png", "platformer/tileGreen_05.png", "platformer/tileYellow_06.png", "platformer/tileBrown_06.png"});
+        add_themes(6, {"platformer/tileBlue_08.png", "platformer/tileGreen_08.png", "platformer/tileYellow_09.png", "platformer/tileBrown_09.png"});
+        platform_backgrounds(backgrounds);
     } else if (game_id == GAME_CAVEFLYER) {  // reference src/games/caveflyer.cpp:31-53
         add_themes(1, {"misc_assets/ufoGreen2.png"});
         add_themes(2, {"misc_assets/meteorBrown_big1.png"});
@@ -347,6 +359,7 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
     if (game_id == GAME_DODGEBALL) ref_type = 10;
     if (game_id == GAME_CHASER) ref_type = 5;
     if (game_id == GAME_CAVEFLYER) ref_type = 8;
+    if (game_id == GAME_JUMPER) ref_type = 6;
     if (ref_type >= 0 && t.type_theme_img[ref_type][0] >= 0) {
         t.ref_w = t.img[t.type_theme_img[ref_type][0]].w;
         t.ref_h = t.img[t.type_theme_img[ref_type][0]].h;

@@ -125,9 +125,15 @@ struct CaveFlyer : BagDefaults<CaveFlyer> {
             return;
         }
         G.out_of_bounds_object = WALL_OBJ;
-        for (int i = 0; i < n; i++) {  // one draw per cell, in index order
-            const bool wall = (double)e.rand01() < .5;
-            e.s->grid[i] = (cell_t)(wall ? WALL_OBJ : SPACE);
+        for (int base = 0; base < n; base += 64) {  // one draw per cell, in index order
+            PG_LANE_VAR(uint32_t, u);
+            e.rand_u32_lanes((n - base) < 64 ? (n - base) : 64, u);
+            PG_FOR_LANES(l) {
+                if (base + l < n) {
+                    const float r01 = (float)((double)PG_LV(u, l) / 4294967296.0);
+                    e.s->grid[base + l] = (cell_t)(((double)r01 < .5) ? WALL_OBJ : SPACE);
+                }
+            }
         }
         G.grid_dirty = 1;
         PG_SYNC();

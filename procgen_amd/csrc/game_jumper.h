@@ -1,0 +1,371 @@
+// game_jumper.h -- Jumper rules as a policy for Env<> / Renderer<> (reference procgen/src/games/jumper.cpp).
+// A double-jumping bunny in a cave: the level is a MazeGen maze blown up 3x, randomised, smoothed by RoomGenerator's
+// cellular automaton, reduced to the widened path from the agent to the carrot, then decorated with spikes; a
+// compass (midpoint ellipse + cosmetic line + distance bar, and a translucent shadow while double-jumping) is painted
+// over the frame.  Hard and memory modes; the easy-mode compass sits on a non-integer rect, which Qt draws through
+// its path engine -- not restated, refused at libenv_make.
+#pragma once
+#include "pg_game_defaults.h"
+#include "pg_mazegen.h"
+#include "pg_roomgen.h"
+
+namespace pgamd {
+
+struct JumperScratch {
+    union {
+        MazeScratch maze;                 // first the maze ...
+        RoomScratch<45 * 45> room;        // ... then the room generator (the maze is dead by then)
+    };
+};
+
+struct Jumper : BagDefaults<Jumper> {
+    static constexpr int GAME_ID = GAME_JUMPER;
+    static constexpr const char *NAME = "jumper";
+    typedef JumperScratch Scratch;
+    static constexpr int MAX_CELLS = 45 * 45;  // jumper.cpp:201-217 (memory mode)
+    static constexpr bool HAS_OVERLAY = true;
+    static constexpr int ENT_CAP_T0 = 64, ENT_CAP_T1 = 128, ENT_CAP_T2 = 256;  // agent, goal, spikes (~10-40), <= 8 trails
+    template <class E>
+    PG_DEV static int slots_needed_next_step(E &e) { return e.G.n_ents + 1 + 1; }
+
+    static constexpr int GOAL = 1, SPIKE = 2, CAVEWALL = 6, CAVEWALL_TOP = 7, PLAYER_JUMP = 9, PLAYER_LEFT1 = 10, PLAYER_LEFT2 = 11, PLAYER_RIGHT1 = 12,
+                         PLAYER_RIGHT2 = 13;
+    static constexpr int MAZE_SCALE = 3, JUMP_COOLDOWN = 3, NUM_WALL_THEMES = 4;
+
+#define JP_JUMP_COUNT(G) (G).gsi0
+#define JP_JUMP_DELTA(G) (G).gsi1
+#define JP_JUMP_TIME(G) (G).gsi2
+#define JP_HAS_SUPPORT(G) (G).gsi3
+#define JP_FACING_RIGHT(G) (G).gsi4
+#define JP_WALL_THEME(G) (G).gsi5
+#define JP_COMPASS_DIM(G) (G).gsf0
+
+    PG_DEV static bool is_wall(int t) { return t == CAVEWALL || t == CAVEWALL_TOP; }
+
+    static void construct(EnvHdr &G) { construct_defaults(G); }  // jumper.cpp:41-44
+    template <class E>
+    PG_DEV static void choose_world_dim(E &e) {  // jumper.cpp:201-217, preceded by game_reset's prologue :219-231
+        EnvHdr &G = e.G;
+        const int dm = e.d.opt.distribution_mode;
+        if (dm == EasyMode) {
+            G.visibility = 12;
+            JP_COMPASS_DIM(G) = 3;
+        } else {
+            G.visibility = 16;
+            JP_COMPASS_DIM(G) = 2;
+        }
+        if (dm == MemoryMode) G.timeout = 2000;
+        const int wd = dm == HardMode ? 40 : (dm == MemoryMode ? 45 : 20);
+        G.main_width = wd;
+        G.main_height = wd;
+    }
+    template <class E>
+    PG_DEV static bool is_blocked(E &e, int src_type, int target, bool) {  // jumper.cpp:108-115
+        return target == WALL_OBJ || target == e.G.out_of_bounds_object || (src_type == PLAYER && is_wall(target));
+    }
+    template <class E>
+    PG_DEV static void handle_agent_collision(E &e, int obj) {  // jumper.cpp:82-92
+        const int t = e.etype(obj);
+        if (t == GOAL) {
+            e.G.reward += 10.0f;
+            e.G.level_complete = 1;
+            e.G.done = 1;
+        } else if (t == SPIKE) {
+            e.G.done = 1;
+        }
+    }
+    template <class E>
+    PG_DEV static void update_agent_velocity(E &e) {  // jumper.cpp:94-100
+        EnvHdr &G = e.G;
+        const int ag = G.agent;
+        const float v_scale = 1.0f;
+        e.evx(ag) = (1 - G.mixrate) * e.evx(ag) + G.mixrate * G.maxspeed * G.action_vx * v_scale;
+        if (G.action_vy != 0) e.evy(ag) = G.maxspeed * G.action_vy * 2;
+    }
+    template <class E>
+    PG_DEV static void set_action_xy(E &e, int move_action) {  // jumper.cpp:398-430
+        EnvHdr &G = e.G;
+        G.action_vx = (float)(move_action / 3 - 1);
+        G.action_vy = (float)((move_action % 3) - 1);
+        if (G.action_vy < 0) G.action_vy = 0;
+        if (G.action_vx > 0) JP_FACING_RIGHT(G) = 1;
+        if (G.action_vx < 0) JP_FACING_RIGHT(G) = 0;
+        const int ag = G.agent;
+        const float ax = e.ex(ag), ay = e.ey(ag), arx = e.erx(ag), ary = e.ery(ag);
+        const float by = (float)((double)ay - ((double)ary + .01));
+        const int o1 = e.get_obj_from_floats((float)((double)ax - ((double)arx - .01)), by);
+        const int o2 = e.get_obj_from_floats((float)((double)ax + ((double)arx - .01)), by);
+        JP_JUMP_DELTA(G) = 0;
+        const bool s1 = is_wall(o1) || o1 == G.out_of_bounds_object;
+        const bool s2 = is_wall(o2) || o2 == G.out_of_bounds_object;
+        JP_HAS_SUPPORT(G) = (s1 || s2) ? 1 : 0;
+        if (JP_HAS_SUPPORT(G)) JP_JUMP_COUNT(G) = 2;
+        if (G.action_vy == 1 && JP_JUMP_COUNT(G) > 0 && (G.cur_time - JP_JUMP_TIME(G) > JUMP_COOLDOWN)) {
+            JP_JUMP_COUNT(G) -= 1;
+            JP_JUMP_DELTA(G) = -1;
+        } else {
+            G.action_vy = 0;
+        }
+        if (G.action_vy > 0) JP_JUMP_TIME(G) = G.cur_time;
+        G.action_vrot = 0;
+    }
+
+    // ---- level generation helpers (jumper.cpp:180-199) ----
+    template <class E>
+    PG_DEV static bool is_space_on_ground(E &e, int x, int y) {
+        if (e.get_obj(x, y) != SPACE) return false;
+        if (e.get_obj(x, y + 1) != SPACE) return false;
+        const int below = e.get_obj(x, y - 1);
+        return below == CAVEWALL || below == e.G.out_of_bounds_object;
+    }
+    template <class E>
+    PG_DEV static bool is_left_wall(E &e, int x, int y) { return e.get_obj(x, y) == CAVEWALL && e.get_obj(x + 1, y) == SPACE; }
+    template <class E>
+    PG_DEV static bool is_right_wall(E &e, int x, int y) { return e.get_obj(x, y) == CAVEWALL && e.get_obj(x - 1, y) == SPACE; }
+    // k-th cell index (ascending) satisfying an index predicate; -1 if fewer
+    template <class E, class Pred>
+    PG_DEV static int nth_index(E &e, int k, Pred pred, int *total = nullptr) {
+        const int nc = e.G.main_width * e.G.main_height;
+        int found = -1, seen = 0;
+        for (int base = 0; base < nc; base += 64) {
+            uint64_t m = PG_BALLOT(l, (base + l) < nc && pred(base + l));
+            const int c = pg_popc64(m);
+            if (found < 0 && k >= seen && k < seen + c) {
+                uint64_t mm = m;
+                for (int q = 0; q < k - seen; q++) mm &= mm - 1;
+                found = base + pg_ctz64(mm);
+                if (!total) return found;
+            }
+            seen += c;
+        }
+        if (total) *total = seen;
+        return found;
+    }
+
+    template <class E>
+    PG_DEV static void game_reset(E &e) {  // jumper.cpp:219-396
+        e.bag_game_reset();
+        EnvHdr &G = e.G;
+        typedef typename E::cell_t cell_t;
+        const int n = G.main_width * G.main_height, w = G.main_width, h = G.main_height;
+        const int dm = e.d.opt.distribution_mode;
+        G.out_of_bounds_object = WALL_OBJ;
+        JP_WALL_THEME(G) = e.randn(NUM_WALL_THEMES);
+        JP_JUMP_COUNT(G) = 0;
+        JP_JUMP_DELTA(G) = 0;
+        JP_JUMP_TIME(G) = 0;
+        JP_HAS_SUPPORT(G) = 0;
+        JP_FACING_RIGHT(G) = 1;
+        const int maze_dim = w / MAZE_SCALE;
+        PG_SYNC();
+        {
+            MazeGenDev<E> mg(e, e.s->scratch.maze, maze_dim);
+            mg.generate_maze_no_dead_ends();
+            for (int base = 0; base < n; base += 64) {  // one draw per cell; walls of the 3x maze are solid with p = .8, corridors with p = .2
+                PG_LANE_VAR(uint32_t, u);
+                e.rand_u32_lanes((n - base) < 64 ? (n - base) : 64, u);
+                PG_FOR_LANES(l) {
+                    const int i = base + l;
+                    if (i < n) {
+                        const int obj = mg.grid_at((i % w) / MAZE_SCALE + 1, (i / w) / MAZE_SCALE + 1);
+                        const float prob = obj == WALL_OBJ ? (float).8 : (float).2;
+                        const float r01 = (float)((double)PG_LV(u, l) / 4294967296.0);
+                        e.s->grid[i] = (cell_t)(r01 < prob ? WALL_OBJ : SPACE);
+                    }
+                }
+            }
+            PG_SYNC();
+        }
+        G.grid_dirty = 1;
+        RoomGenDev<E, 45 * 45> rg(e, e.s->scratch.room);
+        auto &m = e.s->scratch.room;
+        for (int it = 0; it < 2; it++) rg.update();
+        e.fill_elem(0, 0, w, 1, CAVEWALL);  // border cells
+        e.fill_elem(0, h - 1, w, 1, CAVEWALL);
+        e.fill_elem(0, 0, 1, h, CAVEWALL);
+        e.fill_elem(w - 1, 0, 1, h, CAVEWALL);
+        const int best = rg.find_best_room();  // flags in f2
+        if (best <= 0) {
+            e.fail(PGE_ASSERT);
+            return;
+        }
+        for (int base = 0; base < n; base += 64) {
+            PG_FOR_LANES(l) {
+                if (base + l < n) e.s->grid[base + l] = (cell_t)(m.f2[base + l] ? SPACE : CAVEWALL);
+            }
+        }
+        PG_SYNC();
+        const int nfree = e.count_cells([](int v) { return v == SPACE; });
+        const int goal_cell = e.nth_cell(e.randn(nfree), [](int v) { return v == SPACE; });  // choose_one(free_cells)
+        int ncand = 0;
+        nth_index(e, -1, [&](int i) { return is_space_on_ground(e, i % w, i / w); }, &ncand);
+        if (ncand <= 0) {
+            e.fail(PGE_ASSERT);
+            return;
+        }
+        const int agent_cell = nth_index(e, e.randn(ncand), [&](int i) { return is_space_on_ground(e, i % w, i / w); });
+        rg.find_path(agent_cell, goal_cell, m.f3, m.f0);
+        if (dm != MemoryMode) {  // should_prune
+            rg.copy(m.f1, m.f3);
+            rg.expand_room(m.f1, 4, m.f0, m.f2);
+            for (int base = 0; base < n; base += 64) {
+                PG_FOR_LANES(l) {
+                    if (base + l < n) e.s->grid[base + l] = (cell_t)(m.f1[base + l] ? SPACE : CAVEWALL);
+                }
+            }
+            PG_SYNC();
+        }
+        e.add_entity((float)((goal_cell % w) + .5), (float)((goal_cell / w) + .5), 0, 0, (float).5, GOAL);  // spawn_entity_at_idx BAG:577-583
+        const float spike_prob = dm == MemoryMode ? 0.0f : (float).2;
+        // spikes: a placed spike can only disqualify later cells, so candidates are balloted per chunk and re-checked at the visit
+        for (int base = 0; base < n; base += 64) {
+            uint64_t cand = PG_BALLOT(l, ({
+                                          const int i = base + l;
+                                          (i < n) && is_space_on_ground(e, i % w, i / w) && is_space_on_ground(e, i % w - 1, i / w) && is_space_on_ground(e, i % w + 1, i / w);
+                                      }));
+            while (cand) {
+                const int i = base + pg_ctz64(cand);
+                cand &= cand - 1;
+                const int x = i % w, y = i / w;
+                if (is_space_on_ground(e, x, y) && is_space_on_ground(e, x - 1, y) && is_space_on_ground(e, x + 1, y)) {
+                    if (e.rand01() < spike_prob) {
+                        e.s->grid[i] = (cell_t)SPIKE;
+                        PG_SYNC();
+                    }
+                }
+            }
+        }
+        // long vertical walls are broken up; an opened cell can create new walls further on, so the chunk's candidates
+        // are re-balloted after every change
+        for (int base = 0; base < n; base += 64) {
+            int from = 0;  // lanes below `from` are done
+            for (;;) {
+                const uint64_t lm = PG_BALLOT(l, ({
+                                                  const int i = base + l;
+                                                  (l >= from) && (i < n) && is_left_wall(e, i % w, i / w) && is_left_wall(e, i % w, i / w + 1) && is_left_wall(e, i % w, i / w + 2);
+                                              }));
+                const uint64_t rm = PG_BALLOT(l, ({
+                                                  const int i = base + l;
+                                                  (l >= from) && (i < n) && is_right_wall(e, i % w, i / w) && is_right_wall(e, i % w, i / w + 1) && is_right_wall(e, i % w, i / w + 2);
+                                              }));
+                if ((lm | rm) == 0) break;
+                const int l0 = pg_ctz64(lm | rm);
+                const int i = base + l0, x = i % w, y = i / w;
+                if ((lm >> l0) & 1ull) {
+                    e.set_obj(x, y + e.randn(3), SPACE);
+                    PG_SYNC();
+                }
+                // the right-wall test of the same cell sees the grid after the left-wall change
+                if (is_right_wall(e, x, y) && is_right_wall(e, x, y + 1) && is_right_wall(e, x, y + 2)) {
+                    e.set_obj(x, y + e.randn(3), SPACE);
+                    PG_SYNC();
+                }
+                from = l0 + 1;
+                if (from >= 64) break;
+            }
+        }
+        const int ag = G.agent;
+        e.ex(ag) = (float)((agent_cell % w) + .5);
+        e.ey(ag) = (agent_cell / w) + e.ery(ag);
+        for (int base = 0; base < n; base += 64) {  // spike cells become entities, ascending index
+            uint64_t sm = PG_BALLOT(l, (base + l) < n && (int)e.s->grid[base + l] == SPIKE);
+            while (sm) {
+                const int i = base + pg_ctz64(sm);
+                sm &= sm - 1;
+                e.s->grid[i] = (cell_t)SPACE;
+                const float spike_ry = 0.4f, spike_rx = 0.23f;
+                e.add_entity_rxy((float)((i % w) + .5), (i / w) + spike_ry, 0, 0, spike_rx, spike_ry, SPIKE);
+            }
+        }
+        PG_SYNC();
+        for (int base = 0; base < n; base += 64) {  // is_top_wall :189-191 (order-independent)
+            PG_LANE_VAR(uint32_t, top);
+            PG_FOR_LANES(l) {
+                const int i = base + l;
+                PG_LV(top, l) = (i < n && e.get_obj(i % w, i / w) == CAVEWALL && e.get_obj(i % w, i / w + 1) == SPACE) ? 1u : 0u;
+            }
+            PG_SYNC();
+            PG_FOR_LANES(l) {
+                if (PG_LV(top, l)) e.s->grid[base + l] = (cell_t)CAVEWALL_TOP;
+            }
+            PG_SYNC();
+        }
+        e.erx(ag) = 0.254f;
+        e.ery(ag) = 0.4f;
+        G.out_of_bounds_object = CAVEWALL;
+        G.grid_dirty = 1;
+        PG_SYNC();
+    }
+
+    template <class E>
+    PG_DEV static void game_step(E &e) {  // jumper.cpp:432-449
+        e.bag_game_step();
+        EnvHdr &G = e.G;
+        const int ag = G.agent;
+        if (G.action_vx > 0) e.set_flag(ag, MF_REFLECTED, false);
+        if (G.action_vx < 0) e.set_flag(ag, MF_REFLECTED, true);
+        if (pg_fabs((double)e.evx(ag)) + pg_fabs((double)e.evy(ag)) > .05) {
+            const int t = e.add_entity_rxy(e.ex(ag), (float)((double)e.ey(ag) - (double)e.ery(ag) * .5), 0, 0.01f, 0.3f, 0.2f, TRAIL);
+            e.ei(EF_EXPIRE_TIME, t) = 8;
+            e.ef(EF_ALPHA, t) = (float).5;
+        }
+        if (e.evy(ag) > -2) e.evy(ag) -= 0.15f;
+        PG_SYNC();
+    }
+
+    template <class E>
+    PG_DEV static int image_for_type(E &e, int type) {  // jumper.cpp:117-132
+        if (type == PLAYER) {
+            const EnvHdr &G = e.G;
+            if ((double)pg_fabsf(e.evx(G.agent)) < .01 && G.action_vx == 0 && JP_HAS_SUPPORT(G)) return PLAYER;
+            if (JP_FACING_RIGHT(G)) return (G.cur_time / 5 % 2 == 0 || !JP_HAS_SUPPORT(G)) ? PLAYER_RIGHT1 : PLAYER_RIGHT2;
+            return (G.cur_time / 5 % 2 == 0 || !JP_HAS_SUPPORT(G)) ? PLAYER_LEFT1 : PLAYER_LEFT2;
+        }
+        return type < 0 ? -type : type;
+    }
+    template <class E>
+    PG_DEV static int theme_for_grid_obj(E &e, int type) { return is_wall(type) ? JP_WALL_THEME(e.G) : 0; }  // jumper.cpp:102-107
+
+    // draw_compass jumper.cpp:134-169 (skipped in memory mode :171-178)
+    template <class R>
+    PG_DEV static void draw_overlay(R &r) {
+        const EnvHdr &G = r.G;
+        if (r.d.opt.distribution_mode == MemoryMode) return;
+        const int n = G.n_ents;
+        int goal = -1;
+        for (int c = 0; c < ((n + 63) >> 6) && goal < 0; c++) {
+            const uint64_t m = PG_BALLOT(l, ((c << 6) + l) < n && r.etype((c << 6) + l) == GOAL);
+            if (m) goal = (c << 6) + pg_highest(m);
+        }
+        if (goal < 0) {
+            r.fail(PGE_ASSERT);
+            return;
+        }
+        const int ag = G.agent;
+        const float cd = JP_COMPASS_DIM(G);
+        const float cxf = (float)((double)(G.view_dim - cd) - .25), cyf = (float).25;
+        const RectD cr_ = r.get_abs_rect(cxf, cyf, cd, cd);
+        const int bx = (int)cr_.x, by = (int)cr_.y, bw = (int)cr_.w, bh = (int)cr_.h;
+        if ((double)bx != cr_.x || (double)by != cr_.y || (double)bw != cr_.w || (double)bh != cr_.h) {
+            r.fail(PGE_UNSUPPORTED_DRAW);  // Qt's path engine draws ellipses on non-integer rects: not restated
+            return;
+        }
+        r.exec_ellipse(bx, by, bw, bh, true, 0xffa8a69eu, 0xffa8a69eu);
+        const float cx = (float)(cr_.x + cr_.w / 2);
+        const float cy = (float)(cr_.y + cr_.h / 2);
+        const float cr = (float)(cr_.w / 2 * .95);
+        const float theta = (float)pg_atan2((double)(r.ey(goal) - r.ey(ag)), (double)(r.ex(goal) - r.ex(ag)));  // get_theta BAG:233-238
+        r.exec_line((int)cx, (int)cy, (int)((double)cx + (double)cr * pg_cos((double)theta)), (int)((double)cy - (double)cr * pg_sin((double)theta)), 0xfffcba03u);
+        const float ddx = r.ex(ag) - r.ex(goal), ddy = r.ey(ag) - r.ey(goal);
+        const float dist = (float)pg_sqrt((double)(ddx * ddx + ddy * ddy));  // get_distance BAG:133-143
+        const float dist_pct = (float)((double)dist / (G.main_width * pg_sqrt(2.0)));
+        const float bar_thickness = cd / 8;
+        r.exec_fill(r.get_abs_rect(cxf, (float)(.25 + (double)cd), cd * dist_pct, bar_thickness), 0xfffcba03u);
+        if (JP_JUMP_DELTA(G) < 0 && !JP_HAS_SUPPORT(G)) {
+            const RectD r1 = r.get_screen_rect(r.ex(ag) - r.erx(ag), r.ey(ag) + r.ery(ag), 2 * r.erx(ag), 2 * r.ery(ag), 0);
+            r.exec_ellipse((int)r1.x, (int)(r1.y + r1.h * (5.0 / 6)), (int)r1.w, (int)(r1.h / 3), false, 0u, 0x78787878u);  // QColor(255,255,255,120), premultiplied
+        }
+    }
+};
+
+}  // namespace pgamd

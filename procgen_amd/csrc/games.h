@@ -9,6 +9,7 @@
 #include "game_dodgeball.h"
 #include "game_fruitbot.h"
 #include "game_heist.h"
+#include "game_jumper.h"
 #include "game_leaper.h"
 #include "game_maze.h"
 #include "game_miner.h"
@@ -16,4 +17,4 @@
 #include "game_plunder.h"
 #include "game_starpilot.h"
 
-#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist) X(Ninja) X(Dodgeball) X(BossFight) X(Chaser) X(CaveFlyer)
+#define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist) X(Ninja) X(Dodgeball) X(BossFight) X(Chaser) X(CaveFlyer) X(Jumper)

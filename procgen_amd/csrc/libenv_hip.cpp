@@ -210,6 +210,7 @@ VecGame::VecGame(int nenvs, VecOptions opts) {
     opts.consume_int("distribution_mode", &dist_mode);
     o.distribution_mode = dist_mode;
     if (dist_mode == EasyMode || dist_mode == HardMode) {
+        if (env_name == "jumper" && dist_mode == EasyMode) fatal("jumper easy mode is not provided by the HIP stepper yet (its compass lies on a non-integer rect, which Qt draws through the path engine)\n");
     } else if (dist_mode == ExtremeMode) {
         if (!(env_name == "chaser" || env_name == "dodgeball" || env_name == "leaper" || env_name == "starpilot")) fatal("fassert failed: extreme mode unsupported for %s\n", env_name.c_str());
     } else if (dist_mode == MemoryMode) {

@@ -362,6 +362,28 @@ struct Env {
         G.rand_idx += 1;
         return mt_temper(z);
     }
+    // `count` (<= 64) consecutive rand_gen draws at once: lane l gets the l-th of them (tempered u32; lanes >= count get
+    // 0).  Level generators that draw once per grid cell use this instead of 64 dependent trips to the generator state.
+    PG_DEV void rand_u32_lanes(int count, PG_LANE_REF(uint32_t, out)) {
+        int first = MT_N - G.rand_idx;  // draws still available before the next twist
+        if (first > count) first = count;
+        if (first < 0) first = 0;
+        const uint32_t *cur0 = rg_cur;
+        const int idx0 = G.rand_idx;
+        PG_FOR_LANES(l) { PG_LV(out, l) = l < first ? mt_temper(cur0[idx0 + l]) : 0u; }
+        G.rand_idx += first;
+        if (first < count) {
+            uint32_t *dst = (rg_cur == mt_a()) ? mt_b() : mt_a();
+            mt_twist(rg_cur, dst);
+            rg_cur = dst;
+            rg_in_lds = true;
+            const int rest = count - first;
+            PG_FOR_LANES(l) {
+                if (l >= first && l < count) PG_LV(out, l) = mt_temper(dst[l - first]);
+            }
+            G.rand_idx = rest;
+        }
+    }
     // write the live rand_gen state back to its HBM home (before the scratch is reused as framebuffer)
     PG_DEV void rand_flush() {
         if (rg_in_lds) {

@@ -703,6 +703,113 @@ struct Renderer {
         }
         PG_SYNC();
     }
+    // one horizontal span blended onto the band (spans of the ellipse / line primitives; px premultiplied ARGB)
+    PG_DEV void exec_span(int sx, int sy, int len, uint32_t px) {
+        if (sy < row0 || sy >= row1 || len <= 0) return;
+        PG_FOR_LANES(l) {
+            if (l >= sx && l < sx + len) {
+                uint32_t *dp = &fb[(sy - row0) * RES_W + l];
+                *dp = px + byte_mul(*dp, 255u - (px >> 24));
+            }
+        }
+        PG_SYNC();
+    }
+    // QRasterPaintEngine::drawEllipse on an integer-aligned rect, no antialiasing: drawEllipse_midpoint_i +
+    // drawEllipsePoints (Qt 5.9.7 qpaintengine_raster.cpp): brush spans, then outline spans of a pen of width <= 1.
+    // Pinned with tests/tools/qt_compass_probe.py.
+    PG_DEV void ellipse_points(int rx, int ry, int rw, int rh, bool pen, uint32_t pen_px, uint32_t brush_px, int px_, int py_, int length) {
+        if (length == 0) return;
+        const int midx = rx + (rw + 1) / 2, midy = ry + (rh + 1) / 2;
+        const int x = px_ + midx, y = midy - py_;
+        const int o0x = midx + midx - x - (length - 1) - (rw & 1);
+        const int o0len = length < x - o0x ? length : x - o0x;
+        const int o2y = midy + midy - y - (rh & 1);
+        if (o0x + o0len < x) {
+            const int f0x = o0x + o0len - 1, f0len = x - f0x > 0 ? x - f0x : 0;
+            exec_span(f0x, y, f0len, brush_px);
+            if (!(y >= o2y)) exec_span(f0x, o2y, f0len, brush_px);
+        }
+        if (pen) {
+            exec_span(o0x, y, o0len, pen_px);
+            exec_span(x, y, length, pen_px);
+            if (!(y >= o2y)) {
+                exec_span(o0x, o2y, o0len, pen_px);
+                exec_span(x, o2y, length, pen_px);
+            }
+        }
+    }
+    PG_DEV void exec_ellipse(int rx, int ry, int rw, int rh, bool pen, uint32_t pen_px, uint32_t brush_px) {
+        if (rw <= 0 || rh <= 0) return;
+        if (ry > row1 || ry + rh + 1 < row0) return;  // outside this band
+        const double a = rw / 2.0, b = rh / 2.0;
+        double d = b * b - (a * a * b) + 0.25 * a * a;
+        int x = 0, y = (rh + 1) / 2, startx = x;
+        while (a * a * (2 * y - 1) > 2 * b * b * (x + 1)) {
+            if (d < 0) {
+                d += b * b * (2 * x + 3);
+                ++x;
+            } else {
+                d += b * b * (2 * x + 3) + a * a * (-2 * y + 2);
+                ellipse_points(rx, ry, rw, rh, pen, pen_px, brush_px, startx, y, x - startx + 1);
+                startx = ++x;
+                --y;
+            }
+        }
+        ellipse_points(rx, ry, rw, rh, pen, pen_px, brush_px, startx, y, x - startx + 1);
+        d = b * b * (x + 0.5) * (x + 0.5) + a * a * ((y - 1) * (y - 1) - b * b);
+        const int miny = rh & 1;
+        while (y > miny) {
+            if (d < 0) {
+                d += b * b * (2 * x + 2) + a * a * (-2 * y + 3);
+                ++x;
+            } else {
+                d += a * a * (-2 * y + 3);
+            }
+            --y;
+            ellipse_points(rx, ry, rw, rh, pen, pen_px, brush_px, x, y, 1);
+        }
+    }
+    // QCosmeticStroker::drawLine (Qt 5.9.7 qcosmeticstroker.cpp): solid width-0 pen, square caps, integer end points:
+    // 26.6 end points, 16.16 minor-axis walker, half a pixel of cap at both ends.  Opaque colour.
+    PG_DEV void exec_line(int X1, int Y1, int X2, int Y2, uint32_t px) {
+        if (X1 == X2 && Y1 == Y2) {
+            exec_span(X1, Y1, (X1 >= 0 && X1 < RES_W) ? 1 : 0, px);
+            return;
+        }
+        int x1 = X1 * 64, y1 = Y1 * 64, x2 = X2 * 64, y2 = Y2 * 64;
+        const int dx = x2 - x1 < 0 ? x1 - x2 : x2 - x1, dy = y2 - y1 < 0 ? y1 - y2 : y2 - y1;
+        if (dx < dy) {
+            if (y1 > y2) { int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t; }
+            const int xinc = (int)(((long long)(x2 - x1) * 65536) / (y2 - y1));
+            int x = x1 * 1024;
+            y1 -= 32; x -= xinc >> 1; y2 += 32;
+            int y = (y1 + 32) >> 6;
+            const int ys = (y2 + 32) >> 6, rnd = xinc > 0 ? 32 : 0;
+            if (y != ys) {
+                x += (int)(((long long)((y * 64) + rnd - y1) * xinc) >> 6);
+                do {
+                    const int xx = x >> 16;
+                    exec_span(xx, y, (xx >= 0 && xx < RES_W) ? 1 : 0, px);
+                    x += xinc;
+                } while (++y < ys);
+            }
+        } else {
+            if (!dx) return;
+            if (x1 > x2) { int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t; }
+            const int yinc = (int)(((long long)(y2 - y1) * 65536) / (x2 - x1));
+            int y = y1 * 1024;
+            x1 -= 32; y -= yinc >> 1; x2 += 32;
+            int x = (x1 + 32) >> 6;
+            const int xs = (x2 + 32) >> 6, rnd = yinc > 0 ? 32 : 0;
+            if (x != xs) {
+                y += (int)(((long long)((x * 64) + rnd - x1) * yinc) >> 6);
+                do {
+                    exec_span(x, y >> 16, (x >= 0 && x < RES_W) ? 1 : 0, px);
+                    y += yinc;
+                } while (++x < xs);
+            }
+        }
+    }
     PG_DEV RectD get_abs_rect(float x, float y, float dx, float dy) const {  // BAG:803-805
         RectD r;
         r.x = (double)(x * G.unit);

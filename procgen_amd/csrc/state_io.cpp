@@ -253,6 +253,14 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
         w.i(h.gsi1);
     } else if (game_id == GAME_MINER) {  // reference src/games/miner.cpp:309-312
         w.i(h.gsi0);
+    } else if (game_id == GAME_JUMPER) {  // reference src/games/jumper.cpp:451-460
+        w.i(h.gsi0);
+        w.i(h.gsi1);
+        w.i(h.gsi2);
+        w.i(h.gsi3 ? 1 : 0);
+        w.i(h.gsi4 ? 1 : 0);
+        w.i(h.gsi5);
+        w.f(h.gsf0);
     } else if (game_id == GAME_CHASER) {  // reference src/games/chaser.cpp:392-403: free_cells / is_space_vec follow from the walls
         const int MAZE_WALL = 5;
         int nfree = 0;
@@ -519,6 +527,14 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         h.gsi1 = r.i();
     } else if (game_id == GAME_MINER) {
         h.gsi0 = r.i();
+    } else if (game_id == GAME_JUMPER) {
+        h.gsi0 = r.i();
+        h.gsi1 = r.i();
+        h.gsi2 = r.i();
+        h.gsi3 = r.i() > 0;
+        h.gsi4 = r.i() > 0;
+        h.gsi5 = r.i();
+        h.gsf0 = r.f();
     } else if (game_id == GAME_CHASER) {
         const int nf = r.i();
         if (!r.ok || nf < 0 || nf > cnt) return bad("set_state: chaser free_cells");

@@ -59,6 +59,7 @@ struct PgEmuLaneScope {
         pg_emu_lane() > 0 ? pg_first_ : v_;             \
     })
 #define PG_LANE_VAR(T, v) T v[64]
+#define PG_LANE_REF(T, v) T (&v)[64]
 #define PG_LV(v, l) v[l]
 #define PG_READLANE(v, k) v[k]
 #define PG_LANE_ARR(T, v, N) T v[N][64]
@@ -76,6 +77,7 @@ PG_DEV double pg_fabs(double x) { return fabs(x); }
 PG_DEV double pg_pow(double x, double y) { return pow(x, y); }  // glibc, as the reference
 PG_DEV double pg_sin(double x) { return sin(x); }
 PG_DEV double pg_cos(double x) { return cos(x); }
+PG_DEV double pg_atan2(double y, double x) { return atan2(y, x); }
 
 #else
 
@@ -95,6 +97,7 @@ PG_DEV double pg_cos(double x) { return cos(x); }
         __builtin_amdgcn_wave_barrier();                        \
     } while (0)
 #define PG_LANE_VAR(T, v) T v
+#define PG_LANE_REF(T, v) T &v  // a lane variable passed by reference
 #define PG_LV(v, l) v
 #define PG_LANE_ARR(T, v, N) T v[N]
 #define PG_LA(v, j, l) v[j]
@@ -115,6 +118,7 @@ PG_DEV double pg_fabs(double x) { return __builtin_fabs(x); }
 PG_DEV double pg_pow(double x, double y) { return pow(x, y); }
 PG_DEV double pg_sin(double x) { return sin(x); }
 PG_DEV double pg_cos(double x) { return cos(x); }
+PG_DEV double pg_atan2(double y, double x) { return atan2(y, x); }  // only feeds drawing code that truncates to pixels
 
 #endif
 

@@ -14,7 +14,7 @@ from helpers import HIP_LIB, action_stream, assert_rollouts_equal, hip_memcpy_dt
 pytestmark = pytest.mark.gpu
 
 
-GAMES = ["coinrun", "bigfish", "maze", "climber", "miner", "starpilot", "fruitbot", "leaper", "plunder", "heist", "ninja", "dodgeball", "bossfight", "chaser", "caveflyer"]
+GAMES = ["coinrun", "bigfish", "maze", "climber", "miner", "starpilot", "fruitbot", "leaper", "plunder", "heist", "ninja", "dodgeball", "bossfight", "chaser", "caveflyer", "jumper"]
 
 
 def make_env(n, game="coinrun", **kw):

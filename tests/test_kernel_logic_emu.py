@@ -11,7 +11,7 @@ import oracle_env
 from helpers import action_stream, assert_rollouts_equal, rollout
 
 
-@pytest.mark.parametrize("game,use_small", [("coinrun", True), ("coinrun", False), ("bigfish", True), ("maze", True), ("climber", True), ("miner", True), ("starpilot", True), ("fruitbot", True), ("leaper", True), ("plunder", True), ("heist", True), ("ninja", True), ("dodgeball", True), ("bossfight", True), ("chaser", True), ("caveflyer", True)])
+@pytest.mark.parametrize("game,use_small", [("coinrun", True), ("coinrun", False), ("bigfish", True), ("maze", True), ("climber", True), ("miner", True), ("starpilot", True), ("fruitbot", True), ("leaper", True), ("plunder", True), ("heist", True), ("ninja", True), ("dodgeball", True), ("bossfight", True), ("chaser", True), ("caveflyer", True), ("jumper", True)])
 def test_emulated_kernels_match_oracle(game, use_small):
     n, steps = 24, 260
     acts = action_stream(n, steps)

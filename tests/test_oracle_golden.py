@@ -14,7 +14,7 @@ import oracle_env
 from helpers import assert_rollouts_equal, rollout
 
 
-GAMES = ["coinrun", "bigfish", "maze", "climber", "miner", "starpilot", "fruitbot", "leaper", "plunder", "heist", "ninja", "dodgeball", "bossfight", "chaser", "caveflyer"]
+GAMES = ["coinrun", "bigfish", "maze", "climber", "miner", "starpilot", "fruitbot", "leaper", "plunder", "heist", "ninja", "dodgeball", "bossfight", "chaser", "caveflyer", "jumper"]
 
 
 @pytest.fixture(scope="module", params=GAMES)
