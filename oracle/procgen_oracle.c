@@ -4426,6 +4426,10 @@ static RectD hook_adjusted_image_rect(const Game *g, int type, RectD rect) {
     return rect;
 }
 
+static int hook_preserve_type_themes(const Game *g, int type) { /* should_preserve_type_themes: leaper.cpp:91-93, plunder.cpp:83-85, heist.cpp:37-39 */
+    return (g->game_id == GAME_LEAPER && type == PLAYER) || (g->game_id == GAME_PLUNDER && type == PL_SHIP) ||
+           (g->game_id == GAME_HEIST && (type == HS_KEY || type == HS_LOCKED_DOOR));
+}
 static void draw_image(Game *g, uint32_t *dst, RectD base_rect, float rotation, int is_reflected, int base_type, int theme, float alpha, float tile_ratio) { /* BAG:877-913 */
     int img_type = hook_image_for_type(g, base_type);
     if (img_type < 0) return;
@@ -4436,14 +4440,23 @@ static void draw_image(Game *g, uint32_t *dst, RectD base_rect, float rotation, 
             return;
         }
         if (img_type == SPACE) return; /* draw_grid_obj BAG:915-919 */
-        fatal("monochrome / colored grid objects not restated yet");
+        if (!g->opt.use_monochrome_assets) fatal("fassert(false) color_for_type BAG:477");
+        { /* color_for_type BAG:455-481 */
+            int th = theme;
+            if (g->opt.restrict_themes && !hook_preserve_type_themes(g, img_type)) th = 0;
+            int k = 4, kcubed = k * k * k, chunk = 256 / k;
+            if (!(img_type < kcubed)) fatal("fassert type < kcubed (BAG:465)");
+            int new_type = (29 * (img_type + 1)) % kcubed;
+            new_type = (new_type + 19 * th) % kcubed;
+            uint32_t cr = (uint32_t)(chunk * (new_type / (k * k) + 1) - 1), cg = (uint32_t)(chunk * ((new_type / k) % k + 1) - 1), cb = (uint32_t)(chunk * (new_type % k + 1) - 1);
+            fill_rect(dst, base_rect, 0xff000000u | (cr << 16) | (cg << 8) | cb);
+        }
+        return;
     }
     if (theme >= MAX_IMAGE_THEMES) fatal("fassert theme < MAX_IMAGE_THEMES (BAG:888)");
     RectD adjusted = hook_adjusted_image_rect(g, img_type, base_rect);
     int mt = theme; /* mask_theme_if_necessary BAG:450-453 (restrict_themes) */
-    if (g->opt.restrict_themes && !(g->game_id == GAME_LEAPER && img_type == PLAYER) && !(g->game_id == GAME_PLUNDER && img_type == PL_SHIP) &&
-        !(g->game_id == GAME_HEIST && (img_type == HS_KEY || img_type == HS_LOCKED_DOOR)))
-        mt = 0; /* should_preserve_type_themes leaper.cpp:91-93 */
+    if (g->opt.restrict_themes && !hook_preserve_type_themes(g, img_type)) mt = 0; /* should_preserve_type_themes leaper.cpp:91-93 */
     if (g->assets->type_num_themes[img_type] <= mt) fatal("asset theme out of range");
     const Img *img = &g->assets->img[g->assets->type_theme_img[img_type][mt]];
     if (rotation == 0) tile_image(dst, img, is_reflected, adjusted, tile_ratio, alpha);

@@ -35,9 +35,10 @@ struct HostMT {  // std::mt19937 (libstdc++ bits/random.tcc): seed, twist, tempe
     }
 };
 
-// Fills hdr[n] and rng[n][MT_SLOTS][MT_STRIDE] for envs [env_offset, env_offset + num_envs) of the global index space.
+// Fills hdr[n] and rng[n][MT_SLOTS][MT_STRIDE] for the envs env_offset + n * env_stride (n < num_envs) of the global
+// index space (stride > 1: the envs of one game of a joint handle, reference src/vecgame.cpp:309-310).
 template <class Game>
-inline void init_env_state(int num_envs, int rand_seed, int env_offset, EnvHdr *hdr, uint32_t *rng) {
+inline void init_env_state(int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng) {
     HostMT seedgen;
     seedgen.seed(rand_seed);
     for (int k = 0; k < env_offset; k++) seedgen.next();
@@ -49,6 +50,7 @@ inline void init_env_state(int num_envs, int rand_seed, int env_offset, EnvHdr *
         for (int k = 0; k < MT_SLOTS * MT_STRIDE; k++) st[k] = 0;
         HostMT lvl;
         lvl.seed((int)seedgen.next());  // games[n]->level_seed_rand_gen.seed(game_level_seed_gen.randint()), vecgame.cpp:314
+        for (int k = 1; k < env_stride; k++) seedgen.next();  // the draws of the other games' envs in between
         for (int k = 0; k < MT_N; k++) st[MT_STRIDE + k] = lvl.mt[k];
     }
 }

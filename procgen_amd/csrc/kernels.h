@@ -20,5 +20,5 @@ hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t 
 bool game_supported(int game_id);
 int game_tier_for(int game_id, int slots_needed);
 void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes);
-void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, EnvHdr *hdr, uint32_t *rng);
+void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
 }  // namespace pgamd

@@ -149,10 +149,10 @@ void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes) {
     }
 }
 
-void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, EnvHdr *hdr, uint32_t *rng) {
+void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng) {
     switch (game_id) {
 #define PG_X(Game) \
-    case Game::GAME_ID: init_env_state<Game>(num_envs, rand_seed, env_offset, hdr, rng); break;
+    case Game::GAME_ID: init_env_state<Game>(num_envs, rand_seed, env_offset, env_stride, hdr, rng); break;
         PG_FOR_EACH_GAME(PG_X)
 #undef PG_X
         default: break;

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -148,7 +149,8 @@ struct VecGame {
     bool pending = false;
     bool registered_obs = false;
 
-    VecGame(int nenvs, VecOptions opts);
+    // forced_name / stride / index: one game of a joint handle owns the envs index + i * stride
+    VecGame(int nenvs, VecOptions opts, const std::string &forced_name = "", int stride = 1, int index = 0);
     ~VecGame();
     void set_buffers(struct libenv_buffers *bufs);
     void launch(int mode);
@@ -158,9 +160,10 @@ struct VecGame {
     void set_state(int env_idx, const char *data, int length);
     void snapshot(int env_idx, EnvSnapshot *s);
     int env_offset = 0;
+    int env_stride = 1;
 };
 
-VecGame::VecGame(int nenvs, VecOptions opts) {
+VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int stride, int index) {
     num_envs = nenvs;
     if (num_envs <= 0) fatal("num_envs must be positive\n");
     std::string env_name, resource_root;
@@ -182,12 +185,16 @@ VecGame::VecGame(int nenvs, VecOptions opts) {
     opts.consume_int("env_offset", &env_offset);
     opts.consume_bool("host_observations", &host_observations);
 
+    if (!forced_name.empty()) {
+        env_name = forced_name;
+        env_stride = stride;
+        env_offset += index;
+    }
     if (env_name.empty()) fatal("fassert failed 'env_name != \"\"'\n");
     if (!(num_actions > 0)) fatal("fassert failed 'num_actions > 0'\n");
     if (!(num_levels >= 0)) fatal("fassert failed 'num_levels >= 0'\n");
     if (!(start_level >= 0)) fatal("fassert failed 'start_level >= 0'\n");
     if (render_human) fatal("render_human (512x512 antialiased info frame) is not provided by the HIP stepper\n");
-    if (env_name.find(',') != std::string::npos) fatal("joint games (comma separated env_name) are not provided by the HIP stepper yet\n");
     game_id = game_id_from_name(env_name);
     if (game_id < 0) fatal("unknown game %s\n", env_name.c_str());
     if (!game_supported(game_id)) fatal("game %s is not implemented in the HIP stepper yet\n", env_name.c_str());
@@ -226,7 +233,6 @@ VecGame::VecGame(int nenvs, VecOptions opts) {
     opts.consume_int("game_type", &game_type);
     opts.ensure_empty();
     if (o.use_generated_assets) fatal("use_generated_assets is not provided by the HIP stepper\n");
-    if (o.use_monochrome_assets || o.paint_vel_info) fatal("use_monochrome_assets / paint_vel_info are not provided by the HIP stepper yet\n");
     level_seed_range(num_levels, start_level, &o.level_seed_low, &o.level_seed_high);
 
     // tensortypes: reference src/vecgame.cpp:212-268
@@ -312,7 +318,7 @@ VecGame::VecGame(int nenvs, VecOptions opts) {
     {
         std::vector<EnvHdr> hdr(N);
         std::vector<uint32_t> rng(N * MT_SLOTS * MT_STRIDE);
-        game_init_state(game_id, num_envs, rand_seed, env_offset, hdr.data(), rng.data());
+        game_init_state(game_id, num_envs, rand_seed, env_offset, env_stride, hdr.data(), rng.data());
         HIP_CHECK(hipMemcpy(d.hdr, hdr.data(), N * sizeof(EnvHdr), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d.rng, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
     }
@@ -462,7 +468,7 @@ int VecGame::get_state(int e, char *data, int length) {  // reference src/vecgam
     snapshot(e, &s);
     int written = 0;
     std::string err;
-    if (!serialize_state(game_id, d.opt, env_offset + e, s, data, length, &written, &err)) fatal("%s\n", err.c_str());
+    if (!serialize_state(game_id, d.opt, env_offset + e * env_stride, s, data, length, &written, &err)) fatal("%s\n", err.c_str());
     return written;
 }
 
@@ -513,16 +519,62 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
 
 }  // namespace
 
+// One libenv handle: a single game, or the games of a comma separated env_name (reference src/vecgame.cpp:295-310:
+// env n plays names[n % K]).  Each game of a joint handle is a VecGame of its own over the envs k, k + K, k + 2K, ...
+// with its own streams, so the per-game kernels of one libenv_act run concurrently on the GPU.
+struct Handle {
+    std::vector<std::unique_ptr<VecGame>> parts;
+    int num_envs = 0;
+    // joint handles: the parts write rew / first into these and observe() scatters them to the caller's arrays
+    std::vector<std::vector<float>> part_rew;
+    std::vector<std::vector<uint8_t>> part_first;
+    std::vector<std::vector<void *>> part_ob, part_ac, part_info;
+    float *rew = nullptr;
+    uint8_t *first = nullptr;
+    int K() const { return (int)parts.size(); }
+    VecGame *single() {
+        if (parts.size() != 1) fatal("this extension hook is only available on single-game handles\n");
+        return parts[0].get();
+    }
+};
+
+static std::vector<std::string> split_names(const std::string &s) {
+    std::vector<std::string> out;
+    size_t pos = 0;
+    for (;;) {
+        const size_t k = s.find(',', pos);
+        out.push_back(s.substr(pos, k == std::string::npos ? std::string::npos : k - pos));
+        if (k == std::string::npos) break;
+        pos = k + 1;
+    }
+    return out;
+}
+
 extern "C" {
 
 LIBENV_API int libenv_version(void) { return LIBENV_VERSION; }
 
 LIBENV_API libenv_env *libenv_make(int num_envs, const struct libenv_options options) {
-    return (libenv_env *)new VecGame(num_envs, VecOptions(options));
+    Handle *h = new Handle();
+    h->num_envs = num_envs;
+    std::string env_name;
+    {
+        VecOptions peek(options);
+        peek.consume_string("env_name", &env_name);
+    }
+    const std::vector<std::string> names = split_names(env_name);
+    const int K = (int)names.size();
+    if (K <= 1) {
+        h->parts.emplace_back(new VecGame(num_envs, VecOptions(options)));
+    } else {
+        if (num_envs % K != 0) fatal("fassert failed 'num_envs %% num_joint_games == 0'\n");
+        for (int k = 0; k < K; k++) h->parts.emplace_back(new VecGame(num_envs / K, VecOptions(options), names[k], K, k));
+    }
+    return (libenv_env *)h;
 }
 
 LIBENV_API int libenv_get_tensortypes(libenv_env *handle, enum libenv_space_name name, struct libenv_tensortype *out_types) {
-    VecGame *v = (VecGame *)handle;
+    VecGame *v = ((Handle *)handle)->parts[0].get();
     const std::vector<libenv_tensortype> *types;
     if (name == LIBENV_SPACE_OBSERVATION) types = &v->observation_types;
     else if (name == LIBENV_SPACE_ACTION) types = &v->action_types;
@@ -533,18 +585,72 @@ LIBENV_API int libenv_get_tensortypes(libenv_env *handle, enum libenv_space_name
     return (int)types->size();
 }
 
-LIBENV_API void libenv_set_buffers(libenv_env *handle, struct libenv_buffers *bufs) { ((VecGame *)handle)->set_buffers(bufs); }
-LIBENV_API void libenv_observe(libenv_env *handle) { ((VecGame *)handle)->observe(); }
-LIBENV_API void libenv_act(libenv_env *handle) { ((VecGame *)handle)->act(); }
-LIBENV_API void libenv_close(libenv_env *handle) { delete (VecGame *)handle; }
+LIBENV_API void libenv_set_buffers(libenv_env *handle, struct libenv_buffers *bufs) {
+    Handle *h = (Handle *)handle;
+    const int K = h->K();
+    if (K == 1) {
+        h->parts[0]->set_buffers(bufs);
+        return;
+    }
+    const int N = h->num_envs, n = N / K;
+    h->rew = bufs->rew;
+    h->first = bufs->first;
+    h->part_rew.assign(K, std::vector<float>(n));
+    h->part_first.assign(K, std::vector<uint8_t>(n));
+    h->part_ob.assign(K, std::vector<void *>(n));
+    h->part_ac.assign(K, std::vector<void *>(n));
+    h->part_info.assign(K, std::vector<void *>(3 * (size_t)n));
+    for (int k = 0; k < K; k++) {
+        for (int i = 0; i < n; i++) {
+            const int e = k + K * i;  // global env index
+            h->part_ob[k][i] = bufs->ob[e];
+            h->part_ac[k][i] = bufs->ac[e];
+            for (int s = 0; s < 3; s++) h->part_info[k][(size_t)s * n + i] = bufs->info[(size_t)s * N + e];
+        }
+        struct libenv_buffers pb;
+        pb.ob = h->part_ob[k].data();
+        pb.rew = h->part_rew[k].data();
+        pb.first = h->part_first[k].data();
+        pb.info = h->part_info[k].data();
+        pb.ac = h->part_ac[k].data();
+        h->parts[k]->set_buffers(&pb);
+    }
+}
+LIBENV_API void libenv_observe(libenv_env *handle) {
+    Handle *h = (Handle *)handle;
+    const int K = h->K();
+    for (auto &p : h->parts) p->observe();
+    if (K > 1 && h->rew) {
+        const int n = h->num_envs / K;
+        for (int k = 0; k < K; k++)
+            for (int i = 0; i < n; i++) {
+                h->rew[k + K * i] = h->part_rew[k][i];
+                h->first[k + K * i] = h->part_first[k][i];
+            }
+    }
+}
+LIBENV_API void libenv_act(libenv_env *handle) {
+    Handle *h = (Handle *)handle;
+    for (auto &p : h->parts) p->act();  // each game launches on its own streams: the games' kernels overlap
+}
+LIBENV_API void libenv_close(libenv_env *handle) { delete (Handle *)handle; }
 
 // reference src/vecgame.cpp:437-457 (wire format: state_io.cpp)
-LIBENV_API int get_state(libenv_env *handle, int env_idx, char *data, int length) { return ((VecGame *)handle)->get_state(env_idx, data, length); }
-LIBENV_API void set_state(libenv_env *handle, int env_idx, char *data, int length) { ((VecGame *)handle)->set_state(env_idx, data, length); }
+LIBENV_API int get_state(libenv_env *handle, int env_idx, char *data, int length) {
+    Handle *h = (Handle *)handle;
+    if (env_idx < 0 || env_idx >= h->num_envs) fatal("get_state: env index %d out of range\n", env_idx);
+    return h->parts[env_idx % h->K()]->get_state(env_idx / h->K(), data, length);
+}
+LIBENV_API void set_state(libenv_env *handle, int env_idx, char *data, int length) {
+    Handle *h = (Handle *)handle;
+    if (env_idx < 0 || env_idx >= h->num_envs) fatal("set_state: env index %d out of range\n", env_idx);
+    h->parts[env_idx % h->K()]->set_state(env_idx / h->K(), data, length);
+    if (h->K() > 1) libenv_observe(handle);  // refresh the caller's rew / first entries of this env
+}
 
 // ---- extension hooks (include/procgen_amd.h) -------------------------------------------------------------
 LIBENV_API int procgen_amd_device_buffers(libenv_env *handle, struct procgen_amd_buffers *out) {
-    VecGame *v = (VecGame *)handle;
+    VecGame *v = ((Handle *)handle)->single();
     out->device_id = v->device_id;
     out->num_envs = v->num_envs;
     out->stream = (void *)v->stream;
@@ -558,7 +664,7 @@ LIBENV_API int procgen_amd_device_buffers(libenv_env *handle, struct procgen_amd
     return 0;
 }
 LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable) {
-    VecGame *v = (VecGame *)handle;
+    VecGame *v = ((Handle *)handle)->single();
     v->observe();
     if (enable && !v->host_observations && v->buffers_set && !v->ob_contig && !v->h_obs_stage)
         HIP_CHECK(hipHostMalloc((void **)&v->h_obs_stage, (size_t)v->num_envs * OBS_BYTES, hipHostMallocDefault));
@@ -566,7 +672,7 @@ LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable
 }
 // average device time of the step kernels over the given number of act/observe rounds (bench.py roofline leg)
 LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const int32_t *actions_or_null) {
-    VecGame *v = (VecGame *)handle;
+    VecGame *v = ((Handle *)handle)->single();
     v->observe();
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));

@@ -369,13 +369,42 @@ struct Renderer {
             aux_o = cmd_aux((int)im.w, mirrored, false, opacity_to_io(opacity)) | (1u << 15);
         }
     }
+    // p.fillRect(QRectF, QColor) as a draw command (lane-local)
+    PG_DEV void cmd_fill_rect(const RectD &fr, uint32_t color, uint32_t &geom, uint32_t &src_o, uint32_t &aux_o) const {
+        int x1 = q_round(fr.x), x2 = q_round(fr.x + fr.w), y1 = q_round(fr.y), y2 = q_round(fr.y + fr.h);
+        if (x2 < x1) { const int t = x1; x1 = x2; x2 = t; }
+        if (y2 < y1) { const int t = y1; y1 = y2; y2 = t; }
+        if (x1 < 0) x1 = 0;
+        if (y1 < 0) y1 = 0;
+        if (x2 > RES_W) x2 = RES_W;
+        if (y2 > RES_H) y2 = RES_H;
+        if (x2 > x1 && y2 > y1 && !(y1 >= row1 || y2 <= row0)) {
+            geom = (uint32_t)x1 | ((uint32_t)y1 << 7) | ((uint32_t)(x2 - x1) << 14) | ((uint32_t)(y2 - y1) << 21);
+            src_o = color;
+            aux_o = cmd_aux(1, false, true, 256) | (1u << 26);
+        }
+    }
     // draw_image BAG:877-913 for one drawable (lane-local); returns the image index or -1
-    PG_DEV int resolve_image(int base_type, int theme, float rotation, float tile_ratio, RectD &rect) {
+    // returns the image index, -1 (nothing to draw) or IMG_FILL: draw_grid_obj paints the drawable's base rect with
+    // color_for_type (BAG:455-481,915-919; use_monochrome_assets) -- the colour is returned in *fill_color
+    static constexpr int IMG_FILL = -2;
+    PG_DEV int resolve_image(int base_type, int theme, float rotation, float tile_ratio, RectD &rect, uint32_t *fill_color = nullptr) {
         const int img_type = Game::image_for_type(*this, base_type);
         if (img_type < 0) return -1;
         if (d.opt.use_monochrome_assets || img_type >= USE_ASSET_THRESHOLD) {
-            if (img_type != SPACE) fail(PGE_UNSUPPORTED_DRAW);  // colored grid squares: not on the default-option path yet
-            return -1;
+            if (img_type == SPACE) return -1;
+            if (!d.opt.use_monochrome_assets || img_type >= 64 || !fill_color) {  // fassert(false) BAG:477 / fassert(type < kcubed) BAG:465
+                fail(PGE_UNSUPPORTED_DRAW);
+                return -1;
+            }
+            int th = theme;
+            if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) th = 0;
+            const int k = 4, kcubed = 64, chunk = 64;
+            int new_type = (29 * (img_type + 1)) % kcubed;
+            new_type = (new_type + 19 * th) % kcubed;
+            const uint32_t cr = (uint32_t)(chunk * (new_type / (k * k) + 1) - 1), cg = (uint32_t)(chunk * ((new_type / k) % k + 1) - 1), cb = (uint32_t)(chunk * (new_type % k + 1) - 1);
+            *fill_color = 0xff000000u | (cr << 16) | (cg << 8) | cb;
+            return IMG_FILL;
         }
         rect = Game::adjusted_image_rect(img_type, rect);
         int mt = theme;
@@ -516,7 +545,9 @@ struct Renderer {
                         const int theme = Game::theme_for_grid_obj(*this, type);
                         RectD r2 = get_screen_rect((float)(win_lx + cx), (float)(win_ly + cy + 1), 1, 1, RENDER_EPS);
                         const RectD r2_in = r2;
-                        const int im = resolve_image(type, theme, 0.0f, 0.0f, r2);
+                        uint32_t fc = 0;
+                        const int im = resolve_image(type, theme, 0.0f, 0.0f, r2, &fc);
+                        if (im == IMG_FILL) PG_LV(bad, l) = 1;
                         if (im >= 0) {
                             const ImgDesc imd = d.assets->img[im];
                             const bool same_rect = r2.x == r2_in.x && r2.y == r2_in.y && r2.w == r2_in.w && r2.h == r2_in.h;
@@ -1040,9 +1071,12 @@ struct Renderer {
                 } else {
                     r1 = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
                 }
-                const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, 0.0f, r1);
+                const RectD r1_in = r1;
+                uint32_t fc = 0;
+                const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, 0.0f, r1, &fc);
                 const float rotation = ef(EF_ROTATION, i);
                 const float tile_ratio = Game::tile_aspect_ratio(*this, i);
+                if (im == IMG_FILL) cmd_fill_rect(r1_in, fc, PG_LV(r.geom, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                 if (im >= 0) {
                     if (rotation == 0 && tile_ratio != 0 && !GameUsesTiledEntities<Game>::value) {
                         fail(PGE_UNSUPPORTED_DRAW);
@@ -1223,24 +1257,15 @@ struct Renderer {
                                 RectD fr;
                                 uint32_t color;
                                 Game::grid_fill(*this, type, cell, fr, color);
-                                int x1 = q_round(fr.x), x2 = q_round(fr.x + fr.w), y1 = q_round(fr.y), y2 = q_round(fr.y + fr.h);
-                                if (x2 < x1) { const int t = x1; x1 = x2; x2 = t; }
-                                if (y2 < y1) { const int t = y1; y1 = y2; y2 = t; }
-                                if (x1 < 0) x1 = 0;
-                                if (y1 < 0) y1 = 0;
-                                if (x2 > RES_W) x2 = RES_W;
-                                if (y2 > RES_H) y2 = RES_H;
-                                if (x2 > x1 && y2 > y1 && !(y1 >= row1 || y2 <= row0)) {
-                                    PG_LV(r.geom, l) = (uint32_t)x1 | ((uint32_t)y1 << 7) | ((uint32_t)(x2 - x1) << 14) | ((uint32_t)(y2 - y1) << 21);
-                                    PG_LV(r.src, l) = color;
-                                    PG_LV(r.aux, l) = cmd_aux(1, false, true, 256) | (1u << 26);
-                                }
+                                cmd_fill_rect(fr, color, PG_LV(r.geom, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                             }
                         } else if (type != INVALID_OBJ && type != SPACE) {
                             const int theme = Game::theme_for_grid_obj(*this, type);
                             RectD r2 = get_screen_rect((float)x, (float)(y + 1), 1, 1, RENDER_EPS);
                             const RectD r2_in = r2;
-                            const int im = resolve_image(type, theme, 0.0f, 0.0f, r2);
+                            uint32_t fc = 0;
+                            const int im = resolve_image(type, theme, 0.0f, 0.0f, r2, &fc);
+                            if (im == IMG_FILL) cmd_fill_rect(r2_in, fc, PG_LV(r.geom, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                             if (im >= 0) {
                                 const ImgDesc imd = d.assets->img[im];
                                 const bool same_rect = r2.x == r2_in.x && r2.y == r2_in.y && r2.w == r2_in.w && r2.h == r2_in.h;
@@ -1275,7 +1300,17 @@ struct Renderer {
                 draw_entities(0);
                 draw_entities(1);
             }
-            if (G.has_useful_vel_info && d.opt.paint_vel_info) fail(PGE_UNSUPPORTED_DRAW);
+            if (G.has_useful_vel_info && d.opt.paint_vel_info) {  // BAG:960-969, to_shade reference src/qt-utils.h:21-28
+                const float infodim = (float)(RES_H * .2);
+                const int ag = G.agent;
+                int s1 = (int)((float)(.5 * (double)evx(ag) / (double)G.maxspeed + .5) * 255);
+                int s2 = (int)((float)(.5 * (double)evy(ag) / (double)G.max_jump + .5) * 255);
+                s1 = s1 < 0 ? 0 : (s1 > 255 ? 255 : s1);
+                s2 = s2 < 0 ? 0 : (s2 > 255 ? 255 : s2);
+                const RectD d2 = {0, 0, (double)infodim, (double)infodim}, d3 = {(double)infodim, 0, (double)infodim, (double)infodim};
+                exec_fill(d2, 0xff000000u | ((uint32_t)s1 << 16) | ((uint32_t)s1 << 8) | (uint32_t)s1);
+                exec_fill(d3, 0xff000000u | ((uint32_t)s2 << 16) | ((uint32_t)s2 << 8) | (uint32_t)s2);
+            }
             if constexpr (GameHasOverlay<Game>::value) Game::draw_overlay(*this);  // game_draw overrides that paint after the base frame
             PG_SYNC();
             if (!(d.debug_flags & 8)) store_band();

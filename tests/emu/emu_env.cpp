@@ -63,7 +63,7 @@ extern "C" {
 
 void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, int num_levels, int start_level, int distribution_mode,
                int center_agent, int use_backgrounds, int restrict_themes, int use_sequential_levels, int debug_mode, const char *resource_root,
-               const char *atlas_path, int use_small) {
+               const char *atlas_path, int use_small, int use_monochrome_assets, int paint_vel_info) {
     EmuVec *v = new EmuVec();
     v->n = num_envs;
     v->use_small = use_small;
@@ -102,7 +102,7 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     v->ls.assign(num_envs, 0);
     v->rew.assign(num_envs, 0);
 #define PG_X(Game) \
-    if (gid == Game::GAME_ID) init_env_state<Game>(num_envs, rand_seed, env_offset, v->hdr.data(), v->rng.data());
+    if (gid == Game::GAME_ID) init_env_state<Game>(num_envs, rand_seed, env_offset, 1, v->hdr.data(), v->rng.data());
     PG_FOR_EACH_GAME(PG_X)
 #undef PG_X
     DevCtx &d = v->d;
@@ -112,6 +112,8 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.opt.use_backgrounds = use_backgrounds;
     d.opt.center_agent = center_agent;
     d.opt.restrict_themes = restrict_themes;
+    d.opt.use_monochrome_assets = use_monochrome_assets;
+    d.opt.paint_vel_info = paint_vel_info;
     d.opt.distribution_mode = distribution_mode;
     d.opt.use_sequential_levels = use_sequential_levels;
     d.opt.debug_mode = debug_mode;

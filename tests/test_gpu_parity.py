@@ -85,6 +85,8 @@ def test_option_surface_matches_oracle():
                     (dict(use_backgrounds=False), dict(use_backgrounds=False)),
                     (dict(center_agent=False), dict(center_agent=False)),
                     (dict(restrict_themes=True), dict(restrict_themes=True)),
+                    (dict(use_monochrome_assets=True), dict(use_monochrome_assets=True)),
+                    (dict(paint_vel_info=True), dict(paint_vel_info=True)),
                     (dict(use_sequential_levels=True, num_levels=2), dict(use_sequential_levels=True, num_levels=2))):
         a = rollout(oracle_env.OracleEnv(8, "coinrun", rand_seed=3, **okw), acts)
         b = rollout(make_env(8, rand_seed=3, **kw), acts)
@@ -164,6 +166,27 @@ def test_arena_tiers_run_concurrently_without_double_stepping(monkeypatch):
     small = rollout(oracle_env.OracleEnv(m, "coinrun", rand_seed=23), [a[:m] for a in acts])
     for k in small:
         assert np.array_equal(runs[0][k][:, :m], small[k]), k
+
+
+def test_joint_games_handle_matches_per_game_oracles():
+    """BASELINE configs[4] shape: a comma separated env_name (reference src/vecgame.cpp:295-310) gives env n the game
+    names[n % K] and the n-th level-seed generator.  Every env of the joint handle must equal env n of a single-game
+    oracle run with the same num_envs, and get_state must carry the global env index."""
+    names = ["coinrun", "starpilot", "bigfish", "chaser"]
+    K, n, steps = len(names), 24, 120
+    acts = action_stream(n, steps, seed=13)
+    joint = rollout(make_env(n, ",".join(names)), acts, keep_frames=True)
+    for k, game in enumerate(names):
+        ref = rollout(oracle_env.OracleEnv(n, game, rand_seed=23), acts, keep_frames=True)
+        for key in ref:
+            assert np.array_equal(joint[key][:, k::K], ref[key][:, k::K]), (game, key)
+    import state_parse
+
+    env = make_env(n, ",".join(names))
+    for e in (0, 5, 22):
+        st = state_parse.parse_state(env.get_state()[e])
+        assert st["game_name"] == names[e % K] and st["game_n"] == e
+    env.close()
 
 
 def test_bigfish_full_size_prefix_matches_oracle():

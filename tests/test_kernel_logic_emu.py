@@ -33,6 +33,18 @@ def test_emulated_kernels_match_oracle(game, use_small):
             emu.act(acts[t])
 
 
+@pytest.mark.parametrize("game", ["coinrun", "chaser", "dodgeball"])
+@pytest.mark.parametrize("kw", [dict(use_monochrome_assets=True), dict(paint_vel_info=True), dict(use_monochrome_assets=True, restrict_themes=True, use_backgrounds=False)])
+def test_emulated_option_surface_monochrome_and_vel_info(game, kw):
+    """draw_grid_obj / color_for_type fills (use_monochrome_assets) and the velocity squares (paint_vel_info):
+    reference src/basic-abstract-game.cpp:455-481,884-886,915-919,960-969."""
+    acts = action_stream(6, 80, seed=9)
+    a = rollout(oracle_env.OracleEnv(6, game, rand_seed=23, **kw), acts, keep_frames=True)
+    b = rollout(emu_harness.EmuEnv(6, game, rand_seed=23, **kw), acts, keep_frames=True)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_emulated_shard_equals_slice_of_whole():
     """env_offset sharding (include/procgen_amd.h): a shard reproduces the matching slice of one big vector."""
     acts = action_stream(8, 60, seed=3)
