@@ -435,7 +435,7 @@ void VecGame::observe() {  // reference src/vecgame.cpp:363-376,416-435
     pending = false;
     const size_t N = (size_t)num_envs;
     const int err = *(const int *)(h_small + (small_bytes - 4));
-    if (err) fatal("device-side check failed (code %d: 1 entity table overflow, 2 grid index out of range, 3 fassert, 4 asset theme, 5 unsupported draw)\n", err);
+    if (err && !d.debug_flags) fatal("device-side check failed (code %d: 1 entity table overflow, 2 grid index out of range, 3 fassert, 4 asset theme, 5 unsupported draw)\n", err);
     memcpy(rew_ptr, h_small, 4 * N);
     memcpy(first_ptr, h_small + 12 * N, N);
     const int32_t *pls = (const int32_t *)(h_small + 4 * N), *ls = (const int32_t *)(h_small + 8 * N);

@@ -129,6 +129,9 @@ struct Lds {
     uint32_t tmp[64];
     alignas(16) typename Game::cell_t grid[(Game::MAX_CELLS + 15) & ~15];
     typename GameScratch<Game>::type scratch;
+#if defined(PG_LDS_PAD)
+    uint8_t pad[PG_LDS_PAD];  // occupancy experiments only
+#endif
 };
 
 template <class Game, int CAP>
