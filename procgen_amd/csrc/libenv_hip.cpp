@@ -342,12 +342,34 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d.assets = d_assets;
     d.pixels = d_pixels;
     d.debug_flags = getenv("PROCGEN_AMD_DEBUG") ? atoi(getenv("PROCGEN_AMD_DEBUG")) : 0;
+    if (d.debug_flags & 2048) d.phase_cycles = dev_alloc<unsigned long long>(32 * 4096);
     HIP_CHECK(hipHostMalloc((void **)&h_action, N * 4 + 16, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_small, small_bytes + 16, hipHostMallocDefault));
 }
 
 VecGame::~VecGame() {
     if (stream) (void)hipStreamSynchronize(stream);
+    if (d.phase_cycles) {  // PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step kernels, per env-step
+        std::vector<unsigned long long> raw(32 * 4096);
+        unsigned long long pc[32] = {0};
+        const bool got = hipMemcpy(raw.data(), d.phase_cycles, raw.size() * 8, hipMemcpyDeviceToHost) == hipSuccess;
+        for (size_t i = 0; i < raw.size(); i++) pc[i & 31] += raw[i];
+        if (got && pc[14] > 0) {
+            static const char *names[13] = {"load_env", "action+velocity", "step_entities (rest)", "collision_pass", "erase_if_needed", "game_step tail", "reset (per reset)", "outputs+camera", "store_env",
+                                            " bso: setup", " bso: sub_steps", " se: find+plain ents", " se: smart ent_step"};
+            fprintf(stderr, "[procgen_amd phase cycles per env-step, %llu env-steps, %llu resets]\n", pc[14], pc[15]);
+            for (int k = 0; k < 13; k++) {
+                const double denom = k == 6 ? (double)(pc[15] ? pc[15] : 1) : (double)pc[14];
+                fprintf(stderr, "  %-22s %10.1f\n", names[k], (double)pc[k] / denom);
+            }
+            if (pc[31] > 0) {
+                static const char *rn[6] = {"frame set-up", "clear + background", "entities z=-1", "grid cells", "entities z=0,1 + hud", "store band"};
+                fprintf(stderr, "[render kernel, wave cycles per frame, %llu frames]\n", pc[31]);
+                for (int k = 0; k < 6; k++) fprintf(stderr, "  %-22s %10.1f\n", rn[k], (double)pc[16 + k] / (double)pc[31]);
+            }
+        }
+        (void)hipFree(d.phase_cycles);
+    }
     if (registered_obs && !ob_ptr.empty()) (void)hipHostUnregister(ob_ptr[0]);
     (void)hipFree(d_assets);
     (void)hipFree(d_pixels);

@@ -139,6 +139,7 @@ struct DevCtx {
     const uint8_t *route;  // [num_envs]
     uint8_t *next_route;   // [num_envs] written by every env's store_env
     int *error;            // [1] OR of the per-env error codes raised this step (0 = none)
+    unsigned long long *phase_cycles;  // [4096][32] PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step (0-15) and render (16-31) kernels (null otherwise)
     int debug_flags;       // PROCGEN_AMD_DEBUG: phase ablation bits for profiling only (0 in normal operation)
 };
 

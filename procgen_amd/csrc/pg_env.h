@@ -147,6 +147,20 @@ struct Env {
     uint32_t *rg_cur;
     bool rg_in_lds;
 
+    // profiling aid (PROCGEN_AMD_DEBUG & 2048): wave cycles spent since the previous mark are charged to phase k
+    long long t_mark = 0;
+    PG_DEV void phase(int k) {
+#if !defined(PGAMD_WAVE_EMU)
+        if (d.phase_cycles) {
+            const long long t = (long long)__builtin_readcyclecounter();
+            if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + k + 32 * (env & 4095), (unsigned long long)(t - t_mark));
+            t_mark = (long long)__builtin_readcyclecounter();
+        }
+#else
+        (void)k;
+#endif
+    }
+
     PG_DEV Env(const DevCtx &d_, int env_, Lds<Game, CAP> *s_) : d(d_), env(env_), s(s_) {
         rg_home = d.rng + (size_t)env * MT_SLOTS * MT_STRIDE;
         rg_cur = rg_home;
@@ -515,8 +529,14 @@ struct Env {
         ey(obj) = ny;
         PG_SYNC();
 
-        // reverse scan of the entity list (BAG:337-369): broad phase = one ballot per 64 entities, hits are
-        // visited from the highest index down; the ballot is re-evaluated only after a hit moved `obj`.
+        return entity_scan<DEPTH>(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory) || block;
+    }
+
+    // reverse scan of the entity list (BAG:337-369): broad phase = one ballot per 64 entities, hits are
+    // visited from the highest index down; the ballot is re-evaluated only after a hit moved `obj`.  Works on the
+    // LDS copy of `obj`; returns block2.
+    template <int DEPTH>
+    PG_DEV bool entity_scan(int obj, float _vx, float _vy, bool is_horizontal, int scan_axes, int otype, float orx, float ory) {
         bool block2 = false;
         const int n = ((scan_axes >> (is_horizontal ? 0 : 1)) & 1) ? G.n_ents : 0;
         for (int c = (n - 1) >> 6; c >= 0; c--) {
@@ -577,6 +597,112 @@ struct Env {
                 }
             }
         }
+        return block2;
+    }
+
+    // ---- top level of basic_step_object with the stepping entity held in registers --------------------------------
+    // A smart_step entity makes >= 8 sub_steps per env-step and each one used to be a chain of dependent LDS reads and
+    // writes of the entity's own fields; step_entities was two thirds of the step kernel's cycles
+    // (profiles/r01_phase_cycles_coinrun.txt).  The common sub_step touches only the grid and -- through one ballot --
+    // the other entities' boxes, so the entity's x, y, vx, vy, rx, ry live in registers for the whole object step and
+    // go back to LDS only when an entity is actually hit (push / reflect recursion works on LDS) or a hook needs them.
+    struct ObjRegs {
+        float x, y, vx, vy, rx, ry;
+        int type;
+    };
+    PG_DEV void obj_load(int obj, ObjRegs &R) {
+        R.x = ex(obj); R.y = ey(obj); R.vx = evx(obj); R.vy = evy(obj); R.rx = erx(obj); R.ry = ery(obj);
+        R.type = etype(obj);
+    }
+    PG_DEV void obj_flush(int obj, const ObjRegs &R) {
+        ex(obj) = R.x; ey(obj) = R.y; evx(obj) = R.vx; evy(obj) = R.vy;
+        PG_SYNC();
+    }
+    PG_DEV bool sub_step_top(int obj, ObjRegs &R, float _vx, float _vy, int scan_axes) {  // BAG:270-372, depth 0
+        const int otype = R.type;
+        const float orx = R.rx, ory = R.ry;
+        float ny = R.y + _vy;
+        float nx = R.x + _vx;
+        const float margin = 0.98f;
+        const bool is_horizontal = _vx != 0;
+        bool block = false, reflect = false;
+        {
+            const float mx = orx * margin, my = ory * margin;
+            const float px[2] = {nx + mx * -1, nx + mx * 1};
+            const float py[2] = {ny + my * -1, ny + my * 1};
+            int cxi[2], cyi[2];
+            bool xneg[2], yneg[2];
+            for (int k = 0; k < 2; k++) {
+                xneg[k] = px[k] < 0;
+                yneg[k] = py[k] < 0;
+                cxi[k] = (int)pg_floorf(px[k]);
+                cyi[k] = (int)pg_floorf(py[k]);
+            }
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 2; j++) {
+                    const int type2 = (xneg[i] || yneg[j]) ? G.out_of_bounds_object : get_obj(cxi[i], cyi[j]);
+                    block = block || Game::is_blocked(*this, otype, type2, is_horizontal);
+                    reflect = reflect || Game::will_reflect(otype, type2);
+                }
+        }
+        if constexpr (GameHasBlockHook<Game>::value) {
+            if (block) {
+                obj_flush(obj, R);
+                Game::on_grid_block(*this, obj);
+                PG_SYNC();
+                R.vx = evx(obj);
+                R.vy = evy(obj);
+            }
+        }
+        if (reflect) {
+            if (is_horizontal) {
+                float delta;
+                if (_vx < 0) delta = (float)(pg_ceil((double)(nx - orx)) - (double)(nx - orx));
+                else delta = (float)(pg_floor((double)(nx + orx)) - (double)(nx + orx));
+                R.vx = -1 * R.vx;
+                nx = nx + 2 * delta;
+            } else {
+                float delta;
+                if (_vy < 0) delta = (float)(pg_ceil((double)(ny - ory)) - (double)(ny - ory));
+                else delta = (float)(pg_floor((double)(ny + ory)) - (double)(ny + ory));
+                R.vy = -1 * R.vy;
+                ny = ny + 2 * delta;
+            }
+        } else if (block) {
+            if (is_horizontal) {
+                if (G.grid_step) nx = R.x;
+                else nx = (float)(_vx > 0 ? (pg_floor((double)(nx + orx)) - (double)orx) : (pg_ceil((double)(nx - orx)) + (double)orx));
+            } else {
+                if (G.grid_step) ny = R.y;
+                else ny = (float)(_vy > 0 ? (pg_floor((double)(ny + ory)) - (double)ory) : (pg_ceil((double)(ny - ory)) + (double)ory));
+            }
+        }
+        R.x = nx;
+        R.y = ny;
+        // does the entity scan find anything at all?  (the same broad phase as entity_scan, from the register copy)
+        const int n = ((scan_axes >> (is_horizontal ? 0 : 1)) & 1) ? G.n_ents : 0;
+        bool any_hit = false;
+        for (int c = (n - 1) >> 6; c >= 0 && !any_hit; c--) {
+            const uint64_t m = PG_BALLOT(l, ({
+                                             const int idx = (c << 6) + l;
+                                             bool hit = false;
+                                             if (idx < n && idx != obj) {
+                                                 const uint32_t mm = meta(idx);
+                                                 if (!(mm & MF_WILL_ERASE) && Game::may_interact(*this, otype, meta_type(mm), is_horizontal)) {
+                                                     const float tx = (orx + erx(idx)) + POS_EPS;
+                                                     const float ty = (ory + ery(idx)) + POS_EPS;
+                                                     hit = (pg_fabsf(nx - ex(idx)) < tx) && (pg_fabsf(ny - ey(idx)) < ty);
+                                                 }
+                                             }
+                                             hit;
+                                         }));
+            any_hit = m != 0;
+        }
+        if (!any_hit) return block;
+        obj_flush(obj, R);
+        const bool block2 = entity_scan<0>(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory);
+        PG_SYNC();
+        R.x = ex(obj); R.y = ey(obj); R.vx = evx(obj); R.vy = evy(obj);
         return block || block2;
     }
 
@@ -610,14 +736,17 @@ struct Env {
                 scan_axes |= (mh ? 1 : 0) | (mv ? 2 : 0);
             }
         }
+        ObjRegs R;
+        obj_load(obj, R);
+        phase(9);
         float vx_pct = 0, vy_pct = 0;
         for (int st = 0; st < num_sub_steps; st++) {
             bool block_x = false, block_y = false;
-            for (int h = 0; h < 2; h++) {  // one call site for sub_step<0>
+            for (int h = 0; h < 2; h++) {  // one call site for sub_step_top
                 const bool xaxis = (h == 0) == step_x_first;
-                const float dvx = xaxis ? evx(obj) * pct : 0.0f;
-                const float dvy = xaxis ? 0.0f : evy(obj) * pct;
-                const bool b = sub_step<0>(obj, dvx, dvy, scan_axes);
+                const float dvx = xaxis ? R.vx * pct : 0.0f;
+                const float dvy = xaxis ? 0.0f : R.vy * pct;
+                const bool b = sub_step_top(obj, R, dvx, dvy, scan_axes);
                 if (xaxis) block_x = b;
                 else block_y = b;
             }
@@ -627,8 +756,10 @@ struct Env {
         }
         vx_pct = vx_pct / num_sub_steps;
         vy_pct = vy_pct / num_sub_steps;
-        evx(obj) *= vx_pct;
-        evy(obj) *= vy_pct;
+        R.vx *= vx_pct;
+        R.vy *= vy_pct;
+        obj_flush(obj, R);
+        phase(10);
     }
 
     // step_entities BAG:1086-1098: reverse order; runs of non-smart entities are stepped lane-parallel,
@@ -654,10 +785,12 @@ struct Env {
                 }
             }
             PG_SYNC();
+            phase(11);
             if (sidx < 0) break;
             basic_step_object(sidx);
             ent_step(sidx);
             PG_SYNC();
+            phase(12);
             hi = sidx;
         }
     }
@@ -819,9 +952,13 @@ struct Env {
             ef(EF_VROT, ag) = vrot;
         }
         PG_SYNC();
+        phase(1);
         if (!(d.debug_flags & 64)) step_entities();
+        phase(2);
         if (!(d.debug_flags & 128)) collision_pass();
+        phase(3);
         if (!(d.debug_flags & 256)) erase_if_needed();
+        phase(4);
         G.done = G.done || is_out_of_bounds(G.agent);
     }
     // default BAG::update_agent_velocity BAG:669-684 (games may override)
@@ -1050,6 +1187,7 @@ struct Env {
         G.done = 0;
         G.level_complete = 0;
         Game::game_step(*this);
+        phase(5);
         G.done = G.done || will_force_reset || (G.cur_time >= G.timeout);
         G.total_reward += G.reward;
         if (G.reward != 0) {
@@ -1057,7 +1195,13 @@ struct Env {
             G.last_reward = G.reward;
         }
         G.prev_level_seed = G.current_level_seed;
-        if (G.done) game_reset_full();
+        if (G.done) {
+            game_reset_full();
+            phase(6);
+#if !defined(PGAMD_WAVE_EMU)
+            if (d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 15 + 32 * (env & 4095), 1ull);
+#endif
+        }
         if (d.opt.use_sequential_levels && G.level_complete) G.done = 0;
         G.episode_done = G.done;
     }
@@ -1185,7 +1329,11 @@ struct Env {
 
     // one libenv step (mode 1) or the initial reset + first observation (mode 0) of this env
     PG_DEV void run(int mode) {
+#if !defined(PGAMD_WAVE_EMU)
+        if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
+#endif
         load_env();
+        phase(0);
         if (mode != 0) G.action = d.action[env];  // reference src/vecgame.cpp:388
         if (d.debug_flags & 512) {
             // ablation: staging only
@@ -1198,7 +1346,12 @@ struct Env {
         rand_flush();
         prepare_for_drawing((float)RES_H);  // draw_background + draw_foreground both call it (BAG:922,982)
         store_outputs();
+        phase(7);
         store_env();
+        phase(8);
+#if !defined(PGAMD_WAVE_EMU)
+        if (d.phase_cycles && mode != 0 && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 14 + 32 * (env & 4095), 1ull);
+#endif
     }
 };
 

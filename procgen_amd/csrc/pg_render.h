@@ -24,6 +24,7 @@ namespace pgamd {
 #endif
 constexpr int BAND_ROWS = PG_BAND_ROWS;  // rows per pass (64 / BAND_ROWS passes per frame)
 constexpr int NUM_BANDS = RES_H / BAND_ROWS;
+constexpr int WIDE_ROWS = BAND_ROWS;  // rows per fetch batch of full-width draws (background, tile stage 1)
 
 struct DrawCmd {  // uniform (scalar) view of one command
     int tx1, ty1, w, h;
@@ -107,10 +108,12 @@ struct RenderLdsT {
     uint32_t ci[2][64];              // screen column -> the (at most two) cell columns covering it
     uint32_t ri[2][64];              // screen row    -> the (at most two) cell rows covering it
     uint32_t seamcols[64];           // screen columns covered by two cell columns
+    uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of this frame (build_type_table)
     uint32_t cellimg[GameDrawsGrid<Game>::value ? 1024 : 1];  // window cell -> source image (atlas offset | opaque<<31), CELL_NONE = nothing to draw
     uint32_t rot[GameUsesRotation<Game>::value ? 64 * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane
 };
 constexpr uint32_t CELL_NONE = 0xffffffffu;
+constexpr uint32_t TYPE_SLOW = 0xfffffffeu;  // typeimg: this type needs the per-cell path (fill, odd image size, adjusted rect, missing asset)
 
 // x86 double -> int32 conversion (cvttsd2si): out-of-range and NaN give INT_MIN.  Qt's edge walkers convert
 // unbounded slopes this way; the GPU's conversion saturates instead.
@@ -481,6 +484,39 @@ struct Renderer {
     // its covering cells in the reference's x-major draw order: (c0,r0), (c0,r1), (c1,r0), (c1,r1).  Stage 1 does
     // (c0,r0) for all pixels with lane = screen column; the seam stages touch only the doubly covered columns/rows.
     // entry: valid<<31 | cell index<<12 | source coordinate
+    // Grid object type -> image, once per frame: the asset tables live in HBM and resolving a cell costs two dependent
+    // loads; a frame shows a few hundred cells of a handful of types.  Lane t resolves type t without raising errors
+    // (types a level does not use may have no asset); anything unusual is left to the per-cell path (TYPE_SLOW).
+    PG_DEV void build_type_table() {
+        if constexpr (GameDrawsGrid<Game>::value) {
+            const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
+            PG_FOR_LANES(l) {
+                uint32_t v = TYPE_SLOW;
+                const int type = l;
+                bool is_fill = false;
+                if constexpr (GameHasGridFills<Game>::value) is_fill = Game::is_grid_fill(*this, type);
+                if (!is_fill && !d.opt.use_monochrome_assets) {
+                    const int img_type = Game::image_for_type(*this, type);
+                    if (img_type < 0 || img_type == SPACE) {
+                        v = CELL_NONE;
+                    } else if (img_type < USE_ASSET_THRESHOLD) {
+                        int mt = Game::theme_for_grid_obj(*this, type);
+                        if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;
+                        const int img = (mt >= 0 && mt < MAX_IMAGE_THEMES) ? (int)d.assets->type_theme_img[img_type][mt] : -1;
+                        if (img >= 0) {
+                            const ImgDesc imd = d.assets->img[img];
+                            const RectD probe = {1.0, 2.0, 3.0, 5.0};
+                            const RectD adj = Game::adjusted_image_rect(img_type, probe);
+                            const bool same_rect = adj.x == probe.x && adj.y == probe.y && adj.w == probe.w && adj.h == probe.h;
+                            if (same_rect && (int)imd.w == ref_w && (int)imd.h == ref_h && imd.off < 0x7ffffff0u) v = imd.off | (imd.opaque ? (1u << 31) : 0u);
+                        }
+                    }
+                }
+                lds->typeimg[l] = v;
+            }
+            PG_SYNC();
+        }
+    }
     PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, int ix_ref, int iy_ref, uint64_t &colseam, uint64_t &rowseam) {
         PG_LANE_VAR(uint32_t, over);
         PG_FOR_LANES(l) {
@@ -539,7 +575,10 @@ struct Renderer {
                     uint32_t v = CELL_NONE;
                     bool is_fill = false;
                     if constexpr (GameHasGridFills<Game>::value) is_fill = Game::is_grid_fill(*this, type);
-                    if (is_fill) {
+                    const uint32_t tv = (type >= 0 && type < 64) ? lds->typeimg[type] : TYPE_SLOW;
+                    if (tv != TYPE_SLOW) {
+                        v = tv;  // an image of the reference size on the unadjusted cell rect, or nothing
+                    } else if (is_fill) {
                         PG_LV(bad, l) = 1;  // solid squares are not part of the pull form: per-cell commands for this frame
                     } else if (type != INVALID_OBJ && type != SPACE) {
                         const int theme = Game::theme_for_grid_obj(*this, type);
@@ -579,8 +618,29 @@ struct Renderer {
         const int nseam = pg_popc64(colseam);
         // stage 1: (c0, r0), lane = screen column, 8 rows of fetches in flight; stage 2: (c0, r1) on doubly covered rows
         for (int slot_r = 0; slot_r < 2; slot_r++) {
-            for (int yb = row0; yb < row1; yb += 8) {
+            const int rows = slot_r == 0 ? WIDE_ROWS : 8;  // stage 1 fetches a whole band at once; the seam rows go 8 at a time
+            for (int yb = row0; yb < row1; yb += rows) {
                 if (slot_r == 1 && ((rowseam >> yb) & 0xffull) == 0) continue;
+                if (slot_r == 0) {
+                    PG_FOR_LANES(l) {
+                        const uint32_t ce = lds->ci[0][l];
+                        uint32_t tex[WIDE_ROWS];
+                        bool hit[WIDE_ROWS], opq[WIDE_ROWS];
+                        _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
+                            opq[j] = false;
+                            tex[j] = 0;
+                            hit[j] = pull_fetch(ce, lds->ri[0][yb + j], ny_full, ref_w, tex[j], opq[j]);
+                        }
+                        _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
+                            uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];  // this lane owns the pixel
+                            const uint32_t old = *dp;
+                            const uint32_t over = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
+                            *dp = hit[j] ? over : old;
+                        }
+                    }
+                    PG_SYNC();
+                    continue;
+                }
                 PG_FOR_LANES(l) {
                     const uint32_t ce = lds->ci[0][l];
                     uint32_t tex[8];
@@ -668,19 +728,19 @@ struct Renderer {
         const int y0 = c.ty1 > row0 ? c.ty1 : row0;
         const int y1 = (c.ty1 + c.h) < row1 ? (c.ty1 + c.h) : row1;
         if (c.w > 32) {
-            for (int yb = y0; yb < y1; yb += 8) {
+            for (int yb = y0; yb < y1; yb += WIDE_ROWS) {  // a whole band of texel fetches in flight
                 const int last = y1 - 1;  // rows past the end re-sample the last row into the dump row (no per-row branches)
                 PG_FOR_LANES(l) {
                     const bool in = l < c.w;
                     const int lc = in ? l : 0;
                     const int sxp = (int)((c.basex + (uint32_t)lc * c.ix) >> 16);
                     const int scol = mirrored ? (sw - 1 - sxp) : sxp;
-                    uint32_t tex[8];
-                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                    uint32_t tex[WIDE_ROWS];
+                    _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
                         const int y = (yb + j) < last ? (yb + j) : last;
                         tex[j] = src[(int)((c.srcy0 + (uint32_t)(y - c.ty1) * c.iy) >> 16) * sw + scol];
                     }
-                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                    _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
                         const bool ok = in && (yb + j) <= last;
                         uint32_t *dp = &fb[ok ? ((yb + j - row0) * RES_W + c.tx1 + l) : (BAND_ROWS * RES_W + l)];
                         *dp = opaque ? tex[j] : blend(tex[j], *dp, io, ca);
@@ -1113,7 +1173,23 @@ struct Renderer {
     }
 
     // game_draw BAG:1009-1012 (draw_background BAG:979-1007 + draw_foreground BAG:921-970)
+    // profiling aid (PROCGEN_AMD_DEBUG & 2048): wave cycles since the previous mark go to slot 16 + k of the table
+    long long t_mark = 0;
+    PG_DEV void phase(int k) {
+#if !defined(PGAMD_WAVE_EMU)
+        if (d.phase_cycles) {
+            const long long t = (long long)__builtin_readcyclecounter();
+            if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + k, (unsigned long long)(t - t_mark));
+            t_mark = (long long)__builtin_readcyclecounter();
+        }
+#else
+        (void)k;
+#endif
+    }
     PG_DEV void render_env() {
+#if !defined(PGAMD_WAVE_EMU)
+        if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
+#endif
         {
             const EnvHdr *h = d.hdr + env;
 #define PG_X(type, name) G.name = h->name;
@@ -1199,10 +1275,12 @@ struct Renderer {
         int ix_ref = 0, iy_ref = 0;
         if (use_axes) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);
         uint64_t colseam = 0, rowseam = 0;
+        build_type_table();
         bool pull = false;
         if constexpr (GameDrawsGrid<Game>::value)
             pull = use_axes && nx * ny_full <= 1024 && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, ix_ref, iy_ref, colseam, rowseam);
 
+        phase(0);
         // ---- passes -------------------------------------------------------------------------------------------------
         for (int band = 0; band < NUM_BANDS; band++) {
             row0 = band * BAND_ROWS;
@@ -1215,6 +1293,7 @@ struct Renderer {
                 const DrawCmd bc = unpack(bg_geom[k], bg_basex[k], bg_srcy[k], bg_ix[k], bg_iy[k], bg_src[k], bg_aux[k]);
                 if (bc.ty1 < row1 && bc.ty1 + bc.h > row0) exec_large(bc);
             }
+            phase(1);
             if (one_chunk) {
                 if (ezmask[0]) run_batch(er, ezmask[0]);
             } else {
@@ -1236,6 +1315,7 @@ struct Renderer {
             const int ncell = (GameDrawsGrid<Game>::value && ny > 0 && nx > 0) ? nx * ny : 0;
             const uint32_t ny_inv = ny > 0 ? (uint32_t)(((1u << 20) + (uint32_t)ny - 1u) / (uint32_t)ny) : 0u;
             if (ncell > 4096) fail(PGE_ASSERT);
+            phase(2);
             if constexpr (GameDrawsGrid<Game>::value)
                 if (pull && !(d.debug_flags & 2)) draw_tiles_pull(ny_full, colseam, rowseam);
             for (int base = 0; base < ((pull || (d.debug_flags & 2)) ? 0 : ncell); base += 64) {
@@ -1251,7 +1331,25 @@ struct Renderer {
                         const int type = get_obj(x, y);
                         bool is_fill = false;
                         if constexpr (GameHasGridFills<Game>::value) is_fill = Game::is_grid_fill(*this, type);
-                        if (is_fill) {
+                        const uint32_t tv = (type >= 0 && type < 64) ? lds->typeimg[type] : TYPE_SLOW;
+                        if (tv != TYPE_SLOW && use_axes) {
+                            if (tv != CELL_NONE) {  // reference-size image on the unadjusted rect: geometry from the axis tables
+                                const int ry = y - win_ly;
+                                const uint32_t px = ax[cx], py = ax[32 + ry];
+                                if ((px >> 16) && (py >> 16)) {
+                                    const int ty1 = (int)(py & 0xffu), h = (int)((py >> 8) & 0xffu);
+                                    if (!(ty1 >= row1 || ty1 + h <= row0)) {
+                                        PG_LV(r.geom, l) = (px & 0xffu) | ((uint32_t)ty1 << 7) | (((px >> 8) & 0xffu) << 14) | ((uint32_t)h << 21);
+                                        PG_LV(r.basex, l) = ax[64 + cx];
+                                        PG_LV(r.srcy, l) = ax[64 + 32 + ry];
+                                        PG_LV(r.ix, l) = (uint32_t)ix_ref;
+                                        PG_LV(r.iy, l) = (uint32_t)iy_ref;
+                                        PG_LV(r.src, l) = tv & 0x7fffffffu;
+                                        PG_LV(r.aux, l) = cmd_aux(ref_w, false, (tv >> 31) != 0, 256);
+                                    }
+                                }
+                            }
+                        } else if (is_fill) {
                             if constexpr (GameHasGridFills<Game>::value) {  // draw_grid_obj override: p.fillRect(QRectF, QColor)
                                 const RectD cell = get_screen_rect((float)x, (float)(y + 1), 1, 1, RENDER_EPS);
                                 RectD fr;
@@ -1293,6 +1391,7 @@ struct Renderer {
                 }
                 run_batch(r);
             }
+            phase(3);
             if (one_chunk) {
                 if (ezmask[1]) run_batch(er, ezmask[1]);
                 if (ezmask[2]) run_batch(er, ezmask[2]);
@@ -1313,9 +1412,14 @@ struct Renderer {
             }
             if constexpr (GameHasOverlay<Game>::value) Game::draw_overlay(*this);  // game_draw overrides that paint after the base frame
             PG_SYNC();
+            phase(4);
             if (!(d.debug_flags & 8)) store_band();
             PG_SYNC();
+            phase(5);
         }
+#if !defined(PGAMD_WAVE_EMU)
+        if (d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + 15, 1ull);
+#endif
         if (G.error) {
 #if defined(PGAMD_WAVE_EMU)
             if (d.error) *d.error |= G.error;
