@@ -363,9 +363,10 @@ VecGame::~VecGame() {
                 fprintf(stderr, "  %-22s %10.1f\n", names[k], (double)pc[k] / denom);
             }
             if (pc[31] > 0) {
-                static const char *rn[6] = {"frame set-up", "clear + background", "entities z=-1", "grid cells", "entities z=0,1 + hud", "store band"};
+                static const char *rn[11] = {"set-up: pull tables", "clear + background", "entities z=-1", "grid cells", "entities z=0,1 + hud", "store band",
+                                             "set-up: header", "set-up: background", "set-up: entities", "set-up: window + axes", "set-up: type table"};
                 fprintf(stderr, "[render kernel, wave cycles per frame, %llu frames]\n", pc[31]);
-                for (int k = 0; k < 6; k++) fprintf(stderr, "  %-22s %10.1f\n", rn[k], (double)pc[16 + k] / (double)pc[31]);
+                for (int k = 0; k < 11; k++) fprintf(stderr, "  %-22s %10.1f\n", rn[k], (double)pc[16 + k] / (double)pc[31]);
             }
         }
         (void)hipFree(d.phase_cycles);

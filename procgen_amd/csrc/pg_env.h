@@ -609,10 +609,16 @@ struct Env {
     struct ObjRegs {
         float x, y, vx, vy, rx, ry;
         int type;
+        // the four corner cells of the last probe per move direction and what they said: most sub_steps stay inside
+        // the same cells, and neither the grid nor the hooks' answers change while one object steps
+        int pc[2][4];
+        int pneg[2];
+        bool pvalid[2], pblock[2], preflect[2];
     };
     PG_DEV void obj_load(int obj, ObjRegs &R) {
         R.x = ex(obj); R.y = ey(obj); R.vx = evx(obj); R.vy = evy(obj); R.rx = erx(obj); R.ry = ery(obj);
         R.type = etype(obj);
+        R.pvalid[0] = R.pvalid[1] = false;
     }
     PG_DEV void obj_flush(int obj, const ObjRegs &R) {
         ex(obj) = R.x; ey(obj) = R.y; evx(obj) = R.vx; evy(obj) = R.vy;
@@ -638,12 +644,24 @@ struct Env {
                 cxi[k] = (int)pg_floorf(px[k]);
                 cyi[k] = (int)pg_floorf(py[k]);
             }
-            for (int i = 0; i < 2; i++)
-                for (int j = 0; j < 2; j++) {
-                    const int type2 = (xneg[i] || yneg[j]) ? G.out_of_bounds_object : get_obj(cxi[i], cyi[j]);
-                    block = block || Game::is_blocked(*this, otype, type2, is_horizontal);
-                    reflect = reflect || Game::will_reflect(otype, type2);
-                }
+            const int h = is_horizontal ? 1 : 0;
+            const int neg = (xneg[0] ? 1 : 0) | (xneg[1] ? 2 : 0) | (yneg[0] ? 4 : 0) | (yneg[1] ? 8 : 0);
+            if (R.pvalid[h] && R.pc[h][0] == cxi[0] && R.pc[h][1] == cxi[1] && R.pc[h][2] == cyi[0] && R.pc[h][3] == cyi[1] && R.pneg[h] == neg) {
+                block = R.pblock[h];
+                reflect = R.preflect[h];
+            } else {
+                for (int i = 0; i < 2; i++)
+                    for (int j = 0; j < 2; j++) {
+                        const int type2 = (xneg[i] || yneg[j]) ? G.out_of_bounds_object : get_obj(cxi[i], cyi[j]);
+                        block = block || Game::is_blocked(*this, otype, type2, is_horizontal);
+                        reflect = reflect || Game::will_reflect(otype, type2);
+                    }
+                R.pvalid[h] = true;
+                R.pc[h][0] = cxi[0]; R.pc[h][1] = cxi[1]; R.pc[h][2] = cyi[0]; R.pc[h][3] = cyi[1];
+                R.pneg[h] = neg;
+                R.pblock[h] = block;
+                R.preflect[h] = reflect;
+            }
         }
         if constexpr (GameHasBlockHook<Game>::value) {
             if (block) {
@@ -738,6 +756,27 @@ struct Env {
         }
         ObjRegs R;
         obj_load(obj, R);
+        if (scan_axes != 0) {
+            // no entity this object could interact with lies within its reach for this step (its own travel, < 1 cell of
+            // block snapping, < 2 of a reflection): the per-sub_step scans cannot find anything
+            const int otype = R.type;
+            const int n = G.n_ents;
+            const float reach_x = pg_fabsf(R.vx) + 2.01f, reach_y = pg_fabsf(R.vy) + 2.01f;
+            bool any = false;
+            for (int c = 0; c < ((n + 63) >> 6) && !any; c++) {
+                any = PG_BALLOT(l, ({
+                                    const int idx = (c << 6) + l;
+                                    bool near = false;
+                                    if (idx < n && idx != obj) {
+                                        const int t = etype(idx);
+                                        if (Game::may_interact(*this, otype, t, true) || Game::may_interact(*this, otype, t, false))
+                                            near = (pg_fabsf(R.x - ex(idx)) < R.rx + erx(idx) + reach_x) && (pg_fabsf(R.y - ey(idx)) < R.ry + ery(idx) + reach_y);
+                                    }
+                                    near;
+                                })) != 0;
+            }
+            if (!any) scan_axes = 0;
+        }
         phase(9);
         float vx_pct = 0, vy_pct = 0;
         for (int st = 0; st < num_sub_steps; st++) {

@@ -64,6 +64,16 @@ template <class Game>
 struct GameDrawsGrid<Game, decltype((void)Game::DRAWS_GRID)> {
     static constexpr bool value = Game::DRAWS_GRID;
 };
+// most cells the pull form of the grid pass may see at once (window columns x rows): sizes the LDS cell table, which
+// bounds how many frames a CU renders at a time.  A policy whose centred window is small says so (PULL_CELLS).
+template <class Game, class = void>
+struct GamePullCells {
+    static constexpr int value = 1024;
+};
+template <class Game>
+struct GamePullCells<Game, decltype((void)Game::PULL_CELLS)> {
+    static constexpr int value = Game::PULL_CELLS;
+};
 template <class Game, class = void>
 struct GameUsesTiledEntities {
     static constexpr bool value = false;
@@ -109,7 +119,11 @@ struct RenderLdsT {
     uint32_t ri[2][64];              // screen row    -> the (at most two) cell rows covering it
     uint32_t seamcols[64];           // screen columns covered by two cell columns
     uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of this frame (build_type_table)
-    uint32_t cellimg[GameDrawsGrid<Game>::value ? 1024 : 1];  // window cell -> source image (atlas offset | opaque<<31), CELL_NONE = nothing to draw
+    uint32_t typeany[GameDrawsGrid<Game>::value ? 64 : 1];    // ... of any size: atlas offset | size class<<27 | opaque<<31 (pull form)
+    uint32_t typesz[GameDrawsGrid<Game>::value ? 64 : 1];     // its width<<16 | height
+    uint8_t srcx[3][2][64];          // size classes 1..3: screen column -> source column, per covering slot
+    uint16_t srcyw[3][2][64];        // size classes 1..3: screen row -> source row * image width
+    uint32_t cellimg[GameDrawsGrid<Game>::value ? GamePullCells<Game>::value : 1];  // window cell -> source image (atlas offset | opaque<<31), CELL_NONE = nothing to draw
     uint32_t rot[GameUsesRotation<Game>::value ? 64 * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane
 };
 constexpr uint32_t CELL_NONE = 0xffffffffu;
@@ -491,14 +505,14 @@ struct Renderer {
         if constexpr (GameDrawsGrid<Game>::value) {
             const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
             PG_FOR_LANES(l) {
-                uint32_t v = TYPE_SLOW;
+                uint32_t v = TYPE_SLOW, any = TYPE_SLOW, sz = 0;
                 const int type = l;
                 bool is_fill = false;
                 if constexpr (GameHasGridFills<Game>::value) is_fill = Game::is_grid_fill(*this, type);
                 if (!is_fill && !d.opt.use_monochrome_assets) {
                     const int img_type = Game::image_for_type(*this, type);
                     if (img_type < 0 || img_type == SPACE) {
-                        v = CELL_NONE;
+                        v = any = CELL_NONE;
                     } else if (img_type < USE_ASSET_THRESHOLD) {
                         int mt = Game::theme_for_grid_obj(*this, type);
                         if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;
@@ -508,115 +522,215 @@ struct Renderer {
                             const RectD probe = {1.0, 2.0, 3.0, 5.0};
                             const RectD adj = Game::adjusted_image_rect(img_type, probe);
                             const bool same_rect = adj.x == probe.x && adj.y == probe.y && adj.w == probe.w && adj.h == probe.h;
-                            if (same_rect && (int)imd.w == ref_w && (int)imd.h == ref_h && imd.off < 0x7ffffff0u) v = imd.off | (imd.opaque ? (1u << 31) : 0u);
+                            if (same_rect && imd.off < 0x7ffffffu) {  // any size: the pull form keeps size classes (build_pull_tables)
+                                any = imd.off | (imd.opaque ? (1u << 31) : 0u);
+                                sz = ((uint32_t)imd.w << 16) | (uint32_t)imd.h;
+                                if ((int)imd.w == ref_w && (int)imd.h == ref_h) v = any;
+                            }
                         }
                     }
                 }
                 lds->typeimg[l] = v;
+                lds->typeany[l] = any;
+                lds->typesz[l] = sz;
             }
             PG_SYNC();
         }
     }
-    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, int ix_ref, int iy_ref, uint64_t &colseam, uint64_t &rowseam) {
-        PG_LANE_VAR(uint32_t, over);
+    // Cells of one frame may use images of several sizes (maze: 128x128 sand + 27x27 cheese; miner: 16x16 dirt, 70x70
+    // boulders, 72x51 gems): a size class k has its own source-coordinate tables.  Class 0 is the reference size and lives
+    // in ci / ri (covered<<31 | class-0 sample valid<<30 | cell index<<12 | source coordinate); classes 1..3 keep only
+    // the source coordinates (srcx: column, 0xff = none; srcyw: row * image width, 0xffff = none).  Which cell covers a
+    // pixel depends on the rect alone; whether that cell has a sample there is per class (Qt drops a last sample
+    // that would fall outside the source).  Returns false when the frame needs the per-cell path: solid-colour
+    // cells, adjusted rects, more than four sizes, three cells over one pixel.
+    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, uint64_t &colseam, uint64_t &rowseam, bool &multi) {
+        const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
+        uint32_t *present = fb;  // scratch: the band buffer is idle during set-up
+        uint32_t *span = fb + 64;
         PG_FOR_LANES(l) {
-            uint32_t s0 = 0, s1 = 0;
-            int cnt = 0;
-            for (int c = 0; c < nx; c++) {
-                const uint32_t pk = ax[c];
-                const int t1 = (int)(pk & 0xffu), n = (int)((pk >> 8) & 0xffu);
-                if ((pk >> 16) && l >= t1 && l < t1 + n) {
-                    const uint32_t e = (1u << 31) | ((uint32_t)c << 12) | ((ax[64 + c] + (uint32_t)(l - t1) * (uint32_t)ix_ref) >> 16);
-                    if (cnt == 0) s0 = e;
-                    else if (cnt == 1) s1 = e;
-                    cnt++;
+            present[l] = 0;
+            lds->ci[0][l] = lds->ci[1][l] = lds->ri[0][l] = lds->ri[1][l] = 0;
+            for (int k = 0; k < 3; k++)
+                for (int sl = 0; sl < 2; sl++) {
+                    lds->srcx[k][sl][l] = 0xffu;
+                    lds->srcyw[k][sl][l] = 0xffffu;
                 }
-            }
-            lds->ci[0][l] = s0;
-            lds->ci[1][l] = s1;
-            uint32_t ov = cnt > 2;
-            s0 = 0;
-            s1 = 0;
-            cnt = 0;
-            for (int r = 0; r < ny_full; r++) {
-                const uint32_t pk = ax[32 + r];
-                const int t1 = (int)(pk & 0xffu), n = (int)((pk >> 8) & 0xffu);
-                if ((pk >> 16) && l >= t1 && l < t1 + n) {
-                    const uint32_t e = (1u << 31) | ((uint32_t)r << 12) | ((ax[96 + r] + (uint32_t)(l - t1) * (uint32_t)iy_ref) >> 16);
-                    if (cnt == 0) s0 = e;
-                    else if (cnt == 1) s1 = e;
-                    cnt++;
-                }
-            }
-            lds->ri[0][l] = s0;
-            lds->ri[1][l] = s1;
-            PG_LV(over, l) = ov | (cnt > 2);
         }
         PG_SYNC();
-        bool ok = PG_BALLOT(l, PG_LV(over, l) != 0) == 0;
+        // cell -> grid object type (kept in cellimg until the classes are known)
+        const int ncell = nx * ny_full;
+        const uint32_t ny_inv = (uint32_t)(((1u << 20) + (uint32_t)ny_full - 1u) / (uint32_t)ny_full);
+        bool ok = true;
+        for (int base4 = 0; base4 < ncell; base4 += 256) {
+            PG_LANE_ARR(int, types, 4);
+            PG_FOR_LANES(l) {  // the grid reads of four chunks in flight together
+                for (int q = 0; q < 4; q++) {
+                    const int cidx = base4 + q * 64 + l;
+                    const int cc = cidx < ncell ? cidx : 0;
+                    const int cx = (int)(((uint32_t)cc * ny_inv) >> 20);
+                    PG_LA(types, q, l) = get_obj(win_lx + cx, win_ly + (cc - cx * ny_full));
+                }
+            }
+            for (int q = 0; q < 4 && base4 + q * 64 < ncell; q++) {
+                const uint64_t bad = PG_BALLOT(l, ({
+                                                   const int cidx = base4 + q * 64 + l;
+                                                   bool b = false;
+                                                   if (cidx < ncell) {
+                                                       const int type = PG_LA(types, q, l);
+                                                       uint32_t v = CELL_NONE;
+                                                       if (type >= 0 && type < 64) {
+                                                           const uint32_t tv = lds->typeany[type];
+                                                           if (tv == TYPE_SLOW) b = true;
+                                                           else if (tv != CELL_NONE) {
+                                                               v = (uint32_t)type;
+                                                               present[type] = 1;  // several lanes may store the same 1
+                                                           }
+                                                       } else if (type != INVALID_OBJ && type != SPACE) {
+                                                           b = true;
+                                                       }
+                                                       lds->cellimg[cidx] = v;
+                                                   }
+                                                   b;
+                                               }));
+                ok = ok && bad == 0;
+            }
+        }
+        if (!ok) return false;
+        PG_SYNC();
+        // size classes of the types on screen
+        PG_LANE_VAR(uint32_t, key);
+        PG_LANE_VAR(uint32_t, cls);
+        const uint32_t key0 = ((uint32_t)ref_w << 16) | (uint32_t)ref_h;
+        PG_FOR_LANES(l) {
+            PG_LV(key, l) = present[l] ? lds->typesz[l] : key0;
+            PG_LV(cls, l) = 0;
+        }
+        uint32_t ckey[4] = {key0, key0, key0, key0};
+        int ncls = 1;
+        uint64_t todo = PG_BALLOT(l, PG_LV(key, l) != key0);
+        while (todo) {
+            const int leader = pg_ctz64(todo);
+            const uint32_t kk = PG_READLANE(key, leader);
+            if (ncls >= 4 || (kk >> 16) > 255u || (kk & 0xffffu) > 255u) return false;
+            const uint64_t same = PG_BALLOT(l, PG_LV(key, l) == kk);
+            PG_FOR_LANES(l) {
+                if ((same >> l) & 1ull) PG_LV(cls, l) = (uint32_t)ncls;
+            }
+            ckey[ncls++] = kk;
+            todo &= ~same;
+        }
+        multi = ncls > 1;
+        PG_FOR_LANES(l) {
+            const uint32_t tv = lds->typeany[l];
+            if (tv != CELL_NONE && tv != TYPE_SLOW) lds->typeany[l] = tv | (PG_LV(cls, l) << 27);
+        }
+        PG_SYNC();
+        for (int base = 0; base < ncell; base += 64) {
+            PG_FOR_LANES(l) {
+                if (base + l < ncell) {
+                    const uint32_t t = lds->cellimg[base + l];
+                    if (t != CELL_NONE) lds->cellimg[base + l] = lds->typeany[t];
+                }
+            }
+        }
+        // pixel spans of the cell columns (lanes 0..31) and rows (lanes 32..63): the rect alone decides them
+        PG_FOR_LANES(l) {
+            const bool col = l < 32;
+            const int idx = col ? l : l - 32;
+            uint32_t sp = 0;
+            if (idx < (col ? nx : ny_full)) {
+                const RectD r = col ? get_screen_rect((float)(win_lx + idx), 1.0f, 1, 1, RENDER_EPS) : get_screen_rect(0.0f, (float)(win_ly + idx + 1), 1, 1, RENDER_EPS);
+                const double pos = col ? r.x : r.y, len = col ? r.w : r.h;
+                int t1 = q_round(pos), t2 = q_round(pos + len);
+                if (t1 < 0) t1 = 0;
+                if (t2 > (col ? RES_W : RES_H)) t2 = col ? RES_W : RES_H;
+                if (t2 > t1) sp = (uint32_t)t1 | ((uint32_t)(t2 - t1) << 8);
+            }
+            span[l] = sp;
+        }
+        PG_SYNC();
+        PG_LANE_VAR(uint32_t, over);
+        PG_FOR_LANES(l) { PG_LV(over, l) = 0; }
+        for (int k = 0; k < ncls; k++) {
+            const int cw = (int)(ckey[k] >> 16), ch = (int)(ckey[k] & 0xffffu);
+            PG_FOR_LANES(l) {
+                const bool col = l < 32;
+                const int idx = col ? l : l - 32;
+                const uint32_t sp = span[l];
+                const int t1 = (int)(sp & 0xffu), n0 = (int)(sp >> 8);
+                if (n0 > 0) {
+                    const RectD r = col ? get_screen_rect((float)(win_lx + idx), 1.0f, 1, 1, RENDER_EPS) : get_screen_rect(0.0f, (float)(win_ly + idx + 1), 1, 1, RENDER_EPS);
+                    const double pos = col ? r.x : r.y, len = col ? r.w : r.h;
+                    const int src_len = col ? cw : ch;
+                    const int step = (int)(65536 / (len / (double)src_len));  // as cmd_image, one axis
+                    const uint32_t b = (uint32_t)((int)pg_ceil((t1 + 0.5 - pos) * step) - 1);
+                    int n = n0;
+                    const int end = (int)((b + (uint32_t)step * (uint32_t)(n - 1)) >> 16);
+                    if (end < 0 || end >= src_len) --n;
+                    const uint32_t s1 = idx >= 1 ? span[l - 1] : 0u, s2 = idx >= 2 ? span[l - 2] : 0u;
+                    for (int j = 0; j < n0; j++) {
+                        const int p = t1 + j;
+                        // cells before this one in draw order that also cover the pixel take the lower slot
+                        const int slot = ((p >= (int)(s1 & 0xffu) && p < (int)((s1 & 0xffu) + (s1 >> 8))) ? 1 : 0) + ((p >= (int)(s2 & 0xffu) && p < (int)((s2 & 0xffu) + (s2 >> 8))) ? 1 : 0);
+                        if (slot >= 2) {
+                            PG_LV(over, l) = 1;
+                            continue;
+                        }
+                        const bool sv = j < n;
+                        const uint32_t sc = (b + (uint32_t)j * (uint32_t)step) >> 16;
+                        if (k == 0) {
+                            const uint32_t e = (1u << 31) | (sv ? (1u << 30) : 0u) | ((uint32_t)idx << 12) | (sv ? (sc & 0xfffu) : 0u);
+                            if (col) lds->ci[slot][p] = e;
+                            else lds->ri[slot][p] = e;
+                        } else if (col) {
+                            lds->srcx[k - 1][slot][p] = (uint8_t)(sv ? sc : 0xffu);
+                        } else {
+                            lds->srcyw[k - 1][slot][p] = (uint16_t)(sv ? sc * (uint32_t)cw : 0xffffu);
+                        }
+                    }
+                }
+            }
+        }
+        PG_SYNC();
+        if (PG_BALLOT(l, PG_LV(over, l) != 0) != 0) return false;
         colseam = PG_BALLOT(l, (lds->ci[1][l] >> 31) != 0);
         rowseam = PG_BALLOT(l, (lds->ri[1][l] >> 31) != 0);
         PG_FOR_LANES(l) {
             if ((colseam >> l) & 1ull) lds->seamcols[pg_popc64(colseam & pg_mask_lt(l))] = (uint32_t)l;
         }
-        // cell -> image
-        const int ncell = nx * ny_full;
-        const uint32_t ny_inv = (uint32_t)(((1u << 20) + (uint32_t)ny_full - 1u) / (uint32_t)ny_full);
-        const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
-        for (int base = 0; base < ncell; base += 64) {
-            PG_LANE_VAR(uint32_t, bad);
-            PG_FOR_LANES(l) {
-                const int cidx = base + l;
-                PG_LV(bad, l) = 0;
-                if (cidx < ncell) {
-                    const int cx = (int)(((uint32_t)cidx * ny_inv) >> 20);
-                    const int cy = cidx - cx * ny_full;
-                    const int type = get_obj(win_lx + cx, win_ly + cy);
-                    uint32_t v = CELL_NONE;
-                    bool is_fill = false;
-                    if constexpr (GameHasGridFills<Game>::value) is_fill = Game::is_grid_fill(*this, type);
-                    const uint32_t tv = (type >= 0 && type < 64) ? lds->typeimg[type] : TYPE_SLOW;
-                    if (tv != TYPE_SLOW) {
-                        v = tv;  // an image of the reference size on the unadjusted cell rect, or nothing
-                    } else if (is_fill) {
-                        PG_LV(bad, l) = 1;  // solid squares are not part of the pull form: per-cell commands for this frame
-                    } else if (type != INVALID_OBJ && type != SPACE) {
-                        const int theme = Game::theme_for_grid_obj(*this, type);
-                        RectD r2 = get_screen_rect((float)(win_lx + cx), (float)(win_ly + cy + 1), 1, 1, RENDER_EPS);
-                        const RectD r2_in = r2;
-                        uint32_t fc = 0;
-                        const int im = resolve_image(type, theme, 0.0f, 0.0f, r2, &fc);
-                        if (im == IMG_FILL) PG_LV(bad, l) = 1;
-                        if (im >= 0) {
-                            const ImgDesc imd = d.assets->img[im];
-                            const bool same_rect = r2.x == r2_in.x && r2.y == r2_in.y && r2.w == r2_in.w && r2.h == r2_in.h;
-                            if (same_rect && (int)imd.w == ref_w && (int)imd.h == ref_h && imd.off < 0x7fffffffu) v = imd.off | (imd.opaque ? (1u << 31) : 0u);
-                            else PG_LV(bad, l) = 1;
-                        }
-                    }
-                    lds->cellimg[cidx] = v;
-                }
-            }
-            ok = ok && PG_BALLOT(l, PG_LV(bad, l) != 0) == 0;
-        }
         PG_SYNC();
-        return ok;
+        return true;
     }
-    // texel of cell (ce, re) for one pixel, branch-free: lanes without a cell fetch atlas word 0 and report no hit
-    // (per-lane `if`s around memory operations cost exec-mask juggling on the CU's single scalar unit)
-    PG_DEV bool pull_fetch(uint32_t ce, uint32_t re, int ny_full, int ref_w, uint32_t &tex, bool &opaque) const {
-        const bool valid = ((ce & re) >> 31) != 0;
+    // texel of the cell under one pixel for the column slot sc / row slot sr, branch-free: lanes without a cell fetch
+    // atlas word 0 and report no hit (per-lane `if`s around memory operations cost exec-mask juggling on the CU's
+    // single scalar unit).  MULTI: the frame has cells of more than one image size.
+    template <bool MULTI>
+    PG_DEV bool pull_fetch(uint32_t ce, uint32_t re, int sc, int sr, int x, int y, int ny_full, int ref_w, uint32_t &tex, bool &opaque) const {
+        const uint32_t both = ce & re;
+        const bool covered = (both >> 31) != 0;
         const uint32_t cell = lds->cellimg[((ce >> 12) & 0x1fu) * (uint32_t)ny_full + ((re >> 12) & 0x1fu)];
-        const bool hit = valid && cell != CELL_NONE;
         opaque = (cell >> 31) != 0;
-        const uint32_t addr = (cell & 0x7fffffffu) + (re & 0xfffu) * (uint32_t)ref_w + (ce & 0xfffu);
-        tex = d.pixels[hit ? addr : 0u];
+        const bool v0 = ((both >> 30) & 1u) != 0;
+        uint32_t rel = (re & 0xfffu) * (uint32_t)ref_w + (ce & 0xfffu);
+        bool hit = covered && cell != CELL_NONE;
+        if (MULTI) {
+            const uint32_t k = (cell >> 27) & 3u;  // CELL_NONE reads class 3: in bounds, never a hit
+            const uint32_t kk = k ? k - 1u : 0u;
+            const uint32_t sx1 = lds->srcx[kk][sc][x], sy1 = lds->srcyw[kk][sr][y];
+            hit = hit && (k ? (sx1 != 0xffu && sy1 != 0xffffu) : v0);
+            rel = k ? sy1 + sx1 : rel;
+        } else {
+            hit = hit && v0;
+        }
+        tex = d.pixels[hit ? (cell & 0x7ffffffu) + rel : 0u];
         return hit;
     }
+    template <bool MULTI>
     PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam) {
         const int ref_w = d.assets->ref_w;
         const int nseam = pg_popc64(colseam);
-        // stage 1: (c0, r0), lane = screen column, 8 rows of fetches in flight; stage 2: (c0, r1) on doubly covered rows
+        // stage 1: (c0, r0), lane = screen column, a band of fetches in flight; stage 2: (c0, r1) on doubly covered rows
         for (int slot_r = 0; slot_r < 2; slot_r++) {
             const int rows = slot_r == 0 ? WIDE_ROWS : 8;  // stage 1 fetches a whole band at once; the seam rows go 8 at a time
             for (int yb = row0; yb < row1; yb += rows) {
@@ -629,7 +743,7 @@ struct Renderer {
                         _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
                             opq[j] = false;
                             tex[j] = 0;
-                            hit[j] = pull_fetch(ce, lds->ri[0][yb + j], ny_full, ref_w, tex[j], opq[j]);
+                            hit[j] = pull_fetch<MULTI>(ce, lds->ri[0][yb + j], 0, 0, l, yb + j, ny_full, ref_w, tex[j], opq[j]);
                         }
                         _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
                             uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];  // this lane owns the pixel
@@ -648,7 +762,7 @@ struct Renderer {
                     _Pragma("unroll") for (int j = 0; j < 8; j++) {
                         opq[j] = false;
                         tex[j] = 0;
-                        hit[j] = pull_fetch(ce, lds->ri[slot_r][yb + j], ny_full, ref_w, tex[j], opq[j]);
+                        hit[j] = pull_fetch<MULTI>(ce, lds->ri[1][yb + j], 0, 1, l, yb + j, ny_full, ref_w, tex[j], opq[j]);
                     }
                     _Pragma("unroll") for (int j = 0; j < 8; j++) {
                         uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];  // this lane owns the pixel
@@ -678,7 +792,7 @@ struct Renderer {
                         const int pc = in ? p : 0;
                         const int yl = (int)(((uint32_t)pc * inv) >> 20);
                         const int x = (int)lds->seamcols[pc - yl * nseam];
-                        const bool hit = pull_fetch(lds->ci[1][x], lds->ri[slot_r][row0 + yl], ny_full, ref_w, tex[j], opq[j]) && in;
+                        const bool hit = pull_fetch<MULTI>(lds->ci[1][x], lds->ri[slot_r][row0 + yl], 1, slot_r, x, row0 + yl, ny_full, ref_w, tex[j], opq[j]) && in;
                         fbi[j] = hit ? yl * RES_W + x : BAND_ROWS * RES_W + l;  // masked-off lanes use the dump row
                     }
                     _Pragma("unroll") for (int j = 0; j < 8; j++) {
@@ -1196,6 +1310,7 @@ struct Renderer {
             PG_HDR_FIELDS(PG_X)
 #undef PG_X
         }
+        phase(6);
         // ---- frame-level set-up (rows [0, 64)) ------------------------------------------------------------------
         row0 = 0;
         row1 = RES_H;
@@ -1249,12 +1364,14 @@ struct Renderer {
             add_bg(bgi, bg_rect);
             }
         }
+        phase(7);
         // common case (<= 64 entities): their commands are built once and kept in registers for all passes
         if (d.debug_flags & 4) G.n_ents = 0;
         const bool one_chunk = G.n_ents <= 64;
         CmdRegs er;
         uint64_t ezmask[3] = {0, 0, 0};
         if (one_chunk) setup_entities(0, er, ezmask);
+        phase(8);
         int win_lx, win_hx, win_ly, win_hy;  // BAG:926-939
         if (Game::center_agent(d.opt)) {
             const float margin = (float)(G.visibility / 2.0 + 1);
@@ -1275,11 +1392,16 @@ struct Renderer {
         int ix_ref = 0, iy_ref = 0;
         if (use_axes) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);
         uint64_t colseam = 0, rowseam = 0;
+        phase(9);
         build_type_table();
-        bool pull = false;
+        phase(10);
+        bool pull = false, pull_multi = false;
         if constexpr (GameDrawsGrid<Game>::value)
-            pull = use_axes && nx * ny_full <= 1024 && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, ix_ref, iy_ref, colseam, rowseam);
+            pull = use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, pull_multi);
 
+#if defined(PGAMD_WAVE_EMU) && defined(PG_TRACE_PULL)
+        fprintf(stderr, "pull %d multi %d\n", (int)pull, (int)pull_multi);
+#endif
         phase(0);
         // ---- passes -------------------------------------------------------------------------------------------------
         for (int band = 0; band < NUM_BANDS; band++) {
@@ -1317,7 +1439,10 @@ struct Renderer {
             if (ncell > 4096) fail(PGE_ASSERT);
             phase(2);
             if constexpr (GameDrawsGrid<Game>::value)
-                if (pull && !(d.debug_flags & 2)) draw_tiles_pull(ny_full, colseam, rowseam);
+                if (pull && !(d.debug_flags & 2)) {
+                    if (pull_multi) draw_tiles_pull<true>(ny_full, colseam, rowseam);
+                    else draw_tiles_pull<false>(ny_full, colseam, rowseam);
+                }
             for (int base = 0; base < ((pull || (d.debug_flags & 2)) ? 0 : ncell); base += 64) {
                 CmdRegs r;
                 PG_FOR_LANES(l) {
