@@ -13,6 +13,7 @@ struct BigFish {
     static constexpr int MAX_CELLS = 20 * 20;  // bigfish.cpp:29-30 (padded to a 16-byte multiple below)
     static constexpr bool USES_ENTITY_COLLISIONS = false;
     static constexpr int ENT_CAP_T0 = 64, ENT_CAP_T1 = 128, ENT_CAP_T2 = 256;  // <= 1 spawn per step; ~5-15 fish alive
+    static constexpr bool DRAWS_GRID = false;  // the grid holds only SPACE
     template <class E>
     PG_DEV static int slots_needed_next_step(E &e) { return e.G.n_ents + 1 + 3; }
 

@@ -15,6 +15,7 @@ struct BossFight : BagDefaults<BossFight> {
     static constexpr bool USES_ROTATION = true;  // bullets and trails spin (vrot)
     static constexpr bool DRAWS_GRID = false;
     static constexpr int ENT_CAP_T0 = 128, ENT_CAP_T1 = 256, ENT_CAP_T2 = 512;
+    static constexpr int RENDER_CMD_SETS = 2;  // frames with more than 64 visible entities are common
 
     static constexpr int PLAYER_BULLET = 1, BOSS = 2, SHIELDS = 3, ENEMY_BULLET = 4, LASER_TRAIL = 5, REFLECTED_BULLET = 6, BARRIER = 7;
     static constexpr float BOSS_R = 3;

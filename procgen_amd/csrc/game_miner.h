@@ -159,6 +159,28 @@ struct Miner {
         int diamonds_count = 0;
         for (int base = 0; base < main_area; base += 64) {
             uint64_t m = PG_BALLOT(l, (base + l) < main_area && is_round((int)e.s->grid[base + l]));
+            {
+                // Settled objects (a resting boulder / diamond on dirt, rock or the floor) take the last branch below and
+                // change nothing; nothing the sweep does earlier can unsettle them (it only writes to free cells and
+                // to the cells of objects it moves), so they are counted here and leave the serial work list.
+                PG_LANE_VAR(int, own);
+                const uint64_t settled = PG_BALLOT(l, ({
+                                                       const int idx = base + l;
+                                                       bool st = false;
+                                                       PG_LV(own, l) = 0;
+                                                       if (idx < main_area) {
+                                                           const int obj = (int)e.s->grid[idx];
+                                                           PG_LV(own, l) = obj;
+                                                           if (obj == BOULDER || obj == DIAMOND) {
+                                                               const int below = get_idx(e, idx - w);
+                                                               st = below != SPACE && !is_round(below);
+                                                           }
+                                                       }
+                                                       st;
+                                                   }));
+                diamonds_count += pg_popc64(settled & PG_BALLOT(l, PG_LV(own, l) == DIAMOND));
+                m &= ~settled;
+            }
             while (m) {
                 const int bit = pg_ctz64(m);
                 m &= m - 1;

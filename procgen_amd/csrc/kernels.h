@@ -14,6 +14,15 @@ struct LaunchStreams {
     hipEvent_t tier2_done;    // the tier-2 list kernel runs on lane[1] ahead of that lane's chunk
     int chunks;               // 1 = everything on `main`
 };
+// what one per-game kernel object (kernels_game.hip) exports
+struct GameEntry {
+    int game_id;
+    hipError_t (*launch)(const DevCtx &, int mode, const LaunchStreams &);
+    hipError_t (*render_one)(const DevCtx &, int env, hipStream_t);
+    int cap_t0, cap_t1, cap_t2;  // entity slots of the three LDS arenas; cap_t2 is the HBM table size
+    int grid_bytes;
+    void (*init_state)(int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
+};
 // mode 0: initial reset + first observation of every env; mode 1: one step
 hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStreams &ls);
 hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream);

@@ -1,0 +1,113 @@
+// kernels_game.hip -- gfx950 kernels of the vectorized stepper, compiled once per game (-DPG_GAME=<policy struct>):
+// the sixteen instantiations build in parallel and land in one libenv.so; kernels.hip holds the table that dispatches on game id.  One workgroup = one 64-lane wavefront = one env.
+//
+//   step_tier0<Game> : grid = num_envs; LDS arena for Game::ENT_CAP_T0 entities (10 KB -> 16 workgroups / CU); skips
+//                      envs routed to a larger arena.
+//   step_list<Game,CAP,T> : fixed grids that walk the lists of envs whose entity table may outgrow the smaller
+//                      arenas (ENT_CAP_T1 / ENT_CAP_T2), on a side stream.
+//   render<Game>     : grid = num_envs, one wave per env: four passes of 16 rows through a 4 KB LDS band, RGB888
+//                      observation stores (pg_render.h).
+// The step kernels run Env<Game,CAP>::run (pg_env.h): HBM -> LDS staging, Game::step / reset + level generation,
+// state write-back.
+#include <hip/hip_runtime.h>
+
+#include "games.h"
+#include "pg_render.h"
+#include "kernels.h"
+
+namespace pgamd {
+
+template <class Game>
+__global__ __launch_bounds__(64) void step_tier0(DevCtx d, int mode, int env_base) {
+    __shared__ Lds<Game, Game::ENT_CAP_T0> lds;
+    const int env = env_base + (int)blockIdx.x;
+    if (mode != 0 && d.route[env] != 0) return;  // owned by a larger arena this step
+    Env<Game, Game::ENT_CAP_T0> e(d, env, &lds);
+    e.run(mode);
+}
+
+template <class Game, int CAP, int TIER>
+__global__ __launch_bounds__(64) void step_list(DevCtx d, int mode) {
+    __shared__ Lds<Game, CAP> lds;
+    const int count = d.big_count[TIER - 1];
+    const int *list = d.big_list + (size_t)(TIER - 1) * d.num_envs;
+    for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+        const int env = list[k];
+        if (d.route[env] != TIER) continue;  // set_state moved this env to another tier after the list was built
+        Env<Game, CAP> e(d, env, &lds);
+        e.run(mode);
+        __syncthreads();
+    }
+}
+
+template <class Game>
+__global__ __launch_bounds__(64) void render(DevCtx d, int env_base) {
+    __shared__ RenderLdsT<Game> lds;
+    Renderer<Game> r(d, env_base + (int)blockIdx.x, &lds);
+    r.render_env();
+}
+
+// The two step kernels touch disjoint envs, so the (few, slow, low-occupancy) large-arena envs run on a side
+// stream concurrently with the small-arena grid.  The env range is further cut into chunks that alternate between
+// two streams: the latency-bound step kernel of one chunk shares the CUs with the issue-bound render kernel of the
+// previous chunk instead of the two phases running back to back.
+template <class Game>
+static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls) {
+#define PG_TRY(x)                          \
+    do {                                   \
+        hipError_t e_ = (x);               \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+    PG_TRY(hipEventRecord(ls.fork, ls.main));
+    if (mode != 0) {
+        PG_TRY(hipStreamWaitEvent(ls.side, ls.fork, 0));
+        const int g1 = d.num_envs < 8192 ? d.num_envs : 8192, g2 = d.num_envs < 2048 ? d.num_envs : 2048;
+        // the two list kernels run on their own streams (lane[1] is otherwise idle when chunks == 1)
+        PG_TRY(hipStreamWaitEvent(ls.lane[1], ls.fork, 0));
+        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.side, d, mode);
+        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.lane[1], d, mode);
+        PG_TRY(hipEventRecord(ls.tier2_done, ls.lane[1]));
+        PG_TRY(hipStreamWaitEvent(ls.side, ls.tier2_done, 0));
+        PG_TRY(hipEventRecord(ls.join, ls.side));
+    }
+    const int nchunk = (ls.chunks > 1 && d.num_envs >= 4096) ? ls.chunks : 1;
+    const int per = (d.num_envs + nchunk - 1) / nchunk;
+    for (int c = 0; c < nchunk; c++) {
+        const int base = c * per;
+        const int count = (d.num_envs - base) < per ? (d.num_envs - base) : per;
+        if (count <= 0) break;
+        hipStream_t st = nchunk == 1 ? ls.main : ls.lane[c & 1];
+        if (nchunk > 1 && c < 2) PG_TRY(hipStreamWaitEvent(st, ls.fork, 0));
+        if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(count), dim3(64), 0, st, d, mode, base);
+        if (mode != 0) PG_TRY(hipStreamWaitEvent(st, ls.join, 0));
+        if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(count), dim3(64), 0, st, d, base);
+    }
+    if (nchunk > 1) {
+        for (int k = 0; k < 2; k++) {
+            PG_TRY(hipEventRecord(ls.lane_done[k], ls.lane[k]));
+            PG_TRY(hipStreamWaitEvent(ls.main, ls.lane_done[k], 0));
+        }
+    }
+#undef PG_TRY
+    return hipGetLastError();
+}
+
+
+template <class Game>
+static hipError_t render_one(const DevCtx &d, int env, hipStream_t stream) {  // re-renders one env (after set_state)
+    hipLaunchKernelGGL(render<Game>, dim3(1), dim3(64), 0, stream, d, env);
+    return hipGetLastError();
+}
+
+#define PG_CAT2(a, b) a##b
+#define PG_CAT(a, b) PG_CAT2(a, b)
+// a host function (a namespace-scope const table would also be emitted for the device, where the launchers do not exist)
+const GameEntry *PG_CAT(game_entry_, PG_GAME)() {
+    static const GameEntry e = {
+        PG_GAME::GAME_ID,    launch_game<PG_GAME>,       render_one<PG_GAME>,     PG_GAME::ENT_CAP_T0, PG_GAME::ENT_CAP_T1,
+        PG_GAME::ENT_CAP_T2, game_grid_bytes<PG_GAME>(), init_env_state<PG_GAME>,
+    };
+    return &e;
+}
+
+}  // namespace pgamd

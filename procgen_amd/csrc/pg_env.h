@@ -614,11 +614,13 @@ struct Env {
         int pc[2][4];
         int pneg[2];
         bool pvalid[2], pblock[2], preflect[2];
+        bool eventful;  // the last sub_step reflected, was blocked or touched another entity
     };
     PG_DEV void obj_load(int obj, ObjRegs &R) {
         R.x = ex(obj); R.y = ey(obj); R.vx = evx(obj); R.vy = evy(obj); R.rx = erx(obj); R.ry = ery(obj);
         R.type = etype(obj);
         R.pvalid[0] = R.pvalid[1] = false;
+        R.eventful = false;
     }
     PG_DEV void obj_flush(int obj, const ObjRegs &R) {
         ex(obj) = R.x; ey(obj) = R.y; evx(obj) = R.vx; evy(obj) = R.vy;
@@ -716,7 +718,9 @@ struct Env {
                                          }));
             any_hit = m != 0;
         }
+        if (block || reflect) R.eventful = true;
         if (!any_hit) return block;
+        R.eventful = true;
         obj_flush(obj, R);
         const bool block2 = entity_scan<0>(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory);
         PG_SYNC();
@@ -781,6 +785,7 @@ struct Env {
         float vx_pct = 0, vy_pct = 0;
         for (int st = 0; st < num_sub_steps; st++) {
             bool block_x = false, block_y = false;
+            R.eventful = false;
             for (int h = 0; h < 2; h++) {  // one call site for sub_step_top
                 const bool xaxis = (h == 0) == step_x_first;
                 const float dvx = xaxis ? R.vx * pct : 0.0f;
@@ -792,6 +797,12 @@ struct Env {
             if (!block_x) vx_pct += 1;
             if (!block_y) vy_pct += 1;
             if (block_x && block_y) break;
+            if (!R.eventful && R.vx * pct == 0 && R.vy * pct == 0) {
+                // an object at rest that nothing blocked, reflected or touched: the remaining sub_steps see the same state
+                vx_pct += (float)(num_sub_steps - 1 - st);
+                vy_pct += (float)(num_sub_steps - 1 - st);
+                break;
+            }
         }
         vx_pct = vx_pct / num_sub_steps;
         vy_pct = vy_pct / num_sub_steps;

@@ -74,6 +74,16 @@ template <class Game>
 struct GamePullCells<Game, decltype((void)Game::PULL_CELLS)> {
     static constexpr int value = Game::PULL_CELLS;
 };
+// register sets (64 draw commands each) the frame's visible entities are packed into; a policy that routinely shows
+// more than 64 entities asks for two (RENDER_CMD_SETS)
+template <class Game, class = void>
+struct GameRenderCmdSets {
+    static constexpr int value = 1;
+};
+template <class Game>
+struct GameRenderCmdSets<Game, decltype((void)Game::RENDER_CMD_SETS)> {
+    static constexpr int value = Game::RENDER_CMD_SETS;
+};
 template <class Game, class = void>
 struct GameUsesTiledEntities {
     static constexpr bool value = false;
@@ -121,12 +131,13 @@ struct RenderLdsT {
     uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of this frame (build_type_table)
     uint32_t typeany[GameDrawsGrid<Game>::value ? 64 : 1];    // ... of any size: atlas offset | size class<<27 | opaque<<31 (pull form)
     uint32_t typesz[GameDrawsGrid<Game>::value ? 64 : 1];     // its width<<16 | height
-    uint8_t srcx[3][2][64];          // size classes 1..3: screen column -> source column, per covering slot
-    uint16_t srcyw[3][2][64];        // size classes 1..3: screen row -> source row * image width
+    uint8_t srcx[GameDrawsGrid<Game>::value ? 3 : 1][2][64];    // size classes 1..3: screen column -> source column, per covering slot
+    uint16_t srcyw[GameDrawsGrid<Game>::value ? 3 : 1][2][64];  // size classes 1..3: screen row -> source row * image width
     uint32_t cellimg[GameDrawsGrid<Game>::value ? GamePullCells<Game>::value : 1];  // window cell -> source image (atlas offset | opaque<<31), CELL_NONE = nothing to draw
     uint32_t rot[GameUsesRotation<Game>::value ? 64 * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane
 };
 constexpr uint32_t CELL_NONE = 0xffffffffu;
+constexpr uint32_t CELL_FILL = 0xfffffffdu;  // build_pull_tables, transient: a solid-colour cell (draw_grid_obj override) waiting for its command
 constexpr uint32_t TYPE_SLOW = 0xfffffffeu;  // typeimg: this type needs the per-cell path (fill, odd image size, adjusted rect, missing asset)
 
 // x86 double -> int32 conversion (cvttsd2si): out-of-range and NaN give INT_MIN.  Qt's edge walkers convert
@@ -147,7 +158,6 @@ struct Renderer {
     int ecap;
     const typename Game::cell_t *gg;
     int row0, row1;  // band rows [row0, row1)
-    int ent_base = 0;  // first entity of the chunk whose commands run_batch is executing (tiled commands look their entity up)
 
     PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(lds_->ax) {
         ge = d.ents + (size_t)env * EF_COUNT * d.ent_cap;
@@ -544,7 +554,8 @@ struct Renderer {
     // pixel depends on the rect alone; whether that cell has a sample there is per class (Qt drops a last sample
     // that would fall outside the source).  Returns false when the frame needs the per-cell path: solid-colour
     // cells, adjusted rects, more than four sizes, three cells over one pixel.
-    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, uint64_t &colseam, uint64_t &rowseam, bool &multi) {
+    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, uint64_t &colseam, uint64_t &rowseam, bool &multi, int &nfill_out) {
+        nfill_out = 0;
         const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
         uint32_t *present = fb;  // scratch: the band buffer is idle during set-up
         uint32_t *span = fb + 64;
@@ -579,7 +590,11 @@ struct Renderer {
                                                    if (cidx < ncell) {
                                                        const int type = PG_LA(types, q, l);
                                                        uint32_t v = CELL_NONE;
-                                                       if (type >= 0 && type < 64) {
+                                                       bool is_fill = false;
+                                                       if constexpr (GameHasGridFills<Game>::value) is_fill = Game::is_grid_fill(*this, type);
+                                                       if (is_fill) {
+                                                           v = CELL_FILL;
+                                                       } else if (type >= 0 && type < 64) {
                                                            const uint32_t tv = lds->typeany[type];
                                                            if (tv == TYPE_SLOW) b = true;
                                                            else if (tv != CELL_NONE) {
@@ -630,7 +645,7 @@ struct Renderer {
             PG_FOR_LANES(l) {
                 if (base + l < ncell) {
                     const uint32_t t = lds->cellimg[base + l];
-                    if (t != CELL_NONE) lds->cellimg[base + l] = lds->typeany[t];
+                    if (t != CELL_NONE && t != CELL_FILL) lds->cellimg[base + l] = lds->typeany[t];
                 }
             }
         }
@@ -650,6 +665,59 @@ struct Renderer {
             span[l] = sp;
         }
         PG_SYNC();
+        if constexpr (GameHasGridFills<Game>::value) {
+            // Solid-colour cells (chaser's orbs) become fill commands kept behind the cell table.  They may run after the
+            // image cells only if no neighbouring cell's rect reaches the pixels they paint (their own cell draws
+            // nothing else): then no draw order between them and anything else in the grid pass is observable.
+            int nfill = 0;
+            const int fill_cap = (GamePullCells<Game>::value - ncell) / 2;
+            for (int base = 0; base < ncell; base += 64) {
+                PG_LANE_VAR(uint32_t, fg);
+                PG_LANE_VAR(uint32_t, fcol);
+                const uint64_t conflict = PG_BALLOT(l, ({
+                                                        bool bad = false;
+                                                        const int cidx = base + l;
+                                                        PG_LV(fg, l) = 0;
+                                                        PG_LV(fcol, l) = 0;
+                                                        if (cidx < ncell && lds->cellimg[cidx] == CELL_FILL) {
+                                                            const int cx = (int)(((uint32_t)cidx * ny_inv) >> 20);
+                                                            const int cy = cidx - cx * ny_full;
+                                                            const int x = win_lx + cx, y = win_ly + cy;
+                                                            const RectD cell = get_screen_rect((float)x, (float)(y + 1), 1, 1, RENDER_EPS);
+                                                            RectD fr;
+                                                            uint32_t color = 0, g = 0, sc = 0, au = 0;
+                                                            Game::grid_fill(*this, get_obj(x, y), cell, fr, color);
+                                                            cmd_fill_rect(fr, color, g, sc, au);
+                                                            if (g != 0) {
+                                                                const int x1 = (int)(g & 0x7fu), y1 = (int)((g >> 7) & 0x7fu), x2 = x1 + (int)((g >> 14) & 0x7fu), y2 = y1 + (int)((g >> 21) & 0x7fu);
+                                                                for (int dlt = -1; dlt <= 1; dlt += 2) {
+                                                                    const uint32_t sx = (cx + dlt >= 0 && cx + dlt < nx) ? span[cx + dlt] : 0u;
+                                                                    const uint32_t sy = (cy + dlt >= 0 && cy + dlt < ny_full) ? span[32 + cy + dlt] : 0u;
+                                                                    const int ax1 = (int)(sx & 0xffu), ax2 = ax1 + (int)(sx >> 8), ay1 = (int)(sy & 0xffu), ay2 = ay1 + (int)(sy >> 8);
+                                                                    bad = bad || (ax2 > ax1 && ax1 < x2 && ax2 > x1) || (ay2 > ay1 && ay1 < y2 && ay2 > y1);
+                                                                }
+                                                            }
+                                                            PG_LV(fg, l) = g;
+                                                            PG_LV(fcol, l) = sc;
+                                                            lds->cellimg[cidx] = CELL_NONE;
+                                                        }
+                                                        bad;
+                                                    }));
+                if (conflict) return false;
+                const uint64_t vis = PG_BALLOT(l, PG_LV(fg, l) != 0);
+                const int cnt = pg_popc64(vis);
+                if (nfill + cnt > fill_cap) return false;
+                PG_FOR_LANES(l) {
+                    if ((vis >> l) & 1ull) {
+                        const int slot = nfill + pg_popc64(vis & pg_mask_lt(l));
+                        lds->cellimg[ncell + 2 * slot] = PG_LV(fg, l);
+                        lds->cellimg[ncell + 2 * slot + 1] = PG_LV(fcol, l);
+                    }
+                }
+                nfill += cnt;
+            }
+            nfill_out = nfill;
+        }
         PG_LANE_VAR(uint32_t, over);
         PG_FOR_LANES(l) { PG_LV(over, l) = 0; }
         for (int k = 0; k < ncls; k++) {
@@ -1166,7 +1234,7 @@ struct Renderer {
                 const DrawCmd c = read_cmd(r, k);
                 if (cmd_tiled(c.aux)) {
                     if constexpr (NESTED || !GameUsesTiledEntities<Game>::value) fail(PGE_ASSERT);
-                    else exec_tiled(ent_base + (int)(c.basex & 63u));
+                    else exec_tiled((int)c.basex);  // tiled commands carry their entity index
                 } else if (cmd_rotated(c.aux)) exec_rotated(c);
                 else exec_large(c);
             }
@@ -1225,11 +1293,21 @@ struct Renderer {
 
     // draw_entities BAG:1052-1066.  Commands of 64 entities are set up once (they do not depend on the layer) and
     // then executed per render_z layer through a lane mask.
-    PG_DEV void setup_entities(int base, CmdRegs &r, uint64_t (&zmask)[3]) {
+    // rot_base >= 0: the chunk's turned entities take consecutive rotation records from rot_base on (compact_entities);
+    // otherwise lane l uses record l.  Returns the number of records handed out.
+    PG_DEV int setup_entities(int base, CmdRegs &r, uint64_t (&zmask)[3], int rot_base = -1) {
         const int n = G.n_ents;
         for (int z = 0; z < 3; z++) zmask[z] = PG_BALLOT(l, (base + l) < n && meta_render_z(meta(base + l)) == z - 1);
+        uint64_t rotmask = 0;
+        if constexpr (GameUsesRotation<Game>::value) {
+            if (rot_base >= 0) {
+                rotmask = PG_BALLOT(l, (base + l) < n && ef(EF_ROTATION, base + l) != 0);
+                if (rot_base + pg_popc64(rotmask) > 64) return -1;
+            }
+        }
         PG_FOR_LANES(l) {
             const int i = base + l;
+            const int rot_slot = rot_base >= 0 ? rot_base + pg_popc64(rotmask & pg_mask_lt(l)) : l;
             PG_LV(r.geom, l) = 0;
             PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.src, l) = PG_LV(r.aux, l) = 0;
             if (i < n && Game::should_draw_entity(*this, i)) {
@@ -1263,17 +1341,72 @@ struct Renderer {
                         if (by2 > RES_H) by2 = RES_H;
                         if (bx2 > bx1 && by2 > by1) {
                             PG_LV(r.geom, l) = (uint32_t)bx1 | ((uint32_t)by1 << 7) | ((uint32_t)(bx2 - bx1) << 14) | ((uint32_t)(by2 - by1) << 21);
-                            PG_LV(r.basex, l) = (uint32_t)l;
+                            PG_LV(r.basex, l) = (uint32_t)i;
                             PG_LV(r.aux, l) = 1u << 25;
                         }
                     } else if (rotation == 0) cmd_image(im, (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
-                    else cmd_image_rotated(l, im, (mm & MF_REFLECTED) != 0, r1, rotation, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                    else cmd_image_rotated(rot_slot, im, (mm & MF_REFLECTED) != 0, r1, rotation, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                 }
             }
         }
         if constexpr (GameUsesRotation<Game>::value) PG_SYNC();  // the rotated commands' LDS records are read by every lane
+        return pg_popc64(rotmask);
     }
-    PG_DEV void draw_entities(int render_z) {  // general path (more than 64 entities): one set-up per layer and chunk
+    // More than 64 entities: most frames still show fewer than 128 of them (fruitbot keeps a whole level of
+    // objects alive, a dozen on screen), so the commands that draw something are packed, in draw order, into two register
+    // sets through the idle band buffer.  false: too many visible entities or turned sprites; draw_entities() then sets
+    // every chunk up again for every band and layer.
+    static constexpr int CMD_SETS = GameRenderCmdSets<Game>::value;
+    PG_DEV bool compact_entities(CmdRegs (&er)[CMD_SETS], uint64_t (&ezm)[CMD_SETS][3]) {
+        uint32_t *stage = fb;  // [8 words][64 * CMD_SETS slots]
+        constexpr int SLOTS = 64 * CMD_SETS;
+        static_assert(8 * SLOTS <= BAND_ROWS * RES_W + 64, "staging area");
+        const int n = G.n_ents;
+        int total = 0, rot_count = 0;
+        for (int base = 0; base < n; base += 64) {
+            CmdRegs r;
+            uint64_t zm[3];
+            const int nrot = setup_entities(base, r, zm, rot_count);
+            if (nrot < 0) return false;
+            rot_count += nrot;
+            const uint64_t vis = PG_BALLOT(l, PG_LV(r.geom, l) != 0);
+            const int cnt = pg_popc64(vis);
+            if (total + cnt > SLOTS) return false;
+            PG_FOR_LANES(l) {
+                if ((vis >> l) & 1ull) {
+                    const int slot = total + pg_popc64(vis & pg_mask_lt(l));
+                    stage[0 * SLOTS + slot] = PG_LV(r.geom, l);
+                    stage[1 * SLOTS + slot] = PG_LV(r.basex, l);
+                    stage[2 * SLOTS + slot] = PG_LV(r.srcy, l);
+                    stage[3 * SLOTS + slot] = PG_LV(r.ix, l);
+                    stage[4 * SLOTS + slot] = PG_LV(r.iy, l);
+                    stage[5 * SLOTS + slot] = PG_LV(r.src, l);
+                    stage[6 * SLOTS + slot] = PG_LV(r.aux, l);
+                    stage[7 * SLOTS + slot] = ((zm[0] >> l) & 1ull) ? 0u : (((zm[1] >> l) & 1ull) ? 1u : 2u);
+                }
+            }
+            total += cnt;
+        }
+        PG_SYNC();
+        _Pragma("unroll") for (int k = 0; k < CMD_SETS; k++) {
+            PG_FOR_LANES(l) {
+                const int idx = k * 64 + l;
+                const bool in = idx < total;
+                const int si = in ? idx : 0;
+                PG_LV(er[k].geom, l) = in ? stage[0 * SLOTS + si] : 0u;
+                PG_LV(er[k].basex, l) = in ? stage[1 * SLOTS + si] : 0u;
+                PG_LV(er[k].srcy, l) = in ? stage[2 * SLOTS + si] : 0u;
+                PG_LV(er[k].ix, l) = in ? stage[3 * SLOTS + si] : 0u;
+                PG_LV(er[k].iy, l) = in ? stage[4 * SLOTS + si] : 0u;
+                PG_LV(er[k].src, l) = in ? stage[5 * SLOTS + si] : 0u;
+                PG_LV(er[k].aux, l) = in ? stage[6 * SLOTS + si] : 0u;
+            }
+            _Pragma("unroll") for (int z = 0; z < 3; z++) ezm[k][z] = PG_BALLOT(l, (k * 64 + l) < total && stage[7 * SLOTS + k * 64 + l] == (uint32_t)z);
+        }
+        PG_SYNC();
+        return true;
+    }
+    PG_DEV void draw_entities(int render_z) {  // last resort: one set-up per band, layer and chunk
         const int n = G.n_ents;
         for (int base = 0; base < n; base += 64) {
             const uint64_t any = PG_BALLOT(l, (base + l) < n && meta_render_z(meta(base + l)) == render_z);
@@ -1281,7 +1414,6 @@ struct Renderer {
             CmdRegs r;
             uint64_t zmask[3];
             setup_entities(base, r, zmask);
-            ent_base = base;
             run_batch(r, zmask[render_z + 1]);
         }
     }
@@ -1367,10 +1499,20 @@ struct Renderer {
         phase(7);
         // common case (<= 64 entities): their commands are built once and kept in registers for all passes
         if (d.debug_flags & 4) G.n_ents = 0;
-        const bool one_chunk = G.n_ents <= 64;
-        CmdRegs er;
-        uint64_t ezmask[3] = {0, 0, 0};
-        if (one_chunk) setup_entities(0, er, ezmask);
+        bool one_chunk = G.n_ents <= 64;  // or: the visible ones fit the register sets
+        CmdRegs er[CMD_SETS];
+        uint64_t ezmask[CMD_SETS][3];
+        _Pragma("unroll") for (int k = 0; k < CMD_SETS; k++) {
+            ezmask[k][0] = ezmask[k][1] = ezmask[k][2] = 0;
+            PG_FOR_LANES(l) {
+                PG_LV(er[k].geom, l) = 0;
+                PG_LV(er[k].basex, l) = PG_LV(er[k].srcy, l) = PG_LV(er[k].ix, l) = PG_LV(er[k].iy, l) = PG_LV(er[k].src, l) = PG_LV(er[k].aux, l) = 0;
+            }
+        }
+        if (one_chunk) setup_entities(0, er[0], ezmask[0]);
+#if !defined(PG_NO_COMPACT)
+        else one_chunk = compact_entities(er, ezmask);
+#endif
         phase(8);
         int win_lx, win_hx, win_ly, win_hy;  // BAG:926-939
         if (Game::center_agent(d.opt)) {
@@ -1396,8 +1538,9 @@ struct Renderer {
         build_type_table();
         phase(10);
         bool pull = false, pull_multi = false;
+        int pull_nfill = 0, pull_ncell = nx * ny_full;
         if constexpr (GameDrawsGrid<Game>::value)
-            pull = use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, pull_multi);
+            pull = use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, pull_multi, pull_nfill);
 
 #if defined(PGAMD_WAVE_EMU) && defined(PG_TRACE_PULL)
         fprintf(stderr, "pull %d multi %d\n", (int)pull, (int)pull_multi);
@@ -1417,7 +1560,8 @@ struct Renderer {
             }
             phase(1);
             if (one_chunk) {
-                if (ezmask[0]) run_batch(er, ezmask[0]);
+                _Pragma("unroll") for (int k = 0; k < CMD_SETS; k++)
+                    if (ezmask[k][0]) run_batch(er[k], ezmask[k][0]);
             } else {
                 draw_entities(-1);
             }
@@ -1442,6 +1586,20 @@ struct Renderer {
                 if (pull && !(d.debug_flags & 2)) {
                     if (pull_multi) draw_tiles_pull<true>(ny_full, colseam, rowseam);
                     else draw_tiles_pull<false>(ny_full, colseam, rowseam);
+                    if constexpr (GameHasGridFills<Game>::value) {
+                        for (int base = 0; base < pull_nfill; base += 64) {
+                            CmdRegs r;
+                            PG_FOR_LANES(l) {
+                                const bool in = base + l < pull_nfill;
+                                const int si = pull_ncell + 2 * (in ? base + l : 0);
+                                PG_LV(r.geom, l) = in ? lds->cellimg[si] : 0u;
+                                PG_LV(r.src, l) = in ? lds->cellimg[si + 1] : 0u;
+                                PG_LV(r.aux, l) = cmd_aux(1, false, true, 256) | (1u << 26);
+                                PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = 0;
+                            }
+                            run_batch(r);
+                        }
+                    }
                 }
             for (int base = 0; base < ((pull || (d.debug_flags & 2)) ? 0 : ncell); base += 64) {
                 CmdRegs r;
@@ -1518,8 +1676,9 @@ struct Renderer {
             }
             phase(3);
             if (one_chunk) {
-                if (ezmask[1]) run_batch(er, ezmask[1]);
-                if (ezmask[2]) run_batch(er, ezmask[2]);
+                _Pragma("unroll") for (int z = 1; z < 3; z++)
+                    _Pragma("unroll") for (int k = 0; k < CMD_SETS; k++)
+                        if (ezmask[k][z]) run_batch(er[k], ezmask[k][z]);
             } else {
                 draw_entities(0);
                 draw_entities(1);
