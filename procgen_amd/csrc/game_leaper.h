@@ -31,23 +31,28 @@ struct Leaper : BagDefaults<Leaper> {
 #define LP_N_WATER(G) (G).gsi3
 #define LP_GOAL_Y(G) (G).gsi4
     // lane speeds: road lanes 0-4 in gsf0-4, water lanes 0-2 in gsf5-7, water lanes 3-4 as the bits of gsi5-6
-    PG_DEV static float road_speed(const EnvHdr &G, int k) { return k == 0 ? G.gsf0 : (k == 1 ? G.gsf1 : (k == 2 ? G.gsf2 : (k == 3 ? G.gsf3 : G.gsf4))); }
-    PG_DEV static void set_road_speed(EnvHdr &G, int k, float v) {
-        if (k == 0) G.gsf0 = v;
-        else if (k == 1) G.gsf1 = v;
-        else if (k == 2) G.gsf2 = v;
-        else if (k == 3) G.gsf3 = v;
-        else G.gsf4 = v;
+    PG_DEV static float road_speed(const EnvHdr &G, int k) { 
+        const float a0 = pg_opaque_f(G.gsf0), a1 = pg_opaque_f(G.gsf1), a2 = pg_opaque_f(G.gsf2), a3 = pg_opaque_f(G.gsf3), a4 = pg_opaque_f(G.gsf4);
+        return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : (k == 3 ? a3 : a4)));
+    }
+    PG_DEV static void set_road_speed(EnvHdr &G, int k, float v) {  // every field is rewritten: an if / else chain of stores becomes one store at a computed offset (see pg_opaque_f)
+        G.gsf0 = k == 0 ? v : G.gsf0;
+        G.gsf1 = k == 1 ? v : G.gsf1;
+        G.gsf2 = k == 2 ? v : G.gsf2;
+        G.gsf3 = k == 3 ? v : G.gsf3;
+        G.gsf4 = k >= 4 ? v : G.gsf4;
     }
     PG_DEV static float water_speed(const EnvHdr &G, int k) {
-        return k == 0 ? G.gsf5 : (k == 1 ? G.gsf6 : (k == 2 ? G.gsf7 : __builtin_bit_cast(float, k == 3 ? G.gsi5 : G.gsi6)));
+        const float a0 = pg_opaque_f(G.gsf5), a1 = pg_opaque_f(G.gsf6), a2 = pg_opaque_f(G.gsf7);
+        const int b3 = pg_opaque_i(G.gsi5), b4 = pg_opaque_i(G.gsi6);
+        return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : __builtin_bit_cast(float, k == 3 ? b3 : b4)));
     }
     PG_DEV static void set_water_speed(EnvHdr &G, int k, float v) {
-        if (k == 0) G.gsf5 = v;
-        else if (k == 1) G.gsf6 = v;
-        else if (k == 2) G.gsf7 = v;
-        else if (k == 3) G.gsi5 = __builtin_bit_cast(int, v);
-        else G.gsi6 = __builtin_bit_cast(int, v);
+        G.gsf5 = k == 0 ? v : G.gsf5;
+        G.gsf6 = k == 1 ? v : G.gsf6;
+        G.gsf7 = k == 2 ? v : G.gsf7;
+        G.gsi5 = k == 3 ? __builtin_bit_cast(int, v) : G.gsi5;
+        G.gsi6 = k >= 4 ? __builtin_bit_cast(int, v) : G.gsi6;
     }
 
     PG_DEV static bool center_agent(const GameOptions &) { return false; }  // options.center_agent = false, leaper.cpp:125

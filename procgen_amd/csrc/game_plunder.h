@@ -35,13 +35,16 @@ struct Plunder : BagDefaults<Plunder> {
 #define PL_IMAGE_PERM(G) (G).gsi4     // 3 bits per entry, 6 entries
 #define PL_JUICE_LEFT(G) (G).gsf5
 #define PL_MIN_AGENT_X(G) (G).gsf6
-    PG_DEV static float lane_vel(const EnvHdr &G, int k) { return k == 0 ? G.gsf0 : (k == 1 ? G.gsf1 : (k == 2 ? G.gsf2 : (k == 3 ? G.gsf3 : G.gsf4))); }
-    PG_DEV static void set_lane_vel(EnvHdr &G, int k, float v) {
-        if (k == 0) G.gsf0 = v;
-        else if (k == 1) G.gsf1 = v;
-        else if (k == 2) G.gsf2 = v;
-        else if (k == 3) G.gsf3 = v;
-        else G.gsf4 = v;
+    PG_DEV static float lane_vel(const EnvHdr &G, int k) { 
+        const float a0 = pg_opaque_f(G.gsf0), a1 = pg_opaque_f(G.gsf1), a2 = pg_opaque_f(G.gsf2), a3 = pg_opaque_f(G.gsf3), a4 = pg_opaque_f(G.gsf4);
+        return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : (k == 3 ? a3 : a4)));
+    }
+    PG_DEV static void set_lane_vel(EnvHdr &G, int k, float v) {  // every field is rewritten: an if / else chain of stores becomes one store at a computed offset (see pg_opaque_f)
+        G.gsf0 = k == 0 ? v : G.gsf0;
+        G.gsf1 = k == 1 ? v : G.gsf1;
+        G.gsf2 = k == 2 ? v : G.gsf2;
+        G.gsf3 = k == 3 ? v : G.gsf3;
+        G.gsf4 = k >= 4 ? v : G.gsf4;
     }
     PG_DEV static int image_perm(const EnvHdr &G, int k) { return (PL_IMAGE_PERM(G) >> (3 * k)) & 7; }
     template <class O>

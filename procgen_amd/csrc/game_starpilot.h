@@ -533,16 +533,15 @@ struct StarPilot {
         const float tile_width = (float)(rect.w / num_tiles);
         const float tile_height = (float)rect.h;
         int i0 = (int)(-x_off / tile_width) - 1;
-        int n = 0;
-        for (int i = i0; i < i0 + 3; i++) {
-            if (i < 0 || i >= num_tiles) continue;
-            rects[n].x = rect.x + (double)(tile_width * i);
-            rects[n].y = rect.y;
-            rects[n].w = (double)tile_width;
-            rects[n].h = (double)tile_height;
-            n++;
+        _Pragma("unroll") for (int k = 0; k < 3; k++) {  // fixed slots (w = 0: tile off the strip): a running index would put the array in scratch memory
+            const int i = i0 + k;
+            const bool on = i >= 0 && i < num_tiles;
+            rects[k].x = rect.x + (double)(tile_width * i);
+            rects[k].y = rect.y;
+            rects[k].w = on ? (double)tile_width : 0.0;
+            rects[k].h = (double)tile_height;
         }
-        return n;
+        return 3;
     }
 };
 

@@ -17,8 +17,18 @@
 
 namespace pgamd {
 
+#if defined(PG_RENDER_WAVES)
+#define PG_RENDER_OCC __attribute__((amdgpu_waves_per_eu(PG_RENDER_WAVES, PG_RENDER_WAVES)))
+#else
+#define PG_RENDER_OCC
+#endif
+#if defined(PG_STEP_WAVES)
+#define PG_STEP_OCC __attribute__((amdgpu_waves_per_eu(PG_STEP_WAVES, PG_STEP_WAVES)))
+#else
+#define PG_STEP_OCC
+#endif
 template <class Game>
-__global__ __launch_bounds__(64) void step_tier0(DevCtx d, int mode, int env_base) {
+__global__ __launch_bounds__(64) PG_STEP_OCC void step_tier0(DevCtx d, int mode, int env_base) {
     __shared__ Lds<Game, Game::ENT_CAP_T0> lds;
     const int env = env_base + (int)blockIdx.x;
     if (mode != 0 && d.route[env] != 0) return;  // owned by a larger arena this step
@@ -41,7 +51,7 @@ __global__ __launch_bounds__(64) void step_list(DevCtx d, int mode) {
 }
 
 template <class Game>
-__global__ __launch_bounds__(64) void render(DevCtx d, int env_base) {
+__global__ __launch_bounds__(64) PG_RENDER_OCC void render(DevCtx d, int env_base) {
     __shared__ RenderLdsT<Game> lds;
     Renderer<Game> r(d, env_base + (int)blockIdx.x, &lds);
     r.render_env();

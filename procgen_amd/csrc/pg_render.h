@@ -137,6 +137,10 @@ struct RenderLdsT {
     uint32_t rot[GameUsesRotation<Game>::value ? 64 * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane
 };
 constexpr uint32_t CELL_NONE = 0xffffffffu;
+template <int N>
+struct PgInt {
+    static constexpr int value = N;
+};
 constexpr uint32_t CELL_FILL = 0xfffffffdu;  // build_pull_tables, transient: a solid-colour cell (draw_grid_obj override) waiting for its command
 constexpr uint32_t TYPE_SLOW = 0xfffffffeu;  // typeimg: this type needs the per-cell path (fill, odd image size, adjusted rect, missing asset)
 
@@ -345,20 +349,19 @@ struct Renderer {
             rp[3] = (uint32_t)d2i_x86(i12 * 0x10000);                                            // dudy
             rp[4] = (uint32_t)d2i_x86(i21 * 0x10000);                                            // dvdx
             rp[5] = (uint32_t)d2i_x86(i22 * 0x10000);                                            // dvdy
-            // trapezoids: (top-left, bottom-left, top-right, bottom-right, top y, bottom y) as vertex indices
-            int tl[3], bl[3], tr_[3], br[3], yt[3], yb[3];
-            if (vy[1] < vy[3]) {
-                tl[0] = 0; bl[0] = 1; tr_[0] = 0; br[0] = 3; yt[0] = 0; yb[0] = 1;
-                tl[1] = 1; bl[1] = 2; tr_[1] = 0; br[1] = 3; yt[1] = 1; yb[1] = 3;
-                tl[2] = 1; bl[2] = 2; tr_[2] = 3; br[2] = 2; yt[2] = 3; yb[2] = 2;
-            } else {
-                tl[0] = 0; bl[0] = 1; tr_[0] = 0; br[0] = 3; yt[0] = 0; yb[0] = 3;
-                tl[1] = 0; bl[1] = 1; tr_[1] = 3; br[1] = 2; yt[1] = 3; yb[1] = 1;
-                tl[2] = 1; bl[2] = 2; tr_[2] = 3; br[2] = 2; yt[2] = 1; yb[2] = 2;
-            }
+            // trapezoids: top-left, bottom-left, top-right, bottom-right vertices and the top / bottom y of each, picked by
+            // value (index tables would be addressed dynamically, i.e. live in scratch memory):
+            //   vy[1] <  vy[3]: (0,1,0,3 | 0,1) (1,2,0,3 | 1,3) (1,2,3,2 | 3,2)
+            //   vy[1] >= vy[3]: (0,1,0,3 | 0,3) (0,1,3,2 | 3,1) (1,2,3,2 | 1,2)
+            const bool lf = vy[1] < vy[3];
+            const double tlx[3] = {vx[0], lf ? vx[1] : vx[0], vx[1]}, tly[3] = {vy[0], lf ? vy[1] : vy[0], vy[1]};
+            const double blx[3] = {vx[1], lf ? vx[2] : vx[1], vx[2]}, bly[3] = {vy[1], lf ? vy[2] : vy[1], vy[2]};
+            const double trx[3] = {vx[0], lf ? vx[0] : vx[3], vx[3]}, try_[3] = {vy[0], lf ? vy[0] : vy[3], vy[3]};
+            const double brx[3] = {vx[3], lf ? vx[3] : vx[2], vx[2]}, bry[3] = {vy[3], lf ? vy[3] : vy[2], vy[2]};
+            const double ytv[3] = {vy[0], lf ? vy[1] : vy[3], lf ? vy[3] : vy[1]}, ybv[3] = {lf ? vy[1] : vy[3], lf ? vy[3] : vy[1], vy[2]};
             int ymin = RES_H, ymax = 0;
-            for (int t = 0; t < 3; t++) {
-                int from_y = q_round(vy[yt[t]]), to_y = q_round(vy[yb[t]]);
+            _Pragma("unroll") for (int t = 0; t < 3; t++) {
+                int from_y = q_round(ytv[t]), to_y = q_round(ybv[t]);
                 if (from_y < 0) from_y = 0;
                 if (to_y > RES_H) to_y = RES_H;
                 uint32_t *tp = rp + 6 + 6 * t;
@@ -366,13 +369,13 @@ struct Renderer {
                     tp[0] = tp[1] = tp[2] = tp[3] = tp[4] = tp[5] = 0;
                     continue;
                 }
-                const double left_slope = (vx[bl[t]] - vx[tl[t]]) / (vy[bl[t]] - vy[tl[t]]);
-                const double right_slope = (vx[br[t]] - vx[tr_[t]]) / (vy[br[t]] - vy[tr_[t]]);
+                const double left_slope = (blx[t] - tlx[t]) / (bly[t] - tly[t]);
+                const double right_slope = (brx[t] - trx[t]) / (bry[t] - try_[t]);
                 tp[0] = (uint32_t)from_y;
                 tp[1] = (uint32_t)to_y;
-                tp[2] = (uint32_t)d2i_x86((vx[tl[t]] + (0.5 + from_y - vy[tl[t]]) * left_slope + 0.5) * 0x10000);
+                tp[2] = (uint32_t)d2i_x86((tlx[t] + (0.5 + from_y - tly[t]) * left_slope + 0.5) * 0x10000);
                 tp[3] = (uint32_t)d2i_x86(left_slope * 0x10000);
-                tp[4] = (uint32_t)d2i_x86((vx[tr_[t]] + (0.5 + from_y - vy[tr_[t]]) * right_slope + 0.5) * 0x10000);
+                tp[4] = (uint32_t)d2i_x86((trx[t] + (0.5 + from_y - try_[t]) * right_slope + 0.5) * 0x10000);
                 tp[5] = (uint32_t)d2i_x86(right_slope * 0x10000);
                 if (from_y < ymin) ymin = from_y;
                 if (to_y > ymax) ymax = to_y;
@@ -1094,58 +1097,84 @@ struct Renderer {
     // one rotated command (qt_transform_image_rasterize): the pixels of its bounding box are laid out linearly
     // over the lanes; a pixel is covered when its row falls into one of the three trapezoids and its column into
     // that row's span [x_l >> 16, x_r >> 16); its texel is the clamped inverse mapping of the pixel position.
+    // a rotation record travels as 24 wave-uniform scalars passed by value: kept in an array or a struct, the ?: chains over
+    // its fields turn into one load at a computed offset and the record lands in scratch memory
+    template <int NJ>
+    PG_DEV void exec_rotated_pass(const DrawCmd &c, int base, int npix, int y0, uint32_t inv, uint32_t u0, uint32_t v0, uint32_t dudx, uint32_t dudy, uint32_t dvdx, uint32_t dvdy, uint32_t tf0, uint32_t tt0, uint32_t txl0, uint32_t tdl0, uint32_t txr0, uint32_t tdr0, uint32_t tf1, uint32_t tt1, uint32_t txl1, uint32_t tdl1, uint32_t txr1, uint32_t tdr1, uint32_t tf2, uint32_t tt2, uint32_t txl2, uint32_t tdl2, uint32_t txr2, uint32_t tdr2) {
+        const uint32_t *src = d.pixels + c.src;
+        const int sw = cmd_src_w(c.aux), sh = (int)c.iy;
+        const bool mirrored = cmd_mirrored(c.aux);
+        const int io = cmd_alpha(c.aux);
+        const uint32_t ca = (uint32_t)((io * 255) >> 8);
+        PG_FOR_LANES(l) {
+            uint32_t tex[NJ];
+            int fbi[NJ];
+            _Pragma("unroll") for (int j = 0; j < NJ; j++) {
+                const int p = base + j * 64 + l;
+                const int pc = p < npix ? p : 0;
+                const int pyb = (int)(((uint32_t)pc * inv) >> 20);
+                const int X = c.tx1 + (pc - pyb * c.w);
+                const int Y = y0 + pyb;
+                // the trapezoids cover disjoint row ranges
+                const bool s0 = (uint32_t)Y >= tf0 && (uint32_t)Y < tt0;
+                const bool s1 = (uint32_t)Y >= tf1 && (uint32_t)Y < tt1;
+                const bool s2 = (uint32_t)Y >= tf2 && (uint32_t)Y < tt2;
+                const bool in_rows = s0 || s1 || s2;
+                const uint32_t k = (uint32_t)Y - (s0 ? tf0 : (s1 ? tf1 : tf2));
+                int from_x = (int)((s0 ? txl0 : (s1 ? txl1 : txl2)) + k * (s0 ? tdl0 : (s1 ? tdl1 : tdl2))) >> 16;
+                int to_x = (int)((s0 ? txr0 : (s1 ? txr1 : txr2)) + k * (s0 ? tdr0 : (s1 ? tdr1 : tdr2))) >> 16;
+                if (from_x < 0) from_x = 0;
+                if (to_x > RES_W) to_x = RES_W;
+                const bool in = p < npix && in_rows && X >= from_x && X < to_x;
+                int uu = (int)((uint32_t)X * dudx + (uint32_t)Y * dudy + u0) >> 16;
+                int vv = (int)((uint32_t)X * dvdx + (uint32_t)Y * dvdy + v0) >> 16;
+                uu = uu < 0 ? 0 : (uu > sw - 1 ? sw - 1 : uu);
+                vv = vv < 0 ? 0 : (vv > sh - 1 ? sh - 1 : vv);
+                tex[j] = src[in ? (vv * sw + (mirrored ? (sw - 1 - uu) : uu)) : 0];
+                fbi[j] = in ? ((Y - row0) * RES_W + X) : (BAND_ROWS * RES_W + l);  // masked-off lanes use the dump row
+            }
+            _Pragma("unroll") for (int j = 0; j < NJ; j++) { fb[fbi[j]] = blend(tex[j], fb[fbi[j]], io, ca); }
+        }
+    }
     PG_DEV void exec_rotated(const DrawCmd &c) {
         if constexpr (GameUsesRotation<Game>::value) {
             const uint32_t *rp = &lds->rot[(c.basex & 63u) * ROT_WORDS];
-            const uint32_t *src = d.pixels + c.src;
-            const int sw = cmd_src_w(c.aux), sh = (int)c.iy;
-            const bool mirrored = cmd_mirrored(c.aux);
-            const int io = cmd_alpha(c.aux);
-            const uint32_t ca = (uint32_t)((io * 255) >> 8);
-            const uint32_t u0 = rp[0], v0 = rp[1], dudx = rp[2], dudy = rp[3], dvdx = rp[4], dvdy = rp[5];
-            uint32_t tf[3], tt[3], txl[3], tdl[3], txr[3], tdr[3];
-            for (int t = 0; t < 3; t++) {
-                tf[t] = rp[6 + 6 * t];
-                tt[t] = rp[7 + 6 * t];
-                txl[t] = rp[8 + 6 * t];
-                tdl[t] = rp[9 + 6 * t];
-                txr[t] = rp[10 + 6 * t];
-                tdr[t] = rp[11 + 6 * t];
-            }
+#define PG_ROT(k) ((uint32_t)PG_UNIFORM_I(rp[k]))
+            const uint32_t u0 = PG_ROT(0);
+            const uint32_t v0 = PG_ROT(1);
+            const uint32_t dudx = PG_ROT(2);
+            const uint32_t dudy = PG_ROT(3);
+            const uint32_t dvdx = PG_ROT(4);
+            const uint32_t dvdy = PG_ROT(5);
+            const uint32_t tf0 = PG_ROT(6);
+            const uint32_t tt0 = PG_ROT(7);
+            const uint32_t txl0 = PG_ROT(8);
+            const uint32_t tdl0 = PG_ROT(9);
+            const uint32_t txr0 = PG_ROT(10);
+            const uint32_t tdr0 = PG_ROT(11);
+            const uint32_t tf1 = PG_ROT(12);
+            const uint32_t tt1 = PG_ROT(13);
+            const uint32_t txl1 = PG_ROT(14);
+            const uint32_t tdl1 = PG_ROT(15);
+            const uint32_t txr1 = PG_ROT(16);
+            const uint32_t tdr1 = PG_ROT(17);
+            const uint32_t tf2 = PG_ROT(18);
+            const uint32_t tt2 = PG_ROT(19);
+            const uint32_t txl2 = PG_ROT(20);
+            const uint32_t tdl2 = PG_ROT(21);
+            const uint32_t txr2 = PG_ROT(22);
+            const uint32_t tdr2 = PG_ROT(23);
+#undef PG_ROT
             const int y0 = c.ty1 > row0 ? c.ty1 : row0;
             const int y1 = (c.ty1 + c.h) < row1 ? (c.ty1 + c.h) : row1;
             const int npix = c.w * (y1 - y0);
             const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)c.w - 1u) / (uint32_t)c.w);
-            for (int base = 0; base < npix; base += 512) {
-                PG_FOR_LANES(l) {
-                    uint32_t tex[8];
-                    int fbi[8];
-                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
-                        const int p = base + j * 64 + l;
-                        const int pc = p < npix ? p : 0;
-                        const int pyb = (int)(((uint32_t)pc * inv) >> 20);
-                        const int X = c.tx1 + (pc - pyb * c.w);
-                        const int Y = y0 + pyb;
-                        // the trapezoids cover disjoint row ranges
-                        const bool s0 = (uint32_t)Y >= tf[0] && (uint32_t)Y < tt[0];
-                        const bool s1 = (uint32_t)Y >= tf[1] && (uint32_t)Y < tt[1];
-                        const bool s2 = (uint32_t)Y >= tf[2] && (uint32_t)Y < tt[2];
-                        const bool in_rows = s0 || s1 || s2;
-                        const uint32_t k = (uint32_t)Y - (s0 ? tf[0] : (s1 ? tf[1] : tf[2]));
-                        int from_x = (int)((s0 ? txl[0] : (s1 ? txl[1] : txl[2])) + k * (s0 ? tdl[0] : (s1 ? tdl[1] : tdl[2]))) >> 16;
-                        int to_x = (int)((s0 ? txr[0] : (s1 ? txr[1] : txr[2])) + k * (s0 ? tdr[0] : (s1 ? tdr[1] : tdr[2]))) >> 16;
-                        if (from_x < 0) from_x = 0;
-                        if (to_x > RES_W) to_x = RES_W;
-                        const bool in = p < npix && in_rows && X >= from_x && X < to_x;
-                        int uu = (int)((uint32_t)X * dudx + (uint32_t)Y * dudy + u0) >> 16;
-                        int vv = (int)((uint32_t)X * dvdx + (uint32_t)Y * dvdy + v0) >> 16;
-                        uu = uu < 0 ? 0 : (uu > sw - 1 ? sw - 1 : uu);
-                        vv = vv < 0 ? 0 : (vv > sh - 1 ? sh - 1 : vv);
-                        tex[j] = src[in ? (vv * sw + (mirrored ? (sw - 1 - uu) : uu)) : 0];
-                        fbi[j] = in ? ((Y - row0) * RES_W + X) : (BAND_ROWS * RES_W + l);  // masked-off lanes use the dump row
-                    }
-                    _Pragma("unroll") for (int j = 0; j < 8; j++) { fb[fbi[j]] = blend(tex[j], fb[fbi[j]], io, ca); }
-                }
+            // small turned sprites (bossfight's bullets) fit one or two pixels per lane: no point in issuing the
+            // eight-deep fetch batch for them
+            if (npix <= 128) {
+                for (int base = 0; base < npix; base += 64) exec_rotated_pass<1>(c, base, npix, y0, inv, u0, v0, dudx, dudy, dvdx, dvdy, tf0, tt0, txl0, tdl0, txr0, tdr0, tf1, tt1, txl1, tdl1, txr1, tdr1, tf2, tt2, txl2, tdl2, txr2, tdr2);
+            } else {
+                for (int base = 0; base < npix; base += 512) exec_rotated_pass<8>(c, base, npix, y0, inv, u0, v0, dudx, dudy, dvdx, dvdy, tf0, tt0, txl0, tdl0, txr0, tdr0, tf1, tt1, txl1, tdl1, txr1, tdr1, tf2, tt2, txl2, tdl2, txr2, tdr2);
             }
             PG_SYNC();
         } else {
@@ -1357,6 +1386,7 @@ struct Renderer {
     // sets through the idle band buffer.  false: too many visible entities or turned sprites; draw_entities() then sets
     // every chunk up again for every band and layer.
     static constexpr int CMD_SETS = GameRenderCmdSets<Game>::value;
+    static_assert(CMD_SETS == 1 || CMD_SETS == 2, "one or two register sets");
     PG_DEV bool compact_entities(CmdRegs (&er)[CMD_SETS], uint64_t (&ezm)[CMD_SETS][3]) {
         uint32_t *stage = fb;  // [8 words][64 * CMD_SETS slots]
         constexpr int SLOTS = 64 * CMD_SETS;
@@ -1468,7 +1498,8 @@ struct Renderer {
                 RectD rects[4];
                 const int nr = Game::background_rects(*this, rects);
                 const int bgi = (int)d.assets->bg_img[G.background_index];
-                for (int k = 0; k < nr; k++) add_bg(bgi, rects[k]);
+                _Pragma("unroll") for (int k = 0; k < 4; k++)
+                    if (k < nr && rects[k].w > 0) add_bg(bgi, rects[k]);
             }
         } else if (d.opt.use_backgrounds && !(d.debug_flags & 1)) {
             const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);
@@ -1560,8 +1591,10 @@ struct Renderer {
             }
             phase(1);
             if (one_chunk) {
-                _Pragma("unroll") for (int k = 0; k < CMD_SETS; k++)
-                    if (ezmask[k][0]) run_batch(er[k], ezmask[k][0]);
+                // constant indices only: a loop the compiler declines to unroll would index the register sets through scratch memory
+                if (ezmask[0][0]) run_batch(er[0], ezmask[0][0]);
+                if constexpr (CMD_SETS > 1)
+                    if (ezmask[CMD_SETS - 1][0]) run_batch(er[CMD_SETS - 1], ezmask[CMD_SETS - 1][0]);
             } else {
                 draw_entities(-1);
             }
@@ -1676,9 +1709,12 @@ struct Renderer {
             }
             phase(3);
             if (one_chunk) {
-                _Pragma("unroll") for (int z = 1; z < 3; z++)
-                    _Pragma("unroll") for (int k = 0; k < CMD_SETS; k++)
-                        if (ezmask[k][z]) run_batch(er[k], ezmask[k][z]);
+                if (ezmask[0][1]) run_batch(er[0], ezmask[0][1]);
+                if constexpr (CMD_SETS > 1)
+                    if (ezmask[CMD_SETS - 1][1]) run_batch(er[CMD_SETS - 1], ezmask[CMD_SETS - 1][1]);
+                if (ezmask[0][2]) run_batch(er[0], ezmask[0][2]);
+                if constexpr (CMD_SETS > 1)
+                    if (ezmask[CMD_SETS - 1][2]) run_batch(er[CMD_SETS - 1], ezmask[CMD_SETS - 1][2]);
             } else {
                 draw_entities(0);
                 draw_entities(1);

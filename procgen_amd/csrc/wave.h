@@ -122,6 +122,22 @@ PG_DEV double pg_atan2(double y, double x) { return atan2(y, x); }  // only feed
 
 #endif
 
+// A value the optimizer must take as it is.  Choosing one of several adjacent struct fields with a ?: chain otherwise
+// becomes ONE load at a computed offset, which pins the whole per-env state struct in scratch memory instead of registers.
+#if defined(PGAMD_WAVE_EMU)
+PG_DEV float pg_opaque_f(float v) { return v; }
+PG_DEV int pg_opaque_i(int v) { return v; }
+#else
+PG_DEV float pg_opaque_f(float v) {
+    __asm__ volatile("" : "+v"(v));
+    return v;
+}
+PG_DEV int pg_opaque_i(int v) {
+    __asm__ volatile("" : "+v"(v));
+    return v;
+}
+#endif
+
 struct alignas(16) pg_u4 {  // 16-byte move unit for staging copies
     uint32_t x, y, z, w;
 };
