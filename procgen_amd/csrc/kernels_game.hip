@@ -17,18 +17,19 @@
 
 namespace pgamd {
 
-#if defined(PG_RENDER_WAVES)
-#define PG_RENDER_OCC __attribute__((amdgpu_waves_per_eu(PG_RENDER_WAVES, PG_RENDER_WAVES)))
-#else
-#define PG_RENDER_OCC
-#endif
-#if defined(PG_STEP_WAVES)
-#define PG_STEP_OCC __attribute__((amdgpu_waves_per_eu(PG_STEP_WAVES, PG_STEP_WAVES)))
-#else
-#define PG_STEP_OCC
-#endif
+// Occupancy hint of the render kernel (RENDER_MIN_WAVES in a policy); the default leaves the register allocation alone.
+// Tried for coinrun (133 -> 128 VGPRs, a fourth wave per SIMD): +2..4 % steps/s, but the 104 B of spill per lane showed
+// up as +54 % WRITE_SIZE, so no policy sets it.
+template <class Game, class = void>
+struct GameRenderMinWaves {
+    static constexpr int value = 1;
+};
 template <class Game>
-__global__ __launch_bounds__(64) PG_STEP_OCC void step_tier0(DevCtx d, int mode, int env_base) {
+struct GameRenderMinWaves<Game, decltype((void)Game::RENDER_MIN_WAVES)> {
+    static constexpr int value = Game::RENDER_MIN_WAVES;
+};
+template <class Game>
+__global__ __launch_bounds__(64) void step_tier0(DevCtx d, int mode, int env_base) {
     __shared__ Lds<Game, Game::ENT_CAP_T0> lds;
     const int env = env_base + (int)blockIdx.x;
     if (mode != 0 && d.route[env] != 0) return;  // owned by a larger arena this step
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(64) void step_list(DevCtx d, int mode) {
 }
 
 template <class Game>
-__global__ __launch_bounds__(64) PG_RENDER_OCC void render(DevCtx d, int env_base) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GameRenderMinWaves<PG_GAME>::value))) void render(DevCtx d, int env_base) {
     __shared__ RenderLdsT<Game> lds;
     Renderer<Game> r(d, env_base + (int)blockIdx.x, &lds);
     r.render_env();
