@@ -14,6 +14,7 @@ struct Leaper : BagDefaults<Leaper> {
     static constexpr int MAX_CELLS = 20 * 20;  // leaper.cpp:103-116
     static constexpr bool USES_ROTATION = true;  // cars driving left are turned by 180 degrees (a negative scale), the frog by +-90
     static constexpr bool USES_TILED_ENTITIES = true;
+    static constexpr int WIDE_ROWS = 8;  // 161 instead of 170 VGPRs in the renderer: three waves per SIMD instead of two
     // reset: <= 15 cars x 5 lanes + 16 logs x 5 lanes in the worst case, typically < 90; steps: <= 10 spawns
     static constexpr int ENT_CAP_T0 = 192, ENT_CAP_T1 = 224, ENT_CAP_T2 = 256;
     template <class E>

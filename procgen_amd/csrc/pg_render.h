@@ -24,7 +24,6 @@ namespace pgamd {
 #endif
 constexpr int BAND_ROWS = PG_BAND_ROWS;  // rows per pass (64 / BAND_ROWS passes per frame)
 constexpr int NUM_BANDS = RES_H / BAND_ROWS;
-constexpr int WIDE_ROWS = BAND_ROWS;  // rows per fetch batch of full-width draws (background, tile stage 1)
 
 struct DrawCmd {  // uniform (scalar) view of one command
     int tx1, ty1, w, h;
@@ -83,6 +82,16 @@ struct GameRenderCmdSets {
 template <class Game>
 struct GameRenderCmdSets<Game, decltype((void)Game::RENDER_CMD_SETS)> {
     static constexpr int value = Game::RENDER_CMD_SETS;
+};
+// rows per fetch batch of full-width draws (background, tile stage 1): a whole band by default; a policy whose renderer
+// is short of registers takes half a band (WIDE_ROWS = 8) to keep a third wave per SIMD
+template <class Game, class = void>
+struct GameWideRows {
+    static constexpr int value = BAND_ROWS;
+};
+template <class Game>
+struct GameWideRows<Game, decltype((void)Game::WIDE_ROWS)> {
+    static constexpr int value = Game::WIDE_ROWS;
 };
 template <class Game, class = void>
 struct GameUsesTiledEntities {
@@ -154,6 +163,8 @@ struct Renderer {
     const DevCtx &d;
     const int env;
     typedef RenderLdsT<Game> RenderLds;
+    static constexpr int WIDE_ROWS = GameWideRows<Game>::value;
+    static_assert(BAND_ROWS % WIDE_ROWS == 0, "fetch batches tile the band");
     RenderLds *lds;
     uint32_t *fb;  // the band being rasterized: BAND_ROWS x 64 words of 0xffRRGGBB
     uint32_t *ax;  // tile-axis scratch (see setup_tile_axes)
@@ -1054,9 +1065,15 @@ struct Renderer {
         }
         int x1 = X1 * 64, y1 = Y1 * 64, x2 = X2 * 64, y2 = Y2 * 64;
         const int dx = x2 - x1 < 0 ? x1 - x2 : x2 - x1, dy = y2 - y1 < 0 ? y1 - y2 : y2 - y1;
+        // Qt divides in 64 bits; end points within +-127 pixels keep delta * 65536 below 2^31, and a 32-bit divide costs a
+        // fraction of the registers of the 64-bit expansion (this uniform code shares the kernel's allocation)
+        if (dx >= (1 << 14) || dy >= (1 << 14)) {
+            fail(PGE_UNSUPPORTED_DRAW);
+            return;
+        }
         if (dx < dy) {
             if (y1 > y2) { int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t; }
-            const int xinc = (int)(((long long)(x2 - x1) * 65536) / (y2 - y1));
+            const int xinc = ((x2 - x1) * 65536) / (y2 - y1);
             int x = x1 * 1024;
             y1 -= 32; x -= xinc >> 1; y2 += 32;
             int y = (y1 + 32) >> 6;
@@ -1072,7 +1089,7 @@ struct Renderer {
         } else {
             if (!dx) return;
             if (x1 > x2) { int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t; }
-            const int yinc = (int)(((long long)(y2 - y1) * 65536) / (x2 - x1));
+            const int yinc = ((y2 - y1) * 65536) / (x2 - x1);
             int y = y1 * 1024;
             x1 -= 32; y -= yinc >> 1; x2 += 32;
             int x = (x1 + 32) >> 6;

@@ -189,6 +189,18 @@ def test_joint_games_handle_matches_per_game_oracles():
     env.close()
 
 
+def test_joint_handle_of_all_sixteen_games():
+    """BASELINE configs[4] in small: env_name = all 16 games (reference src/vecgame.cpp:295-310), env n plays names[n % 16].
+    Every env equals env n of a single-game oracle run of the same num_envs."""
+    K, n, steps = len(GAMES), 32, 60
+    acts = action_stream(n, steps, seed=17)
+    joint = rollout(make_env(n, ",".join(GAMES)), acts, keep_frames=True)
+    for k, game in enumerate(GAMES):
+        ref = rollout(oracle_env.OracleEnv(n, game, rand_seed=23), acts, keep_frames=True)
+        for key in ref:
+            assert np.array_equal(joint[key][:, k::K], ref[key][:, k::K]), (game, key)
+
+
 def test_bigfish_full_size_prefix_matches_oracle():
     """BASELINE configs[2] (bigfish, 65536 envs): the first 128 envs equal a 128-env oracle run."""
     n, steps, m = 65536, 10, 128
