@@ -69,6 +69,19 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         hipError_t e_ = (x);               \
         if (e_ != hipSuccess) return e_;   \
     } while (0)
+    if (d.num_envs < 4096) {
+        // Small handles (and the 16 parts of a joint handle, each with its own streams): the kernels are far too short
+        // for tier / chunk concurrency to matter, while every cross-stream event costs tens of microseconds and the
+        // runtime multiplexes all streams of the process onto a few hardware queues.  Everything goes down one stream.
+        if (mode != 0) {
+            const int g1 = d.num_envs < 8192 ? d.num_envs : 8192, g2 = d.num_envs < 2048 ? d.num_envs : 2048;
+            hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.main, d, mode);
+            hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.main, d, mode);
+        }
+        if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode, 0);
+        if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, 0);
+        return hipGetLastError();
+    }
     PG_TRY(hipEventRecord(ls.fork, ls.main));
     if (mode != 0) {
         PG_TRY(hipStreamWaitEvent(ls.side, ls.fork, 0));
