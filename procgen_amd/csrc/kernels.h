@@ -13,6 +13,7 @@ struct LaunchStreams {
     hipEvent_t lane_done[2];
     hipEvent_t tier2_done;    // the tier-2 list kernel runs on lane[1] ahead of that lane's chunk
     int chunks;               // 1 = everything on `main`
+    int list_count[2] = {-1, -1};  // entries of the tier-1 / tier-2 lists this step reads, when the host knows them: an empty list's kernel is not launched
 };
 // what one per-game kernel object (kernels_game.hip) exports
 struct GameEntry {

@@ -75,8 +75,8 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         // runtime multiplexes all streams of the process onto a few hardware queues.  Everything goes down one stream.
         if (mode != 0) {
             const int g1 = d.num_envs < 8192 ? d.num_envs : 8192, g2 = d.num_envs < 2048 ? d.num_envs : 2048;
-            hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.main, d, mode);
-            hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.main, d, mode);
+            if (ls.list_count[0] != 0) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.main, d, mode);
+            if (ls.list_count[1] != 0) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.main, d, mode);
         }
         if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode, 0);
         if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, 0);
@@ -88,8 +88,8 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         const int g1 = d.num_envs < 8192 ? d.num_envs : 8192, g2 = d.num_envs < 2048 ? d.num_envs : 2048;
         // the two list kernels run on their own streams (lane[1] is otherwise idle when chunks == 1)
         PG_TRY(hipStreamWaitEvent(ls.lane[1], ls.fork, 0));
-        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.side, d, mode);
-        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.lane[1], d, mode);
+        if (ls.list_count[0] != 0) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.side, d, mode);
+        if (ls.list_count[1] != 0) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.lane[1], d, mode);
         PG_TRY(hipEventRecord(ls.tier2_done, ls.lane[1]));
         PG_TRY(hipStreamWaitEvent(ls.side, ls.tier2_done, 0));
         PG_TRY(hipEventRecord(ls.join, ls.side));

@@ -121,7 +121,12 @@ struct VecGame {
     GameAssetsDev *d_assets = nullptr;
     uint32_t *d_pixels = nullptr;
     int32_t *d_action = nullptr;
-    uint8_t *d_small = nullptr;  // [rew f32 N | prev_level_seed i32 N | level_seed i32 N | first u8 N | prev_level_complete u8 N | error i32]
+    // [rew f32 N | prev_level_seed i32 N | level_seed i32 N | first u8 N | prev_level_complete u8 N | list counts A i32 x2 | error i32 | list counts B i32 x2]
+    // The tail doubles as the tier-list counters (double-buffered A / B) so that one memset clears "next counts + error" and
+    // the one download per step tells the host which list kernels have work next step.
+    uint8_t *d_small = nullptr;
+    size_t tail_off = 0;            // offset of the 5-int tail
+    int host_list_count[2] = {0, 0};  // entries of the tier-1 / tier-2 lists the coming step reads
     size_t small_bytes = 0;
     int *d_big_list[2] = {nullptr, nullptr};
     int *d_big_count[2] = {nullptr, nullptr};
@@ -331,18 +336,19 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d_action = dev_alloc<int32_t>(N);
     d.action = d_action;
     d.obs = dev_alloc<uint8_t>(N * OBS_BYTES);
-    small_bytes = N * 14 + 4;
+    small_bytes = N * 14 + 4 + 5 * sizeof(int);
     d_small = dev_alloc<uint8_t>(small_bytes);
     d.rew = (float *)d_small;
     d.prev_level_seed = (int32_t *)(d_small + 4 * N);
     d.level_seed = (int32_t *)(d_small + 8 * N);
     d.first = d_small + 12 * N;
     d.prev_level_complete = d_small + 13 * N;
-    d.error = (int *)(d_small + ((14 * N + 3) & ~(size_t)3));
-    small_bytes = ((14 * N + 3) & ~(size_t)3) + 4;
+    tail_off = (14 * N + 3) & ~(size_t)3;
+    d.error = (int *)(d_small + tail_off) + 2;
+    small_bytes = tail_off + 5 * sizeof(int);
     for (int k = 0; k < 2; k++) {
         d_big_list[k] = dev_alloc<int>(N * (NUM_TIERS - 1));
-        d_big_count[k] = dev_alloc<int>(NUM_TIERS - 1);
+        d_big_count[k] = (int *)(d_small + tail_off) + 3 * k;  // A: ints 0-1, B: ints 3-4 (error between them)
         d_route[k] = dev_alloc<uint8_t>(N);
     }
     d.assets = d_assets;
@@ -389,7 +395,6 @@ VecGame::~VecGame() {
     (void)hipFree(d_small);
     for (int k = 0; k < 2; k++) {
         (void)hipFree(d_big_list[k]);
-        (void)hipFree(d_big_count[k]);
         (void)hipFree(d_route[k]);
     }
     if (h_action) (void)hipHostFree(h_action);
@@ -434,9 +439,14 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
 
 void VecGame::launch(int mode) {
     bind_routing();
-    HIP_CHECK(hipMemsetAsync(d.next_big_count, 0, sizeof(int) * (NUM_TIERS - 1), stream));
-    HIP_CHECK(hipMemsetAsync(d.error, 0, sizeof(int), stream));
-    HIP_CHECK(launch_step(game_id, d, mode, streams()));
+    {   // next counts + error are adjacent in either parity: [A | error] or [error | B]
+        int *first = d.next_big_count < d.error ? d.next_big_count : d.error;
+        HIP_CHECK(hipMemsetAsync(first, 0, 3 * sizeof(int), stream));
+    }
+    LaunchStreams ls = streams();
+    ls.list_count[0] = mode == 0 ? 0 : host_list_count[0];
+    ls.list_count[1] = mode == 0 ? 0 : host_list_count[1];
+    HIP_CHECK(launch_step(game_id, d, mode, ls));
     step_count++;
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
     if (host_observations) {
@@ -463,7 +473,13 @@ void VecGame::observe() {  // reference src/vecgame.cpp:363-376,416-435
     HIP_CHECK(hipStreamSynchronize(stream));
     pending = false;
     const size_t N = (size_t)num_envs;
-    const int err = *(const int *)(h_small + (small_bytes - 4));
+    const int *tail = (const int *)(h_small + tail_off);
+    const int err = tail[2];
+    {   // the lists the step just run filled are the ones the next step reads
+        const int *cnt = tail + 3 * (int)(step_count & 1);
+        host_list_count[0] = cnt[0];
+        host_list_count[1] = cnt[1];
+    }
     if (err && !d.debug_flags) fatal("device-side check failed (code %d: 1 entity table overflow, 2 grid index out of range, 3 fassert, 4 asset theme, 5 unsupported draw)\n", err);
     memcpy(rew_ptr, h_small, 4 * N);
     memcpy(first_ptr, h_small + 12 * N, N);
@@ -527,6 +543,7 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
         HIP_CHECK(hipMemcpy(d_big_list[cur] + (size_t)t * num_envs + count, &e, sizeof(int), hipMemcpyHostToDevice));
         count++;
         HIP_CHECK(hipMemcpy(d_big_count[cur] + t, &count, sizeof(int), hipMemcpyHostToDevice));
+        host_list_count[t] = count;
     }
     // Game::observe(): refresh this env's observation / reward / first / info (reference src/vecgame.cpp:453-455)
     const uint8_t first = (uint8_t)s.hdr.done, plc = (uint8_t)s.hdr.level_complete;
