@@ -2,7 +2,8 @@
 // A ship with rotational control (thrust along its heading, vrot) in a cave grown by a cellular automaton
 // (RoomGenerator): the largest room is kept, a BFS path from the agent to the goal is widened and re-eroded, then
 // obstacles, targets and patrolling enemies are dropped on free cells.  Bullets and exhaust are rotated sprites.
-// Easy / hard worlds (<= 40x40); the memory-mode 60x60 world would need a larger LDS arena and is refused.
+// CaveFlyerT<40 * 40> serves the easy / hard worlds; the memory-mode 60x60 world is its own instantiation
+// (CaveFlyerMemory, kernel id KERNEL_CAVEFLYER_MEMORY) so that the default modes keep the small LDS arena.
 #pragma once
 #include "pg_game_defaults.h"
 #include "pg_math.h"
@@ -10,14 +11,16 @@
 
 namespace pgamd {
 
-struct CaveFlyer : BagDefaults<CaveFlyer> {
-    static constexpr int GAME_ID = GAME_CAVEFLYER;
+template <int CELLS, int KERNEL_ID>
+struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
+    static constexpr int GAME_ID = KERNEL_ID;
     static constexpr const char *NAME = "caveflyer";
-    static constexpr int MAX_CELLS = 40 * 40;  // caveflyer.cpp:131-146 (hard mode)
+    static constexpr int MAX_CELLS = CELLS;  // caveflyer.cpp:131-146
     typedef RoomScratch<MAX_CELLS> Scratch;
     static constexpr bool USES_ENTITY_COLLISIONS = true;
     static constexpr bool USES_ROTATION = true;
-    static constexpr int ENT_CAP_T0 = 64, ENT_CAP_T1 = 96, ENT_CAP_T2 = 160;
+    // a level drops 3 * (free cells / 80) objects: <= 60 in the 40x40 world, <= 135 in the 60x60 one
+    static constexpr int ENT_CAP_T0 = CELLS > 1600 ? 160 : 64, ENT_CAP_T1 = CELLS > 1600 ? 192 : 96, ENT_CAP_T2 = CELLS > 1600 ? 256 : 160;
     // a bullet, an exhaust puff, one explosion per bullet (wall hits, collisions) and per target, the reserved slot
     template <class E>
     PG_DEV static int slots_needed_next_step(E &e) {
@@ -32,14 +35,14 @@ struct CaveFlyer : BagDefaults<CaveFlyer> {
     static constexpr int MARKER = 250;  // the reference's transient 1003 (never visible outside game_reset); any unused id does
 
     static void construct(EnvHdr &G) {  // caveflyer.cpp:27-30
-        construct_defaults(G);
+        CaveFlyerT::construct_defaults(G);
         G.mixrate = 0.9f;
     }
     template <class E>
     PG_DEV static void choose_world_dim(E &e) {  // caveflyer.cpp:131-146
         const int dm = e.d.opt.distribution_mode;
-        const int wd = dm == EasyMode ? 30 : (dm == HardMode ? 40 : 20);
-        if (dm == MemoryMode) e.fail(PGE_ASSERT);
+        const int wd = dm == EasyMode ? 30 : (dm == HardMode ? 40 : (dm == MemoryMode ? 60 : 20));
+        if (wd * wd > MAX_CELLS) e.fail(PGE_ASSERT);
         e.G.main_width = wd;
         e.G.main_height = wd;
     }
@@ -163,7 +166,7 @@ struct CaveFlyer : BagDefaults<CaveFlyer> {
         PG_SYNC();
         // goal path (flags in f3, kept until the end), covered flags in f0
         rg.find_path(agent_cell, goal_cell, m.f3, m.f0);
-        {   // should_prune (every mode but memory): keep the path widened by 4 rings
+        if (e.d.opt.distribution_mode != MemoryMode) {  // should_prune: keep the path widened by 4 rings
             rg.copy(m.f1, m.f3);
             rg.expand_room(m.f1, 4, m.f0, m.f2);
             for (int base = 0; base < n; base += 64) {
@@ -278,5 +281,7 @@ struct CaveFlyer : BagDefaults<CaveFlyer> {
         PG_SYNC();
     }
 };
+using CaveFlyer = CaveFlyerT<40 * 40, GAME_CAVEFLYER>;
+using CaveFlyerMemory = CaveFlyerT<60 * 60, KERNEL_CAVEFLYER_MEMORY>;
 
 }  // namespace pgamd

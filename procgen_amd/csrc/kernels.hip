@@ -3,7 +3,7 @@
 
 namespace pgamd {
 
-#define PG_GAME_NAMES(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist) X(Ninja) X(Dodgeball) X(BossFight) X(Chaser) X(CaveFlyer) X(Jumper)
+#define PG_GAME_NAMES(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist) X(Ninja) X(Dodgeball) X(BossFight) X(Chaser) X(CaveFlyer) X(Jumper) X(CaveFlyerMemory)
 #define PG_X(Game) const GameEntry *game_entry_##Game();
 PG_GAME_NAMES(PG_X)
 #undef PG_X

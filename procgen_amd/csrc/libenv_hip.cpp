@@ -106,7 +106,8 @@ T *dev_alloc(size_t count) {
 
 struct VecGame {
     int num_envs = 0;
-    int game_id = -1;
+    int game_id = -1;    // assets, state wire format
+    int kernel_id = -1;  // the policy instantiation the kernels run (kernel_id_for)
     int device_id = 0;
     bool host_observations = true;
     std::vector<libenv_tensortype> observation_types, action_types, info_types;
@@ -226,11 +227,12 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     } else if (dist_mode == ExtremeMode) {
         if (!(env_name == "chaser" || env_name == "dodgeball" || env_name == "leaper" || env_name == "starpilot")) fatal("fassert failed: extreme mode unsupported for %s\n", env_name.c_str());
     } else if (dist_mode == MemoryMode) {
-        if (env_name == "caveflyer") fatal("caveflyer memory mode (60x60 world) is not provided by the HIP stepper yet (its level generator's LDS arena is sized for 40x40)\n");
         if (!(env_name == "caveflyer" || env_name == "dodgeball" || env_name == "heist" || env_name == "jumper" || env_name == "maze" || env_name == "miner")) fatal("fassert failed: memory mode unsupported for %s\n", env_name.c_str());
     } else {
         fatal("invalid distribution_mode %d\n", dist_mode);
     }
+    kernel_id = kernel_id_for(game_id, dist_mode);
+    if (!game_supported(kernel_id)) fatal("game %s has no kernel for distribution_mode %d in the HIP stepper\n", env_name.c_str(), dist_mode);
     int plain_assets = 0, physics_mode = 0, game_type = 0;
     opts.consume_int("plain_assets", &plain_assets);
     opts.consume_int("physics_mode", &physics_mode);
@@ -320,7 +322,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
 
     // per-env state in HBM
     const size_t N = (size_t)num_envs;
-    game_limits(game_id, &d.ent_cap, &d.grid_bytes);
+    game_limits(kernel_id, &d.ent_cap, &d.grid_bytes);
     d.num_envs = num_envs;
     d.hdr = dev_alloc<EnvHdr>(N);
     d.rng = dev_alloc<uint32_t>(N * MT_SLOTS * MT_STRIDE);
@@ -329,7 +331,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     {
         std::vector<EnvHdr> hdr(N);
         std::vector<uint32_t> rng(N * MT_SLOTS * MT_STRIDE);
-        game_init_state(game_id, num_envs, rand_seed, env_offset, env_stride, hdr.data(), rng.data());
+        game_init_state(kernel_id, num_envs, rand_seed, env_offset, env_stride, hdr.data(), rng.data());
         HIP_CHECK(hipMemcpy(d.hdr, hdr.data(), N * sizeof(EnvHdr), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d.rng, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
     }
@@ -446,7 +448,7 @@ void VecGame::launch(int mode) {
     LaunchStreams ls = streams();
     ls.list_count[0] = mode == 0 ? 0 : host_list_count[0];
     ls.list_count[1] = mode == 0 ? 0 : host_list_count[1];
-    HIP_CHECK(launch_step(game_id, d, mode, ls));
+    HIP_CHECK(launch_step(kernel_id, d, mode, ls));
     step_count++;
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
     if (host_observations) {
@@ -527,7 +529,7 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     std::string err;
     if (!deserialize_state(game_id, d.opt, &s, data, length, &err)) fatal("%s\n", err.c_str());
     // routing between the arena tiers of the step kernel: conservative bound (a step at most doubles the table)
-    s.hdr.big = game_tier_for(game_id, 2 * s.hdr.n_ents + 4);
+    s.hdr.big = game_tier_for(kernel_id, 2 * s.hdr.n_ents + 4);
     HIP_CHECK(hipMemcpy(d.ents + (size_t)e * EF_COUNT * d.ent_cap, s.ents.data(), s.ents.size() * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, s.rng.data(), s.rng.size() * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.grid + (size_t)e * d.grid_bytes, s.grid.data(), s.grid.size(), hipMemcpyHostToDevice));
@@ -553,7 +555,7 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     HIP_CHECK(hipMemcpy(d.prev_level_complete + e, &plc, 1, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.level_seed + e, &s.hdr.current_level_seed, 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemsetAsync(d.error, 0, sizeof(int), stream));
-    HIP_CHECK(launch_render_one(game_id, d, e, stream));
+    HIP_CHECK(launch_render_one(kernel_id, d, e, stream));
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
     if (host_observations) {
         void *dst = ob_contig ? ob_ptr[0] : (void *)h_obs_stage;
@@ -729,7 +731,7 @@ LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const in
         v->bind_routing();
         HIP_CHECK(hipMemsetAsync(v->d.next_big_count, 0, sizeof(int) * (NUM_TIERS - 1), v->stream));
         HIP_CHECK(hipEventRecord(e0, v->stream));
-        HIP_CHECK(launch_step(v->game_id, v->d, 1, v->streams()));
+        HIP_CHECK(launch_step(v->kernel_id, v->d, 1, v->streams()));
         HIP_CHECK(hipEventRecord(e1, v->stream));
         v->step_count++;
         HIP_CHECK(hipEventSynchronize(e1));

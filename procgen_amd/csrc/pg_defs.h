@@ -28,6 +28,11 @@ enum GameId : int {
     GAME_STARPILOT, NUM_GAMES
 };
 
+// Kernel variants: the policy a handle is compiled against.  Normally the game id; caveflyer's memory mode (60x60 world)
+// is its own instantiation with a larger LDS arena, so the default modes keep theirs small.
+constexpr int KERNEL_CAVEFLYER_MEMORY = NUM_GAMES;
+inline int kernel_id_for(int game_id, int distribution_mode) { return (game_id == GAME_CAVEFLYER && distribution_mode == 10) ? KERNEL_CAVEFLYER_MEMORY : game_id; }
+
 enum DistributionMode : int { EasyMode = 0, HardMode = 1, ExtremeMode = 2, MemoryMode = 10 };
 
 // ---- options common to every env of a handle (reference src/game.h:45-60, src/vecgame.cpp:183-190) ----

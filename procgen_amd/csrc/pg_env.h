@@ -126,7 +126,7 @@ struct GameHasBlockHook<Game, decltype((void)Game::HAS_BLOCK_HOOK)> {
 template <class Game, int CAP>
 struct Lds {
     uint32_t ent[EF_COUNT * CAP];
-    uint32_t tmp[64];
+    uint32_t tmp[128];  // lane scratch; simple_choose keeps up to 128 picks here
     alignas(16) typename Game::cell_t grid[(Game::MAX_CELLS + 15) & ~15];
     typename GameScratch<Game>::type scratch;
 #if defined(PG_LDS_PAD)
@@ -1139,15 +1139,15 @@ struct Env {
         for (int base = 0; base < nc; base += 64) n += pg_popc64(PG_BALLOT(l, (base + l) < nc && pred((int)s->grid[base + l])));
         return n;
     }
-    // RandGen::simple_choose (reference src/randgen.cpp:71-88): k <= 64 distinct draws below n, kept in s->tmp[0..k)
+    // RandGen::simple_choose (reference src/randgen.cpp:71-88): k <= 128 distinct draws below n, kept in s->tmp[0..k)
     PG_DEV void simple_choose(int n, int k) {
-        if (!(k <= n) || k > 64) {
+        if (!(k <= n) || k > 128) {
             fail(PGE_ASSERT);
             return;
         }
         for (int i = 0; i < k; i++) {
             int next = randn(n);
-            while (PG_BALLOT(l, l < i && (int)s->tmp[l] == next) != 0) next = randn(n);
+            while ((PG_BALLOT(l, l < i && (int)s->tmp[l] == next) | PG_BALLOT(l, 64 + l < i && (int)s->tmp[64 + l] == next)) != 0) next = randn(n);
             s->tmp[i] = (uint32_t)next;
             PG_SYNC();
         }

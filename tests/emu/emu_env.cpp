@@ -35,6 +35,7 @@ struct EmuVec {
     int use_small;
     int dev_error = 0;
     int game_id = -1;
+    int kernel_id = -1;
 };
 
 template <class Game, int CAP>
@@ -68,7 +69,8 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     v->n = num_envs;
     v->use_small = use_small;
     std::string err;
-    int gid = game_id_from_name(game);
+    const int game_id = game_id_from_name(game);
+    const int gid = kernel_id_for(game_id, distribution_mode);  // the policy instantiation (caveflyer's memory mode has its own)
     bool known = false;
 #define PG_X(Game) known = known || gid == Game::GAME_ID;
     PG_FOR_EACH_GAME(PG_X)
@@ -77,8 +79,9 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
         fprintf(stderr, "emu: game %s not implemented\n", game);
         return nullptr;
     }
-    v->game_id = gid;
-    if (!load_game_assets(gid, resource_root ? resource_root : "", atlas_path ? atlas_path : "", &v->assets, &err)) {
+    v->game_id = game_id;
+    v->kernel_id = gid;
+    if (!load_game_assets(game_id, resource_root ? resource_root : "", atlas_path ? atlas_path : "", &v->assets, &err)) {
         fprintf(stderr, "emu: %s\n", err.c_str());
         return nullptr;
     }
@@ -140,7 +143,7 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
 void emu_free(void *h) { delete (EmuVec *)h; }
 static void run_game(EmuVec *v, int mode) {
 #define PG_X(Game) \
-    if (v->game_id == Game::GAME_ID) run_all<Game>(v, mode);
+    if (v->kernel_id == Game::GAME_ID) run_all<Game>(v, mode);
     PG_FOR_EACH_GAME(PG_X)
 #undef PG_X
 }
@@ -201,7 +204,7 @@ int emu_set_state(void *h, int env, const char *data, int length) {
     v->plc[env] = (uint8_t)s.hdr.level_complete;
     v->ls[env] = s.hdr.current_level_seed;
 #define PG_X(Game)                            \
-    if (v->game_id == Game::GAME_ID) {        \
+    if (v->kernel_id == Game::GAME_ID) {      \
         static RenderLdsT<Game> rlds;         \
         Renderer<Game> r(v->d, env, &rlds);   \
         r.render_env();                       \

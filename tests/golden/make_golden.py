@@ -10,6 +10,8 @@ Fixtures (npz, small):
                        N envs x T steps: actions, rew, first, prev_level_seed, prev_level_complete, level_seed,
                        per-frame CRC32 of the RGB888 frame, full frames every `frame_every` steps, and the entity
                        table / grid / key scalars parsed from get_state at a few checkpoints.
+  mode_matrix.npz    : (`make_golden.py modes`) every accepted (game, distribution_mode) pair besides the default:
+                       rew / first / level_seed / frame CRC32 of 6 envs x 100 steps.
   <game>_seeding.npz : reference procgen/env_test.py:7-30 (num_levels=1, start_level in {0,1}): first frames after
                        one step of action 0.
 """
@@ -83,7 +85,39 @@ def seeding(game):
     return res
 
 
+# distribution modes other than the default (reference src/game.cpp:55-62 and each game's choose_world_dim / game_reset):
+# every (game, mode) pair the reference accepts, except jumper easy (refused by the HIP stepper)
+MODE_MATRIX = ([(g, "easy") for g in ("bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot", "heist", "leaper", "maze",
+                                      "miner", "ninja", "plunder", "starpilot")]
+               + [(g, "extreme") for g in ("chaser", "dodgeball", "leaper", "starpilot")]
+               + [(g, "memory") for g in ("caveflyer", "dodgeball", "heist", "jumper", "maze", "miner")])
+
+
+def mode_matrix(n=6, t_steps=100):
+    """<game>/<mode>/{rew, first, level_seed, crc}: n envs x t_steps of the compiled reference in that mode; actions as above."""
+    res = {}
+    for game, mode in MODE_MATRIX:
+        env = ref_env.make_ref_env(n, game, rand_seed=23, distribution_mode=mode)
+        rng = np.random.RandomState(0)
+        out = {k: [] for k in ("rew", "first", "level_seed", "crc")}
+        for t in range(t_steps + 1):
+            rew, ob, first = env.observe()
+            out["rew"].append(rew.copy())
+            out["first"].append(first.astype(np.uint8))
+            out["level_seed"].append(env.info_arrays()["level_seed"].copy())
+            out["crc"].append(np.array([zlib.crc32(ob["rgb"][e].tobytes()) for e in range(n)], dtype=np.uint32))
+            env.act(rng.randint(0, 15, size=(n,), dtype=np.int32))
+        env.close()
+        for k, v in out.items():
+            res[f"{game}/{mode}/{k}"] = np.array(v)
+    return res
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["modes"]:
+        np.savez_compressed(os.path.join(HERE, "mode_matrix.npz"), **mode_matrix())
+        print("mode matrix done")
+        sys.exit(0)
     games = sys.argv[1:] or ["coinrun"]
     for game in games:
         r = rollout(game, n=16, t_steps=512, frame_every=64, state_at=(0, 100, 300, 512))

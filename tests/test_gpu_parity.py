@@ -201,6 +201,19 @@ def test_joint_handle_of_all_sixteen_games():
             assert np.array_equal(joint[key][:, k::K], ref[key][:, k::K]), (game, key)
 
 
+def test_every_distribution_mode_matches_reference_fixture(golden_dir):
+    """All accepted (game, distribution_mode) pairs besides the default against tests/golden/mode_matrix.npz (compiled reference)."""
+    g = np.load(os.path.join(golden_dir, "mode_matrix.npz"))
+    pairs = sorted({tuple(k.split("/")[:2]) for k in g.files})
+    assert len(pairs) == 25
+    for game, mode in pairs:
+        n = g[f"{game}/{mode}/rew"].shape[1]
+        steps = g[f"{game}/{mode}/rew"].shape[0] - 1
+        got = rollout(make_env(n, game, distribution_mode=mode), action_stream(n, steps))
+        for k in ("rew", "first", "level_seed", "crc"):
+            assert np.array_equal(got[k], g[f"{game}/{mode}/{k}"]), (game, mode, k)
+
+
 def test_bigfish_full_size_prefix_matches_oracle():
     """BASELINE configs[2] (bigfish, 65536 envs): the first 128 envs equal a 128-env oracle run."""
     n, steps, m = 65536, 10, 128

@@ -3,6 +3,8 @@ CPU: the kernel sources themselves (procgen_amd/csrc/pg_env.h + game policies), 
 emulation (tests/emu), against the oracle: frames, rew/first/info, entity tables and grids, bit exact, including the
 routing between the small and the large LDS arena.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -60,3 +62,15 @@ def test_emulated_num_levels_and_easy_mode():
         a = rollout(oracle_env.OracleEnv(4, "coinrun", rand_seed=2, **kw), acts)
         b = rollout(emu_harness.EmuEnv(4, "coinrun", rand_seed=2, **kw), acts)
         assert_rollouts_equal(a, b, str(kw))
+
+
+@pytest.mark.parametrize("game,mode", [("caveflyer", "memory"), ("maze", "memory"), ("jumper", "memory"), ("dodgeball", "extreme"), ("leaper", "extreme"),
+                                       ("heist", "easy"), ("miner", "easy"), ("starpilot", "easy")])
+def test_emulated_distribution_modes_match_reference_fixture(golden_dir, game, mode):
+    """Kernel logic in non-default modes against the compiled reference's fixture (caveflyer memory runs its own 60x60 policy)."""
+    g = np.load(os.path.join(golden_dir, "mode_matrix.npz"))
+    n = g[f"{game}/{mode}/rew"].shape[1]
+    steps = g[f"{game}/{mode}/rew"].shape[0] - 1
+    got = rollout(emu_harness.EmuEnv(n, game, rand_seed=23, distribution_mode={"easy": 0, "extreme": 2, "memory": 10}[mode]), action_stream(n, steps))
+    for k in ("rew", "first", "level_seed", "crc"):
+        assert np.array_equal(got[k], g[f"{game}/{mode}/{k}"]), (game, mode, k)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_env
-from helpers import assert_rollouts_equal, rollout
+from helpers import action_stream, assert_rollouts_equal, rollout
 
 
 GAMES = ["coinrun", "bigfish", "maze", "climber", "miner", "starpilot", "fruitbot", "leaper", "plunder", "heist", "ninja", "dodgeball", "bossfight", "chaser", "caveflyer", "jumper"]
@@ -78,3 +78,23 @@ def test_oracle_env_independent_of_num_envs():
     b = rollout(oracle_env.OracleEnv(3, "coinrun", rand_seed=11), [x[:3] for x in acts])
     for k in a:
         assert np.array_equal(a[k][:, :3], b[k])
+
+
+MODE_IDS = {"easy": 0, "hard": 1, "extreme": 2, "memory": 10}
+
+
+def _mode_pairs(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mode_matrix.npz"))
+    return g, sorted({tuple(k.split("/")[:2]) for k in g.files})
+
+
+def test_oracle_matches_reference_in_every_distribution_mode(golden_dir):
+    """tests/golden/mode_matrix.npz (compiled reference, `make_golden.py modes`): all accepted (game, mode) pairs besides the default."""
+    g, pairs = _mode_pairs(golden_dir)
+    assert len(pairs) == 25
+    for game, mode in pairs:
+        n = g[f"{game}/{mode}/rew"].shape[1]
+        steps = g[f"{game}/{mode}/rew"].shape[0] - 1
+        got = rollout(oracle_env.OracleEnv(n, game, rand_seed=23, distribution_mode=MODE_IDS[mode]), action_stream(n, steps))
+        for k in ("rew", "first", "level_seed", "crc"):
+            assert np.array_equal(got[k], g[f"{game}/{mode}/{k}"]), (game, mode, k)
