@@ -220,9 +220,12 @@ struct Renderer {
     // qt_scale_image_32bit.  tr.w / tr.h may be negative (a 180 degree rotation arrives as a negative scale).
     PG_DEV void cmd_image(int img_index, bool mirrored, RectD tr, float opacity, uint32_t &geom, uint32_t &basex_o, uint32_t &srcy_o,
                           uint32_t &ix_o, uint32_t &iy_o, uint32_t &src_o, uint32_t &aux_o) const {
+        cmd_image_desc(d.assets->img[img_index], mirrored, tr, opacity, geom, basex_o, srcy_o, ix_o, iy_o, src_o, aux_o);
+    }
+    PG_DEV void cmd_image_desc(const ImgDesc im, bool mirrored, RectD tr, float opacity, uint32_t &geom, uint32_t &basex_o, uint32_t &srcy_o,
+                               uint32_t &ix_o, uint32_t &iy_o, uint32_t &src_o, uint32_t &aux_o) const {
         geom = 0;
         basex_o = srcy_o = ix_o = iy_o = src_o = aux_o = 0;
-        const ImgDesc im = d.assets->img[img_index];
         const double sx = tr.w / (double)im.w;
         const double sy = tr.h / (double)im.h;
         const int ix = (int)(65536 / sx);
@@ -1280,39 +1283,34 @@ struct Renderer {
                 const DrawCmd c = read_cmd(r, k);
                 if (cmd_tiled(c.aux)) {
                     if constexpr (NESTED || !GameUsesTiledEntities<Game>::value) fail(PGE_ASSERT);
-                    else exec_tiled((int)c.basex);  // tiled commands carry their entity index
+                    else exec_tiled(c);
                 } else if (cmd_rotated(c.aux)) exec_rotated(c);
                 else exec_large(c);
             }
         }
     }
 
-    // tile_image BAG:840-865 for entity i: a row (tile_ratio > 0) or column (< 0) of equally sized tiles, each its
-    // own drawImage with its own rounding.  Lanes set up 64 tiles at a time.
-    PG_DEV void exec_tiled(int i) {
-        const uint32_t mm = meta(i);
-        const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
-        RectD rect;
-        if (mm & MF_ABS_COORDS) {
-            const float vd = G.view_dim;
-            rect.x = (double)((vd * (x - rx)) * G.unit);
-            rect.y = (double)((vd * (y + ry)) * G.unit);
-            rect.w = (double)((2 * vd * rx) * G.unit);
-            rect.h = (double)((2 * vd * ry) * G.unit);
-        } else {
-            rect = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
-        }
-        const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, 0.0f, rect);
-        if (im < 0) return;
-        float tile_ratio = Game::tile_aspect_ratio(*this, i);
+    // tile_image BAG:840-865 for one tiled entity: a row (tile_ratio > 0) or column (< 0) of equally sized tiles, each its
+    // own drawImage with its own rounding.  Lanes set up 64 tiles at a time.  The entity's rect, image and flags come
+    // from the record its set-up lane left in LDS (slot = c.srcy): a band pass pays no HBM round trips for them.
+    PG_DEV static double words_to_double(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32)); }
+    PG_DEV void exec_tiled(const DrawCmd &c) {
+        const uint32_t *rp = &lds->rot[(c.srcy0 & 63u) * ROT_WORDS];
+        const RectD rect = {words_to_double(rp[0], rp[1]), words_to_double(rp[2], rp[3]), words_to_double(rp[4], rp[5]), words_to_double(rp[6], rp[7])};
+        ImgDesc imd;
+        imd.off = rp[8];
+        imd.w = (uint16_t)(rp[9] & 0xffffu);
+        imd.h = (uint16_t)(rp[9] >> 16);
+        imd.opaque = rp[10];
+        const float alpha = __builtin_bit_cast(float, rp[11]);
+        float tile_ratio = __builtin_bit_cast(float, rp[12]);
+        const bool mirrored = (rp[13] & 1u) != 0;
         const bool vertical = tile_ratio < 0;
         if (vertical) tile_ratio = -1 * tile_ratio;
         int num_tiles = vertical ? (int)(rect.h / (rect.w * (double)tile_ratio)) : (int)(rect.w / (rect.h * (double)tile_ratio));
         if (num_tiles < 1) num_tiles = 1;
         const float tile_width = vertical ? (float)rect.w : (float)(rect.w / num_tiles);
         const float tile_height = vertical ? (float)(rect.h / num_tiles) : (float)rect.h;
-        const float alpha = ef(EF_ALPHA, i);
-        const bool mirrored = (mm & MF_REFLECTED) != 0;
         for (int base = 0; base < num_tiles; base += 64) {
             CmdRegs r;
             PG_FOR_LANES(l) {
@@ -1330,7 +1328,7 @@ struct Renderer {
                     }
                     tr.w = (double)tile_width;
                     tr.h = (double)tile_height;
-                    cmd_image(im, mirrored, tr, alpha, PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                    cmd_image_desc(imd, mirrored, tr, alpha, PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                 }
             }
             run_batch<true>(r);
@@ -1344,10 +1342,10 @@ struct Renderer {
     PG_DEV int setup_entities(int base, CmdRegs &r, uint64_t (&zmask)[3], int rot_base = -1) {
         const int n = G.n_ents;
         for (int z = 0; z < 3; z++) zmask[z] = PG_BALLOT(l, (base + l) < n && meta_render_z(meta(base + l)) == z - 1);
-        uint64_t rotmask = 0;
+        uint64_t rotmask = 0;  // entities that need an LDS record: turned sprites and tiled ones
         if constexpr (GameUsesRotation<Game>::value) {
             if (rot_base >= 0) {
-                rotmask = PG_BALLOT(l, (base + l) < n && ef(EF_ROTATION, base + l) != 0);
+                rotmask = PG_BALLOT(l, (base + l) < n && (ef(EF_ROTATION, base + l) != 0 || (GameUsesTiledEntities<Game>::value && Game::tile_aspect_ratio(*this, base + l) != 0)));
                 if (rot_base + pg_popc64(rotmask) > 64) return -1;
             }
         }
@@ -1388,7 +1386,24 @@ struct Renderer {
                         if (bx2 > bx1 && by2 > by1) {
                             PG_LV(r.geom, l) = (uint32_t)bx1 | ((uint32_t)by1 << 7) | ((uint32_t)(bx2 - bx1) << 14) | ((uint32_t)(by2 - by1) << 21);
                             PG_LV(r.basex, l) = (uint32_t)i;
+                            PG_LV(r.srcy, l) = (uint32_t)rot_slot;
                             PG_LV(r.aux, l) = 1u << 25;
+                            if constexpr (GameUsesTiledEntities<Game>::value && GameUsesRotation<Game>::value) {  // what exec_tiled needs, see there
+                                uint32_t *rp = &lds->rot[rot_slot * ROT_WORDS];
+                                const double rv[4] = {r1.x, r1.y, r1.w, r1.h};
+                                for (int k = 0; k < 4; k++) {
+                                    const uint64_t bits = __builtin_bit_cast(uint64_t, rv[k]);
+                                    rp[2 * k] = (uint32_t)bits;
+                                    rp[2 * k + 1] = (uint32_t)(bits >> 32);
+                                }
+                                const ImgDesc imd = d.assets->img[im];
+                                rp[8] = imd.off;
+                                rp[9] = (uint32_t)imd.w | ((uint32_t)imd.h << 16);
+                                rp[10] = imd.opaque;
+                                rp[11] = __builtin_bit_cast(uint32_t, ef(EF_ALPHA, i));
+                                rp[12] = __builtin_bit_cast(uint32_t, tile_ratio);
+                                rp[13] = (mm & MF_REFLECTED) ? 1u : 0u;
+                            }
                         }
                     } else if (rotation == 0) cmd_image(im, (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                     else cmd_image_rotated(rot_slot, im, (mm & MF_REFLECTED) != 0, r1, rotation, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
