@@ -1,0 +1,40 @@
+"""
+CPU (hipcc cross-compiles without a GPU): no kernel may use scratch (private) memory.
+
+A `?:` chain over adjacent struct fields or small local arrays is folded by LLVM into one access at a computed
+offset, which pins the whole per-env state struct in scratch memory instead of registers; plunder's and leaper's step
+kernels ran 2x slower for it.  The guard compiles the device code of the games that were hit,
+plus the headline game, and reads `private_segment_fixed_size` from the emitted kernel descriptors.
+"""
+import os
+import re
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "procgen_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+GAMES = ["CoinRun", "Plunder", "Leaper", "FruitBot"]
+
+
+def _scratch_bytes(game, tmp):
+    out = os.path.join(tmp, f"{game}.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing", f"-DPG_GAME={game}",
+                           "--cuda-device-only", "-S", "-c", os.path.join(CSRC, "kernels_game.hip"), "-o", out], cwd=CSRC, stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    names = re.findall(r"^\s+\.name:\s+(\S+)", text, re.M)
+    sizes = [int(x) for x in re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", text, re.M)]
+    assert len(names) == len(sizes) == 4, (game, names)  # step_tier0, two step_list tiers, render
+    return dict(zip(names, sizes))
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs the ROCm compiler")
+def test_kernels_use_no_scratch_memory(tmp_path):
+    with ThreadPoolExecutor(len(GAMES)) as ex:
+        results = list(ex.map(lambda g: _scratch_bytes(g, str(tmp_path)), GAMES))
+    for game, res in zip(GAMES, results):
+        for kernel, size in res.items():
+            assert size == 0, f"{game}: {kernel} uses {size} B of scratch per lane"
+    shutil.rmtree(str(tmp_path), ignore_errors=True)
