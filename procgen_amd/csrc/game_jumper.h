@@ -6,6 +6,7 @@
 // its path engine -- not restated, refused at libenv_make.
 #pragma once
 #include "pg_game_defaults.h"
+#include "pg_math.h"
 #include "pg_mazegen.h"
 #include "pg_roomgen.h"
 
@@ -354,7 +355,7 @@ struct Jumper : BagDefaults<Jumper> {
         const float cx = (float)(cr_.x + cr_.w / 2);
         const float cy = (float)(cr_.y + cr_.h / 2);
         const float cr = (float)(cr_.w / 2 * .95);
-        const float theta = (float)pg_atan2((double)(r.ey(goal) - r.ey(ag)), (double)(r.ex(goal) - r.ex(ag)));  // get_theta BAG:233-238
+        const float theta = (float)pg_atan2_d((double)(r.ey(goal) - r.ey(ag)), (double)(r.ex(goal) - r.ex(ag)));  // get_theta BAG:233-238
         r.exec_line((int)cx, (int)cy, (int)((double)cx + (double)cr * pg_cos((double)theta)), (int)((double)cy - (double)cr * pg_sin((double)theta)), 0xfffcba03u);
         const float ddx = r.ex(ag) - r.ex(goal), ddy = r.ey(ag) - r.ey(goal);
         const float dist = (float)pg_sqrt((double)(ddx * ddx + ddy * ddy));  // get_distance BAG:133-143

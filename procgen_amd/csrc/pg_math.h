@@ -103,4 +103,93 @@ PG_DEV float pg_atan2f(float y, float x) {
     }
 }
 
+// Double precision atan2 for BasicAbstractGame::get_theta (reference src/basic-abstract-game.cpp:233-238: float dx, dy
+// promoted to double, the result narrowed to float; only jumper's compass uses it, and only to place a line).  The
+// published fdlibm algorithm (e_atan2.c, s_atan.c; error < 1 ulp): the same four-interval reduction as the float
+// version above with a degree-11 odd polynomial in double.  The device libm's atan2 costs 41 VGPRs more in the render
+// kernel (a wave per SIMD in jumper); after the narrowing to float both agree with glibc's correctly rounded atan2
+// except on a ~2^-29 fraction of inputs (tests/test_device_math.py measures it on the host).
+PG_DEV double pg_atan_d(double x) {
+    const double atanhi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01, 1.57079632679489655800e+00};
+    const double atanlo[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17, 6.12323399573676603587e-17};
+    const double aT[11] = {3.33333333333329318027e-01,  -1.99999999998764832476e-01, 1.42857142725034663711e-01,  -1.11111104054623557880e-01,
+                           9.09088713343650656196e-02,  -7.69187620504482999495e-02, 6.66107313738753120669e-02,  -5.83357013379057348645e-02,
+                           4.97687799461593236017e-02,  -3.65315727442169155270e-02, 1.62858201153657823623e-02};
+    const int64_t bits = __builtin_bit_cast(int64_t, x);
+    const int32_t hx = (int32_t)(bits >> 32);
+    const int32_t ix = hx & 0x7fffffff;
+    double hi = 0, lo = 0;
+    bool reduced = true;
+    if (ix >= 0x44100000) {  // |x| >= 2^66 (or NaN)
+        if (x != x) return x + x;
+        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3fdc0000) {  // |x| < 0.4375
+        if (ix < 0x3e200000) return x;  // |x| < 2^-29
+        reduced = false;
+    } else {
+        x = __builtin_fabs(x);
+        if (ix < 0x3ff30000) {  // |x| < 1.1875
+            if (ix < 0x3fe60000) {  // 7/16 <= |x| < 11/16
+                hi = atanhi[0]; lo = atanlo[0];
+                x = (2.0 * x - 1.0) / (2.0 + x);
+            } else {  // 11/16 <= |x| < 19/16
+                hi = atanhi[1]; lo = atanlo[1];
+                x = (x - 1.0) / (x + 1.0);
+            }
+        } else if (ix < 0x40038000) {  // |x| < 2.4375
+            hi = atanhi[2]; lo = atanlo[2];
+            x = (x - 1.5) / (1.0 + 1.5 * x);
+        } else {  // 2.4375 <= |x| < 2^66
+            hi = atanhi[3]; lo = atanlo[3];
+            x = -1.0 / x;
+        }
+    }
+    const double z = x * x;
+    const double w = z * z;
+    const double s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    const double s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (!reduced) return x - x * (s1 + s2);
+    const double r = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -r : r;
+}
+PG_DEV double pg_atan2_d(double y, double x) {
+    const double tiny = 1.0e-300, pi_o_4 = 7.8539816339744827900E-01, pi_o_2 = 1.5707963267948965580E+00, pi = 3.1415926535897931160E+00,
+                 pi_lo = 1.2246467991473531772E-16;
+    if (x != x || y != y) return x + y;
+    const int64_t bx = __builtin_bit_cast(int64_t, x), by = __builtin_bit_cast(int64_t, y);
+    const int32_t hx = (int32_t)(bx >> 32), hy = (int32_t)(by >> 32);
+    const uint32_t lx = (uint32_t)bx, ly = (uint32_t)by;
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if ((((uint32_t)hx - 0x3ff00000u) | lx) == 0) return pg_atan_d(y);  // x = 1.0
+    int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);                       // 2 * sign(x) + sign(y)
+    if ((iy | ly) == 0) {                                              // y = 0
+        if (m < 2) return y;
+        return m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if ((ix | lx) == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;  // x = 0
+    if (ix == 0x7ff00000) {                                                // x = +-inf
+        if (iy == 0x7ff00000) {
+            if (m == 0) return pi_o_4 + tiny;
+            if (m == 1) return -pi_o_4 - tiny;
+            return m == 2 ? 3.0 * pi_o_4 + tiny : -3.0 * pi_o_4 - tiny;
+        }
+        if (m == 0) return 0.0;
+        if (m == 1) return -0.0;
+        return m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7ff00000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;  // y = +-inf
+    const int32_t k = (iy - ix) >> 20;
+    double z;
+    if (k > 60) {  // |y / x| > 2^60
+        z = pi_o_2 + 0.5 * pi_lo;
+        m &= 1;
+    } else if (hx < 0 && k < -60) z = 0.0;  // 0 > |y| / x > -2^-60
+    else z = pg_atan_d(__builtin_fabs(y / x));
+    if (m == 0) return z;
+    if (m == 1) return -z;
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
+
 }  // namespace pgamd

@@ -217,6 +217,9 @@ int emu_set_state(void *h, int env, const char *data, int length) {
 void emu_atan2f_array(const float *y, const float *x, float *out, int n) {
     for (int i = 0; i < n; i++) out[i] = pg_atan2f(y[i], x[i]);
 }
+void emu_atan2d_array(const double *y, const double *x, double *out, int n) {
+    for (int i = 0; i < n; i++) out[i] = pg_atan2_d(y[i], x[i]);
+}
 int emu_error(void *h, int env) { return ((EmuVec *)h)->hdr[env].error | ((EmuVec *)h)->dev_error; }
 int emu_num_entities(void *h, int env) { return ((EmuVec *)h)->hdr[env].n_ents; }
 int emu_is_big(void *h, int env) { return ((EmuVec *)h)->hdr[env].big; }

@@ -39,3 +39,21 @@ def test_atan2f_matches_host_libm_bit_for_bit():
     both_nan = np.isnan(out) & np.isnan(ref)
     same = (out.view(np.uint32) == ref.view(np.uint32)) | both_nan
     assert same.all(), f"{(~same).sum()} of {len(y)} differ, first: y={y[~same][0]!r} x={x[~same][0]!r}"
+
+
+def test_double_atan2_narrowed_to_float_matches_host_libm():
+    """pg_atan2_d (get_theta, reference src/basic-abstract-game.cpp:233-238: float offsets promoted to double, result
+    narrowed to float): within 1 ulp of glibc's correctly rounded atan2 in double, identical after the narrowing."""
+    L = emu_harness.lib()
+    L.emu_atan2d_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.RandomState(11)
+    y = np.concatenate([rng.uniform(-64, 64, 400000), rng.uniform(-1, 1, 100000) * 1e-4, rng.uniform(-64, 64, 100000), [0.0, -0.0, 3.0, -3.0, 0.0, 1e30]])
+    x = np.concatenate([rng.uniform(-64, 64, 400000), rng.uniform(-64, 64, 100000), rng.uniform(-1, 1, 100000) * 1e-4, [1.0, -1.0, 0.0, 0.0, -0.0, -1e30]])
+    y = y.astype(np.float32).astype(np.float64)  # the game's inputs are float differences
+    x = x.astype(np.float32).astype(np.float64)
+    out = np.zeros_like(y)
+    L.emu_atan2d_array(y.ctypes.data, x.ctypes.data, out.ctypes.data, len(y))
+    ref = np.arctan2(y, x)  # numpy calls the host libm
+    assert np.array_equal(out.astype(np.float32).view(np.uint32), ref.astype(np.float32).view(np.uint32))
+    ulp = np.abs(out - ref) / np.maximum(np.spacing(np.abs(ref)), 5e-324)
+    assert ulp.max() <= 1.0
