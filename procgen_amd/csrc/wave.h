@@ -77,7 +77,6 @@ PG_DEV double pg_fabs(double x) { return fabs(x); }
 PG_DEV double pg_pow(double x, double y) { return pow(x, y); }  // glibc, as the reference
 PG_DEV double pg_sin(double x) { return sin(x); }
 PG_DEV double pg_cos(double x) { return cos(x); }
-PG_DEV double pg_atan2(double y, double x) { return atan2(y, x); }
 
 #else
 
@@ -118,7 +117,6 @@ PG_DEV double pg_fabs(double x) { return __builtin_fabs(x); }
 PG_DEV double pg_pow(double x, double y) { return pow(x, y); }
 PG_DEV double pg_sin(double x) { return sin(x); }
 PG_DEV double pg_cos(double x) { return cos(x); }
-PG_DEV double pg_atan2(double y, double x) { return atan2(y, x); }  // only feeds drawing code that truncates to pixels
 
 #endif
 
