@@ -1595,7 +1595,6 @@ struct Renderer {
         const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
         const bool use_axes = GameDrawsGrid<Game>::value && nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
         int ix_ref = 0, iy_ref = 0;
-        if (use_axes) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);
         uint64_t colseam = 0, rowseam = 0;
         phase(9);
         build_type_table();
@@ -1605,9 +1604,8 @@ struct Renderer {
         if constexpr (GameDrawsGrid<Game>::value)
             pull = use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, pull_multi, pull_nfill);
 
-#if defined(PGAMD_WAVE_EMU) && defined(PG_TRACE_PULL)
-        fprintf(stderr, "pull %d multi %d\n", (int)pull, (int)pull_multi);
-#endif
+        if (use_axes && !pull) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);  // only the per-cell path reads the axis tables
+
         phase(0);
         // ---- passes -------------------------------------------------------------------------------------------------
         for (int band = 0; band < NUM_BANDS; band++) {
