@@ -1562,7 +1562,8 @@ struct Renderer {
         phase(7);
         // common case (<= 64 entities): their commands are built once and kept in registers for all passes
         if (d.debug_flags & 4) G.n_ents = 0;
-        bool one_chunk = G.n_ents <= 64;  // or: the visible ones fit the register sets
+        const bool force_chunks = (d.debug_flags & 4096) != 0;  // test aid: every frame through draw_entities()
+        bool one_chunk = G.n_ents <= 64 && !force_chunks;  // or: the visible ones fit the register sets
         CmdRegs er[CMD_SETS];
         uint64_t ezmask[CMD_SETS][3];
         _Pragma("unroll") for (int k = 0; k < CMD_SETS; k++) {
@@ -1573,9 +1574,7 @@ struct Renderer {
             }
         }
         if (one_chunk) setup_entities(0, er[0], ezmask[0]);
-#if !defined(PG_NO_COMPACT)
-        else one_chunk = compact_entities(er, ezmask);
-#endif
+        else if (!force_chunks) one_chunk = compact_entities(er, ezmask);
         phase(8);
         int win_lx, win_hx, win_ly, win_hy;  // BAG:926-939
         if (Game::center_agent(d.opt)) {

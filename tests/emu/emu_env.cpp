@@ -120,6 +120,7 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.opt.distribution_mode = distribution_mode;
     d.opt.use_sequential_levels = use_sequential_levels;
     d.opt.debug_mode = debug_mode;
+    if (const char *dbg = getenv("PROCGEN_AMD_DEBUG")) d.debug_flags = atoi(dbg);  // e.g. 1024: renderer without the pull form (per-cell blits)
     level_seed_range(num_levels, start_level, &d.opt.level_seed_low, &d.opt.level_seed_high);
     d.hdr = v->hdr.data();
     d.rng = v->rng.data();

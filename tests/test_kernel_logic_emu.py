@@ -74,3 +74,28 @@ def test_emulated_distribution_modes_match_reference_fixture(golden_dir, game, m
     got = rollout(emu_harness.EmuEnv(n, game, rand_seed=23, distribution_mode={"easy": 0, "extreme": 2, "memory": 10}[mode]), action_stream(n, steps))
     for k in ("rew", "first", "level_seed", "crc"):
         assert np.array_equal(got[k], g[f"{game}/{mode}/{k}"]), (game, mode, k)
+
+
+@pytest.mark.parametrize("game", ["coinrun", "maze", "chaser", "miner"])
+def test_emulated_per_cell_grid_path_matches_oracle(monkeypatch, game):
+    """The renderer's per-cell blit path for grid cells (taken when a frame cannot use the pull form: adjusted rects,
+    more than four image sizes, ...) is forced for every frame (debug flag 1024) and must give the same frames."""
+    monkeypatch.setenv("PROCGEN_AMD_DEBUG", "1024")
+    n, steps = 6, 60
+    acts = action_stream(n, steps, seed=3)
+    a = rollout(oracle_env.OracleEnv(n, game, rand_seed=23), acts)
+    b = rollout(emu_harness.EmuEnv(n, game, rand_seed=23), acts)
+    assert_rollouts_equal(a, b, f"per-cell path ({game})")
+
+
+@pytest.mark.parametrize("game", ["starpilot", "fruitbot", "coinrun"])
+def test_emulated_chunked_entity_path_matches_oracle(monkeypatch, game):
+    """Frames with more visible entities than the renderer's register sets hold are drawn chunk by chunk, set up again
+    for every band and layer (draw_entities); debug flag 4096 sends every frame down that path (rotated and tiled
+    sprites included)."""
+    monkeypatch.setenv("PROCGEN_AMD_DEBUG", "4096")
+    n, steps = 6, 60
+    acts = action_stream(n, steps, seed=5)
+    a = rollout(oracle_env.OracleEnv(n, game, rand_seed=23), acts)
+    b = rollout(emu_harness.EmuEnv(n, game, rand_seed=23), acts)
+    assert_rollouts_equal(a, b, f"chunked entities ({game})")
