@@ -1675,6 +1675,7 @@ static void bag_game_step(Game *g) {
 
 static void choose_random_theme(Game *g, Ent *ent);
 static void match_aspect_ratio(Game *g, Ent *ent);
+static int hook_preserve_type_themes(const Game *g, int type);
 static void mn_game_step_tail(Game *g);
 static void sp_game_step_tail(Game *g);
 static void db_game_step_tail(Game *g);
@@ -2148,16 +2149,21 @@ static void choose_random_theme(Game *g, Ent *ent) { /* BAG:1038-1041 */
     ent->image_theme = rng_randn(&g->rand_gen, g->assets->type_num_themes[ent->image_type]);
 }
 
+/* asset_aspect_ratios[img_idx] is filled by initialize_asset_if_necessary from the image of the MASKED theme (BAG:82-86,114):
+   with restrict_themes every theme of a type has the aspect ratio of theme 0 */
+static int aspect_theme(const Game *g, const Ent *ent) {
+    return (g->opt.restrict_themes && !hook_preserve_type_themes(g, ent->image_type)) ? 0 : ent->image_theme;
+}
 static void match_aspect_ratio(Game *g, Ent *ent) { /* BAG:1014-1023 (match_width = true), aspect from BAG:114 */
     if (g->assets->type_num_themes[ent->image_type] <= ent->image_theme) fatal("asset theme out of range");
-    const Img *im = &g->assets->img[g->assets->type_theme_img[ent->image_type][ent->image_theme]];
+    const Img *im = &g->assets->img[g->assets->type_theme_img[ent->image_type][aspect_theme(g, ent)]];
     float aspect = (float)(im->w * 1.0 / im->h);
     ent->ry = ent->rx / aspect;
 }
 
 static void match_aspect_ratio_h(Game *g, Ent *ent) { /* BAG:1014-1023 (match_width = false) */
     if (g->assets->type_num_themes[ent->image_type] <= ent->image_theme) fatal("asset theme out of range");
-    const Img *im = &g->assets->img[g->assets->type_theme_img[ent->image_type][ent->image_theme]];
+    const Img *im = &g->assets->img[g->assets->type_theme_img[ent->image_type][aspect_theme(g, ent)]];
     float aspect = (float)(im->w * 1.0 / im->h);
     ent->rx = ent->ry * aspect;
 }
@@ -2205,7 +2211,7 @@ static void spawn_entities(Game *g, int num, float r, int type, float x, float y
 }
 static void fit_aspect_ratio(Game *g, Ent *ent) { /* BAG:1025-1036 */
     if (g->assets->type_num_themes[ent->image_type] <= ent->image_theme) fatal("asset theme out of range");
-    const Img *im = &g->assets->img[g->assets->type_theme_img[ent->image_type][ent->image_theme]];
+    const Img *im = &g->assets->img[g->assets->type_theme_img[ent->image_type][aspect_theme(g, ent)]];
     float ar = (float)(im->w * 1.0 / im->h);
     if (ar > 1) ent->ry = ent->rx / ar;
     else ent->rx = ent->ry * ar;

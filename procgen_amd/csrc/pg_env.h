@@ -1055,9 +1055,14 @@ struct Env {
         set_image_theme(i, randn(nt));
     }
 
+    // asset_aspect_ratios[img_idx] comes from the image of the MASKED theme (initialize_asset_if_necessary BAG:82-86,114):
+    // with restrict_themes every theme of a type has the aspect ratio of theme 0
+    PG_DEV int aspect_theme(uint32_t mm) const {
+        return (d.opt.restrict_themes && !Game::should_preserve_type_themes(meta_image_type(mm))) ? 0 : meta_image_theme(mm);
+    }
     PG_DEV void match_aspect_ratio(int i) {  // BAG:1014-1023 (match_width), aspect ratio BAG:114
         const uint32_t mm = meta(i);
-        const int img = (int)d.assets->type_theme_img[meta_image_type(mm)][meta_image_theme(mm)];
+        const int img = (int)d.assets->type_theme_img[meta_image_type(mm)][aspect_theme(mm)];
         if (img < 0) {
             fail(PGE_THEME);
             return;
@@ -1069,7 +1074,7 @@ struct Env {
 
     PG_DEV void fit_aspect_ratio(int i) {  // BAG:1025-1036
         const uint32_t mm = meta(i);
-        const int img = (int)d.assets->type_theme_img[meta_image_type(mm)][meta_image_theme(mm)];
+        const int img = (int)d.assets->type_theme_img[meta_image_type(mm)][aspect_theme(mm)];
         if (img < 0) {
             fail(PGE_THEME);
             return;
@@ -1191,7 +1196,7 @@ struct Env {
 
     PG_DEV void match_aspect_ratio_h(int i) {  // BAG:1014-1023 (match_width = false)
         const uint32_t mm = meta(i);
-        const int img = (int)d.assets->type_theme_img[meta_image_type(mm)][meta_image_theme(mm)];
+        const int img = (int)d.assets->type_theme_img[meta_image_type(mm)][aspect_theme(mm)];
         if (img < 0) {
             fail(PGE_THEME);
             return;

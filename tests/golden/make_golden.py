@@ -12,6 +12,8 @@ Fixtures (npz, small):
                        table / grid / key scalars parsed from get_state at a few checkpoints.
   mode_matrix.npz    : (`make_golden.py modes`) every accepted (game, distribution_mode) pair besides the default:
                        rew / first / level_seed / frame CRC32 of 6 envs x 100 steps.
+  option_matrix.npz  : (`make_golden.py options`) 7 option sets x 16 games (rand_seed=7, actions RandomState(1)): the same
+                       four arrays for 6 envs x 60 steps.
   <game>_seeding.npz : reference procgen/env_test.py:7-30 (num_levels=1, start_level in {0,1}): first frames after
                        one step of action 0.
 """
@@ -113,7 +115,49 @@ def mode_matrix(n=6, t_steps=100):
     return res
 
 
+# the option surface of reference src/game.cpp:42-75 that changes frames or level selection, on every game
+OPTION_SETS = {
+    "no_backgrounds": dict(use_backgrounds=False),
+    "no_center_agent": dict(center_agent=False),
+    "restrict_themes": dict(restrict_themes=True),
+    "two_levels": dict(num_levels=2, start_level=5),
+    "sequential_levels": dict(use_sequential_levels=True, num_levels=3),
+    "monochrome": dict(use_monochrome_assets=True),
+    "vel_info": dict(paint_vel_info=True),
+}
+ALL_GAMES = ["bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot", "heist", "jumper", "leaper", "maze", "miner", "ninja",
+             "plunder", "starpilot"]
+
+
+def option_matrix(n=6, t_steps=60):
+    """<game>/<option set>/{rew, first, level_seed, crc}; jumper without center_agent is left out (its compass then lies on a
+    non-integer rect, drawn by Qt's path engine: refused by the oracle and the HIP stepper alike)."""
+    res = {}
+    for game in ALL_GAMES:
+        for name, kw in OPTION_SETS.items():
+            if game == "jumper" and name == "no_center_agent":
+                continue
+            env = ref_env.make_ref_env(n, game, rand_seed=7, **kw)
+            rng = np.random.RandomState(1)
+            out = {k: [] for k in ("rew", "first", "level_seed", "crc")}
+            for t in range(t_steps + 1):
+                rew, ob, first = env.observe()
+                out["rew"].append(rew.copy())
+                out["first"].append(first.astype(np.uint8))
+                out["level_seed"].append(env.info_arrays()["level_seed"].copy())
+                out["crc"].append(np.array([zlib.crc32(ob["rgb"][e].tobytes()) for e in range(n)], dtype=np.uint32))
+                env.act(rng.randint(0, 15, size=(n,), dtype=np.int32))
+            env.close()
+            for k, v in out.items():
+                res[f"{game}/{name}/{k}"] = np.array(v)
+    return res
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["options"]:
+        np.savez_compressed(os.path.join(HERE, "option_matrix.npz"), **option_matrix())
+        print("option matrix done")
+        sys.exit(0)
     if sys.argv[1:] == ["modes"]:
         np.savez_compressed(os.path.join(HERE, "mode_matrix.npz"), **mode_matrix())
         print("mode matrix done")

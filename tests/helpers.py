@@ -53,3 +53,25 @@ def hip_memcpy_dtoh(dev_ptr, nbytes):
     rc = hip.hipMemcpy(C.c_void_p(buf.ctypes.data), C.c_void_p(dev_ptr), C.c_size_t(nbytes), C.c_int(2))
     assert rc == 0, f"hipMemcpy failed: {rc}"
     return buf
+
+
+# tests/golden/option_matrix.npz (make_golden.py options): option sets by name
+OPTION_SETS = {
+    "no_backgrounds": dict(use_backgrounds=False),
+    "no_center_agent": dict(center_agent=False),
+    "restrict_themes": dict(restrict_themes=True),
+    "two_levels": dict(num_levels=2, start_level=5),
+    "sequential_levels": dict(use_sequential_levels=True, num_levels=3),
+    "monochrome": dict(use_monochrome_assets=True),
+    "vel_info": dict(paint_vel_info=True),
+}
+
+
+def check_against_option_matrix(g, make, pairs):
+    """make(game, n, **options) -> env; compares rew / first / level_seed / frame CRCs with the fixture for the given (game, set) pairs."""
+    for game, name in pairs:
+        n = g[f"{game}/{name}/rew"].shape[1]
+        steps = g[f"{game}/{name}/rew"].shape[0] - 1
+        got = rollout(make(game, n, **OPTION_SETS[name]), action_stream(n, steps, seed=1))
+        for k in ("rew", "first", "level_seed", "crc"):
+            assert np.array_equal(got[k], g[f"{game}/{name}/{k}"]), (game, name, k)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle_env
-from helpers import HIP_LIB, action_stream, assert_rollouts_equal, hip_memcpy_dtoh, rollout
+from helpers import HIP_LIB, action_stream, assert_rollouts_equal, check_against_option_matrix, hip_memcpy_dtoh, rollout
 
 pytestmark = pytest.mark.gpu
 
@@ -212,6 +212,14 @@ def test_every_distribution_mode_matches_reference_fixture(golden_dir):
         got = rollout(make_env(n, game, distribution_mode=mode), action_stream(n, steps))
         for k in ("rew", "first", "level_seed", "crc"):
             assert np.array_equal(got[k], g[f"{game}/{mode}/{k}"]), (game, mode, k)
+
+
+def test_option_surface_of_every_game_matches_reference_fixture(golden_dir):
+    """7 option sets x 16 games against tests/golden/option_matrix.npz (compiled reference)."""
+    g = np.load(os.path.join(golden_dir, "option_matrix.npz"))
+    pairs = sorted({tuple(k.split("/")[:2]) for k in g.files})
+    assert len(pairs) == 16 * 7 - 1
+    check_against_option_matrix(g, lambda game, n, **kw: make_env(n, game, rand_seed=7, **kw), pairs)
 
 
 def test_bigfish_full_size_prefix_matches_oracle():

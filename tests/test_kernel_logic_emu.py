@@ -10,7 +10,7 @@ import pytest
 
 import emu_harness
 import oracle_env
-from helpers import action_stream, assert_rollouts_equal, rollout
+from helpers import action_stream, assert_rollouts_equal, check_against_option_matrix, rollout
 
 
 @pytest.mark.parametrize("game,use_small", [("coinrun", True), ("coinrun", False), ("bigfish", True), ("maze", True), ("climber", True), ("miner", True), ("starpilot", True), ("fruitbot", True), ("leaper", True), ("plunder", True), ("heist", True), ("ninja", True), ("dodgeball", True), ("bossfight", True), ("chaser", True), ("caveflyer", True), ("jumper", True)])
@@ -99,3 +99,12 @@ def test_emulated_chunked_entity_path_matches_oracle(monkeypatch, game):
     a = rollout(oracle_env.OracleEnv(n, game, rand_seed=23), acts)
     b = rollout(emu_harness.EmuEnv(n, game, rand_seed=23), acts)
     assert_rollouts_equal(a, b, f"chunked entities ({game})")
+
+
+def test_emulated_option_surface_matches_reference_fixture(golden_dir):
+    """A spread of (game, option set) pairs of tests/golden/option_matrix.npz through the emulated kernels (the GPU suite runs all)."""
+    g = np.load(os.path.join(golden_dir, "option_matrix.npz"))
+    pairs = [("bigfish", "restrict_themes"), ("bossfight", "restrict_themes"), ("fruitbot", "restrict_themes"), ("heist", "restrict_themes"),
+             ("plunder", "restrict_themes"), ("maze", "no_backgrounds"), ("starpilot", "no_backgrounds"), ("climber", "no_center_agent"),
+             ("ninja", "two_levels"), ("miner", "sequential_levels"), ("dodgeball", "monochrome"), ("caveflyer", "monochrome"), ("leaper", "vel_info")]
+    check_against_option_matrix(g, lambda game, n, **kw: emu_harness.EmuEnv(n, game, rand_seed=7, **kw), pairs)

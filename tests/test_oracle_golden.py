@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_env
-from helpers import action_stream, assert_rollouts_equal, rollout
+from helpers import action_stream, assert_rollouts_equal, check_against_option_matrix, rollout
 
 
 GAMES = ["coinrun", "bigfish", "maze", "climber", "miner", "starpilot", "fruitbot", "leaper", "plunder", "heist", "ninja", "dodgeball", "bossfight", "chaser", "caveflyer", "jumper"]
@@ -98,3 +98,13 @@ def test_oracle_matches_reference_in_every_distribution_mode(golden_dir):
         got = rollout(oracle_env.OracleEnv(n, game, rand_seed=23, distribution_mode=MODE_IDS[mode]), action_stream(n, steps))
         for k in ("rew", "first", "level_seed", "crc"):
             assert np.array_equal(got[k], g[f"{game}/{mode}/{k}"]), (game, mode, k)
+
+
+def test_oracle_matches_reference_on_the_option_surface(golden_dir):
+    """tests/golden/option_matrix.npz (compiled reference): 7 option sets x 16 games.  restrict_themes also masks the theme
+    the aspect ratio of an entity comes from (reference src/basic-abstract-game.cpp:82-86,114), which moves bigfish /
+    bossfight / fruitbot physics."""
+    g = np.load(os.path.join(golden_dir, "option_matrix.npz"))
+    pairs = sorted({tuple(k.split("/")[:2]) for k in g.files})
+    assert len(pairs) == 16 * 7 - 1
+    check_against_option_matrix(g, lambda game, n, **kw: oracle_env.OracleEnv(n, game, rand_seed=7, **kw), pairs)
