@@ -16,6 +16,7 @@ struct FruitBot : BagDefaults<FruitBot> {
     static constexpr bool USES_TILED_ENTITIES = true;
     // 10 walls x 2 barriers + doors and locks + 20 presents + <= 19 good + <= 19 bad + agent + <= 2 bullets
     static constexpr int ENT_CAP_T0 = 96, ENT_CAP_T1 = 112, ENT_CAP_T2 = 128;
+    static constexpr bool TILED_BACKGROUND = true;  // bg_tile_ratio = -1 (fruitbot.cpp:41)
     static constexpr int WIDE_ROWS = 8;  // half-band fetch batches: the renderer stays under 168 VGPRs (three waves per SIMD)
     static constexpr int RENDER_CMD_SETS = 2;  // frames with more than 64 visible entities are common
     template <class E>

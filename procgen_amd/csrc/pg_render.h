@@ -93,6 +93,15 @@ template <class Game>
 struct GameWideRows<Game, decltype((void)Game::WIDE_ROWS)> {
     static constexpr int value = Game::WIDE_ROWS;
 };
+// the game draws its background as a column of tiles (bg_tile_ratio < 0 in its constructor; fruitbot)
+template <class Game, class = void>
+struct GameTiledBackground {
+    static constexpr bool value = false;
+};
+template <class Game>
+struct GameTiledBackground<Game, decltype((void)Game::TILED_BACKGROUND)> {
+    static constexpr bool value = Game::TILED_BACKGROUND;
+};
 template <class Game, class = void>
 struct GameUsesTiledEntities {
     static constexpr bool value = false;
@@ -1513,6 +1522,10 @@ struct Renderer {
         uint32_t bg_geom[MAXBG] = {0, 0, 0}, bg_basex[MAXBG] = {0, 0, 0}, bg_srcy[MAXBG] = {0, 0, 0}, bg_ix[MAXBG] = {0, 0, 0}, bg_iy[MAXBG] = {0, 0, 0}, bg_src[MAXBG] = {0, 0, 0},
                  bg_aux[MAXBG] = {0, 0, 0};
         int nbg = 0;
+        bool bgt_many = false;  // tiled background with more tiles on screen than the register slots above
+        double bgt_x = 0, bgt_y = 0, bgt_w = 0;
+        float bgt_h = 0;
+        int bgt_ia = 0, bgt_ib = 0, bgt_img = 0;
         auto add_bg = [&](int bgi, const RectD &rc) {
             uint32_t g, bx, sy, ix, iy, sr, au;
             cmd_image(bgi, false, rc, 1.0f, g, bx, sy, ix, iy, sr, au);
@@ -1543,7 +1556,23 @@ struct Renderer {
                 const float tile_height = (float)(main_rect.h / num_tiles);
                 const float tile_width = (float)main_rect.w;
                 const int i0 = (int)pg_floor(-main_rect.y / (double)tile_height) - 1;
-                for (int i = i0; i < i0 + 4; i++) {
+                if constexpr (GameTiledBackground<Game>::value) {
+                    int ia = i0 < 0 ? 0 : i0, ib = (int)pg_ceil(((double)RES_H - main_rect.y) / (double)tile_height) + 1;
+                    if (ib > num_tiles) ib = num_tiles;
+                    if (ib - ia > 4) {
+                        // a tall world shown whole (fruitbot without center_agent): a dozen tiles on screen.  Their commands
+                        // are set up lane-parallel in every band pass instead of living in registers across the passes.
+                        bgt_many = true;
+                        bgt_x = main_rect.x;
+                        bgt_y = main_rect.y;
+                        bgt_w = (double)tile_width;
+                        bgt_h = tile_height;
+                        bgt_ia = ia;
+                        bgt_ib = ib;
+                        bgt_img = bgi;
+                    }
+                }
+                for (int i = i0; i < i0 + 4 && !bgt_many; i++) {
                     if (i < 0 || i >= num_tiles) continue;
                     const RectD tr = {main_rect.x, main_rect.y + (double)(tile_height * i), (double)tile_width, (double)tile_height};
                     add_bg(bgi, tr);
@@ -1614,9 +1643,31 @@ struct Renderer {
                 PG_FOR_LANES(l) { fb[base + l] = 0xff000000u; }  // p.fillRect(rect, QColor(0,0,0))
             }
             PG_SYNC();
-            for (int k = 0; k < nbg; k++) {
-                const DrawCmd bc = unpack(bg_geom[k], bg_basex[k], bg_srcy[k], bg_ix[k], bg_iy[k], bg_src[k], bg_aux[k]);
-                if (bc.ty1 < row1 && bc.ty1 + bc.h > row0) exec_large(bc);
+            {
+                // background commands of this pass: the frame's register slots, or -- with more tiles on screen than slots --
+                // the tiles that can touch these rows, each set up here (wave-uniform) and fed to the same blit
+                int bg_first = 0, bg_count = nbg;
+                if constexpr (GameTiledBackground<Game>::value) {
+                    if (bgt_many) {
+                        bg_first = (int)pg_floor(((double)row0 - bgt_y) / (double)bgt_h) - 1;
+                        int last = (int)pg_ceil(((double)row1 - bgt_y) / (double)bgt_h) + 1;
+                        if (bg_first < bgt_ia) bg_first = bgt_ia;
+                        if (last > bgt_ib) last = bgt_ib;
+                        bg_count = last - bg_first;
+                    }
+                }
+                for (int k = 0; k < bg_count; k++) {
+                    uint32_t g = bg_geom[k < MAXBG ? k : 0], bx = bg_basex[k < MAXBG ? k : 0], sy = bg_srcy[k < MAXBG ? k : 0], ix = bg_ix[k < MAXBG ? k : 0],
+                             iy = bg_iy[k < MAXBG ? k : 0], sr = bg_src[k < MAXBG ? k : 0], au = bg_aux[k < MAXBG ? k : 0];
+                    if constexpr (GameTiledBackground<Game>::value) {
+                        if (bgt_many) {
+                            const RectD tr = {bgt_x, bgt_y + (double)(bgt_h * (bg_first + k)), bgt_w, (double)bgt_h};
+                            cmd_image(bgt_img, false, tr, 1.0f, g, bx, sy, ix, iy, sr, au);
+                        }
+                    }
+                    const DrawCmd bc = unpack(g, bx, sy, ix, iy, sr, au);
+                    if (g != 0 && bc.ty1 < row1 && bc.ty1 + bc.h > row0) exec_large(bc);
+                }
             }
             phase(1);
             if (one_chunk) {

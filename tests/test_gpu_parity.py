@@ -222,6 +222,15 @@ def test_option_surface_of_every_game_matches_reference_fixture(golden_dir):
     check_against_option_matrix(g, lambda game, n, **kw: make_env(n, game, rand_seed=7, **kw), pairs)
 
 
+def test_tall_world_shown_whole_draws_every_background_tile():
+    """fruitbot, easy mode, center_agent=False: a dozen background tiles on screen at once (see the emulation test of the same name)."""
+    n, steps = 8, 60
+    acts = action_stream(n, steps, seed=2)
+    a = rollout(oracle_env.OracleEnv(n, "fruitbot", rand_seed=3, distribution_mode=0, center_agent=False), acts)
+    b = rollout(make_env(n, "fruitbot", rand_seed=3, distribution_mode="easy", center_agent=False), acts)
+    assert_rollouts_equal(a, b, "fruitbot easy, not centred")
+
+
 def test_bigfish_full_size_prefix_matches_oracle():
     """BASELINE configs[2] (bigfish, 65536 envs): the first 128 envs equal a 128-env oracle run."""
     n, steps, m = 65536, 10, 128

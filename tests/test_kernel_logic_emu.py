@@ -108,3 +108,13 @@ def test_emulated_option_surface_matches_reference_fixture(golden_dir):
              ("plunder", "restrict_themes"), ("maze", "no_backgrounds"), ("starpilot", "no_backgrounds"), ("climber", "no_center_agent"),
              ("ninja", "two_levels"), ("miner", "sequential_levels"), ("dodgeball", "monochrome"), ("caveflyer", "monochrome"), ("leaper", "vel_info")]
     check_against_option_matrix(g, lambda game, n, **kw: emu_harness.EmuEnv(n, game, rand_seed=7, **kw), pairs)
+
+
+def test_emulated_tall_world_shown_whole_draws_every_background_tile():
+    """fruitbot, easy mode, center_agent=False: the 10 x 60 world is scaled into the frame and a dozen background tiles
+    (tile_image, reference src/basic-abstract-game.cpp:840-869,999) are on screen at once."""
+    n, steps = 4, 50
+    acts = action_stream(n, steps, seed=2)
+    a = rollout(oracle_env.OracleEnv(n, "fruitbot", rand_seed=3, distribution_mode=0, center_agent=False), acts)
+    b = rollout(emu_harness.EmuEnv(n, "fruitbot", rand_seed=3, distribution_mode=0, center_agent=False), acts)
+    assert_rollouts_equal(a, b, "fruitbot easy, not centred")
