@@ -118,3 +118,23 @@ def test_emulated_tall_world_shown_whole_draws_every_background_tile():
     a = rollout(oracle_env.OracleEnv(n, "fruitbot", rand_seed=3, distribution_mode=0, center_agent=False), acts)
     b = rollout(emu_harness.EmuEnv(n, "fruitbot", rand_seed=3, distribution_mode=0, center_agent=False), acts)
     assert_rollouts_equal(a, b, "fruitbot easy, not centred")
+
+
+def _actions_with_forced_resets(n, steps, seed):
+    rng = np.random.RandomState(seed)
+    acts = []
+    for _ in range(steps):
+        a = rng.randint(0, 15, size=(n,), dtype=np.int32)
+        a[rng.rand(n) < 0.05] = -1  # Game::step: action -1 forces a reset (reference src/game.cpp:123-127)
+        acts.append(a)
+    return acts
+
+
+@pytest.mark.parametrize("game", ["coinrun", "maze", "starpilot"])
+def test_emulated_forced_reset_action(game):
+    n, steps = 6, 100
+    acts = _actions_with_forced_resets(n, steps, 4)
+    a = rollout(oracle_env.OracleEnv(n, game, rand_seed=23), acts)
+    b = rollout(emu_harness.EmuEnv(n, game, rand_seed=23), acts)
+    assert_rollouts_equal(a, b, f"forced resets ({game})")
+    assert a["first"][1:].sum() > 10
