@@ -231,22 +231,6 @@ def test_tall_world_shown_whole_draws_every_background_tile():
     assert_rollouts_equal(a, b, "fruitbot easy, not centred")
 
 
-@pytest.mark.parametrize("game", ["coinrun", "maze", "starpilot"])
-def test_forced_reset_action(game):
-    """action -1 forces a reset (reference src/game.cpp:123-127)."""
-    n, steps = 32, 120
-    rng = np.random.RandomState(4)
-    acts = []
-    for _ in range(steps):
-        a = rng.randint(0, 15, size=(n,), dtype=np.int32)
-        a[rng.rand(n) < 0.05] = -1
-        acts.append(a)
-    a = rollout(oracle_env.OracleEnv(n, game, rand_seed=23), acts)
-    b = rollout(make_env(n, game), acts)
-    assert_rollouts_equal(a, b, f"forced resets ({game})")
-    assert a["first"][1:].sum() > 50
-
-
 def test_bigfish_full_size_prefix_matches_oracle():
     """BASELINE configs[2] (bigfish, 65536 envs): the first 128 envs equal a 128-env oracle run."""
     n, steps, m = 65536, 10, 128
@@ -286,3 +270,19 @@ def test_state_protocol_through_the_c_abi(golden_dir, game):
     import zlib
 
     assert [zlib.crc32(ob["rgb"][e].tobytes()) for e in range(2)] == list(g["crc"][130, :2])
+
+
+@pytest.mark.parametrize("game", ["coinrun", "maze", "starpilot"])
+def test_forced_reset_action(game):
+    """action -1 forces a reset (reference src/game.cpp:123-127)."""
+    n, steps = 32, 120
+    rng = np.random.RandomState(4)
+    acts = []
+    for _ in range(steps):
+        a = rng.randint(0, 15, size=(n,), dtype=np.int32)
+        a[rng.rand(n) < 0.05] = -1
+        acts.append(a)
+    a = rollout(oracle_env.OracleEnv(n, game, rand_seed=23), acts)
+    b = rollout(make_env(n, game), acts)
+    assert_rollouts_equal(a, b, f"forced resets ({game})")
+    assert a["first"][1:].sum() > 50
