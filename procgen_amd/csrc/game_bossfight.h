@@ -4,6 +4,7 @@
 // colliders of the entity-entity pass, shields reflect bullets, rounds switch attack modes.
 #pragma once
 #include "pg_game_defaults.h"
+#include "pg_math.h"
 
 namespace pgamd {
 
@@ -105,8 +106,8 @@ struct BossFight : BagDefaults<BossFight> {
                 if (BF_SHIELDS_UP(G)) {
                     e.meta(src) = (e.meta(src) & ~M_TYPE_MASK) | (uint32_t)REFLECTED_BULLET;
                     const float theta = (float)((double)PG_PI * (1.25 + .5 * (double)BF_RAND_PCT(G)));
-                    e.evy(src) = (float)(1 * pg_sin((double)theta) * .5);
-                    e.evx(src) = (float)(1 * pg_cos((double)theta) * .5);
+                    e.evy(src) = (float)(1 * pg_sin_d((double)theta) * .5);
+                    e.evx(src) = (float)(1 * pg_cos_d((double)theta) * .5);
                     e.ei(EF_EXPIRE_TIME, src) = 4;
                     e.ei(EF_LIFE_TIME, src) = 0;
                     e.ef(EF_ALPHA_DECAY, src) = 0.8f;
@@ -215,7 +216,7 @@ struct BossFight : BagDefaults<BossFight> {
 
     template <class E>
     PG_DEV static void boss_fire(E &e, int boss, float bullet_r, float vel, float theta) {  // bossfight.cpp:264-269
-        const int b = e.add_entity(e.ex(boss), e.ey(boss), (float)((double)vel * pg_cos((double)theta)), (float)((double)vel * pg_sin((double)theta)), bullet_r, ENEMY_BULLET);
+        const int b = e.add_entity(e.ex(boss), e.ey(boss), (float)((double)vel * pg_cos_d((double)theta)), (float)((double)vel * pg_sin_d((double)theta)), bullet_r, ENEMY_BULLET);
         e.set_image_theme(b, boss_laser_theme(e.G));
         e.ei(EF_EXPIRE_TIME, b) = 50;
         e.ef(EF_VROT, b) = PG_PI / 8;

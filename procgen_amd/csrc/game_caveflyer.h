@@ -93,7 +93,7 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
         float acceleration = (float)(move_action % 3 - 1);
         if (acceleration < 0) acceleration *= 0.33f;
         const float theta = -1 * e.ef(EF_ROTATION, ag) + PG_PI / 2;
-        const double ct = pg_cos((double)theta), st = pg_sin((double)theta);
+        const double ct = pg_cos_d((double)theta), st = pg_sin_d((double)theta);
         if (acceleration > 0) {
             const float arx = e.erx(ag), ary = e.ery(ag);
             const int x = e.add_entity((float)((double)e.ex(ag) - (double)arx * ct), (float)((double)e.ey(ag) - (double)ary * st), 0, 0, (float)(.5 * (double)arx), EXHAUST);
@@ -238,8 +238,8 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
         if (G.special_action == 1) {
             const int ag = G.agent;
             const float theta = -1 * e.ef(EF_ROTATION, ag) + PG_PI / 2;
-            const float vx = (float)pg_cos((double)theta);
-            const float vy = (float)pg_sin((double)theta);
+            const float vx = (float)pg_cos_d((double)theta);
+            const float vy = (float)pg_sin_d((double)theta);
             const int b = e.add_entity_rxy(e.ex(ag), e.ey(ag), vx, vy, 0.1f, 0.25f, PLAYER_BULLET);
             e.ei(EF_EXPIRE_TIME, b) = 10;
             e.ef(EF_ROTATION, b) = e.ef(EF_ROTATION, ag);

@@ -356,7 +356,7 @@ struct Jumper : BagDefaults<Jumper> {
         const float cy = (float)(cr_.y + cr_.h / 2);
         const float cr = (float)(cr_.w / 2 * .95);
         const float theta = (float)pg_atan2_d((double)(r.ey(goal) - r.ey(ag)), (double)(r.ex(goal) - r.ex(ag)));  // get_theta BAG:233-238
-        r.exec_line((int)cx, (int)cy, (int)((double)cx + (double)cr * pg_cos((double)theta)), (int)((double)cy - (double)cr * pg_sin((double)theta)), 0xfffcba03u);
+        r.exec_line((int)cx, (int)cy, (int)((double)cx + (double)cr * pg_cos_d((double)theta)), (int)((double)cy - (double)cr * pg_sin_d((double)theta)), 0xfffcba03u);
         const float ddx = r.ex(ag) - r.ex(goal), ddy = r.ey(ag) - r.ey(goal);
         const float dist = (float)pg_sqrt((double)(ddx * ddx + ddy * ddy));  // get_distance BAG:133-143
         const float dist_pct = (float)((double)dist / (G.main_width * pg_sqrt(2.0)));

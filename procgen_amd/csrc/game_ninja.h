@@ -3,6 +3,7 @@
 // cells, and throwing stars: smart_step projectiles that stick to walls and detonate bombs.
 #pragma once
 #include "pg_game_defaults.h"
+#include "pg_math.h"
 
 namespace pgamd {
 
@@ -243,7 +244,7 @@ struct Ninja : BagDefaults<Ninja> {
             else if (G.special_action == 3) theta = PG_PI / 2;
             else if (G.special_action == 4) theta = -1 * PG_PI / 4;
             if (e.eflag(ag, MF_REFLECTED)) theta = PG_PI - theta;
-            const int b = e.add_entity(e.ex(ag), e.ey(ag), (float)((double)bullet_vel * pg_cos((double)theta)), (float)((double)bullet_vel * pg_sin((double)theta)), (float).25, THROWING_STAR);
+            const int b = e.add_entity(e.ex(ag), e.ey(ag), (float)((double)bullet_vel * pg_cos_d((double)theta)), (float)((double)bullet_vel * pg_sin_d((double)theta)), (float).25, THROWING_STAR);
             e.set_flag(b, MF_COLLIDES, true);
             e.ei(EF_EXPIRE_TIME, b) = 15;
             e.set_flag(b, MF_SMART_STEP, true);

@@ -233,8 +233,8 @@ struct StarPilot {
                     fire_time = e.randint(20, 30);
                 }
                 v_scale *= V_SCALE;
-                float vx = (float)(-1 * pg_cos((double)theta) * (double)v_scale);
-                const float vy = (float)(pg_sin((double)theta) * (double)v_scale);
+                float vx = (float)(-1 * pg_cos_d((double)theta) * (double)v_scale);
+                const float vy = (float)(pg_sin_d((double)theta) * (double)v_scale);
                 bool spawn_right = true;
                 float x_pos;
                 if (type == FLYER || type == FAST_FLYER) {
@@ -490,9 +490,9 @@ struct StarPilot {
             const float bullet_r = hp_bullet_r(dm);
             const float theta = G.special_action == 2 ? PG_PI : 0;
             const float v_scale = hp_vs(dm, BULLET_PLAYER) * V_SCALE;
-            const float vx = (float)(pg_cos((double)theta) * (double)v_scale);
-            const float vy = (float)(pg_sin((double)theta) * (double)v_scale);
-            const float x_off = (float)((double)e.erx(ag) * pg_cos((double)theta));
+            const float vx = (float)(pg_cos_d((double)theta) * (double)v_scale);
+            const float vy = (float)(pg_sin_d((double)theta) * (double)v_scale);
+            const float x_off = (float)((double)e.erx(ag) * pg_cos_d((double)theta));
             const int b = e.add_entity(e.ex(ag) + x_off, e.ey(ag), vx, vy, bullet_r, BULLET_PLAYER);
             e.set_flag(b, MF_COLLIDES, true);
             face_direction(e, b, vx, vy, 0);

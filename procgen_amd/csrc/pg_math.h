@@ -192,4 +192,99 @@ PG_DEV double pg_atan2_d(double y, double x) {
     return (z - pi_lo) - pi;
 }
 
+// Double precision sin / cos (rotated sprites' QTransform, bullet and thrust directions in bossfight / caveflyer / ninja /
+// starpilot, jumper's compass): the published fdlibm algorithm (k_sin.c, k_cos.c, the Cody-Waite part of e_rem_pio2.c),
+// error < 1 ulp like the device libm's -- but the same IEEE operations on the host and on the GPU, so the CPU tests
+// (tests/emu) exercise exactly the arithmetic the kernels run, and several VGPRs lighter than the library routines.
+// Every result is narrowed to float or truncated to a pixel / 16.16 coefficient by its caller; glibc's sin / cos are
+// correctly rounded in nearly all cases, so the two differ after the narrowing about once in 2^29 calls.
+// Domain: |x| <= 2^19 * pi/2 (8.2e5 rad; rotations are a few thousand rad at most); beyond it the reduction below loses
+// accuracy gracefully instead of running the Payne-Hanek path.
+PG_DEV double pg_ksin_d(double x, double y, bool have_tail) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const int32_t ix = (int32_t)(__builtin_bit_cast(int64_t, x) >> 32) & 0x7fffffff;
+    if (ix < 0x3e400000 && (int)x == 0) return x;  // |x| < 2^-27
+    const double z = x * x;
+    const double v = z * x;
+    const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    if (!have_tail) return x + v * (S1 + z * r);
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+PG_DEV double pg_kcos_d(double x, double y) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const int32_t ix = (int32_t)(__builtin_bit_cast(int64_t, x) >> 32) & 0x7fffffff;
+    if (ix < 0x3e400000 && (int)x == 0) return 1.0;  // |x| < 2^-27
+    const double z = x * x;
+    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    if (ix < 0x3FD33333) return 1.0 - (0.5 * z - (z * r - x * y));  // |x| < 0.3
+    const double qx = ix > 0x3fe90000 ? 0.28125 : __builtin_bit_cast(double, (int64_t)(ix - 0x00200000) << 32);  // x / 4
+    const double hz = 0.5 * z - qx;
+    const double a = 1.0 - qx;
+    return a - (hz - (z * r - x * y));
+}
+// x = n * pi/2 + (y0 + y1), |y0 + y1| <= pi/4; returns n mod 4 as a non-negative residue
+PG_DEV int pg_rem_pio2_d(double x, double &y0, double &y1) {
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11,
+                 pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21, pio2_3 = 2.02226624871116645580e-21,
+                 pio2_3t = 8.47842766036889956997e-32;
+    const int32_t hx = (int32_t)(__builtin_bit_cast(int64_t, x) >> 32);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix <= 0x3fe921fb) {  // |x| <= pi/4
+        y0 = x;
+        y1 = 0;
+        return 0;
+    }
+    const double t0 = __builtin_fabs(x);
+    const int n = (int)(t0 * invpio2 + 0.5);
+    const double fn = (double)n;
+    double r = t0 - fn * pio2_1;
+    double w = fn * pio2_1t;  // first round, good to 85 bits
+    const int j = ix >> 20;
+    y0 = r - w;
+    int i = j - (((int32_t)(__builtin_bit_cast(int64_t, y0) >> 32) >> 20) & 0x7ff);
+    if (i > 16) {  // cancellation: second round, good to 118 bits
+        double t = r;
+        w = fn * pio2_2;
+        r = t - w;
+        w = fn * pio2_2t - ((t - r) - w);
+        y0 = r - w;
+        i = j - (((int32_t)(__builtin_bit_cast(int64_t, y0) >> 32) >> 20) & 0x7ff);
+        if (i > 49) {  // third round, 151 bits
+            t = r;
+            w = fn * pio2_3;
+            r = t - w;
+            w = fn * pio2_3t - ((t - r) - w);
+            y0 = r - w;
+        }
+    }
+    y1 = (r - y0) - w;
+    if (hx < 0) {
+        y0 = -y0;
+        y1 = -y1;
+        return (-n) & 3;
+    }
+    return n & 3;
+}
+PG_DEV double pg_sin_d(double x) {
+    if (!(__builtin_fabs(x) <= 1.7976931348623157e308)) return x - x;  // inf / NaN
+    double y0, y1;
+    const int n = pg_rem_pio2_d(x, y0, y1);
+    const bool tail = !(y1 == 0 && y0 == x);
+    if (n == 0) return pg_ksin_d(y0, y1, tail);
+    if (n == 1) return pg_kcos_d(y0, y1);
+    if (n == 2) return -pg_ksin_d(y0, y1, true);
+    return -pg_kcos_d(y0, y1);
+}
+PG_DEV double pg_cos_d(double x) {
+    if (!(__builtin_fabs(x) <= 1.7976931348623157e308)) return x - x;
+    double y0, y1;
+    const int n = pg_rem_pio2_d(x, y0, y1);
+    if (n == 0) return pg_kcos_d(y0, y1);
+    if (n == 1) return -pg_ksin_d(y0, y1, true);
+    if (n == 2) return -pg_kcos_d(y0, y1);
+    return pg_ksin_d(y0, y1, true);
+}
+
 }  // namespace pgamd

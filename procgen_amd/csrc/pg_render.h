@@ -16,6 +16,7 @@
 // per lane of a large one) are issued before the first blend so that several HBM/L2 round trips overlap.
 #pragma once
 #include "pg_env.h"
+#include "pg_math.h"
 
 namespace pgamd {
 
@@ -292,8 +293,8 @@ struct Renderer {
         else if (a == 180.) cosa = -1.;
         else {
             const double b = 0.017453292519943295769 * a;
-            sina = pg_sin(b);
-            cosa = pg_cos(b);
+            sina = pg_sin_d(b);
+            cosa = pg_cos_d(b);
         }
         const double m11 = cosa, m12 = sina, m21 = -sina, m22 = cosa;
         if (q_fuzzy_is_null(m12) && q_fuzzy_is_null(m21)) {  // TxScale or below: qt_mapRect_non_normalizing + scale path

@@ -75,8 +75,6 @@ PG_DEV float pg_fabsf(float x) { return fabsf(x); }
 PG_DEV float pg_roundf(float x) { return roundf(x); }
 PG_DEV double pg_fabs(double x) { return fabs(x); }
 PG_DEV double pg_pow(double x, double y) { return pow(x, y); }  // glibc, as the reference
-PG_DEV double pg_sin(double x) { return sin(x); }
-PG_DEV double pg_cos(double x) { return cos(x); }
 
 #else
 
@@ -113,10 +111,8 @@ PG_DEV double pg_ceil(double x) { return __builtin_ceil(x); }
 PG_DEV float pg_fabsf(float x) { return __builtin_fabsf(x); }
 PG_DEV float pg_roundf(float x) { return __builtin_roundf(x); }  // half away from zero, as C roundf
 PG_DEV double pg_fabs(double x) { return __builtin_fabs(x); }
-// ROCm device libm (OCML), < 1 ulp in double; callers narrow the result to float (bit-exactness notes)
+// ROCm device libm (OCML), < 1 ulp in double; the caller narrows the result to float (bit-exactness notes); sin / cos / atan2 are restated in pg_math.h
 PG_DEV double pg_pow(double x, double y) { return pow(x, y); }
-PG_DEV double pg_sin(double x) { return sin(x); }
-PG_DEV double pg_cos(double x) { return cos(x); }
 
 #endif
 

@@ -221,6 +221,12 @@ void emu_atan2f_array(const float *y, const float *x, float *out, int n) {
 void emu_atan2d_array(const double *y, const double *x, double *out, int n) {
     for (int i = 0; i < n; i++) out[i] = pg_atan2_d(y[i], x[i]);
 }
+void emu_sincos_array(const double *x, double *s, double *c, int n) {
+    for (int i = 0; i < n; i++) {
+        s[i] = pg_sin_d(x[i]);
+        c[i] = pg_cos_d(x[i]);
+    }
+}
 int emu_error(void *h, int env) { return ((EmuVec *)h)->hdr[env].error | ((EmuVec *)h)->dev_error; }
 int emu_num_entities(void *h, int env) { return ((EmuVec *)h)->hdr[env].n_ents; }
 int emu_is_big(void *h, int env) { return ((EmuVec *)h)->hdr[env].big; }

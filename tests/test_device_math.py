@@ -57,3 +57,24 @@ def test_double_atan2_narrowed_to_float_matches_host_libm():
     assert np.array_equal(out.astype(np.float32).view(np.uint32), ref.astype(np.float32).view(np.uint32))
     ulp = np.abs(out - ref) / np.maximum(np.spacing(np.abs(ref)), 5e-324)
     assert ulp.max() <= 1.0
+
+
+def test_double_sin_cos_narrowed_to_float_match_host_libm():
+    """pg_sin_d / pg_cos_d (rotated sprites, bullet and thrust directions; their callers narrow to float or truncate to
+    pixels / 16.16 coefficients): within 1 ulp of the host libm in double, identical after the narrowing."""
+    L = emu_harness.lib()
+    L.emu_sincos_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.RandomState(13)
+    x = np.concatenate([
+        rng.uniform(-3.2, 3.2, 300000).astype(np.float32).astype(np.float64),                      # angles from atan2f / rand01 * 2 pi
+        rng.uniform(-4000, 4000, 300000).astype(np.float32).astype(np.float64),                    # accumulated rotations
+        0.017453292519943295769 * rng.uniform(-2e5, 2e5, 300000).astype(np.float32).astype(np.float64),  # QTransform::rotate: deg2rad * a
+        rng.uniform(-1e-3, 1e-3, 50000), np.array([0.0, -0.0, np.pi / 4, -np.pi / 4, np.pi / 2, np.pi, 1.5707963267948966, 8.0e5]),
+    ])
+    s = np.zeros_like(x)
+    c = np.zeros_like(x)
+    L.emu_sincos_array(x.ctypes.data, s.ctypes.data, c.ctypes.data, len(x))
+    for got, ref in ((s, np.sin(x)), (c, np.cos(x))):
+        assert np.array_equal(got.astype(np.float32).view(np.uint32), ref.astype(np.float32).view(np.uint32))
+        ulp = np.abs(got - ref) / np.maximum(np.spacing(np.abs(ref)), 5e-324)
+        assert ulp.max() <= 1.0
