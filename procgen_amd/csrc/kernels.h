@@ -22,12 +22,14 @@ struct GameEntry {
     hipError_t (*render_one)(const DevCtx &, int env, hipStream_t);
     int cap_t0, cap_t1, cap_t2;  // entity slots of the three LDS arenas; cap_t2 is the HBM table size
     int grid_bytes;
+    bool has_lane;  // the game has a lane = env step path (mode-1 steps launch lane_step + reset_list instead of the tier-0 grid)
     void (*init_state)(int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
 };
 // mode 0: initial reset + first observation of every env; mode 1: one step
 hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStreams &ls);
 hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream);
 bool game_supported(int game_id);
+bool game_has_lane(int game_id);
 int game_tier_for(int game_id, int slots_needed);
 void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes);
 void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);

@@ -27,6 +27,10 @@ hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t 
     return e ? e->render_one(d, env, stream) : hipErrorInvalidValue;
 }
 bool game_supported(int game_id) { return find(game_id) != nullptr; }
+bool game_has_lane(int game_id) {
+    const GameEntry *e = find(game_id);
+    return e && e->has_lane;
+}
 int game_tier_for(int game_id, int slots_needed) {
     const GameEntry *e = find(game_id);
     if (!e) return 0;

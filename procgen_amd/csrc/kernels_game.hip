@@ -51,6 +51,39 @@ __global__ __launch_bounds__(64) void step_list(DevCtx d, int mode) {
     }
 }
 
+// lane = env physics: one LANE per env, one wave per tile of 64 consecutive envs (the tile-interleaved entity table makes a
+// wave's accesses to one slot contiguous); LDS holds the hot words of each env's first entity slots (LaneLds).  Takes the envs the route table gives it; everything wave-structured
+// (level generation after an episode ends, generator twists) goes to the wave = env kernels through the lists.
+template <class Game>
+__global__ __launch_bounds__(64) void lane_step(DevCtx d, int chunk, int env_base, int env_end) {
+    __shared__ LaneLds<typename Game::cell_t> cache;
+    // One wave per workgroup and a long chain of dependent operations: when it shares a SIMD with the issue-hungry waves of
+    // another chunk's render kernel it should win the arbitration, the others fill its stalls.
+    if (!(d.debug_flags & 8192)) __builtin_amdgcn_s_setprio(3);
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.next_reset_count[chunk] = 0;
+    const int env = env_base + (int)blockIdx.x * TILE_ENVS + (int)threadIdx.x;
+    if (env >= env_end) return;
+    if (d.route[env] != ROUTE_LANE) return;
+    Env<Game, Game::ENT_CAP_T2, true> e(d, env, nullptr);
+    e.lcache = (PG_LDS_PTR(uint32_t))(cache.c + threadIdx.x);
+    e.lwin = (PG_LDS_PTR(typename Game::cell_t))(cache.win + threadIdx.x);
+    e.lcand = (PG_LDS_PTR(uint32_t))(cache.cand + threadIdx.x);
+    e.has_lds = true;
+    e.run_lane(chunk, env_base);
+}
+
+// the episodes the lane kernel of this chunk ended: reset + level generation, outputs and state write-back (Env::run mode 2)
+template <class Game>
+__global__ __launch_bounds__(64) void reset_list(DevCtx d, int chunk, int env_base) {
+    __shared__ Lds<Game, Game::ENT_CAP_T0> lds;
+    const int count = d.reset_count[chunk];
+    for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+        Env<Game, Game::ENT_CAP_T0> e(d, d.reset_list[env_base + k], &lds);
+        e.run(2);
+        __syncthreads();
+    }
+}
+
 template <class Game>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GameRenderMinWaves<PG_GAME>::value))) void render(DevCtx d, int env_base) {
     __shared__ RenderLdsT<Game> lds;
@@ -62,6 +95,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GameRenderMi
 // stream concurrently with the small-arena grid.  The env range is further cut into chunks that alternate between
 // two streams: the latency-bound step kernel of one chunk shares the CUs with the issue-bound render kernel of the
 // previous chunk instead of the two phases running back to back.
+// the step work of the envs [base, base + count) on one stream: the tier-0 grid, or (games with a lane = env path) the lane
+// kernel and the reset kernel behind it
+template <class Game>
+static void launch_chunk_step(const DevCtx &d, int mode, int chunk, int base, int count, hipStream_t st) {
+    if constexpr (GameLane<Game>::value) {
+        if (mode != 0) {
+            if (d.debug_flags & 32) return;
+            hipLaunchKernelGGL(lane_step<Game>, dim3((count + TILE_ENVS - 1) / TILE_ENVS), dim3(64), 0, st, d, chunk, base, base + count);
+            const int rg = count < 512 ? count : 512;
+            hipLaunchKernelGGL(reset_list<Game>, dim3(rg), dim3(64), 0, st, d, chunk, base);
+            return;
+        }
+    }
+    if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(count), dim3(64), 0, st, d, mode, base);
+}
+
 template <class Game>
 static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls) {
 #define PG_TRY(x)                          \
@@ -78,7 +127,7 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
             if (ls.list_count[0] != 0) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.main, d, mode);
             if (ls.list_count[1] != 0) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.main, d, mode);
         }
-        if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode, 0);
+        launch_chunk_step<Game>(d, mode, 0, 0, d.num_envs, ls.main);
         if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, 0);
         return hipGetLastError();
     }
@@ -95,14 +144,14 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         PG_TRY(hipEventRecord(ls.join, ls.side));
     }
     const int nchunk = (ls.chunks > 1 && d.num_envs >= 4096) ? ls.chunks : 1;
-    const int per = (d.num_envs + nchunk - 1) / nchunk;
+    const int per = ((d.num_envs + nchunk - 1) / nchunk + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;  // whole tiles
     for (int c = 0; c < nchunk; c++) {
         const int base = c * per;
         const int count = (d.num_envs - base) < per ? (d.num_envs - base) : per;
         if (count <= 0) break;
         hipStream_t st = nchunk == 1 ? ls.main : ls.lane[c & 1];
         if (nchunk > 1 && c < 2) PG_TRY(hipStreamWaitEvent(st, ls.fork, 0));
-        if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(count), dim3(64), 0, st, d, mode, base);
+        launch_chunk_step<Game>(d, mode, c, base, count, st);
         if (mode != 0) PG_TRY(hipStreamWaitEvent(st, ls.join, 0));
         if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(count), dim3(64), 0, st, d, base);
     }
@@ -129,7 +178,7 @@ static hipError_t render_one(const DevCtx &d, int env, hipStream_t stream) {  //
 const GameEntry *PG_CAT(game_entry_, PG_GAME)() {
     static const GameEntry e = {
         PG_GAME::GAME_ID,    launch_game<PG_GAME>,       render_one<PG_GAME>,     PG_GAME::ENT_CAP_T0, PG_GAME::ENT_CAP_T1,
-        PG_GAME::ENT_CAP_T2, game_grid_bytes<PG_GAME>(), init_env_state<PG_GAME>,
+        PG_GAME::ENT_CAP_T2, game_grid_bytes<PG_GAME>(), GameLane<PG_GAME>::value, init_env_state<PG_GAME>,
     };
     return &e;
 }

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdarg.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -131,6 +132,8 @@ struct VecGame {
     size_t small_bytes = 0;
     int *d_big_list[2] = {nullptr, nullptr};
     int *d_big_count[2] = {nullptr, nullptr};
+    int *d_reset_list = nullptr;   // envs whose episode the lane = env kernel ended this step (consumed by the reset kernel)
+    int *d_reset_count = nullptr;  // [2][MAX_CHUNKS], double-buffered by step parity (the lane kernel zeroes the next step's)
     uint8_t *d_route[2] = {nullptr, nullptr};
     void bind_routing() {  // double-buffered by step parity: this step reads [cur], fills [nxt]
         const int cur = (int)(step_count & 1), nxt = cur ^ 1;
@@ -140,6 +143,9 @@ struct VecGame {
         d.next_big_count = d_big_count[nxt];
         d.route = d_route[cur];
         d.next_route = d_route[nxt];
+        d.reset_list = d_reset_list;
+        d.reset_count = d_reset_count + cur * MAX_CHUNKS;
+        d.next_reset_count = d_reset_count + nxt * MAX_CHUNKS;
     }
     uint64_t step_count = 0;
     // host staging (pinned)
@@ -159,12 +165,17 @@ struct VecGame {
     VecGame(int nenvs, VecOptions opts, const std::string &forced_name = "", int stride = 1, int index = 0);
     ~VecGame();
     void set_buffers(struct libenv_buffers *bufs);
+    void launch_kernels(int mode);
+    void read_tail();
     void launch(int mode);
     void act();
     void observe();
     int get_state(int env_idx, char *data, int length);
     void set_state(int env_idx, const char *data, int length);
     void snapshot(int env_idx, EnvSnapshot *s);
+    void flush_routes();
+    std::vector<uint8_t> h_route;  // host copy of the route table the coming step reads (valid between a set_state and the next launch)
+    bool route_mirror_valid = false, route_dirty = false;
     int env_offset = 0;
     int env_stride = 1;
 };
@@ -309,7 +320,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
             HIP_CHECK(hipEventCreateWithFlags(&ev_lane[k], hipEventDisableTiming));
         }
     }
-    if (const char *c = getenv("PROCGEN_AMD_CHUNKS")) chunks = atoi(c) > 0 ? atoi(c) : 1;
+    if (const char *c = getenv("PROCGEN_AMD_CHUNKS")) chunks = atoi(c) > 0 ? (atoi(c) < MAX_CHUNKS ? atoi(c) : MAX_CHUNKS) : 1;
 
     // assets: baked pack next to the library (procgen_amd/data/<game>.atlas) or the PNG tree at resource_root
     std::string data_dir = getenv("PROCGEN_AMD_DATA_DIR") ? getenv("PROCGEN_AMD_DATA_DIR") : this_library_dir() + "/../../data";
@@ -326,7 +337,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d.num_envs = num_envs;
     d.hdr = dev_alloc<EnvHdr>(N);
     d.rng = dev_alloc<uint32_t>(N * MT_SLOTS * MT_STRIDE);
-    d.ents = dev_alloc<uint32_t>(N * EF_COUNT * d.ent_cap);
+    d.ents = dev_alloc<uint32_t>(ent_table_words(num_envs, d.ent_cap));
     d.grid = dev_alloc<uint8_t>(N * d.grid_bytes);
     {
         std::vector<EnvHdr> hdr(N);
@@ -353,10 +364,14 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         d_big_count[k] = (int *)(d_small + tail_off) + 3 * k;  // A: ints 0-1, B: ints 3-4 (error between them)
         d_route[k] = dev_alloc<uint8_t>(N);
     }
+    d_reset_list = dev_alloc<int>(N);
+    d_reset_count = dev_alloc<int>(2 * MAX_CHUNKS);
     d.assets = d_assets;
     d.pixels = d_pixels;
     d.debug_flags = getenv("PROCGEN_AMD_DEBUG") ? atoi(getenv("PROCGEN_AMD_DEBUG")) : 0;
-    if (d.debug_flags & 2048) d.phase_cycles = dev_alloc<unsigned long long>(32 * 4096);
+    d.lane_max_ents = getenv("PROCGEN_AMD_LANE_ENTS") ? atoi(getenv("PROCGEN_AMD_LANE_ENTS")) : LANE_MAX_ENTS;
+    d.lane_max_smart = getenv("PROCGEN_AMD_LANE_SMART") ? atoi(getenv("PROCGEN_AMD_LANE_SMART")) : LANE_MAX_SMART;
+    if (d.debug_flags & 2048) d.phase_cycles = dev_alloc<unsigned long long>(48 * 4096);
     HIP_CHECK(hipHostMalloc((void **)&h_action, N * 4 + 16, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_small, small_bytes + 16, hipHostMallocDefault));
 }
@@ -364,10 +379,10 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
 VecGame::~VecGame() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (d.phase_cycles) {  // PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step kernels, per env-step
-        std::vector<unsigned long long> raw(32 * 4096);
+        std::vector<unsigned long long> raw(48 * 4096);
         unsigned long long pc[32] = {0};
         const bool got = hipMemcpy(raw.data(), d.phase_cycles, raw.size() * 8, hipMemcpyDeviceToHost) == hipSuccess;
-        for (size_t i = 0; i < raw.size(); i++) pc[i & 31] += raw[i];
+        for (size_t i = 0; i < 32 * 4096; i++) pc[i & 31] += raw[i];
         if (got && pc[14] > 0) {
             static const char *names[13] = {"load_env", "action+velocity", "step_entities (rest)", "collision_pass", "erase_if_needed", "game_step tail", "reset (per reset)", "outputs+camera", "store_env",
                                             " bso: setup", " bso: sub_steps", " se: find+plain ents", " se: smart ent_step"};
@@ -375,6 +390,21 @@ VecGame::~VecGame() {
             for (int k = 0; k < 13; k++) {
                 const double denom = k == 6 ? (double)(pc[15] ? pc[15] : 1) : (double)pc[14];
                 fprintf(stderr, "  %-22s %10.1f\n", names[k], (double)pc[k] / denom);
+            }
+            unsigned long long lc[16] = {0};
+            for (size_t i = 32 * 4096; i < raw.size(); i++)
+                if ((i & 15) != 15) lc[i & 15] += raw[i];
+            if (lc[14] > 0) {  // lane = env kernel: cycles per WAVE-step (64 envs)
+                static const char *ln[13] = {"hdr + cache fill", "action+velocity", "step_entities (rest)", "collision_pass", "erase_if_needed", "game_step tail", "-", "-", "outputs+route+store",
+                                             " bso: setup", " bso: sub_steps", " se: find+plain ents", " se: smart ent_step"};
+                fprintf(stderr, "[lane = env kernel, cycles per wave-step (64 envs), %llu wave-steps]\n", lc[14]);
+                for (int k = 0; k < 13; k++) fprintf(stderr, "  %-22s %10.1f\n", ln[k], (double)lc[k] / (double)lc[14]);
+                fprintf(stderr, "  sub_step rounds per wave-step %.1f, of which with an entity hit in some lane %.1f\n", (double)lc[6] / (double)lc[14], (double)lc[7] / (double)lc[14]);
+                std::vector<unsigned long long> mx;
+                for (size_t i = 32 * 4096 + 15; i < raw.size(); i += 16)
+                    if (raw[i]) mx.push_back(raw[i]);
+                std::sort(mx.begin(), mx.end());
+                if (!mx.empty()) fprintf(stderr, "  slowest wave-step per wave slot (cycles): median %llu, p90 %llu, max %llu (%zu slots)\n", mx[mx.size() / 2], mx[mx.size() * 9 / 10], mx.back(), mx.size());
             }
             if (pc[31] > 0) {
                 static const char *rn[11] = {"set-up: pull tables", "clear + background", "entities z=-1", "grid cells", "entities z=0,1 + hud", "store band",
@@ -399,6 +429,8 @@ VecGame::~VecGame() {
         (void)hipFree(d_big_list[k]);
         (void)hipFree(d_route[k]);
     }
+    (void)hipFree(d_reset_list);
+    (void)hipFree(d_reset_count);
     if (h_action) (void)hipHostFree(h_action);
     if (h_small) (void)hipHostFree(h_small);
     if (h_obs_stage) (void)hipHostFree(h_obs_stage);
@@ -439,7 +471,10 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
     launch(0);  // initial reset + first frame (reference src/vecgame.cpp:346-357)
 }
 
-void VecGame::launch(int mode) {
+// the device work of one step: counter memset + the step / reset / render kernels (what procgen_amd_time_steps brackets)
+void VecGame::launch_kernels(int mode) {
+    if (route_dirty) flush_routes();
+    route_mirror_valid = false;
     bind_routing();
     {   // next counts + error are adjacent in either parity: [A | error] or [error | B]
         int *first = d.next_big_count < d.error ? d.next_big_count : d.error;
@@ -450,6 +485,20 @@ void VecGame::launch(int mode) {
     ls.list_count[1] = mode == 0 ? 0 : host_list_count[1];
     HIP_CHECK(launch_step(kernel_id, d, mode, ls));
     step_count++;
+}
+
+// after the step's small download has landed: device error word, and which list kernels the next step needs
+void VecGame::read_tail() {
+    const int *tail = (const int *)(h_small + tail_off);
+    const int err = tail[2];
+    const int *cnt = tail + 3 * (int)(step_count & 1);  // the lists the step just run filled are the ones the next step reads
+    host_list_count[0] = cnt[0];
+    host_list_count[1] = cnt[1];
+    if (err && !d.debug_flags) fatal("device-side check failed (code %d: 1 entity table overflow, 2 grid index out of range, 3 fassert, 4 asset theme, 5 unsupported draw)\n", err);
+}
+
+void VecGame::launch(int mode) {
+    launch_kernels(mode);
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
     if (host_observations) {
         void *dst = ob_contig ? ob_ptr[0] : (void *)h_obs_stage;
@@ -475,14 +524,7 @@ void VecGame::observe() {  // reference src/vecgame.cpp:363-376,416-435
     HIP_CHECK(hipStreamSynchronize(stream));
     pending = false;
     const size_t N = (size_t)num_envs;
-    const int *tail = (const int *)(h_small + tail_off);
-    const int err = tail[2];
-    {   // the lists the step just run filled are the ones the next step reads
-        const int *cnt = tail + 3 * (int)(step_count & 1);
-        host_list_count[0] = cnt[0];
-        host_list_count[1] = cnt[1];
-    }
-    if (err && !d.debug_flags) fatal("device-side check failed (code %d: 1 entity table overflow, 2 grid index out of range, 3 fassert, 4 asset theme, 5 unsupported draw)\n", err);
+    read_tail();
     memcpy(rew_ptr, h_small, 4 * N);
     memcpy(first_ptr, h_small + 12 * N, N);
     const int32_t *pls = (const int32_t *)(h_small + 4 * N), *ls = (const int32_t *)(h_small + 8 * N);
@@ -502,7 +544,8 @@ void VecGame::snapshot(int e, EnvSnapshot *s) {
     s->rng.resize(2 * MT_STRIDE);
     s->grid.resize(d.grid_bytes);
     HIP_CHECK(hipMemcpy(&s->hdr, d.hdr + e, sizeof(EnvHdr), hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(s->ents.data(), d.ents + (size_t)e * EF_COUNT * d.ent_cap, s->ents.size() * 4, hipMemcpyDeviceToHost));
+    // one word per 256-byte row of the tile-interleaved table
+    HIP_CHECK(hipMemcpy2D(s->ents.data(), 4, d.ents + ent_tile_base(e, d.ent_cap), (size_t)TILE_ENVS * 4, 4, (size_t)EF_COUNT * d.ent_cap, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(s->rng.data(), d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, s->rng.size() * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(s->grid.data(), d.grid + (size_t)e * d.grid_bytes, s->grid.size(), hipMemcpyDeviceToHost));
 }
@@ -525,29 +568,27 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     observe();
     EnvSnapshot s;
     snapshot(e, &s);  // fields the wire format does not carry keep their current values
-    const int was_tier = s.hdr.big;
     std::string err;
     if (!deserialize_state(game_id, d.opt, &s, data, length, &err)) fatal("%s\n", err.c_str());
-    // routing between the arena tiers of the step kernel: conservative bound (a step at most doubles the table)
-    s.hdr.big = game_tier_for(kernel_id, 2 * s.hdr.n_ents + 4);
-    HIP_CHECK(hipMemcpy(d.ents + (size_t)e * EF_COUNT * d.ent_cap, s.ents.data(), s.ents.size() * 4, hipMemcpyHostToDevice));
+    // routing: the restored env takes a wave = env kernel for one step (conservative bound: a step at most doubles the
+    // table); the lists the next step walks are rebuilt from the host's copy of the route table before the next launch,
+    // so restoring the same env several times, in any tier order, leaves exactly one entry for it
+    int tier = game_tier_for(kernel_id, 2 * s.hdr.n_ents + 4);
+    if (game_has_lane(kernel_id) && tier < 1) tier = 1;
+    s.hdr.big = tier;
+    HIP_CHECK(hipMemcpy2D(d.ents + ent_tile_base(e, d.ent_cap), (size_t)TILE_ENVS * 4, s.ents.data(), 4, 4, (size_t)EF_COUNT * d.ent_cap, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, s.rng.data(), s.rng.size() * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.grid + (size_t)e * d.grid_bytes, s.grid.data(), s.grid.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.hdr + e, &s.hdr, sizeof(EnvHdr), hipMemcpyHostToDevice));
-    {
-        const uint8_t tier = (uint8_t)s.hdr.big;  // the route table the next step reads
-        HIP_CHECK(hipMemcpy(d_route[step_count & 1] + e, &tier, 1, hipMemcpyHostToDevice));
+    if (!route_mirror_valid) {
+        h_route.resize(num_envs);
+        HIP_CHECK(hipMemcpy(h_route.data(), d_route[step_count & 1], num_envs, hipMemcpyDeviceToHost));
+        route_mirror_valid = true;
     }
-    if (s.hdr.big && s.hdr.big != was_tier) {  // append to the list the next step's tier kernel will walk
-        const int cur = (int)(step_count & 1), t = s.hdr.big - 1;
-        int count = 0;
-        HIP_CHECK(hipMemcpy(&count, d_big_count[cur] + t, sizeof(int), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(d_big_list[cur] + (size_t)t * num_envs + count, &e, sizeof(int), hipMemcpyHostToDevice));
-        count++;
-        HIP_CHECK(hipMemcpy(d_big_count[cur] + t, &count, sizeof(int), hipMemcpyHostToDevice));
-        host_list_count[t] = count;
-    }
-    // Game::observe(): refresh this env's observation / reward / first / info (reference src/vecgame.cpp:453-455)
+    h_route[e] = (uint8_t)tier;
+    route_dirty = true;
+    // Game::observe(): refresh this env's observation / reward / first / info (reference src/vecgame.cpp:453-455) --
+    // only this env's 12 KB frame and scalars move
     const uint8_t first = (uint8_t)s.hdr.done, plc = (uint8_t)s.hdr.level_complete;
     HIP_CHECK(hipMemcpy(d.rew + e, &s.hdr.reward, 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.first + e, &first, 1, hipMemcpyHostToDevice));
@@ -556,13 +597,34 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     HIP_CHECK(hipMemcpy(d.level_seed + e, &s.hdr.current_level_seed, 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemsetAsync(d.error, 0, sizeof(int), stream));
     HIP_CHECK(launch_render_one(kernel_id, d, e, stream));
-    HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
-    if (host_observations) {
-        void *dst = ob_contig ? ob_ptr[0] : (void *)h_obs_stage;
-        HIP_CHECK(hipMemcpyAsync(dst, d.obs, (size_t)num_envs * OBS_BYTES, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    int dev_err = 0;
+    HIP_CHECK(hipMemcpy(&dev_err, d.error, sizeof(int), hipMemcpyDeviceToHost));
+    if (dev_err && !d.debug_flags) fatal("device-side check failed while drawing a restored state (code %d)\n", dev_err);
+    rew_ptr[e] = s.hdr.reward;
+    first_ptr[e] = first;
+    *(int32_t *)info_ptr[0][e] = s.hdr.prev_level_seed;
+    *(uint8_t *)info_ptr[1][e] = plc;
+    *(int32_t *)info_ptr[2][e] = s.hdr.current_level_seed;
+    if (host_observations) HIP_CHECK(hipMemcpy(ob_ptr[e], d.obs + (size_t)e * OBS_BYTES, OBS_BYTES, hipMemcpyDeviceToHost));
+}
+
+// the tier lists and the route table the coming step reads, rebuilt from the host's copy after set_state calls
+void VecGame::flush_routes() {
+    const int cur = (int)(step_count & 1);
+    std::vector<int> lists((size_t)num_envs * (NUM_TIERS - 1));
+    int count[NUM_TIERS - 1] = {0, 0};
+    for (int e = 0; e < num_envs; e++) {
+        const int t = h_route[e];
+        if (t == 1 || t == 2) lists[(size_t)(t - 1) * num_envs + count[t - 1]++] = e;
     }
-    pending = true;
-    observe();
+    HIP_CHECK(hipMemcpy(d_route[cur], h_route.data(), num_envs, hipMemcpyHostToDevice));
+    for (int t = 0; t < NUM_TIERS - 1; t++) {
+        if (count[t]) HIP_CHECK(hipMemcpy(d_big_list[cur] + (size_t)t * num_envs, lists.data() + (size_t)t * num_envs, (size_t)count[t] * sizeof(int), hipMemcpyHostToDevice));
+        host_list_count[t] = count[t];
+    }
+    HIP_CHECK(hipMemcpy(d_big_count[cur], count, sizeof(count), hipMemcpyHostToDevice));
+    route_dirty = false;
 }
 
 }  // namespace
@@ -718,7 +780,9 @@ LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable
         HIP_CHECK(hipHostMalloc((void **)&v->h_obs_stage, (size_t)v->num_envs * OBS_BYTES, hipHostMallocDefault));
     v->host_observations = enable != 0;
 }
-// average device time of the step kernels over the given number of act/observe rounds (bench.py roofline leg)
+// average device time of one step's launch sequence -- exactly what libenv_act enqueues (VecGame::launch_kernels: counter
+// memset, list / lane / reset / step / render kernels, empty lists skipped) -- over the given number of rounds, measured
+// with HIP events on the library's stream (bench.py roofline leg)
 LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const int32_t *actions_or_null) {
     VecGame *v = ((Handle *)handle)->single();
     v->observe();
@@ -728,18 +792,16 @@ LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const in
     float total_ms = 0.f;
     for (int s = 0; s < steps; s++) {
         if (actions_or_null) HIP_CHECK(hipMemcpyAsync(v->d_action, actions_or_null + (size_t)s * v->num_envs, (size_t)v->num_envs * 4, hipMemcpyHostToDevice, v->stream));
-        v->bind_routing();
-        HIP_CHECK(hipMemsetAsync(v->d.next_big_count, 0, sizeof(int) * (NUM_TIERS - 1), v->stream));
         HIP_CHECK(hipEventRecord(e0, v->stream));
-        HIP_CHECK(launch_step(v->kernel_id, v->d, 1, v->streams()));
+        v->launch_kernels(1);
         HIP_CHECK(hipEventRecord(e1, v->stream));
-        v->step_count++;
-        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipMemcpyAsync(v->h_small, v->d_small, v->small_bytes, hipMemcpyDeviceToHost, v->stream));
+        HIP_CHECK(hipStreamSynchronize(v->stream));
+        v->read_tail();
         float ms = 0.f;
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
         total_ms += ms;
     }
-    HIP_CHECK(hipMemcpyAsync(v->h_small, v->d_small, v->small_bytes, hipMemcpyDeviceToHost, v->stream));
     v->pending = true;
     v->observe();
     (void)hipEventDestroy(e0);

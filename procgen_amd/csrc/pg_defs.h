@@ -3,6 +3,7 @@
 // References: object ids reference src/object-ids.h; resolution reference src/game.h:23-26;
 // BasicAbstractGame constants reference src/basic-abstract-game.cpp:6-20 ("BAG").
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace pgamd {
@@ -96,6 +97,34 @@ enum EntField : int {
     EF_COUNT
 };
 
+// The entity tables of 64 consecutive envs (one "tile") are interleaved in HBM: word (field, slot) of env e lives at
+//   ents[(((e / 64) * EF_COUNT + field) * ent_cap + slot) * 64 + e % 64].
+// The lane = env step kernel (one lane per env, one wave per tile) then reads a field of the same slot for its 64 envs
+// as one 256-byte access; the wave = env kernels (level generation, rendering) read a table at a 256-byte stride.
+constexpr int TILE_ENVS = 64;
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define PG_HOSTDEV __host__ __device__
+#else
+#define PG_HOSTDEV
+#endif
+PG_HOSTDEV inline size_t ent_tile_base(int env, int ent_cap) {  // word index of (field 0, slot 0) of env
+    return (size_t)(env / TILE_ENVS) * EF_COUNT * (size_t)ent_cap * TILE_ENVS + (size_t)(env % TILE_ENVS);
+}
+PG_HOSTDEV inline size_t ent_word_index(int env, int ent_cap, int field, int slot) {
+    return ent_tile_base(env, ent_cap) + ((size_t)field * ent_cap + slot) * TILE_ENVS;
+}
+inline size_t ent_table_words(int num_envs, int ent_cap) {  // allocation size (whole tiles)
+    return (size_t)((num_envs + TILE_ENVS - 1) / TILE_ENVS) * TILE_ENVS * EF_COUNT * (size_t)ent_cap;
+}
+
+// values of the route table (which step kernel owns an env this step): 0..2 = wave = env kernel with LDS arena tier 0..2,
+// ROUTE_LANE = the lane = env physics kernel (games that declare HAS_LANE_STEP)
+constexpr int MAX_CHUNKS = 8;  // env chunks of one step (step of chunk c+1 overlaps the render of chunk c)
+constexpr int ROUTE_LANE = 3;
+constexpr int LANE_MAX_ENTS = 32;  // default routing bounds of the lane = env kernel (see pg_env.h GameLane)
+constexpr int LANE_MAX_SMART = 4;
+constexpr int ROUTE_RESET = 4;  // EnvHdr::big only: the lane kernel ended the episode, the reset kernel of the same step takes over
+
 // ---- sprite atlas in HBM ----
 struct ImgDesc {
     uint32_t off;  // first pixel (0xAARRGGBB words) in the atlas blob
@@ -120,7 +149,7 @@ struct DevCtx {
     // per-env state
     EnvHdr *hdr;          // [num_envs]
     uint32_t *rng;        // [num_envs][MT_SLOTS][MT_STRIDE]  (0: rand_gen, 1: level_seed_rand_gen, 2-3: scratch)
-    uint32_t *ents;       // [num_envs][EF_COUNT][ent_cap]
+    uint32_t *ents;       // [num_envs / 64][EF_COUNT][ent_cap][64]  (ent_word_index)
     int ent_cap;          // slots per env in HBM
     uint8_t *grid;        // [num_envs][grid_bytes]
     int grid_bytes;
@@ -143,8 +172,13 @@ struct DevCtx {
     // the three tiers run concurrently: an env re-routed by a fast kernel is not picked up again by a slower one)
     const uint8_t *route;  // [num_envs]
     uint8_t *next_route;   // [num_envs] written by every env's store_env
+    // envs the lane = env kernel stepped into `done`: the wave = env reset kernel of the same step generates their next level
+    int *reset_list;        // [num_envs]: the envs of chunk c are appended from index c's first env on
+    int *reset_count;       // [MAX_CHUNKS] per env chunk, this step
+    int *next_reset_count;  // [MAX_CHUNKS] the next step's counters (double-buffered by step parity), zeroed by this step's lane kernel
     int *error;            // [1] OR of the per-env error codes raised this step (0 = none)
     unsigned long long *phase_cycles;  // [4096][32] PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step (0-15) and render (16-31) kernels (null otherwise)
+    int lane_max_ents, lane_max_smart;  // routing bounds of the lane = env kernel (pg_env.h LANE_MAX_ENTS / LANE_MAX_SMART; PROCGEN_AMD_LANE_ENTS / _SMART override them for tuning)
     int debug_flags;       // PROCGEN_AMD_DEBUG: phase ablation bits for profiling only (0 in normal operation)
 };
 

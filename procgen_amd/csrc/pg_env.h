@@ -112,6 +112,24 @@ constexpr int game_grid_bytes() {
     return game_cell_bytes<Game>() + GameAux<Game>::WORDS * 4;
 }
 
+// a game with a lane = env step path declares HAS_LANE_STEP = true and LANE_MAX_DRAWS, an upper bound of the rand_gen
+// draws one step can make without a reset
+template <class Game, class = void>
+struct GameLane {
+    static constexpr bool value = false;
+    static constexpr int MAX_DRAWS = MT_N + 1;
+};
+template <class Game>
+struct GameLane<Game, decltype((void)Game::HAS_LANE_STEP)> {
+    static constexpr bool value = Game::HAS_LANE_STEP;
+    static constexpr int MAX_DRAWS = Game::LANE_MAX_DRAWS;
+};
+// A wave of the lane = env kernel takes as long as its heaviest env and the kernel as long as its slowest wave, so the
+// lane path only takes envs of bounded work: at most LANE_MAX_ENTS entities (all inside the LDS cache) of which at most
+// LANE_MAX_SMART are smart_step ones (each costs a basic_step_object).  The heavy tail (coinrun: 10 % of the env-steps,
+// up to 350 entities / 35 walking enemies) stays with the wave = env kernels, one workgroup each.
+// (the defaults LANE_MAX_ENTS / LANE_MAX_SMART live in pg_defs.h; DevCtx carries the values in use)
+
 // a game whose is_blocked has a side effect on the moving entity (ninja's throwing stars stick to walls) declares
 // HAS_BLOCK_HOOK and on_grid_block(e, obj): called when the corner probes of sub_step found a blocking cell
 template <class Game, class = void>
@@ -122,6 +140,59 @@ template <class Game>
 struct GameHasBlockHook<Game, decltype((void)Game::HAS_BLOCK_HOOK)> {
     static constexpr bool value = Game::HAS_BLOCK_HOOK;
 };
+
+// LDS of the lane = env kernel: the seven hot words of an entity (x, y, vx, vy, rx, ry, meta = EntField 0..6: what the
+// entity scans, the collision pass and the erase pass read) of the first LANE_CACHE_SLOTS slots of each of the wave's 64
+// envs, [field][slot][lane].  A dependent global access costs ~1 us per trip on this latency-bound kernel, an LDS
+// access ~0.05 us.  Slots beyond the cache stay in HBM; Env::ew picks per access (generic pointer -> flat load).
+constexpr int LANE_CACHE_FIELDS = 7;
+constexpr int LANE_CACHE_SLOTS = 32;
+static_assert(EF_META == LANE_CACHE_FIELDS - 1 && EF_X == 0, "the cached fields are the first enum values");
+// ... and, per lane, a LANE_WIN x LANE_WIN window of grid cells around the entity being stepped (Env::grid_window):
+// the corner probes of its sub_steps and its grid collisions read LDS instead of making one HBM trip each.
+constexpr int LANE_WIN = 8;
+constexpr int LANE_MAX_CAND = 8;
+template <class cell_t>
+struct LaneLds {
+    uint32_t c[LANE_CACHE_FIELDS * LANE_CACHE_SLOTS * TILE_ENVS];
+    cell_t win[LANE_WIN * LANE_WIN * TILE_ENVS];  // [cell of the window][lane]
+    // ... and the entities the object being stepped could touch during this step (Env::basic_step_object): its sub_steps
+    // test these few instead of walking the whole table
+    uint32_t cand[LANE_MAX_CAND * TILE_ENVS];
+};
+
+// an LDS pointer the compiler knows to be one (ds_read / ds_write instead of flat accesses through a generic pointer)
+#if defined(PGAMD_WAVE_EMU)
+#define PG_LDS_PTR(T) T *
+#else
+#define PG_LDS_PTR(T) __attribute__((address_space(3))) T *
+#endif
+
+// LANE_MODE: what ex(i), meta(i), ... return instead of a reference -- a handle that reads / writes the word where it
+// lives (this lane's LDS cache column for the hot words of the first slots, the HBM table otherwise), so that the game
+// policies' `e.evx(i) *= f` and `e.erx(j) > e.erx(ag)` compile to ds_read / global_load rather than flat accesses
+template <class T, class EnvT>
+struct LaneRef {
+    EnvT *e;
+    int field, i;
+    PG_DEV operator T() const { return __builtin_bit_cast(T, e->ldw(field, i)); }
+    PG_DEV T operator=(T v) const {
+        e->stw(field, i, __builtin_bit_cast(uint32_t, v));
+        return v;
+    }
+    PG_DEV T operator=(const LaneRef &o) const { return *this = (T)o; }
+    PG_DEV T operator+=(T v) const { return *this = (T)((T) * this + v); }
+    PG_DEV T operator-=(T v) const { return *this = (T)((T) * this - v); }
+    PG_DEV T operator*=(T v) const { return *this = (T)((T) * this * v); }
+    PG_DEV T operator|=(T v) const { return *this = (T)((T) * this | v); }
+    PG_DEV T operator&=(T v) const { return *this = (T)((T) * this & v); }
+};
+
+// memory ordering between two lane sections of one wave; nothing to order when a lane owns the whole env
+#define PG_SYNC_E()                      \
+    do {                                 \
+        if constexpr (!LANE) PG_SYNC();  \
+    } while (0)
 
 template <class Game, int CAP>
 struct Lds {
@@ -134,13 +205,28 @@ struct Lds {
 #endif
 };
 
-template <class Game, int CAP>
+// LANE_MODE = false: one wavefront advances this env, state staged in the workgroup's LDS arena (`s`), lanes cover
+//   entity slots / cells (wave.h's lane sections and ballots).
+// LANE_MODE = true: ONE LANE advances this env (64 envs per wavefront, see run_lane / kernels_game.hip lane_step); the
+//   entity table and the grid are accessed in place in HBM (the tile-interleaved table makes a wave's 64 accesses to
+//   one slot contiguous), every loop over entities is the lane's own serial loop, and nothing in this mode may use a
+//   lane section or a ballot -- level generation (resets) is handed to the wave = env reset kernel.
+template <class Game, int CAP, bool LANE_MODE = false>
 struct Env {
     using cell_t = typename Game::cell_t;
     static constexpr int CAPACITY = CAP;
+    static constexpr bool LANE = LANE_MODE;
     const DevCtx &d;
     const int env;
     Lds<Game, CAP> *s;
+    uint32_t *lent;   // LANE: this env's (field 0, slot 0) word in the tile-interleaved HBM table
+    PG_LDS_PTR(uint32_t) lcache;  // LANE: this lane's column of the LDS entity cache (LaneLds)
+    PG_LDS_PTR(cell_t) lwin;      // LANE: this lane's column of the LDS grid window
+    PG_LDS_PTR(uint32_t) lcand;   // LANE: this lane's column of the candidate list
+    bool has_lds;                 // LANE: the three above are set
+    int ncand;                    // LANE: candidates of the object being stepped, ascending index; -1 = too many, walk the table
+    int win_x0, win_y0;  // its origin in the grid (INT_MIN/2: nothing loaded)
+    cell_t *lgrid;    // LANE: this env's grid cells in HBM
     EnvHdr G;
     // rand_gen bookkeeping: where the live 624-word state is (HBM home or LDS scratch)
     uint32_t *rg_home;
@@ -148,12 +234,17 @@ struct Env {
     bool rg_in_lds;
 
     // profiling aid (PROCGEN_AMD_DEBUG & 2048): wave cycles spent since the previous mark are charged to phase k
-    long long t_mark = 0;
+    long long t_mark = 0, t_start = 0;
+    bool needs_reset = false;  // LANE: this step ended the episode
+    int lane_smart_count = 0;  // LANE: smart_step entities met by step_entities
     PG_DEV void phase(int k) {
 #if !defined(PGAMD_WAVE_EMU)
         if (d.phase_cycles) {
             const long long t = (long long)__builtin_readcyclecounter();
-            if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + k + 32 * (env & 4095), (unsigned long long)(t - t_mark));
+            // (LANE: called where the wave's lanes have reconverged; its first active lane accounts for the wave)
+            const bool me = LANE ? PG_LANE_ID() == (int)__ffsll((long long)__ballot(1)) - 1 : PG_LANE_ID() == 0;
+            // (the lane kernel's counters follow the [4096][32] block of the wave = env kernels: [4096][16])
+            if (me && t_mark != 0) atomicAdd(d.phase_cycles + (LANE ? 32 * 4096 + k + 16 * ((env >> 6) & 4095) : k + 32 * (env & 4095)), (unsigned long long)(t - t_mark));
             t_mark = (long long)__builtin_readcyclecounter();
         }
 #else
@@ -161,7 +252,26 @@ struct Env {
 #endif
     }
 
+    // profiling aid of the lane kernel (PROCGEN_AMD_DEBUG & 2048): per-wave event counters / maxima in the lane block of phase_cycles
+    PG_DEV void lane_count(int slot, unsigned long long v, bool is_max = false) {
+#if !defined(PGAMD_WAVE_EMU)
+        if constexpr (LANE) {
+            if (d.phase_cycles && PG_LANE_ID() == (int)__ffsll((long long)__ballot(1)) - 1) {
+                unsigned long long *p = d.phase_cycles + 32 * 4096 + slot + 16 * ((env >> 6) & 4095);
+                if (is_max) atomicMax(p, v);
+                else atomicAdd(p, v);
+            }
+        }
+#else
+        (void)slot; (void)v; (void)is_max;
+#endif
+    }
     PG_DEV Env(const DevCtx &d_, int env_, Lds<Game, CAP> *s_) : d(d_), env(env_), s(s_) {
+        lent = LANE ? d.ents + ent_tile_base(env_, CAP) : nullptr;
+        has_lds = false;
+        ncand = -1;
+        win_x0 = win_y0 = -(1 << 30);
+        lgrid = LANE ? reinterpret_cast<cell_t *>(d.grid + (size_t)env_ * d.grid_bytes) : nullptr;
         rg_home = d.rng + (size_t)env * MT_SLOTS * MT_STRIDE;
         rg_cur = rg_home;
         rg_in_lds = false;
@@ -169,15 +279,46 @@ struct Env {
 
     // ======================================================================================================
     // entity table accessors (LDS SoA)
-    PG_DEV float &ef(int field, int i) { return reinterpret_cast<float *>(s->ent)[field * CAP + i]; }
-    PG_DEV int &ei(int field, int i) { return reinterpret_cast<int *>(s->ent)[field * CAP + i]; }
-    PG_DEV uint32_t &meta(int i) { return s->ent[EF_META * CAP + i]; }
-    PG_DEV float &ex(int i) { return ef(EF_X, i); }
-    PG_DEV float &ey(int i) { return ef(EF_Y, i); }
-    PG_DEV float &evx(int i) { return ef(EF_VX, i); }
-    PG_DEV float &evy(int i) { return ef(EF_VY, i); }
-    PG_DEV float &erx(int i) { return ef(EF_RX, i); }
-    PG_DEV float &ery(int i) { return ef(EF_RY, i); }
+    // one word of the entity table: where it lives depends on the mode (LDS arena / LDS cache column / HBM table)
+    PG_DEV uint32_t ldw(int field, int i) const {
+        if constexpr (LANE) {
+            if (field < LANE_CACHE_FIELDS && i < LANE_CACHE_SLOTS) return lcache[(field * LANE_CACHE_SLOTS + i) * TILE_ENVS];
+            return lent[(size_t)(field * CAP + i) * TILE_ENVS];
+        } else {
+            return s->ent[field * CAP + i];
+        }
+    }
+    PG_DEV void stw(int field, int i, uint32_t v) const {
+        if constexpr (LANE) {
+            if (field < LANE_CACHE_FIELDS && i < LANE_CACHE_SLOTS) lcache[(field * LANE_CACHE_SLOTS + i) * TILE_ENVS] = v;
+            else lent[(size_t)(field * CAP + i) * TILE_ENVS] = v;
+        } else {
+            s->ent[field * CAP + i] = v;
+        }
+    }
+    PG_DEV uint32_t &ew_hbm(int field, int i) { return lent[(size_t)(field * CAP + i) * TILE_ENVS]; }  // LANE
+    PG_DEV cell_t &cell(int idx) {
+        if constexpr (LANE) return lgrid[idx];
+        else return s->grid[idx];
+    }
+    PG_DEV decltype(auto) ef(int field, int i) {
+        if constexpr (LANE) return LaneRef<float, Env>{this, field, i};
+        else return (reinterpret_cast<float *>(s->ent)[field * CAP + i]);
+    }
+    PG_DEV decltype(auto) ei(int field, int i) {
+        if constexpr (LANE) return LaneRef<int, Env>{this, field, i};
+        else return (reinterpret_cast<int *>(s->ent)[field * CAP + i]);
+    }
+    PG_DEV decltype(auto) meta(int i) {
+        if constexpr (LANE) return LaneRef<uint32_t, Env>{this, (int)EF_META, i};
+        else return (s->ent[EF_META * CAP + i]);
+    }
+    PG_DEV decltype(auto) ex(int i) { return ef(EF_X, i); }
+    PG_DEV decltype(auto) ey(int i) { return ef(EF_Y, i); }
+    PG_DEV decltype(auto) evx(int i) { return ef(EF_VX, i); }
+    PG_DEV decltype(auto) evy(int i) { return ef(EF_VY, i); }
+    PG_DEV decltype(auto) erx(int i) { return ef(EF_RX, i); }
+    PG_DEV decltype(auto) ery(int i) { return ef(EF_RY, i); }
     PG_DEV int etype(int i) { return meta_type(meta(i)); }
     PG_DEV bool eflag(int i, uint32_t f) { return (meta(i) & f) != 0; }
     PG_DEV void set_flag(int i, uint32_t f, bool v) { meta(i) = v ? (meta(i) | f) : (meta(i) & ~f); }
@@ -250,19 +391,91 @@ struct Env {
         ef(EF_ALPHA, i) = ef(EF_ALPHA_DECAY, i) * ef(EF_ALPHA, i);
     }
 
+    // Entity::step for the entities [lo, hi), none of them smart_step (LANE): four per round so that one memory round
+    // trip serves four entities; entities are independent of each other here
+    PG_DEV void ent_step_run(int lo, int hi) {
+        constexpr int B = 4;
+        for (int base = lo; base < hi; base += B) {
+            float x[B], y[B], vx[B], vy[B], rot[B], vrot[B], fr[B], gr[B], rx[B], ry[B], al[B], ad[B];
+            int lt[B], et[B];
+            uint32_t m[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                const int i = base + k < hi ? base + k : hi - 1;  // (a duplicate load of the last one instead of a branch)
+                x[k] = ex(i); y[k] = ey(i); vx[k] = evx(i); vy[k] = evy(i); rx[k] = erx(i); ry[k] = ery(i); m[k] = meta(i);
+                rot[k] = ef(EF_ROTATION, i); vrot[k] = ef(EF_VROT, i); fr[k] = ef(EF_FRICTION, i); gr[k] = ef(EF_GROW_RATE, i);
+                al[k] = ef(EF_ALPHA, i); ad[k] = ef(EF_ALPHA_DECAY, i); lt[k] = ei(EF_LIFE_TIME, i); et[k] = ei(EF_EXPIRE_TIME, i);
+            }
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                const int i = base + k;
+                if (i < hi) {
+                    // (the same operations as ent_step; a value is stored only when its bits change -- most entities stand still)
+                    const float nx = x[k] + vx[k], ny = y[k] + vy[k], nrot = rot[k] + vrot[k], nvx = vx[k] * fr[k], nvy = vy[k] * fr[k];
+                    if (__builtin_bit_cast(uint32_t, nx) != __builtin_bit_cast(uint32_t, x[k])) ex(i) = nx;
+                    if (__builtin_bit_cast(uint32_t, ny) != __builtin_bit_cast(uint32_t, y[k])) ey(i) = ny;
+                    if (__builtin_bit_cast(uint32_t, nrot) != __builtin_bit_cast(uint32_t, rot[k])) ef(EF_ROTATION, i) = nrot;
+                    if (__builtin_bit_cast(uint32_t, nvx) != __builtin_bit_cast(uint32_t, vx[k])) evx(i) = nvx;
+                    if (__builtin_bit_cast(uint32_t, nvy) != __builtin_bit_cast(uint32_t, vy[k])) evy(i) = nvy;
+                    const int nlt = lt[k] + 1;
+                    ei(EF_LIFE_TIME, i) = nlt;
+                    uint32_t mm = m[k];
+                    if (et[k] > 0 && nlt > et[k]) mm |= MF_WILL_ERASE;
+                    if (meta_type(mm) == EXPLOSION) {
+                        const int it = meta_image_type(mm);
+                        if (it < EXPLOSION5) mm = (mm & ~(0xffu << M_IMG_SHIFT)) | ((uint32_t)(it + 1) << M_IMG_SHIFT);
+                    }
+                    if (mm != m[k]) meta(i) = mm;
+                    const float nrx = rx[k] * gr[k], nry = ry[k] * gr[k], nal = ad[k] * al[k];
+                    if (__builtin_bit_cast(uint32_t, nrx) != __builtin_bit_cast(uint32_t, rx[k])) erx(i) = nrx;
+                    if (__builtin_bit_cast(uint32_t, nry) != __builtin_bit_cast(uint32_t, ry[k])) ery(i) = nry;
+                    if (__builtin_bit_cast(uint32_t, nal) != __builtin_bit_cast(uint32_t, al[k])) ef(EF_ALPHA, i) = nal;
+                }
+            }
+        }
+    }
+
     // ======================================================================================================
     // grid (staged in LDS): reference src/grid.h, BAG:125-131,167-223
     PG_DEV bool grid_contains(int x, int y) { return 0 <= y && y < G.main_height && 0 <= x && x < G.main_width; }
+    // LANE: make the window cover the cells around (fx, fy) (at least 3 cells either side); reloaded only when it does not
+    PG_DEV void grid_window(float fx, float fy) {
+        if constexpr (LANE) {
+            if (!has_lds) return;
+            const int cx = (int)pg_floorf(fx), cy = (int)pg_floorf(fy);
+            if (cx - 3 >= win_x0 && cx + 3 < win_x0 + LANE_WIN && cy - 3 >= win_y0 && cy + 3 < win_y0 + LANE_WIN) return;
+            win_x0 = cx - LANE_WIN / 2;
+            win_y0 = cy - LANE_WIN / 2;
+            const int w = G.main_width, h = G.main_height;
+            cell_t v[LANE_WIN * LANE_WIN];
+#pragma unroll
+            for (int k = 0; k < LANE_WIN * LANE_WIN; k++) {  // all loads in flight together; cells outside the grid are never read back
+                const int x = win_x0 + (k % LANE_WIN), y = win_y0 + (k / LANE_WIN);
+                const bool in = 0 <= y && y < h && 0 <= x && x < w;
+                v[k] = lgrid[in ? y * w + x : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < LANE_WIN * LANE_WIN; k++) lwin[k * TILE_ENVS] = v[k];
+        }
+    }
     PG_DEV int get_obj(int x, int y) {  // BAG:180-185
         if (!grid_contains(x, y)) return G.out_of_bounds_object;
-        return (int)s->grid[y * G.main_width + x];
+        if constexpr (LANE) {
+            const unsigned wx = (unsigned)(x - win_x0), wy = (unsigned)(y - win_y0);
+            if (wx < (unsigned)LANE_WIN && wy < (unsigned)LANE_WIN) return (int)lwin[(wy * LANE_WIN + wx) * TILE_ENVS];
+        }
+        return (int)cell(y * G.main_width + x);
     }
     PG_DEV void set_obj(int x, int y, int v) {  // grid.h:54-57 (fassert on out-of-range)
         if (!grid_contains(x, y)) {
             fail(PGE_GRID_OOB);
             return;
         }
-        s->grid[y * G.main_width + x] = (cell_t)v;
+        cell(y * G.main_width + x) = (cell_t)v;
+        if constexpr (LANE) {
+            const unsigned wx = (unsigned)(x - win_x0), wy = (unsigned)(y - win_y0);
+            if (wx < (unsigned)LANE_WIN && wy < (unsigned)LANE_WIN) lwin[(wy * LANE_WIN + wx) * TILE_ENVS] = (cell_t)v;
+        }
         G.grid_dirty = 1;
     }
     PG_DEV int get_obj_from_floats(float i, float j) {  // BAG:167-174
@@ -284,7 +497,7 @@ struct Env {
             }
         }
         G.grid_dirty = 1;
-        PG_SYNC();
+        PG_SYNC_E();
     }
 
     // ======================================================================================================
@@ -305,7 +518,7 @@ struct Env {
                 }
             }
         }
-        PG_SYNC();
+        PG_SYNC_E();
         // k in [227,454): new[k-227] was produced by the previous phase
         for (int base = 227; base < 454; base += 64) {
             PG_FOR_LANES(l) {
@@ -316,7 +529,7 @@ struct Env {
                 }
             }
         }
-        PG_SYNC();
+        PG_SYNC_E();
         for (int base = 454; base < 623; base += 64) {
             PG_FOR_LANES(l) {
                 int k = base + l;
@@ -326,7 +539,7 @@ struct Env {
                 }
             }
         }
-        PG_SYNC();
+        PG_SYNC_E();
         {
             uint32_t y = (src[623] & 0x80000000u) | (dst[0] & 0x7fffffffu);
             uint32_t v = dst[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
@@ -334,7 +547,7 @@ struct Env {
                 if (l == 0) dst[623] = v;
             }
         }
-        PG_SYNC();
+        PG_SYNC_E();
     }
     PG_DEV void mt_copy(const uint32_t *src, uint32_t *dst) {
         for (int base = 0; base < MT_N; base += 64) {
@@ -343,7 +556,7 @@ struct Env {
                 if (k < MT_N) dst[k] = src[k];
             }
         }
-        PG_SYNC();
+        PG_SYNC_E();
     }
     PG_DEV static uint32_t mt_temper(uint32_t z) {
         z ^= (z >> 11);
@@ -362,12 +575,22 @@ struct Env {
                 if (l == 0) a[i] = x;
             }
         }
-        PG_SYNC();
+        PG_SYNC_E();
         rg_cur = a;
         rg_in_lds = true;
         G.rand_idx = MT_N;
     }
     PG_DEV uint32_t rand_u32() {
+        if constexpr (LANE) {
+            // routing keeps envs whose generator could need a twist this step out of the lane kernel (Game::LANE_MAX_DRAWS)
+            if (G.rand_idx >= MT_N) {
+                fail(PGE_ASSERT);
+                return 0u;
+            }
+            const uint32_t z = rg_home[G.rand_idx];
+            G.rand_idx += 1;
+            return mt_temper(z);
+        }
         if (G.rand_idx >= MT_N) {
             uint32_t *dst = (rg_cur == mt_a()) ? mt_b() : mt_a();
             mt_twist(rg_cur, dst);
@@ -527,7 +750,7 @@ struct Env {
         }
         ex(obj) = nx;
         ey(obj) = ny;
-        PG_SYNC();
+        PG_SYNC_E();
 
         return entity_scan<DEPTH>(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory) || block;
     }
@@ -539,6 +762,41 @@ struct Env {
     PG_DEV bool entity_scan(int obj, float _vx, float _vy, bool is_horizontal, int scan_axes, int otype, float orx, float ory) {
         bool block2 = false;
         const int n = ((scan_axes >> (is_horizontal ? 0 : 1)) & 1) ? G.n_ents : 0;
+        if constexpr (LANE) {  // the reference's own reverse loop (BAG:337-369), candidates filtered like the ballot below
+            // push_obj always moves `obj` itself (BAG:364), so the candidates of the object being stepped serve every depth;
+            // they are in ascending index order, the reference walks the list downwards
+            const int count = n == 0 ? 0 : (ncand >= 0 ? ncand : n);
+            for (int c = count - 1; c >= 0; c--) {
+                const int j = ncand >= 0 ? (int)lcand[c * TILE_ENVS] : c;
+                if (j == obj) continue;
+                const uint32_t mm = meta(j);
+                if ((mm & MF_WILL_ERASE) || !Game::may_interact(*this, otype, meta_type(mm), is_horizontal)) continue;
+                {
+                    const float tx = (orx + erx(j)) + POS_EPS;
+                    const float ty = (ory + ery(j)) + POS_EPS;
+                    if (!((pg_fabsf(ex(obj) - ex(j)) < tx) && (pg_fabsf(ey(obj) - ey(j)) < ty))) continue;
+                }
+                bool curr_block = false;
+                if (Game::is_blocked_ents(*this, obj, j, is_horizontal)) {
+                    curr_block = true;
+                } else if (Game::will_reflect(otype, etype(j))) {
+                    if (is_horizontal) {
+                        float delx = ex(j) - ex(obj);
+                        float rsum = erx(j) + orx;
+                        ex(obj) += _vx > 0 ? -2 * (rsum - delx) : 2 * (rsum + delx);
+                        evx(obj) = -1 * evx(obj);
+                    } else {
+                        float dely = ey(j) - ey(obj);
+                        float rsum = ery(j) + ory;
+                        ey(obj) += _vy > 0 ? -2 * (rsum - dely) : 2 * (rsum + dely);
+                        evy(obj) = -1 * evy(obj);
+                    }
+                }
+                if (curr_block) push_obj<DEPTH>(j, obj, is_horizontal, scan_axes);
+                block2 = block2 || curr_block;
+            }
+            return block2;
+        }
         for (int c = (n - 1) >> 6; c >= 0; c--) {
             int limit = 64;  // lanes >= limit of this chunk have been visited
             bool need_ballot = true;
@@ -592,7 +850,7 @@ struct Env {
                 }
                 block2 = block2 || curr_block;
                 if (moved) {
-                    PG_SYNC();
+                    PG_SYNC_E();
                     need_ballot = true;
                 }
             }
@@ -624,7 +882,7 @@ struct Env {
     }
     PG_DEV void obj_flush(int obj, const ObjRegs &R) {
         ex(obj) = R.x; ey(obj) = R.y; evx(obj) = R.vx; evy(obj) = R.vy;
-        PG_SYNC();
+        PG_SYNC_E();
     }
     PG_DEV bool sub_step_top(int obj, ObjRegs &R, float _vx, float _vy, int scan_axes) {  // BAG:270-372, depth 0
         const int otype = R.type;
@@ -669,7 +927,7 @@ struct Env {
             if (block) {
                 obj_flush(obj, R);
                 Game::on_grid_block(*this, obj);
-                PG_SYNC();
+                PG_SYNC_E();
                 R.vx = evx(obj);
                 R.vy = evy(obj);
             }
@@ -702,7 +960,21 @@ struct Env {
         // does the entity scan find anything at all?  (the same broad phase as entity_scan, from the register copy)
         const int n = ((scan_axes >> (is_horizontal ? 0 : 1)) & 1) ? G.n_ents : 0;
         bool any_hit = false;
-        for (int c = (n - 1) >> 6; c >= 0 && !any_hit; c--) {
+        if constexpr (LANE) {
+            // (only entities within this step's reach can be hit: the candidates collected by basic_step_object)
+            const int count = n == 0 ? 0 : (ncand >= 0 ? ncand : n);
+            for (int c = count - 1; c >= 0 && !any_hit; c--) {
+                const int idx = ncand >= 0 ? (int)lcand[c * TILE_ENVS] : c;
+                if (idx == obj) continue;
+                const uint32_t mm = meta(idx);
+                if (!(mm & MF_WILL_ERASE) && Game::may_interact(*this, otype, meta_type(mm), is_horizontal)) {
+                    const float tx = (orx + erx(idx)) + POS_EPS;
+                    const float ty = (ory + ery(idx)) + POS_EPS;
+                    any_hit = (pg_fabsf(nx - ex(idx)) < tx) && (pg_fabsf(ny - ey(idx)) < ty);
+                }
+            }
+        }
+        for (int c = LANE ? -1 : ((n - 1) >> 6); c >= 0 && !any_hit; c--) {
             const uint64_t m = PG_BALLOT(l, ({
                                              const int idx = (c << 6) + l;
                                              bool hit = false;
@@ -719,17 +991,20 @@ struct Env {
             any_hit = m != 0;
         }
         if (block || reflect) R.eventful = true;
+        lane_count(6, 1);  // sub_step_top rounds of this wave
         if (!any_hit) return block;
+        lane_count(7, 1);  // ... in which some lane took the entity path
         R.eventful = true;
         obj_flush(obj, R);
         const bool block2 = entity_scan<0>(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory);
-        PG_SYNC();
+        PG_SYNC_E();
         R.x = ex(obj); R.y = ey(obj); R.vx = evx(obj); R.vy = evy(obj);
         return block || block2;
     }
 
     PG_DEV void basic_step_object(int obj) {  // BAG:593-656
         if (eflag(obj, MF_WILL_ERASE)) return;
+        grid_window(ex(obj), ey(obj));
         int num_sub_steps;
         {
             const float vx = evx(obj), vy = evy(obj);
@@ -749,7 +1024,26 @@ struct Env {
         }
         // which axes need the entity scan at all for this object (entity types do not change while it steps)
         int scan_axes = 0;
-        {
+        if constexpr (LANE) {
+            // one pass: the axes on which some entity within this step's reach could block or reflect `obj`
+            const int otype = etype(obj);
+            const int n = G.n_ents;
+            const float ox = ex(obj), oy = ey(obj), orx = erx(obj), ory = ery(obj);
+            const float reach_x = pg_fabsf(evx(obj)) + 2.01f, reach_y = pg_fabsf(evy(obj)) + 2.01f;
+            ncand = has_lds ? 0 : -1;
+            for (int idx = 0; idx < n; idx++) {
+                if (idx == obj) continue;
+                const int t = etype(idx);
+                const int ax = (Game::may_interact(*this, otype, t, true) ? 1 : 0) | (Game::may_interact(*this, otype, t, false) ? 2 : 0);
+                if (ax != 0 && (pg_fabsf(ox - ex(idx)) < orx + erx(idx) + reach_x) && (pg_fabsf(oy - ey(idx)) < ory + ery(idx) + reach_y)) {
+                    scan_axes |= ax;
+                    if (ncand >= 0) {
+                        if (ncand < LANE_MAX_CAND) lcand[ncand++ * TILE_ENVS] = (uint32_t)idx;
+                        else ncand = -1;
+                    }
+                }
+            }
+        } else {
             const int otype = etype(obj);
             const int n = G.n_ents;
             for (int c = 0; c < ((n + 63) >> 6) && scan_axes != 3; c++) {
@@ -760,7 +1054,7 @@ struct Env {
         }
         ObjRegs R;
         obj_load(obj, R);
-        if (scan_axes != 0) {
+        if (!LANE && scan_axes != 0) {
             // no entity this object could interact with lies within its reach for this step (its own travel, < 1 cell of
             // block snapping, < 2 of a reflection): the per-sub_step scans cannot find anything
             const int otype = R.type;
@@ -815,6 +1109,25 @@ struct Env {
     // step_entities BAG:1086-1098: reverse order; runs of non-smart entities are stepped lane-parallel,
     // smart_step entities (agent, walkers) serially in their list position.
     PG_DEV void step_entities() {
+        if constexpr (LANE) {
+            // The reference order (i descending: basic_step_object of a smart entity, then Entity::step), shaped for a
+            // wave of 64 envs: every lane first finds its next smart entity, steps the plain entities above it four at
+            // a time (their loads in flight together), and then ALL lanes run their basic_step_object side by side --
+            // a loop that met smart entities at each lane's own iteration would run them one lane after the other.
+            int hi = G.n_ents;  // entities [hi, n) are done
+            while (hi > 0) {
+                int sidx = hi - 1;
+                while (sidx >= 0 && !(meta(sidx) & MF_SMART_STEP)) sidx--;
+                ent_step_run(sidx + 1, hi);
+                if (sidx >= 0) {
+                    lane_smart_count++;
+                    basic_step_object(sidx);
+                    ent_step(sidx);
+                }
+                hi = sidx;
+            }
+            return;
+        }
         const int n0 = G.n_ents;
         int hi = n0;  // entities [hi, n0) are done
         while (hi > 0) {
@@ -834,12 +1147,12 @@ struct Env {
                     if (idx >= lo && idx < hi) ent_step(idx);
                 }
             }
-            PG_SYNC();
+            PG_SYNC_E();
             phase(11);
             if (sidx < 0) break;
             basic_step_object(sidx);
             ent_step(sidx);
-            PG_SYNC();
+            PG_SYNC_E();
             phase(12);
             hi = sidx;
         }
@@ -847,6 +1160,7 @@ struct Env {
 
     PG_DEV void check_grid_collisions(int ent) {  // BAG:145-165
         float ax = ex(ent), ay = ey(ent), arx = erx(ent), ary = ery(ent);
+        grid_window(ax, ay);
         int min_x = (int)(ax - (arx + POS_EPS));
         int max_x = (int)(ax + (arx + POS_EPS));
         int min_y = (int)(ay - (ary + POS_EPS));
@@ -862,6 +1176,32 @@ struct Env {
     // smart_step) are found by ballot and visited from the highest index down; predicates are re-evaluated
     // at visit time, and the ballot is refreshed after every handler (handlers may change geometry).
     PG_DEV void collision_pass() {
+        if constexpr (LANE) {
+            int i = G.n_ents - 1;
+            while (i >= 0) {
+                // every lane skips ahead to its next entity with anything to do (overlap with the agent, collides_with_entities,
+                // smart_step); the handlers then run side by side in all lanes
+                while (i >= 0) {
+                    const uint32_t mq = meta(i);
+                    if ((mq & (MF_COLLIDES | MF_SMART_STEP)) != 0 || has_agent_collision(i)) break;
+                    i--;
+                }
+                if (i < 0) break;
+                if (has_agent_collision(i)) Game::handle_agent_collision(*this, i);
+                const uint32_t mi = meta(i);
+                if constexpr (Game::USES_ENTITY_COLLISIONS) {
+                    if (mi & MF_COLLIDES) {
+                        for (int j = G.n_ents - 1; j >= 0; j--) {
+                            if (j == i) continue;
+                            if (has_collision_idx(i, j, ef(EF_COLLISION_MARGIN, i)) && !eflag(i, MF_WILL_ERASE) && !eflag(j, MF_WILL_ERASE)) Game::handle_collision(*this, i, j);
+                        }
+                    }
+                }
+                if (mi & MF_SMART_STEP) check_grid_collisions(i);
+                i--;
+            }
+            return;
+        }
         int limit = G.n_ents;
         while (limit > 0) {
             const int n = G.n_ents;
@@ -912,20 +1252,72 @@ struct Env {
                             hits &= ~(1ull << (j & 63));
                             if (!eflag(i, MF_WILL_ERASE) && !eflag(j, MF_WILL_ERASE)) {
                                 Game::handle_collision(*this, i, j);
-                                PG_SYNC();
+                                PG_SYNC_E();
                             }
                         }
                     }
                 }
             }
             if (eflag(i, MF_SMART_STEP)) check_grid_collisions(i);
-            PG_SYNC();
+            PG_SYNC_E();
             limit = i;
         }
     }
 
     // erase_if_needed BAG:748-756: stable compaction of the SoA table, field by field through LDS scratch.
     PG_DEV void erase_if_needed() {
+        if constexpr (LANE) {
+            const int n = G.n_ents;
+            int first = 0;  // entities below the first erased one stay where they are
+            while (first < n) {
+                const uint32_t mm = meta(first);
+                if ((mm & MF_WILL_ERASE) || ((mm & MF_AUTO_ERASE) && is_out_of_bounds(first))) break;
+                first++;
+            }
+            int kept = first, new_agent = G.agent;
+            constexpr int B = 2;  // entities moved per round (their 21-word loads in flight together)
+            for (int base = first; base < n; base += B) {
+                bool mv[B];
+                int dst[B];
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    const int i = base + k;
+                    mv[k] = false;
+                    dst[k] = kept;
+                    if (i < n) {
+                        const uint32_t mm = meta(i);
+                        const bool keep = !((mm & MF_WILL_ERASE) || ((mm & MF_AUTO_ERASE) && is_out_of_bounds(i)));
+                        if (i == G.agent) {
+                            if (keep) {
+                                new_agent = kept;
+                            } else {  // the detached agent stays readable in the reserved last slot
+                                for (int f = 0; f < EF_COUNT; f++) stw(f, CAP - 1, ldw(f, i));
+                                new_agent = CAP - 1;
+                            }
+                        }
+                        mv[k] = keep && kept != i;
+                        if (keep) kept++;
+                    }
+                }
+                uint32_t v[B][EF_COUNT];
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    const int i = base + k < n ? base + k : n - 1;
+#pragma unroll
+                    for (int f = 0; f < EF_COUNT; f++) v[k][f] = ldw(f, i);
+                }
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    if (mv[k]) {
+#pragma unroll
+                        for (int f = 0; f < EF_COUNT; f++) stw(f, dst[k], v[k][f]);
+                    }
+                }
+            }
+            G.n_ents = kept;
+            G.agent = new_agent;
+            return;
+        }
         const int n = G.n_ents;
         int kept = 0;
         int new_agent = G.agent;
@@ -954,21 +1346,21 @@ struct Env {
                 PG_FOR_LANES(l) {
                     if (l < EF_COUNT) s->tmp[l] = s->ent[l * CAP + src_i];
                 }
-                PG_SYNC();
+                PG_SYNC_E();
                 PG_FOR_LANES(l) {
                     if (l < EF_COUNT) s->ent[l * CAP + (CAP - 1)] = s->tmp[l];
                 }
-                PG_SYNC();
+                PG_SYNC_E();
                 new_agent = CAP - 1;
             }
             if (keep != valid || kept != base) {
                 for (int f = 0; f < EF_COUNT; f++) {
                     PG_FOR_LANES(l) { s->tmp[l] = s->ent[f * CAP + base + l]; }
-                    PG_SYNC();
+                    PG_SYNC_E();
                     PG_FOR_LANES(l) {
                         if (keep & (1ull << l)) s->ent[f * CAP + kept + pg_popc64(keep & pg_mask_lt(l))] = s->tmp[l];
                     }
-                    PG_SYNC();
+                    PG_SYNC_E();
                 }
             }
             kept += pg_popc64(keep);
@@ -1001,7 +1393,7 @@ struct Env {
             vrot += MIXRATEROT * MAXVTHETA * G.action_vrot;
             ef(EF_VROT, ag) = vrot;
         }
-        PG_SYNC();
+        PG_SYNC_E();
         phase(1);
         if (!(d.debug_flags & 64)) step_entities();
         phase(2);
@@ -1042,7 +1434,7 @@ struct Env {
         G.agent = ag;
         set_flag(ag, MF_SMART_STEP, true);
         set_render_z(ag, 1);
-        PG_SYNC();
+        PG_SYNC_E();
         erase_if_needed();
         fill_elem(0, 0, G.main_width, G.main_height, SPACE);
     }
@@ -1094,6 +1486,15 @@ struct Env {
     PG_DEV bool has_any_collision(int i, float margin) {
         const int n = G.n_ents;
         const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
+        if constexpr (LANE) {
+            for (int idx = 0; idx < n; idx++) {
+                if (meta(idx) & MF_AVOIDS) continue;
+                const float tx = (rx + erx(idx)) + margin;
+                const float ty = (ry + ery(idx)) + margin;
+                if ((pg_fabsf(x - ex(idx)) < tx) && (pg_fabsf(y - ey(idx)) < ty)) return true;
+            }
+            return false;
+        }
         for (int c = 0; c < ((n + 63) >> 6); c++) {
             const uint64_t m = PG_BALLOT(l, ({
                                              const int idx = (c << 6) + l;
@@ -1113,12 +1514,12 @@ struct Env {
         const float rx = erx(i), ry = ery(i);
         ex(i) = rand_pos(rx, x, x + w);
         ey(i) = rand_pos(ry, y, y + h);
-        PG_SYNC();
+        PG_SYNC_E();
         int count = 0;
         while ((has_agent_collision(i) || (check_collisions && has_any_collision(i, 0))) && (count < 100)) {
             ex(i) = rand_pos(rx, x, x + w);
             ey(i) = rand_pos(ry, y, y + h);
-            PG_SYNC();
+            PG_SYNC_E();
             count++;
         }
     }
@@ -1154,12 +1555,17 @@ struct Env {
             int next = randn(n);
             while ((PG_BALLOT(l, l < i && (int)s->tmp[l] == next) | PG_BALLOT(l, 64 + l < i && (int)s->tmp[64 + l] == next)) != 0) next = randn(n);
             s->tmp[i] = (uint32_t)next;
-            PG_SYNC();
+            PG_SYNC_E();
         }
     }
 
     PG_DEV bool agent_has_collision() {  // BAG:521-529
         const int n = G.n_ents;
+        if constexpr (LANE) {
+            for (int idx = 0; idx < n; idx++)
+                if (has_agent_collision(idx)) return true;
+            return false;
+        }
         for (int c = 0; c < ((n + 63) >> 6); c++)
             if (PG_BALLOT(l, ((c << 6) + l) < n && has_agent_collision((c << 6) + l))) return true;
         return false;
@@ -1170,7 +1576,7 @@ struct Env {
         do {
             ex(ag) = rand01() * (G.main_width - 2 * erx(ag)) + erx(ag);
             ey(ag) = rand01() * (G.main_height - 2 * ery(ag)) + ery(ag);
-            PG_SYNC();
+            PG_SYNC_E();
             count++;
         } while (agent_has_collision() && (count < 100));
     }
@@ -1182,7 +1588,7 @@ struct Env {
             return CAP - 2;
         }
         ent_init(i, 0, 0, 0, 0, rx, ry, type);
-        PG_SYNC();
+        PG_SYNC_E();
         reposition(i, x, y, w, h, check_collisions);
         G.n_ents = i + 1;
         return i;
@@ -1250,12 +1656,23 @@ struct Env {
             G.last_reward = G.reward;
         }
         G.prev_level_seed = G.current_level_seed;
-        if (G.done) {
-            game_reset_full();
-            phase(6);
+        if constexpr (LANE) {
+            // level generation is wave-structured: a finished episode goes to the reset kernel of this step (run(2))
+            needs_reset = G.done != 0;
+            if (needs_reset) return;
+        }
+        finish_step();
+    }
+    // the rest of Game::step once game_step has run (reference src/game.cpp:144-155)
+    PG_DEV void finish_step() {
+        if constexpr (!LANE) {
+            if (G.done) {
+                game_reset_full();
+                phase(6);
 #if !defined(PGAMD_WAVE_EMU)
-            if (d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 15 + 32 * (env & 4095), 1ull);
+                if (d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 15 + 32 * (env & 4095), 1ull);
 #endif
+            }
         }
         if (d.opt.use_sequential_levels && G.level_complete) G.done = 0;
         G.episode_done = G.done;
@@ -1281,33 +1698,41 @@ struct Env {
 
     // Game::observe minus the frame (reference src/game.cpp:160-164)
     PG_DEV void store_outputs() {
-        PG_FOR_LANES(l) {
-            if (l == 0) {
-                d.rew[env] = G.reward;
-                d.first[env] = (uint8_t)G.done;
-                d.prev_level_seed[env] = G.prev_level_seed;
-                d.prev_level_complete[env] = (uint8_t)G.level_complete;
-                d.level_seed[env] = G.current_level_seed;
+        if constexpr (LANE) {
+            d.rew[env] = G.reward;
+            d.first[env] = (uint8_t)G.done;
+            d.prev_level_seed[env] = G.prev_level_seed;
+            d.prev_level_complete[env] = (uint8_t)G.level_complete;
+            d.level_seed[env] = G.current_level_seed;
+        } else {
+            PG_FOR_LANES(l) {
+                if (l == 0) {
+                    d.rew[env] = G.reward;
+                    d.first[env] = (uint8_t)G.done;
+                    d.prev_level_seed[env] = G.prev_level_seed;
+                    d.prev_level_complete[env] = (uint8_t)G.level_complete;
+                    d.level_seed[env] = G.current_level_seed;
+                }
             }
         }
     }
 
     // ======================================================================================================
     // HBM <-> LDS staging of one env
-    PG_DEV void load_env() {
+    PG_DEV void load_env(bool with_entities = true) {
         {
             const EnvHdr *h = d.hdr + env;  // wave-uniform address
 #define PG_X(type, name) G.name = h->name;
             PG_HDR_FIELDS(PG_X)
 #undef PG_X
         }
-        const int n = G.n_ents;
-        const uint32_t *ge = d.ents + (size_t)env * EF_COUNT * d.ent_cap;
+        const int n = with_entities ? G.n_ents : 0;
+        const uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap);
         for (int base = 0; base < n; base += 64) {
             PG_FOR_LANES(l) {
                 if (base + l < n) {
                     uint32_t v[EF_COUNT];  // all field loads in flight before the first LDS store
-                    for (int f = 0; f < EF_COUNT; f++) v[f] = ge[f * d.ent_cap + base + l];
+                    for (int f = 0; f < EF_COUNT; f++) v[f] = ge[(size_t)(f * d.ent_cap + base + l) * TILE_ENVS];
                     for (int f = 0; f < EF_COUNT; f++) s->ent[f * CAP + base + l] = v[f];
                 }
             }
@@ -1323,16 +1748,16 @@ struct Env {
             }
         }
         G.grid_dirty = 0;
-        PG_SYNC();
+        PG_SYNC_E();
     }
     PG_DEV void store_env() {
         const int n = G.n_ents;
-        uint32_t *ge = d.ents + (size_t)env * EF_COUNT * d.ent_cap;
+        uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap);
         if (n > d.ent_cap - 1) fail(PGE_ENT_OVERFLOW);
         for (int f = 0; f < EF_COUNT; f++) {
             for (int base = 0; base < n; base += 64) {
                 PG_FOR_LANES(l) {
-                    if (base + l < n && base + l < d.ent_cap) ge[f * d.ent_cap + base + l] = s->ent[f * CAP + base + l];
+                    if (base + l < n && base + l < d.ent_cap) ge[(size_t)(f * d.ent_cap + base + l) * TILE_ENVS] = s->ent[f * CAP + base + l];
                 }
             }
         }
@@ -1347,11 +1772,7 @@ struct Env {
                 }
             }
         }
-        {
-            const int need = Game::slots_needed_next_step(*this);  // entity slots incl. growth of one step + the reserved one
-            G.big = need <= Game::ENT_CAP_T0 ? 0 : (need <= Game::ENT_CAP_T1 ? 1 : 2);
-            if (need > Game::ENT_CAP_T2) fail(PGE_ENT_OVERFLOW);
-        }
+        decide_route();
         publish_routing();
         {
             EnvHdr *h = d.hdr + env;
@@ -1365,14 +1786,44 @@ struct Env {
         }
     }
 
+    // which step kernel owns this env next step (EnvHdr::big -> route table)
+    PG_DEV void decide_route() {
+        bool lane_ok = false;
+        if constexpr (GameLane<Game>::value) {
+            // the lane = env kernel cannot twist a generator: it takes an env only while the draws of one step are
+            // certain to come from the current 624-word block (PROCGEN_AMD_DEBUG & 4096 keeps every env on the wave = env kernels)
+            lane_ok = G.rand_idx + GameLane<Game>::MAX_DRAWS <= MT_N && !(d.debug_flags & 4096) && G.n_ents <= d.lane_max_ents;
+            if (lane_ok) {
+                int smart = 0;
+                if constexpr (LANE) {
+                    smart = lane_smart_count;  // counted by step_entities
+                } else {
+                    const int n = G.n_ents;
+                    for (int c = 0; c < ((n + 63) >> 6); c++) smart += pg_popc64(PG_BALLOT(l, ((c << 6) + l) < n && (meta((c << 6) + l) & MF_SMART_STEP) != 0));
+                }
+                lane_ok = smart <= d.lane_max_smart;
+            }
+        }
+        if (LANE && lane_ok) {  // table growth is checked where entities are added (HBM capacity)
+            G.big = ROUTE_LANE;
+            return;
+        }
+        const int need = Game::slots_needed_next_step(*this);  // entity slots incl. growth of one step + the reserved one
+        int tier = need <= Game::ENT_CAP_T0 ? 0 : (need <= Game::ENT_CAP_T1 ? 1 : 2);
+        if (need > Game::ENT_CAP_T2) fail(PGE_ENT_OVERFLOW);
+        // the wave = env envs of a lane-stepped game all go through the list kernels (no grid over every env)
+        if constexpr (GameLane<Game>::value) tier = lane_ok ? ROUTE_LANE : (tier < 1 ? 1 : tier);
+        G.big = tier;
+    }
+
     // tell the next step which kernel owns this env, and surface error codes to the host
     PG_DEV void publish_routing() {
 #if defined(PGAMD_WAVE_EMU)
         if (G.error && d.error) *d.error |= G.error;
 #else
-        if (PG_LANE_ID() == 0) {
+        if (LANE || PG_LANE_ID() == 0) {
             if (d.next_route) d.next_route[env] = (uint8_t)G.big;
-            if (G.big) {
+            if (G.big == 1 || G.big == 2) {
                 const int t = G.big - 1;
                 const int slot = atomicAdd(d.next_big_count + t, 1);
                 d.next_big_list[(size_t)t * d.num_envs + slot] = env;
@@ -1382,19 +1833,22 @@ struct Env {
 #endif
     }
 
-    // one libenv step (mode 1) or the initial reset + first observation (mode 0) of this env
+    // wave = env: one libenv step (mode 1), the initial reset + first observation (mode 0), or the reset that finishes
+    // a step the lane = env kernel took up to the end of the episode (mode 2) of this env
     PG_DEV void run(int mode) {
 #if !defined(PGAMD_WAVE_EMU)
         if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
 #endif
-        load_env();
+        load_env(mode != 2);  // a reset starts from an empty entity table (whose old size may exceed this arena)
         phase(0);
-        if (mode != 0) G.action = d.action[env];  // reference src/vecgame.cpp:388
+        if (mode == 1) G.action = d.action[env];  // reference src/vecgame.cpp:388
         if (d.debug_flags & 512) {
             // ablation: staging only
         } else if (mode == 0) {
             game_reset_full();
             G.initial_reset_complete = 1;
+        } else if (mode == 2) {
+            finish_step();
         } else {
             game_step_full();
         }
@@ -1406,6 +1860,83 @@ struct Env {
         phase(8);
 #if !defined(PGAMD_WAVE_EMU)
         if (d.phase_cycles && mode != 0 && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 14 + 32 * (env & 4095), 1ull);
+#endif
+    }
+
+    // lane = env: one libenv step of this lane's env.  Game state is read and written in place in HBM; an episode
+    // that ends is queued for the wave = env reset kernel launched behind this one (run(2)).
+    PG_DEV void run_lane(int chunk, int chunk_base) {
+        static_assert(LANE, "run_lane is the lane = env entry point");
+        {
+            const EnvHdr *h = d.hdr + env;
+#define PG_X(type, name) G.name = h->name;
+            PG_HDR_FIELDS(PG_X)
+#undef PG_X
+        }
+        G.grid_dirty = 0;
+        G.action = d.action[env];
+#if !defined(PGAMD_WAVE_EMU)
+        if (d.phase_cycles) t_mark = t_start = (long long)__builtin_readcyclecounter();
+#endif
+        if (has_lds) {  // hot words of the first slots -> this lane's LDS column (all loads of a round in flight together)
+            const int nc = G.n_ents < LANE_CACHE_SLOTS ? G.n_ents : LANE_CACHE_SLOTS;
+            for (int base = 0; base < nc; base += 4) {
+                uint32_t v[4][LANE_CACHE_FIELDS];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = base + k < nc ? base + k : nc - 1;
+#pragma unroll
+                    for (int f = 0; f < LANE_CACHE_FIELDS; f++) v[k][f] = ew_hbm(f, i);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (base + k < nc) {
+#pragma unroll
+                        for (int f = 0; f < LANE_CACHE_FIELDS; f++) lcache[(f * LANE_CACHE_SLOTS + base + k) * TILE_ENVS] = v[k][f];
+                    }
+                }
+            }
+        }
+        phase(0);
+        game_step_full();
+        if (has_lds && !needs_reset) {  // ... and back (a reset starts from an empty table)
+            const int nc = G.n_ents < LANE_CACHE_SLOTS ? G.n_ents : LANE_CACHE_SLOTS;
+            for (int i = 0; i < nc; i++) {
+#pragma unroll
+                for (int f = 0; f < LANE_CACHE_FIELDS; f++) ew_hbm(f, i) = lcache[(f * LANE_CACHE_SLOTS + i) * TILE_ENVS];
+            }
+        }
+        if (needs_reset) {
+            G.big = ROUTE_RESET;  // (the reset kernel's store_env decides the next route)
+        } else {
+            prepare_for_drawing((float)RES_H);
+            store_outputs();
+            if (G.agent < 0 || G.agent >= G.n_ents) fail(PGE_ASSERT);
+            decide_route();
+            publish_routing();
+        }
+        {
+            EnvHdr *h = d.hdr + env;
+#define PG_X(type, name) h->name = G.name;
+            PG_HDR_FIELDS(PG_X)
+#undef PG_X
+        }
+        phase(8);
+#if !defined(PGAMD_WAVE_EMU)
+        if (d.phase_cycles) {
+            lane_count(14, 1);
+            lane_count(15, (unsigned long long)((long long)__builtin_readcyclecounter() - t_start), true);  // slowest wave-step of this wave slot
+            lane_count(13, (unsigned long long)lane_smart_count);  // (of the accounting lane)
+        }
+#endif
+#if !defined(PGAMD_WAVE_EMU)
+        if (needs_reset) {
+            if (G.error) atomicOr(d.error, G.error);
+            d.reset_list[chunk_base + atomicAdd(d.reset_count + chunk, 1)] = env;
+        }
+#else
+        (void)chunk;
+        (void)chunk_base;
 #endif
     }
 };

@@ -23,6 +23,8 @@
 #if defined(PGAMD_WAVE_EMU)
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #define PG_DEV inline
 // the lane a lane section is currently executing (-1: wave-uniform code); lets the emulation give
@@ -32,9 +34,20 @@ inline int &pg_emu_lane() {
     static thread_local int lane = -1;
     return lane;
 }
+// set by the harness while it runs a lane = env kernel body (pg_env.h LANE_MODE): there a lane owns its env, and a lane
+// section or ballot (which would span 64 different envs on the device) is a bug the CPU tests must catch
+inline bool &pg_emu_in_lane_kernel() {
+    static thread_local bool v = false;
+    return v;
+}
 struct PgEmuLaneScope {
     int saved;
-    PgEmuLaneScope() : saved(pg_emu_lane()) {}
+    PgEmuLaneScope() : saved(pg_emu_lane()) {
+        if (pg_emu_in_lane_kernel()) {
+            fprintf(stderr, "wave.h: lane section / ballot used inside a lane = env kernel\n");
+            abort();
+        }
+    }
     ~PgEmuLaneScope() { pg_emu_lane() = saved; }
 };
 #define PG_FOR_LANES(l) \
@@ -98,7 +111,12 @@ PG_DEV double pg_pow(double x, double y) { return pow(x, y); }  // glibc, as the
 #define PG_LV(v, l) v
 #define PG_LANE_ARR(T, v, N) T v[N]
 #define PG_LA(v, j, l) v[j]
-#define PG_READLANE(v, k) ((decltype(v))__builtin_amdgcn_readlane((int)(v), (k)))
+// 32-bit integer lane values only (a float would be value-converted, not bit-copied)
+#define PG_READLANE(v, k)                                                                                      \
+    ({                                                                                                         \
+        static_assert(__is_integral(decltype(v)) && sizeof(v) == 4, "PG_READLANE takes a 32-bit integer");    \
+        (decltype(v))__builtin_amdgcn_readlane((int)(v), (k));                                                 \
+    })
 // value known to be wave-uniform: move it to an SGPR so branches on it are scalar branches
 #define PG_UNIFORM_I(x) __builtin_amdgcn_readfirstlane((int)(x))
 PG_DEV int pg_popc64(uint64_t m) { return __popcll(m); }

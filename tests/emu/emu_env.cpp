@@ -36,6 +36,7 @@ struct EmuVec {
     int dev_error = 0;
     int game_id = -1;
     int kernel_id = -1;
+    long long lane_steps = 0, lane_resets = 0, wave_steps = 0;  // which execution model stepped the envs (tests assert both ran)
 };
 
 template <class Game, int CAP>
@@ -48,7 +49,32 @@ static void run_env(EmuVec *v, int env, int mode) {
 template <class Game>
 static void run_all(EmuVec *v, int mode) {
     for (int e = 0; e < v->n; e++) {  // "step kernels"
-        const int tier = v->use_small ? v->hdr[e].big : 2;
+        int tier = v->use_small ? v->hdr[e].big : 2;
+        if constexpr (GameLane<Game>::value) {
+            // "lane_step": the env's lane runs the step in place on the HBM arrays; an ended episode goes to "reset_list"
+            // (use_small = 0 keeps every env on the wave = env kernels, like PROCGEN_AMD_DEBUG & 4096 on the device)
+            if (mode == 1 && tier == ROUTE_LANE) {
+                pg_emu_in_lane_kernel() = true;
+                {
+                    static LaneLds<typename Game::cell_t> cache;  // the lane's LDS columns (lane = env index within its tile)
+                    Env<Game, Game::ENT_CAP_T2, true> le(v->d, e, nullptr);
+                    le.lcache = cache.c + (e % TILE_ENVS);
+                    le.lwin = cache.win + (e % TILE_ENVS);
+                    le.lcand = cache.cand + (e % TILE_ENVS);
+                    le.has_lds = true;
+                    le.run_lane(0, 0);
+                }
+                pg_emu_in_lane_kernel() = false;
+                v->lane_steps++;
+                if (v->hdr[e].big == ROUTE_RESET) {
+                    v->lane_resets++;
+                    run_env<Game, Game::ENT_CAP_T0>(v, e, 2);
+                }
+                continue;
+            }
+            if (tier == ROUTE_LANE) tier = 0;  // (mode 0: everything starts in the tier-0 grid)
+        }
+        if (mode == 1) v->wave_steps++;
         if (tier == 0) run_env<Game, Game::ENT_CAP_T0>(v, e, mode);
         else if (tier == 1) run_env<Game, Game::ENT_CAP_T1>(v, e, mode);
         else run_env<Game, Game::ENT_CAP_T2>(v, e, mode);
@@ -95,7 +121,7 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
 #undef PG_X
     v->hdr.resize(num_envs);
     v->rng.assign((size_t)num_envs * MT_SLOTS * MT_STRIDE, 0);
-    v->ents.assign((size_t)num_envs * EF_COUNT * ent_cap, 0);
+    v->ents.assign(ent_table_words(num_envs, ent_cap), 0);
     v->grid.assign((size_t)num_envs * grid_bytes, 0);
     v->obs.assign((size_t)num_envs * OBS_BYTES, 0);
     v->first.assign(num_envs, 0);
@@ -120,7 +146,10 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.opt.distribution_mode = distribution_mode;
     d.opt.use_sequential_levels = use_sequential_levels;
     d.opt.debug_mode = debug_mode;
-    if (const char *dbg = getenv("PROCGEN_AMD_DEBUG")) d.debug_flags = atoi(dbg);  // e.g. 1024: renderer without the pull form (per-cell blits)
+    if (const char *dbg = getenv("PROCGEN_AMD_DEBUG")) d.debug_flags = atoi(dbg);
+    d.lane_max_ents = getenv("PROCGEN_AMD_LANE_ENTS") ? atoi(getenv("PROCGEN_AMD_LANE_ENTS")) : LANE_MAX_ENTS;
+    d.lane_max_smart = getenv("PROCGEN_AMD_LANE_SMART") ? atoi(getenv("PROCGEN_AMD_LANE_SMART")) : LANE_MAX_SMART;
+    if (!use_small) d.debug_flags |= 4096;  // no lane = env routing either: every env on the largest wave = env arena  // e.g. 1024: renderer without the pull form (per-cell blits)
     level_seed_range(num_levels, start_level, &d.opt.level_seed_low, &d.opt.level_seed_high);
     d.hdr = v->hdr.data();
     d.rng = v->rng.data();
@@ -167,7 +196,8 @@ static void emu_snapshot(EmuVec *v, int env, EnvSnapshot *s) {
     const int cap = v->d.ent_cap;
     s->hdr = v->hdr[env];
     s->ent_cap = cap;
-    s->ents.assign(v->ents.begin() + (size_t)env * EF_COUNT * cap, v->ents.begin() + (size_t)(env + 1) * EF_COUNT * cap);
+    s->ents.resize((size_t)EF_COUNT * cap);
+    for (int k = 0; k < EF_COUNT * cap; k++) s->ents[k] = v->ents[ent_tile_base(env, cap) + (size_t)k * TILE_ENVS];
     s->rng.assign(v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE, v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE + 2 * MT_STRIDE);
     s->grid.assign(v->grid.begin() + (size_t)env * v->d.grid_bytes, v->grid.begin() + (size_t)(env + 1) * v->d.grid_bytes);
 }
@@ -196,7 +226,7 @@ int emu_set_state(void *h, int env, const char *data, int length) {
     s.hdr.big = 2;  // the emulation picks the arena from this field alone; the largest arena is always safe
     const int cap = v->d.ent_cap;
     v->hdr[env] = s.hdr;
-    std::copy(s.ents.begin(), s.ents.end(), v->ents.begin() + (size_t)env * EF_COUNT * cap);
+    for (int k = 0; k < EF_COUNT * cap; k++) v->ents[ent_tile_base(env, cap) + (size_t)k * TILE_ENVS] = s.ents[k];
     std::copy(s.rng.begin(), s.rng.end(), v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE);
     std::copy(s.grid.begin(), s.grid.end(), v->grid.begin() + (size_t)env * v->d.grid_bytes);
     v->rew[env] = s.hdr.reward;
@@ -227,6 +257,12 @@ void emu_sincos_array(const double *x, double *s, double *c, int n) {
         c[i] = pg_cos_d(x[i]);
     }
 }
+void emu_path_counts(void *h, long long *out) {
+    EmuVec *v = (EmuVec *)h;
+    out[0] = v->lane_steps;
+    out[1] = v->lane_resets;
+    out[2] = v->wave_steps;
+}
 int emu_error(void *h, int env) { return ((EmuVec *)h)->hdr[env].error | ((EmuVec *)h)->dev_error; }
 int emu_num_entities(void *h, int env) { return ((EmuVec *)h)->hdr[env].n_ents; }
 int emu_is_big(void *h, int env) { return ((EmuVec *)h)->hdr[env].big; }
@@ -234,11 +270,11 @@ int emu_is_big(void *h, int env) { return ((EmuVec *)h)->hdr[env].big; }
 void emu_dump_entities(void *h, int env, int32_t *out) {
     EmuVec *v = (EmuVec *)h;
     const int cap = v->d.ent_cap;
-    const uint32_t *e = v->ents.data() + (size_t)env * EF_COUNT * cap;
-    auto W = [&](int f, int i) { return (int32_t)e[f * cap + i]; };
+    const uint32_t *e = v->ents.data() + ent_tile_base(env, cap);
+    auto W = [&](int f, int i) { return (int32_t)e[(size_t)(f * cap + i) * TILE_ENVS]; };
     for (int i = 0; i < v->hdr[env].n_ents; i++) {
         int32_t *o = out + 31 * i;
-        const uint32_t m = e[EF_META * cap + i];
+        const uint32_t m = (uint32_t)W(EF_META, i);
         int k = 0;
         o[k++] = W(EF_X, i); o[k++] = W(EF_Y, i); o[k++] = W(EF_VX, i); o[k++] = W(EF_VY, i); o[k++] = W(EF_RX, i); o[k++] = W(EF_RY, i);
         o[k++] = meta_type(m); o[k++] = meta_image_type(m); o[k++] = meta_image_theme(m); o[k++] = meta_render_z(m);

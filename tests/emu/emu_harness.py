@@ -41,6 +41,7 @@ def lib():
             getattr(L, f).argtypes = [C.c_void_p, C.c_int]
         L.emu_get_state.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
         L.emu_set_state.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+        L.emu_path_counts.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_dump_entities.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_dump_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
@@ -109,6 +110,12 @@ class EmuEnv:
     def set_state(self, states):
         for e, st in enumerate(states):
             assert self.L.emu_set_state(self.h, e, st, len(st)) == 0
+
+    def path_counts(self):
+        """(env-steps taken by the lane = env kernel, of which ended an episode -> reset kernel, env-steps taken by the wave = env kernels)"""
+        out = (C.c_longlong * 3)()
+        self.L.emu_path_counts(self.h, out)
+        return tuple(out)
 
     def is_big(self, env):
         return self.L.emu_is_big(self.h, env)

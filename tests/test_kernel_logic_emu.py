@@ -35,6 +35,36 @@ def test_emulated_kernels_match_oracle(game, use_small):
             emu.act(acts[t])
 
 
+def noop_heavy_actions(n, steps, seed, p_noop=0.97):
+    """Mostly action 4 (stand still), so episodes live until `cur_time >= timeout` (reference src/game.cpp:134)."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(steps):
+        a = rng.randint(0, 15, size=(n,), dtype=np.int32)
+        a[rng.rand(n) < p_noop] = 4
+        out.append(a)
+    return out
+
+
+@pytest.mark.parametrize("game,steps", [("coinrun", 1100)])
+def test_lane_env_kernel_over_timeouts_twists_and_resets(game, steps):
+    """Games with a lane = env step path (pg_env.h LANE_MODE): a rollout long enough that episodes reach their timeout,
+    rand_gen crosses a 624-word block (those steps fall back to the wave = env kernel, which can twist) and the reset
+    kernel takes over episodes the lane kernel ended -- bit-exact against the oracle, with all three paths exercised."""
+    n = 8
+    acts = noop_heavy_actions(n, steps, seed=21)
+    orc = oracle_env.OracleEnv(n, game, rand_seed=23)
+    emu = emu_harness.EmuEnv(n, game, rand_seed=23)
+    a = rollout(orc, acts)
+    b = rollout(emu, acts)
+    assert_rollouts_equal(a, b, f"lane path, long horizon ({game})")
+    for e in range(n):
+        assert np.array_equal(orc.entities(e), emu.entities(e)) and np.array_equal(orc.grid(e), emu.grid(e))
+    lane, lane_resets, wave = emu.path_counts()
+    assert lane > 0.5 * n * steps and lane_resets > 0 and wave > 0, (lane, lane_resets, wave)
+    assert a["first"][1000:1002].any(), "an episode must have ended by timeout"
+
+
 @pytest.mark.parametrize("game", ["coinrun", "chaser", "dodgeball"])
 @pytest.mark.parametrize("kw", [dict(use_monochrome_assets=True), dict(paint_vel_info=True), dict(use_monochrome_assets=True, restrict_themes=True, use_backgrounds=False)])
 def test_emulated_option_surface_monochrome_and_vel_info(game, kw):
