@@ -14,8 +14,11 @@ logical vector of N*65536 (env_offset = rank*65536, no collective on the data pa
 Extra objects on the JSON line:
   roofline     : algorithmic bytes (12306 B per env-step) / mean device time of one step's kernels
                  (HIP events on the library's stream, procgen_amd_time_steps) against the 8 TB/s HBM peak.
-  cpu_baseline : the compiled reference (oracle/_ref, all host cores) or the plain-C oracle port (1 core) timed
-                 on a bounded sample of the same workload on this box's host cores (rank 0, N=1 only).
+  cpu_baseline : the compiled reference (oracle/_ref; best of a sweep over its worker pool sizes and over independent
+                 processes) or the plain-C oracle port (1 core) timed on a bounded sample of the same workload on this
+                 box's host cores (rank 0, N=1 only).
+  host_landed  : the PCIe-inclusive rate of the same loop through the unmodified libenv ABI (observations copied into
+                 the caller's host array every step) -- reported beside `value`, never as it.
 """
 import argparse
 import ctypes as C
@@ -35,36 +38,76 @@ ALGO_BYTES_PER_ENV_STEP = 12288 + 4 + 1 + 9 + 4  # obs + reward + first + info +
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(game="coinrun", budget_s=15.0):
-    """Reported baseline, not the optimisation target."""
+def _ref_rate(game, n, num_threads, seconds):
+    """env steps/sec of the compiled reference on n envs (this process)."""
     import ref_env
 
-    if ref_env.available():
-        cores = os.cpu_count() or 1
-        n = 1024
-        env = ref_env.make_ref_env(n, game, rand_seed=23, num_threads=cores)
-        kind, label = "reference", f"compiled reference C++/Qt (oracle/_ref), num_threads={cores}"
-    else:
-        import oracle_env
-
-        cores, n = 1, 256
-        env = oracle_env.OracleEnv(n, game, rand_seed=23)
-        kind, label = "port", "plain-C oracle port, single thread"
+    env = ref_env.make_ref_env(n, game, rand_seed=23, num_threads=num_threads)
     rng = np.random.RandomState(0)
     env.observe()
-    for _ in range(5):
+    for _ in range(3):
         env.act(rng.randint(0, 15, size=(n,), dtype=np.int32))
         env.observe()
     t0 = time.perf_counter()
     steps = 0
-    while time.perf_counter() - t0 < budget_s:
+    while time.perf_counter() - t0 < seconds:
         env.act(rng.randint(0, 15, size=(n,), dtype=np.int32))
         env.observe()
         steps += 1
     dt = time.perf_counter() - t0
     env.close()
-    return {"value": round(n * steps / dt, 1), "unit": "env steps/sec", "cores": cores, "kind": kind,
-            "sample": f"{game} num_envs={n}, {steps} steps, random actions, {label}"}
+    return n * steps / dt, steps
+
+
+def cpu_baseline(game="coinrun", budget_s=24.0):
+    """Reported baseline, not the optimisation target: the best of a small sweep over how the reference can use this box's
+    host cores -- its own worker pool (num_threads in {4, 16, 64, cores}) on one 1024-env vector, and P independent
+    processes each stepping its own vector inline (num_threads = 0), which avoids the pool's mutex round trip per env."""
+    import ref_env
+
+    if not ref_env.available():
+        import oracle_env
+
+        n = 256
+        env = oracle_env.OracleEnv(n, game, rand_seed=23)
+        rng = np.random.RandomState(0)
+        env.observe()
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < min(budget_s, 15.0):
+            env.act(rng.randint(0, 15, size=(n,), dtype=np.int32))
+            env.observe()
+            steps += 1
+        dt = time.perf_counter() - t0
+        env.close()
+        return {"value": round(n * steps / dt, 1), "unit": "env steps/sec", "cores": 1, "kind": "port",
+                "sample": f"{game} num_envs={n}, {steps} steps, random actions, plain-C oracle port, single thread"}
+    cores = os.cpu_count() or 1
+    slot = budget_s / 6.0
+    tried = {}
+    for nt in sorted({4, 16, 64, cores}):
+        if nt <= cores:
+            tried[f"pool num_threads={nt}"] = (_ref_rate(game, 1024, nt, slot)[0], nt)
+    # P processes x inline stepping
+    import subprocess
+
+    procs = min(cores, 64)
+    code = (f"import sys; sys.path.insert(0, {os.path.join(REPO, 'oracle')!r}); sys.path.insert(0, {REPO!r}); import bench; "
+            f"print(bench._ref_rate({game!r}, 64, 0, {slot})[0])")
+    ps = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(procs)]
+    rates = []
+    for p_ in ps:
+        out, _ = p_.communicate()
+        try:
+            rates.append(float(out.strip().splitlines()[-1]))
+        except (ValueError, IndexError):
+            pass
+    if rates:
+        tried[f"{len(rates)} processes x num_threads=0 (64 envs each)"] = (sum(rates), len(rates))
+    best = max(tried, key=lambda k: tried[k][0])
+    return {"value": round(tried[best][0], 1), "unit": "env steps/sec", "cores": tried[best][1], "kind": "reference",
+            "sample": f"{game}, random actions, compiled reference C++/Qt (oracle/_ref), best of a sweep with ~{slot:.0f} s per point on a {cores}-core host: {best}",
+            "sweep": {k: round(v[0], 1) for k, v in tried.items()}}
 
 
 ALL_GAMES = ["bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot", "heist", "jumper", "leaper", "maze", "miner",
@@ -127,7 +170,26 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # dominant kernel: device time of one step's kernels, HIP events on the library's own stream
+    # the same loop with the observations landed in the caller's (pinned) host array through the unmodified libenv ABI:
+    # the PCIe-inclusive rate (never `value`), on a bounded number of steps
+    host_landed = None
+    if not joint and not args.host_landed and world == 1:
+        env._lib.procgen_amd_set_host_observations.argtypes = [C.c_void_p, C.c_int]
+        env._lib.procgen_amd_set_host_observations(env._handle, 1)
+        hl_steps = min(args.steps, 40)
+        for t in range(3):
+            env.act(acts[t])
+            env.observe()
+        t1 = time.perf_counter()
+        for t in range(hl_steps):
+            env.act(acts[t])
+            env.observe()
+        hl_dt = time.perf_counter() - t1
+        host_landed = {"value": round(n * hl_steps / hl_dt, 1), "unit": "env steps/sec", "ms_per_step": round(hl_dt / hl_steps * 1e3, 4), "steps": hl_steps,
+                       "note": "observations copied D2H into the caller's registered host array every step (libenv ABI as gym3 uses it); PCIe Gen5 x16 bounds this at ~5.1 M steps/s per GPU"}
+        env._lib.procgen_amd_set_host_observations(env._handle, 0)
+
+    # dominant kernel: device time of one step's launch sequence, HIP events on the library's own stream
     env._lib.procgen_amd_time_steps.restype = C.c_double
     env._lib.procgen_amd_time_steps.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     k_steps = min(50, args.steps)
@@ -158,12 +220,14 @@ def main():
                        "num_envs_per_gpu": n, "sharding": f"env_offset shards x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "launch": "one step = step_small + step_big + render kernels over all envs of this GPU",
+                         "launch": "one step = exactly what libenv_act enqueues (counter memset, step grids + list kernels, render kernels) over all envs of this GPU",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "kernel_ms_per_step": round(kernel_ms, 4), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
         }
         if joint:
             line["roofline"]["launch"] = "one step = the step + render kernels of all games of the joint handle (wall time of the step, kernels of different games overlap)"
+        if host_landed is not None:
+            line["host_landed"] = host_landed
         if world == 1 and not args.no_cpu_baseline and not joint:
             line["cpu_baseline"] = cpu_baseline(args.game)
         print(json.dumps(line), flush=True)

@@ -42,6 +42,8 @@ def lib():
         L.pgo_set_image.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.pgo_make.restype = C.c_void_p
         L.pgo_make.argtypes = [C.c_int, C.c_int, C.POINTER(PgoOptions)]
+        L.pgo_make_strided.restype = C.c_void_p
+        L.pgo_make_strided.argtypes = [C.c_int, C.c_int, C.POINTER(PgoOptions), C.c_int, C.c_int]
         L.pgo_free.argtypes = [C.c_void_p]
         L.pgo_init.argtypes = [C.c_void_p]
         L.pgo_step.argtypes = [C.c_void_p, C.c_void_p]
@@ -115,14 +117,15 @@ class OracleEnv:
 
     def __init__(self, num, env_name, rand_seed=0, num_levels=0, start_level=0, distribution_mode=1,
                  center_agent=True, use_backgrounds=True, use_monochrome_assets=False, restrict_themes=False,
-                 paint_vel_info=False, use_sequential_levels=False, debug_mode=0, resource_root=None, atlas_path=None):
+                 paint_vel_info=False, use_sequential_levels=False, debug_mode=0, resource_root=None, atlas_path=None,
+                 env_offset=0, env_stride=1):
         self.L = lib()
         self.gid = load_images(env_name, resource_root, atlas_path)
         self.num = num
         o = PgoOptions(rand_seed, num_levels, start_level, distribution_mode, int(center_agent), int(use_backgrounds),
                        int(use_monochrome_assets), int(restrict_themes), 0, int(paint_vel_info),
                        int(use_sequential_levels), debug_mode)
-        self.h = C.c_void_p(self.L.pgo_make(self.gid, num, C.byref(o)))
+        self.h = C.c_void_p(self.L.pgo_make_strided(self.gid, num, C.byref(o), env_offset, env_stride))
         self.rgb = np.zeros((num, 64, 64, 3), np.uint8)
         self.rew = np.zeros(num, np.float32)
         self.first = np.zeros(num, np.uint8)

@@ -4855,7 +4855,12 @@ static void game_construct(Game *g, int game_id, const PgoOptions *opt) {
     }
 }
 
-PgoVec *pgo_make(int game_id, int num_envs, const PgoOptions *opt) {
+PgoVec *pgo_make(int game_id, int num_envs, const PgoOptions *opt) { return pgo_make_strided(game_id, num_envs, opt, 0, 1); }
+
+/* oracle env k is env (env_offset + k * env_stride) of the logical vector: env n's level-seed generator is seeded with
+ * the n-th raw draw of RandGen(rand_seed) whatever num_envs is (src/vecgame.cpp:301-314), so a strided sample of a
+ * large vector -- e.g. the envs of one game of a joint handle -- can be replayed without simulating the rest */
+PgoVec *pgo_make_strided(int game_id, int num_envs, const PgoOptions *opt, int env_offset, int env_stride) {
     assets_build(game_id);
     if (opt->use_generated_assets) fatal("use_generated_assets is out of scope");
     PgoVec *v = (PgoVec *)calloc(1, sizeof(PgoVec));
@@ -4871,10 +4876,13 @@ PgoVec *pgo_make(int game_id, int num_envs, const PgoOptions *opt) {
     }
     Rng seedgen; /* src/vecgame.cpp:301-314 */
     rng_seed(&seedgen, opt->rand_seed);
+    if (env_offset < 0 || env_stride < 1) fatal("pgo_make_strided: bad offset / stride");
+    for (int skip = 0; skip < env_offset; skip++) (void)rng_randint_raw(&seedgen);
     for (int n = 0; n < num_envs; n++) {
         Game *g = &v->games[n];
         game_construct(g, game_id, opt);
         rng_seed(&g->level_seed_rand_gen, rng_randint_raw(&seedgen));
+        for (int skip = 1; skip < env_stride; skip++) (void)rng_randint_raw(&seedgen);
         g->level_seed_low = lo;
         g->level_seed_high = hi;
     }

@@ -48,6 +48,8 @@ int pgo_image_is_background(int game_id, int idx);
 void pgo_set_image(int game_id, int idx, int w, int h, const uint32_t *px); /* copies */
 
 PgoVec *pgo_make(int game_id, int num_envs, const PgoOptions *opt);
+/* oracle env k = env (env_offset + k * env_stride) of the logical vector (a shard, or the envs of one game of a joint handle) */
+PgoVec *pgo_make_strided(int game_id, int num_envs, const PgoOptions *opt, int env_offset, int env_stride);
 void pgo_free(PgoVec *v);
 
 /* Initial reset + first observation of every env (reference src/vecgame.cpp:346-357). */

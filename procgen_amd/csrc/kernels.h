@@ -7,14 +7,16 @@
 
 namespace pgamd {
 struct LaunchStreams {
-    hipStream_t main, side;   // side: large-arena step kernel, concurrent with the small-arena one
-    hipEvent_t fork, join;
+    hipStream_t main;
+    hipEvent_t fork;
     hipStream_t lane[2];      // env chunks alternate between these two streams (step of chunk c+1 overlaps render of chunk c)
+    hipStream_t side[3];      // [0]: lane = env kernel + reset kernel of a game with a lane path, concurrent with the tier-0 grids of the chunks
     hipEvent_t lane_done[2];
-    hipEvent_t tier2_done;    // the tier-2 list kernel runs on lane[1] ahead of that lane's chunk
+    hipEvent_t side_done[3];
     int chunks;               // 1 = everything on `main`
-    int list_count[2] = {-1, -1};  // entries of the tier-1 / tier-2 lists this step reads, when the host knows them: an empty list's kernel is not launched
+    int list_count[MAX_CHUNKS][NUM_TIERS];  // entries of the lists this step reads (the host knows them from the previous step's download): an empty list's kernel is not launched
 };
+int chunk_envs_for(int num_envs, int chunks);  // envs per chunk: whole tiles; one chunk below 4096 envs
 // what one per-game kernel object (kernels_game.hip) exports
 struct GameEntry {
     int game_id;

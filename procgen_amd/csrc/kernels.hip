@@ -26,6 +26,11 @@ hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t 
     const GameEntry *e = find(game_id);
     return e ? e->render_one(d, env, stream) : hipErrorInvalidValue;
 }
+int chunk_envs_for(int num_envs, int chunks) {
+    const int nchunk = (chunks > 1 && num_envs >= 4096) ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1;
+    const int per = ((num_envs + nchunk - 1) / nchunk + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;
+    return per > 0 ? per : TILE_ENVS;
+}
 bool game_supported(int game_id) { return find(game_id) != nullptr; }
 bool game_has_lane(int game_id) {
     const GameEntry *e = find(game_id);

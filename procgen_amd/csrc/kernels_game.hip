@@ -38,10 +38,10 @@ __global__ __launch_bounds__(64) void step_tier0(DevCtx d, int mode, int env_bas
 }
 
 template <class Game, int CAP, int TIER>
-__global__ __launch_bounds__(64) void step_list(DevCtx d, int mode) {
+__global__ __launch_bounds__(64) void step_list(DevCtx d, int mode, int chunk) {
     __shared__ Lds<Game, CAP> lds;
-    const int count = d.big_count[TIER - 1];
-    const int *list = d.big_list + (size_t)(TIER - 1) * d.num_envs;
+    const int count = d.big_count[chunk * NUM_TIERS + TIER];
+    const int *list = d.big_list + (size_t)TIER * d.num_envs + (size_t)chunk * d.chunk_envs;
     for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
         const int env = list[k];
         if (d.route[env] != TIER) continue;  // set_state moved this env to another tier after the list was built
@@ -91,26 +91,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GameRenderMi
     r.render_env();
 }
 
-// The two step kernels touch disjoint envs, so the (few, slow, low-occupancy) large-arena envs run on a side
-// stream concurrently with the small-arena grid.  The env range is further cut into chunks that alternate between
-// two streams: the latency-bound step kernel of one chunk shares the CUs with the issue-bound render kernel of the
-// previous chunk instead of the two phases running back to back.
-// the step work of the envs [base, base + count) on one stream: the tier-0 grid, or (games with a lane = env path) the lane
-// kernel and the reset kernel behind it
-template <class Game>
-static void launch_chunk_step(const DevCtx &d, int mode, int chunk, int base, int count, hipStream_t st) {
-    if constexpr (GameLane<Game>::value) {
-        if (mode != 0) {
-            if (d.debug_flags & 32) return;
-            hipLaunchKernelGGL(lane_step<Game>, dim3((count + TILE_ENVS - 1) / TILE_ENVS), dim3(64), 0, st, d, chunk, base, base + count);
-            const int rg = count < 512 ? count : 512;
-            hipLaunchKernelGGL(reset_list<Game>, dim3(rg), dim3(64), 0, st, d, chunk, base);
-            return;
-        }
-    }
-    if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(count), dim3(64), 0, st, d, mode, base);
-}
-
+// One step of a handle.  The envs are stepped by up to four kinds of kernel that touch disjoint envs (route table):
+//   * step_tier0 grids over env chunks -- chunk c on stream lane[c & 1], followed by the chunk's render kernel, so the
+//     latency-bound step work of one chunk shares the CUs with the issue-bound render kernel of its neighbour;
+//   * the tier-1 and tier-2 list kernels (larger LDS arenas), each on a side stream;
+//   * for games with a lane = env path, lane_step over all tiles + the reset kernel for the episodes it ended, on a
+//     third side stream.
+// A chunk's render kernel waits for the side streams (their envs lie in every chunk).
 template <class Game>
 static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls) {
 #define PG_TRY(x)                          \
@@ -118,53 +105,79 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         hipError_t e_ = (x);               \
         if (e_ != hipSuccess) return e_;   \
     } while (0)
+    const int *cnt = ls.list_count[0];
+    const bool t1 = mode != 0 && cnt[1] != 0, t2 = mode != 0 && cnt[2] != 0;
+    const bool lane = GameLane<Game>::value && d.ent_tile == TILE_ENVS && mode != 0 && !(d.debug_flags & 32);
+    const int g1 = cnt[1] < 0 || cnt[1] > 8192 ? (d.num_envs < 8192 ? d.num_envs : 8192) : cnt[1];
+    const int g2 = cnt[2] < 0 || cnt[2] > 2048 ? (d.num_envs < 2048 ? d.num_envs : 2048) : cnt[2];
+    const int tiles = (d.num_envs + TILE_ENVS - 1) / TILE_ENVS;
+    const int rg = d.num_envs < 1024 ? d.num_envs : 1024;
     if (d.num_envs < 4096) {
-        // Small handles (and the 16 parts of a joint handle, each with its own streams): the kernels are far too short
-        // for tier / chunk concurrency to matter, while every cross-stream event costs tens of microseconds and the
-        // runtime multiplexes all streams of the process onto a few hardware queues.  Everything goes down one stream.
-        if (mode != 0) {
-            const int g1 = d.num_envs < 8192 ? d.num_envs : 8192, g2 = d.num_envs < 2048 ? d.num_envs : 2048;
-            if (ls.list_count[0] != 0) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.main, d, mode);
-            if (ls.list_count[1] != 0) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.main, d, mode);
+        // Small handles (and the parts of a joint handle, each with its own stream): the kernels are far too short for
+        // concurrency to matter, while every cross-stream event costs tens of microseconds and the runtime multiplexes
+        // all streams of the process onto a few hardware queues.  Everything goes down one stream.
+        if (t1) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.main, d, mode, 0);
+        if (t2) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.main, d, mode, 0);
+        if constexpr (GameLane<Game>::value) {
+            if (lane) {
+                hipLaunchKernelGGL(lane_step<Game>, dim3(tiles), dim3(64), 0, ls.main, d, 0, 0, d.num_envs);
+                hipLaunchKernelGGL(reset_list<Game>, dim3(rg), dim3(64), 0, ls.main, d, 0, 0);
+            }
         }
-        launch_chunk_step<Game>(d, mode, 0, 0, d.num_envs, ls.main);
+        if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode, 0);
         if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, 0);
         return hipGetLastError();
     }
-    PG_TRY(hipEventRecord(ls.fork, ls.main));
-    if (mode != 0) {
-        PG_TRY(hipStreamWaitEvent(ls.side, ls.fork, 0));
-        const int g1 = d.num_envs < 8192 ? d.num_envs : 8192, g2 = d.num_envs < 2048 ? d.num_envs : 2048;
-        // the two list kernels run on their own streams (lane[1] is otherwise idle when chunks == 1)
-        PG_TRY(hipStreamWaitEvent(ls.lane[1], ls.fork, 0));
-        if (ls.list_count[0] != 0) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.side, d, mode);
-        if (ls.list_count[1] != 0) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.lane[1], d, mode);
-        PG_TRY(hipEventRecord(ls.tier2_done, ls.lane[1]));
-        PG_TRY(hipStreamWaitEvent(ls.side, ls.tier2_done, 0));
-        PG_TRY(hipEventRecord(ls.join, ls.side));
+    // Four streams in all: the runtime deals a process's streams round-robin onto four hardware queues, and two streams on one
+    // queue run their kernels one after the other (measured with six streams: the lane kernel and a chunk's grid serialised).
+    //   main    : tier-1 list          lane[1] : tier-2 list, then chunk 1, 3, ...
+    //   side[0] : lane_step + reset    lane[0] : chunk 0, 2, ...
+    if constexpr (GameLane<Game>::value) {
+        if (lane && (d.debug_flags & 16384)) {  // experiment: the lane kernel alone at the head of the step, everything else behind it
+            hipLaunchKernelGGL(lane_step<Game>, dim3(tiles), dim3(64), 0, ls.main, d, 0, 0, d.num_envs);
+            hipLaunchKernelGGL(reset_list<Game>, dim3(rg), dim3(64), 0, ls.main, d, 0, 0);
+        }
     }
-    const int nchunk = (ls.chunks > 1 && d.num_envs >= 4096) ? ls.chunks : 1;
-    const int per = ((d.num_envs + nchunk - 1) / nchunk + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;  // whole tiles
+    PG_TRY(hipEventRecord(ls.fork, ls.main));
+    if (t1) {
+        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.main, d, mode, 0);
+        PG_TRY(hipEventRecord(ls.side_done[0], ls.main));
+    }
+    PG_TRY(hipStreamWaitEvent(ls.lane[0], ls.fork, 0));
+    PG_TRY(hipStreamWaitEvent(ls.lane[1], ls.fork, 0));
+    if (t2) {
+        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.lane[1], d, mode, 0);
+        PG_TRY(hipEventRecord(ls.side_done[1], ls.lane[1]));
+    }
+    const bool lane_side = lane && !(d.debug_flags & 16384);
+    if constexpr (GameLane<Game>::value) {
+        if (lane_side) {
+            PG_TRY(hipStreamWaitEvent(ls.side[0], ls.fork, 0));
+            hipLaunchKernelGGL(lane_step<Game>, dim3(tiles), dim3(64), 0, ls.side[0], d, 0, 0, d.num_envs);
+            hipLaunchKernelGGL(reset_list<Game>, dim3(rg), dim3(64), 0, ls.side[0], d, 0, 0);
+            PG_TRY(hipEventRecord(ls.side_done[2], ls.side[0]));
+        }
+    }
+    const int nchunk = ls.chunks > 1 ? (ls.chunks < MAX_CHUNKS ? ls.chunks : MAX_CHUNKS) : 1;
+    const int per = ((d.num_envs + nchunk - 1) / nchunk + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;
     for (int c = 0; c < nchunk; c++) {
         const int base = c * per;
         const int count = (d.num_envs - base) < per ? (d.num_envs - base) : per;
         if (count <= 0) break;
-        hipStream_t st = nchunk == 1 ? ls.main : ls.lane[c & 1];
-        if (nchunk > 1 && c < 2) PG_TRY(hipStreamWaitEvent(st, ls.fork, 0));
-        launch_chunk_step<Game>(d, mode, c, base, count, st);
-        if (mode != 0) PG_TRY(hipStreamWaitEvent(st, ls.join, 0));
+        hipStream_t st = ls.lane[c & 1];
+        if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(count), dim3(64), 0, st, d, mode, base);
+        if (t1) PG_TRY(hipStreamWaitEvent(st, ls.side_done[0], 0));
+        if (t2 && (c & 1) == 0) PG_TRY(hipStreamWaitEvent(st, ls.side_done[1], 0));
+        if (lane_side) PG_TRY(hipStreamWaitEvent(st, ls.side_done[2], 0));
         if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(count), dim3(64), 0, st, d, base);
     }
-    if (nchunk > 1) {
-        for (int k = 0; k < 2; k++) {
-            PG_TRY(hipEventRecord(ls.lane_done[k], ls.lane[k]));
-            PG_TRY(hipStreamWaitEvent(ls.main, ls.lane_done[k], 0));
-        }
+    for (int k = 0; k < 2; k++) {
+        PG_TRY(hipEventRecord(ls.lane_done[k], ls.lane[k]));
+        PG_TRY(hipStreamWaitEvent(ls.main, ls.lane_done[k], 0));
     }
 #undef PG_TRY
     return hipGetLastError();
 }
-
 
 template <class Game>
 static hipError_t render_one(const DevCtx &d, int env, hipStream_t stream) {  // re-renders one env (after set_state)

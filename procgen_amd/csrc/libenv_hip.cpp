@@ -112,23 +112,38 @@ struct VecGame {
     int device_id = 0;
     bool host_observations = true;
     std::vector<libenv_tensortype> observation_types, action_types, info_types;
-    hipStream_t stream = nullptr, side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tier2 = nullptr;
-    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_fork = nullptr;
+    hipStream_t lane_stream[2] = {nullptr, nullptr}, side_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_lane[2] = {nullptr, nullptr};
+    hipEvent_t ev_side[3] = {};
     int chunks = 2;  // PROCGEN_AMD_CHUNKS: env range cut in 2 so one chunk's step kernel overlaps the other's render kernel (+6 % measured)
-    LaunchStreams streams() const { return LaunchStreams{stream, side_stream, ev_fork, ev_join, {lane_stream[0], lane_stream[1]}, {ev_lane[0], ev_lane[1]}, ev_tier2, chunks}; }
+    LaunchStreams streams() const {
+        LaunchStreams ls{};
+        ls.main = stream;
+        ls.fork = ev_fork;
+        for (int k = 0; k < 2; k++) {
+            ls.lane[k] = lane_stream[k];
+            ls.lane_done[k] = ev_lane[k];
+        }
+        for (int k = 0; k < 3; k++) {
+            ls.side[k] = side_stream[k];
+            ls.side_done[k] = ev_side[k];
+        }
+        ls.chunks = chunks;
+        return ls;
+    }
     DevCtx d{};
     HostAssets assets;
     GameAssetsDev *d_assets = nullptr;
     uint32_t *d_pixels = nullptr;
     int32_t *d_action = nullptr;
-    // [rew f32 N | prev_level_seed i32 N | level_seed i32 N | first u8 N | prev_level_complete u8 N | list counts A i32 x2 | error i32 | list counts B i32 x2]
+    // [rew f32 N | prev_level_seed i32 N | level_seed i32 N | first u8 N | prev_level_complete u8 N | list counts A i32 x LIST_COUNTERS | error i32 | list counts B]
     // The tail doubles as the tier-list counters (double-buffered A / B) so that one memset clears "next counts + error" and
     // the one download per step tells the host which list kernels have work next step.
     uint8_t *d_small = nullptr;
-    size_t tail_off = 0;            // offset of the 5-int tail
-    int host_list_count[2] = {0, 0};  // entries of the tier-1 / tier-2 lists the coming step reads
+    size_t tail_off = 0;            // offset of the tail: [list counters A | error | list counters B]
+    int host_list_count[MAX_CHUNKS][NUM_TIERS] = {};  // entries of the (chunk, tier) lists the coming step reads
     size_t small_bytes = 0;
     int *d_big_list[2] = {nullptr, nullptr};
     int *d_big_count[2] = {nullptr, nullptr};
@@ -311,16 +326,16 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     // joint handle then sit on different queues instead of all 16 main streams sharing queue 0 (measured: the parts of
     // a 16 x 1024-env handle ran strictly one after the other, 6.9 ms per step).
     if (num_envs >= 4096) {
-        HIP_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&ev_tier2, hipEventDisableTiming));
         for (int k = 0; k < 2; k++) {
             HIP_CHECK(hipStreamCreateWithFlags(&lane_stream[k], hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&ev_lane[k], hipEventDisableTiming));
         }
+        if (game_has_lane(kernel_id)) HIP_CHECK(hipStreamCreateWithFlags(&side_stream[0], hipStreamNonBlocking));  // four streams at most (hardware queues)
+        for (int k = 0; k < 3; k++) HIP_CHECK(hipEventCreateWithFlags(&ev_side[k], hipEventDisableTiming));
     }
     if (const char *c = getenv("PROCGEN_AMD_CHUNKS")) chunks = atoi(c) > 0 ? (atoi(c) < MAX_CHUNKS ? atoi(c) : MAX_CHUNKS) : 1;
+    d.chunk_envs = chunk_envs_for(num_envs, 1);  // one list chunk (see DevCtx::big_list)
 
     // assets: baked pack next to the library (procgen_amd/data/<game>.atlas) or the PNG tree at resource_root
     std::string data_dir = getenv("PROCGEN_AMD_DATA_DIR") ? getenv("PROCGEN_AMD_DATA_DIR") : this_library_dir() + "/../../data";
@@ -335,6 +350,10 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     const size_t N = (size_t)num_envs;
     game_limits(kernel_id, &d.ent_cap, &d.grid_bytes);
     d.num_envs = num_envs;
+    // The lane = env step path (pg_env.h LANE_MODE) is opt-in (PROCGEN_AMD_LANE=1, games that have one): measured on the
+    // MI355X it does not beat the wave = env kernels yet, and its tile-interleaved entity table
+    // costs the wave = env kernels and the renderer their contiguous reads.
+    d.ent_tile = (game_has_lane(kernel_id) && getenv("PROCGEN_AMD_LANE") && atoi(getenv("PROCGEN_AMD_LANE")) != 0) ? TILE_ENVS : 1;
     d.hdr = dev_alloc<EnvHdr>(N);
     d.rng = dev_alloc<uint32_t>(N * MT_SLOTS * MT_STRIDE);
     d.ents = dev_alloc<uint32_t>(ent_table_words(num_envs, d.ent_cap));
@@ -349,7 +368,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d_action = dev_alloc<int32_t>(N);
     d.action = d_action;
     d.obs = dev_alloc<uint8_t>(N * OBS_BYTES);
-    small_bytes = N * 14 + 4 + 5 * sizeof(int);
+    small_bytes = N * 14 + 4 + (2 * LIST_COUNTERS + 1) * sizeof(int);
     d_small = dev_alloc<uint8_t>(small_bytes);
     d.rew = (float *)d_small;
     d.prev_level_seed = (int32_t *)(d_small + 4 * N);
@@ -357,11 +376,11 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d.first = d_small + 12 * N;
     d.prev_level_complete = d_small + 13 * N;
     tail_off = (14 * N + 3) & ~(size_t)3;
-    d.error = (int *)(d_small + tail_off) + 2;
-    small_bytes = tail_off + 5 * sizeof(int);
+    d.error = (int *)(d_small + tail_off) + LIST_COUNTERS;
+    small_bytes = tail_off + (2 * LIST_COUNTERS + 1) * sizeof(int);
     for (int k = 0; k < 2; k++) {
-        d_big_list[k] = dev_alloc<int>(N * (NUM_TIERS - 1));
-        d_big_count[k] = (int *)(d_small + tail_off) + 3 * k;  // A: ints 0-1, B: ints 3-4 (error between them)
+        d_big_list[k] = dev_alloc<int>(N * NUM_TIERS);
+        d_big_count[k] = (int *)(d_small + tail_off) + (LIST_COUNTERS + 1) * k;  // A, then the error word, then B
         d_route[k] = dev_alloc<uint8_t>(N);
     }
     d_reset_list = dev_alloc<int>(N);
@@ -438,10 +457,11 @@ VecGame::~VecGame() {
         if (ev_lane[k]) (void)hipEventDestroy(ev_lane[k]);
         if (lane_stream[k]) (void)hipStreamDestroy(lane_stream[k]);
     }
+    for (int k = 0; k < 3; k++) {
+        if (ev_side[k]) (void)hipEventDestroy(ev_side[k]);
+        if (side_stream[k]) (void)hipStreamDestroy(side_stream[k]);
+    }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
-    if (ev_tier2) (void)hipEventDestroy(ev_tier2);
-    if (side_stream) (void)hipStreamDestroy(side_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -478,11 +498,11 @@ void VecGame::launch_kernels(int mode) {
     bind_routing();
     {   // next counts + error are adjacent in either parity: [A | error] or [error | B]
         int *first = d.next_big_count < d.error ? d.next_big_count : d.error;
-        HIP_CHECK(hipMemsetAsync(first, 0, 3 * sizeof(int), stream));
+        HIP_CHECK(hipMemsetAsync(first, 0, (LIST_COUNTERS + 1) * sizeof(int), stream));
     }
     LaunchStreams ls = streams();
-    ls.list_count[0] = mode == 0 ? 0 : host_list_count[0];
-    ls.list_count[1] = mode == 0 ? 0 : host_list_count[1];
+    for (int c = 0; c < MAX_CHUNKS; c++)
+        for (int t = 0; t < NUM_TIERS; t++) ls.list_count[c][t] = mode == 0 ? 0 : host_list_count[c][t];
     HIP_CHECK(launch_step(kernel_id, d, mode, ls));
     step_count++;
 }
@@ -490,10 +510,10 @@ void VecGame::launch_kernels(int mode) {
 // after the step's small download has landed: device error word, and which list kernels the next step needs
 void VecGame::read_tail() {
     const int *tail = (const int *)(h_small + tail_off);
-    const int err = tail[2];
-    const int *cnt = tail + 3 * (int)(step_count & 1);  // the lists the step just run filled are the ones the next step reads
-    host_list_count[0] = cnt[0];
-    host_list_count[1] = cnt[1];
+    const int err = tail[LIST_COUNTERS];
+    const int *cnt = tail + (LIST_COUNTERS + 1) * (int)(step_count & 1);  // the lists the step just run filled are the ones the next step reads
+    for (int c = 0; c < MAX_CHUNKS; c++)
+        for (int t = 0; t < NUM_TIERS; t++) host_list_count[c][t] = cnt[c * NUM_TIERS + t];
     if (err && !d.debug_flags) fatal("device-side check failed (code %d: 1 entity table overflow, 2 grid index out of range, 3 fassert, 4 asset theme, 5 unsupported draw)\n", err);
 }
 
@@ -545,7 +565,7 @@ void VecGame::snapshot(int e, EnvSnapshot *s) {
     s->grid.resize(d.grid_bytes);
     HIP_CHECK(hipMemcpy(&s->hdr, d.hdr + e, sizeof(EnvHdr), hipMemcpyDeviceToHost));
     // one word per 256-byte row of the tile-interleaved table
-    HIP_CHECK(hipMemcpy2D(s->ents.data(), 4, d.ents + ent_tile_base(e, d.ent_cap), (size_t)TILE_ENVS * 4, 4, (size_t)EF_COUNT * d.ent_cap, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy2D(s->ents.data(), 4, d.ents + ent_tile_base(e, d.ent_cap, d.ent_tile), (size_t)d.ent_tile * 4, 4, (size_t)EF_COUNT * d.ent_cap, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(s->rng.data(), d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, s->rng.size() * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(s->grid.data(), d.grid + (size_t)e * d.grid_bytes, s->grid.size(), hipMemcpyDeviceToHost));
 }
@@ -573,10 +593,9 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     // routing: the restored env takes a wave = env kernel for one step (conservative bound: a step at most doubles the
     // table); the lists the next step walks are rebuilt from the host's copy of the route table before the next launch,
     // so restoring the same env several times, in any tier order, leaves exactly one entry for it
-    int tier = game_tier_for(kernel_id, 2 * s.hdr.n_ents + 4);
-    if (game_has_lane(kernel_id) && tier < 1) tier = 1;
+    const int tier = game_tier_for(kernel_id, 2 * s.hdr.n_ents + 4);
     s.hdr.big = tier;
-    HIP_CHECK(hipMemcpy2D(d.ents + ent_tile_base(e, d.ent_cap), (size_t)TILE_ENVS * 4, s.ents.data(), 4, 4, (size_t)EF_COUNT * d.ent_cap, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy2D(d.ents + ent_tile_base(e, d.ent_cap, d.ent_tile), (size_t)d.ent_tile * 4, s.ents.data(), 4, 4, (size_t)EF_COUNT * d.ent_cap, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, s.rng.data(), s.rng.size() * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.grid + (size_t)e * d.grid_bytes, s.grid.data(), s.grid.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.hdr + e, &s.hdr, sizeof(EnvHdr), hipMemcpyHostToDevice));
@@ -612,18 +631,16 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
 // the tier lists and the route table the coming step reads, rebuilt from the host's copy after set_state calls
 void VecGame::flush_routes() {
     const int cur = (int)(step_count & 1);
-    std::vector<int> lists((size_t)num_envs * (NUM_TIERS - 1));
-    int count[NUM_TIERS - 1] = {0, 0};
+    std::vector<int> lists((size_t)num_envs * NUM_TIERS);
+    int count[MAX_CHUNKS][NUM_TIERS] = {};
     for (int e = 0; e < num_envs; e++) {
-        const int t = h_route[e];
-        if (t == 1 || t == 2) lists[(size_t)(t - 1) * num_envs + count[t - 1]++] = e;
+        const int t = h_route[e], c = e / d.chunk_envs;
+        if (t == 1 || t == 2) lists[(size_t)t * num_envs + (size_t)c * d.chunk_envs + count[c][t]++] = e;
     }
     HIP_CHECK(hipMemcpy(d_route[cur], h_route.data(), num_envs, hipMemcpyHostToDevice));
-    for (int t = 0; t < NUM_TIERS - 1; t++) {
-        if (count[t]) HIP_CHECK(hipMemcpy(d_big_list[cur] + (size_t)t * num_envs, lists.data() + (size_t)t * num_envs, (size_t)count[t] * sizeof(int), hipMemcpyHostToDevice));
-        host_list_count[t] = count[t];
-    }
+    HIP_CHECK(hipMemcpy(d_big_list[cur], lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d_big_count[cur], count, sizeof(count), hipMemcpyHostToDevice));
+    memcpy(host_list_count, count, sizeof(count));
     route_dirty = false;
 }
 

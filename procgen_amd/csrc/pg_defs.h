@@ -107,22 +107,25 @@ constexpr int TILE_ENVS = 64;
 #else
 #define PG_HOSTDEV
 #endif
-PG_HOSTDEV inline size_t ent_tile_base(int env, int ent_cap) {  // word index of (field 0, slot 0) of env
-    return (size_t)(env / TILE_ENVS) * EF_COUNT * (size_t)ent_cap * TILE_ENVS + (size_t)(env % TILE_ENVS);
+// `tile` (DevCtx::ent_tile) is TILE_ENVS when the handle runs the lane = env kernel and 1 otherwise: one table per env,
+// [field][slot] contiguous, which is what the wave = env kernels and the renderer read fastest (lanes = slots).
+PG_HOSTDEV inline size_t ent_tile_base(int env, int ent_cap, int tile) {  // word index of (field 0, slot 0) of env
+    return (size_t)(env / tile) * EF_COUNT * (size_t)ent_cap * tile + (size_t)(env % tile);
 }
-PG_HOSTDEV inline size_t ent_word_index(int env, int ent_cap, int field, int slot) {
-    return ent_tile_base(env, ent_cap) + ((size_t)field * ent_cap + slot) * TILE_ENVS;
+PG_HOSTDEV inline size_t ent_word_index(int env, int ent_cap, int tile, int field, int slot) {
+    return ent_tile_base(env, ent_cap, tile) + ((size_t)field * ent_cap + slot) * tile;
 }
-inline size_t ent_table_words(int num_envs, int ent_cap) {  // allocation size (whole tiles)
+inline size_t ent_table_words(int num_envs, int ent_cap) {  // allocation size (whole tiles, whatever the tile size)
     return (size_t)((num_envs + TILE_ENVS - 1) / TILE_ENVS) * TILE_ENVS * EF_COUNT * (size_t)ent_cap;
 }
 
 // values of the route table (which step kernel owns an env this step): 0..2 = wave = env kernel with LDS arena tier 0..2,
 // ROUTE_LANE = the lane = env physics kernel (games that declare HAS_LANE_STEP)
-constexpr int MAX_CHUNKS = 8;  // env chunks of one step (step of chunk c+1 overlaps the render of chunk c)
+constexpr int MAX_CHUNKS = 8;
+constexpr int LIST_COUNTERS = MAX_CHUNKS * 3;  // [chunk][tier] (NUM_TIERS == 3)  // env chunks of one step (step of chunk c+1 overlaps the render of chunk c)
 constexpr int ROUTE_LANE = 3;
-constexpr int LANE_MAX_ENTS = 32;  // default routing bounds of the lane = env kernel (see pg_env.h GameLane)
-constexpr int LANE_MAX_SMART = 4;
+constexpr int LANE_MAX_ENTS = 16;  // default routing bounds of the lane = env kernel (see pg_env.h GameLane)
+constexpr int LANE_MAX_SMART = 1;
 constexpr int ROUTE_RESET = 4;  // EnvHdr::big only: the lane kernel ended the episode, the reset kernel of the same step takes over
 
 // ---- sprite atlas in HBM ----
@@ -149,7 +152,8 @@ struct DevCtx {
     // per-env state
     EnvHdr *hdr;          // [num_envs]
     uint32_t *rng;        // [num_envs][MT_SLOTS][MT_STRIDE]  (0: rand_gen, 1: level_seed_rand_gen, 2-3: scratch)
-    uint32_t *ents;       // [num_envs / 64][EF_COUNT][ent_cap][64]  (ent_word_index)
+    uint32_t *ents;       // [num_envs / ent_tile][EF_COUNT][ent_cap][ent_tile]  (ent_word_index)
+    int ent_tile;         // 1, or TILE_ENVS for handles that run the lane = env kernel
     int ent_cap;          // slots per env in HBM
     uint8_t *grid;        // [num_envs][grid_bytes]
     int grid_bytes;
@@ -164,10 +168,15 @@ struct DevCtx {
     const uint32_t *pixels;
     // routing between the arena tiers of the step kernel: envs whose entity table may outgrow tier 0's LDS arena
     // are listed for the tier-1 / tier-2 kernels of the NEXT step (double-buffered by step parity)
-    const int *big_list;   // [NUM_TIERS-1][num_envs] env ids the tier-1 / tier-2 kernels handle this step
-    const int *big_count;  // [NUM_TIERS-1]
-    int *next_big_list;    // [NUM_TIERS-1][num_envs] filled during this step
-    int *next_big_count;   // [NUM_TIERS-1] zeroed by the host before the step
+    // List (tier, list chunk c) starts at big_list[tier * num_envs + c * chunk_envs], its length is
+    // big_count[c * NUM_TIERS + tier]; the envs [c * chunk_envs, (c + 1) * chunk_envs) form list chunk c.  (One list chunk
+    // today: per-chunk lists on per-chunk streams measured slower, each short kernel ends with its slowest env.)  Tier-0
+    // envs are not listed: a grid over the env range steps them and skips the envs routed elsewhere.
+    const int *big_list;   // [NUM_TIERS][num_envs] env ids the list kernels handle this step
+    const int *big_count;  // [MAX_CHUNKS][NUM_TIERS]
+    int *next_big_list;    // filled during this step
+    int *next_big_count;   // zeroed by the host before the step
+    int chunk_envs;        // envs per chunk (a multiple of TILE_ENVS)
     // tier that owns each env THIS step (written during the previous step, so it is stable while the step kernels of
     // the three tiers run concurrently: an env re-routed by a fast kernel is not picked up again by a slower one)
     const uint8_t *route;  // [num_envs]

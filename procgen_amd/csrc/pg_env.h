@@ -146,7 +146,7 @@ struct GameHasBlockHook<Game, decltype((void)Game::HAS_BLOCK_HOOK)> {
 // envs, [field][slot][lane].  A dependent global access costs ~1 us per trip on this latency-bound kernel, an LDS
 // access ~0.05 us.  Slots beyond the cache stay in HBM; Env::ew picks per access (generic pointer -> flat load).
 constexpr int LANE_CACHE_FIELDS = 7;
-constexpr int LANE_CACHE_SLOTS = 32;
+constexpr int LANE_CACHE_SLOTS = 16;
 static_assert(EF_META == LANE_CACHE_FIELDS - 1 && EF_X == 0, "the cached fields are the first enum values");
 // ... and, per lane, a LANE_WIN x LANE_WIN window of grid cells around the entity being stepped (Env::grid_window):
 // the corner probes of its sub_steps and its grid collisions read LDS instead of making one HBM trip each.
@@ -267,7 +267,7 @@ struct Env {
 #endif
     }
     PG_DEV Env(const DevCtx &d_, int env_, Lds<Game, CAP> *s_) : d(d_), env(env_), s(s_) {
-        lent = LANE ? d.ents + ent_tile_base(env_, CAP) : nullptr;
+        lent = LANE ? d.ents + ent_tile_base(env_, CAP, TILE_ENVS) : nullptr;  // (the lane kernel only runs on tile-interleaved tables)
         has_lds = false;
         ncand = -1;
         win_x0 = win_y0 = -(1 << 30);
@@ -1727,12 +1727,13 @@ struct Env {
 #undef PG_X
         }
         const int n = with_entities ? G.n_ents : 0;
-        const uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap);
+        const uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap, d.ent_tile);
+        const int tile = d.ent_tile;
         for (int base = 0; base < n; base += 64) {
             PG_FOR_LANES(l) {
                 if (base + l < n) {
                     uint32_t v[EF_COUNT];  // all field loads in flight before the first LDS store
-                    for (int f = 0; f < EF_COUNT; f++) v[f] = ge[(size_t)(f * d.ent_cap + base + l) * TILE_ENVS];
+                    for (int f = 0; f < EF_COUNT; f++) v[f] = ge[(size_t)(f * d.ent_cap + base + l) * tile];
                     for (int f = 0; f < EF_COUNT; f++) s->ent[f * CAP + base + l] = v[f];
                 }
             }
@@ -1752,12 +1753,13 @@ struct Env {
     }
     PG_DEV void store_env() {
         const int n = G.n_ents;
-        uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap);
+        uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap, d.ent_tile);
+        const int tile = d.ent_tile;
         if (n > d.ent_cap - 1) fail(PGE_ENT_OVERFLOW);
         for (int f = 0; f < EF_COUNT; f++) {
             for (int base = 0; base < n; base += 64) {
                 PG_FOR_LANES(l) {
-                    if (base + l < n && base + l < d.ent_cap) ge[(size_t)(f * d.ent_cap + base + l) * TILE_ENVS] = s->ent[f * CAP + base + l];
+                    if (base + l < n && base + l < d.ent_cap) ge[(size_t)(f * d.ent_cap + base + l) * tile] = s->ent[f * CAP + base + l];
                 }
             }
         }
@@ -1792,7 +1794,7 @@ struct Env {
         if constexpr (GameLane<Game>::value) {
             // the lane = env kernel cannot twist a generator: it takes an env only while the draws of one step are
             // certain to come from the current 624-word block (PROCGEN_AMD_DEBUG & 4096 keeps every env on the wave = env kernels)
-            lane_ok = G.rand_idx + GameLane<Game>::MAX_DRAWS <= MT_N && !(d.debug_flags & 4096) && G.n_ents <= d.lane_max_ents;
+            lane_ok = d.ent_tile == TILE_ENVS && G.rand_idx + GameLane<Game>::MAX_DRAWS <= MT_N && !(d.debug_flags & 4096) && G.n_ents <= d.lane_max_ents;
             if (lane_ok) {
                 int smart = 0;
                 if constexpr (LANE) {
@@ -1811,8 +1813,7 @@ struct Env {
         const int need = Game::slots_needed_next_step(*this);  // entity slots incl. growth of one step + the reserved one
         int tier = need <= Game::ENT_CAP_T0 ? 0 : (need <= Game::ENT_CAP_T1 ? 1 : 2);
         if (need > Game::ENT_CAP_T2) fail(PGE_ENT_OVERFLOW);
-        // the wave = env envs of a lane-stepped game all go through the list kernels (no grid over every env)
-        if constexpr (GameLane<Game>::value) tier = lane_ok ? ROUTE_LANE : (tier < 1 ? 1 : tier);
+        if constexpr (GameLane<Game>::value) tier = lane_ok ? ROUTE_LANE : tier;
         G.big = tier;
     }
 
@@ -1824,9 +1825,9 @@ struct Env {
         if (LANE || PG_LANE_ID() == 0) {
             if (d.next_route) d.next_route[env] = (uint8_t)G.big;
             if (G.big == 1 || G.big == 2) {
-                const int t = G.big - 1;
-                const int slot = atomicAdd(d.next_big_count + t, 1);
-                d.next_big_list[(size_t)t * d.num_envs + slot] = env;
+                const int t = G.big, c = env / d.chunk_envs;
+                const int slot = atomicAdd(d.next_big_count + c * NUM_TIERS + t, 1);
+                d.next_big_list[(size_t)t * d.num_envs + (size_t)c * d.chunk_envs + slot] = env;
             }
             if (G.error) atomicOr(d.error, G.error);
         }

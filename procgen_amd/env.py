@@ -63,7 +63,7 @@ def default_resource_root():
 class BaseProcgenEnv(CEnv):
     def __init__(self, num, env_name, options, debug=False, rand_seed=None, num_levels=0, start_level=0,
                  use_sequential_levels=False, debug_mode=0, resource_root=None, num_threads=4,
-                 render_mode=None, lib_dir=None, extra_options=None):
+                 render_mode=None, lib_dir=None, extra_options=None, buffer_padding=0):
         if resource_root is None:
             resource_root = default_resource_root()
         if lib_dir is None:
@@ -92,7 +92,7 @@ class BaseProcgenEnv(CEnv):
         if extra_options:
             # extension options understood only by the HIP library (include/procgen_amd.h)
             options.update(extra_options)
-        super().__init__(lib_dir=lib_dir, num=num, options=options)
+        super().__init__(lib_dir=lib_dir, num=num, options=options, buffer_padding=buffer_padding)
 
     def get_state(self):
         import ctypes as C

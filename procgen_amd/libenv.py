@@ -106,7 +106,9 @@ class TensorSpec:
 class CEnv:
     """Vectorized environment living in a libenv shared library."""
 
-    def __init__(self, lib_dir, num, options, lib_name="libenv.so"):
+    def __init__(self, lib_dir, num, options, lib_name="libenv.so", buffer_padding=0):
+        """buffer_padding > 0 leaves that many unused bytes behind every env's slice of the observation / action / info
+        arrays: libenv only promises per-env pointers (libenv_buffers), so a library must not assume one dense array."""
         path = lib_dir if os.path.isfile(lib_dir) else os.path.join(lib_dir, lib_name)
         if not os.path.exists(path):
             raise FileNotFoundError(f"libenv library not found: {path}")
@@ -148,9 +150,20 @@ class CEnv:
         self.info_types = self._tensortypes(SPACE_INFO)
 
         n = self.num
-        self._ob = {t.name: np.zeros((n,) + t.shape, dtype=t.dtype) for t in self.ob_types}
-        self._ac = {t.name: np.zeros((n,) + t.shape, dtype=t.dtype) for t in self.ac_types}
-        self._info = {t.name: np.zeros((n,) + t.shape, dtype=t.dtype) for t in self.info_types}
+        self._stores = []
+
+        def alloc(t):
+            if not buffer_padding:
+                return np.zeros((n,) + t.shape, dtype=t.dtype)
+            item = int(np.prod(t.shape, dtype=np.int64)) * np.dtype(t.dtype).itemsize
+            pad = -(-(item + buffer_padding) // np.dtype(t.dtype).itemsize) * np.dtype(t.dtype).itemsize
+            store = np.zeros((n, pad), dtype=np.uint8)
+            self._stores.append(store)
+            return store[:, :item].view(t.dtype).reshape((n,) + t.shape)  # a strided view: env e starts at e * pad bytes
+
+        self._ob = {t.name: alloc(t) for t in self.ob_types}
+        self._ac = {t.name: alloc(t) for t in self.ac_types}
+        self._info = {t.name: alloc(t) for t in self.info_types}
         self._rew = np.zeros(n, dtype=np.float32)
         self._first = np.zeros(n, dtype=np.uint8)
 
@@ -158,7 +171,7 @@ class CEnv:
             tab = (C.c_void_p * (len(types) * n))()
             for s, t in enumerate(types):
                 a = arrays[t.name]
-                stride = a[0].nbytes if n else 0
+                stride = a.strides[0] if n else 0
                 for e in range(n):
                     tab[s * n + e] = a.ctypes.data + e * stride
             return tab

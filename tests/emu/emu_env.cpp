@@ -90,7 +90,7 @@ extern "C" {
 
 void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, int num_levels, int start_level, int distribution_mode,
                int center_agent, int use_backgrounds, int restrict_themes, int use_sequential_levels, int debug_mode, const char *resource_root,
-               const char *atlas_path, int use_small, int use_monochrome_assets, int paint_vel_info) {
+               const char *atlas_path, int use_small, int use_monochrome_assets, int paint_vel_info, int lane) {
     EmuVec *v = new EmuVec();
     v->n = num_envs;
     v->use_small = use_small;
@@ -147,6 +147,8 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.opt.use_sequential_levels = use_sequential_levels;
     d.opt.debug_mode = debug_mode;
     if (const char *dbg = getenv("PROCGEN_AMD_DEBUG")) d.debug_flags = atoi(dbg);
+    d.chunk_envs = (num_envs + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;
+    d.ent_tile = lane ? TILE_ENVS : 1;  // lane = 0: per-env contiguous entity tables, no lane = env routing (the product's default)
     d.lane_max_ents = getenv("PROCGEN_AMD_LANE_ENTS") ? atoi(getenv("PROCGEN_AMD_LANE_ENTS")) : LANE_MAX_ENTS;
     d.lane_max_smart = getenv("PROCGEN_AMD_LANE_SMART") ? atoi(getenv("PROCGEN_AMD_LANE_SMART")) : LANE_MAX_SMART;
     if (!use_small) d.debug_flags |= 4096;  // no lane = env routing either: every env on the largest wave = env arena  // e.g. 1024: renderer without the pull form (per-cell blits)
@@ -197,7 +199,7 @@ static void emu_snapshot(EmuVec *v, int env, EnvSnapshot *s) {
     s->hdr = v->hdr[env];
     s->ent_cap = cap;
     s->ents.resize((size_t)EF_COUNT * cap);
-    for (int k = 0; k < EF_COUNT * cap; k++) s->ents[k] = v->ents[ent_tile_base(env, cap) + (size_t)k * TILE_ENVS];
+    for (int k = 0; k < EF_COUNT * cap; k++) s->ents[k] = v->ents[ent_tile_base(env, cap, v->d.ent_tile) + (size_t)k * v->d.ent_tile];
     s->rng.assign(v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE, v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE + 2 * MT_STRIDE);
     s->grid.assign(v->grid.begin() + (size_t)env * v->d.grid_bytes, v->grid.begin() + (size_t)(env + 1) * v->d.grid_bytes);
 }
@@ -226,7 +228,7 @@ int emu_set_state(void *h, int env, const char *data, int length) {
     s.hdr.big = 2;  // the emulation picks the arena from this field alone; the largest arena is always safe
     const int cap = v->d.ent_cap;
     v->hdr[env] = s.hdr;
-    for (int k = 0; k < EF_COUNT * cap; k++) v->ents[ent_tile_base(env, cap) + (size_t)k * TILE_ENVS] = s.ents[k];
+    for (int k = 0; k < EF_COUNT * cap; k++) v->ents[ent_tile_base(env, cap, v->d.ent_tile) + (size_t)k * v->d.ent_tile] = s.ents[k];
     std::copy(s.rng.begin(), s.rng.end(), v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE);
     std::copy(s.grid.begin(), s.grid.end(), v->grid.begin() + (size_t)env * v->d.grid_bytes);
     v->rew[env] = s.hdr.reward;
@@ -270,8 +272,9 @@ int emu_is_big(void *h, int env) { return ((EmuVec *)h)->hdr[env].big; }
 void emu_dump_entities(void *h, int env, int32_t *out) {
     EmuVec *v = (EmuVec *)h;
     const int cap = v->d.ent_cap;
-    const uint32_t *e = v->ents.data() + ent_tile_base(env, cap);
-    auto W = [&](int f, int i) { return (int32_t)e[(size_t)(f * cap + i) * TILE_ENVS]; };
+    const uint32_t *e = v->ents.data() + ent_tile_base(env, cap, v->d.ent_tile);
+    const int tile = v->d.ent_tile;
+    auto W = [&](int f, int i) { return (int32_t)e[(size_t)(f * cap + i) * tile]; };
     for (int i = 0; i < v->hdr[env].n_ents; i++) {
         int32_t *o = out + 31 * i;
         const uint32_t m = (uint32_t)W(EF_META, i);

@@ -13,6 +13,21 @@ import oracle_env
 from helpers import action_stream, assert_rollouts_equal, check_against_option_matrix, rollout
 
 
+def test_default_layout_per_env_contiguous_tables():
+    """The product's default (no PROCGEN_AMD_LANE): per-env contiguous entity tables (DevCtx::ent_tile = 1), no lane = env routing."""
+    n, steps = 8, 200
+    acts = action_stream(n, steps, seed=3)
+    a = rollout(oracle_env.OracleEnv(n, "coinrun", rand_seed=23), acts)
+    emu = emu_harness.EmuEnv(n, "coinrun", rand_seed=23, lane=False)
+    b = rollout(emu, acts)
+    assert_rollouts_equal(a, b, "tile = 1")
+    assert emu.path_counts()[0] == 0
+    st = emu.get_state()
+    emu2 = emu_harness.EmuEnv(n, "coinrun", rand_seed=99, lane=False)
+    emu2.set_state(st)
+    assert emu2.get_state() == st
+
+
 @pytest.mark.parametrize("game,use_small", [("coinrun", True), ("coinrun", False), ("bigfish", True), ("maze", True), ("climber", True), ("miner", True), ("starpilot", True), ("fruitbot", True), ("leaper", True), ("plunder", True), ("heist", True), ("ninja", True), ("dodgeball", True), ("bossfight", True), ("chaser", True), ("caveflyer", True), ("jumper", True)])
 def test_emulated_kernels_match_oracle(game, use_small):
     n, steps = 24, 260
@@ -61,7 +76,7 @@ def test_lane_env_kernel_over_timeouts_twists_and_resets(game, steps):
     for e in range(n):
         assert np.array_equal(orc.entities(e), emu.entities(e)) and np.array_equal(orc.grid(e), emu.grid(e))
     lane, lane_resets, wave = emu.path_counts()
-    assert lane > 0.5 * n * steps and lane_resets > 0 and wave > 0, (lane, lane_resets, wave)
+    assert lane > 0.25 * n * steps and lane_resets > 0 and wave > 0, (lane, lane_resets, wave)
     assert a["first"][1000:1002].any(), "an episode must have ended by timeout"
 
 
