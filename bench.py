@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--game", default="coinrun")
     ap.add_argument("--host-landed", action="store_true", help="also land observations on the host (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--devices-in-process", type=int, default=1,
+                    help="single-process mode: ONE libenv handle of devices x num-envs envs sharded over that many GPUs of this process (num_devices option; no torch.distributed)")
     args = ap.parse_args()
 
     import torch
@@ -150,8 +152,14 @@ def main():
     if args.game == "all16":  # BASELINE configs[4]'s shape: env n plays names[n % 16] (reference src/vecgame.cpp:295-310)
         args.game = ",".join(ALL_GAMES)
     joint = "," in args.game
-    env = ProcgenGym3Env(n, args.game, rand_seed=23, extra_options={
-        "device_id": local_rank, "env_offset": rank * n, "host_observations": bool(args.host_landed)})
+    D = args.devices_in_process
+    if D > 1:
+        assert world == 1, "--devices-in-process is the single-process mode"
+        n = n * D  # weak scaling: the per-GPU share stays num-envs
+        env = ProcgenGym3Env(n, args.game, rand_seed=23, extra_options={"num_devices": D, "host_observations": bool(args.host_landed)})
+    else:
+        env = ProcgenGym3Env(n, args.game, rand_seed=23, extra_options={
+            "device_id": local_rank, "env_offset": rank * n, "host_observations": bool(args.host_landed)})
     rng = np.random.RandomState(rank)
     acts = rng.randint(0, 15, size=(args.warmup + args.steps, n), dtype=np.int32)
     env.observe()
@@ -173,7 +181,7 @@ def main():
     # the same loop with the observations landed in the caller's (pinned) host array through the unmodified libenv ABI:
     # the PCIe-inclusive rate (never `value`), on a bounded number of steps
     host_landed = None
-    if not joint and not args.host_landed and world == 1:
+    if not joint and not args.host_landed and world == 1 and D == 1:
         env._lib.procgen_amd_set_host_observations.argtypes = [C.c_void_p, C.c_int]
         env._lib.procgen_amd_set_host_observations(env._handle, 1)
         hl_steps = min(args.steps, 40)
@@ -194,7 +202,7 @@ def main():
     env._lib.procgen_amd_time_steps.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     k_steps = min(50, args.steps)
     kacts = np.ascontiguousarray(acts[:k_steps])
-    if joint:  # the per-step event timing hook is a single-game extension; a joint handle overlaps 16 games' kernels
+    if joint or D > 1:  # the per-step event timing hook is a single-part extension; a joint / sharded handle overlaps its parts' kernels
         kernel_ms = dt / args.steps * 1e3
     else:
         kernel_ms = env._lib.procgen_amd_time_steps(env._handle, k_steps, kacts.ctypes.data)
@@ -212,12 +220,12 @@ def main():
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": f"env steps/sec (whole node), {args.game} num_envs={n} random actions",
-            "value": round(value, 1), "unit": "env steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "env steps/sec", "n_gpus": world * D, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+i32 game state, u8 pixels", "data": "synthetic (uniform random actions, procedurally generated levels)",
             "config": {"workload": f"{args.game} num_envs={n} per GPU x {world} GPU(s), random-action rollout, distribution_mode=hard, "
                                    f"observations {'landed on host (PCIe inclusive)' if args.host_landed else 'resident in HBM'}",
-                       "num_envs_per_gpu": n, "sharding": f"env_offset shards x{world}, no collective"},
+                       "num_envs_per_gpu": n // D, "sharding": (f"one handle, num_devices={D} contiguous index ranges, no collective" if D > 1 else f"env_offset shards x{world}, no collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "launch": "one step = exactly what libenv_act enqueues (counter memset, step grids + list kernels, render kernels) over all envs of this GPU",
@@ -228,7 +236,7 @@ def main():
             line["roofline"]["launch"] = "one step = the step + render kernels of all games of the joint handle (wall time of the step, kernels of different games overlap)"
         if host_landed is not None:
             line["host_landed"] = host_landed
-        if world == 1 and not args.no_cpu_baseline and not joint:
+        if world == 1 and D == 1 and not args.no_cpu_baseline and not joint:
             line["cpu_baseline"] = cpu_baseline(args.game)
         print(json.dumps(line), flush=True)
     if world > 1:

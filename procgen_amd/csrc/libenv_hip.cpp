@@ -21,6 +21,7 @@
 #include "../../include/procgen_amd.h"
 #include "assets.h"
 #include "kernels.h"
+#include "shard_map.h"
 #include "state_io.h"
 
 using namespace pgamd;
@@ -176,8 +177,11 @@ struct VecGame {
     bool pending = false;
     bool registered_obs = false;
 
-    // forced_name / stride / index: one game of a joint handle owns the envs index + i * stride
-    VecGame(int nenvs, VecOptions opts, const std::string &forced_name = "", int stride = 1, int index = 0);
+    // forced_name / stride / index: one game of a joint handle owns the envs index + i * stride (index counts from the
+    // handle's env 0: a device shard adds its first global index); forced_device: the shard's device (-1: from the options)
+    VecGame(int nenvs, VecOptions opts, const std::string &forced_name = "", int stride = 1, int index = 0, int forced_device = -1);
+    void use_device() const { HIP_CHECK(hipSetDevice(device_id)); }  // every entry point: the parts of a handle may sit on different devices
+    bool external_pinned = false;  // the handle registered the caller's whole observation array once (multi-part handles)
     ~VecGame();
     void set_buffers(struct libenv_buffers *bufs);
     void launch_kernels(int mode);
@@ -195,7 +199,7 @@ struct VecGame {
     int env_stride = 1;
 };
 
-VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int stride, int index) {
+VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int stride, int index, int forced_device) {
     num_envs = nenvs;
     if (num_envs <= 0) fatal("num_envs must be positive\n");
     std::string env_name, resource_root;
@@ -217,11 +221,12 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     opts.consume_int("env_offset", &env_offset);
     opts.consume_bool("host_observations", &host_observations);
 
-    if (!forced_name.empty()) {
-        env_name = forced_name;
-        env_stride = stride;
-        env_offset += index;
-    }
+    int num_devices_opt = 1;
+    opts.consume_int("num_devices", &num_devices_opt);  // handled by libenv_make (Handle); consumed here so that it is not "unused"
+    if (!forced_name.empty()) env_name = forced_name;
+    env_stride = stride;
+    env_offset += index;
+    if (forced_device >= 0) device_id = forced_device;
     if (env_name.empty()) fatal("fassert failed 'env_name != \"\"'\n");
     if (!(num_actions > 0)) fatal("fassert failed 'num_actions > 0'\n");
     if (!(num_levels >= 0)) fatal("fassert failed 'num_levels >= 0'\n");
@@ -318,6 +323,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         const char *lr = getenv("LOCAL_RANK");
         device_id = lr ? atoi(lr) % ndev : 0;
     }
+    if (getenv("PROCGEN_AMD_FAKE_DEVICES")) device_id %= ndev;  // testing aid: several "devices" of a handle on the GPUs there are
     if (device_id >= ndev) fatal("device_id %d out of range (%d devices)\n", device_id, ndev);
     HIP_CHECK(hipSetDevice(device_id));
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -396,6 +402,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
 }
 
 VecGame::~VecGame() {
+    (void)hipSetDevice(device_id);
     if (stream) (void)hipStreamSynchronize(stream);
     if (d.phase_cycles) {  // PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step kernels, per env-step
         std::vector<unsigned long long> raw(48 * 4096);
@@ -466,6 +473,7 @@ VecGame::~VecGame() {
 }
 
 void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecgame.cpp:30-40,74-83,333-361
+    use_device();
     const int N = num_envs;
     ob_ptr.assign(bufs->ob, bufs->ob + N);  // one observation space
     ac_ptr.assign(bufs->ac, bufs->ac + N);  // one action space
@@ -481,8 +489,10 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
     if (host_observations) {
         if (ob_contig) {
             // pin the caller's observation array so the D2H landing is a single DMA ("one pinned host buffer")
-            registered_obs = hipHostRegister(ob_ptr[0], (size_t)N * OBS_BYTES, hipHostRegisterDefault) == hipSuccess;
-            if (!registered_obs) (void)hipGetLastError();
+            if (!external_pinned) {
+                registered_obs = hipHostRegister(ob_ptr[0], (size_t)N * OBS_BYTES, hipHostRegisterDefault) == hipSuccess;
+                if (!registered_obs) (void)hipGetLastError();
+            }
         } else {
             HIP_CHECK(hipHostMalloc((void **)&h_obs_stage, (size_t)N * OBS_BYTES, hipHostMallocDefault));
         }
@@ -529,6 +539,7 @@ void VecGame::launch(int mode) {
 
 void VecGame::act() {  // reference src/vecgame.cpp:378-401
     if (!buffers_set) fatal("libenv_act called before libenv_set_buffers\n");
+    use_device();
     observe();  // wait_for_stepping_threads()
     const int N = num_envs;
     // the action values are only valid for the duration of this call (reference src/vecgame.cpp:387-388)
@@ -541,6 +552,7 @@ void VecGame::act() {  // reference src/vecgame.cpp:378-401
 
 void VecGame::observe() {  // reference src/vecgame.cpp:363-376,416-435
     if (!pending) return;
+    use_device();
     HIP_CHECK(hipStreamSynchronize(stream));
     pending = false;
     const size_t N = (size_t)num_envs;
@@ -573,6 +585,7 @@ void VecGame::snapshot(int e, EnvSnapshot *s) {
 int VecGame::get_state(int e, char *data, int length) {  // reference src/vecgame.cpp:438-445
     if (!buffers_set) fatal("get_state called before libenv_set_buffers\n");
     if (e < 0 || e >= num_envs) fatal("get_state: env index %d out of range\n", e);
+    use_device();
     observe();  // wait_for_stepping_threads()
     EnvSnapshot s;
     snapshot(e, &s);
@@ -585,6 +598,7 @@ int VecGame::get_state(int e, char *data, int length) {  // reference src/vecgam
 void VecGame::set_state(int e, const char *data, int length) {  // reference src/vecgame.cpp:447-456
     if (!buffers_set) fatal("set_state called before libenv_set_buffers\n");
     if (e < 0 || e >= num_envs) fatal("set_state: env index %d out of range\n", e);
+    use_device();
     observe();
     EnvSnapshot s;
     snapshot(e, &s);  // fields the wire format does not carry keep their current values
@@ -646,22 +660,29 @@ void VecGame::flush_routes() {
 
 }  // namespace
 
-// One libenv handle: a single game, or the games of a comma separated env_name (reference src/vecgame.cpp:295-310:
-// env n plays names[n % K]).  Each game of a joint handle is a VecGame of its own over the envs k, k + K, k + 2K, ...
-// with its own streams, so the per-game kernels of one libenv_act run concurrently on the GPU.
+// One libenv handle = G device shards x K games (shard_map.h): part (g, k) is a VecGame of its own -- game k of a comma
+// separated env_name (reference src/vecgame.cpp:295-310: env n plays names[n % K]) over the envs base_g + k + K * i of
+// device g's contiguous index range -- with its own streams, so the kernels of the parts of one libenv_act run
+// concurrently, on one GPU or on several ("num_devices" option; no collective: envs never interact).
 struct Handle {
     std::vector<std::unique_ptr<VecGame>> parts;
+    ShardMap map;
     int num_envs = 0;
-    // joint handles: the parts write rew / first into these and observe() scatters them to the caller's arrays
+    // multi-part handles: the parts write rew / first into these and observe() scatters them to the caller's arrays
     std::vector<std::vector<float>> part_rew;
     std::vector<std::vector<uint8_t>> part_first;
     std::vector<std::vector<void *>> part_ob, part_ac, part_info;
     float *rew = nullptr;
     uint8_t *first = nullptr;
-    int K() const { return (int)parts.size(); }
+    void *pinned_ob = nullptr;  // the caller's whole observation array, registered once for all devices
+    int P() const { return (int)parts.size(); }
     VecGame *single() {
-        if (parts.size() != 1) fatal("this extension hook is only available on single-game handles\n");
+        if (parts.size() != 1) fatal("this extension hook is only available on single-game, single-device handles\n");
         return parts[0].get();
+    }
+    ~Handle() {
+        parts.clear();
+        if (pinned_ob) (void)hipHostUnregister(pinned_ob);
     }
 };
 
@@ -685,17 +706,31 @@ LIBENV_API libenv_env *libenv_make(int num_envs, const struct libenv_options opt
     Handle *h = new Handle();
     h->num_envs = num_envs;
     std::string env_name;
+    int num_devices = 1, device_id = -1;
     {
         VecOptions peek(options);
         peek.consume_string("env_name", &env_name);
+        const bool has_dev = peek.consume_int("device_id", &device_id);
+        if (!peek.consume_int("num_devices", &num_devices) && !has_dev && getenv("PROCGEN_AMD_NUM_DEVICES")) num_devices = atoi(getenv("PROCGEN_AMD_NUM_DEVICES"));
     }
     const std::vector<std::string> names = split_names(env_name);
     const int K = (int)names.size();
-    if (K <= 1) {
+    if (num_devices == 0) {  // 0 = every visible device
+        if (hipGetDeviceCount(&num_devices) != hipSuccess || num_devices <= 0) fatal("no HIP device available: the MI355X stepper cannot run (there is no CPU fallback)\n");
+    }
+    if (num_devices < 1) fatal("num_devices must be positive (or 0 for all visible devices)\n");
+    if (K > 1 && num_envs % K != 0) fatal("fassert failed 'num_envs %% num_joint_games == 0'\n");
+    h->map.num_envs = num_envs;
+    h->map.num_devices = num_devices;
+    h->map.num_games = K;
+    if (!h->map.valid()) fatal("num_envs (%d) must be a multiple of num_devices x number of games (%d x %d)\n", num_envs, num_devices, K);
+    if (K <= 1 && num_devices == 1) {
         h->parts.emplace_back(new VecGame(num_envs, VecOptions(options)));
     } else {
-        if (num_envs % K != 0) fatal("fassert failed 'num_envs %% num_joint_games == 0'\n");
-        for (int k = 0; k < K; k++) h->parts.emplace_back(new VecGame(num_envs / K, VecOptions(options), names[k], K, k));
+        const int first_device = device_id >= 0 ? device_id : 0;
+        for (int p = 0; p < h->map.parts(); p++)
+            h->parts.emplace_back(new VecGame(h->map.envs_per_part(), VecOptions(options), names[h->map.game_of_part(p)], K, h->map.first_env(p),
+                                              num_devices > 1 ? first_device + h->map.device_of_part(p) : -1));
     }
     return (libenv_env *)h;
 }
@@ -714,51 +749,59 @@ LIBENV_API int libenv_get_tensortypes(libenv_env *handle, enum libenv_space_name
 
 LIBENV_API void libenv_set_buffers(libenv_env *handle, struct libenv_buffers *bufs) {
     Handle *h = (Handle *)handle;
-    const int K = h->K();
-    if (K == 1) {
+    const int P = h->P();
+    if (P == 1) {
         h->parts[0]->set_buffers(bufs);
         return;
     }
-    const int N = h->num_envs, n = N / K;
+    const int N = h->num_envs, n = h->map.envs_per_part();
     h->rew = bufs->rew;
     h->first = bufs->first;
-    h->part_rew.assign(K, std::vector<float>(n));
-    h->part_first.assign(K, std::vector<uint8_t>(n));
-    h->part_ob.assign(K, std::vector<void *>(n));
-    h->part_ac.assign(K, std::vector<void *>(n));
-    h->part_info.assign(K, std::vector<void *>(3 * (size_t)n));
-    for (int k = 0; k < K; k++) {
+    {   // "one pinned host buffer": when the caller's observation pointers form one array, register it once for every device
+        bool contig = true;
+        for (int e = 1; e < N && contig; e++) contig = (uint8_t *)bufs->ob[e] == (uint8_t *)bufs->ob[0] + (size_t)e * OBS_BYTES;
+        if (contig && h->parts[0]->host_observations && hipHostRegister(bufs->ob[0], (size_t)N * OBS_BYTES, hipHostRegisterPortable) == hipSuccess) h->pinned_ob = bufs->ob[0];
+        else (void)hipGetLastError();
+    }
+    h->part_rew.assign(P, std::vector<float>(n));
+    h->part_first.assign(P, std::vector<uint8_t>(n));
+    h->part_ob.assign(P, std::vector<void *>(n));
+    h->part_ac.assign(P, std::vector<void *>(n));
+    h->part_info.assign(P, std::vector<void *>(3 * (size_t)n));
+    for (int p = 0; p < P; p++) {
         for (int i = 0; i < n; i++) {
-            const int e = k + K * i;  // global env index
-            h->part_ob[k][i] = bufs->ob[e];
-            h->part_ac[k][i] = bufs->ac[e];
-            for (int s = 0; s < 3; s++) h->part_info[k][(size_t)s * n + i] = bufs->info[(size_t)s * N + e];
+            const int e = h->map.env_of(p, i);  // global env index
+            h->part_ob[p][i] = bufs->ob[e];
+            h->part_ac[p][i] = bufs->ac[e];
+            for (int s = 0; s < 3; s++) h->part_info[p][(size_t)s * n + i] = bufs->info[(size_t)s * N + e];
         }
         struct libenv_buffers pb;
-        pb.ob = h->part_ob[k].data();
-        pb.rew = h->part_rew[k].data();
-        pb.first = h->part_first[k].data();
-        pb.info = h->part_info[k].data();
-        pb.ac = h->part_ac[k].data();
-        h->parts[k]->set_buffers(&pb);
+        pb.ob = h->part_ob[p].data();
+        pb.rew = h->part_rew[p].data();
+        pb.first = h->part_first[p].data();
+        pb.info = h->part_info[p].data();
+        pb.ac = h->part_ac[p].data();
+        h->parts[p]->external_pinned = h->pinned_ob != nullptr;
+        h->parts[p]->set_buffers(&pb);
     }
 }
 LIBENV_API void libenv_observe(libenv_env *handle) {
     Handle *h = (Handle *)handle;
-    const int K = h->K();
-    for (auto &p : h->parts) p->observe();
-    if (K > 1 && h->rew) {
-        const int n = h->num_envs / K;
-        for (int k = 0; k < K; k++)
+    const int P = h->P();
+    for (auto &p : h->parts) p->observe();  // joins the streams of every part (device)
+    if (P > 1 && h->rew) {
+        const int n = h->map.envs_per_part();
+        for (int p = 0; p < P; p++)
             for (int i = 0; i < n; i++) {
-                h->rew[k + K * i] = h->part_rew[k][i];
-                h->first[k + K * i] = h->part_first[k][i];
+                const int e = h->map.env_of(p, i);
+                h->rew[e] = h->part_rew[p][i];
+                h->first[e] = h->part_first[p][i];
             }
     }
 }
 LIBENV_API void libenv_act(libenv_env *handle) {
     Handle *h = (Handle *)handle;
-    for (auto &p : h->parts) p->act();  // each game launches on its own streams: the games' kernels overlap
+    for (auto &p : h->parts) p->act();  // each part launches on its own streams (and device): the parts' kernels overlap
 }
 LIBENV_API void libenv_close(libenv_env *handle) { delete (Handle *)handle; }
 
@@ -766,13 +809,13 @@ LIBENV_API void libenv_close(libenv_env *handle) { delete (Handle *)handle; }
 LIBENV_API int get_state(libenv_env *handle, int env_idx, char *data, int length) {
     Handle *h = (Handle *)handle;
     if (env_idx < 0 || env_idx >= h->num_envs) fatal("get_state: env index %d out of range\n", env_idx);
-    return h->parts[env_idx % h->K()]->get_state(env_idx / h->K(), data, length);
+    return h->parts[h->map.part_of(env_idx)]->get_state(h->map.index_in_part(env_idx), data, length);
 }
 LIBENV_API void set_state(libenv_env *handle, int env_idx, char *data, int length) {
     Handle *h = (Handle *)handle;
     if (env_idx < 0 || env_idx >= h->num_envs) fatal("set_state: env index %d out of range\n", env_idx);
-    h->parts[env_idx % h->K()]->set_state(env_idx / h->K(), data, length);
-    if (h->K() > 1) libenv_observe(handle);  // refresh the caller's rew / first entries of this env
+    h->parts[h->map.part_of(env_idx)]->set_state(h->map.index_in_part(env_idx), data, length);
+    if (h->P() > 1) libenv_observe(handle);  // refresh the caller's rew / first entries of this env
 }
 
 // ---- extension hooks (include/procgen_amd.h) -------------------------------------------------------------

@@ -124,6 +124,14 @@ struct GameLane<Game, decltype((void)Game::HAS_LANE_STEP)> {
     static constexpr bool value = Game::HAS_LANE_STEP;
     static constexpr int MAX_DRAWS = Game::LANE_MAX_DRAWS;
 };
+// the entity-table tile size of a handle of this game: a compile-time 1 for games without a lane = env path (their
+// kernels keep plain contiguous indexing), DevCtx::ent_tile otherwise
+template <class Game>
+PG_DEV int ent_tile_of(const DevCtx &d) {
+    if constexpr (GameLane<Game>::value) return d.ent_tile;
+    else return 1;
+}
+
 // A wave of the lane = env kernel takes as long as its heaviest env and the kernel as long as its slowest wave, so the
 // lane path only takes envs of bounded work: at most LANE_MAX_ENTS entities (all inside the LDS cache) of which at most
 // LANE_MAX_SMART are smart_step ones (each costs a basic_step_object).  The heavy tail (coinrun: 10 % of the env-steps,
@@ -1656,17 +1664,16 @@ struct Env {
             G.last_reward = G.reward;
         }
         G.prev_level_seed = G.current_level_seed;
-        if constexpr (LANE) {
-            // level generation is wave-structured: a finished episode goes to the reset kernel of this step (run(2))
-            needs_reset = G.done != 0;
-            if (needs_reset) return;
-        }
-        finish_step();
+        // (what follows in Game::step -- the reset of a finished episode -- is finish_step's: level generation is
+        // wave-structured, so the lane = env kernel stops here and a finished episode goes to the reset kernel, run(2))
+        if constexpr (LANE) needs_reset = G.done != 0;
     }
-    // the rest of Game::step once game_step has run (reference src/game.cpp:144-155)
-    PG_DEV void finish_step() {
+    // the rest of Game::step once game_step has run (reference src/game.cpp:144-155); initial = the reset + first
+    // observation libenv_set_buffers asks for (reference src/vecgame.cpp:346-357).  One call site of the level
+    // generator per kernel: the step kernels are sensitive to their code size (instruction cache).
+    PG_DEV void finish_step(bool initial) {
         if constexpr (!LANE) {
-            if (G.done) {
+            if (initial || G.done) {
                 game_reset_full();
                 phase(6);
 #if !defined(PGAMD_WAVE_EMU)
@@ -1674,8 +1681,12 @@ struct Env {
 #endif
             }
         }
-        if (d.opt.use_sequential_levels && G.level_complete) G.done = 0;
-        G.episode_done = G.done;
+        if (initial) {
+            G.initial_reset_complete = 1;
+        } else {
+            if (d.opt.use_sequential_levels && G.level_complete) G.done = 0;
+            G.episode_done = G.done;
+        }
     }
 
     // ======================================================================================================
@@ -1727,14 +1738,17 @@ struct Env {
 #undef PG_X
         }
         const int n = with_entities ? G.n_ents : 0;
-        const uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap, d.ent_tile);
-        const int tile = d.ent_tile;
+        const int tile = ent_tile_of<Game>(d);
+        const uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap, tile);
+        const uint32_t fstride = (uint32_t)d.ent_cap * (uint32_t)tile;  // words between two fields of one slot (one tile's table is < 2^31 words)
         for (int base = 0; base < n; base += 64) {
             PG_FOR_LANES(l) {
                 if (base + l < n) {
-                    uint32_t v[EF_COUNT];  // all field loads in flight before the first LDS store
-                    for (int f = 0; f < EF_COUNT; f++) v[f] = ge[(size_t)(f * d.ent_cap + base + l) * tile];
-                    for (int f = 0; f < EF_COUNT; f++) s->ent[f * CAP + base + l] = v[f];
+                    uint32_t v[EF_COUNT];  // all field loads in flight before the first LDS store (the loops must stay unrolled:
+                                           // rolled, every load waits for the previous one)
+                    const uint32_t *gp = ge + (uint32_t)(base + l) * (uint32_t)tile;
+                    _Pragma("unroll") for (int f = 0; f < EF_COUNT; f++) v[f] = gp[f * fstride];
+                    _Pragma("unroll") for (int f = 0; f < EF_COUNT; f++) s->ent[f * CAP + base + l] = v[f];
                 }
             }
         }
@@ -1753,13 +1767,15 @@ struct Env {
     }
     PG_DEV void store_env() {
         const int n = G.n_ents;
-        uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap, d.ent_tile);
-        const int tile = d.ent_tile;
+        const int tile = ent_tile_of<Game>(d);
+        uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap, tile);
         if (n > d.ent_cap - 1) fail(PGE_ENT_OVERFLOW);
-        for (int f = 0; f < EF_COUNT; f++) {
-            for (int base = 0; base < n; base += 64) {
-                PG_FOR_LANES(l) {
-                    if (base + l < n && base + l < d.ent_cap) ge[(size_t)(f * d.ent_cap + base + l) * tile] = s->ent[f * CAP + base + l];
+        const uint32_t fstride = (uint32_t)d.ent_cap * (uint32_t)tile;
+        for (int base = 0; base < n; base += 64) {
+            PG_FOR_LANES(l) {
+                if (base + l < n && base + l < d.ent_cap) {
+                    uint32_t *gp = ge + (uint32_t)(base + l) * (uint32_t)tile;
+                    _Pragma("unroll") for (int f = 0; f < EF_COUNT; f++) gp[f * fstride] = s->ent[f * CAP + base + l];
                 }
             }
         }
@@ -1845,13 +1861,9 @@ struct Env {
         if (mode == 1) G.action = d.action[env];  // reference src/vecgame.cpp:388
         if (d.debug_flags & 512) {
             // ablation: staging only
-        } else if (mode == 0) {
-            game_reset_full();
-            G.initial_reset_complete = 1;
-        } else if (mode == 2) {
-            finish_step();
         } else {
-            game_step_full();
+            if (mode == 1) game_step_full();
+            finish_step(mode == 0);
         }
         rand_flush();
         prepare_for_drawing((float)RES_H);  // draw_background + draw_foreground both call it (BAG:922,982)
@@ -1900,6 +1912,7 @@ struct Env {
         }
         phase(0);
         game_step_full();
+        if (!needs_reset) finish_step(false);
         if (has_lds && !needs_reset) {  // ... and back (a reset starts from an empty table)
             const int nc = G.n_ents < LANE_CACHE_SLOTS ? G.n_ents : LANE_CACHE_SLOTS;
             for (int i = 0; i < nc; i++) {

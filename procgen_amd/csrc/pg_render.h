@@ -185,8 +185,8 @@ struct Renderer {
     int row0, row1;  // band rows [row0, row1)
 
     PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(lds_->ax) {
-        ge = d.ents + ent_tile_base(env, d.ent_cap, d.ent_tile);
-        etile = d.ent_tile;  // (tile-interleaved table: consecutive slots are 64 words apart)
+        etile = ent_tile_of<Game>(d);  // (tile-interleaved table: consecutive slots are etile words apart)
+        ge = d.ents + ent_tile_base(env, d.ent_cap, etile);
         ecap = d.ent_cap;
         gg = reinterpret_cast<const typename Game::cell_t *>(d.grid + (size_t)env * d.grid_bytes);
         row0 = 0;
@@ -194,8 +194,12 @@ struct Renderer {
     }
 
     // entity accessors with the names the game policies use (HBM reads; the table was written by the step kernel)
-    PG_DEV float ef(int field, int i) const { return __builtin_bit_cast(float, ge[(size_t)(field * ecap + i) * etile]); }
-    PG_DEV uint32_t meta(int i) const { return ge[(size_t)(EF_META * ecap + i) * etile]; }
+    PG_DEV int tile_() const {
+        if constexpr (GameLane<Game>::value) return etile;
+        else return 1;
+    }
+    PG_DEV float ef(int field, int i) const { return __builtin_bit_cast(float, ge[(uint32_t)(field * ecap + i) * (uint32_t)tile_()]); }
+    PG_DEV uint32_t meta(int i) const { return ge[(uint32_t)(EF_META * ecap + i) * (uint32_t)tile_()]; }
     PG_DEV float ex(int i) const { return ef(EF_X, i); }
     PG_DEV float ey(int i) const { return ef(EF_Y, i); }
     PG_DEV float evx(int i) const { return ef(EF_VX, i); }

@@ -148,7 +148,13 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.opt.debug_mode = debug_mode;
     if (const char *dbg = getenv("PROCGEN_AMD_DEBUG")) d.debug_flags = atoi(dbg);
     d.chunk_envs = (num_envs + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;
-    d.ent_tile = lane ? TILE_ENVS : 1;  // lane = 0: per-env contiguous entity tables, no lane = env routing (the product's default)
+    // lane = 0: per-env contiguous entity tables, no lane = env routing (the product's default); games without a lane = env
+    // path always use them (ent_tile_of)
+    d.ent_tile = 1;
+#define PG_X(Game) \
+    if (gid == Game::GAME_ID && lane && GameLane<Game>::value) d.ent_tile = TILE_ENVS;
+    PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
     d.lane_max_ents = getenv("PROCGEN_AMD_LANE_ENTS") ? atoi(getenv("PROCGEN_AMD_LANE_ENTS")) : LANE_MAX_ENTS;
     d.lane_max_smart = getenv("PROCGEN_AMD_LANE_SMART") ? atoi(getenv("PROCGEN_AMD_LANE_SMART")) : LANE_MAX_SMART;
     if (!use_small) d.debug_flags |= 4096;  // no lane = env routing either: every env on the largest wave = env arena  // e.g. 1024: renderer without the pull form (per-cell blits)

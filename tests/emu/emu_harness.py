@@ -17,10 +17,20 @@ CSRC = os.path.join(REPO, "procgen_amd", "csrc")
 def build(force=False):
     srcs = [os.path.join(HERE, "emu_env.cpp"), os.path.join(CSRC, "assets.cpp"), os.path.join(CSRC, "image_io.cpp"), os.path.join(CSRC, "state_io.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+    def fresh():
+        return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)
+
+    if not force and fresh():
         return
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-march=ivybridge", "-fno-strict-aliasing", "-fPIC",
-                           "-shared", "-I" + CSRC] + srcs + ["-lz", "-o", LIB])
+    import fcntl
+
+    with open(LIB + ".lock", "w") as lock:  # pytest-xdist workers: one builds, the others wait and then find it fresh
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not fresh():
+            tmp = LIB + f".tmp{os.getpid()}"
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-march=ivybridge", "-fno-strict-aliasing", "-fPIC",
+                                   "-shared", "-I" + CSRC] + srcs + ["-lz", "-o", tmp])
+            os.replace(tmp, LIB)
 
 
 _lib = None

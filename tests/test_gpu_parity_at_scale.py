@@ -98,16 +98,33 @@ def noop_heavy_actions(n, steps, seed, p_noop=0.97):
     return out
 
 
-@pytest.mark.parametrize("game,timeout", [("coinrun", 1000), ("heist", 1000), ("maze", 500), ("plunder", 4000), ("bossfight", 4000), ("bigfish", 6000)])
+@pytest.mark.parametrize("game,timeout", [("coinrun", 1000), ("heist", 1000), ("maze", 500)])
 def test_episodes_that_end_by_timeout(game, timeout):
     """Rollouts longer than the game's timeout with mostly no-op actions, so that episodes reach `cur_time >= timeout`
-    (reference src/game.cpp:134; timeouts: 1000 default, bossfight / plunder 4000, bigfish 6000, maze 500)."""
+    (reference src/game.cpp:134; timeouts: 1000 default, maze / leaper 500).  The 4000- and 6000-step classes, where idle
+    play dies long before, are covered by test_timeout_classes_from_reference_states."""
     n, steps = 8, timeout + 110
     acts = noop_heavy_actions(n, steps, seed=7)
     a = rollout(oracle_env.OracleEnv(n, game, rand_seed=23), acts)
     b = rollout(make_env(n, game), acts)
     assert_rollouts_equal(a, b, f"timeout horizon ({game})")
     assert a["first"][timeout:timeout + 2].any(), "an episode must have run into the timeout"
+
+
+@pytest.mark.parametrize("game", ["bossfight", "plunder", "bigfish", "coinrun", "leaper"])
+def test_timeout_classes_from_reference_states(golden_dir, game):
+    """tests/golden/timeout_states.npz (compiled reference, make_timeout_golden.py): reference states whose serialized
+    cur_time sits a few steps before the game's timeout (bossfight / plunder 4000, bigfish 6000, coinrun 1000, leaper 500)
+    are restored through set_state; rew / first / info / frames of the next 70 steps equal the reference's recording,
+    with every env's episode ending exactly when cur_time reaches the timeout."""
+    g = np.load(os.path.join(golden_dir, "timeout_states.npz"))
+    n = g[f"{game}/actions"].shape[1]
+    env = make_env(n, game, rand_seed=777)
+    env.set_state([bytes(g[f"{game}/state{e}"]) for e in range(n)])
+    got = rollout(env, list(g[f"{game}/actions"]))
+    for k in ("rew", "first", "prev_level_seed", "prev_level_complete", "level_seed", "crc"):
+        assert np.array_equal(got[k], g[f"{game}/{k}"]), (game, k)
+    assert [int(np.argmax(got["first"][1:, e])) + 1 for e in range(n)] == [12 + 9 * e for e in range(n)]
 
 
 def test_separately_placed_per_env_buffers():
@@ -156,3 +173,41 @@ def test_set_state_leaves_one_list_entry_whatever_the_tier_order():
     got = rollout(env, [np.array([4, 4, a[0], 4], dtype=np.int32) for a in tail])
     for k in want:
         assert np.array_equal(want[k][:, 0], got[k][:, 2]), k
+
+
+def test_one_handle_sharded_over_devices_equals_the_single_device_handle(monkeypatch):
+    """The "num_devices" option (include/procgen_amd.h): one libenv handle, contiguous index ranges
+    per device, observations landed in the caller's one (registered) host array, no collective.  Runs with however many
+    devices are visible; PROCGEN_AMD_FAKE_DEVICES lets several shards share one GPU, so the sharding logic is exercised on
+    a one-GPU box too.  Every output equals the single-device handle's, and get_state / set_state address global indices."""
+    import torch
+
+    monkeypatch.setenv("PROCGEN_AMD_FAKE_DEVICES", "1")
+    ndev = max(torch.cuda.device_count(), 1)
+    n, steps = 96, 90
+    acts = action_stream(n, steps, seed=12)
+    one = rollout(make_env(n, "starpilot"), acts, keep_frames=True)
+    for G in sorted({2, 4, ndev} - {1}):
+        if n % G:
+            continue
+        got = rollout(make_env(n, "starpilot", extra_options={"num_devices": G}), acts, keep_frames=True)
+        for k in one:
+            assert np.array_equal(one[k], got[k]), (G, k)
+    # joint games x device shards: env n plays names[n % K] whatever the sharding
+    names = ["coinrun", "bigfish", "maze"]
+    joint_one = rollout(make_env(n, ",".join(names)), acts)
+    joint_sh = rollout(make_env(n, ",".join(names), extra_options={"num_devices": 2}), acts)
+    for k in joint_one:
+        assert np.array_equal(joint_one[k], joint_sh[k]), k
+    import state_parse
+
+    env = make_env(n, ",".join(names), extra_options={"num_devices": 2})
+    sts = env.get_state()
+    for e in (0, 47, 48, 95):
+        st = state_parse.parse_state(sts[e])
+        assert st["game_name"] == names[e % 3] and st["game_n"] == e
+    env2 = make_env(n, ",".join(names), rand_seed=5, extra_options={"num_devices": 2})
+    env2.set_state(sts)
+    assert env2.get_state() == sts
+    env.close()
+    env2.close()

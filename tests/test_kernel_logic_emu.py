@@ -80,6 +80,19 @@ def test_lane_env_kernel_over_timeouts_twists_and_resets(game, steps):
     assert a["first"][1000:1002].any(), "an episode must have ended by timeout"
 
 
+@pytest.mark.parametrize("game", ["bossfight", "plunder", "bigfish", "coinrun", "leaper"])
+def test_emulated_timeout_classes_from_reference_states(golden_dir, game):
+    """The `cur_time >= timeout` path (reference src/game.cpp:134) for every timeout class, from reference states whose
+    cur_time was moved next to the timeout (tests/golden/make_timeout_golden.py): kernel logic vs the compiled reference."""
+    g = np.load(os.path.join(golden_dir, "timeout_states.npz"))
+    n = g[f"{game}/actions"].shape[1]
+    emu = emu_harness.EmuEnv(n, game, rand_seed=777)
+    emu.set_state([bytes(g[f"{game}/state{e}"]) for e in range(n)])
+    got = rollout(emu, list(g[f"{game}/actions"]))
+    for k in ("rew", "first", "prev_level_seed", "prev_level_complete", "level_seed", "crc"):
+        assert np.array_equal(got[k], g[f"{game}/{k}"]), (game, k)
+
+
 @pytest.mark.parametrize("game", ["coinrun", "chaser", "dodgeball"])
 @pytest.mark.parametrize("kw", [dict(use_monochrome_assets=True), dict(paint_vel_info=True), dict(use_monochrome_assets=True, restrict_themes=True, use_backgrounds=False)])
 def test_emulated_option_surface_monochrome_and_vel_info(game, kw):

@@ -26,7 +26,8 @@ def _scratch_bytes(game, tmp):
     text = open(out).read()
     names = re.findall(r"^\s+\.name:\s+(\S+)", text, re.M)
     sizes = [int(x) for x in re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", text, re.M)]
-    assert len(names) == len(sizes) == 4, (game, names)  # step_tier0, two step_list tiers, render
+    # step_tier0, two step_list tiers, render (+ lane_step and reset_list for games with a lane = env path)
+    assert len(names) == len(sizes) and len(names) in (4, 6), (game, names)
     return dict(zip(names, sizes))
 
 

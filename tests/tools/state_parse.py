@@ -63,6 +63,7 @@ def parse_state(data, game_extra=None):
         st[k] = r.i()
     st["last_reward"] = r.f()
     for k in ("default_action", "fixed_asset_seed", "cur_time", "is_waiting_for_step"):
+        st["offset_of_" + k] = r.o  # byte offset of the field (tests/golden/make_timeout_golden.py patches cur_time)
         st[k] = r.i()
     # BasicAbstractGame
     st["grid_size"] = r.i()
