@@ -49,6 +49,17 @@ LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable
  * measured with HIP events on the library's own stream.  Used by bench.py for the roofline figure. */
 LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const int32_t *actions_or_null);
 
+/* Device math self-tests (no handle, current HIP device; host pointers in and out): the exact device functions the game
+ * kernels call, over caller-chosen inputs, so that a test can sweep a whole input domain against the host libm.
+ *   bigfish_radius: out[i] = the fish radius bigfish computes from the rand01() draw r01[i] (pow, reference
+ *                   src/games/bigfish.cpp:84)
+ *   sincos:         sin / cos (pg_math.h) of the float with bit pattern first_bits + i, as doubles */
+LIBENV_API void procgen_amd_selftest_bigfish_radius(const float *r01, float *out, int n);
+LIBENV_API void procgen_amd_selftest_sincos(uint32_t first_bits, int n, double *out_sin, double *out_cos);
+/*   sincos_scaled:  float(sin(x) * scale), float(cos(x) * scale) for the floats x with the given bit patterns -- the shape of
+ *                   every call site that feeds game state (bullet / thrust velocities) */
+LIBENV_API void procgen_amd_selftest_sincos_scaled(const uint32_t *bits, int n, double scale, float *out_sin, float *out_cos);
+
 /* reference src/vecgame.cpp:437-457 (declared to cffi by reference procgen/env.py:132-135) */
 LIBENV_API int get_state(libenv_env *handle, int env_idx, char *data, int length);
 LIBENV_API void set_state(libenv_env *handle, int env_idx, char *data, int length);

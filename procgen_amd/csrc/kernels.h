@@ -35,4 +35,8 @@ bool game_has_lane(int game_id);
 int game_tier_for(int game_id, int slots_needed);
 void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes);
 void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
+// device math self-tests (kernels.hip)
+hipError_t selftest_bigfish_radius(const float *d_in, float *d_out, int n);
+hipError_t selftest_sincos(uint32_t first_bits, int n, double *d_sin, double *d_cos);
+hipError_t selftest_sincos_scaled(const uint32_t *d_bits, int n, double scale, float *d_sin, float *d_cos);
 }  // namespace pgamd

@@ -1,6 +1,11 @@
 // kernels.hip -- dispatch on game id over the per-game kernel objects (kernels_game.hip, one translation unit per game).
 #include "kernels.h"
 
+#include <hip/hip_runtime.h>
+
+#include "pg_math.h"
+#include "wave.h"
+
 namespace pgamd {
 
 #define PG_GAME_NAMES(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist) X(Ninja) X(Dodgeball) X(BossFight) X(Chaser) X(CaveFlyer) X(Jumper) X(CaveFlyerMemory)
@@ -49,6 +54,42 @@ void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes) {
 void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng) {
     const GameEntry *e = find(game_id);
     if (e) e->init_state(num_envs, rand_seed, env_offset, env_stride, hdr, rng);
+}
+
+// ---- device math self-tests (procgen_amd_selftest_*, include/procgen_amd.h): the exact device functions the game
+// policies call, run over caller-chosen inputs so that a test can sweep a whole input domain against the host libm ----
+__global__ void selftest_bigfish_radius_kernel(const float *r01, float *out, int n) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    // game_bigfish.h game_step (reference src/games/bigfish.cpp:84): FISH_MAX_R = 2, FISH_MIN_R = .25
+    if (i < n) out[i] = (float)((double)(2.0f - .25f) * pg_pow((double)r01[i], 1.4) + (double).25f);
+}
+__global__ void selftest_sincos_kernel(uint32_t first_bits, int n, double *out_sin, double *out_cos) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) {
+        const double x = (double)__builtin_bit_cast(float, first_bits + (uint32_t)i);  // the games pass float angles
+        out_sin[i] = pg_sin_d(x);
+        out_cos[i] = pg_cos_d(x);
+    }
+}
+__global__ void selftest_sincos_scaled_kernel(const uint32_t *bits, int n, double scale, float *out_sin, float *out_cos) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) {
+        const double x = (double)__builtin_bit_cast(float, bits[i]);
+        out_sin[i] = (float)(pg_sin_d(x) * scale);  // the shape of every call site: float(trig(double(float angle)) * double(float speed))
+        out_cos[i] = (float)(pg_cos_d(x) * scale);
+    }
+}
+hipError_t selftest_sincos_scaled(const uint32_t *d_bits, int n, double scale, float *d_sin, float *d_cos) {
+    hipLaunchKernelGGL(selftest_sincos_scaled_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_bits, n, scale, d_sin, d_cos);
+    return hipGetLastError();
+}
+hipError_t selftest_bigfish_radius(const float *d_in, float *d_out, int n) {
+    hipLaunchKernelGGL(selftest_bigfish_radius_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_in, d_out, n);
+    return hipGetLastError();
+}
+hipError_t selftest_sincos(uint32_t first_bits, int n, double *d_sin, double *d_cos) {
+    hipLaunchKernelGGL(selftest_sincos_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, first_bits, n, d_sin, d_cos);
+    return hipGetLastError();
 }
 
 }  // namespace pgamd

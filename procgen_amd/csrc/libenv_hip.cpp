@@ -10,6 +10,10 @@
 #include <stdarg.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -660,6 +664,61 @@ void VecGame::flush_routes() {
 
 }  // namespace
 
+// Host threads that issue the HIP calls of the parts of a multi-part handle side by side: a step of a 16-game handle is
+// ~150 runtime calls (copies, memsets, launches, stream joins) which one thread issues in over a millisecond -- longer
+// than the GPU needs for the kernels (reference analogue: the stepping threads of src/vecgame.cpp:103-142, there for the
+// game logic itself).  run(n, f) calls f(0) .. f(n-1) across the workers and returns when all are done.
+class PartPool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)> *job = nullptr;
+    int next = 0, total = 0, running = 0;
+    uint64_t epoch = 0;
+    bool stop = false;
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || (epoch != seen && next < total); });
+            if (stop) return;
+            while (next < total) {
+                const int i = next++;
+                running++;
+                lk.unlock();
+                (*job)(i);
+                lk.lock();
+                running--;
+            }
+            seen = epoch;
+            if (running == 0) cv_done.notify_all();
+        }
+    }
+
+public:
+    explicit PartPool(int threads) {
+        for (int t = 0; t < threads; t++) workers.emplace_back([this] { loop(); });
+    }
+    ~PartPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &w : workers) w.join();
+    }
+    void run(int n, const std::function<void(int)> &f) {
+        std::unique_lock<std::mutex> lk(m);
+        job = &f;
+        next = 0;
+        total = n;
+        epoch++;
+        cv_work.notify_all();
+        cv_done.wait(lk, [&] { return next >= total && running == 0; });
+        job = nullptr;
+    }
+};
+
 // One libenv handle = G device shards x K games (shard_map.h): part (g, k) is a VecGame of its own -- game k of a comma
 // separated env_name (reference src/vecgame.cpp:295-310: env n plays names[n % K]) over the envs base_g + k + K * i of
 // device g's contiguous index range -- with its own streams, so the kernels of the parts of one libenv_act run
@@ -675,12 +734,19 @@ struct Handle {
     float *rew = nullptr;
     uint8_t *first = nullptr;
     void *pinned_ob = nullptr;  // the caller's whole observation array, registered once for all devices
+    std::unique_ptr<PartPool> pool;  // multi-part handles
     int P() const { return (int)parts.size(); }
+    void for_parts(const std::function<void(int)> &f) {
+        if (pool) pool->run(P(), f);
+        else
+            for (int p = 0; p < P(); p++) f(p);
+    }
     VecGame *single() {
         if (parts.size() != 1) fatal("this extension hook is only available on single-game, single-device handles\n");
         return parts[0].get();
     }
     ~Handle() {
+        pool.reset();
         parts.clear();
         if (pinned_ob) (void)hipHostUnregister(pinned_ob);
     }
@@ -731,6 +797,9 @@ LIBENV_API libenv_env *libenv_make(int num_envs, const struct libenv_options opt
         for (int p = 0; p < h->map.parts(); p++)
             h->parts.emplace_back(new VecGame(h->map.envs_per_part(), VecOptions(options), names[h->map.game_of_part(p)], K, h->map.first_env(p),
                                               num_devices > 1 ? first_device + h->map.device_of_part(p) : -1));
+        int threads = h->P() < 8 ? h->P() : 8;
+        if (const char *t = getenv("PROCGEN_AMD_HOST_THREADS")) threads = atoi(t);
+        if (threads > 1) h->pool.reset(new PartPool(threads));
     }
     return (libenv_env *)h;
 }
@@ -788,7 +857,7 @@ LIBENV_API void libenv_set_buffers(libenv_env *handle, struct libenv_buffers *bu
 LIBENV_API void libenv_observe(libenv_env *handle) {
     Handle *h = (Handle *)handle;
     const int P = h->P();
-    for (auto &p : h->parts) p->observe();  // joins the streams of every part (device)
+    h->for_parts([&](int p) { h->parts[p]->observe(); });  // joins the streams of every part (device)
     if (P > 1 && h->rew) {
         const int n = h->map.envs_per_part();
         for (int p = 0; p < P; p++)
@@ -801,7 +870,7 @@ LIBENV_API void libenv_observe(libenv_env *handle) {
 }
 LIBENV_API void libenv_act(libenv_env *handle) {
     Handle *h = (Handle *)handle;
-    for (auto &p : h->parts) p->act();  // each part launches on its own streams (and device): the parts' kernels overlap
+    h->for_parts([&](int p) { h->parts[p]->act(); });  // each part launches on its own streams (and device): the parts' kernels overlap
 }
 LIBENV_API void libenv_close(libenv_env *handle) { delete (Handle *)handle; }
 
@@ -840,6 +909,43 @@ LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable
         HIP_CHECK(hipHostMalloc((void **)&v->h_obs_stage, (size_t)v->num_envs * OBS_BYTES, hipHostMallocDefault));
     v->host_observations = enable != 0;
 }
+// Device math self-tests: no handle; run on the current device.  Host pointers in, host pointers out.
+LIBENV_API void procgen_amd_selftest_bigfish_radius(const float *r01, float *out, int n) {
+    float *d_in = nullptr, *d_out = nullptr;
+    HIP_CHECK(hipMalloc((void **)&d_in, (size_t)n * 4));
+    HIP_CHECK(hipMalloc((void **)&d_out, (size_t)n * 4));
+    HIP_CHECK(hipMemcpy(d_in, r01, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(selftest_bigfish_radius(d_in, d_out, n));
+    HIP_CHECK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+}
+LIBENV_API void procgen_amd_selftest_sincos(uint32_t first_bits, int n, double *out_sin, double *out_cos) {
+    double *d_s = nullptr, *d_c = nullptr;
+    HIP_CHECK(hipMalloc((void **)&d_s, (size_t)n * 8));
+    HIP_CHECK(hipMalloc((void **)&d_c, (size_t)n * 8));
+    HIP_CHECK(selftest_sincos(first_bits, n, d_s, d_c));
+    HIP_CHECK(hipMemcpy(out_sin, d_s, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out_cos, d_c, (size_t)n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_s);
+    (void)hipFree(d_c);
+}
+
+LIBENV_API void procgen_amd_selftest_sincos_scaled(const uint32_t *bits, int n, double scale, float *out_sin, float *out_cos) {
+    uint32_t *d_b = nullptr;
+    float *d_s = nullptr, *d_c = nullptr;
+    HIP_CHECK(hipMalloc((void **)&d_b, (size_t)n * 4));
+    HIP_CHECK(hipMalloc((void **)&d_s, (size_t)n * 4));
+    HIP_CHECK(hipMalloc((void **)&d_c, (size_t)n * 4));
+    HIP_CHECK(hipMemcpy(d_b, bits, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(selftest_sincos_scaled(d_b, n, scale, d_s, d_c));
+    HIP_CHECK(hipMemcpy(out_sin, d_s, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out_cos, d_c, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_b);
+    (void)hipFree(d_s);
+    (void)hipFree(d_c);
+}
+
 // average device time of one step's launch sequence -- exactly what libenv_act enqueues (VecGame::launch_kernels: counter
 // memset, list / lane / reset / step / render kernels, empty lists skipped) -- over the given number of rounds, measured
 // with HIP events on the library's stream (bench.py roofline leg)

@@ -240,6 +240,10 @@ struct Env {
     uint32_t *rg_home;
     uint32_t *rg_cur;
     bool rg_in_lds;
+    // 64 state words of rand_gen ahead of the next draw, lane l = word rc_base + l of buffer rc_buf (rand_u32)
+    PG_LANE_VAR(uint32_t, rc_words);
+    const uint32_t *rc_buf = nullptr;
+    int rc_base = 0;
 
     // profiling aid (PROCGEN_AMD_DEBUG & 2048): wave cycles spent since the previous mark are charged to phase k
     long long t_mark = 0, t_start = 0;
@@ -575,6 +579,7 @@ struct Env {
     }
     // rand_gen.seed(seed): state generated serially into LDS scratch A (the recurrence is a dependent chain)
     PG_DEV void rand_seed(int seed) {
+        rc_buf = nullptr;  // (the scratch state is about to be rewritten)
         uint32_t *a = mt_a();
         uint32_t x = (uint32_t)seed;
         for (int i = 0; i < MT_N; i++) {
@@ -605,8 +610,19 @@ struct Env {
             rg_cur = dst;
             rg_in_lds = true;
             G.rand_idx = 0;
+            rc_buf = nullptr;
         }
-        uint32_t z = rg_cur[G.rand_idx];
+        // The generator state lives in HBM (home or scratch): a draw used to be one dependent ~1 us round trip, and level
+        // generators make hundreds to thousands of them (leaper's reset: 400 spawn rounds of up to nine draws, 1.5 ms of
+        // a lone wave).  One coalesced load now brings the next 64 state words into a lane variable; draws read lanes.
+        const int idx = G.rand_idx;
+        if (rc_buf != rg_cur || idx < rc_base || idx >= rc_base + 64) {
+            const uint32_t *src = rg_cur;
+            PG_FOR_LANES(l) { PG_LV(rc_words, l) = idx + l < MT_N ? src[idx + l] : 0u; }
+            rc_buf = rg_cur;
+            rc_base = idx;
+        }
+        const uint32_t z = PG_READLANE(rc_words, idx - rc_base);
         G.rand_idx += 1;
         return mt_temper(z);
     }
@@ -621,6 +637,7 @@ struct Env {
         PG_FOR_LANES(l) { PG_LV(out, l) = l < first ? mt_temper(cur0[idx0 + l]) : 0u; }
         G.rand_idx += first;
         if (first < count) {
+            rc_buf = nullptr;
             uint32_t *dst = (rg_cur == mt_a()) ? mt_b() : mt_a();
             mt_twist(rg_cur, dst);
             rg_cur = dst;
@@ -652,6 +669,7 @@ struct Env {
         uint32_t *home = rg_home + MT_STRIDE;
         uint32_t z;
         if (G.lvl_rand_idx >= MT_N) {
+            rc_buf = nullptr;  // (scratch A is used for the twist)
             mt_twist(home, mt_a());
             z = mt_a()[0];
             mt_copy(mt_a(), home);
