@@ -187,10 +187,26 @@ struct Leaper : BagDefaults<Leaper> {
         LP_N_WATER(G) = num_water_lanes;
         LP_GOAL_Y(G) = LP_BOTTOM_WATER_Y(G) + num_water_lanes + 1;
         const float lim = G.main_width / (min_car_speed < min_log_speed ? min_car_speed : min_log_speed);
+        // leaper.cpp:171-174: the lanes are filled by running the spawners for main_width / min speed = 300-400 steps.  The
+        // agent -- the only smart_step entity, at rest, and no entity type blocks or reflects it (BAG defaults) -- makes
+        // the same basic_step_object every time: its inputs (its own box, the grid) do not change.  Once one round has
+        // left it exactly where it was, the remaining rounds only need Entity::step for every entity (a reset used to
+        // take 1.5 ms of a lone wave, almost all of it the agent's 400 object steps).
+        bool agent_idle = false;
         for (int i = 0; i < lim; i++) {
             spawn_entities(e);
             PG_SYNC();
-            e.step_entities();
+            if (agent_idle) {
+                e.step_entities_all_plain();
+            } else {
+                const int a = G.agent;
+                const float x0 = e.ex(a), y0 = e.ey(a), vx0 = e.evx(a), vy0 = e.evy(a);
+                e.step_entities();
+                const float x1 = e.ex(a), y1 = e.ey(a), vx1 = e.evx(a), vy1 = e.evy(a);
+                agent_idle = vx0 == 0 && vy0 == 0 && __builtin_bit_cast(uint32_t, x0) == __builtin_bit_cast(uint32_t, x1) &&
+                             __builtin_bit_cast(uint32_t, y0) == __builtin_bit_cast(uint32_t, y1) &&
+                             __builtin_bit_cast(uint32_t, vx0) == __builtin_bit_cast(uint32_t, vx1) && __builtin_bit_cast(uint32_t, vy0) == __builtin_bit_cast(uint32_t, vy1);
+            }
         }
         e.add_entity_rxy((float)(G.main_width / 2.0), (float)(LP_GOAL_Y(G) - .5), 0, 0, (float)(G.main_width / 2.0), (float).5, FINISH_LINE);
         PG_SYNC();

@@ -176,7 +176,7 @@ struct VecGame {
     std::vector<void *> ob_ptr, ac_ptr, info_ptr[3];
     float *rew_ptr = nullptr;
     uint8_t *first_ptr = nullptr;
-    bool ob_contig = false, ac_contig = false;
+    bool ob_contig = false, ac_contig = false, info_contig = false;
     bool buffers_set = false;
     bool pending = false;
     bool registered_obs = false;
@@ -486,9 +486,13 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
     first_ptr = bufs->first;
     ob_contig = true;
     ac_contig = true;
+    info_contig = true;
     for (int e = 0; e < N; e++) {
         if ((uint8_t *)ob_ptr[e] != (uint8_t *)ob_ptr[0] + (size_t)e * OBS_BYTES) ob_contig = false;
         if ((uint8_t *)ac_ptr[e] != (uint8_t *)ac_ptr[0] + (size_t)e * 4) ac_contig = false;
+        if ((uint8_t *)info_ptr[0][e] != (uint8_t *)info_ptr[0][0] + (size_t)e * 4 || (uint8_t *)info_ptr[1][e] != (uint8_t *)info_ptr[1][0] + (size_t)e ||
+            (uint8_t *)info_ptr[2][e] != (uint8_t *)info_ptr[2][0] + (size_t)e * 4)
+            info_contig = false;
     }
     if (host_observations) {
         if (ob_contig) {
@@ -565,10 +569,16 @@ void VecGame::observe() {  // reference src/vecgame.cpp:363-376,416-435
     memcpy(first_ptr, h_small + 12 * N, N);
     const int32_t *pls = (const int32_t *)(h_small + 4 * N), *ls = (const int32_t *)(h_small + 8 * N);
     const uint8_t *plc = h_small + 13 * N;
-    for (size_t e = 0; e < N; e++) {
-        *(int32_t *)info_ptr[0][e] = pls[e];
-        *(uint8_t *)info_ptr[1][e] = plc[e];
-        *(int32_t *)info_ptr[2][e] = ls[e];
+    if (info_contig) {  // gym3's arrays are dense: three block copies instead of 3 N scattered stores (0.2 ms per step at 65536 envs)
+        memcpy(info_ptr[0][0], pls, 4 * N);
+        memcpy(info_ptr[1][0], plc, N);
+        memcpy(info_ptr[2][0], ls, 4 * N);
+    } else {
+        for (size_t e = 0; e < N; e++) {
+            *(int32_t *)info_ptr[0][e] = pls[e];
+            *(uint8_t *)info_ptr[1][e] = plc[e];
+            *(int32_t *)info_ptr[2][e] = ls[e];
+        }
     }
     if (host_observations && !ob_contig)
         for (size_t e = 0; e < N; e++) memcpy(ob_ptr[e], h_obs_stage + e * OBS_BYTES, OBS_BYTES);
