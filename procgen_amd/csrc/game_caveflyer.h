@@ -21,6 +21,9 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
     static constexpr bool USES_ROTATION = true;
     // a level drops 3 * (free cells / 80) objects: <= 60 in the 40x40 world, <= 135 in the 60x60 one
     static constexpr int ENT_CAP_T0 = CELLS > 1600 ? 160 : 64, ENT_CAP_T1 = CELLS > 1600 ? 192 : 96, ENT_CAP_T2 = CELLS > 1600 ? 256 : 160;
+    // the level generator's scratch dominates the arena: step kernels without it, resets in the reset kernel (pg_env.h GameSplit)
+    static constexpr bool SPLIT_RESET = true;
+    static constexpr int RESET_CAP = ENT_CAP_T0;
     // a bullet, an exhaust puff, one explosion per bullet (wall hits, collisions) and per target, the reserved slot
     template <class E>
     PG_DEV static int slots_needed_next_step(E &e) {

@@ -26,6 +26,9 @@ struct Jumper : BagDefaults<Jumper> {
     static constexpr int MAX_CELLS = 45 * 45;  // jumper.cpp:201-217 (memory mode)
     static constexpr bool HAS_OVERLAY = true;
     static constexpr int ENT_CAP_T0 = 64, ENT_CAP_T1 = 128, ENT_CAP_T2 = 256;  // agent, goal, spikes (~10-40), <= 8 trails
+    // the level generator's scratch dominates the arena: step kernels without it, resets in the reset kernel (pg_env.h GameSplit)
+    static constexpr bool SPLIT_RESET = true;
+    static constexpr int RESET_CAP = ENT_CAP_T0;
     template <class E>
     PG_DEV static int slots_needed_next_step(E &e) { return e.G.n_ents + 1 + 1; }
 

@@ -15,10 +15,14 @@ struct Leaper : BagDefaults<Leaper> {
     static constexpr bool USES_ROTATION = true;  // cars driving left are turned by 180 degrees (a negative scale), the frog by +-90
     static constexpr bool USES_TILED_ENTITIES = true;
     static constexpr int WIDE_ROWS = 8;  // 161 instead of 170 VGPRs in the renderer: three waves per SIMD instead of two
-    // reset: <= 15 cars x 5 lanes + 16 logs x 5 lanes in the worst case, typically < 90; steps: <= 10 spawns
-    static constexpr int ENT_CAP_T0 = 192, ENT_CAP_T1 = 224, ENT_CAP_T2 = 256;
+    // reset: <= 15 cars x 5 lanes + 16 logs x 5 lanes in the worst case, typically < 90 (its 300-400 spawner rounds never
+    // erase); steps: <= 10 spawns, and the first step's erase pass drops everything that left the world.  The reset kernel
+    // has the big table (SPLIT_RESET), the step kernels take the tier the entity count asks for.
+    static constexpr int ENT_CAP_T0 = 64, ENT_CAP_T1 = 128, ENT_CAP_T2 = 256;
+    static constexpr bool SPLIT_RESET = true;
+    static constexpr int RESET_CAP = ENT_CAP_T2;
     template <class E>
-    PG_DEV static int slots_needed_next_step(E &) { return 0; }  // every step may end in a reset: always the tier-0 arena
+    PG_DEV static int slots_needed_next_step(E &e) { return e.G.n_ents + e.G.gsi1 + e.G.gsi3 + 3; }  // (gsi1 / gsi3 = LP_N_ROAD / LP_N_WATER)  // one spawn per lane and step at most
 
     static constexpr int LOG = 1, ROAD = 2, WATER = 3, CAR = 4, FINISH_LINE = 5;
     static constexpr float MONSTER_RADIUS = 0.25f, LOG_RADIUS = 0.45f;

@@ -13,6 +13,8 @@ struct LaunchStreams {
     hipStream_t side[3];      // [0]: lane = env kernel + reset kernel of a game with a lane path, concurrent with the tier-0 grids of the chunks
     hipEvent_t lane_done[2];
     hipEvent_t side_done[3];
+    hipEvent_t step_done[MAX_CHUNKS];
+    int order;                // launch-order variant (PROCGEN_AMD_ORDER, see launch_game)
     int chunks;               // 1 = everything on `main`
     int list_count[MAX_CHUNKS][NUM_TIERS];  // entries of the lists this step reads (the host knows them from the previous step's download): an empty list's kernel is not launched
 };

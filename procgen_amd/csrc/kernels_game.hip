@@ -28,24 +28,37 @@ template <class Game>
 struct GameRenderMinWaves<Game, decltype((void)Game::RENDER_MIN_WAVES)> {
     static constexpr int value = Game::RENDER_MIN_WAVES;
 };
+// games with SPLIT_RESET: their step kernels carry no level generator (Env NO_RESET, arena without scratch)
+template <class Game, int CAP>
+using StepEnv = Env<Game, CAP, false, GameSplit<Game>::value>;
+
 template <class Game>
 __global__ __launch_bounds__(64) void step_tier0(DevCtx d, int mode, int env_base) {
-    __shared__ Lds<Game, Game::ENT_CAP_T0> lds;
+    __shared__ typename StepEnv<Game, Game::ENT_CAP_T0>::LdsT lds;
+    if (GameSplit<Game>::value && blockIdx.x == 0 && threadIdx.x == 0) d.next_reset_count[env_base / d.reset_chunk_envs] = 0;
     const int env = env_base + (int)blockIdx.x;
     if (mode != 0 && d.route[env] != 0) return;  // owned by a larger arena this step
-    Env<Game, Game::ENT_CAP_T0> e(d, env, &lds);
+    StepEnv<Game, Game::ENT_CAP_T0> e(d, env, &lds);
     e.run(mode);
+}
+
+// SPLIT_RESET games: the initial reset + first observation of every env (mode 0) needs the level generator's arena
+template <class Game>
+__global__ __launch_bounds__(64) void reset_grid(DevCtx d, int env_base) {
+    __shared__ Lds<Game, GameSplit<Game>::RESET_CAP> lds;
+    Env<Game, GameSplit<Game>::RESET_CAP> e(d, env_base + (int)blockIdx.x, &lds);
+    e.run(0);
 }
 
 template <class Game, int CAP, int TIER>
 __global__ __launch_bounds__(64) void step_list(DevCtx d, int mode, int chunk) {
-    __shared__ Lds<Game, CAP> lds;
+    __shared__ typename StepEnv<Game, CAP>::LdsT lds;
     const int count = d.big_count[chunk * NUM_TIERS + TIER];
     const int *list = d.big_list + (size_t)TIER * d.num_envs + (size_t)chunk * d.chunk_envs;
     for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
         const int env = list[k];
         if (d.route[env] != TIER) continue;  // set_state moved this env to another tier after the list was built
-        Env<Game, CAP> e(d, env, &lds);
+        StepEnv<Game, CAP> e(d, env, &lds);
         e.run(mode);
         __syncthreads();
     }
@@ -75,10 +88,10 @@ __global__ __launch_bounds__(64) void lane_step(DevCtx d, int chunk, int env_bas
 // the episodes the lane kernel of this chunk ended: reset + level generation, outputs and state write-back (Env::run mode 2)
 template <class Game>
 __global__ __launch_bounds__(64) void reset_list(DevCtx d, int chunk, int env_base) {
-    __shared__ Lds<Game, Game::ENT_CAP_T0> lds;
+    __shared__ Lds<Game, GameSplit<Game>::RESET_CAP> lds;
     const int count = d.reset_count[chunk];
     for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
-        Env<Game, Game::ENT_CAP_T0> e(d, d.reset_list[env_base + k], &lds);
+        Env<Game, GameSplit<Game>::RESET_CAP> e(d, d.reset_list[env_base + k], &lds);
         e.run(2);
         __syncthreads();
     }
@@ -124,7 +137,16 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
                 hipLaunchKernelGGL(reset_list<Game>, dim3(rg), dim3(64), 0, ls.main, d, 0, 0);
             }
         }
-        if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode, 0);
+        if constexpr (GameSplit<Game>::value) {
+            if (mode == 0) {
+                hipLaunchKernelGGL(reset_grid<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, 0);
+            } else {
+                hipLaunchKernelGGL(step_tier0<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode, 0);
+                hipLaunchKernelGGL(reset_list<Game>, dim3(rg), dim3(64), 0, ls.main, d, 0, 0);
+            }
+        } else {
+            if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode, 0);
+        }
         if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, 0);
         return hipGetLastError();
     }
@@ -145,11 +167,18 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
     }
     PG_TRY(hipStreamWaitEvent(ls.lane[0], ls.fork, 0));
     PG_TRY(hipStreamWaitEvent(ls.lane[1], ls.fork, 0));
-    if (t2) {
-        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.lane[1], d, mode, 0);
-        PG_TRY(hipEventRecord(ls.side_done[1], ls.lane[1]));
-    }
+    // launch order experiments (PROCGEN_AMD_ORDER): 0 = tier-2 list ahead of chunk 1 on its stream (which also delays that
+    // chunk's step kernel: an accidental pipeline); 1 / 3 = tier-2 list on the side stream and chunk c + 1's step kernel
+    // explicitly behind chunk c's; 2 = side stream, no chaining
     const bool lane_side = lane && !(d.debug_flags & 16384);
+    const bool t2_side = ls.order != 0 && !lane_side && ls.side[0] != nullptr;
+    const bool chain = ls.order == 1 || ls.order == 3;
+    if (t2) {
+        hipStream_t s2 = t2_side ? ls.side[0] : ls.lane[1];
+        if (t2_side) PG_TRY(hipStreamWaitEvent(s2, ls.fork, 0));
+        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, s2, d, mode, 0);
+        PG_TRY(hipEventRecord(ls.side_done[1], s2));
+    }
     if constexpr (GameLane<Game>::value) {
         if (lane_side) {
             PG_TRY(hipStreamWaitEvent(ls.side[0], ls.fork, 0));
@@ -165,9 +194,19 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         const int count = (d.num_envs - base) < per ? (d.num_envs - base) : per;
         if (count <= 0) break;
         hipStream_t st = ls.lane[c & 1];
-        if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(count), dim3(64), 0, st, d, mode, base);
+        if (chain && c > 0 && mode != 0) PG_TRY(hipStreamWaitEvent(st, ls.step_done[c - 1], 0));
+        if (GameSplit<Game>::value && mode == 0) {
+            if constexpr (GameSplit<Game>::value) hipLaunchKernelGGL(reset_grid<Game>, dim3(count), dim3(64), 0, st, d, base);
+        } else if (!(d.debug_flags & 32) || mode == 0) {
+            hipLaunchKernelGGL(step_tier0<Game>, dim3(count), dim3(64), 0, st, d, mode, base);
+        }
+        if (chain && mode != 0) PG_TRY(hipEventRecord(ls.step_done[c], st));
         if (t1) PG_TRY(hipStreamWaitEvent(st, ls.side_done[0], 0));
-        if (t2 && (c & 1) == 0) PG_TRY(hipStreamWaitEvent(st, ls.side_done[1], 0));
+        if (t2 && ((c & 1) == 0 || t2_side)) PG_TRY(hipStreamWaitEvent(st, ls.side_done[1], 0));
+        if constexpr (GameSplit<Game>::value) {
+            // the episodes this chunk's step kernel (and the list kernels, for its envs) ended: next level, outputs, routing
+            if (mode != 0) hipLaunchKernelGGL(reset_list<Game>, dim3(count < 1024 ? count : 1024), dim3(64), 0, st, d, c, base);
+        }
         if (lane_side) PG_TRY(hipStreamWaitEvent(st, ls.side_done[2], 0));
         if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(count), dim3(64), 0, st, d, base);
     }

@@ -122,6 +122,8 @@ struct VecGame {
     hipStream_t lane_stream[2] = {nullptr, nullptr}, side_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_lane[2] = {nullptr, nullptr};
     hipEvent_t ev_side[3] = {};
+    hipEvent_t ev_step[MAX_CHUNKS] = {};
+    int order = 0;  // PROCGEN_AMD_ORDER
     int chunks = 2;  // PROCGEN_AMD_CHUNKS: env range cut in 2 so one chunk's step kernel overlaps the other's render kernel (+6 % measured)
     LaunchStreams streams() const {
         LaunchStreams ls{};
@@ -135,6 +137,8 @@ struct VecGame {
             ls.side[k] = side_stream[k];
             ls.side_done[k] = ev_side[k];
         }
+        for (int c = 0; c < MAX_CHUNKS; c++) ls.step_done[c] = ev_step[c];
+        ls.order = order;
         ls.chunks = chunks;
         return ls;
     }
@@ -341,7 +345,9 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
             HIP_CHECK(hipStreamCreateWithFlags(&lane_stream[k], hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&ev_lane[k], hipEventDisableTiming));
         }
-        if (game_has_lane(kernel_id)) HIP_CHECK(hipStreamCreateWithFlags(&side_stream[0], hipStreamNonBlocking));  // four streams at most (hardware queues)
+        if (const char *o = getenv("PROCGEN_AMD_ORDER")) order = atoi(o);
+        if (game_has_lane(kernel_id) || order != 0) HIP_CHECK(hipStreamCreateWithFlags(&side_stream[0], hipStreamNonBlocking));  // four streams at most (hardware queues)
+        for (int c = 0; c < MAX_CHUNKS; c++) HIP_CHECK(hipEventCreateWithFlags(&ev_step[c], hipEventDisableTiming));
         for (int k = 0; k < 3; k++) HIP_CHECK(hipEventCreateWithFlags(&ev_side[k], hipEventDisableTiming));
     }
     if (const char *c = getenv("PROCGEN_AMD_CHUNKS")) chunks = atoi(c) > 0 ? (atoi(c) < MAX_CHUNKS ? atoi(c) : MAX_CHUNKS) : 1;
@@ -364,6 +370,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     // MI355X it does not beat the wave = env kernels yet, and its tile-interleaved entity table
     // costs the wave = env kernels and the renderer their contiguous reads.
     d.ent_tile = (game_has_lane(kernel_id) && getenv("PROCGEN_AMD_LANE") && atoi(getenv("PROCGEN_AMD_LANE")) != 0) ? TILE_ENVS : 1;
+    // reset lists follow the launch chunks (SPLIT_RESET games); the lane = env kernel is one launch over all tiles
+    d.reset_chunk_envs = d.ent_tile == TILE_ENVS ? chunk_envs_for(num_envs, 1) : chunk_envs_for(num_envs, chunks);
     d.hdr = dev_alloc<EnvHdr>(N);
     d.rng = dev_alloc<uint32_t>(N * MT_SLOTS * MT_STRIDE);
     d.ents = dev_alloc<uint32_t>(ent_table_words(num_envs, d.ent_cap));
@@ -468,6 +476,8 @@ VecGame::~VecGame() {
         if (ev_lane[k]) (void)hipEventDestroy(ev_lane[k]);
         if (lane_stream[k]) (void)hipStreamDestroy(lane_stream[k]);
     }
+    for (int c = 0; c < MAX_CHUNKS; c++)
+        if (ev_step[c]) (void)hipEventDestroy(ev_step[c]);
     for (int k = 0; k < 3; k++) {
         if (ev_side[k]) (void)hipEventDestroy(ev_side[k]);
         if (side_stream[k]) (void)hipStreamDestroy(side_stream[k]);

@@ -12,6 +12,8 @@
 // (game_coinrun.h, ...).  Floating point mirrors the reference expression by expression (float/double
 // promotion order); build with -ffp-contract=off.
 #pragma once
+#include <type_traits>
+
 #include "pg_defs.h"
 #include "wave.h"
 
@@ -124,6 +126,21 @@ struct GameLane<Game, decltype((void)Game::HAS_LANE_STEP)> {
     static constexpr bool value = Game::HAS_LANE_STEP;
     static constexpr int MAX_DRAWS = Game::LANE_MAX_DRAWS;
 };
+// A game whose level generator needs much more LDS than its steps (scratch for maze / room generation, or an entity table
+// that only a reset fills) declares SPLIT_RESET = true and RESET_CAP: its step kernels are compiled without the generator
+// (Env NO_RESET: no scratch in their arena, smaller entity tiers), an episode that ends is queued, and the reset kernel
+// (reset_list, arena RESET_CAP + scratch) generates the next level behind the chunk's step kernel.
+template <class Game, class = void>
+struct GameSplit {
+    static constexpr bool value = false;
+    static constexpr int RESET_CAP = Game::ENT_CAP_T0;
+};
+template <class Game>
+struct GameSplit<Game, decltype((void)Game::SPLIT_RESET)> {
+    static constexpr bool value = Game::SPLIT_RESET;
+    static constexpr int RESET_CAP = Game::RESET_CAP;
+};
+
 // the entity-table tile size of a handle of this game: a compile-time 1 for games without a lane = env path (their
 // kernels keep plain contiguous indexing), DevCtx::ent_tile otherwise
 template <class Game>
@@ -202,12 +219,13 @@ struct LaneRef {
         if constexpr (!LANE) PG_SYNC();  \
     } while (0)
 
-template <class Game, int CAP>
+// WITH_SCRATCH = false: the arena of a step kernel that never generates a level (games with SPLIT_RESET, see GameSplit)
+template <class Game, int CAP, bool WITH_SCRATCH = true>
 struct Lds {
     uint32_t ent[EF_COUNT * CAP];
     uint32_t tmp[128];  // lane scratch; simple_choose keeps up to 128 picks here
     alignas(16) typename Game::cell_t grid[(Game::MAX_CELLS + 15) & ~15];
-    typename GameScratch<Game>::type scratch;
+    typename std::conditional<WITH_SCRATCH, typename GameScratch<Game>::type, NoScratch>::type scratch;
 #if defined(PG_LDS_PAD)
     uint8_t pad[PG_LDS_PAD];  // occupancy experiments only
 #endif
@@ -219,14 +237,17 @@ struct Lds {
 //   entity table and the grid are accessed in place in HBM (the tile-interleaved table makes a wave's 64 accesses to
 //   one slot contiguous), every loop over entities is the lane's own serial loop, and nothing in this mode may use a
 //   lane section or a ballot -- level generation (resets) is handed to the wave = env reset kernel.
-template <class Game, int CAP, bool LANE_MODE = false>
+// NO_RESET (wave = env only): a step kernel of a SPLIT_RESET game -- like the lane kernel it stops where the episode ends.
+template <class Game, int CAP, bool LANE_MODE = false, bool NO_RESET_MODE = false>
 struct Env {
     using cell_t = typename Game::cell_t;
     static constexpr int CAPACITY = CAP;
     static constexpr bool LANE = LANE_MODE;
+    static constexpr bool NO_RESET = NO_RESET_MODE;
+    typedef Lds<Game, CAP, !NO_RESET_MODE> LdsT;
     const DevCtx &d;
     const int env;
-    Lds<Game, CAP> *s;
+    LdsT *s;
     uint32_t *lent;   // LANE: this env's (field 0, slot 0) word in the tile-interleaved HBM table
     PG_LDS_PTR(uint32_t) lcache;  // LANE: this lane's column of the LDS entity cache (LaneLds)
     PG_LDS_PTR(cell_t) lwin;      // LANE: this lane's column of the LDS grid window
@@ -278,7 +299,7 @@ struct Env {
         (void)slot; (void)v; (void)is_max;
 #endif
     }
-    PG_DEV Env(const DevCtx &d_, int env_, Lds<Game, CAP> *s_) : d(d_), env(env_), s(s_) {
+    PG_DEV Env(const DevCtx &d_, int env_, LdsT *s_) : d(d_), env(env_), s(s_) {
         lent = LANE ? d.ents + ent_tile_base(env_, CAP, TILE_ENVS) : nullptr;  // (the lane kernel only runs on tile-interleaved tables)
         has_lds = false;
         ncand = -1;
@@ -1696,13 +1717,13 @@ struct Env {
         G.prev_level_seed = G.current_level_seed;
         // (what follows in Game::step -- the reset of a finished episode -- is finish_step's: level generation is
         // wave-structured, so the lane = env kernel stops here and a finished episode goes to the reset kernel, run(2))
-        if constexpr (LANE) needs_reset = G.done != 0;
+        if constexpr (LANE || NO_RESET) needs_reset = G.done != 0;
     }
     // the rest of Game::step once game_step has run (reference src/game.cpp:144-155); initial = the reset + first
     // observation libenv_set_buffers asks for (reference src/vecgame.cpp:346-357).  One call site of the level
     // generator per kernel: the step kernels are sensitive to their code size (instruction cache).
     PG_DEV void finish_step(bool initial) {
-        if constexpr (!LANE) {
+        if constexpr (!LANE && !NO_RESET) {
             if (initial || G.done) {
                 game_reset_full();
                 phase(6);
@@ -1863,6 +1884,17 @@ struct Env {
         G.big = tier;
     }
 
+    // hand this env (its episode just ended, its header is stored) to the reset kernel of its chunk
+    PG_DEV void queue_reset() {
+#if !defined(PGAMD_WAVE_EMU)
+        if (LANE || PG_LANE_ID() == 0) {
+            if (G.error) atomicOr(d.error, G.error);
+            const int c = env / d.reset_chunk_envs;
+            d.reset_list[(size_t)c * d.reset_chunk_envs + atomicAdd(d.reset_count + c, 1)] = env;
+        }
+#endif
+    }
+
     // tell the next step which kernel owns this env, and surface error codes to the host
     PG_DEV void publish_routing() {
 #if defined(PGAMD_WAVE_EMU)
@@ -1893,6 +1925,21 @@ struct Env {
             // ablation: staging only
         } else {
             if (mode == 1) game_step_full();
+            if constexpr (NO_RESET) {
+                if (needs_reset) {  // the reset kernel behind this one takes over (run(2)): it needs the header only
+                    G.big = ROUTE_RESET;
+                    EnvHdr *h = d.hdr + env;
+                    PG_FOR_LANES(l) {
+                        if (l == 0) {
+#define PG_X(type, name) h->name = G.name;
+                            PG_HDR_FIELDS(PG_X)
+#undef PG_X
+                        }
+                    }
+                    queue_reset();
+                    return;
+                }
+            }
             finish_step(mode == 0);
         }
         rand_flush();
@@ -1973,15 +2020,9 @@ struct Env {
             lane_count(13, (unsigned long long)lane_smart_count);  // (of the accounting lane)
         }
 #endif
-#if !defined(PGAMD_WAVE_EMU)
-        if (needs_reset) {
-            if (G.error) atomicOr(d.error, G.error);
-            d.reset_list[chunk_base + atomicAdd(d.reset_count + chunk, 1)] = env;
-        }
-#else
         (void)chunk;
         (void)chunk_base;
-#endif
+        if (needs_reset) queue_reset();
     }
 };
 

@@ -36,7 +36,7 @@ struct EmuVec {
     int dev_error = 0;
     int game_id = -1;
     int kernel_id = -1;
-    long long lane_steps = 0, lane_resets = 0, wave_steps = 0;  // which execution model stepped the envs (tests assert both ran)
+    long long lane_steps = 0, lane_resets = 0, wave_steps = 0, split_resets = 0;  // which execution model stepped the envs (tests assert both ran)
 };
 
 template <class Game, int CAP>
@@ -44,6 +44,21 @@ static void run_env(EmuVec *v, int env, int mode) {
     static Lds<Game, CAP> lds;  // one "workgroup" at a time
     Env<Game, CAP> e(v->d, env, &lds);
     e.run(mode);
+}
+// a step kernel of a SPLIT_RESET game: no level generator, arena without scratch; an ended episode goes to "reset_list"
+template <class Game, int CAP>
+static void run_step_env(EmuVec *v, int env) {
+    if constexpr (GameSplit<Game>::value) {
+        static Lds<Game, CAP, false> lds;
+        Env<Game, CAP, false, true> e(v->d, env, &lds);
+        e.run(1);
+        if (v->hdr[env].big == ROUTE_RESET) {
+            v->split_resets++;
+            run_env<Game, GameSplit<Game>::RESET_CAP>(v, env, 2);
+        }
+    } else {
+        run_env<Game, CAP>(v, env, 1);
+    }
 }
 
 template <class Game>
@@ -74,10 +89,14 @@ static void run_all(EmuVec *v, int mode) {
             }
             if (tier == ROUTE_LANE) tier = 0;  // (mode 0: everything starts in the tier-0 grid)
         }
-        if (mode == 1) v->wave_steps++;
-        if (tier == 0) run_env<Game, Game::ENT_CAP_T0>(v, e, mode);
-        else if (tier == 1) run_env<Game, Game::ENT_CAP_T1>(v, e, mode);
-        else run_env<Game, Game::ENT_CAP_T2>(v, e, mode);
+        if (mode == 1) {
+            v->wave_steps++;
+            if (tier == 0) run_step_env<Game, Game::ENT_CAP_T0>(v, e);
+            else if (tier == 1) run_step_env<Game, Game::ENT_CAP_T1>(v, e);
+            else run_step_env<Game, Game::ENT_CAP_T2>(v, e);
+        } else {
+            run_env<Game, GameSplit<Game>::RESET_CAP>(v, e, mode);  // "reset_grid" / the tier-0 grid in mode 0
+        }
     }
     static RenderLdsT<Game> rlds;
     for (int e = 0; e < v->n; e++) {  // "render kernel": one wave per env
@@ -148,6 +167,7 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.opt.debug_mode = debug_mode;
     if (const char *dbg = getenv("PROCGEN_AMD_DEBUG")) d.debug_flags = atoi(dbg);
     d.chunk_envs = (num_envs + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;
+    d.reset_chunk_envs = d.chunk_envs;
     // lane = 0: per-env contiguous entity tables, no lane = env routing (the product's default); games without a lane = env
     // path always use them (ent_tile_of)
     d.ent_tile = 1;
@@ -270,6 +290,7 @@ void emu_path_counts(void *h, long long *out) {
     out[0] = v->lane_steps;
     out[1] = v->lane_resets;
     out[2] = v->wave_steps;
+    out[3] = v->split_resets;
 }
 int emu_error(void *h, int env) { return ((EmuVec *)h)->hdr[env].error | ((EmuVec *)h)->dev_error; }
 int emu_num_entities(void *h, int env) { return ((EmuVec *)h)->hdr[env].n_ents; }

@@ -122,8 +122,9 @@ class EmuEnv:
             assert self.L.emu_set_state(self.h, e, st, len(st)) == 0
 
     def path_counts(self):
-        """(env-steps taken by the lane = env kernel, of which ended an episode -> reset kernel, env-steps taken by the wave = env kernels)"""
-        out = (C.c_longlong * 3)()
+        """(env-steps taken by the lane = env kernel, of which ended an episode -> reset kernel, env-steps taken by the wave = env
+        kernels, episodes a SPLIT_RESET game's step kernels handed to the reset kernel)"""
+        out = (C.c_longlong * 4)()
         self.L.emu_path_counts(self.h, out)
         return tuple(out)
 

@@ -75,9 +75,20 @@ def test_lane_env_kernel_over_timeouts_twists_and_resets(game, steps):
     assert_rollouts_equal(a, b, f"lane path, long horizon ({game})")
     for e in range(n):
         assert np.array_equal(orc.entities(e), emu.entities(e)) and np.array_equal(orc.grid(e), emu.grid(e))
-    lane, lane_resets, wave = emu.path_counts()
+    lane, lane_resets, wave, _ = emu.path_counts()
     assert lane > 0.25 * n * steps and lane_resets > 0 and wave > 0, (lane, lane_resets, wave)
     assert a["first"][1000:1002].any(), "an episode must have ended by timeout"
+
+
+@pytest.mark.parametrize("game", ["jumper", "caveflyer"])
+def test_split_reset_games_hand_ended_episodes_to_the_reset_kernel(game):
+    """Games with SPLIT_RESET (pg_env.h GameSplit): their step kernels carry no level generator; an episode that ends is
+    finished by the reset kernel (Env::run(2)).  Bit-exact against the oracle, with that path taken."""
+    n, steps = 12, 300
+    acts = action_stream(n, steps, seed=14)
+    emu = emu_harness.EmuEnv(n, game, rand_seed=23)
+    assert_rollouts_equal(rollout(oracle_env.OracleEnv(n, game, rand_seed=23), acts), rollout(emu, acts), game)
+    assert emu.path_counts()[3] >= 3
 
 
 @pytest.mark.parametrize("game", ["bossfight", "plunder", "bigfish", "coinrun", "leaper"])
