@@ -20,6 +20,9 @@ Extra objects on the JSON line:
   host_landed  : the PCIe-inclusive rate of the same loop through the unmodified libenv ABI (observations copied into
                  the caller's host array every step) -- reported beside `value`, never as it.
 """
+import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before torch initialises HIP: see INTEGRATION.md section 5 (joint handles: one stream per game)
 import argparse
 import ctypes as C
 import json

@@ -1,5 +1,7 @@
 R=$GRAFT_REPO_ROOT
 cd $R
-python tools/gpu/ab_bench.py tools/gpu/ab/libenv_r01.so,procgen_amd/csrc/build/libenv.so coinrun,leaper,jumper,caveflyer,starpilot 2>&1 | grep -v amdgpu.ids
-python bench.py --game all16 --num-envs 16384 --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('joint 16384:', j['value'], j['ms_per_step'])"
-python -m pytest tests/test_gpu_parity.py -x -q -k "parity_with_oracle_many_envs" 2>&1 | tail -2
+b() { python bench.py --game all16 --num-envs 16384 --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'])"; }
+echo "default"; b
+echo "queues 16"; GPU_MAX_HW_QUEUES=16 b
+echo "threads 1"; PROCGEN_AMD_HOST_THREADS=1 b
+python -m pytest tests -m gpu -x -q -k "joint or sharded or sixteen" 2>&1 | tail -2
