@@ -201,7 +201,23 @@ struct Leaper : BagDefaults<Leaper> {
             spawn_entities(e);
             PG_SYNC();
             if (agent_idle) {
-                e.step_entities_all_plain();
+                // Entity::step of a car / log as spawn_entities creates them (vy = 0, no spin, friction = grow_rate =
+                // alpha_decay = 1, no expiry): x += vx and life_time += 1, every other member keeps its bits
+                const int n = G.n_ents, a = G.agent;
+                for (int base = 0; base < n; base += 64) {
+                    PG_FOR_LANES(l) {
+                        const int idx = base + l;
+                        if (idx < n) {
+                            if (idx == a) {
+                                e.ent_step(idx);
+                            } else {
+                                e.ex(idx) += e.evx(idx);
+                                e.ei(EF_LIFE_TIME, idx) += 1;
+                            }
+                        }
+                    }
+                }
+                PG_SYNC();
             } else {
                 const int a = G.agent;
                 const float x0 = e.ex(a), y0 = e.ey(a), vx0 = e.evx(a), vy0 = e.evy(a);

@@ -548,7 +548,7 @@ void VecGame::read_tail() {
 void VecGame::launch(int mode) {
     launch_kernels(mode);
     HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
-    if (host_observations) {
+    if (host_observations) {  // one copy behind the whole step (a copy per chunk behind its render kernel measured 4 % slower: 17.6 vs 16.9 ms)
         void *dst = ob_contig ? ob_ptr[0] : (void *)h_obs_stage;
         HIP_CHECK(hipMemcpyAsync(dst, d.obs, (size_t)num_envs * OBS_BYTES, hipMemcpyDeviceToHost, stream));
     }
