@@ -14,6 +14,7 @@ struct LaunchStreams {
     hipEvent_t lane_done[2];
     hipEvent_t side_done[3];
     hipEvent_t step_done[MAX_CHUNKS];
+    int first_pct;            // experiment: share of the first of two chunks in percent (0 = even)
     int order;                // launch-order variant (PROCGEN_AMD_ORDER, see launch_game)
     int chunks;               // 1 = everything on `main`
     int list_count[MAX_CHUNKS][NUM_TIERS];  // entries of the lists this step reads (the host knows them from the previous step's download): an empty list's kernel is not launched

@@ -139,6 +139,7 @@ struct VecGame {
         }
         for (int c = 0; c < MAX_CHUNKS; c++) ls.step_done[c] = ev_step[c];
         ls.order = order;
+        ls.first_pct = getenv("PROCGEN_AMD_FIRST_PCT") ? atoi(getenv("PROCGEN_AMD_FIRST_PCT")) : 75;
         ls.chunks = chunks;
         return ls;
     }
