@@ -19,6 +19,7 @@ struct LaunchStreams {
     int chunks;               // 1 = everything on `main`
     int list_count[MAX_CHUNKS][NUM_TIERS];  // entries of the lists this step reads (the host knows them from the previous step's download): an empty list's kernel is not launched
 };
+int first_chunk_envs(int num_envs, int first_pct);  // envs of the first of two uneven chunks (whole tiles; 0 = even cut)
 int chunk_envs_for(int num_envs, int chunks);  // envs per chunk: whole tiles; one chunk below 4096 envs
 // what one per-game kernel object (kernels_game.hip) exports
 struct GameEntry {

@@ -31,6 +31,11 @@ hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t 
     const GameEntry *e = find(game_id);
     return e ? e->render_one(d, env, stream) : hipErrorInvalidValue;
 }
+int first_chunk_envs(int num_envs, int first_pct) {
+    if (first_pct <= 0 || first_pct >= 100 || num_envs < 4096) return 0;
+    const int first = (int)((long long)num_envs * first_pct / 100) / TILE_ENVS * TILE_ENVS;
+    return (first > 0 && first < num_envs) ? first : 0;
+}
 int chunk_envs_for(int num_envs, int chunks) {
     const int nchunk = (chunks > 1 && num_envs >= 4096) ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1;
     const int per = ((num_envs + nchunk - 1) / nchunk + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;

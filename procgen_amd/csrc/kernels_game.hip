@@ -35,7 +35,7 @@ using StepEnv = Env<Game, CAP, false, GameSplit<Game>::value>;
 template <class Game>
 __global__ __launch_bounds__(64) void step_tier0(DevCtx d, int mode, int env_base) {
     __shared__ typename StepEnv<Game, Game::ENT_CAP_T0>::LdsT lds;
-    if (GameSplit<Game>::value && blockIdx.x == 0 && threadIdx.x == 0) d.next_reset_count[env_base / d.reset_chunk_envs] = 0;
+    if (GameSplit<Game>::value && blockIdx.x == 0 && threadIdx.x == 0) d.next_reset_count[d.reset_first > 0 ? (env_base >= d.reset_first ? 1 : 0) : env_base / d.reset_chunk_envs] = 0;
     const int env = env_base + (int)blockIdx.x;
     if (mode != 0 && d.route[env] != 0) return;  // owned by a larger arena this step
     StepEnv<Game, Game::ENT_CAP_T0> e(d, env, &lds);
@@ -193,7 +193,7 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
     // streams run in lockstep -- both step kernels, then both render kernels -- and the step / render overlap the chunks exist
     // for hardly happens.  Measured 25 / 75 or 75 / 25 against 50 / 50: starpilot +9 %, maze +3-6 %, bigfish +4 %, coinrun +1 %
     // (coinrun only with the large chunk first: its tier-2 list kernel already delays the second stream).
-    const int first = (nchunk == 2 && ls.first_pct > 0 && !GameSplit<Game>::value) ? (int)((long long)d.num_envs * ls.first_pct / 100) / TILE_ENVS * TILE_ENVS : 0;
+    const int first = (nchunk == 2 && ls.first_pct > 0) ? first_chunk_envs(d.num_envs, ls.first_pct) : 0;  // (== DevCtx::reset_first)
     for (int c = 0; c < nchunk; c++) {
         const int base = first > 0 ? (c == 0 ? 0 : first) : c * per;
         const int count = first > 0 ? (c == 0 ? first : d.num_envs - first) : ((d.num_envs - base) < per ? (d.num_envs - base) : per);

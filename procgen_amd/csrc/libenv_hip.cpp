@@ -124,6 +124,7 @@ struct VecGame {
     hipEvent_t ev_side[3] = {};
     hipEvent_t ev_step[MAX_CHUNKS] = {};
     int order = 0;  // PROCGEN_AMD_ORDER
+    int first_pct = 75;  // PROCGEN_AMD_FIRST_PCT: share of the first of two chunks
     int chunks = 2;  // PROCGEN_AMD_CHUNKS: env range cut in 2 so one chunk's step kernel overlaps the other's render kernel (+6 % measured)
     LaunchStreams streams() const {
         LaunchStreams ls{};
@@ -139,7 +140,7 @@ struct VecGame {
         }
         for (int c = 0; c < MAX_CHUNKS; c++) ls.step_done[c] = ev_step[c];
         ls.order = order;
-        ls.first_pct = getenv("PROCGEN_AMD_FIRST_PCT") ? atoi(getenv("PROCGEN_AMD_FIRST_PCT")) : 75;
+        ls.first_pct = first_pct;
         ls.chunks = chunks;
         return ls;
     }
@@ -373,6 +374,9 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d.ent_tile = (game_has_lane(kernel_id) && getenv("PROCGEN_AMD_LANE") && atoi(getenv("PROCGEN_AMD_LANE")) != 0) ? TILE_ENVS : 1;
     // reset lists follow the launch chunks (SPLIT_RESET games); the lane = env kernel is one launch over all tiles
     d.reset_chunk_envs = d.ent_tile == TILE_ENVS ? chunk_envs_for(num_envs, 1) : chunk_envs_for(num_envs, chunks);
+    if (const char *f = getenv("PROCGEN_AMD_FIRST_PCT")) first_pct = atoi(f);
+    d.reset_first = (chunks == 2 && d.ent_tile != TILE_ENVS) ? first_chunk_envs(num_envs, first_pct) : 0;
+    if (d.reset_first == 0) first_pct = 0;
     d.hdr = dev_alloc<EnvHdr>(N);
     d.rng = dev_alloc<uint32_t>(N * MT_SLOTS * MT_STRIDE);
     d.ents = dev_alloc<uint32_t>(ent_table_words(num_envs, d.ent_cap));

@@ -182,7 +182,8 @@ struct DevCtx {
     const uint8_t *route;  // [num_envs]
     uint8_t *next_route;   // [num_envs] written by every env's store_env
     // envs the lane = env kernel stepped into `done`: the wave = env reset kernel of the same step generates their next level
-    int reset_chunk_envs;   // envs per reset chunk: env e's reset goes to list chunk e / reset_chunk_envs
+    int reset_chunk_envs;   // envs per reset chunk: env e's reset goes to list chunk e / reset_chunk_envs ...
+    int reset_first;        // ... unless > 0: two uneven chunks, [0, reset_first) and the rest (list chunk 1 starts at reset_first)
     int *reset_list;        // [num_envs]: the envs of chunk c are appended from index c * reset_chunk_envs on
     int *reset_count;       // [MAX_CHUNKS] per env chunk, this step
     int *next_reset_count;  // [MAX_CHUNKS] the next step's counters (double-buffered by step parity), zeroed by this step's lane kernel

@@ -1889,8 +1889,9 @@ struct Env {
 #if !defined(PGAMD_WAVE_EMU)
         if (LANE || PG_LANE_ID() == 0) {
             if (G.error) atomicOr(d.error, G.error);
-            const int c = env / d.reset_chunk_envs;
-            d.reset_list[(size_t)c * d.reset_chunk_envs + atomicAdd(d.reset_count + c, 1)] = env;
+            const int c = d.reset_first > 0 ? (env >= d.reset_first ? 1 : 0) : env / d.reset_chunk_envs;
+            const size_t base = d.reset_first > 0 ? (c ? (size_t)d.reset_first : 0) : (size_t)c * d.reset_chunk_envs;
+            d.reset_list[base + atomicAdd(d.reset_count + c, 1)] = env;
         }
 #endif
     }

@@ -168,6 +168,7 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     if (const char *dbg = getenv("PROCGEN_AMD_DEBUG")) d.debug_flags = atoi(dbg);
     d.chunk_envs = (num_envs + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;
     d.reset_chunk_envs = d.chunk_envs;
+    d.reset_first = 0;
     // lane = 0: per-env contiguous entity tables, no lane = env routing (the product's default); games without a lane = env
     // path always use them (ent_tile_of)
     d.ent_tile = 1;
