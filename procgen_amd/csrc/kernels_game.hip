@@ -192,7 +192,8 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
     // Two chunks are cut unevenly (PROCGEN_AMD_FIRST_PCT, default 75 / 25; games without split resets): with equal chunks the two
     // streams run in lockstep -- both step kernels, then both render kernels -- and the step / render overlap the chunks exist
     // for hardly happens.  Measured 25 / 75 or 75 / 25 against 50 / 50: starpilot +9 %, maze +3-6 %, bigfish +4 %, coinrun +1 %
-    // (coinrun only with the large chunk first: its tier-2 list kernel already delays the second stream).
+    // (coinrun only with the large chunk first: its tier-2 list kernel already delays the second stream).  Three or four
+    // chunks, even or uneven (50/30/20, 40/30/20/10, ...), measured 15-18 % slower than two for coinrun and starpilot.
     const int first = (nchunk == 2 && ls.first_pct > 0) ? first_chunk_envs(d.num_envs, ls.first_pct) : 0;  // (== DevCtx::reset_first)
     for (int c = 0; c < nchunk; c++) {
         const int base = first > 0 ? (c == 0 ? 0 : first) : c * per;
