@@ -1,7 +1,6 @@
 R=$GRAFT_REPO_ROOT
-cd $R
-b() { python bench.py --game all16 --num-envs 16384 --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'])"; }
-echo "default"; b
-echo "queues 16"; GPU_MAX_HW_QUEUES=16 b
-echo "threads 1"; PROCGEN_AMD_HOST_THREADS=1 b
-python -m pytest tests -m gpu -x -q -k "joint or sharded or sixteen" 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt -o kt -- python $R/bench.py --game all16 --num-envs 16384 --steps 40 --warmup 10 --no-cpu-baseline > $R/gpurun_out/r2_joint_kt.log 2>&1
+python $R/tests/tools/rocpd_summary.py $(find $R/gpurun_out/kt -name "*.db" | head -1) > $R/gpurun_out/r02_joint_kernel_trace_final.csv 2>&1
+rm -rf $R/gpurun_out/kt
+cat $R/gpurun_out/r02_joint_kernel_trace_final.csv | cut -c1-130 | head -24
