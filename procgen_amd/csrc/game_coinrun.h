@@ -21,6 +21,10 @@ struct CoinRun {
     static constexpr int ENT_CAP_T0 = 64, ENT_CAP_T1 = 160, ENT_CAP_T2 = 384;
     // Per step the list grows by at most one trail per ENEMY (enemies are only created by a reset); a reset
     // creates <= 42 entities.  One slot is reserved (detached agent).
+    // pg_env.h GameParSmart: the agent and the walking enemies are never the target of a sub_step scan (may_interact(., PLAYER)
+    // and may_interact(., ENEMY) are false for every type) and their hooks touch nothing but the moving object
+    static constexpr bool PAR_SMART = true;
+    PG_DEV static bool par_smart_type_ok(int t) { return t == PLAYER || t == ENEMY; }
     // lane = env step path (pg_env.h LANE_MODE): a step draws step_rand_int and nothing else from rand_gen
     static constexpr bool HAS_LANE_STEP = true;
     static constexpr int LANE_MAX_DRAWS = 1;

@@ -40,6 +40,7 @@ constexpr uint32_t MF_ABS_COORDS = 1u << 27;
 constexpr uint32_t MF_SMART_STEP = 1u << 28;
 constexpr uint32_t MF_AVOIDS = 1u << 29;
 constexpr uint32_t MF_AUTO_ERASE = 1u << 30;
+constexpr uint32_t MF_PAR_DONE = 1u << 31;  // transient, inside step_entities only: basic_step_object already done in the parallel pass
 
 PG_DEV uint32_t meta_make(int type, int image_type, int image_theme, int render_z, uint32_t flags) {
     return ((uint32_t)type & M_TYPE_MASK) | (((uint32_t)image_type & 0xffu) << M_IMG_SHIFT) | (((uint32_t)image_theme & 0xfu) << M_THEME_SHIFT) |
@@ -139,6 +140,19 @@ template <class Game>
 struct GameSplit<Game, decltype((void)Game::SPLIT_RESET)> {
     static constexpr bool value = Game::SPLIT_RESET;
     static constexpr int RESET_CAP = Game::RESET_CAP;
+};
+
+// A game declares PAR_SMART = true and par_smart_type_ok(type) for the smart_step entity types (a) whose basic_step_object
+// has no side effect beyond the object itself when no entity can block or reflect it, and (b) that no smart entity's
+// sub_step scan can ever hit (may_interact(any smart type, type) is false): the wave = env step_entities then steps all
+// such objects of an env at once, one lane per object, instead of one after the other (Env::step_entities).
+template <class Game, class = void>
+struct GameParSmart {
+    static constexpr bool value = false;
+};
+template <class Game>
+struct GameParSmart<Game, decltype((void)Game::PAR_SMART)> {
+    static constexpr bool value = Game::PAR_SMART;
 };
 
 // the entity-table tile size of a handle of this game: a compile-time 1 for games without a lane = env path (their
@@ -400,7 +414,7 @@ struct Env {
 
     // Entity::step: reference src/entity.cpp:57-82 (callable from a lane section or from uniform code)
     PG_DEV void ent_step(int i) {
-        uint32_t m = meta(i);
+        uint32_t m = meta(i) & ~MF_PAR_DONE;
         if (!(m & MF_SMART_STEP)) {
             ex(i) += evx(i);
             ey(i) += evy(i);
@@ -1049,27 +1063,9 @@ struct Env {
         return block || block2;
     }
 
-    PG_DEV void basic_step_object(int obj) {  // BAG:593-656
-        if (eflag(obj, MF_WILL_ERASE)) return;
-        grid_window(ex(obj), ey(obj));
-        int num_sub_steps;
-        {
-            const float vx = evx(obj), vy = evy(obj);
-            if (G.grid_step) {
-                num_sub_steps = 1;
-            } else {
-                num_sub_steps = (int)(4 * pg_sqrt((double)(vx * vx + vy * vy)));  // double sqrt, see oracle note
-                if (num_sub_steps < 4) num_sub_steps = 4;
-            }
-        }
-        const float pct = (float)(1.0 / num_sub_steps);
-        const float cmp = pg_fabsf(evx(obj)) - pg_fabsf(evy(obj));
-        bool step_x_first = cmp == 0 ? (G.step_rand_int % 2 == 0) : (cmp > 0);
-        if (etype(obj) == PLAYER) {
-            if (G.action_vx != 0) step_x_first = true;
-            if (G.action_vy != 0) step_x_first = false;
-        }
-        // which axes need the entity scan at all for this object (entity types do not change while it steps)
+    // which axes of `obj` need the entity scan of sub_step at all this step: bit 0 / 1 = some entity that could block or reflect
+    // it on a horizontal / vertical move lies within its reach (entity types do not change while it steps)
+    PG_DEV int bso_scan_axes(int obj) {
         int scan_axes = 0;
         if constexpr (LANE) {
             // one pass: the axes on which some entity within this step's reach could block or reflect `obj`
@@ -1098,31 +1094,62 @@ struct Env {
                 const uint64_t mv = PG_BALLOT(l, ((c << 6) + l) < n && ((c << 6) + l) != obj && Game::may_interact(*this, otype, etype((c << 6) + l), false));
                 scan_axes |= (mh ? 1 : 0) | (mv ? 2 : 0);
             }
+            if (scan_axes != 0) {
+                // no entity this object could interact with lies within its reach for this step (its own travel, < 1 cell of
+                // block snapping, < 2 of a reflection): the per-sub_step scans cannot find anything
+                const float ox = ex(obj), oy = ey(obj), orx = erx(obj), ory = ery(obj);
+                const float reach_x = pg_fabsf(evx(obj)) + 2.01f, reach_y = pg_fabsf(evy(obj)) + 2.01f;
+                bool any = false;
+                for (int c = 0; c < ((n + 63) >> 6) && !any; c++) {
+                    any = PG_BALLOT(l, ({
+                                        const int idx = (c << 6) + l;
+                                        bool near = false;
+                                        if (idx < n && idx != obj) {
+                                            const int t = etype(idx);
+                                            if (Game::may_interact(*this, otype, t, true) || Game::may_interact(*this, otype, t, false))
+                                                near = (pg_fabsf(ox - ex(idx)) < orx + erx(idx) + reach_x) && (pg_fabsf(oy - ey(idx)) < ory + ery(idx) + reach_y);
+                                        }
+                                        near;
+                                    })) != 0;
+                }
+                if (!any) scan_axes = 0;
+            }
+        }
+        return scan_axes;
+    }
+
+    PG_DEV void basic_step_object(int obj) {  // BAG:593-656
+        if (eflag(obj, MF_WILL_ERASE)) return;
+        grid_window(ex(obj), ey(obj));
+        const int scan_axes = bso_scan_axes(obj);
+        bso_core<true>(obj, scan_axes);
+    }
+
+    // basic_step_object once the scan axes are known.  With scan_axes == 0 it reads and writes nothing but `obj`'s own
+    // words, the grid and scalars of G: wave = env kernels then run it for several objects at once, one LANE per object
+    // (WAVE_UNIFORM = false: no profiling marks, which assume a uniform call).
+    template <bool WAVE_UNIFORM>
+    PG_DEV void bso_core(int obj, int scan_axes) {
+        int num_sub_steps;
+        {
+            const float vx = evx(obj), vy = evy(obj);
+            if (G.grid_step) {
+                num_sub_steps = 1;
+            } else {
+                num_sub_steps = (int)(4 * pg_sqrt((double)(vx * vx + vy * vy)));  // double sqrt, see oracle note
+                if (num_sub_steps < 4) num_sub_steps = 4;
+            }
+        }
+        const float pct = (float)(1.0 / num_sub_steps);
+        const float cmp = pg_fabsf(evx(obj)) - pg_fabsf(evy(obj));
+        bool step_x_first = cmp == 0 ? (G.step_rand_int % 2 == 0) : (cmp > 0);
+        if (etype(obj) == PLAYER) {
+            if (G.action_vx != 0) step_x_first = true;
+            if (G.action_vy != 0) step_x_first = false;
         }
         ObjRegs R;
         obj_load(obj, R);
-        if (!LANE && scan_axes != 0) {
-            // no entity this object could interact with lies within its reach for this step (its own travel, < 1 cell of
-            // block snapping, < 2 of a reflection): the per-sub_step scans cannot find anything
-            const int otype = R.type;
-            const int n = G.n_ents;
-            const float reach_x = pg_fabsf(R.vx) + 2.01f, reach_y = pg_fabsf(R.vy) + 2.01f;
-            bool any = false;
-            for (int c = 0; c < ((n + 63) >> 6) && !any; c++) {
-                any = PG_BALLOT(l, ({
-                                    const int idx = (c << 6) + l;
-                                    bool near = false;
-                                    if (idx < n && idx != obj) {
-                                        const int t = etype(idx);
-                                        if (Game::may_interact(*this, otype, t, true) || Game::may_interact(*this, otype, t, false))
-                                            near = (pg_fabsf(R.x - ex(idx)) < R.rx + erx(idx) + reach_x) && (pg_fabsf(R.y - ey(idx)) < R.ry + ery(idx) + reach_y);
-                                    }
-                                    near;
-                                })) != 0;
-            }
-            if (!any) scan_axes = 0;
-        }
-        phase(9);
+        if constexpr (WAVE_UNIFORM) phase(9);
         float vx_pct = 0, vy_pct = 0;
         for (int st = 0; st < num_sub_steps; st++) {
             bool block_x = false, block_y = false;
@@ -1150,7 +1177,7 @@ struct Env {
         R.vx *= vx_pct;
         R.vy *= vy_pct;
         obj_flush(obj, R);
-        phase(10);
+        if constexpr (WAVE_UNIFORM) phase(10);
     }
 
     // step_entities BAG:1086-1098: reverse order; runs of non-smart entities are stepped lane-parallel,
@@ -1176,14 +1203,60 @@ struct Env {
             return;
         }
         const int n0 = G.n_ents;
+        if constexpr (GameParSmart<Game>::value) {
+            // Parallel pass.  A smart entity that no entity can block or reflect this step (scan axes 0) steps through the
+            // grid alone: its basic_step_object reads and writes its own words only, so it commutes with every other
+            // entity's step, and the wave's idle lanes can take one such object each -- an env with ten walking enemies
+            // pays for one object step instead of ten.  The objects done here are marked and then ride with the plain
+            // entities (Entity::step) in the ordered loop below, which keeps only the objects that do interact.
+            int ns = 0;
+            for (int c = 0; c < ((n0 + 63) >> 6); c++) ns += pg_popc64(PG_BALLOT(l, ((c << 6) + l) < n0 && (meta((c << 6) + l) & MF_SMART_STEP) != 0));
+            if (ns >= 2) {
+                int np = 0;
+                for (int c = 0; c < ((n0 + 63) >> 6) && np < 64; c++) {
+                    uint64_t m = PG_BALLOT(l, ({
+                                               const int idx = (c << 6) + l;
+                                               bool ok = false;
+                                               if (idx < n0) {
+                                                   const uint32_t mm = meta(idx);
+                                                   ok = (mm & MF_SMART_STEP) != 0 && !(mm & MF_WILL_ERASE) && Game::par_smart_type_ok(meta_type(mm));
+                                               }
+                                               ok;
+                                           }));
+                    while (m && np < 64) {
+                        const int obj = (c << 6) + pg_ctz64(m);
+                        m &= m - 1;
+                        if (bso_scan_axes(obj) == 0) {
+                            s->tmp[np] = (uint32_t)obj;
+                            np++;
+                        }
+                    }
+                }
+                PG_SYNC_E();
+                if (np >= 2) {
+#if defined(PGAMD_WAVE_EMU)
+                    pg_emu_counters()[0] += np;
+#endif
+                    PG_FOR_LANES(l) {
+                        if (l < np) {
+                            const int obj = (int)s->tmp[l];
+                            bso_core<false>(obj, 0);
+                            meta(obj) |= MF_PAR_DONE;
+                        }
+                    }
+                    PG_SYNC_E();
+                }
+            }
+            phase(9);
+        }
         int hi = n0;  // entities [hi, n0) are done
         while (hi > 0) {
-            // highest smart_step index below hi
+            // highest smart_step index below hi (that the parallel pass has not done)
             int sidx = -1;
             for (int c = (hi - 1) >> 6; c >= 0 && sidx < 0; c--) {
                 uint64_t m = PG_BALLOT(l, ({
                                            const int idx = (c << 6) + l;
-                                           idx < hi && (meta(idx) & MF_SMART_STEP) != 0;
+                                           idx < hi && (meta(idx) & (MF_SMART_STEP | MF_PAR_DONE)) == MF_SMART_STEP;
                                        }));
                 if (m) sidx = (c << 6) + pg_highest(m);
             }

@@ -40,6 +40,11 @@ inline bool &pg_emu_in_lane_kernel() {
     static thread_local bool v = false;
     return v;
 }
+// event counters the harness reads back (which code paths a test really took); slot 0: objects stepped by the parallel pass
+inline long long *pg_emu_counters() {
+    static long long c[8] = {0};
+    return c;
+}
 struct PgEmuLaneScope {
     int saved;
     PgEmuLaneScope() : saved(pg_emu_lane()) {

@@ -286,6 +286,7 @@ void emu_sincos_array(const double *x, double *s, double *c, int n) {
         c[i] = pg_cos_d(x[i]);
     }
 }
+long long emu_counter(int k) { return pg_emu_counters()[k]; }
 void emu_path_counts(void *h, long long *out) {
     EmuVec *v = (EmuVec *)h;
     out[0] = v->lane_steps;

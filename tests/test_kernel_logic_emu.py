@@ -3,6 +3,7 @@ CPU: the kernel sources themselves (procgen_amd/csrc/pg_env.h + game policies), 
 emulation (tests/emu), against the oracle: frames, rew/first/info, entity tables and grids, bit exact, including the
 routing between the small and the large LDS arena.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -78,6 +79,29 @@ def test_lane_env_kernel_over_timeouts_twists_and_resets(game, steps):
     lane, lane_resets, wave, _ = emu.path_counts()
     assert lane > 0.25 * n * steps and lane_resets > 0 and wave > 0, (lane, lane_resets, wave)
     assert a["first"][1000:1002].any(), "an episode must have ended by timeout"
+
+
+def test_independent_smart_entities_are_stepped_side_by_side():
+    """pg_env.h GameParSmart (coinrun: the agent and the walking enemies): smart entities that nothing can block or reflect
+    this step take one lane each in a parallel pass of step_entities.  Heavy levels (many enemies) against the oracle,
+    entity tables included, with the pass really taken."""
+    L = emu_harness.lib()
+    L.emu_counter.restype = C.c_longlong
+    before = L.emu_counter(0)
+    n, steps = 48, 300
+    acts = action_stream(n, steps, seed=19)
+    orc = oracle_env.OracleEnv(n, "coinrun", rand_seed=99)
+    emu = emu_harness.EmuEnv(n, "coinrun", rand_seed=99, lane=False)
+    for t in range(steps):
+        orc.act(acts[t])
+        emu.act(acts[t])
+        if t % 25 == 0:
+            r1, o1, f1 = orc.observe()
+            r2, o2, f2 = emu.observe()
+            assert np.array_equal(r1, r2) and np.array_equal(f1, f2) and np.array_equal(o1["rgb"], o2["rgb"]), t
+            for e in range(n):
+                assert np.array_equal(orc.entities(e), emu.entities(e)), (t, e)
+    assert L.emu_counter(0) - before > 1000
 
 
 @pytest.mark.parametrize("game", ["jumper", "caveflyer"])
