@@ -14,6 +14,10 @@ namespace pgamd {
 template <int CELLS, int KERNEL_ID>
 struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
     static constexpr int GAME_ID = KERNEL_ID;
+    // pg_env.h GameParSmart: blocking / reflecting targets of this game are wall types only, never a smart entity's type,
+    // and the hooks basic_step_object calls touch nothing but the moving object
+    static constexpr bool PAR_SMART = true;
+    PG_DEV static bool par_smart_type_ok(int t) { return t == PLAYER || t == ENEMY; }
     static constexpr const char *NAME = "caveflyer";
     static constexpr int MAX_CELLS = CELLS;  // caveflyer.cpp:131-146
     typedef RoomScratch<MAX_CELLS> Scratch;

@@ -10,6 +10,10 @@ namespace pgamd {
 
 struct Chaser : BagDefaults<Chaser> {
     static constexpr int GAME_ID = GAME_CHASER;
+    // pg_env.h GameParSmart: blocking / reflecting targets of this game are wall types only, never a smart entity's type,
+    // and the hooks basic_step_object calls touch nothing but the moving object
+    static constexpr bool PAR_SMART = true;
+    PG_DEV static bool par_smart_type_ok(int t) { return t == PLAYER || t == ENEMY; }
     static constexpr const char *NAME = "chaser";
     typedef uint16_t cell_t;  // MARKER = 1001, ORB = 1002
     typedef MazeScratch Scratch;

@@ -8,6 +8,10 @@ namespace pgamd {
 
 struct Climber {
     static constexpr int GAME_ID = GAME_CLIMBER;
+    // pg_env.h GameParSmart: blocking / reflecting targets of this game are wall types only, never a smart entity's type,
+    // and the hooks basic_step_object calls touch nothing but the moving object
+    static constexpr bool PAR_SMART = true;
+    PG_DEV static bool par_smart_type_ok(int t) { return t == PLAYER || t == ENEMY; }
     static constexpr const char *NAME = "climber";
     typedef uint8_t cell_t;
     static constexpr int MAX_CELLS = 20 * 64;  // climber.cpp:230-233

@@ -9,6 +9,10 @@ namespace pgamd {
 
 struct Ninja : BagDefaults<Ninja> {
     static constexpr int GAME_ID = GAME_NINJA;
+    // pg_env.h GameParSmart: blocking / reflecting targets of this game are wall types only, never a smart entity's type,
+    // and the hooks basic_step_object calls touch nothing but the moving object
+    static constexpr bool PAR_SMART = true;
+    PG_DEV static bool par_smart_type_ok(int t) { return t == PLAYER || t == THROWING_STAR; }
     static constexpr const char *NAME = "ninja";
     static constexpr int MAX_CELLS = 64 * 64;  // ninja.cpp:36-37
     static constexpr bool HAS_OVERLAY = true;
