@@ -122,6 +122,35 @@ struct Leaper : BagDefaults<Leaper> {
     PG_DEV static void spawn_entities(E &e) {
         EnvHdr &G = e.G;
         const int n_road = LP_N_ROAD(G), n_water = LP_N_WATER(G);
+        if constexpr (!E::LANE) {
+            // Most rounds no lane spawns anything (spawn probability = |speed| / 6 or / 2, a few percent): each lane then makes
+            // exactly one draw, so the round's draws are looked at side by side, one wave lane per road / water lane, and
+            // consumed together.  A round with a spawn attempt takes the reference's loop below (an attempt makes further
+            // draws and may or may not add an entity).  A level's 300-400 spawner rounds are the reset's critical path.
+            PG_LANE_VAR(uint32_t, u);
+            const int L = n_road + n_water;
+            if (L > 0 && e.rand_peek_lanes(L, u)) {
+                const float r0 = pg_opaque_f(G.gsf0), r1 = pg_opaque_f(G.gsf1), r2 = pg_opaque_f(G.gsf2), r3 = pg_opaque_f(G.gsf3), r4 = pg_opaque_f(G.gsf4);
+                const float w0 = pg_opaque_f(G.gsf5), w1 = pg_opaque_f(G.gsf6), w2 = pg_opaque_f(G.gsf7);
+                const float w3 = __builtin_bit_cast(float, pg_opaque_i(G.gsi5)), w4 = __builtin_bit_cast(float, pg_opaque_i(G.gsi6));
+                const uint64_t attempts = PG_BALLOT(l, ({
+                                                        bool a = false;
+                                                        if (l < L) {
+                                                            const bool car = l < n_road;
+                                                            const int k = car ? l : l - n_road;
+                                                            const float speed = car ? (k == 0 ? r0 : (k == 1 ? r1 : (k == 2 ? r2 : (k == 3 ? r3 : r4))))
+                                                                                    : (k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : (k == 3 ? w3 : w4))));
+                                                            const float spawn_prob = (float)(pg_fabs((double)speed) / (car ? 6.0 : 2.0));
+                                                            a = (float)((double)PG_LV(u, l) / 4294967296.0) < spawn_prob;
+                                                        }
+                                                        a;
+                                                    }));
+                if (attempts == 0) {
+                    e.rand_skip(L);
+                    return;
+                }
+            }
+        }
         for (int lane = 0; lane < n_road + n_water; lane++) {
             const bool car = lane < n_road;
             const int k = car ? lane : lane - n_road;

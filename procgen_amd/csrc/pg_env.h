@@ -661,6 +661,24 @@ struct Env {
         G.rand_idx += 1;
         return mt_temper(z);
     }
+    // The next `count` (<= 32) rand_gen draws WITHOUT consuming them: lane l < count gets the l-th (tempered); false when they
+    // would cross a twist (the caller then draws one at a time).  rand_skip consumes draws seen this way.
+    PG_DEV bool rand_peek_lanes(int count, PG_LANE_REF(uint32_t, out)) {
+        static_assert(!LANE, "wave = env only");
+        const int idx = G.rand_idx;
+        if (idx + count > MT_N) return false;
+        if (rc_buf != rg_cur || idx < rc_base || idx + count > rc_base + 64) {
+            const uint32_t *src = rg_cur;
+            PG_FOR_LANES(l) { PG_LV(rc_words, l) = idx + l < MT_N ? src[idx + l] : 0u; }
+            rc_buf = rg_cur;
+            rc_base = idx;
+        }
+        const int shift = idx - rc_base;
+        PG_FOR_LANES(l) { PG_LV(out, l) = l < count ? mt_temper(PG_SHFL(rc_words, l, shift + l)) : 0u; }
+        return true;
+    }
+    PG_DEV void rand_skip(int count) { G.rand_idx += count; }
+
     // `count` (<= 64) consecutive rand_gen draws at once: lane l gets the l-th of them (tempered u32; lanes >= count get
     // 0).  Level generators that draw once per grid cell use this instead of 64 dependent trips to the generator state.
     PG_DEV void rand_u32_lanes(int count, PG_LANE_REF(uint32_t, out)) {

@@ -82,6 +82,13 @@ struct PgEmuLaneScope {
 #define PG_READLANE(v, k) v[k]
 #define PG_LANE_ARR(T, v, N) T v[N][64]
 #define PG_LA(v, j, l) v[j][l]
+#define PG_SHFL(v, l, src) v[(src) & 63]  // inside a lane section: the value lane `src` holds (v is only read in that section)
+// atomic OR on a 32-bit word shared by the wave's lanes, returns the old value (the emulation's lanes run one after the other)
+PG_DEV uint32_t pg_atomic_or(uint32_t *p, uint32_t v) {
+    const uint32_t o = *p;
+    *p = o | v;
+    return o;
+}
 PG_DEV int pg_popc64(uint64_t m) { return __builtin_popcountll(m); }
 PG_DEV int pg_clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
 PG_DEV int pg_ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
@@ -122,6 +129,8 @@ PG_DEV double pg_pow(double x, double y) { return pow(x, y); }  // glibc, as the
         static_assert(__is_integral(decltype(v)) && sizeof(v) == 4, "PG_READLANE takes a 32-bit integer");    \
         (decltype(v))__builtin_amdgcn_readlane((int)(v), (k));                                                 \
     })
+#define PG_SHFL(v, l, src) ((decltype(v))__shfl((int)(v), (src), 64))  // ds_bpermute: the value lane `src` holds
+PG_DEV uint32_t pg_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 // value known to be wave-uniform: move it to an SGPR so branches on it are scalar branches
 #define PG_UNIFORM_I(x) __builtin_amdgcn_readfirstlane((int)(x))
 PG_DEV int pg_popc64(uint64_t m) { return __popcll(m); }
