@@ -1229,7 +1229,7 @@ struct Env {
             // entities (Entity::step) in the ordered loop below, which keeps only the objects that do interact.
             int ns = 0;
             for (int c = 0; c < ((n0 + 63) >> 6); c++) ns += pg_popc64(PG_BALLOT(l, ((c << 6) + l) < n0 && (meta((c << 6) + l) & MF_SMART_STEP) != 0));
-            if (ns >= 2) {
+            if (ns >= 2 && !(d.debug_flags & 32768)) {  // (PROCGEN_AMD_DEBUG & 32768: A/B switch, every object in the ordered loop)
                 int np = 0;
                 for (int c = 0; c < ((n0 + 63) >> 6) && np < 64; c++) {
                     uint64_t m = PG_BALLOT(l, ({

@@ -104,6 +104,29 @@ def test_independent_smart_entities_are_stepped_side_by_side():
     assert L.emu_counter(0) - before > 1000
 
 
+@pytest.mark.parametrize("game", ["climber", "ninja", "dodgeball", "chaser", "caveflyer"])
+def test_parallel_pass_in_the_other_multi_smart_games(game, monkeypatch):
+    """The other games that opt into GameParSmart: 300 steps against the oracle with entity tables, the pass taken; and the
+    same rollout with the pass switched off (PROCGEN_AMD_DEBUG & 32768) gives the same frames -- the pass commutes."""
+    L = emu_harness.lib()
+    L.emu_counter.restype = C.c_longlong
+    n, steps = 24, 300
+    acts = action_stream(n, steps, seed=23)
+    before = L.emu_counter(0)
+    orc = oracle_env.OracleEnv(n, game, rand_seed=41)
+    emu = emu_harness.EmuEnv(n, game, rand_seed=41)
+    a, b = rollout(orc, acts), rollout(emu, acts)
+    assert_rollouts_equal(a, b, game)
+    for e in range(n):
+        assert np.array_equal(orc.entities(e), emu.entities(e)), e
+    taken = L.emu_counter(0) - before
+    assert taken > 500, taken
+    monkeypatch.setenv("PROCGEN_AMD_DEBUG", "32768")
+    before = L.emu_counter(0)
+    assert_rollouts_equal(a, rollout(emu_harness.EmuEnv(n, game, rand_seed=41), acts), game + " (ordered loop only)")
+    assert L.emu_counter(0) == before
+
+
 @pytest.mark.parametrize("game", ["jumper", "caveflyer"])
 def test_split_reset_games_hand_ended_episodes_to_the_reset_kernel(game):
     """Games with SPLIT_RESET (pg_env.h GameSplit): their step kernels carry no level generator; an episode that ends is
