@@ -12,6 +12,7 @@
  */
 #include "procgen_oracle.h"
 
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -4499,12 +4500,18 @@ static void draw_entities(Game *g, uint32_t *dst, int render_z) { /* BAG:1052-10
 /* QRasterPaintEngine::drawEllipse on an integer-aligned rect without antialiasing: drawEllipse_midpoint_i +
  * drawEllipsePoints (qpaintengine_raster.cpp, Qt 5.9.7), pen of width <= 1 (outline spans) and/or brush (fill spans).
  * Third-party algorithm restated; pinned with tests/tools/qt_compass_probe.py. */
-typedef struct { uint32_t *dst; int rx, ry, rw, rh, pen; uint32_t pen_px, brush_px; } EllipseCtx;
-static void ell_span(const EllipseCtx *c, int sx, int sy, int len, uint32_t px) {
-    if (sy < 0 || sy >= RES_H) return;
-    for (int x = sx; x < sx + len; x++)
-        if (x >= 0 && x < RES_W) c->dst[sy * RES_W + x] = px + byte_mul(c->dst[sy * RES_W + x], 255u - (px >> 24));
+typedef struct { uint32_t *dst; int w, h; int source_mode; } QtCanvas; /* source_mode: CompositionMode_Source (assetgen.cpp:158) */
+static void qc_span(const QtCanvas *c, int y, int x0, int x1, uint32_t px) { /* [x0, x1) clipped, premultiplied px */
+    if (y < 0 || y >= c->h) return;
+    if (x0 < 0) x0 = 0;
+    if (x1 > c->w) x1 = c->w;
+    for (int x = x0; x < x1; x++) {
+        uint32_t *d = &c->dst[y * c->w + x];
+        *d = c->source_mode ? px : px + byte_mul(*d, 255u - (px >> 24));
+    }
 }
+typedef struct { const QtCanvas *cv; int rx, ry, rw, rh, pen, brush; uint32_t pen_px, brush_px; } EllipseCtx;
+static void ell_span(const EllipseCtx *c, int sx, int sy, int len, uint32_t px) { qc_span(c->cv, sy, sx, sx + len, px); }
 static void ell_points(const EllipseCtx *c, int px, int py, int length) {
     if (length == 0) return;
     int midx = c->rx + (c->rw + 1) / 2, midy = c->ry + (c->rh + 1) / 2;
@@ -4514,8 +4521,10 @@ static void ell_points(const EllipseCtx *c, int px, int py, int length) {
     int o2y = midy + midy - y - (c->rh & 1);
     if (o0x + o0len < x) {
         int f0x = o0x + o0len - 1, f0len = x - f0x > 0 ? x - f0x : 0;
-        ell_span(c, f0x, y, f0len, c->brush_px);
-        if (!(y >= o2y)) ell_span(c, f0x, o2y, f0len, c->brush_px);
+        if (c->brush) {
+            ell_span(c, f0x, y, f0len, c->brush_px);
+            if (!(y >= o2y)) ell_span(c, f0x, o2y, f0len, c->brush_px);
+        }
     }
     if (c->pen) {
         ell_span(c, o0x, y, o0len, c->pen_px);
@@ -4526,9 +4535,9 @@ static void ell_points(const EllipseCtx *c, int px, int py, int length) {
         }
     }
 }
-static void draw_ellipse_i(uint32_t *dst, int rx, int ry, int rw, int rh, int pen, uint32_t pen_px, uint32_t brush_px) {
+static void draw_ellipse_i(const QtCanvas *cv, int rx, int ry, int rw, int rh, int pen, uint32_t pen_px, int brush, uint32_t brush_px) {
     if (rw <= 0 || rh <= 0) return;
-    EllipseCtx c = {dst, rx, ry, rw, rh, pen, pen_px, brush_px};
+    EllipseCtx c = {cv, rx, ry, rw, rh, pen, brush, pen_px, brush_px};
     double a = rw / 2.0, b = rh / 2.0;
     double d = b * b - (a * a * b) + 0.25 * a * a;
     int x = 0, y = (rh + 1) / 2, startx = x;
@@ -4598,14 +4607,373 @@ static void draw_line_cosmetic(uint32_t *dst, int X1, int Y1, int X2, int Y2, ui
     }
 #undef PUT
 }
+/* ---- QPainter::drawEllipse(QRectF) on a rect that is NOT integer aligned, no antialiasing, identity transform (Qt 5.9.7).
+ * QRasterPaintEngine::drawEllipse falls through to QPaintEngineEx::drawEllipse: qt_curves_for_arc(rect, 0, -360) gives a
+ * start point and four cubics (QT_PATH_KAPPA), then draw(path) = fill with the brush + stroke with the pen.
+ *   brush: QRasterPaintEngine::fill(QVectorPath): culled unless controlPointRect().toRect() -- 5.9's toRect rounds x, y, w
+ *          and h separately -- intersects the device rect; QOutlineMapper::curveTo flattens every cubic with
+ *          QBezier::addToPolygon (threshold .25), points become 26.6 by qRound(v * 64); QRasterizer's QScanConverter walks
+ *          each line in 16.16 and samples it at the pixel centres; a row is filled from its first to its second crossing.
+ *   pen  : width <= 1 => QCosmeticStroker::drawPath: calculateLastPoint on the closed path's last two points, renderCubic
+ *          (<= 6 levels of subdivision), drawLine<drawPixel, NoDasher> with its duplicate / drop-out control between
+ *          consecutive segments (incl. the horizontal branch repeating the vertical branch's half-step test).
+ * Third-party algorithm (source not on disk); pinned with tests/tools/qt_path_probe.py against PyQt5 5.9.7: tens of
+ * thousands of random, knife-edge, tiny and partly-outside rects, pen / brush / both, 0 misses.  Call sites:
+ * jumper.cpp:137-142 (compass in easy mode / without center_agent), assetgen.cpp:99-105. */
+#define QT_PATH_KAPPA 0.5522847498
+typedef struct { double x1, y1, x2, y2, x3, y3, x4, y4; } QBez;
+static void qbez_split(const QBez *b, QBez *first, QBez *second) { /* qbezier_p.h QBezier::split */
+    double c = (b->x2 + b->x3) * .5;
+    first->x2 = (b->x1 + b->x2) * .5;
+    second->x3 = (b->x3 + b->x4) * .5;
+    first->x1 = b->x1;
+    second->x4 = b->x4;
+    first->x3 = (first->x2 + c) * .5;
+    second->x2 = (second->x3 + c) * .5;
+    first->x4 = second->x1 = (first->x3 + second->x2) * .5;
+    c = (b->y2 + b->y3) / 2;
+    first->y2 = (b->y1 + b->y2) * .5;
+    second->y3 = (b->y3 + b->y4) * .5;
+    first->y1 = b->y1;
+    second->y4 = b->y4;
+    first->y3 = (first->y2 + c) * .5;
+    second->y2 = (second->y3 + c) * .5;
+    first->y4 = second->y1 = (first->y3 + second->y2) * .5;
+}
+#define QT_MAX_FLAT 2100 /* 4 cubics x at most 2^9 segments */
+static int qbez_add_to_polygon(QBez bz, double *px, double *py, int n, double thr) { /* qbezier.cpp QBezier::addToPolygon */
+    QBez beziers[10];
+    int levels[10];
+    beziers[0] = bz;
+    levels[0] = 9;
+    int top = 0;
+    while (top >= 0) {
+        QBez *b = &beziers[top];
+        double y4y1 = b->y4 - b->y1, x4x1 = b->x4 - b->x1;
+        double l = fabs(x4x1) + fabs(y4y1), d;
+        if (l > 1.) {
+            d = fabs(x4x1 * (b->y1 - b->y2) - y4y1 * (b->x1 - b->x2)) + fabs(x4x1 * (b->y1 - b->y3) - y4y1 * (b->x1 - b->x3));
+        } else {
+            d = fabs(b->x1 - b->x2) + fabs(b->y1 - b->y2) + fabs(b->x1 - b->x3) + fabs(b->y1 - b->y3);
+            l = 1.;
+        }
+        if (d < thr * l || levels[top] == 0) {
+            if (n >= QT_MAX_FLAT) fatal("flattened path overflow");
+            px[n] = b->x4;
+            py[n] = b->y4;
+            n++;
+            --top;
+        } else {
+            QBez whole = *b;
+            qbez_split(&whole, b + 1, b);
+            levels[top + 1] = --levels[top];
+            ++top;
+        }
+    }
+    return n;
+}
+static void qt_arc_points(RectD r, double *ax, double *ay) { /* qpainterpath.cpp qt_curves_for_arc(rect, 0, -360): 13 points */
+    double x = r.x, y = r.y, w = r.w, w2 = r.w / 2, w2k = w2 * QT_PATH_KAPPA, h = r.h, h2 = r.h / 2, h2k = h2 * QT_PATH_KAPPA;
+    const double X[13] = {x + w, x + w, x + w2 + w2k, x + w2, x + w2 - w2k, x, x, x, x + w2 - w2k, x + w2, x + w2 + w2k, x + w, x + w};
+    const double Y[13] = {y + h2, y + h2 + h2k, y + h, y + h, y + h, y + h2 + h2k, y + h2, y + h2 - h2k, y, y, y, y + h2 - h2k, y + h2};
+    for (int i = 0; i < 13; i++) { ax[i] = X[i]; ay[i] = Y[i]; }
+}
+static void qt_fill_ellipse_path(const QtCanvas *c, RectD r, uint32_t px) {
+    double ax[13], ay[13];
+    qt_arc_points(r, ax, ay);
+    { /* QRasterPaintEngine::fill: controlPointRect().toRect() must intersect the device rect (QRect::intersects) */
+        double l = r.x, rr = r.x + r.w, t = r.y, b = r.y + r.h;
+        int x1 = q_round(l), y1 = q_round(t), x2 = x1 + q_round(rr - l) - 1, y2 = y1 + q_round(b - t) - 1;
+        if (x2 == x1 - 1 && y2 == y1 - 1) return;
+        if (x1 > c->w - 1 || 0 > x2 || y1 > c->h - 1 || 0 > y2) return;
+    }
+    static double fx[QT_MAX_FLAT + 2], fy[QT_MAX_FLAT + 2];
+    int n = 0;
+    fx[n] = ax[0]; fy[n] = ay[0]; n++;
+    for (int k = 0; k < 4; k++) {
+        QBez b = {fx[n - 1], fy[n - 1], ax[1 + 3 * k], ay[1 + 3 * k], ax[2 + 3 * k], ay[2 + 3 * k], ax[3 + 3 * k], ay[3 + 3 * k]};
+        n = qbez_add_to_polygon(b, fx, fy, n, 0.25);
+    }
+    if (fx[n - 1] != fx[0] || fy[n - 1] != fy[0]) { fx[n] = fx[0]; fy[n] = fy[0]; n++; } /* closeSubpath */
+    static int qx[QT_MAX_FLAT + 2], qy[QT_MAX_FLAT + 2];
+    int min_y = 0, max_y = 0;
+    for (int i = 0; i < n; i++) {
+        qx[i] = q_round(fx[i] * 64);
+        qy[i] = q_round(fy[i] * 64);
+        if (i == 0 || qy[i] < min_y) min_y = qy[i];
+        if (i == 0 || qy[i] > max_y) max_y = qy[i];
+    }
+    int top = (min_y + 32) >> 6, bot = (max_y - 32) >> 6; /* QRasterizer::rasterize */
+    if (top < 0) top = 0;
+    if (bot > c->h - 1) bot = c->h - 1;
+    if (top > bot) return;
+    /* a convex outline crosses a row's centre line twice: keep both crossings per row (odd-even rule) */
+    int *cnt = (int *)calloc((size_t)c->h, sizeof(int)), *xa = (int *)calloc((size_t)c->h, sizeof(int)), *xb = (int *)calloc((size_t)c->h, sizeof(int));
+    for (int i = 0; i + 1 < n; i++) { /* QScanConverter::mergeLine */
+        int a_x = qx[i], a_y = qy[i], b_x = qx[i + 1], b_y = qy[i + 1];
+        if (a_y > b_y) { int t = a_x; a_x = b_x; b_x = t; t = a_y; a_y = b_y; b_y = t; }
+        int itop = (a_y + 32) >> 6, ibot = (b_y - 32) >> 6;
+        if (itop < top) itop = top;
+        if (ibot > bot) ibot = bot;
+        if (itop > ibot) continue;
+        int xfp = 32768 + a_x * 1024, slope = 0;
+        if (b_x != a_x) {
+            double s = (b_x - a_x) / (double)(b_y - a_y);
+            slope = (int)(s * 65536.);
+            xfp += (int)(((long long)slope * (long long)((itop << 16) + 32768 - (a_y << 10))) >> 16);
+        }
+        for (int y = itop; y <= ibot; y++) {
+            int xi = xfp >> 16;
+            if (cnt[y] == 0) xa[y] = xi;
+            else if (cnt[y] == 1) xb[y] = xi;
+            else fatal("more than two crossings on a row of an ellipse outline");
+            cnt[y]++;
+            xfp += slope;
+        }
+    }
+    for (int y = top; y <= bot; y++)
+        if (cnt[y] == 2) qc_span(c, y, xa[y] < xb[y] ? xa[y] : xb[y], xa[y] < xb[y] ? xb[y] : xa[y], px);
+    free(cnt); free(xa); free(xb);
+}
+/* QCosmeticStroker (qcosmeticstroker.cpp): state carried from segment to segment */
+enum { QCS_TB = 1, QCS_BT = 2, QCS_LR = 4, QCS_RL = 8 };
+typedef struct { const QtCanvas *c; uint32_t px; int last_dir, last_x, last_y, last_axis_aligned; double xmin, xmax, ymin, ymax; } QCosmetic;
+static int qcs_fixdiv(int x, int y) { return (int)(((long long)x << 16) / y); } /* F16Dot16FixedDiv */
+static int qcs_clip_line(QCosmetic *s, double *x1, double *y1, double *x2, double *y2) { /* QCosmeticStroker::clipLine */
+    if (*x1 < s->xmin) {
+        if (*x2 <= s->xmin) goto clipped;
+        *y1 += (*y2 - *y1) / (*x2 - *x1) * (s->xmin - *x1);
+        *x1 = s->xmin;
+    } else if (*x1 > s->xmax) {
+        if (*x2 >= s->xmax) goto clipped;
+        *y1 += (*y2 - *y1) / (*x2 - *x1) * (s->xmax - *x1);
+        *x1 = s->xmax;
+    }
+    if (*x2 < s->xmin) {
+        s->last_x = INT_MIN;
+        *y2 += (*y2 - *y1) / (*x2 - *x1) * (s->xmin - *x2);
+        *x2 = s->xmin;
+    } else if (*x2 > s->xmax) {
+        s->last_x = INT_MIN;
+        *y2 += (*y2 - *y1) / (*x2 - *x1) * (s->xmax - *x2);
+        *x2 = s->xmax;
+    }
+    if (*y1 < s->ymin) {
+        if (*y2 <= s->ymin) goto clipped;
+        *x1 += (*x2 - *x1) / (*y2 - *y1) * (s->ymin - *y1);
+        *y1 = s->ymin;
+    } else if (*y1 > s->ymax) {
+        if (*y2 >= s->ymax) goto clipped;
+        *x1 += (*x2 - *x1) / (*y2 - *y1) * (s->ymax - *y1);
+        *y1 = s->ymax;
+    }
+    if (*y2 < s->ymin) {
+        s->last_x = INT_MIN;
+        *x2 += (*x2 - *x1) / (*y2 - *y1) * (s->ymin - *y2);
+        *y2 = s->ymin;
+    } else if (*y2 > s->ymax) {
+        s->last_x = INT_MIN;
+        *x2 += (*x2 - *x1) / (*y2 - *y1) * (s->ymax - *y2);
+        *y2 = s->ymax;
+    }
+    return 0;
+clipped:
+    s->last_x = INT_MIN;
+    return 1;
+}
+static void qcs_calculate_last_point(QCosmetic *s, double rx1, double ry1, double rx2, double ry2) {
+    s->last_x = INT_MIN;
+    s->last_y = INT_MIN;
+    if (qcs_clip_line(s, &rx1, &ry1, &rx2, &ry2)) return;
+    int x1 = (int)(rx1 * 64.), y1 = (int)(ry1 * 64.), x2 = (int)(rx2 * 64.), y2 = (int)(ry2 * 64.);
+    int dx = abs(x2 - x1), dy = abs(y2 - y1);
+    if (dx < dy) {
+        int swapped = 0;
+        if (y1 > y2) { swapped = 1; int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t; }
+        int xinc = qcs_fixdiv(x2 - x1, y2 - y1);
+        int x = x1 * 1024, y = (y1 + 32) >> 6, ys = (y2 + 32) >> 6, rnd = xinc > 0 ? 32 : 0;
+        if (y != ys) {
+            x += (int)(((long long)((y * 64) + rnd - y1) * xinc) >> 6);
+            if (swapped) {
+                s->last_x = x >> 16; s->last_y = y; s->last_dir = QCS_BT;
+            } else {
+                s->last_x = (x + (ys - y - 1) * xinc) >> 16; s->last_y = ys - 1; s->last_dir = QCS_TB;
+            }
+            s->last_axis_aligned = abs(xinc) < (1 << 14);
+        }
+    } else {
+        if (!dx) return;
+        int swapped = 0;
+        if (x1 > x2) { swapped = 1; int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t; }
+        int yinc = qcs_fixdiv(y2 - y1, x2 - x1);
+        int y = y1 * 1024, x = (x1 + 32) >> 6, xs = (x2 + 32) >> 6, rnd = yinc > 0 ? 32 : 0;
+        if (x != xs) {
+            y += (int)(((long long)((x * 64) + rnd - x1) * yinc) >> 6);
+            if (swapped) {
+                s->last_x = x; s->last_y = y >> 16; s->last_dir = QCS_RL;
+            } else {
+                s->last_x = xs - 1; s->last_y = (y + (xs - x - 1) * yinc) >> 16; s->last_dir = QCS_LR;
+            }
+            s->last_axis_aligned = abs(yinc) < (1 << 14);
+        }
+    }
+}
+static void qcs_line(QCosmetic *s, double rx1, double ry1, double rx2, double ry2, int caps) { /* drawLine<drawPixel, NoDasher> */
+    if (qcs_clip_line(s, &rx1, &ry1, &rx2, &ry2)) return;
+    int x1 = (int)(rx1 * 64.), y1 = (int)(ry1 * 64.), x2 = (int)(rx2 * 64.), y2 = (int)(ry2 * 64.);
+    int dx = abs(x2 - x1), dy = abs(y2 - y1);
+    int last_x = s->last_x, last_y = s->last_y; /* QCosmeticStroker::Point last = stroker->lastPixel */
+    const int lpx = s->last_x, lpy = s->last_y;
+    if (dx < dy) {
+        int dir = QCS_TB, swapped = 0;
+        if (y1 > y2) {
+            swapped = 1;
+            int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t;
+            caps = ((caps & 1) << 1) | ((caps & 2) >> 1);
+            dir = QCS_BT;
+        }
+        int xinc = qcs_fixdiv(x2 - x1, y2 - y1);
+        int x = x1 * 1024;
+        if ((s->last_dir ^ 3) == dir) caps |= swapped ? 2 : 1; /* turned around: cap towards the previous segment */
+        if (caps & 1) { y1 -= 32; x -= xinc >> 1; } /* capAdjust */
+        if (caps & 2) y2 += 32;
+        int y = (y1 + 32) >> 6, ys = (y2 + 32) >> 6, rnd = xinc > 0 ? 32 : 0;
+        if ((caps & 1) && lpy == y + 1) y++; /* "capAdjust made us round away from what calculateLastPoint gave us" */
+        if (y != ys) {
+            x += (int)(((long long)((y * 64) + rnd - y1) * xinc) >> 6);
+            int first_x = x >> 16, first_y = y;
+            last_x = (x + (ys - y - 1) * xinc) >> 16;
+            last_y = ys - 1;
+            if (swapped) { int t = first_x; first_x = last_x; last_x = t; t = first_y; first_y = last_y; last_y = t; }
+            int axis_aligned = abs(xinc) < (1 << 14);
+            if (lpx > INT_MIN) {
+                if (first_x == lpx && first_y == lpy) { /* remove duplicated pixel */
+                    if (swapped) --ys;
+                    else { ++y; x += xinc; }
+                } else if (s->last_dir != dir && ((axis_aligned && s->last_axis_aligned && lpx != first_x && lpy != first_y) || (abs(lpx - first_x) > 1 || abs(lpy - first_y) > 1))) { /* have a missing pixel, insert it */
+                    if (swapped) ++ys;
+                    else { --y; x -= xinc; }
+                } else if (s->last_dir == dir && (abs(lpx - first_x) <= 1 && abs(lpy - first_y) > 1)) {
+                    x += xinc >> 1;
+                    if (swapped) last_x = x >> 16;
+                    else last_x = (x + (ys - y - 1) * xinc) >> 16;
+                }
+            }
+            s->last_dir = dir;
+            s->last_axis_aligned = axis_aligned;
+            do {
+                qc_span(s->c, y, x >> 16, (x >> 16) + 1, s->px);
+                x += xinc;
+            } while (++y < ys);
+        }
+    } else {
+        if (!dx) return;
+        int dir = QCS_LR, swapped = 0;
+        if (x1 > x2) {
+            swapped = 1;
+            int t = y1; y1 = y2; y2 = t; t = x1; x1 = x2; x2 = t;
+            caps = ((caps & 1) << 1) | ((caps & 2) >> 1);
+            dir = QCS_RL;
+        }
+        int yinc = qcs_fixdiv(y2 - y1, x2 - x1);
+        int y = y1 * 1024;
+        if ((s->last_dir ^ 0xc) == dir) caps |= swapped ? 2 : 1;
+        if (caps & 1) { x1 -= 32; y -= yinc >> 1; }
+        if (caps & 2) x2 += 32;
+        int x = (x1 + 32) >> 6, xs = (x2 + 32) >> 6, rnd = yinc > 0 ? 32 : 0;
+        if ((caps & 1) && lpx == x + 1) x++;
+        if (x != xs) {
+            y += (int)(((long long)((x * 64) + rnd - x1) * yinc) >> 6);
+            int first_x = x, first_y = y >> 16;
+            last_x = xs - 1;
+            last_y = (y + (xs - x - 1) * yinc) >> 16;
+            if (swapped) { int t = first_x; first_x = last_x; last_x = t; t = first_y; first_y = last_y; last_y = t; }
+            int axis_aligned = abs(yinc) < (1 << 14);
+            if (lpx > INT_MIN) {
+                if (first_x == lpx && first_y == lpy) {
+                    if (swapped) --xs;
+                    else { ++x; y += yinc; }
+                } else if (s->last_dir != dir && ((axis_aligned && s->last_axis_aligned && lpx != first_x && lpy != first_y) || (abs(lpx - first_x) > 1 || abs(lpy - first_y) > 1))) {
+                    if (swapped) ++xs;
+                    else { --x; y -= yinc; }
+                } else if (s->last_dir == dir && (abs(lpx - first_x) <= 1 && abs(lpy - first_y) > 1)) { /* sic: the vertical branch's test (probe) */
+                    y += yinc >> 1;
+                    if (swapped) last_y = y >> 16;
+                    else last_y = (y + (xs - x - 1) * yinc) >> 16;
+                }
+            }
+            s->last_dir = dir;
+            s->last_axis_aligned = axis_aligned;
+            do {
+                qc_span(s->c, y >> 16, x, x + 1, s->px);
+                y += yinc;
+            } while (++x < xs);
+        }
+    }
+    s->last_x = last_x;
+    s->last_y = last_y;
+}
+static void qcs_cubic_sub(QCosmetic *s, double *px, double *py, int level, int caps) { /* renderCubicSubdivision; points[3] = start ... points[0] = end */
+    if (level) {
+        double dx = px[3] - px[0], dy = py[3] - py[0];
+        double len = .25 * (fabs(dx) + fabs(dy));
+        if (fabs(dx * (py[0] - py[2]) - dy * (px[0] - px[2])) >= len || fabs(dx * (py[0] - py[1]) - dy * (px[0] - px[1])) >= len) {
+            for (int k = 0; k < 2; k++) { /* splitCubic */
+                double *p = k ? py : px, a, b, c, d;
+                p[6] = p[3];
+                c = p[1];
+                d = p[2];
+                p[1] = a = (p[0] + c) * .5;
+                p[5] = b = (p[3] + d) * .5;
+                c = (c + d) * .5;
+                p[2] = a = (a + c) * .5;
+                p[4] = b = (b + c) * .5;
+                p[3] = (a + b) * .5;
+            }
+            --level;
+            qcs_cubic_sub(s, px + 3, py + 3, level, caps & 1);
+            qcs_cubic_sub(s, px, py, level, caps & 2);
+            return;
+        }
+    }
+    qcs_line(s, px[3], py[3], px[0], py[0], caps);
+}
+static void qt_stroke_ellipse_path(const QtCanvas *c, RectD r, uint32_t px) { /* QCosmeticStroker::drawPath on the closed 4-cubic path */
+    double ax[13], ay[13];
+    qt_arc_points(r, ax, ay);
+    QCosmetic s = {c, px, QCS_LR, INT_MIN, INT_MIN, 0, -1., c->w + 1., -1., c->h + 1.}; /* setup(): device rect widened by one pixel */
+    qcs_calculate_last_point(&s, ax[11], ay[11], ax[12], ay[12]);
+    for (int k = 0; k < 4; k++) {
+        double px_[3 * 6 + 4], py_[3 * 6 + 4];
+        px_[3] = ax[3 * k]; py_[3] = ay[3 * k];
+        px_[2] = ax[3 * k + 1]; py_[2] = ay[3 * k + 1];
+        px_[1] = ax[3 * k + 2]; py_[1] = ay[3 * k + 2];
+        px_[0] = ax[3 * k + 3]; py_[0] = ay[3 * k + 3];
+        qcs_cubic_sub(&s, px_, py_, 6, 0);
+    }
+}
+/* QRasterPaintEngine::drawEllipse: the midpoint algorithm when the rect is integer aligned, else the path route */
+static void draw_ellipse_f(const QtCanvas *c, RectD r, int pen, uint32_t pen_px, int brush, uint32_t brush_px) { /* qpaintengine_raster.cpp QRasterPaintEngine::drawEllipse */
+    if (r.w < 0) { r.x += r.w; r.w = -r.w; } /* QPainter::drawEllipse: rect.normalized() */
+    if (r.h < 0) { r.y += r.h; r.h = -r.h; }
+    if ((r.w > r.h ? r.w : r.h) < 32767 && r.w > 0 && r.h > 0) {
+        int bx = (int)r.x, by = (int)r.y, bw = (int)r.w, bh = (int)r.h;
+        if ((double)bx == r.x && (double)by == r.y && (double)bw == r.w && (double)bh == r.h) {
+            draw_ellipse_i(c, bx, by, bw, bh, pen, pen_px, brush, brush_px);
+            return;
+        }
+    }
+    if (r.w == 0 && r.h == 0) return; /* qt_curves_for_arc: rect.isNull() */
+    if (brush) qt_fill_ellipse_path(c, r, brush_px);
+    if (pen) qt_stroke_ellipse_path(c, r, pen_px);
+}
+
 static void jp_draw_compass(Game *g, uint32_t *dst) { /* jumper.cpp:134-169 */
     const Ent *agent = &g->pool[g->agent], *goal = &g->pool[g->goal];
     float cxf = (float)(g->view_dim - g->compass_dim - .25), cyf = (float).25;
     RectD cr_ = {cxf * g->unit, cyf * g->unit, g->compass_dim * g->unit, g->compass_dim * g->unit}; /* get_abs_rect BAG:803-805 */
-    int bx = (int)cr_.x, by = (int)cr_.y, bw = (int)cr_.w, bh = (int)cr_.h;
-    if ((double)bx != cr_.x || (double)by != cr_.y || (double)bw != cr_.w || (double)bh != cr_.h)
-        fatal("jumper compass on a non-integer rect (QPaintEngineEx path) is not restated");
-    draw_ellipse_i(dst, bx, by, bw, bh, 1, 0xffa8a69eu, 0xffa8a69eu);
+    const QtCanvas cv = {dst, RES_W, RES_H, 0};
+    draw_ellipse_f(&cv, cr_, 1, 0xffa8a69eu, 1, 0xffa8a69eu); /* integer aligned in hard / memory mode with center_agent, else the path route */
     float cx = (float)(cr_.x + cr_.w / 2);
     float cy = (float)(cr_.y + cr_.h / 2);
     float cr = (float)(cr_.w / 2 * .95);
@@ -4619,8 +4987,17 @@ static void jp_draw_compass(Game *g, uint32_t *dst) { /* jumper.cpp:134-169 */
     fill_rect(dst, dr, 0xfffcba03u);
     if (g->jump_delta < 0 && !g->has_support) {
         RectD r1 = get_screen_rect(g, agent->x - agent->rx, agent->y + agent->ry, 2 * agent->rx, 2 * agent->ry, 0);
-        draw_ellipse_i(dst, (int)r1.x, (int)(r1.y + r1.h * (5.0 / 6)), (int)r1.w, (int)(r1.h / 3), 0, 0, 0x78787878u); /* QColor(255,255,255,120) premultiplied */
+        draw_ellipse_i(&cv, (int)r1.x, (int)(r1.y + r1.h * (5.0 / 6)), (int)r1.w, (int)(r1.h / 3), 0, 0, 1, 0x78787878u); /* QColor(255,255,255,120) premultiplied */
     }
+}
+
+void pgo_test_draw_ellipse(double x, double y, double w, double h, int pen, int brush, uint8_t *out) {
+    uint32_t px[RES_W * RES_H];
+    memset(px, 0, sizeof(px));
+    const QtCanvas cv = {px, RES_W, RES_H, 0};
+    RectD r = {x, y, w, h};
+    draw_ellipse_f(&cv, r, pen, 0xff000002u, brush, 0xff000001u);
+    for (int i = 0; i < RES_W * RES_H; i++) out[i] = (uint8_t)(px[i] & 3u);
 }
 
 static void game_draw(Game *g, uint32_t *dst) { /* BAG:979-1012,921-970 */

@@ -67,6 +67,9 @@ void pgo_dump_entities(PgoVec *v, int env, int32_t *out_words);
 void pgo_dump_grid(PgoVec *v, int env, int32_t *out, int *w, int *h);
 /* Miscellaneous scalars: out[0]=cur_time out[1]=rand_gen draws since seed (mod 2^31) ... */
 void pgo_dump_scalars(PgoVec *v, int env, int32_t *out16);
+/* test hook: the Qt 5.9 ellipse restatement (midpoint or path route) on a cleared 64 x 64 canvas; out[64*64]: 0 untouched,
+ * 1 brush, 2 pen */
+void pgo_test_draw_ellipse(double x, double y, double w, double h, int pen, int brush, uint8_t *out);
 
 #ifdef __cplusplus
 }

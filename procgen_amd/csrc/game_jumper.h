@@ -1,13 +1,18 @@
 // game_jumper.h -- Jumper rules as a policy for Env<> / Renderer<> (reference procgen/src/games/jumper.cpp).
 // A double-jumping bunny in a cave: the level is a MazeGen maze blown up 3x, randomised, smoothed by RoomGenerator's
 // cellular automaton, reduced to the widened path from the agent to the carrot, then decorated with spikes; a
-// compass (midpoint ellipse + cosmetic line + distance bar, and a translucent shadow while double-jumping) is painted
-// over the frame.  Hard and memory modes; the easy-mode compass sits on a non-integer rect, which Qt draws through
-// its path engine -- not restated, refused at libenv_make.
+// compass (ellipse + cosmetic line + distance bar, and a translucent shadow while double-jumping) is painted over the
+// frame.  The compass rect depends on the options alone.  In hard / memory mode with center_agent it is integer aligned
+// and Qt draws it with the midpoint algorithm (pg_render.h exec_ellipse); in easy mode and without center_agent it is
+// not, and Qt takes its path route (pg_qtpath.h): that ellipse is rasterised once per handle on the host into two 64-bit
+// row masks per frame row (brush, pen), which the renderer applies.
 #pragma once
+#include <string.h>
+
 #include "pg_game_defaults.h"
 #include "pg_math.h"
 #include "pg_mazegen.h"
+#include "pg_qtpath.h"
 #include "pg_roomgen.h"
 
 namespace pgamd {
@@ -47,21 +52,72 @@ struct Jumper : BagDefaults<Jumper> {
     PG_DEV static bool is_wall(int t) { return t == CAVEWALL || t == CAVEWALL_TOP; }
 
     static void construct(EnvHdr &G) { construct_defaults(G); }  // jumper.cpp:41-44
+    // jumper.cpp:201-231: what the distribution mode fixes
+    PG_HOSTDEV static float mode_visibility(int dm) { return dm == EasyMode ? 12.f : 16.f; }
+    PG_HOSTDEV static float mode_compass_dim(int dm) { return dm == EasyMode ? 3.f : 2.f; }
+    PG_HOSTDEV static int mode_world_dim(int dm) { return dm == HardMode ? 40 : (dm == MemoryMode ? 45 : 20); }
     template <class E>
     PG_DEV static void choose_world_dim(E &e) {  // jumper.cpp:201-217, preceded by game_reset's prologue :219-231
         EnvHdr &G = e.G;
         const int dm = e.d.opt.distribution_mode;
-        if (dm == EasyMode) {
-            G.visibility = 12;
-            JP_COMPASS_DIM(G) = 3;
-        } else {
-            G.visibility = 16;
-            JP_COMPASS_DIM(G) = 2;
-        }
+        G.visibility = mode_visibility(dm);
+        JP_COMPASS_DIM(G) = mode_compass_dim(dm);
         if (dm == MemoryMode) G.timeout = 2000;
-        const int wd = dm == HardMode ? 40 : (dm == MemoryMode ? 45 : 20);
+        const int wd = mode_world_dim(dm);
         G.main_width = wd;
         G.main_height = wd;
+    }
+    // compass_rect (jumper.cpp:138) as get_abs_rect (BAG:803-805) yields it after prepare_for_drawing (BAG:819-838)
+    PG_HOSTDEV static void compass_rect(float unit, float view_dim, float cd, double r[4]) {
+        const float cxf = (float)((double)(view_dim - cd) - .25), cyf = (float).25;
+        r[0] = (double)(cxf * unit);
+        r[1] = (double)(cyf * unit);
+        r[2] = (double)(cd * unit);
+        r[3] = (double)(cd * unit);
+    }
+    // game tables: [0..7] the compass rect (4 doubles) the masks were made for, then per frame row the brush mask and the
+    // pen mask (bit x = column x), 64 x 2 x 64 bits.  Empty when the rect is integer aligned (midpoint route) or in memory mode.
+    static constexpr int TABLE_WORDS = 8 + RES_H * 4, HOST_TABLE_WORDS = TABLE_WORDS;
+    struct MaskSink {
+        uint64_t brush[RES_H], pen[RES_H];
+        int cnt[RES_H], xa[RES_H];
+        void cross(int y, int x) {  // second crossing of a row: fill between the two (QScanConverter, odd-even)
+            if (cnt[y]++ == 0) {
+                xa[y] = x;
+                return;
+            }
+            int x0 = xa[y] < x ? xa[y] : x, x1 = xa[y] < x ? x : xa[y];
+            if (x0 < 0) x0 = 0;
+            if (x1 > RES_W) x1 = RES_W;
+            for (int c = x0; c < x1; c++) brush[y] |= 1ull << c;
+        }
+        void pixel(int x, int y) { pen[y] |= 1ull << x; }
+    };
+    static int host_tables(const GameOptions &o, uint32_t *out, int max_words) {
+        if (o.distribution_mode == MemoryMode || max_words < TABLE_WORDS) return 0;
+        // BAG::prepare_for_drawing for a 64-pixel frame: jumper keeps BAG's choose_center and min_visibility = 0
+        const float world = (float)mode_world_dim(o.distribution_mode);
+        const float visibility = o.center_agent ? mode_visibility(o.distribution_mode) : world;
+        const float raw_unit = 64 / visibility;
+        const float unit = (float)((double)raw_unit * (64.0 / 64.0));
+        const float view_dim = (float)(64.0 / (double)raw_unit);
+        double r[4];
+        compass_rect(unit, view_dim, mode_compass_dim(o.distribution_mode), r);
+        if (qtpath::is_integer_rect(r[0], r[1], r[2], r[3])) return 0;
+        MaskSink *m = new MaskSink();
+        memset(m, 0, sizeof(*m));
+        int top, bot;
+        qtpath::fill_crossings(*m, r[0], r[1], r[2], r[3], RES_W, RES_H, top, bot);
+        qtpath::stroke_ellipse(*m, r[0], r[1], r[2], r[3], RES_W, RES_H);
+        memcpy(out, r, sizeof(r));
+        for (int y = 0; y < RES_H; y++) {
+            out[8 + y * 4 + 0] = (uint32_t)m->brush[y];
+            out[8 + y * 4 + 1] = (uint32_t)(m->brush[y] >> 32);
+            out[8 + y * 4 + 2] = (uint32_t)m->pen[y];
+            out[8 + y * 4 + 3] = (uint32_t)(m->pen[y] >> 32);
+        }
+        delete m;
+        return TABLE_WORDS;
     }
     template <class E>
     PG_DEV static bool is_blocked(E &e, int src_type, int target, bool) {  // jumper.cpp:108-115
@@ -347,14 +403,26 @@ struct Jumper : BagDefaults<Jumper> {
         }
         const int ag = G.agent;
         const float cd = JP_COMPASS_DIM(G);
-        const float cxf = (float)((double)(G.view_dim - cd) - .25), cyf = (float).25;
-        const RectD cr_ = r.get_abs_rect(cxf, cyf, cd, cd);
-        const int bx = (int)cr_.x, by = (int)cr_.y, bw = (int)cr_.w, bh = (int)cr_.h;
-        if ((double)bx != cr_.x || (double)by != cr_.y || (double)bw != cr_.w || (double)bh != cr_.h) {
-            r.fail(PGE_UNSUPPORTED_DRAW);  // Qt's path engine draws ellipses on non-integer rects: not restated
-            return;
+        const float cxf = (float)((double)(G.view_dim - cd) - .25);
+        double crv[4];
+        compass_rect(G.unit, G.view_dim, cd, crv);
+        const RectD cr_ = {crv[0], crv[1], crv[2], crv[3]};
+        if (qtpath::is_integer_rect(cr_.x, cr_.y, cr_.w, cr_.h)) {
+            r.exec_ellipse((int)cr_.x, (int)cr_.y, (int)cr_.w, (int)cr_.h, true, 0xffa8a69eu, 0xffa8a69eu);
+        } else {
+            // Qt's path route: the handle's precomputed row masks -- valid for exactly this rect
+            const uint32_t *t = r.d.game_tables;
+            bool same = t != nullptr;
+            if (same) {
+                const double *tr = (const double *)t;
+                same = tr[0] == cr_.x && tr[1] == cr_.y && tr[2] == cr_.w && tr[3] == cr_.h;
+            }
+            if (!same) {
+                r.fail(PGE_ASSERT);
+                return;
+            }
+            r.exec_row_masks(t + 8, (int)cr_.y - 1, (int)(cr_.y + cr_.h) + 2, 0xffa8a69eu, 0xffa8a69eu);
         }
-        r.exec_ellipse(bx, by, bw, bh, true, 0xffa8a69eu, 0xffa8a69eu);
         const float cx = (float)(cr_.x + cr_.w / 2);
         const float cy = (float)(cr_.y + cr_.h / 2);
         const float cr = (float)(cr_.w / 2 * .95);

@@ -30,7 +30,9 @@ struct GameEntry {
     int grid_bytes;
     bool has_lane;  // the game has a lane = env step path (mode-1 steps launch lane_step + reset_list instead of the tier-0 grid)
     void (*init_state)(int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
+    int (*host_tables)(const GameOptions &opt, uint32_t *out, int max_words);  // GameHostTables<Game>::build (pg_env.h)
 };
+constexpr int MAX_GAME_TABLE_WORDS = 1024;
 // mode 0: initial reset + first observation of every env; mode 1: one step
 hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStreams &ls);
 hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream);
@@ -39,6 +41,7 @@ bool game_has_lane(int game_id);
 int game_tier_for(int game_id, int slots_needed);
 void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes);
 void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
+int game_host_tables(int game_id, const GameOptions &opt, uint32_t *out, int max_words);
 // device math self-tests (kernels.hip)
 hipError_t selftest_bigfish_radius(const float *d_in, float *d_out, int n);
 hipError_t selftest_sincos(uint32_t first_bits, int n, double *d_sin, double *d_cos);

@@ -61,6 +61,11 @@ void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, i
     if (e) e->init_state(num_envs, rand_seed, env_offset, env_stride, hdr, rng);
 }
 
+int game_host_tables(int game_id, const GameOptions &opt, uint32_t *out, int max_words) {
+    const GameEntry *e = find(game_id);
+    return e ? e->host_tables(opt, out, max_words) : 0;
+}
+
 // ---- device math self-tests (procgen_amd_selftest_*, include/procgen_amd.h): the exact device functions the game
 // policies call, run over caller-chosen inputs so that a test can sweep a whole input domain against the host libm ----
 __global__ void selftest_bigfish_radius_kernel(const float *r01, float *out, int n) {

@@ -237,6 +237,7 @@ const GameEntry *PG_CAT(game_entry_, PG_GAME)() {
     static const GameEntry e = {
         PG_GAME::GAME_ID,    launch_game<PG_GAME>,       render_one<PG_GAME>,     PG_GAME::ENT_CAP_T0, PG_GAME::ENT_CAP_T1,
         PG_GAME::ENT_CAP_T2, game_grid_bytes<PG_GAME>(), GameLane<PG_GAME>::value, init_env_state<PG_GAME>,
+        GameHostTables<PG_GAME>::build,
     };
     return &e;
 }

@@ -148,6 +148,7 @@ struct VecGame {
     HostAssets assets;
     GameAssetsDev *d_assets = nullptr;
     uint32_t *d_pixels = nullptr;
+    uint32_t *d_game_tables = nullptr;
     int32_t *d_action = nullptr;
     // [rew f32 N | prev_level_seed i32 N | level_seed i32 N | first u8 N | prev_level_complete u8 N | list counts A i32 x LIST_COUNTERS | error i32 | list counts B]
     // The tail doubles as the tier-list counters (double-buffered A / B) so that one memset clears "next counts + error" and
@@ -264,7 +265,6 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     opts.consume_int("distribution_mode", &dist_mode);
     o.distribution_mode = dist_mode;
     if (dist_mode == EasyMode || dist_mode == HardMode) {
-        if (env_name == "jumper" && dist_mode == EasyMode) fatal("jumper easy mode is not provided by the HIP stepper yet (its compass lies on a non-integer rect, which Qt draws through the path engine)\n");
     } else if (dist_mode == ExtremeMode) {
         if (!(env_name == "chaser" || env_name == "dodgeball" || env_name == "leaper" || env_name == "starpilot")) fatal("fassert failed: extreme mode unsupported for %s\n", env_name.c_str());
     } else if (dist_mode == MemoryMode) {
@@ -410,6 +410,15 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d_reset_count = dev_alloc<int>(2 * MAX_CHUNKS);
     d.assets = d_assets;
     d.pixels = d_pixels;
+    {
+        std::vector<uint32_t> tab(MAX_GAME_TABLE_WORDS);
+        const int nw = game_host_tables(kernel_id, d.opt, tab.data(), MAX_GAME_TABLE_WORDS);
+        if (nw > 0) {
+            d_game_tables = dev_alloc<uint32_t>((size_t)nw);
+            HIP_CHECK(hipMemcpy(d_game_tables, tab.data(), (size_t)nw * 4, hipMemcpyHostToDevice));
+        }
+        d.game_tables = d_game_tables;
+    }
     d.debug_flags = getenv("PROCGEN_AMD_DEBUG") ? atoi(getenv("PROCGEN_AMD_DEBUG")) : 0;
     d.lane_max_ents = getenv("PROCGEN_AMD_LANE_ENTS") ? atoi(getenv("PROCGEN_AMD_LANE_ENTS")) : LANE_MAX_ENTS;
     d.lane_max_smart = getenv("PROCGEN_AMD_LANE_SMART") ? atoi(getenv("PROCGEN_AMD_LANE_SMART")) : LANE_MAX_SMART;
@@ -461,6 +470,7 @@ VecGame::~VecGame() {
     if (registered_obs && !ob_ptr.empty()) (void)hipHostUnregister(ob_ptr[0]);
     (void)hipFree(d_assets);
     (void)hipFree(d_pixels);
+    if (d_game_tables) (void)hipFree(d_game_tables);
     (void)hipFree(d.hdr);
     (void)hipFree(d.rng);
     (void)hipFree(d.ents);

@@ -102,7 +102,7 @@ enum EntField : int {
 // The lane = env step kernel (one lane per env, one wave per tile) then reads a field of the same slot for its 64 envs
 // as one 256-byte access; the wave = env kernels (level generation, rendering) read a table at a 256-byte stride.
 constexpr int TILE_ENVS = 64;
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PG_HOSTDEV __host__ __device__
 #else
 #define PG_HOSTDEV
@@ -166,6 +166,7 @@ struct DevCtx {
     // assets
     const GameAssetsDev *assets;
     const uint32_t *pixels;
+    const uint32_t *game_tables;  // Game::host_tables' words (null when the game has none)
     // routing between the arena tiers of the step kernel: envs whose entity table may outgrow tier 0's LDS arena
     // are listed for the tier-1 / tier-2 kernels of the NEXT step (double-buffered by step parity)
     // List (tier, list chunk c) starts at big_list[tier * num_envs + c * chunk_envs], its length is

@@ -142,6 +142,18 @@ struct GameSplit<Game, decltype((void)Game::SPLIT_RESET)> {
     static constexpr int RESET_CAP = Game::RESET_CAP;
 };
 
+// Constant tables a game wants in HBM next to the sprite atlas (DevCtx::game_tables): a game declares HOST_TABLE_WORDS and
+// host_tables(options, out, max_words) -> words written; built once per handle on the host from the options alone
+// (jumper: the row masks of its compass ellipse).
+template <class Game, class = void>
+struct GameHostTables {
+    static int build(const GameOptions &, uint32_t *, int) { return 0; }
+};
+template <class Game>
+struct GameHostTables<Game, decltype((void)Game::HOST_TABLE_WORDS)> {
+    static int build(const GameOptions &o, uint32_t *out, int max_words) { return Game::host_tables(o, out, max_words); }
+};
+
 // A game declares PAR_SMART = true and par_smart_type_ok(type) for the smart_step entity types (a) whose basic_step_object
 // has no side effect beyond the object itself when no entity can block or reflect it, and (b) that no smart entity's
 // sub_step scan can ever hit (may_interact(any smart type, type) is false): the wave = env step_entities then steps all

@@ -1019,6 +1019,18 @@ struct Renderer {
         }
         PG_SYNC();
     }
+    // a shape rasterised ahead of time into two 64-bit masks per frame row, words [row][brush lo, hi, pen lo, hi]: brush
+    // pixels, then pen pixels over them, both opaque (the jumper compass on a non-integer rect, game_jumper.h host_tables)
+    PG_DEV void exec_row_masks(const uint32_t *rows, int y_first, int y_end, uint32_t brush_px, uint32_t pen_px) {
+        for (int y = y_first > row0 ? y_first : row0; y < (y_end < row1 ? y_end : row1); y++) {
+            PG_FOR_LANES(l) {
+                const uint32_t *w = rows + y * 4;
+                const uint32_t b = l < 32 ? w[0] >> l : w[1] >> (l - 32), p = l < 32 ? w[2] >> l : w[3] >> (l - 32);
+                if ((b | p) & 1u) fb[(y - row0) * RES_W + l] = (p & 1u) ? pen_px : brush_px;
+            }
+        }
+        PG_SYNC();
+    }
     // QRasterPaintEngine::drawEllipse on an integer-aligned rect, no antialiasing: drawEllipse_midpoint_i +
     // drawEllipsePoints (Qt 5.9.7 qpaintengine_raster.cpp): brush spans, then outline spans of a pen of width <= 1.
     // Pinned with tests/tools/qt_compass_probe.py.

@@ -32,6 +32,7 @@ struct EmuVec {
     std::vector<int32_t> action, pls, ls;
     std::vector<float> rew;
     HostAssets assets;
+    std::vector<uint32_t> game_tables;
     int use_small;
     int dev_error = 0;
     int game_id = -1;
@@ -196,6 +197,13 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.assets = &v->assets.table;
     d.pixels = v->assets.pixels.data();
     d.error = &v->dev_error;
+    v->game_tables.assign(1024, 0);
+    int nw = 0;
+#define PG_X(Game) \
+    if (gid == Game::GAME_ID) nw = GameHostTables<Game>::build(d.opt, v->game_tables.data(), 1024);
+    PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
+    d.game_tables = nw > 0 ? v->game_tables.data() : nullptr;
     return v;
 }
 
@@ -285,6 +293,16 @@ void emu_sincos_array(const double *x, double *s, double *c, int n) {
         s[i] = pg_sin_d(x[i]);
         c[i] = pg_cos_d(x[i]);
     }
+}
+// pg_qtpath.h (the header the product builds the jumper compass masks with) on a 64 x 64 canvas: 0 untouched, 1 brush, 2 pen
+void emu_qt_path_ellipse(double x, double y, double w, double h, int pen, int brush, uint8_t *out) {
+    Jumper::MaskSink m;
+    memset(&m, 0, sizeof(m));
+    int top, bot;
+    if (brush) qtpath::fill_crossings(m, x, y, w, h, RES_W, RES_H, top, bot);
+    if (pen) qtpath::stroke_ellipse(m, x, y, w, h, RES_W, RES_H);
+    for (int yy = 0; yy < RES_H; yy++)
+        for (int xx = 0; xx < RES_W; xx++) out[yy * RES_W + xx] = ((m.pen[yy] >> xx) & 1) ? 2 : (((m.brush[yy] >> xx) & 1) ? 1 : 0);
 }
 long long emu_counter(int k) { return pg_emu_counters()[k]; }
 void emu_path_counts(void *h, long long *out) {

@@ -88,9 +88,9 @@ def seeding(game):
 
 
 # distribution modes other than the default (reference src/game.cpp:55-62 and each game's choose_world_dim / game_reset):
-# every (game, mode) pair the reference accepts, except jumper easy (refused by the HIP stepper)
-MODE_MATRIX = ([(g, "easy") for g in ("bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot", "heist", "leaper", "maze",
-                                      "miner", "ninja", "plunder", "starpilot")]
+# every (game, mode) pair the reference accepts: 16 easy + 4 extreme + 6 memory (hard is the default the rollouts cover)
+MODE_MATRIX = ([(g, "easy") for g in ("bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot", "heist", "jumper", "leaper",
+                                      "maze", "miner", "ninja", "plunder", "starpilot")]
                + [(g, "extreme") for g in ("chaser", "dodgeball", "leaper", "starpilot")]
                + [(g, "memory") for g in ("caveflyer", "dodgeball", "heist", "jumper", "maze", "miner")])
 
@@ -130,13 +130,11 @@ ALL_GAMES = ["bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun"
 
 
 def option_matrix(n=6, t_steps=60):
-    """<game>/<option set>/{rew, first, level_seed, crc}; jumper without center_agent is left out (its compass then lies on a
-    non-integer rect, drawn by Qt's path engine: refused by the oracle and the HIP stepper alike)."""
+    """<game>/<option set>/{rew, first, level_seed, crc} for all 16 x 7 pairs (jumper without center_agent draws its compass
+    on a non-integer rect: Qt's path engine, pg_qtpath.h)."""
     res = {}
     for game in ALL_GAMES:
         for name, kw in OPTION_SETS.items():
-            if game == "jumper" and name == "no_center_agent":
-                continue
             env = ref_env.make_ref_env(n, game, rand_seed=7, **kw)
             rng = np.random.RandomState(1)
             out = {k: [] for k in ("rew", "first", "level_seed", "crc")}

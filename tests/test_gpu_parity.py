@@ -205,7 +205,7 @@ def test_every_distribution_mode_matches_reference_fixture(golden_dir):
     """All accepted (game, distribution_mode) pairs besides the default against tests/golden/mode_matrix.npz (compiled reference)."""
     g = np.load(os.path.join(golden_dir, "mode_matrix.npz"))
     pairs = sorted({tuple(k.split("/")[:2]) for k in g.files})
-    assert len(pairs) == 25
+    assert len(pairs) == 26  # 16 easy + 4 extreme + 6 memory: every pair reference src/game.cpp:55-66 accepts
     for game, mode in pairs:
         n = g[f"{game}/{mode}/rew"].shape[1]
         steps = g[f"{game}/{mode}/rew"].shape[0] - 1
@@ -218,7 +218,7 @@ def test_option_surface_of_every_game_matches_reference_fixture(golden_dir):
     """7 option sets x 16 games against tests/golden/option_matrix.npz (compiled reference)."""
     g = np.load(os.path.join(golden_dir, "option_matrix.npz"))
     pairs = sorted({tuple(k.split("/")[:2]) for k in g.files})
-    assert len(pairs) == 16 * 7 - 1
+    assert len(pairs) == 16 * 7
     check_against_option_matrix(g, lambda game, n, **kw: make_env(n, game, rand_seed=7, **kw), pairs)
 
 

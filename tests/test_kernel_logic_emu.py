@@ -181,7 +181,7 @@ def test_emulated_num_levels_and_easy_mode():
 
 
 @pytest.mark.parametrize("game,mode", [("caveflyer", "memory"), ("maze", "memory"), ("jumper", "memory"), ("dodgeball", "extreme"), ("leaper", "extreme"),
-                                       ("heist", "easy"), ("miner", "easy"), ("starpilot", "easy")])
+                                       ("heist", "easy"), ("miner", "easy"), ("starpilot", "easy"), ("jumper", "easy")])
 def test_emulated_distribution_modes_match_reference_fixture(golden_dir, game, mode):
     """Kernel logic in non-default modes against the compiled reference's fixture (caveflyer memory runs its own 60x60 policy)."""
     g = np.load(os.path.join(golden_dir, "mode_matrix.npz"))
@@ -221,7 +221,7 @@ def test_emulated_option_surface_matches_reference_fixture(golden_dir):
     """A spread of (game, option set) pairs of tests/golden/option_matrix.npz through the emulated kernels (the GPU suite runs all)."""
     g = np.load(os.path.join(golden_dir, "option_matrix.npz"))
     pairs = [("bigfish", "restrict_themes"), ("bossfight", "restrict_themes"), ("fruitbot", "restrict_themes"), ("heist", "restrict_themes"),
-             ("plunder", "restrict_themes"), ("maze", "no_backgrounds"), ("starpilot", "no_backgrounds"), ("climber", "no_center_agent"),
+             ("plunder", "restrict_themes"), ("maze", "no_backgrounds"), ("starpilot", "no_backgrounds"), ("climber", "no_center_agent"), ("jumper", "no_center_agent"),
              ("ninja", "two_levels"), ("miner", "sequential_levels"), ("dodgeball", "monochrome"), ("caveflyer", "monochrome"), ("leaper", "vel_info")]
     check_against_option_matrix(g, lambda game, n, **kw: emu_harness.EmuEnv(n, game, rand_seed=7, **kw), pairs)
 
@@ -254,3 +254,28 @@ def test_emulated_forced_reset_action(game):
     b = rollout(emu_harness.EmuEnv(n, game, rand_seed=23), acts)
     assert_rollouts_equal(a, b, f"forced resets ({game})")
     assert a["first"][1:].sum() > 10
+
+
+def test_product_qt_path_header_matches_qt_pixels(golden_dir):
+    """procgen_amd/csrc/pg_qtpath.h -- the code libenv_make builds the jumper compass masks with -- against Qt 5.9.7's own pixels
+    (tests/golden/qt_path_ellipses.npz); integer-aligned rects take Qt's midpoint route (pg_render.h exec_ellipse) and are skipped."""
+    import ctypes as C
+
+    L = emu_harness.lib()
+    L.emu_qt_path_ellipse.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_void_p]
+    g = np.load(os.path.join(golden_dir, "qt_path_ellipses.npz"))
+    unpack = lambda k: np.unpackbits(g[k], axis=-1).astype(bool)
+    both_pen, both_brush, brush_only, pen_only = unpack("both"), unpack("both_brush"), unpack("brush_only"), unpack("pen_only")
+    out = np.zeros((64, 64), np.uint8)
+    checked = 0
+    for i, (x, y, w, h) in enumerate(g["rects"]):
+        if all(float(int(v)) == v for v in (x, y, w, h)):
+            continue
+        checked += 1
+        L.emu_qt_path_ellipse(x, y, w, h, 1, 1, out.ctypes.data)
+        assert np.array_equal(out == 2, both_pen[i]) and np.array_equal(out == 1, both_brush[i]), ("pen + brush", i, (x, y, w, h))
+        L.emu_qt_path_ellipse(x, y, w, h, 0, 1, out.ctypes.data)
+        assert np.array_equal(out == 1, brush_only[i]), ("brush", i, (x, y, w, h))
+        L.emu_qt_path_ellipse(x, y, w, h, 1, 0, out.ctypes.data)
+        assert np.array_equal(out == 2, pen_only[i]), ("pen", i, (x, y, w, h))
+    assert checked > 1000

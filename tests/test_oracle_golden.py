@@ -91,7 +91,7 @@ def _mode_pairs(golden_dir):
 def test_oracle_matches_reference_in_every_distribution_mode(golden_dir):
     """tests/golden/mode_matrix.npz (compiled reference, `make_golden.py modes`): all accepted (game, mode) pairs besides the default."""
     g, pairs = _mode_pairs(golden_dir)
-    assert len(pairs) == 25
+    assert len(pairs) == 26  # 16 easy + 4 extreme + 6 memory: every pair reference src/game.cpp:55-66 accepts
     for game, mode in pairs:
         n = g[f"{game}/{mode}/rew"].shape[1]
         steps = g[f"{game}/{mode}/rew"].shape[0] - 1
@@ -106,5 +106,30 @@ def test_oracle_matches_reference_on_the_option_surface(golden_dir):
     bossfight / fruitbot physics."""
     g = np.load(os.path.join(golden_dir, "option_matrix.npz"))
     pairs = sorted({tuple(k.split("/")[:2]) for k in g.files})
-    assert len(pairs) == 16 * 7 - 1
+    assert len(pairs) == 16 * 7
     check_against_option_matrix(g, lambda game, n, **kw: oracle_env.OracleEnv(n, game, rand_seed=7, **kw), pairs)
+
+
+def _qt_ellipse_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "qt_path_ellipses.npz"))
+    unpack = lambda k: np.unpackbits(g[k], axis=-1).astype(bool)
+    return g["rects"], unpack("both"), unpack("both_brush"), unpack("brush_only"), unpack("pen_only")
+
+
+def test_oracle_ellipse_restatement_matches_qt_pixels(golden_dir):
+    """drawEllipse(QRectF) without antialiasing, as Qt 5.9.7 itself drew it (tests/golden/qt_path_ellipses.npz, written by
+    tests/tools/qt_path_probe.py golden with PyQt5 5.9.7): the five jumper compass rects + 1200 random / knife-edge / tiny /
+    partly-outside rects; pen + brush, brush alone, pen alone."""
+    import ctypes as C
+
+    L = oracle_env.lib()
+    L.pgo_test_draw_ellipse.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_void_p]
+    rects, both_pen, both_brush, brush_only, pen_only = _qt_ellipse_fixture(golden_dir)
+    out = np.zeros((64, 64), np.uint8)
+    for i, (x, y, w, h) in enumerate(rects):
+        L.pgo_test_draw_ellipse(x, y, w, h, 1, 1, out.ctypes.data)
+        assert np.array_equal(out == 2, both_pen[i]) and np.array_equal(out == 1, both_brush[i]), ("pen + brush", i, (x, y, w, h))
+        L.pgo_test_draw_ellipse(x, y, w, h, 0, 1, out.ctypes.data)
+        assert np.array_equal(out == 1, brush_only[i]), ("brush", i, (x, y, w, h))
+        L.pgo_test_draw_ellipse(x, y, w, h, 1, 0, out.ctypes.data)
+        assert np.array_equal(out == 2, pen_only[i]), ("pen", i, (x, y, w, h))

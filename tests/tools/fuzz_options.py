@@ -24,14 +24,13 @@ master=np.random.RandomState(int(sys.argv[1]) if len(sys.argv)>1 else 0)
 N=5; T=70; total=0; fails=0
 for game in ALL:
     for rep in range(4):
-        modes=(["easy"] if game!="jumper" else [])+["hard"]+(["extreme"] if game in EXT else [])+(["memory"] if game in MEM else [])
+        modes=["easy","hard"]+(["extreme"] if game in EXT else [])+(["memory"] if game in MEM else [])
         mode=modes[master.randint(len(modes))]
         kw={}
         for name in ("use_backgrounds","center_agent"):
             if master.rand()<0.4: kw[name]=False
         for name in ("restrict_themes","use_monochrome_assets","paint_vel_info","use_sequential_levels"):
             if master.rand()<0.4: kw[name]=True
-        if game=="jumper": kw.pop("center_agent",None)
         if master.rand()<0.5: kw["num_levels"]=int(master.randint(1,5)); kw["start_level"]=int(master.randint(0,1000))
         if kw.get("use_sequential_levels") and "num_levels" not in kw: kw["num_levels"]=2
         seed=int(master.randint(0,2**31-1))
