@@ -25,18 +25,11 @@ struct CoinRun {
     // and may_interact(., ENEMY) are false for every type) and their hooks touch nothing but the moving object
     static constexpr bool PAR_SMART = true;
     PG_DEV static bool par_smart_type_ok(int t) { return t == PLAYER || t == ENEMY; }
-    // lane = env step path (pg_env.h LANE_MODE): a step draws step_rand_int and nothing else from rand_gen
-    static constexpr bool HAS_LANE_STEP = true;
-    static constexpr int LANE_MAX_DRAWS = 1;
     template <class E>
     PG_DEV static int slots_needed_next_step(E &e) {
         const int n = e.G.n_ents;
         int enemies = 0;
-        if constexpr (E::LANE) {
-            for (int i = 0; i < n; i++) enemies += e.etype(i) == ENEMY ? 1 : 0;
-        } else {
-            for (int c = 0; c < ((n + 63) >> 6); c++) enemies += pg_popc64(PG_BALLOT(l, ((c << 6) + l) < n && e.etype((c << 6) + l) == ENEMY));
-        }
+        for (int c = 0; c < ((n + 63) >> 6); c++) enemies += pg_popc64(PG_BALLOT(l, ((c << 6) + l) < n && e.etype((c << 6) + l) == ENEMY));
         const int need = n + enemies + 3;
         return need < 46 ? 46 : need;
     }
@@ -145,7 +138,6 @@ struct CoinRun {
         if (G.action_vx < 0) CR_FACING_RIGHT(G) = 0;
         const int ag = G.agent;
         const float ax = e.ex(ag), ay = e.ey(ag), arx = e.erx(ag), ary = e.ery(ag);
-        e.grid_window(ax, ay);  // (lane = env kernel: the agent's neighbourhood for these probes and its sub_steps)
         const float by = (float)((double)ay - ((double)ary + .01));
         const int obj_below_1 = e.get_obj_from_floats((float)((double)ax - ((double)arx - .01)), by);
         const int obj_below_2 = e.get_obj_from_floats((float)((double)ax + ((double)arx - .01)), by);
@@ -197,31 +189,7 @@ struct CoinRun {
         const int n = G.n_ents;
         int added = 0;
         const int cur_time = G.cur_time;
-        if constexpr (E::LANE) {  // the reference's loop as it stands (coinrun.cpp:480-495)
-            int i = n - 1;
-            while (i >= 0) {
-                int t = e.etype(i);
-                while (t != ENEMY && t != SAW && --i >= 0) t = e.etype(i);  // every lane finds its next enemy / saw ...
-                if (i < 0) break;
-                if (t == ENEMY) {  // ... and the lanes append their trails side by side
-                    if (n + added + 1 > E_CAP<E>() - 1) {
-                        e.fail(PGE_ENT_OVERFLOW);
-                        break;
-                    }
-                    const int slot = n + added;
-                    e.ent_init(slot, e.ex(i), (float)((double)e.ey(i) - (double)e.ery(i) * .5), 0, 0.01f, 0.3f, 0.2f, TRAIL);
-                    e.ei(EF_EXPIRE_TIME, slot) = 8;
-                    e.ef(EF_ALPHA, slot) = (float).5;
-                    e.set_image_type(i, cur_time / 5 % 2 == 0 ? ENEMY1 : ENEMY2);
-                    e.set_flag(i, MF_REFLECTED, e.evx(i) > 0);
-                    added++;
-                } else if (t == SAW) {
-                    e.set_image_type(i, cur_time % 2 == 0 ? SAW : SAW2);
-                }
-                i--;
-            }
-        }
-        for (int c = E::LANE ? -1 : ((n - 1) >> 6); c >= 0; c--) {
+        for (int c = (n - 1) >> 6; c >= 0; c--) {
             const uint64_t em = PG_BALLOT(l, ((c << 6) + l) < n && e.etype((c << 6) + l) == ENEMY);
             if (n + added + pg_popc64(em) > E_CAP<E>() - 1) {
                 e.fail(PGE_ENT_OVERFLOW);

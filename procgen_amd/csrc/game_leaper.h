@@ -122,7 +122,7 @@ struct Leaper : BagDefaults<Leaper> {
     PG_DEV static void spawn_entities(E &e) {
         EnvHdr &G = e.G;
         const int n_road = LP_N_ROAD(G), n_water = LP_N_WATER(G);
-        if constexpr (!E::LANE) {
+        {
             // Most rounds no lane spawns anything (spawn probability = |speed| / 6 or / 2, a few percent): each lane then makes
             // exactly one draw, so the round's draws are looked at side by side, one wave lane per road / water lane, and
             // consumed together.  A round with a spawn attempt takes the reference's loop below (an attempt makes further

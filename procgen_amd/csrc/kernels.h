@@ -10,7 +10,7 @@ struct LaunchStreams {
     hipStream_t main;
     hipEvent_t fork;
     hipStream_t lane[2];      // env chunks alternate between these two streams (step of chunk c+1 overlaps render of chunk c)
-    hipStream_t side[3];      // [0]: lane = env kernel + reset kernel of a game with a lane path, concurrent with the tier-0 grids of the chunks
+    hipStream_t side[3];      // [0]: launch-order experiments (PROCGEN_AMD_ORDER): the tier-2 list kernel off the chunk streams
     hipEvent_t lane_done[2];
     hipEvent_t side_done[3];
     hipEvent_t step_done[MAX_CHUNKS];
@@ -28,7 +28,6 @@ struct GameEntry {
     hipError_t (*render_one)(const DevCtx &, int env, hipStream_t);
     int cap_t0, cap_t1, cap_t2;  // entity slots of the three LDS arenas; cap_t2 is the HBM table size
     int grid_bytes;
-    bool has_lane;  // the game has a lane = env step path (mode-1 steps launch lane_step + reset_list instead of the tier-0 grid)
     void (*init_state)(int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
     int (*host_tables)(const GameOptions &opt, uint32_t *out, int max_words);  // GameHostTables<Game>::build (pg_env.h)
 };
@@ -37,7 +36,6 @@ constexpr int MAX_GAME_TABLE_WORDS = 1024;
 hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStreams &ls);
 hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream);
 bool game_supported(int game_id);
-bool game_has_lane(int game_id);
 int game_tier_for(int game_id, int slots_needed);
 void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes);
 void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);

@@ -42,10 +42,6 @@ int chunk_envs_for(int num_envs, int chunks) {
     return per > 0 ? per : TILE_ENVS;
 }
 bool game_supported(int game_id) { return find(game_id) != nullptr; }
-bool game_has_lane(int game_id) {
-    const GameEntry *e = find(game_id);
-    return e && e->has_lane;
-}
 int game_tier_for(int game_id, int slots_needed) {
     const GameEntry *e = find(game_id);
     if (!e) return 0;

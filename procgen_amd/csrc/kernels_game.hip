@@ -30,7 +30,7 @@ struct GameRenderMinWaves<Game, decltype((void)Game::RENDER_MIN_WAVES)> {
 };
 // games with SPLIT_RESET: their step kernels carry no level generator (Env NO_RESET, arena without scratch)
 template <class Game, int CAP>
-using StepEnv = Env<Game, CAP, false, GameSplit<Game>::value>;
+using StepEnv = Env<Game, CAP, GameSplit<Game>::value>;
 
 template <class Game>
 __global__ __launch_bounds__(64) void step_tier0(DevCtx d, int mode, int env_base) {
@@ -64,28 +64,7 @@ __global__ __launch_bounds__(64) void step_list(DevCtx d, int mode, int chunk) {
     }
 }
 
-// lane = env physics: one LANE per env, one wave per tile of 64 consecutive envs (the tile-interleaved entity table makes a
-// wave's accesses to one slot contiguous); LDS holds the hot words of each env's first entity slots (LaneLds).  Takes the envs the route table gives it; everything wave-structured
-// (level generation after an episode ends, generator twists) goes to the wave = env kernels through the lists.
-template <class Game>
-__global__ __launch_bounds__(64) void lane_step(DevCtx d, int chunk, int env_base, int env_end) {
-    __shared__ LaneLds<typename Game::cell_t> cache;
-    // One wave per workgroup and a long chain of dependent operations: when it shares a SIMD with the issue-hungry waves of
-    // another chunk's render kernel it should win the arbitration, the others fill its stalls.
-    if (!(d.debug_flags & 8192)) __builtin_amdgcn_s_setprio(3);
-    if (blockIdx.x == 0 && threadIdx.x == 0) d.next_reset_count[chunk] = 0;
-    const int env = env_base + (int)blockIdx.x * TILE_ENVS + (int)threadIdx.x;
-    if (env >= env_end) return;
-    if (d.route[env] != ROUTE_LANE) return;
-    Env<Game, Game::ENT_CAP_T2, true> e(d, env, nullptr);
-    e.lcache = (PG_LDS_PTR(uint32_t))(cache.c + threadIdx.x);
-    e.lwin = (PG_LDS_PTR(typename Game::cell_t))(cache.win + threadIdx.x);
-    e.lcand = (PG_LDS_PTR(uint32_t))(cache.cand + threadIdx.x);
-    e.has_lds = true;
-    e.run_lane(chunk, env_base);
-}
-
-// the episodes the lane kernel of this chunk ended: reset + level generation, outputs and state write-back (Env::run mode 2)
+// SPLIT_RESET games: the episodes this chunk's step kernels ended: reset + level generation, outputs and state write-back (Env::run mode 2)
 template <class Game>
 __global__ __launch_bounds__(64) void reset_list(DevCtx d, int chunk, int env_base) {
     __shared__ Lds<Game, GameSplit<Game>::RESET_CAP> lds;
@@ -104,13 +83,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GameRenderMi
     r.render_env();
 }
 
-// One step of a handle.  The envs are stepped by up to four kinds of kernel that touch disjoint envs (route table):
+// One step of a handle.  The envs are stepped by up to three kinds of kernel that touch disjoint envs (route table):
 //   * step_tier0 grids over env chunks -- chunk c on stream lane[c & 1], followed by the chunk's render kernel, so the
 //     latency-bound step work of one chunk shares the CUs with the issue-bound render kernel of its neighbour;
-//   * the tier-1 and tier-2 list kernels (larger LDS arenas), each on a side stream;
-//   * for games with a lane = env path, lane_step over all tiles + the reset kernel for the episodes it ended, on a
-//     third side stream.
-// A chunk's render kernel waits for the side streams (their envs lie in every chunk).
+//   * the tier-1 and tier-2 list kernels (larger LDS arenas).
+// A chunk's render kernel waits for the list kernels (their envs lie in every chunk).
 template <class Game>
 static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls) {
 #define PG_TRY(x)                          \
@@ -120,10 +97,8 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
     } while (0)
     const int *cnt = ls.list_count[0];
     const bool t1 = mode != 0 && cnt[1] != 0, t2 = mode != 0 && cnt[2] != 0;
-    const bool lane = GameLane<Game>::value && d.ent_tile == TILE_ENVS && mode != 0 && !(d.debug_flags & 32);
     const int g1 = cnt[1] < 0 || cnt[1] > 8192 ? (d.num_envs < 8192 ? d.num_envs : 8192) : cnt[1];
     const int g2 = cnt[2] < 0 || cnt[2] > 2048 ? (d.num_envs < 2048 ? d.num_envs : 2048) : cnt[2];
-    const int tiles = (d.num_envs + TILE_ENVS - 1) / TILE_ENVS;
     const int rg = d.num_envs < 1024 ? d.num_envs : 1024;
     if (d.num_envs < 4096) {
         // Small handles (and the parts of a joint handle, each with its own stream): the kernels are far too short for
@@ -131,12 +106,6 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         // all streams of the process onto a few hardware queues.  Everything goes down one stream.
         if (t1) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.main, d, mode, 0);
         if (t2) hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, ls.main, d, mode, 0);
-        if constexpr (GameLane<Game>::value) {
-            if (lane) {
-                hipLaunchKernelGGL(lane_step<Game>, dim3(tiles), dim3(64), 0, ls.main, d, 0, 0, d.num_envs);
-                hipLaunchKernelGGL(reset_list<Game>, dim3(rg), dim3(64), 0, ls.main, d, 0, 0);
-            }
-        }
         if constexpr (GameSplit<Game>::value) {
             if (mode == 0) {
                 hipLaunchKernelGGL(reset_grid<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, 0);
@@ -150,16 +119,10 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, 0);
         return hipGetLastError();
     }
-    // Four streams in all: the runtime deals a process's streams round-robin onto four hardware queues, and two streams on one
-    // queue run their kernels one after the other (measured with six streams: the lane kernel and a chunk's grid serialised).
+    // At most four streams: the runtime deals a process's streams round-robin onto four hardware queues, and two streams on one
+    // queue run their kernels one after the other.
     //   main    : tier-1 list          lane[1] : tier-2 list, then chunk 1, 3, ...
-    //   side[0] : lane_step + reset    lane[0] : chunk 0, 2, ...
-    if constexpr (GameLane<Game>::value) {
-        if (lane && (d.debug_flags & 16384)) {  // experiment: the lane kernel alone at the head of the step, everything else behind it
-            hipLaunchKernelGGL(lane_step<Game>, dim3(tiles), dim3(64), 0, ls.main, d, 0, 0, d.num_envs);
-            hipLaunchKernelGGL(reset_list<Game>, dim3(rg), dim3(64), 0, ls.main, d, 0, 0);
-        }
-    }
+    //                                  lane[0] : chunk 0, 2, ...
     PG_TRY(hipEventRecord(ls.fork, ls.main));
     if (t1) {
         hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.main, d, mode, 0);
@@ -170,22 +133,13 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
     // launch order experiments (PROCGEN_AMD_ORDER): 0 = tier-2 list ahead of chunk 1 on its stream (which also delays that
     // chunk's step kernel: an accidental pipeline); 1 / 3 = tier-2 list on the side stream and chunk c + 1's step kernel
     // explicitly behind chunk c's; 2 = side stream, no chaining
-    const bool lane_side = lane && !(d.debug_flags & 16384);
-    const bool t2_side = ls.order != 0 && !lane_side && ls.side[0] != nullptr;
+    const bool t2_side = ls.order != 0 && ls.side[0] != nullptr;
     const bool chain = ls.order == 1 || ls.order == 3;
     if (t2) {
         hipStream_t s2 = t2_side ? ls.side[0] : ls.lane[1];
         if (t2_side) PG_TRY(hipStreamWaitEvent(s2, ls.fork, 0));
         hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, s2, d, mode, 0);
         PG_TRY(hipEventRecord(ls.side_done[1], s2));
-    }
-    if constexpr (GameLane<Game>::value) {
-        if (lane_side) {
-            PG_TRY(hipStreamWaitEvent(ls.side[0], ls.fork, 0));
-            hipLaunchKernelGGL(lane_step<Game>, dim3(tiles), dim3(64), 0, ls.side[0], d, 0, 0, d.num_envs);
-            hipLaunchKernelGGL(reset_list<Game>, dim3(rg), dim3(64), 0, ls.side[0], d, 0, 0);
-            PG_TRY(hipEventRecord(ls.side_done[2], ls.side[0]));
-        }
     }
     const int nchunk = ls.chunks > 1 ? (ls.chunks < MAX_CHUNKS ? ls.chunks : MAX_CHUNKS) : 1;
     const int per = ((d.num_envs + nchunk - 1) / nchunk + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;
@@ -213,7 +167,6 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
             // the episodes this chunk's step kernel (and the list kernels, for its envs) ended: next level, outputs, routing
             if (mode != 0) hipLaunchKernelGGL(reset_list<Game>, dim3(count < 1024 ? count : 1024), dim3(64), 0, st, d, c, base);
         }
-        if (lane_side) PG_TRY(hipStreamWaitEvent(st, ls.side_done[2], 0));
         if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(count), dim3(64), 0, st, d, base);
     }
     for (int k = 0; k < 2; k++) {
@@ -236,7 +189,7 @@ static hipError_t render_one(const DevCtx &d, int env, hipStream_t stream) {  //
 const GameEntry *PG_CAT(game_entry_, PG_GAME)() {
     static const GameEntry e = {
         PG_GAME::GAME_ID,    launch_game<PG_GAME>,       render_one<PG_GAME>,     PG_GAME::ENT_CAP_T0, PG_GAME::ENT_CAP_T1,
-        PG_GAME::ENT_CAP_T2, game_grid_bytes<PG_GAME>(), GameLane<PG_GAME>::value, init_env_state<PG_GAME>,
+        PG_GAME::ENT_CAP_T2, game_grid_bytes<PG_GAME>(), init_env_state<PG_GAME>,
         GameHostTables<PG_GAME>::build,
     };
     return &e;

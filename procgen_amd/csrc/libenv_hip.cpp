@@ -159,8 +159,8 @@ struct VecGame {
     size_t small_bytes = 0;
     int *d_big_list[2] = {nullptr, nullptr};
     int *d_big_count[2] = {nullptr, nullptr};
-    int *d_reset_list = nullptr;   // envs whose episode the lane = env kernel ended this step (consumed by the reset kernel)
-    int *d_reset_count = nullptr;  // [2][MAX_CHUNKS], double-buffered by step parity (the lane kernel zeroes the next step's)
+    int *d_reset_list = nullptr;   // SPLIT_RESET games: envs whose episode a step kernel ended this step (consumed by the reset kernel)
+    int *d_reset_count = nullptr;  // [2][MAX_CHUNKS], double-buffered by step parity (a step kernel zeroes the next step's)
     uint8_t *d_route[2] = {nullptr, nullptr};
     void bind_routing() {  // double-buffered by step parity: this step reads [cur], fills [nxt]
         const int cur = (int)(step_count & 1), nxt = cur ^ 1;
@@ -348,7 +348,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
             HIP_CHECK(hipEventCreateWithFlags(&ev_lane[k], hipEventDisableTiming));
         }
         if (const char *o = getenv("PROCGEN_AMD_ORDER")) order = atoi(o);
-        if (game_has_lane(kernel_id) || order != 0) HIP_CHECK(hipStreamCreateWithFlags(&side_stream[0], hipStreamNonBlocking));  // four streams at most (hardware queues)
+        if (order != 0) HIP_CHECK(hipStreamCreateWithFlags(&side_stream[0], hipStreamNonBlocking));  // four streams at most (hardware queues)
         for (int c = 0; c < MAX_CHUNKS; c++) HIP_CHECK(hipEventCreateWithFlags(&ev_step[c], hipEventDisableTiming));
         for (int k = 0; k < 3; k++) HIP_CHECK(hipEventCreateWithFlags(&ev_side[k], hipEventDisableTiming));
     }
@@ -368,14 +368,9 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     const size_t N = (size_t)num_envs;
     game_limits(kernel_id, &d.ent_cap, &d.grid_bytes);
     d.num_envs = num_envs;
-    // The lane = env step path (pg_env.h LANE_MODE) is opt-in (PROCGEN_AMD_LANE=1, games that have one): measured on the
-    // MI355X it does not beat the wave = env kernels yet, and its tile-interleaved entity table
-    // costs the wave = env kernels and the renderer their contiguous reads.
-    d.ent_tile = (game_has_lane(kernel_id) && getenv("PROCGEN_AMD_LANE") && atoi(getenv("PROCGEN_AMD_LANE")) != 0) ? TILE_ENVS : 1;
-    // reset lists follow the launch chunks (SPLIT_RESET games); the lane = env kernel is one launch over all tiles
-    d.reset_chunk_envs = d.ent_tile == TILE_ENVS ? chunk_envs_for(num_envs, 1) : chunk_envs_for(num_envs, chunks);
+    d.reset_chunk_envs = chunk_envs_for(num_envs, chunks);  // reset lists follow the launch chunks (SPLIT_RESET games)
     if (const char *f = getenv("PROCGEN_AMD_FIRST_PCT")) first_pct = atoi(f);
-    d.reset_first = (chunks == 2 && d.ent_tile != TILE_ENVS) ? first_chunk_envs(num_envs, first_pct) : 0;
+    d.reset_first = chunks == 2 ? first_chunk_envs(num_envs, first_pct) : 0;
     if (d.reset_first == 0) first_pct = 0;
     d.hdr = dev_alloc<EnvHdr>(N);
     d.rng = dev_alloc<uint32_t>(N * MT_SLOTS * MT_STRIDE);
@@ -420,9 +415,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         d.game_tables = d_game_tables;
     }
     d.debug_flags = getenv("PROCGEN_AMD_DEBUG") ? atoi(getenv("PROCGEN_AMD_DEBUG")) : 0;
-    d.lane_max_ents = getenv("PROCGEN_AMD_LANE_ENTS") ? atoi(getenv("PROCGEN_AMD_LANE_ENTS")) : LANE_MAX_ENTS;
-    d.lane_max_smart = getenv("PROCGEN_AMD_LANE_SMART") ? atoi(getenv("PROCGEN_AMD_LANE_SMART")) : LANE_MAX_SMART;
-    if (d.debug_flags & 2048) d.phase_cycles = dev_alloc<unsigned long long>(48 * 4096);
+    if (d.debug_flags & 2048) d.phase_cycles = dev_alloc<unsigned long long>(32 * 4096);
     HIP_CHECK(hipHostMalloc((void **)&h_action, N * 4 + 16, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_small, small_bytes + 16, hipHostMallocDefault));
 }
@@ -431,7 +424,7 @@ VecGame::~VecGame() {
     (void)hipSetDevice(device_id);
     if (stream) (void)hipStreamSynchronize(stream);
     if (d.phase_cycles) {  // PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step kernels, per env-step
-        std::vector<unsigned long long> raw(48 * 4096);
+        std::vector<unsigned long long> raw(32 * 4096);
         unsigned long long pc[32] = {0};
         const bool got = hipMemcpy(raw.data(), d.phase_cycles, raw.size() * 8, hipMemcpyDeviceToHost) == hipSuccess;
         for (size_t i = 0; i < 32 * 4096; i++) pc[i & 31] += raw[i];
@@ -442,21 +435,6 @@ VecGame::~VecGame() {
             for (int k = 0; k < 13; k++) {
                 const double denom = k == 6 ? (double)(pc[15] ? pc[15] : 1) : (double)pc[14];
                 fprintf(stderr, "  %-22s %10.1f\n", names[k], (double)pc[k] / denom);
-            }
-            unsigned long long lc[16] = {0};
-            for (size_t i = 32 * 4096; i < raw.size(); i++)
-                if ((i & 15) != 15) lc[i & 15] += raw[i];
-            if (lc[14] > 0) {  // lane = env kernel: cycles per WAVE-step (64 envs)
-                static const char *ln[13] = {"hdr + cache fill", "action+velocity", "step_entities (rest)", "collision_pass", "erase_if_needed", "game_step tail", "-", "-", "outputs+route+store",
-                                             " bso: setup", " bso: sub_steps", " se: find+plain ents", " se: smart ent_step"};
-                fprintf(stderr, "[lane = env kernel, cycles per wave-step (64 envs), %llu wave-steps]\n", lc[14]);
-                for (int k = 0; k < 13; k++) fprintf(stderr, "  %-22s %10.1f\n", ln[k], (double)lc[k] / (double)lc[14]);
-                fprintf(stderr, "  sub_step rounds per wave-step %.1f, of which with an entity hit in some lane %.1f\n", (double)lc[6] / (double)lc[14], (double)lc[7] / (double)lc[14]);
-                std::vector<unsigned long long> mx;
-                for (size_t i = 32 * 4096 + 15; i < raw.size(); i += 16)
-                    if (raw[i]) mx.push_back(raw[i]);
-                std::sort(mx.begin(), mx.end());
-                if (!mx.empty()) fprintf(stderr, "  slowest wave-step per wave slot (cycles): median %llu, p90 %llu, max %llu (%zu slots)\n", mx[mx.size() / 2], mx[mx.size() * 9 / 10], mx.back(), mx.size());
             }
             if (pc[31] > 0) {
                 static const char *rn[11] = {"set-up: pull tables", "clear + background", "entities z=-1", "grid cells", "entities z=0,1 + hud", "store band",
@@ -616,7 +594,7 @@ void VecGame::snapshot(int e, EnvSnapshot *s) {
     s->grid.resize(d.grid_bytes);
     HIP_CHECK(hipMemcpy(&s->hdr, d.hdr + e, sizeof(EnvHdr), hipMemcpyDeviceToHost));
     // one word per 256-byte row of the tile-interleaved table
-    HIP_CHECK(hipMemcpy2D(s->ents.data(), 4, d.ents + ent_tile_base(e, d.ent_cap, d.ent_tile), (size_t)d.ent_tile * 4, 4, (size_t)EF_COUNT * d.ent_cap, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(s->ents.data(), d.ents + ent_table_base(e, d.ent_cap), (size_t)EF_COUNT * d.ent_cap * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(s->rng.data(), d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, s->rng.size() * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(s->grid.data(), d.grid + (size_t)e * d.grid_bytes, s->grid.size(), hipMemcpyDeviceToHost));
 }
@@ -648,7 +626,7 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     // so restoring the same env several times, in any tier order, leaves exactly one entry for it
     const int tier = game_tier_for(kernel_id, 2 * s.hdr.n_ents + 4);
     s.hdr.big = tier;
-    HIP_CHECK(hipMemcpy2D(d.ents + ent_tile_base(e, d.ent_cap, d.ent_tile), (size_t)d.ent_tile * 4, s.ents.data(), 4, 4, (size_t)EF_COUNT * d.ent_cap, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.ents + ent_table_base(e, d.ent_cap), s.ents.data(), (size_t)EF_COUNT * d.ent_cap * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, s.rng.data(), s.rng.size() * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.grid + (size_t)e * d.grid_bytes, s.grid.data(), s.grid.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.hdr + e, &s.hdr, sizeof(EnvHdr), hipMemcpyHostToDevice));
@@ -1016,7 +994,7 @@ LIBENV_API void procgen_amd_selftest_sincos_scaled(const uint32_t *bits, int n, 
 }
 
 // average device time of one step's launch sequence -- exactly what libenv_act enqueues (VecGame::launch_kernels: counter
-// memset, list / lane / reset / step / render kernels, empty lists skipped) -- over the given number of rounds, measured
+// memset, list / reset / step / render kernels, empty lists skipped) -- over the given number of rounds, measured
 // with HIP events on the library's stream (bench.py roofline leg)
 LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const int32_t *actions_or_null) {
     VecGame *v = ((Handle *)handle)->single();

@@ -97,36 +97,20 @@ enum EntField : int {
     EF_COUNT
 };
 
-// The entity tables of 64 consecutive envs (one "tile") are interleaved in HBM: word (field, slot) of env e lives at
-//   ents[(((e / 64) * EF_COUNT + field) * ent_cap + slot) * 64 + e % 64].
-// The lane = env step kernel (one lane per env, one wave per tile) then reads a field of the same slot for its 64 envs
-// as one 256-byte access; the wave = env kernels (level generation, rendering) read a table at a 256-byte stride.
-constexpr int TILE_ENVS = 64;
+// One table per env in HBM, [field][slot] contiguous (lanes = slots when a kernel stages it).
+constexpr int TILE_ENVS = 64;  // env chunks are cut at multiples of this
 #if defined(__HIPCC__)
 #define PG_HOSTDEV __host__ __device__
 #else
 #define PG_HOSTDEV
 #endif
-// `tile` (DevCtx::ent_tile) is TILE_ENVS when the handle runs the lane = env kernel and 1 otherwise: one table per env,
-// [field][slot] contiguous, which is what the wave = env kernels and the renderer read fastest (lanes = slots).
-PG_HOSTDEV inline size_t ent_tile_base(int env, int ent_cap, int tile) {  // word index of (field 0, slot 0) of env
-    return (size_t)(env / tile) * EF_COUNT * (size_t)ent_cap * tile + (size_t)(env % tile);
-}
-PG_HOSTDEV inline size_t ent_word_index(int env, int ent_cap, int tile, int field, int slot) {
-    return ent_tile_base(env, ent_cap, tile) + ((size_t)field * ent_cap + slot) * tile;
-}
-inline size_t ent_table_words(int num_envs, int ent_cap) {  // allocation size (whole tiles, whatever the tile size)
-    return (size_t)((num_envs + TILE_ENVS - 1) / TILE_ENVS) * TILE_ENVS * EF_COUNT * (size_t)ent_cap;
-}
+PG_HOSTDEV inline size_t ent_table_base(int env, int ent_cap) { return (size_t)env * EF_COUNT * (size_t)ent_cap; }  // word index of (field 0, slot 0)
+inline size_t ent_table_words(int num_envs, int ent_cap) { return (size_t)num_envs * EF_COUNT * (size_t)ent_cap; }
 
-// values of the route table (which step kernel owns an env this step): 0..2 = wave = env kernel with LDS arena tier 0..2,
-// ROUTE_LANE = the lane = env physics kernel (games that declare HAS_LANE_STEP)
+// values of the route table (which step kernel owns an env this step): 0..2 = the kernel with LDS arena tier 0..2
 constexpr int MAX_CHUNKS = 8;
 constexpr int LIST_COUNTERS = MAX_CHUNKS * 3;  // [chunk][tier] (NUM_TIERS == 3)  // env chunks of one step (step of chunk c+1 overlaps the render of chunk c)
-constexpr int ROUTE_LANE = 3;
-constexpr int LANE_MAX_ENTS = 16;  // default routing bounds of the lane = env kernel (see pg_env.h GameLane)
-constexpr int LANE_MAX_SMART = 1;
-constexpr int ROUTE_RESET = 4;  // EnvHdr::big only: the lane kernel ended the episode, the reset kernel of the same step takes over
+constexpr int ROUTE_RESET = 4;  // EnvHdr::big only: a NO_RESET step kernel ended the episode, the reset kernel of the same step takes over
 
 // ---- sprite atlas in HBM ----
 struct ImgDesc {
@@ -152,8 +136,7 @@ struct DevCtx {
     // per-env state
     EnvHdr *hdr;          // [num_envs]
     uint32_t *rng;        // [num_envs][MT_SLOTS][MT_STRIDE]  (0: rand_gen, 1: level_seed_rand_gen, 2-3: scratch)
-    uint32_t *ents;       // [num_envs / ent_tile][EF_COUNT][ent_cap][ent_tile]  (ent_word_index)
-    int ent_tile;         // 1, or TILE_ENVS for handles that run the lane = env kernel
+    uint32_t *ents;       // [num_envs][EF_COUNT][ent_cap]
     int ent_cap;          // slots per env in HBM
     uint8_t *grid;        // [num_envs][grid_bytes]
     int grid_bytes;
@@ -182,7 +165,7 @@ struct DevCtx {
     // the three tiers run concurrently: an env re-routed by a fast kernel is not picked up again by a slower one)
     const uint8_t *route;  // [num_envs]
     uint8_t *next_route;   // [num_envs] written by every env's store_env
-    // envs the lane = env kernel stepped into `done`: the wave = env reset kernel of the same step generates their next level
+    // envs a NO_RESET step kernel (SPLIT_RESET games) stepped into `done`: the reset kernel of the same step generates their next level
     int reset_chunk_envs;   // envs per reset chunk: env e's reset goes to list chunk e / reset_chunk_envs ...
     int reset_first;        // ... unless > 0: two uneven chunks, [0, reset_first) and the rest (list chunk 1 starts at reset_first)
     int *reset_list;        // [num_envs]: the envs of chunk c are appended from index c * reset_chunk_envs on
@@ -190,7 +173,6 @@ struct DevCtx {
     int *next_reset_count;  // [MAX_CHUNKS] the next step's counters (double-buffered by step parity), zeroed by this step's lane kernel
     int *error;            // [1] OR of the per-env error codes raised this step (0 = none)
     unsigned long long *phase_cycles;  // [4096][32] PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step (0-15) and render (16-31) kernels (null otherwise)
-    int lane_max_ents, lane_max_smart;  // routing bounds of the lane = env kernel (pg_env.h LANE_MAX_ENTS / LANE_MAX_SMART; PROCGEN_AMD_LANE_ENTS / _SMART override them for tuning)
     int debug_flags;       // PROCGEN_AMD_DEBUG: phase ablation bits for profiling only (0 in normal operation)
 };
 

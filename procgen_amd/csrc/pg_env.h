@@ -115,18 +115,6 @@ constexpr int game_grid_bytes() {
     return game_cell_bytes<Game>() + GameAux<Game>::WORDS * 4;
 }
 
-// a game with a lane = env step path declares HAS_LANE_STEP = true and LANE_MAX_DRAWS, an upper bound of the rand_gen
-// draws one step can make without a reset
-template <class Game, class = void>
-struct GameLane {
-    static constexpr bool value = false;
-    static constexpr int MAX_DRAWS = MT_N + 1;
-};
-template <class Game>
-struct GameLane<Game, decltype((void)Game::HAS_LANE_STEP)> {
-    static constexpr bool value = Game::HAS_LANE_STEP;
-    static constexpr int MAX_DRAWS = Game::LANE_MAX_DRAWS;
-};
 // A game whose level generator needs much more LDS than its steps (scratch for maze / room generation, or an entity table
 // that only a reset fills) declares SPLIT_RESET = true and RESET_CAP: its step kernels are compiled without the generator
 // (Env NO_RESET: no scratch in their arena, smaller entity tiers), an episode that ends is queued, and the reset kernel
@@ -167,20 +155,6 @@ struct GameParSmart<Game, decltype((void)Game::PAR_SMART)> {
     static constexpr bool value = Game::PAR_SMART;
 };
 
-// the entity-table tile size of a handle of this game: a compile-time 1 for games without a lane = env path (their
-// kernels keep plain contiguous indexing), DevCtx::ent_tile otherwise
-template <class Game>
-PG_DEV int ent_tile_of(const DevCtx &d) {
-    if constexpr (GameLane<Game>::value) return d.ent_tile;
-    else return 1;
-}
-
-// A wave of the lane = env kernel takes as long as its heaviest env and the kernel as long as its slowest wave, so the
-// lane path only takes envs of bounded work: at most LANE_MAX_ENTS entities (all inside the LDS cache) of which at most
-// LANE_MAX_SMART are smart_step ones (each costs a basic_step_object).  The heavy tail (coinrun: 10 % of the env-steps,
-// up to 350 entities / 35 walking enemies) stays with the wave = env kernels, one workgroup each.
-// (the defaults LANE_MAX_ENTS / LANE_MAX_SMART live in pg_defs.h; DevCtx carries the values in use)
-
 // a game whose is_blocked has a side effect on the moving entity (ninja's throwing stars stick to walls) declares
 // HAS_BLOCK_HOOK and on_grid_block(e, obj): called when the corner probes of sub_step found a blocking cell
 template <class Game, class = void>
@@ -192,58 +166,7 @@ struct GameHasBlockHook<Game, decltype((void)Game::HAS_BLOCK_HOOK)> {
     static constexpr bool value = Game::HAS_BLOCK_HOOK;
 };
 
-// LDS of the lane = env kernel: the seven hot words of an entity (x, y, vx, vy, rx, ry, meta = EntField 0..6: what the
-// entity scans, the collision pass and the erase pass read) of the first LANE_CACHE_SLOTS slots of each of the wave's 64
-// envs, [field][slot][lane].  A dependent global access costs ~1 us per trip on this latency-bound kernel, an LDS
-// access ~0.05 us.  Slots beyond the cache stay in HBM; Env::ew picks per access (generic pointer -> flat load).
-constexpr int LANE_CACHE_FIELDS = 7;
-constexpr int LANE_CACHE_SLOTS = 16;
-static_assert(EF_META == LANE_CACHE_FIELDS - 1 && EF_X == 0, "the cached fields are the first enum values");
-// ... and, per lane, a LANE_WIN x LANE_WIN window of grid cells around the entity being stepped (Env::grid_window):
-// the corner probes of its sub_steps and its grid collisions read LDS instead of making one HBM trip each.
-constexpr int LANE_WIN = 8;
-constexpr int LANE_MAX_CAND = 8;
-template <class cell_t>
-struct LaneLds {
-    uint32_t c[LANE_CACHE_FIELDS * LANE_CACHE_SLOTS * TILE_ENVS];
-    cell_t win[LANE_WIN * LANE_WIN * TILE_ENVS];  // [cell of the window][lane]
-    // ... and the entities the object being stepped could touch during this step (Env::basic_step_object): its sub_steps
-    // test these few instead of walking the whole table
-    uint32_t cand[LANE_MAX_CAND * TILE_ENVS];
-};
-
-// an LDS pointer the compiler knows to be one (ds_read / ds_write instead of flat accesses through a generic pointer)
-#if defined(PGAMD_WAVE_EMU)
-#define PG_LDS_PTR(T) T *
-#else
-#define PG_LDS_PTR(T) __attribute__((address_space(3))) T *
-#endif
-
-// LANE_MODE: what ex(i), meta(i), ... return instead of a reference -- a handle that reads / writes the word where it
-// lives (this lane's LDS cache column for the hot words of the first slots, the HBM table otherwise), so that the game
-// policies' `e.evx(i) *= f` and `e.erx(j) > e.erx(ag)` compile to ds_read / global_load rather than flat accesses
-template <class T, class EnvT>
-struct LaneRef {
-    EnvT *e;
-    int field, i;
-    PG_DEV operator T() const { return __builtin_bit_cast(T, e->ldw(field, i)); }
-    PG_DEV T operator=(T v) const {
-        e->stw(field, i, __builtin_bit_cast(uint32_t, v));
-        return v;
-    }
-    PG_DEV T operator=(const LaneRef &o) const { return *this = (T)o; }
-    PG_DEV T operator+=(T v) const { return *this = (T)((T) * this + v); }
-    PG_DEV T operator-=(T v) const { return *this = (T)((T) * this - v); }
-    PG_DEV T operator*=(T v) const { return *this = (T)((T) * this * v); }
-    PG_DEV T operator|=(T v) const { return *this = (T)((T) * this | v); }
-    PG_DEV T operator&=(T v) const { return *this = (T)((T) * this & v); }
-};
-
-// memory ordering between two lane sections of one wave; nothing to order when a lane owns the whole env
-#define PG_SYNC_E()                      \
-    do {                                 \
-        if constexpr (!LANE) PG_SYNC();  \
-    } while (0)
+#define PG_SYNC_E() PG_SYNC()  // memory ordering between two lane sections of the wave that owns this env
 
 // WITH_SCRATCH = false: the arena of a step kernel that never generates a level (games with SPLIT_RESET, see GameSplit)
 template <class Game, int CAP, bool WITH_SCRATCH = true>
@@ -257,31 +180,18 @@ struct Lds {
 #endif
 };
 
-// LANE_MODE = false: one wavefront advances this env, state staged in the workgroup's LDS arena (`s`), lanes cover
-//   entity slots / cells (wave.h's lane sections and ballots).
-// LANE_MODE = true: ONE LANE advances this env (64 envs per wavefront, see run_lane / kernels_game.hip lane_step); the
-//   entity table and the grid are accessed in place in HBM (the tile-interleaved table makes a wave's 64 accesses to
-//   one slot contiguous), every loop over entities is the lane's own serial loop, and nothing in this mode may use a
-//   lane section or a ballot -- level generation (resets) is handed to the wave = env reset kernel.
-// NO_RESET (wave = env only): a step kernel of a SPLIT_RESET game -- like the lane kernel it stops where the episode ends.
-template <class Game, int CAP, bool LANE_MODE = false, bool NO_RESET_MODE = false>
+// One wavefront advances this env: state staged in the workgroup's LDS arena (`s`), lanes cover entity slots / cells (wave.h's
+// lane sections and ballots).
+// NO_RESET: a step kernel of a SPLIT_RESET game -- it stops where the episode ends and queues the env for the reset kernel.
+template <class Game, int CAP, bool NO_RESET_MODE = false>
 struct Env {
     using cell_t = typename Game::cell_t;
     static constexpr int CAPACITY = CAP;
-    static constexpr bool LANE = LANE_MODE;
     static constexpr bool NO_RESET = NO_RESET_MODE;
     typedef Lds<Game, CAP, !NO_RESET_MODE> LdsT;
     const DevCtx &d;
     const int env;
     LdsT *s;
-    uint32_t *lent;   // LANE: this env's (field 0, slot 0) word in the tile-interleaved HBM table
-    PG_LDS_PTR(uint32_t) lcache;  // LANE: this lane's column of the LDS entity cache (LaneLds)
-    PG_LDS_PTR(cell_t) lwin;      // LANE: this lane's column of the LDS grid window
-    PG_LDS_PTR(uint32_t) lcand;   // LANE: this lane's column of the candidate list
-    bool has_lds;                 // LANE: the three above are set
-    int ncand;                    // LANE: candidates of the object being stepped, ascending index; -1 = too many, walk the table
-    int win_x0, win_y0;  // its origin in the grid (INT_MIN/2: nothing loaded)
-    cell_t *lgrid;    // LANE: this env's grid cells in HBM
     EnvHdr G;
     // rand_gen bookkeeping: where the live 624-word state is (HBM home or LDS scratch)
     uint32_t *rg_home;
@@ -294,16 +204,12 @@ struct Env {
 
     // profiling aid (PROCGEN_AMD_DEBUG & 2048): wave cycles spent since the previous mark are charged to phase k
     long long t_mark = 0, t_start = 0;
-    bool needs_reset = false;  // LANE: this step ended the episode
-    int lane_smart_count = 0;  // LANE: smart_step entities met by step_entities
+    bool needs_reset = false;  // NO_RESET: this step ended the episode
     PG_DEV void phase(int k) {
 #if !defined(PGAMD_WAVE_EMU)
         if (d.phase_cycles) {
             const long long t = (long long)__builtin_readcyclecounter();
-            // (LANE: called where the wave's lanes have reconverged; its first active lane accounts for the wave)
-            const bool me = LANE ? PG_LANE_ID() == (int)__ffsll((long long)__ballot(1)) - 1 : PG_LANE_ID() == 0;
-            // (the lane kernel's counters follow the [4096][32] block of the wave = env kernels: [4096][16])
-            if (me && t_mark != 0) atomicAdd(d.phase_cycles + (LANE ? 32 * 4096 + k + 16 * ((env >> 6) & 4095) : k + 32 * (env & 4095)), (unsigned long long)(t - t_mark));
+            if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + k + 32 * (env & 4095), (unsigned long long)(t - t_mark));
             t_mark = (long long)__builtin_readcyclecounter();
         }
 #else
@@ -311,26 +217,7 @@ struct Env {
 #endif
     }
 
-    // profiling aid of the lane kernel (PROCGEN_AMD_DEBUG & 2048): per-wave event counters / maxima in the lane block of phase_cycles
-    PG_DEV void lane_count(int slot, unsigned long long v, bool is_max = false) {
-#if !defined(PGAMD_WAVE_EMU)
-        if constexpr (LANE) {
-            if (d.phase_cycles && PG_LANE_ID() == (int)__ffsll((long long)__ballot(1)) - 1) {
-                unsigned long long *p = d.phase_cycles + 32 * 4096 + slot + 16 * ((env >> 6) & 4095);
-                if (is_max) atomicMax(p, v);
-                else atomicAdd(p, v);
-            }
-        }
-#else
-        (void)slot; (void)v; (void)is_max;
-#endif
-    }
     PG_DEV Env(const DevCtx &d_, int env_, LdsT *s_) : d(d_), env(env_), s(s_) {
-        lent = LANE ? d.ents + ent_tile_base(env_, CAP, TILE_ENVS) : nullptr;  // (the lane kernel only runs on tile-interleaved tables)
-        has_lds = false;
-        ncand = -1;
-        win_x0 = win_y0 = -(1 << 30);
-        lgrid = LANE ? reinterpret_cast<cell_t *>(d.grid + (size_t)env_ * d.grid_bytes) : nullptr;
         rg_home = d.rng + (size_t)env * MT_SLOTS * MT_STRIDE;
         rg_cur = rg_home;
         rg_in_lds = false;
@@ -338,46 +225,16 @@ struct Env {
 
     // ======================================================================================================
     // entity table accessors (LDS SoA)
-    // one word of the entity table: where it lives depends on the mode (LDS arena / LDS cache column / HBM table)
-    PG_DEV uint32_t ldw(int field, int i) const {
-        if constexpr (LANE) {
-            if (field < LANE_CACHE_FIELDS && i < LANE_CACHE_SLOTS) return lcache[(field * LANE_CACHE_SLOTS + i) * TILE_ENVS];
-            return lent[(size_t)(field * CAP + i) * TILE_ENVS];
-        } else {
-            return s->ent[field * CAP + i];
-        }
-    }
-    PG_DEV void stw(int field, int i, uint32_t v) const {
-        if constexpr (LANE) {
-            if (field < LANE_CACHE_FIELDS && i < LANE_CACHE_SLOTS) lcache[(field * LANE_CACHE_SLOTS + i) * TILE_ENVS] = v;
-            else lent[(size_t)(field * CAP + i) * TILE_ENVS] = v;
-        } else {
-            s->ent[field * CAP + i] = v;
-        }
-    }
-    PG_DEV uint32_t &ew_hbm(int field, int i) { return lent[(size_t)(field * CAP + i) * TILE_ENVS]; }  // LANE
-    PG_DEV cell_t &cell(int idx) {
-        if constexpr (LANE) return lgrid[idx];
-        else return s->grid[idx];
-    }
-    PG_DEV decltype(auto) ef(int field, int i) {
-        if constexpr (LANE) return LaneRef<float, Env>{this, field, i};
-        else return (reinterpret_cast<float *>(s->ent)[field * CAP + i]);
-    }
-    PG_DEV decltype(auto) ei(int field, int i) {
-        if constexpr (LANE) return LaneRef<int, Env>{this, field, i};
-        else return (reinterpret_cast<int *>(s->ent)[field * CAP + i]);
-    }
-    PG_DEV decltype(auto) meta(int i) {
-        if constexpr (LANE) return LaneRef<uint32_t, Env>{this, (int)EF_META, i};
-        else return (s->ent[EF_META * CAP + i]);
-    }
-    PG_DEV decltype(auto) ex(int i) { return ef(EF_X, i); }
-    PG_DEV decltype(auto) ey(int i) { return ef(EF_Y, i); }
-    PG_DEV decltype(auto) evx(int i) { return ef(EF_VX, i); }
-    PG_DEV decltype(auto) evy(int i) { return ef(EF_VY, i); }
-    PG_DEV decltype(auto) erx(int i) { return ef(EF_RX, i); }
-    PG_DEV decltype(auto) ery(int i) { return ef(EF_RY, i); }
+    PG_DEV cell_t &cell(int idx) { return s->grid[idx]; }
+    PG_DEV float &ef(int field, int i) { return reinterpret_cast<float *>(s->ent)[field * CAP + i]; }
+    PG_DEV int &ei(int field, int i) { return reinterpret_cast<int *>(s->ent)[field * CAP + i]; }
+    PG_DEV uint32_t &meta(int i) { return s->ent[EF_META * CAP + i]; }
+    PG_DEV float &ex(int i) { return ef(EF_X, i); }
+    PG_DEV float &ey(int i) { return ef(EF_Y, i); }
+    PG_DEV float &evx(int i) { return ef(EF_VX, i); }
+    PG_DEV float &evy(int i) { return ef(EF_VY, i); }
+    PG_DEV float &erx(int i) { return ef(EF_RX, i); }
+    PG_DEV float &ery(int i) { return ef(EF_RY, i); }
     PG_DEV int etype(int i) { return meta_type(meta(i)); }
     PG_DEV bool eflag(int i, uint32_t f) { return (meta(i) & f) != 0; }
     PG_DEV void set_flag(int i, uint32_t f, bool v) { meta(i) = v ? (meta(i) | f) : (meta(i) & ~f); }
@@ -450,79 +307,11 @@ struct Env {
         ef(EF_ALPHA, i) = ef(EF_ALPHA_DECAY, i) * ef(EF_ALPHA, i);
     }
 
-    // Entity::step for the entities [lo, hi), none of them smart_step (LANE): four per round so that one memory round
-    // trip serves four entities; entities are independent of each other here
-    PG_DEV void ent_step_run(int lo, int hi) {
-        constexpr int B = 4;
-        for (int base = lo; base < hi; base += B) {
-            float x[B], y[B], vx[B], vy[B], rot[B], vrot[B], fr[B], gr[B], rx[B], ry[B], al[B], ad[B];
-            int lt[B], et[B];
-            uint32_t m[B];
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-                const int i = base + k < hi ? base + k : hi - 1;  // (a duplicate load of the last one instead of a branch)
-                x[k] = ex(i); y[k] = ey(i); vx[k] = evx(i); vy[k] = evy(i); rx[k] = erx(i); ry[k] = ery(i); m[k] = meta(i);
-                rot[k] = ef(EF_ROTATION, i); vrot[k] = ef(EF_VROT, i); fr[k] = ef(EF_FRICTION, i); gr[k] = ef(EF_GROW_RATE, i);
-                al[k] = ef(EF_ALPHA, i); ad[k] = ef(EF_ALPHA_DECAY, i); lt[k] = ei(EF_LIFE_TIME, i); et[k] = ei(EF_EXPIRE_TIME, i);
-            }
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-                const int i = base + k;
-                if (i < hi) {
-                    // (the same operations as ent_step; a value is stored only when its bits change -- most entities stand still)
-                    const float nx = x[k] + vx[k], ny = y[k] + vy[k], nrot = rot[k] + vrot[k], nvx = vx[k] * fr[k], nvy = vy[k] * fr[k];
-                    if (__builtin_bit_cast(uint32_t, nx) != __builtin_bit_cast(uint32_t, x[k])) ex(i) = nx;
-                    if (__builtin_bit_cast(uint32_t, ny) != __builtin_bit_cast(uint32_t, y[k])) ey(i) = ny;
-                    if (__builtin_bit_cast(uint32_t, nrot) != __builtin_bit_cast(uint32_t, rot[k])) ef(EF_ROTATION, i) = nrot;
-                    if (__builtin_bit_cast(uint32_t, nvx) != __builtin_bit_cast(uint32_t, vx[k])) evx(i) = nvx;
-                    if (__builtin_bit_cast(uint32_t, nvy) != __builtin_bit_cast(uint32_t, vy[k])) evy(i) = nvy;
-                    const int nlt = lt[k] + 1;
-                    ei(EF_LIFE_TIME, i) = nlt;
-                    uint32_t mm = m[k];
-                    if (et[k] > 0 && nlt > et[k]) mm |= MF_WILL_ERASE;
-                    if (meta_type(mm) == EXPLOSION) {
-                        const int it = meta_image_type(mm);
-                        if (it < EXPLOSION5) mm = (mm & ~(0xffu << M_IMG_SHIFT)) | ((uint32_t)(it + 1) << M_IMG_SHIFT);
-                    }
-                    if (mm != m[k]) meta(i) = mm;
-                    const float nrx = rx[k] * gr[k], nry = ry[k] * gr[k], nal = ad[k] * al[k];
-                    if (__builtin_bit_cast(uint32_t, nrx) != __builtin_bit_cast(uint32_t, rx[k])) erx(i) = nrx;
-                    if (__builtin_bit_cast(uint32_t, nry) != __builtin_bit_cast(uint32_t, ry[k])) ery(i) = nry;
-                    if (__builtin_bit_cast(uint32_t, nal) != __builtin_bit_cast(uint32_t, al[k])) ef(EF_ALPHA, i) = nal;
-                }
-            }
-        }
-    }
-
     // ======================================================================================================
     // grid (staged in LDS): reference src/grid.h, BAG:125-131,167-223
     PG_DEV bool grid_contains(int x, int y) { return 0 <= y && y < G.main_height && 0 <= x && x < G.main_width; }
-    // LANE: make the window cover the cells around (fx, fy) (at least 3 cells either side); reloaded only when it does not
-    PG_DEV void grid_window(float fx, float fy) {
-        if constexpr (LANE) {
-            if (!has_lds) return;
-            const int cx = (int)pg_floorf(fx), cy = (int)pg_floorf(fy);
-            if (cx - 3 >= win_x0 && cx + 3 < win_x0 + LANE_WIN && cy - 3 >= win_y0 && cy + 3 < win_y0 + LANE_WIN) return;
-            win_x0 = cx - LANE_WIN / 2;
-            win_y0 = cy - LANE_WIN / 2;
-            const int w = G.main_width, h = G.main_height;
-            cell_t v[LANE_WIN * LANE_WIN];
-#pragma unroll
-            for (int k = 0; k < LANE_WIN * LANE_WIN; k++) {  // all loads in flight together; cells outside the grid are never read back
-                const int x = win_x0 + (k % LANE_WIN), y = win_y0 + (k / LANE_WIN);
-                const bool in = 0 <= y && y < h && 0 <= x && x < w;
-                v[k] = lgrid[in ? y * w + x : 0];
-            }
-#pragma unroll
-            for (int k = 0; k < LANE_WIN * LANE_WIN; k++) lwin[k * TILE_ENVS] = v[k];
-        }
-    }
     PG_DEV int get_obj(int x, int y) {  // BAG:180-185
         if (!grid_contains(x, y)) return G.out_of_bounds_object;
-        if constexpr (LANE) {
-            const unsigned wx = (unsigned)(x - win_x0), wy = (unsigned)(y - win_y0);
-            if (wx < (unsigned)LANE_WIN && wy < (unsigned)LANE_WIN) return (int)lwin[(wy * LANE_WIN + wx) * TILE_ENVS];
-        }
         return (int)cell(y * G.main_width + x);
     }
     PG_DEV void set_obj(int x, int y, int v) {  // grid.h:54-57 (fassert on out-of-range)
@@ -531,10 +320,6 @@ struct Env {
             return;
         }
         cell(y * G.main_width + x) = (cell_t)v;
-        if constexpr (LANE) {
-            const unsigned wx = (unsigned)(x - win_x0), wy = (unsigned)(y - win_y0);
-            if (wx < (unsigned)LANE_WIN && wy < (unsigned)LANE_WIN) lwin[(wy * LANE_WIN + wx) * TILE_ENVS] = (cell_t)v;
-        }
         G.grid_dirty = 1;
     }
     PG_DEV int get_obj_from_floats(float i, float j) {  // BAG:167-174
@@ -641,16 +426,6 @@ struct Env {
         G.rand_idx = MT_N;
     }
     PG_DEV uint32_t rand_u32() {
-        if constexpr (LANE) {
-            // routing keeps envs whose generator could need a twist this step out of the lane kernel (Game::LANE_MAX_DRAWS)
-            if (G.rand_idx >= MT_N) {
-                fail(PGE_ASSERT);
-                return 0u;
-            }
-            const uint32_t z = rg_home[G.rand_idx];
-            G.rand_idx += 1;
-            return mt_temper(z);
-        }
         if (G.rand_idx >= MT_N) {
             uint32_t *dst = (rg_cur == mt_a()) ? mt_b() : mt_a();
             mt_twist(rg_cur, dst);
@@ -676,7 +451,6 @@ struct Env {
     // The next `count` (<= 32) rand_gen draws WITHOUT consuming them: lane l < count gets the l-th (tempered); false when they
     // would cross a twist (the caller then draws one at a time).  rand_skip consumes draws seen this way.
     PG_DEV bool rand_peek_lanes(int count, PG_LANE_REF(uint32_t, out)) {
-        static_assert(!LANE, "wave = env only");
         const int idx = G.rand_idx;
         if (idx + count > MT_N) return false;
         if (rc_buf != rg_cur || idx < rc_base || idx + count > rc_base + 64) {
@@ -853,41 +627,6 @@ struct Env {
     PG_DEV bool entity_scan(int obj, float _vx, float _vy, bool is_horizontal, int scan_axes, int otype, float orx, float ory) {
         bool block2 = false;
         const int n = ((scan_axes >> (is_horizontal ? 0 : 1)) & 1) ? G.n_ents : 0;
-        if constexpr (LANE) {  // the reference's own reverse loop (BAG:337-369), candidates filtered like the ballot below
-            // push_obj always moves `obj` itself (BAG:364), so the candidates of the object being stepped serve every depth;
-            // they are in ascending index order, the reference walks the list downwards
-            const int count = n == 0 ? 0 : (ncand >= 0 ? ncand : n);
-            for (int c = count - 1; c >= 0; c--) {
-                const int j = ncand >= 0 ? (int)lcand[c * TILE_ENVS] : c;
-                if (j == obj) continue;
-                const uint32_t mm = meta(j);
-                if ((mm & MF_WILL_ERASE) || !Game::may_interact(*this, otype, meta_type(mm), is_horizontal)) continue;
-                {
-                    const float tx = (orx + erx(j)) + POS_EPS;
-                    const float ty = (ory + ery(j)) + POS_EPS;
-                    if (!((pg_fabsf(ex(obj) - ex(j)) < tx) && (pg_fabsf(ey(obj) - ey(j)) < ty))) continue;
-                }
-                bool curr_block = false;
-                if (Game::is_blocked_ents(*this, obj, j, is_horizontal)) {
-                    curr_block = true;
-                } else if (Game::will_reflect(otype, etype(j))) {
-                    if (is_horizontal) {
-                        float delx = ex(j) - ex(obj);
-                        float rsum = erx(j) + orx;
-                        ex(obj) += _vx > 0 ? -2 * (rsum - delx) : 2 * (rsum + delx);
-                        evx(obj) = -1 * evx(obj);
-                    } else {
-                        float dely = ey(j) - ey(obj);
-                        float rsum = ery(j) + ory;
-                        ey(obj) += _vy > 0 ? -2 * (rsum - dely) : 2 * (rsum + dely);
-                        evy(obj) = -1 * evy(obj);
-                    }
-                }
-                if (curr_block) push_obj<DEPTH>(j, obj, is_horizontal, scan_axes);
-                block2 = block2 || curr_block;
-            }
-            return block2;
-        }
         for (int c = (n - 1) >> 6; c >= 0; c--) {
             int limit = 64;  // lanes >= limit of this chunk have been visited
             bool need_ballot = true;
@@ -1051,21 +790,7 @@ struct Env {
         // does the entity scan find anything at all?  (the same broad phase as entity_scan, from the register copy)
         const int n = ((scan_axes >> (is_horizontal ? 0 : 1)) & 1) ? G.n_ents : 0;
         bool any_hit = false;
-        if constexpr (LANE) {
-            // (only entities within this step's reach can be hit: the candidates collected by basic_step_object)
-            const int count = n == 0 ? 0 : (ncand >= 0 ? ncand : n);
-            for (int c = count - 1; c >= 0 && !any_hit; c--) {
-                const int idx = ncand >= 0 ? (int)lcand[c * TILE_ENVS] : c;
-                if (idx == obj) continue;
-                const uint32_t mm = meta(idx);
-                if (!(mm & MF_WILL_ERASE) && Game::may_interact(*this, otype, meta_type(mm), is_horizontal)) {
-                    const float tx = (orx + erx(idx)) + POS_EPS;
-                    const float ty = (ory + ery(idx)) + POS_EPS;
-                    any_hit = (pg_fabsf(nx - ex(idx)) < tx) && (pg_fabsf(ny - ey(idx)) < ty);
-                }
-            }
-        }
-        for (int c = LANE ? -1 : ((n - 1) >> 6); c >= 0 && !any_hit; c--) {
+        for (int c = (n - 1) >> 6; c >= 0 && !any_hit; c--) {
             const uint64_t m = PG_BALLOT(l, ({
                                              const int idx = (c << 6) + l;
                                              bool hit = false;
@@ -1082,9 +807,7 @@ struct Env {
             any_hit = m != 0;
         }
         if (block || reflect) R.eventful = true;
-        lane_count(6, 1);  // sub_step_top rounds of this wave
         if (!any_hit) return block;
-        lane_count(7, 1);  // ... in which some lane took the entity path
         R.eventful = true;
         obj_flush(obj, R);
         const bool block2 = entity_scan<0>(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory);
@@ -1097,66 +820,44 @@ struct Env {
     // it on a horizontal / vertical move lies within its reach (entity types do not change while it steps)
     PG_DEV int bso_scan_axes(int obj) {
         int scan_axes = 0;
-        if constexpr (LANE) {
-            // one pass: the axes on which some entity within this step's reach could block or reflect `obj`
-            const int otype = etype(obj);
-            const int n = G.n_ents;
+        const int otype = etype(obj);
+        const int n = G.n_ents;
+        for (int c = 0; c < ((n + 63) >> 6) && scan_axes != 3; c++) {
+            const uint64_t mh = PG_BALLOT(l, ((c << 6) + l) < n && ((c << 6) + l) != obj && Game::may_interact(*this, otype, etype((c << 6) + l), true));
+            const uint64_t mv = PG_BALLOT(l, ((c << 6) + l) < n && ((c << 6) + l) != obj && Game::may_interact(*this, otype, etype((c << 6) + l), false));
+            scan_axes |= (mh ? 1 : 0) | (mv ? 2 : 0);
+        }
+        if (scan_axes != 0) {
+            // no entity this object could interact with lies within its reach for this step (its own travel, < 1 cell of
+            // block snapping, < 2 of a reflection): the per-sub_step scans cannot find anything
             const float ox = ex(obj), oy = ey(obj), orx = erx(obj), ory = ery(obj);
             const float reach_x = pg_fabsf(evx(obj)) + 2.01f, reach_y = pg_fabsf(evy(obj)) + 2.01f;
-            ncand = has_lds ? 0 : -1;
-            for (int idx = 0; idx < n; idx++) {
-                if (idx == obj) continue;
-                const int t = etype(idx);
-                const int ax = (Game::may_interact(*this, otype, t, true) ? 1 : 0) | (Game::may_interact(*this, otype, t, false) ? 2 : 0);
-                if (ax != 0 && (pg_fabsf(ox - ex(idx)) < orx + erx(idx) + reach_x) && (pg_fabsf(oy - ey(idx)) < ory + ery(idx) + reach_y)) {
-                    scan_axes |= ax;
-                    if (ncand >= 0) {
-                        if (ncand < LANE_MAX_CAND) lcand[ncand++ * TILE_ENVS] = (uint32_t)idx;
-                        else ncand = -1;
-                    }
-                }
+            bool any = false;
+            for (int c = 0; c < ((n + 63) >> 6) && !any; c++) {
+                any = PG_BALLOT(l, ({
+                                    const int idx = (c << 6) + l;
+                                    bool near = false;
+                                    if (idx < n && idx != obj) {
+                                        const int t = etype(idx);
+                                        if (Game::may_interact(*this, otype, t, true) || Game::may_interact(*this, otype, t, false))
+                                            near = (pg_fabsf(ox - ex(idx)) < orx + erx(idx) + reach_x) && (pg_fabsf(oy - ey(idx)) < ory + ery(idx) + reach_y);
+                                    }
+                                    near;
+                                })) != 0;
             }
-        } else {
-            const int otype = etype(obj);
-            const int n = G.n_ents;
-            for (int c = 0; c < ((n + 63) >> 6) && scan_axes != 3; c++) {
-                const uint64_t mh = PG_BALLOT(l, ((c << 6) + l) < n && ((c << 6) + l) != obj && Game::may_interact(*this, otype, etype((c << 6) + l), true));
-                const uint64_t mv = PG_BALLOT(l, ((c << 6) + l) < n && ((c << 6) + l) != obj && Game::may_interact(*this, otype, etype((c << 6) + l), false));
-                scan_axes |= (mh ? 1 : 0) | (mv ? 2 : 0);
-            }
-            if (scan_axes != 0) {
-                // no entity this object could interact with lies within its reach for this step (its own travel, < 1 cell of
-                // block snapping, < 2 of a reflection): the per-sub_step scans cannot find anything
-                const float ox = ex(obj), oy = ey(obj), orx = erx(obj), ory = ery(obj);
-                const float reach_x = pg_fabsf(evx(obj)) + 2.01f, reach_y = pg_fabsf(evy(obj)) + 2.01f;
-                bool any = false;
-                for (int c = 0; c < ((n + 63) >> 6) && !any; c++) {
-                    any = PG_BALLOT(l, ({
-                                        const int idx = (c << 6) + l;
-                                        bool near = false;
-                                        if (idx < n && idx != obj) {
-                                            const int t = etype(idx);
-                                            if (Game::may_interact(*this, otype, t, true) || Game::may_interact(*this, otype, t, false))
-                                                near = (pg_fabsf(ox - ex(idx)) < orx + erx(idx) + reach_x) && (pg_fabsf(oy - ey(idx)) < ory + ery(idx) + reach_y);
-                                        }
-                                        near;
-                                    })) != 0;
-                }
-                if (!any) scan_axes = 0;
-            }
+            if (!any) scan_axes = 0;
         }
         return scan_axes;
     }
 
     PG_DEV void basic_step_object(int obj) {  // BAG:593-656
         if (eflag(obj, MF_WILL_ERASE)) return;
-        grid_window(ex(obj), ey(obj));
         const int scan_axes = bso_scan_axes(obj);
         bso_core<true>(obj, scan_axes);
     }
 
     // basic_step_object once the scan axes are known.  With scan_axes == 0 it reads and writes nothing but `obj`'s own
-    // words, the grid and scalars of G: wave = env kernels then run it for several objects at once, one LANE per object
+    // words, the grid and scalars of G: wave = env kernels then run it for several objects at once, one lane per object
     // (WAVE_UNIFORM = false: no profiling marks, which assume a uniform call).
     template <bool WAVE_UNIFORM>
     PG_DEV void bso_core(int obj, int scan_axes) {
@@ -1213,25 +914,6 @@ struct Env {
     // step_entities BAG:1086-1098: reverse order; runs of non-smart entities are stepped lane-parallel,
     // smart_step entities (agent, walkers) serially in their list position.
     PG_DEV void step_entities() {
-        if constexpr (LANE) {
-            // The reference order (i descending: basic_step_object of a smart entity, then Entity::step), shaped for a
-            // wave of 64 envs: every lane first finds its next smart entity, steps the plain entities above it four at
-            // a time (their loads in flight together), and then ALL lanes run their basic_step_object side by side --
-            // a loop that met smart entities at each lane's own iteration would run them one lane after the other.
-            int hi = G.n_ents;  // entities [hi, n) are done
-            while (hi > 0) {
-                int sidx = hi - 1;
-                while (sidx >= 0 && !(meta(sidx) & MF_SMART_STEP)) sidx--;
-                ent_step_run(sidx + 1, hi);
-                if (sidx >= 0) {
-                    lane_smart_count++;
-                    basic_step_object(sidx);
-                    ent_step(sidx);
-                }
-                hi = sidx;
-            }
-            return;
-        }
         const int n0 = G.n_ents;
         if constexpr (GameParSmart<Game>::value) {
             // Parallel pass.  A smart entity that no entity can block or reflect this step (scan axes 0) steps through the
@@ -1322,7 +1004,6 @@ struct Env {
 
     PG_DEV void check_grid_collisions(int ent) {  // BAG:145-165
         float ax = ex(ent), ay = ey(ent), arx = erx(ent), ary = ery(ent);
-        grid_window(ax, ay);
         int min_x = (int)(ax - (arx + POS_EPS));
         int max_x = (int)(ax + (arx + POS_EPS));
         int min_y = (int)(ay - (ary + POS_EPS));
@@ -1338,32 +1019,6 @@ struct Env {
     // smart_step) are found by ballot and visited from the highest index down; predicates are re-evaluated
     // at visit time, and the ballot is refreshed after every handler (handlers may change geometry).
     PG_DEV void collision_pass() {
-        if constexpr (LANE) {
-            int i = G.n_ents - 1;
-            while (i >= 0) {
-                // every lane skips ahead to its next entity with anything to do (overlap with the agent, collides_with_entities,
-                // smart_step); the handlers then run side by side in all lanes
-                while (i >= 0) {
-                    const uint32_t mq = meta(i);
-                    if ((mq & (MF_COLLIDES | MF_SMART_STEP)) != 0 || has_agent_collision(i)) break;
-                    i--;
-                }
-                if (i < 0) break;
-                if (has_agent_collision(i)) Game::handle_agent_collision(*this, i);
-                const uint32_t mi = meta(i);
-                if constexpr (Game::USES_ENTITY_COLLISIONS) {
-                    if (mi & MF_COLLIDES) {
-                        for (int j = G.n_ents - 1; j >= 0; j--) {
-                            if (j == i) continue;
-                            if (has_collision_idx(i, j, ef(EF_COLLISION_MARGIN, i)) && !eflag(i, MF_WILL_ERASE) && !eflag(j, MF_WILL_ERASE)) Game::handle_collision(*this, i, j);
-                        }
-                    }
-                }
-                if (mi & MF_SMART_STEP) check_grid_collisions(i);
-                i--;
-            }
-            return;
-        }
         int limit = G.n_ents;
         while (limit > 0) {
             const int n = G.n_ents;
@@ -1428,58 +1083,6 @@ struct Env {
 
     // erase_if_needed BAG:748-756: stable compaction of the SoA table, field by field through LDS scratch.
     PG_DEV void erase_if_needed() {
-        if constexpr (LANE) {
-            const int n = G.n_ents;
-            int first = 0;  // entities below the first erased one stay where they are
-            while (first < n) {
-                const uint32_t mm = meta(first);
-                if ((mm & MF_WILL_ERASE) || ((mm & MF_AUTO_ERASE) && is_out_of_bounds(first))) break;
-                first++;
-            }
-            int kept = first, new_agent = G.agent;
-            constexpr int B = 2;  // entities moved per round (their 21-word loads in flight together)
-            for (int base = first; base < n; base += B) {
-                bool mv[B];
-                int dst[B];
-#pragma unroll
-                for (int k = 0; k < B; k++) {
-                    const int i = base + k;
-                    mv[k] = false;
-                    dst[k] = kept;
-                    if (i < n) {
-                        const uint32_t mm = meta(i);
-                        const bool keep = !((mm & MF_WILL_ERASE) || ((mm & MF_AUTO_ERASE) && is_out_of_bounds(i)));
-                        if (i == G.agent) {
-                            if (keep) {
-                                new_agent = kept;
-                            } else {  // the detached agent stays readable in the reserved last slot
-                                for (int f = 0; f < EF_COUNT; f++) stw(f, CAP - 1, ldw(f, i));
-                                new_agent = CAP - 1;
-                            }
-                        }
-                        mv[k] = keep && kept != i;
-                        if (keep) kept++;
-                    }
-                }
-                uint32_t v[B][EF_COUNT];
-#pragma unroll
-                for (int k = 0; k < B; k++) {
-                    const int i = base + k < n ? base + k : n - 1;
-#pragma unroll
-                    for (int f = 0; f < EF_COUNT; f++) v[k][f] = ldw(f, i);
-                }
-#pragma unroll
-                for (int k = 0; k < B; k++) {
-                    if (mv[k]) {
-#pragma unroll
-                        for (int f = 0; f < EF_COUNT; f++) stw(f, dst[k], v[k][f]);
-                    }
-                }
-            }
-            G.n_ents = kept;
-            G.agent = new_agent;
-            return;
-        }
         const int n = G.n_ents;
         int kept = 0;
         int new_agent = G.agent;
@@ -1648,15 +1251,6 @@ struct Env {
     PG_DEV bool has_any_collision(int i, float margin) {
         const int n = G.n_ents;
         const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
-        if constexpr (LANE) {
-            for (int idx = 0; idx < n; idx++) {
-                if (meta(idx) & MF_AVOIDS) continue;
-                const float tx = (rx + erx(idx)) + margin;
-                const float ty = (ry + ery(idx)) + margin;
-                if ((pg_fabsf(x - ex(idx)) < tx) && (pg_fabsf(y - ey(idx)) < ty)) return true;
-            }
-            return false;
-        }
         for (int c = 0; c < ((n + 63) >> 6); c++) {
             const uint64_t m = PG_BALLOT(l, ({
                                              const int idx = (c << 6) + l;
@@ -1723,11 +1317,6 @@ struct Env {
 
     PG_DEV bool agent_has_collision() {  // BAG:521-529
         const int n = G.n_ents;
-        if constexpr (LANE) {
-            for (int idx = 0; idx < n; idx++)
-                if (has_agent_collision(idx)) return true;
-            return false;
-        }
         for (int c = 0; c < ((n + 63) >> 6); c++)
             if (PG_BALLOT(l, ((c << 6) + l) < n && has_agent_collision((c << 6) + l))) return true;
         return false;
@@ -1818,15 +1407,15 @@ struct Env {
             G.last_reward = G.reward;
         }
         G.prev_level_seed = G.current_level_seed;
-        // (what follows in Game::step -- the reset of a finished episode -- is finish_step's: level generation is
-        // wave-structured, so the lane = env kernel stops here and a finished episode goes to the reset kernel, run(2))
-        if constexpr (LANE || NO_RESET) needs_reset = G.done != 0;
+        // (what follows in Game::step -- the reset of a finished episode -- is finish_step's; a NO_RESET step kernel stops
+        // here and a finished episode goes to the reset kernel, run(2))
+        if constexpr (NO_RESET) needs_reset = G.done != 0;
     }
     // the rest of Game::step once game_step has run (reference src/game.cpp:144-155); initial = the reset + first
     // observation libenv_set_buffers asks for (reference src/vecgame.cpp:346-357).  One call site of the level
     // generator per kernel: the step kernels are sensitive to their code size (instruction cache).
     PG_DEV void finish_step(bool initial) {
-        if constexpr (!LANE && !NO_RESET) {
+        if constexpr (!NO_RESET) {
             if (initial || G.done) {
                 game_reset_full();
                 phase(6);
@@ -1863,21 +1452,13 @@ struct Env {
 
     // Game::observe minus the frame (reference src/game.cpp:160-164)
     PG_DEV void store_outputs() {
-        if constexpr (LANE) {
-            d.rew[env] = G.reward;
-            d.first[env] = (uint8_t)G.done;
-            d.prev_level_seed[env] = G.prev_level_seed;
-            d.prev_level_complete[env] = (uint8_t)G.level_complete;
-            d.level_seed[env] = G.current_level_seed;
-        } else {
-            PG_FOR_LANES(l) {
-                if (l == 0) {
-                    d.rew[env] = G.reward;
-                    d.first[env] = (uint8_t)G.done;
-                    d.prev_level_seed[env] = G.prev_level_seed;
-                    d.prev_level_complete[env] = (uint8_t)G.level_complete;
-                    d.level_seed[env] = G.current_level_seed;
-                }
+        PG_FOR_LANES(l) {
+            if (l == 0) {
+                d.rew[env] = G.reward;
+                d.first[env] = (uint8_t)G.done;
+                d.prev_level_seed[env] = G.prev_level_seed;
+                d.prev_level_complete[env] = (uint8_t)G.level_complete;
+                d.level_seed[env] = G.current_level_seed;
             }
         }
     }
@@ -1892,15 +1473,14 @@ struct Env {
 #undef PG_X
         }
         const int n = with_entities ? G.n_ents : 0;
-        const int tile = ent_tile_of<Game>(d);
-        const uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap, tile);
-        const uint32_t fstride = (uint32_t)d.ent_cap * (uint32_t)tile;  // words between two fields of one slot (one tile's table is < 2^31 words)
+        const uint32_t *ge = d.ents + ent_table_base(env, d.ent_cap);
+        const uint32_t fstride = (uint32_t)d.ent_cap;  // words between two fields of one slot
         for (int base = 0; base < n; base += 64) {
             PG_FOR_LANES(l) {
                 if (base + l < n) {
                     uint32_t v[EF_COUNT];  // all field loads in flight before the first LDS store (the loops must stay unrolled:
                                            // rolled, every load waits for the previous one)
-                    const uint32_t *gp = ge + (uint32_t)(base + l) * (uint32_t)tile;
+                    const uint32_t *gp = ge + (uint32_t)(base + l);
                     _Pragma("unroll") for (int f = 0; f < EF_COUNT; f++) v[f] = gp[f * fstride];
                     _Pragma("unroll") for (int f = 0; f < EF_COUNT; f++) s->ent[f * CAP + base + l] = v[f];
                 }
@@ -1921,14 +1501,13 @@ struct Env {
     }
     PG_DEV void store_env() {
         const int n = G.n_ents;
-        const int tile = ent_tile_of<Game>(d);
-        uint32_t *ge = d.ents + ent_tile_base(env, d.ent_cap, tile);
+        uint32_t *ge = d.ents + ent_table_base(env, d.ent_cap);
         if (n > d.ent_cap - 1) fail(PGE_ENT_OVERFLOW);
-        const uint32_t fstride = (uint32_t)d.ent_cap * (uint32_t)tile;
+        const uint32_t fstride = (uint32_t)d.ent_cap;
         for (int base = 0; base < n; base += 64) {
             PG_FOR_LANES(l) {
                 if (base + l < n && base + l < d.ent_cap) {
-                    uint32_t *gp = ge + (uint32_t)(base + l) * (uint32_t)tile;
+                    uint32_t *gp = ge + (uint32_t)(base + l);
                     _Pragma("unroll") for (int f = 0; f < EF_COUNT; f++) gp[f * fstride] = s->ent[f * CAP + base + l];
                 }
             }
@@ -1958,39 +1537,17 @@ struct Env {
         }
     }
 
-    // which step kernel owns this env next step (EnvHdr::big -> route table)
+    // which step kernel owns this env next step (EnvHdr::big -> route table): the smallest LDS arena its table fits
     PG_DEV void decide_route() {
-        bool lane_ok = false;
-        if constexpr (GameLane<Game>::value) {
-            // the lane = env kernel cannot twist a generator: it takes an env only while the draws of one step are
-            // certain to come from the current 624-word block (PROCGEN_AMD_DEBUG & 4096 keeps every env on the wave = env kernels)
-            lane_ok = d.ent_tile == TILE_ENVS && G.rand_idx + GameLane<Game>::MAX_DRAWS <= MT_N && !(d.debug_flags & 4096) && G.n_ents <= d.lane_max_ents;
-            if (lane_ok) {
-                int smart = 0;
-                if constexpr (LANE) {
-                    smart = lane_smart_count;  // counted by step_entities
-                } else {
-                    const int n = G.n_ents;
-                    for (int c = 0; c < ((n + 63) >> 6); c++) smart += pg_popc64(PG_BALLOT(l, ((c << 6) + l) < n && (meta((c << 6) + l) & MF_SMART_STEP) != 0));
-                }
-                lane_ok = smart <= d.lane_max_smart;
-            }
-        }
-        if (LANE && lane_ok) {  // table growth is checked where entities are added (HBM capacity)
-            G.big = ROUTE_LANE;
-            return;
-        }
         const int need = Game::slots_needed_next_step(*this);  // entity slots incl. growth of one step + the reserved one
-        int tier = need <= Game::ENT_CAP_T0 ? 0 : (need <= Game::ENT_CAP_T1 ? 1 : 2);
         if (need > Game::ENT_CAP_T2) fail(PGE_ENT_OVERFLOW);
-        if constexpr (GameLane<Game>::value) tier = lane_ok ? ROUTE_LANE : tier;
-        G.big = tier;
+        G.big = need <= Game::ENT_CAP_T0 ? 0 : (need <= Game::ENT_CAP_T1 ? 1 : 2);
     }
 
     // hand this env (its episode just ended, its header is stored) to the reset kernel of its chunk
     PG_DEV void queue_reset() {
 #if !defined(PGAMD_WAVE_EMU)
-        if (LANE || PG_LANE_ID() == 0) {
+        if (PG_LANE_ID() == 0) {
             if (G.error) atomicOr(d.error, G.error);
             const int c = d.reset_first > 0 ? (env >= d.reset_first ? 1 : 0) : env / d.reset_chunk_envs;
             const size_t base = d.reset_first > 0 ? (c ? (size_t)d.reset_first : 0) : (size_t)c * d.reset_chunk_envs;
@@ -2004,7 +1561,7 @@ struct Env {
 #if defined(PGAMD_WAVE_EMU)
         if (G.error && d.error) *d.error |= G.error;
 #else
-        if (LANE || PG_LANE_ID() == 0) {
+        if (PG_LANE_ID() == 0) {
             if (d.next_route) d.next_route[env] = (uint8_t)G.big;
             if (G.big == 1 || G.big == 2) {
                 const int t = G.big, c = env / d.chunk_envs;
@@ -2016,8 +1573,8 @@ struct Env {
 #endif
     }
 
-    // wave = env: one libenv step (mode 1), the initial reset + first observation (mode 0), or the reset that finishes
-    // a step the lane = env kernel took up to the end of the episode (mode 2) of this env
+    // one libenv step (mode 1), the initial reset + first observation (mode 0), or the reset that finishes a step a NO_RESET
+    // step kernel took up to the end of the episode (mode 2) of this env
     PG_DEV void run(int mode) {
 #if !defined(PGAMD_WAVE_EMU)
         if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
@@ -2055,78 +1612,6 @@ struct Env {
 #if !defined(PGAMD_WAVE_EMU)
         if (d.phase_cycles && mode != 0 && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 14 + 32 * (env & 4095), 1ull);
 #endif
-    }
-
-    // lane = env: one libenv step of this lane's env.  Game state is read and written in place in HBM; an episode
-    // that ends is queued for the wave = env reset kernel launched behind this one (run(2)).
-    PG_DEV void run_lane(int chunk, int chunk_base) {
-        static_assert(LANE, "run_lane is the lane = env entry point");
-        {
-            const EnvHdr *h = d.hdr + env;
-#define PG_X(type, name) G.name = h->name;
-            PG_HDR_FIELDS(PG_X)
-#undef PG_X
-        }
-        G.grid_dirty = 0;
-        G.action = d.action[env];
-#if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles) t_mark = t_start = (long long)__builtin_readcyclecounter();
-#endif
-        if (has_lds) {  // hot words of the first slots -> this lane's LDS column (all loads of a round in flight together)
-            const int nc = G.n_ents < LANE_CACHE_SLOTS ? G.n_ents : LANE_CACHE_SLOTS;
-            for (int base = 0; base < nc; base += 4) {
-                uint32_t v[4][LANE_CACHE_FIELDS];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int i = base + k < nc ? base + k : nc - 1;
-#pragma unroll
-                    for (int f = 0; f < LANE_CACHE_FIELDS; f++) v[k][f] = ew_hbm(f, i);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (base + k < nc) {
-#pragma unroll
-                        for (int f = 0; f < LANE_CACHE_FIELDS; f++) lcache[(f * LANE_CACHE_SLOTS + base + k) * TILE_ENVS] = v[k][f];
-                    }
-                }
-            }
-        }
-        phase(0);
-        game_step_full();
-        if (!needs_reset) finish_step(false);
-        if (has_lds && !needs_reset) {  // ... and back (a reset starts from an empty table)
-            const int nc = G.n_ents < LANE_CACHE_SLOTS ? G.n_ents : LANE_CACHE_SLOTS;
-            for (int i = 0; i < nc; i++) {
-#pragma unroll
-                for (int f = 0; f < LANE_CACHE_FIELDS; f++) ew_hbm(f, i) = lcache[(f * LANE_CACHE_SLOTS + i) * TILE_ENVS];
-            }
-        }
-        if (needs_reset) {
-            G.big = ROUTE_RESET;  // (the reset kernel's store_env decides the next route)
-        } else {
-            prepare_for_drawing((float)RES_H);
-            store_outputs();
-            if (G.agent < 0 || G.agent >= G.n_ents) fail(PGE_ASSERT);
-            decide_route();
-            publish_routing();
-        }
-        {
-            EnvHdr *h = d.hdr + env;
-#define PG_X(type, name) h->name = G.name;
-            PG_HDR_FIELDS(PG_X)
-#undef PG_X
-        }
-        phase(8);
-#if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles) {
-            lane_count(14, 1);
-            lane_count(15, (unsigned long long)((long long)__builtin_readcyclecounter() - t_start), true);  // slowest wave-step of this wave slot
-            lane_count(13, (unsigned long long)lane_smart_count);  // (of the accounting lane)
-        }
-#endif
-        (void)chunk;
-        (void)chunk_base;
-        if (needs_reset) queue_reset();
     }
 };
 

@@ -180,13 +180,12 @@ struct Renderer {
     uint32_t *ax;  // tile-axis scratch (see setup_tile_axes)
     EnvHdr G;
     const uint32_t *ge;  // this env's entity table in HBM
-    int ecap, etile;
+    int ecap;
     const typename Game::cell_t *gg;
     int row0, row1;  // band rows [row0, row1)
 
     PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(lds_->ax) {
-        etile = ent_tile_of<Game>(d);  // (tile-interleaved table: consecutive slots are etile words apart)
-        ge = d.ents + ent_tile_base(env, d.ent_cap, etile);
+        ge = d.ents + ent_table_base(env, d.ent_cap);
         ecap = d.ent_cap;
         gg = reinterpret_cast<const typename Game::cell_t *>(d.grid + (size_t)env * d.grid_bytes);
         row0 = 0;
@@ -194,12 +193,8 @@ struct Renderer {
     }
 
     // entity accessors with the names the game policies use (HBM reads; the table was written by the step kernel)
-    PG_DEV int tile_() const {
-        if constexpr (GameLane<Game>::value) return etile;
-        else return 1;
-    }
-    PG_DEV float ef(int field, int i) const { return __builtin_bit_cast(float, ge[(uint32_t)(field * ecap + i) * (uint32_t)tile_()]); }
-    PG_DEV uint32_t meta(int i) const { return ge[(uint32_t)(EF_META * ecap + i) * (uint32_t)tile_()]; }
+    PG_DEV float ef(int field, int i) const { return __builtin_bit_cast(float, ge[(uint32_t)(field * ecap + i)]); }
+    PG_DEV uint32_t meta(int i) const { return ge[(uint32_t)(EF_META * ecap + i)]; }
     PG_DEV float ex(int i) const { return ef(EF_X, i); }
     PG_DEV float ey(int i) const { return ef(EF_Y, i); }
     PG_DEV float evx(int i) const { return ef(EF_VX, i); }

@@ -34,12 +34,6 @@ inline int &pg_emu_lane() {
     static thread_local int lane = -1;
     return lane;
 }
-// set by the harness while it runs a lane = env kernel body (pg_env.h LANE_MODE): there a lane owns its env, and a lane
-// section or ballot (which would span 64 different envs on the device) is a bug the CPU tests must catch
-inline bool &pg_emu_in_lane_kernel() {
-    static thread_local bool v = false;
-    return v;
-}
 // event counters the harness reads back (which code paths a test really took); slot 0: objects stepped by the parallel pass
 inline long long *pg_emu_counters() {
     static long long c[8] = {0};
@@ -47,12 +41,7 @@ inline long long *pg_emu_counters() {
 }
 struct PgEmuLaneScope {
     int saved;
-    PgEmuLaneScope() : saved(pg_emu_lane()) {
-        if (pg_emu_in_lane_kernel()) {
-            fprintf(stderr, "wave.h: lane section / ballot used inside a lane = env kernel\n");
-            abort();
-        }
-    }
+    PgEmuLaneScope() : saved(pg_emu_lane()) {}
     ~PgEmuLaneScope() { pg_emu_lane() = saved; }
 };
 #define PG_FOR_LANES(l) \

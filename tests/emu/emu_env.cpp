@@ -37,7 +37,7 @@ struct EmuVec {
     int dev_error = 0;
     int game_id = -1;
     int kernel_id = -1;
-    long long lane_steps = 0, lane_resets = 0, wave_steps = 0, split_resets = 0;  // which execution model stepped the envs (tests assert both ran)
+    long long wave_steps = 0, split_resets = 0;  // env-steps taken, and how many of them went on to the reset kernel (SPLIT_RESET games)
 };
 
 template <class Game, int CAP>
@@ -51,7 +51,7 @@ template <class Game, int CAP>
 static void run_step_env(EmuVec *v, int env) {
     if constexpr (GameSplit<Game>::value) {
         static Lds<Game, CAP, false> lds;
-        Env<Game, CAP, false, true> e(v->d, env, &lds);
+        Env<Game, CAP, true> e(v->d, env, &lds);
         e.run(1);
         if (v->hdr[env].big == ROUTE_RESET) {
             v->split_resets++;
@@ -66,30 +66,6 @@ template <class Game>
 static void run_all(EmuVec *v, int mode) {
     for (int e = 0; e < v->n; e++) {  // "step kernels"
         int tier = v->use_small ? v->hdr[e].big : 2;
-        if constexpr (GameLane<Game>::value) {
-            // "lane_step": the env's lane runs the step in place on the HBM arrays; an ended episode goes to "reset_list"
-            // (use_small = 0 keeps every env on the wave = env kernels, like PROCGEN_AMD_DEBUG & 4096 on the device)
-            if (mode == 1 && tier == ROUTE_LANE) {
-                pg_emu_in_lane_kernel() = true;
-                {
-                    static LaneLds<typename Game::cell_t> cache;  // the lane's LDS columns (lane = env index within its tile)
-                    Env<Game, Game::ENT_CAP_T2, true> le(v->d, e, nullptr);
-                    le.lcache = cache.c + (e % TILE_ENVS);
-                    le.lwin = cache.win + (e % TILE_ENVS);
-                    le.lcand = cache.cand + (e % TILE_ENVS);
-                    le.has_lds = true;
-                    le.run_lane(0, 0);
-                }
-                pg_emu_in_lane_kernel() = false;
-                v->lane_steps++;
-                if (v->hdr[e].big == ROUTE_RESET) {
-                    v->lane_resets++;
-                    run_env<Game, Game::ENT_CAP_T0>(v, e, 2);
-                }
-                continue;
-            }
-            if (tier == ROUTE_LANE) tier = 0;  // (mode 0: everything starts in the tier-0 grid)
-        }
         if (mode == 1) {
             v->wave_steps++;
             if (tier == 0) run_step_env<Game, Game::ENT_CAP_T0>(v, e);
@@ -110,7 +86,7 @@ extern "C" {
 
 void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, int num_levels, int start_level, int distribution_mode,
                int center_agent, int use_backgrounds, int restrict_themes, int use_sequential_levels, int debug_mode, const char *resource_root,
-               const char *atlas_path, int use_small, int use_monochrome_assets, int paint_vel_info, int lane) {
+               const char *atlas_path, int use_small, int use_monochrome_assets, int paint_vel_info) {
     EmuVec *v = new EmuVec();
     v->n = num_envs;
     v->use_small = use_small;
@@ -170,16 +146,6 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.chunk_envs = (num_envs + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;
     d.reset_chunk_envs = d.chunk_envs;
     d.reset_first = 0;
-    // lane = 0: per-env contiguous entity tables, no lane = env routing (the product's default); games without a lane = env
-    // path always use them (ent_tile_of)
-    d.ent_tile = 1;
-#define PG_X(Game) \
-    if (gid == Game::GAME_ID && lane && GameLane<Game>::value) d.ent_tile = TILE_ENVS;
-    PG_FOR_EACH_GAME(PG_X)
-#undef PG_X
-    d.lane_max_ents = getenv("PROCGEN_AMD_LANE_ENTS") ? atoi(getenv("PROCGEN_AMD_LANE_ENTS")) : LANE_MAX_ENTS;
-    d.lane_max_smart = getenv("PROCGEN_AMD_LANE_SMART") ? atoi(getenv("PROCGEN_AMD_LANE_SMART")) : LANE_MAX_SMART;
-    if (!use_small) d.debug_flags |= 4096;  // no lane = env routing either: every env on the largest wave = env arena  // e.g. 1024: renderer without the pull form (per-cell blits)
     level_seed_range(num_levels, start_level, &d.opt.level_seed_low, &d.opt.level_seed_high);
     d.hdr = v->hdr.data();
     d.rng = v->rng.data();
@@ -234,7 +200,7 @@ static void emu_snapshot(EmuVec *v, int env, EnvSnapshot *s) {
     s->hdr = v->hdr[env];
     s->ent_cap = cap;
     s->ents.resize((size_t)EF_COUNT * cap);
-    for (int k = 0; k < EF_COUNT * cap; k++) s->ents[k] = v->ents[ent_tile_base(env, cap, v->d.ent_tile) + (size_t)k * v->d.ent_tile];
+    for (int k = 0; k < EF_COUNT * cap; k++) s->ents[k] = v->ents[ent_table_base(env, cap) + (size_t)k];
     s->rng.assign(v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE, v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE + 2 * MT_STRIDE);
     s->grid.assign(v->grid.begin() + (size_t)env * v->d.grid_bytes, v->grid.begin() + (size_t)(env + 1) * v->d.grid_bytes);
 }
@@ -263,7 +229,7 @@ int emu_set_state(void *h, int env, const char *data, int length) {
     s.hdr.big = 2;  // the emulation picks the arena from this field alone; the largest arena is always safe
     const int cap = v->d.ent_cap;
     v->hdr[env] = s.hdr;
-    for (int k = 0; k < EF_COUNT * cap; k++) v->ents[ent_tile_base(env, cap, v->d.ent_tile) + (size_t)k * v->d.ent_tile] = s.ents[k];
+    for (int k = 0; k < EF_COUNT * cap; k++) v->ents[ent_table_base(env, cap) + (size_t)k] = s.ents[k];
     std::copy(s.rng.begin(), s.rng.end(), v->rng.begin() + (size_t)env * MT_SLOTS * MT_STRIDE);
     std::copy(s.grid.begin(), s.grid.end(), v->grid.begin() + (size_t)env * v->d.grid_bytes);
     v->rew[env] = s.hdr.reward;
@@ -307,8 +273,8 @@ void emu_qt_path_ellipse(double x, double y, double w, double h, int pen, int br
 long long emu_counter(int k) { return pg_emu_counters()[k]; }
 void emu_path_counts(void *h, long long *out) {
     EmuVec *v = (EmuVec *)h;
-    out[0] = v->lane_steps;
-    out[1] = v->lane_resets;
+    out[0] = 0;
+    out[1] = 0;
     out[2] = v->wave_steps;
     out[3] = v->split_resets;
 }
@@ -319,8 +285,8 @@ int emu_is_big(void *h, int env) { return ((EmuVec *)h)->hdr[env].big; }
 void emu_dump_entities(void *h, int env, int32_t *out) {
     EmuVec *v = (EmuVec *)h;
     const int cap = v->d.ent_cap;
-    const uint32_t *e = v->ents.data() + ent_tile_base(env, cap, v->d.ent_tile);
-    const int tile = v->d.ent_tile;
+    const uint32_t *e = v->ents.data() + ent_table_base(env, cap);
+    const int tile = 1;
     auto W = [&](int f, int i) { return (int32_t)e[(size_t)(f * cap + i) * tile]; };
     for (int i = 0; i < v->hdr[env].n_ents; i++) {
         int32_t *o = out + 31 * i;

@@ -14,17 +14,16 @@ import oracle_env
 from helpers import action_stream, assert_rollouts_equal, check_against_option_matrix, rollout
 
 
-def test_default_layout_per_env_contiguous_tables():
-    """The product's default (no PROCGEN_AMD_LANE): per-env contiguous entity tables (DevCtx::ent_tile = 1), no lane = env routing."""
+def test_rollout_and_state_round_trip_through_the_emulated_kernels():
+    """coinrun through the emulated kernels against the oracle, then get_state / set_state into a handle with another seed."""
     n, steps = 8, 200
     acts = action_stream(n, steps, seed=3)
     a = rollout(oracle_env.OracleEnv(n, "coinrun", rand_seed=23), acts)
-    emu = emu_harness.EmuEnv(n, "coinrun", rand_seed=23, lane=False)
+    emu = emu_harness.EmuEnv(n, "coinrun", rand_seed=23)
     b = rollout(emu, acts)
-    assert_rollouts_equal(a, b, "tile = 1")
-    assert emu.path_counts()[0] == 0
+    assert_rollouts_equal(a, b, "coinrun")
     st = emu.get_state()
-    emu2 = emu_harness.EmuEnv(n, "coinrun", rand_seed=99, lane=False)
+    emu2 = emu_harness.EmuEnv(n, "coinrun", rand_seed=99)
     emu2.set_state(st)
     assert emu2.get_state() == st
 
@@ -63,21 +62,18 @@ def noop_heavy_actions(n, steps, seed, p_noop=0.97):
 
 
 @pytest.mark.parametrize("game,steps", [("coinrun", 1100)])
-def test_lane_env_kernel_over_timeouts_twists_and_resets(game, steps):
-    """Games with a lane = env step path (pg_env.h LANE_MODE): a rollout long enough that episodes reach their timeout,
-    rand_gen crosses a 624-word block (those steps fall back to the wave = env kernel, which can twist) and the reset
-    kernel takes over episodes the lane kernel ended -- bit-exact against the oracle, with all three paths exercised."""
+def test_long_horizon_over_timeouts_and_generator_twists(game, steps):
+    """A rollout long enough that episodes reach their timeout and rand_gen crosses a 624-word block (a twist inside a plain
+    step) -- bit-exact against the oracle, entity tables and grids included."""
     n = 8
     acts = noop_heavy_actions(n, steps, seed=21)
     orc = oracle_env.OracleEnv(n, game, rand_seed=23)
     emu = emu_harness.EmuEnv(n, game, rand_seed=23)
     a = rollout(orc, acts)
     b = rollout(emu, acts)
-    assert_rollouts_equal(a, b, f"lane path, long horizon ({game})")
+    assert_rollouts_equal(a, b, f"long horizon ({game})")
     for e in range(n):
         assert np.array_equal(orc.entities(e), emu.entities(e)) and np.array_equal(orc.grid(e), emu.grid(e))
-    lane, lane_resets, wave, _ = emu.path_counts()
-    assert lane > 0.25 * n * steps and lane_resets > 0 and wave > 0, (lane, lane_resets, wave)
     assert a["first"][1000:1002].any(), "an episode must have ended by timeout"
 
 
@@ -91,7 +87,7 @@ def test_independent_smart_entities_are_stepped_side_by_side():
     n, steps = 48, 300
     acts = action_stream(n, steps, seed=19)
     orc = oracle_env.OracleEnv(n, "coinrun", rand_seed=99)
-    emu = emu_harness.EmuEnv(n, "coinrun", rand_seed=99, lane=False)
+    emu = emu_harness.EmuEnv(n, "coinrun", rand_seed=99)
     for t in range(steps):
         orc.act(acts[t])
         emu.act(acts[t])
