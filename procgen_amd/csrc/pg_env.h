@@ -144,8 +144,14 @@ struct GameHostTables<Game, decltype((void)Game::HOST_TABLE_WORDS)> {
 
 // A game declares PAR_SMART = true and par_smart_type_ok(type) for the smart_step entity types (a) whose basic_step_object
 // has no side effect beyond the object itself when no entity can block or reflect it, and (b) that no smart entity's
-// sub_step scan can ever hit (may_interact(any smart type, type) is false): the wave = env step_entities then steps all
-// such objects of an env at once, one lane per object, instead of one after the other (Env::step_entities).
+// sub_step scan can ever hit (may_interact(any smart type, type) is false): step_entities then steps all such objects of an
+// env side by side instead of one after the other (Env::step_entities).  (c) The pass decides "nothing can block or reflect
+// this object" (bso_scan_axes == 0) BEFORE anyone has moved, whereas the reference reaches object i after the entities above
+// it have stepped: the reach test therefore allows for the target's own travel (|v|, plus the snapping / reflection slack
+// when the target is a smart entity).  Blockers are never displaced by a push (push_obj moves the MOVER out of the blocker,
+// BAG:240-268), and entities are only spawned after step_entities, so a target's motion within the step is bounded by that.
+// Per game: coinrun (crates, ENEMY_BARRIER), climber, ninja, dodgeball, chaser, caveflyer -- every blocking / reflecting
+// target of their parallel types has zero velocity; the widened reach is what keeps a future game with moving blockers exact.
 template <class Game, class = void>
 struct GameParSmart {
     static constexpr bool value = false;
@@ -819,40 +825,253 @@ struct Env {
     // which axes of `obj` need the entity scan of sub_step at all this step: bit 0 / 1 = some entity that could block or reflect
     // it on a horizontal / vertical move lies within its reach (entity types do not change while it steps)
     PG_DEV int bso_scan_axes(int obj) {
-        int scan_axes = 0;
         const int otype = etype(obj);
         const int n = G.n_ents;
+        // Does any entity this object could interact with lie within its reach for this step (its own travel, < 1 cell of
+        // block snapping, < 2 of a reflection)?  If not -- the usual case -- the per-sub_step scans cannot find anything.
+        const float ox = ex(obj), oy = ey(obj), orx = erx(obj), ory = ery(obj);
+        const float reach_x = pg_fabsf(evx(obj)) + 2.01f, reach_y = pg_fabsf(evy(obj)) + 2.01f;
+        bool any = false;
+        for (int c = 0; c < ((n + 63) >> 6) && !any; c++) {
+            any = PG_BALLOT(l, ({
+                                const int idx = (c << 6) + l;
+                                bool near = false;
+                                if (idx < n && idx != obj) {
+                                    // (the target may itself move before `obj` meets it -- the reference steps higher indices
+                                    // first, the parallel pass asks before anyone has moved: its own travel widens the reach)
+                                    const uint32_t mt = meta(idx);
+                                    const float tsl = (mt & MF_SMART_STEP) ? 2.01f : 0.0f;
+                                    if ((pg_fabsf(ox - ex(idx)) < orx + erx(idx) + reach_x + (pg_fabsf(evx(idx)) + tsl)) && (pg_fabsf(oy - ey(idx)) < ory + ery(idx) + reach_y + (pg_fabsf(evy(idx)) + tsl))) {
+                                        const int t = meta_type(mt);
+                                        near = Game::may_interact(*this, otype, t, true) || Game::may_interact(*this, otype, t, false);
+                                    }
+                                }
+                                near;
+                            })) != 0;
+        }
+        if (!any) return 0;
+        int scan_axes = 0;
         for (int c = 0; c < ((n + 63) >> 6) && scan_axes != 3; c++) {
             const uint64_t mh = PG_BALLOT(l, ((c << 6) + l) < n && ((c << 6) + l) != obj && Game::may_interact(*this, otype, etype((c << 6) + l), true));
             const uint64_t mv = PG_BALLOT(l, ((c << 6) + l) < n && ((c << 6) + l) != obj && Game::may_interact(*this, otype, etype((c << 6) + l), false));
             scan_axes |= (mh ? 1 : 0) | (mv ? 2 : 0);
         }
-        if (scan_axes != 0) {
-            // no entity this object could interact with lies within its reach for this step (its own travel, < 1 cell of
-            // block snapping, < 2 of a reflection): the per-sub_step scans cannot find anything
-            const float ox = ex(obj), oy = ey(obj), orx = erx(obj), ory = ery(obj);
-            const float reach_x = pg_fabsf(evx(obj)) + 2.01f, reach_y = pg_fabsf(evy(obj)) + 2.01f;
-            bool any = false;
-            for (int c = 0; c < ((n + 63) >> 6) && !any; c++) {
-                any = PG_BALLOT(l, ({
-                                    const int idx = (c << 6) + l;
-                                    bool near = false;
-                                    if (idx < n && idx != obj) {
-                                        const int t = etype(idx);
-                                        if (Game::may_interact(*this, otype, t, true) || Game::may_interact(*this, otype, t, false))
-                                            near = (pg_fabsf(ox - ex(idx)) < orx + erx(idx) + reach_x) && (pg_fabsf(oy - ey(idx)) < ory + ery(idx) + reach_y);
-                                    }
-                                    near;
-                                })) != 0;
-            }
-            if (!any) scan_axes = 0;
-        }
         return scan_axes;
+    }
+
+    // ---- free objects: sub_steps evaluated side by side ---------------------------------------------------------------
+    // An object that no entity can block or reflect this step (scan axes 0) steps through the grid alone: sub_step k reads
+    // the grid and the object's own position, nothing else.  Its 4-8 sub_steps were the longest dependent chain of the step
+    // kernel (profiles/r03_phase_cycles_coinrun.txt: "bso: sub_steps").  They are now evaluated by 8 lanes at once, lane i
+    // taking sub_step k0 + i from a PREDICTED start state -- per axis either "moves freely" (k0's position plus i times the
+    // same float add the serial loop would make) or "stuck" (blocked and snapped back to where it was: a grounded agent's y
+    // axis) -- and the longest prefix whose outcomes equal their successors' predicted starts is accepted, bit for bit what
+    // the serial loop computes.  The first lane that disagrees has still done its own sub_step from a correct start, so a
+    // round accepts at least one sub_step and re-predicts from what that one did; two rounds serve the common cases
+    // (free flight: one).  Eight objects go side by side (lane = object * 8 + sub_step).
+    struct FreeState {
+        float x, y, vx, vy;
+    };
+    // the grid half of sub_step (BAG:270-334) for one axis move on a register copy (no entity scan: scan axes are 0)
+    PG_DEV bool sub_step_grid(FreeState &R, int otype, float orx, float ory, float _vx, float _vy) {
+        float ny = R.y + _vy;
+        float nx = R.x + _vx;
+        const float margin = 0.98f;
+        const bool is_horizontal = _vx != 0;
+        bool block = false, reflect = false;
+        {
+            const float mx = orx * margin, my = ory * margin;
+            const float px[2] = {nx + mx * -1, nx + mx * 1};
+            const float py[2] = {ny + my * -1, ny + my * 1};
+            int cxi[2], cyi[2];
+            bool xneg[2], yneg[2];
+            for (int k = 0; k < 2; k++) {
+                xneg[k] = px[k] < 0;
+                yneg[k] = py[k] < 0;
+                cxi[k] = (int)pg_floorf(px[k]);
+                cyi[k] = (int)pg_floorf(py[k]);
+            }
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 2; j++) {
+                    const int type2 = (xneg[i] || yneg[j]) ? G.out_of_bounds_object : get_obj(cxi[i], cyi[j]);
+                    block = block || Game::is_blocked(*this, otype, type2, is_horizontal);
+                    reflect = reflect || Game::will_reflect(otype, type2);
+                }
+        }
+        if (reflect) {
+            if (is_horizontal) {
+                float delta;
+                if (_vx < 0) delta = (float)(pg_ceil((double)(nx - orx)) - (double)(nx - orx));
+                else delta = (float)(pg_floor((double)(nx + orx)) - (double)(nx + orx));
+                R.vx = -1 * R.vx;
+                nx = nx + 2 * delta;
+            } else {
+                float delta;
+                if (_vy < 0) delta = (float)(pg_ceil((double)(ny - ory)) - (double)(ny - ory));
+                else delta = (float)(pg_floor((double)(ny + ory)) - (double)(ny + ory));
+                R.vy = -1 * R.vy;
+                ny = ny + 2 * delta;
+            }
+        } else if (block) {
+            if (is_horizontal) nx = (float)(_vx > 0 ? (pg_floor((double)(nx + orx)) - (double)orx) : (pg_ceil((double)(nx - orx)) + (double)orx));
+            else ny = (float)(_vy > 0 ? (pg_floor((double)(ny + ory)) - (double)ory) : (pg_ceil((double)(ny - ory)) + (double)ory));
+        }
+        R.x = nx;
+        R.y = ny;
+        return block;
+    }
+    static constexpr bool FREE_OBJECTS_OK = !GameHasBlockHook<Game>::value;  // (a block hook writes entity words from inside sub_step)
+    // basic_step_object (BAG:593-656) for the objects s->tmp[first .. first + count), count <= 8, all alive, with scan axes 0,
+    // in a game that is not grid_step
+    PG_DEV void bso_free_objects(int first, int count) {
+        PG_LANE_VAR(uint32_t, sx);  // true state of the lane's object at its sub_step k0 (bit patterns; the 8 lanes of an object agree)
+        PG_LANE_VAR(uint32_t, sy);
+        PG_LANE_VAR(uint32_t, svx);
+        PG_LANE_VAR(uint32_t, svy);
+        PG_LANE_VAR(uint32_t, ox);  // outcome of this lane's sub_step
+        PG_LANE_VAR(uint32_t, oy);
+        PG_LANE_VAR(uint32_t, ovx);
+        PG_LANE_VAR(uint32_t, ovy);
+        PG_LANE_VAR(int, oflags);  // 1 block_x, 2 block_y, 4 the accepted prefix ends here, 8 active, 16 / 32 x / y came out where it went in
+        PG_LANE_VAR(int, k0);
+        PG_LANE_VAR(int, nsub);
+        PG_LANE_VAR(int, cntx);  // sub_steps that did not block x / y so far (vx_pct / vy_pct before the division)
+        PG_LANE_VAR(int, cnty);
+        PG_LANE_VAR(int, pred);  // 1: x predicted stuck, 2: y predicted stuck
+        PG_FOR_LANES(l) {
+            const int g = l >> 3;
+            PG_LV(k0, l) = 0;
+            PG_LV(nsub, l) = 0;
+            PG_LV(cntx, l) = 0;
+            PG_LV(cnty, l) = 0;
+            PG_LV(pred, l) = 0;
+            PG_LV(oflags, l) = 0;
+            PG_LV(sx, l) = PG_LV(sy, l) = PG_LV(svx, l) = PG_LV(svy, l) = 0u;
+            PG_LV(ox, l) = PG_LV(oy, l) = PG_LV(ovx, l) = PG_LV(ovy, l) = 0u;
+            if (g < count) {
+                const int obj = (int)s->tmp[first + g];
+                const float vx = evx(obj), vy = evy(obj);
+                int n = (int)(4 * pg_sqrt((double)(vx * vx + vy * vy)));  // double sqrt, see oracle note
+                if (n < 4) n = 4;
+                PG_LV(nsub, l) = n;
+                PG_LV(sx, l) = __builtin_bit_cast(uint32_t, ex(obj));
+                PG_LV(sy, l) = __builtin_bit_cast(uint32_t, ey(obj));
+                PG_LV(svx, l) = __builtin_bit_cast(uint32_t, vx);
+                PG_LV(svy, l) = __builtin_bit_cast(uint32_t, vy);
+            }
+        }
+        while (true) {
+            PG_FOR_LANES(l) {
+                const int g = l >> 3, i = l & 7;
+                int fl = 0;
+                if (g < count && PG_LV(k0, l) + i < PG_LV(nsub, l)) {
+                    const int obj = (int)s->tmp[first + g];
+                    const int n = PG_LV(nsub, l);
+                    const float pct = (float)(1.0 / n);
+                    const float vx0 = evx(obj), vy0 = evy(obj);  // (untouched until the object is finished)
+                    const float cmp = pg_fabsf(vx0) - pg_fabsf(vy0);
+                    const int otype = etype(obj);
+                    bool step_x_first = cmp == 0 ? (G.step_rand_int % 2 == 0) : (cmp > 0);
+                    if (otype == PLAYER) {
+                        if (G.action_vx != 0) step_x_first = true;
+                        if (G.action_vy != 0) step_x_first = false;
+                    }
+                    const float orx = erx(obj), ory = ery(obj);
+                    FreeState R;
+                    R.x = __builtin_bit_cast(float, PG_LV(sx, l));
+                    R.y = __builtin_bit_cast(float, PG_LV(sy, l));
+                    R.vx = __builtin_bit_cast(float, PG_LV(svx, l));
+                    R.vy = __builtin_bit_cast(float, PG_LV(svy, l));
+                    const int pr = PG_LV(pred, l);
+                    const float dvx = R.vx * pct, dvy = R.vy * pct;
+                    for (int t = 0; t < i; t++) {  // predicted start of sub_step k0 + i
+                        if (!(pr & 1)) R.x = R.x + dvx;
+                        if (!(pr & 2)) R.y = R.y + dvy;
+                    }
+                    const float in_x = R.x, in_y = R.y;
+                    const float next_x = (pr & 1) ? R.x : R.x + dvx, next_y = (pr & 2) ? R.y : R.y + dvy;  // ... and of its successor
+                    for (int h = 0; h < 2; h++) {  // BAG:627-640
+                        const bool xaxis = (h == 0) == step_x_first;
+                        const float mvx = xaxis ? R.vx * pct : 0.0f;
+                        const float mvy = xaxis ? 0.0f : R.vy * pct;
+                        if (sub_step_grid(R, otype, orx, ory, mvx, mvy)) fl |= xaxis ? 1 : 2;
+                    }
+                    const uint32_t bx = __builtin_bit_cast(uint32_t, R.x), by = __builtin_bit_cast(uint32_t, R.y);
+                    const uint32_t bvx = __builtin_bit_cast(uint32_t, R.vx), bvy = __builtin_bit_cast(uint32_t, R.vy);
+                    const bool as_predicted = bx == __builtin_bit_cast(uint32_t, next_x) && by == __builtin_bit_cast(uint32_t, next_y) && bvx == PG_LV(svx, l) && bvy == PG_LV(svy, l);
+                    if (!as_predicted || PG_LV(k0, l) + i == n - 1 || (fl & 3) == 3) fl |= 4;
+                    fl |= 8;
+                    if (bx == __builtin_bit_cast(uint32_t, in_x)) fl |= 16;
+                    if (by == __builtin_bit_cast(uint32_t, in_y)) fl |= 32;
+                    PG_LV(ox, l) = bx;
+                    PG_LV(oy, l) = by;
+                    PG_LV(ovx, l) = bvx;
+                    PG_LV(ovy, l) = bvy;
+                }
+                PG_LV(oflags, l) = fl;
+            }
+            const uint64_t m_act = PG_BALLOT(l, (PG_LV(oflags, l) & 8) != 0);
+            if (m_act == 0) break;
+#if defined(PGAMD_WAVE_EMU)
+            pg_emu_counters()[1] += 1;                  // rounds
+            pg_emu_counters()[2] += pg_popc64(m_act);   // sub_steps evaluated (accepted or not)
+#endif
+            const uint64_t m_stop = PG_BALLOT(l, (PG_LV(oflags, l) & 4) != 0);
+            const uint64_t m_nbx = PG_BALLOT(l, (PG_LV(oflags, l) & 9) == 8);
+            const uint64_t m_nby = PG_BALLOT(l, (PG_LV(oflags, l) & 10) == 8);
+            PG_FOR_LANES(l) {
+                const int g = l >> 3;
+                const uint32_t act = (uint32_t)(m_act >> (g * 8)) & 0xffu;
+                if (act) {
+                    const uint32_t stopm = (uint32_t)(m_stop >> (g * 8)) & 0xffu;  // (never 0: the object's last sub_step stops)
+                    const int j = pg_ctz64((uint64_t)stopm);
+                    const uint32_t pre = (2u << j) - 1u;
+                    PG_LV(cntx, l) += pg_popc64((uint64_t)((uint32_t)(m_nbx >> (g * 8)) & pre));
+                    PG_LV(cnty, l) += pg_popc64((uint64_t)((uint32_t)(m_nby >> (g * 8)) & pre));
+                    const int src = g * 8 + j;
+                    const int fj = PG_SHFL(oflags, l, src);
+                    const uint32_t nx = PG_SHFL(ox, l, src), ny = PG_SHFL(oy, l, src), nvx = PG_SHFL(ovx, l, src), nvy = PG_SHFL(ovy, l, src);
+                    PG_LV(sx, l) = nx;
+                    PG_LV(sy, l) = ny;
+                    PG_LV(svx, l) = nvx;
+                    PG_LV(svy, l) = nvy;
+                    PG_LV(pred, l) = (fj >> 4) & 3;
+                    PG_LV(k0, l) = (fj & 3) == 3 ? PG_LV(nsub, l) : PG_LV(k0, l) + j + 1;  // both axes blocked: the reference loop breaks
+                }
+            }
+        }
+#if defined(PGAMD_WAVE_EMU)
+        pg_emu_counters()[3] += 1;      // calls
+        pg_emu_counters()[4] += count;  // objects
+#endif
+        PG_FOR_LANES(l) {
+            const int g = l >> 3;
+            if (g < count && (l & 7) == 0) {
+                const int obj = (int)s->tmp[first + g];
+                const int n = PG_LV(nsub, l);
+                float vx_pct = (float)PG_LV(cntx, l), vy_pct = (float)PG_LV(cnty, l);
+                vx_pct = vx_pct / n;
+                vy_pct = vy_pct / n;
+                ex(obj) = __builtin_bit_cast(float, PG_LV(sx, l));
+                ey(obj) = __builtin_bit_cast(float, PG_LV(sy, l));
+                evx(obj) = __builtin_bit_cast(float, PG_LV(svx, l)) * vx_pct;
+                evy(obj) = __builtin_bit_cast(float, PG_LV(svy, l)) * vy_pct;
+            }
+        }
+        PG_SYNC_E();
     }
 
     PG_DEV void basic_step_object(int obj) {  // BAG:593-656
         if (eflag(obj, MF_WILL_ERASE)) return;
         const int scan_axes = bso_scan_axes(obj);
+        if constexpr (FREE_OBJECTS_OK) {
+            if (scan_axes == 0 && !G.grid_step && !(d.debug_flags & 32768)) {
+                s->tmp[0] = (uint32_t)obj;
+                PG_SYNC_E();
+                bso_free_objects(0, 1);
+                return;
+            }
+        }
         bso_core<true>(obj, scan_axes);
     }
 
@@ -949,11 +1168,23 @@ struct Env {
 #if defined(PGAMD_WAVE_EMU)
                     pg_emu_counters()[0] += np;
 #endif
-                    PG_FOR_LANES(l) {
-                        if (l < np) {
-                            const int obj = (int)s->tmp[l];
-                            bso_core<false>(obj, 0);
-                            meta(obj) |= MF_PAR_DONE;
+                    bool done = false;
+                    if constexpr (FREE_OBJECTS_OK) {
+                        if (!G.grid_step) {  // eight objects at a time, their sub_steps side by side
+                            for (int b = 0; b < np; b += 8) bso_free_objects(b, np - b < 8 ? np - b : 8);
+                            PG_FOR_LANES(l) {
+                                if (l < np) meta((int)s->tmp[l]) |= MF_PAR_DONE;
+                            }
+                            done = true;
+                        }
+                    }
+                    if (!done) {  // one lane per object
+                        PG_FOR_LANES(l) {
+                            if (l < np) {
+                                const int obj = (int)s->tmp[l];
+                                bso_core<false>(obj, 0);
+                                meta(obj) |= MF_PAR_DONE;
+                            }
                         }
                     }
                     PG_SYNC_E();

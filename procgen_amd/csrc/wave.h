@@ -34,7 +34,8 @@ inline int &pg_emu_lane() {
     static thread_local int lane = -1;
     return lane;
 }
-// event counters the harness reads back (which code paths a test really took); slot 0: objects stepped by the parallel pass
+// event counters the harness reads back (which code paths a test really took); slot 0: objects stepped by the parallel pass,
+// 1-4: bso_free_objects rounds / sub_steps evaluated / calls / objects
 inline long long *pg_emu_counters() {
     static long long c[8] = {0};
     return c;
