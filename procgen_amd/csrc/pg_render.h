@@ -581,8 +581,9 @@ struct Renderer {
     // pixel depends on the rect alone; whether that cell has a sample there is per class (Qt drops a last sample
     // that would fall outside the source).  Returns false when the frame needs the per-cell path: solid-colour
     // cells, adjusted rects, more than four sizes, three cells over one pixel.
-    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, uint64_t &colseam, uint64_t &rowseam, bool &multi, int &nfill_out) {
+    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, uint64_t &colseam, uint64_t &rowseam, uint64_t &rowany, bool &multi, int &nfill_out) {
         nfill_out = 0;
+        rowany = ~0ull;
         const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
         uint32_t *present = fb;  // scratch: the band buffer is idle during set-up
         uint32_t *span = fb + 64;
@@ -668,11 +669,28 @@ struct Renderer {
             if (tv != CELL_NONE && tv != TYPE_SLOW) lds->typeany[l] = tv | (PG_LV(cls, l) << 27);
         }
         PG_SYNC();
+        uint32_t cellrows = 0;  // bit r: cell row r of the window holds a cell with an image
         for (int base = 0; base < ncell; base += 64) {
+            PG_LANE_VAR(uint32_t, has);
             PG_FOR_LANES(l) {
+                PG_LV(has, l) = 0;
                 if (base + l < ncell) {
                     const uint32_t t = lds->cellimg[base + l];
-                    if (t != CELL_NONE && t != CELL_FILL) lds->cellimg[base + l] = lds->typeany[t];
+                    if (t != CELL_NONE && t != CELL_FILL) {
+                        lds->cellimg[base + l] = lds->typeany[t];
+                        PG_LV(has, l) = 1;
+                    }
+                }
+            }
+            // cells are x-major (index = column * ny_full + row): fold the chunk's mask onto the rows, column by column
+            const uint64_t m = PG_BALLOT(l, PG_LV(has, l) != 0);
+            if (m != 0) {
+                const int last = base + 63 < ncell - 1 ? base + 63 : ncell - 1;
+                for (int cx = (int)(((uint32_t)base * ny_inv) >> 20); cx * ny_full <= last; cx++) {
+                    const int lo = cx * ny_full > base ? cx * ny_full : base;
+                    const int hi = (cx + 1) * ny_full < base + 64 ? (cx + 1) * ny_full : base + 64;
+                    const uint64_t bits = (m >> (lo - base)) & (hi - lo >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull));
+                    cellrows |= (uint32_t)(bits << (lo - cx * ny_full));
                 }
             }
         }
@@ -791,6 +809,13 @@ struct Renderer {
         if (PG_BALLOT(l, PG_LV(over, l) != 0) != 0) return false;
         colseam = PG_BALLOT(l, (lds->ci[1][l] >> 31) != 0);
         rowseam = PG_BALLOT(l, (lds->ri[1][l] >> 31) != 0);
+        {
+            // screen rows that some cell with an image reaches: a cell row with nothing to draw (sky) costs its pixels nothing
+            rowany = PG_BALLOT(l, ({
+                                   const uint32_t cr = cellrows, e0 = lds->ri[0][l], e1 = lds->ri[1][l];
+                                   ((e0 >> 31) != 0 && ((cr >> ((e0 >> 12) & 0x1fu)) & 1u) != 0) || ((e1 >> 31) != 0 && ((cr >> ((e1 >> 12) & 0x1fu)) & 1u) != 0);
+                               }));
+        }
         PG_FOR_LANES(l) {
             if ((colseam >> l) & 1ull) lds->seamcols[pg_popc64(colseam & pg_mask_lt(l))] = (uint32_t)l;
         }
@@ -822,81 +847,127 @@ struct Renderer {
         return hit;
     }
     template <bool MULTI>
-    PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam) {
+    PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam, uint64_t rowany) {
         const int ref_w = d.assets->ref_w;
         const int nseam = pg_popc64(colseam);
-        // stage 1: (c0, r0), lane = screen column, a band of fetches in flight; stage 2: (c0, r1) on doubly covered rows
-        for (int slot_r = 0; slot_r < 2; slot_r++) {
-            const int rows = slot_r == 0 ? WIDE_ROWS : 8;  // stage 1 fetches a whole band at once; the seam rows go 8 at a time
-            for (int yb = row0; yb < row1; yb += rows) {
-                if (slot_r == 1 && ((rowseam >> yb) & 0xffull) == 0) continue;
-                if (slot_r == 0) {
-                    PG_FOR_LANES(l) {
-                        const uint32_t ce = lds->ci[0][l];
-                        uint32_t tex[WIDE_ROWS];
-                        bool hit[WIDE_ROWS], opq[WIDE_ROWS];
-                        _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
-                            opq[j] = false;
-                            tex[j] = 0;
-                            hit[j] = pull_fetch<MULTI>(ce, lds->ri[0][yb + j], 0, 0, l, yb + j, ny_full, ref_w, tex[j], opq[j]);
-                        }
-                        _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
-                            uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];  // this lane owns the pixel
-                            const uint32_t old = *dp;
-                            const uint32_t over = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
-                            *dp = hit[j] ? over : old;
-                        }
-                    }
-                    PG_SYNC();
-                    continue;
+        const uint32_t band_any = (uint32_t)((rowany >> row0) & ((1ull << BAND_ROWS) - 1ull));
+        if (band_any == 0) return;  // no cell with an image reaches these rows (sky)
+        // stage 1: (c0, r0), lane = screen column, a band of fetches in flight
+        for (int yb = row0; yb < row1; yb += WIDE_ROWS) {
+            if (((band_any >> (yb - row0)) & ((1u << WIDE_ROWS) - 1u)) == 0) continue;
+            PG_FOR_LANES(l) {
+                const uint32_t ce = lds->ci[0][l];
+                uint32_t tex[WIDE_ROWS];
+                bool hit[WIDE_ROWS], opq[WIDE_ROWS];
+                _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
+                    opq[j] = false;
+                    tex[j] = 0;
+                    hit[j] = pull_fetch<MULTI>(ce, lds->ri[0][yb + j], 0, 0, l, yb + j, ny_full, ref_w, tex[j], opq[j]);
                 }
-                PG_FOR_LANES(l) {
-                    const uint32_t ce = lds->ci[0][l];
-                    uint32_t tex[8];
-                    bool hit[8], opq[8];
-                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
-                        opq[j] = false;
-                        tex[j] = 0;
-                        hit[j] = pull_fetch<MULTI>(ce, lds->ri[1][yb + j], 0, 1, l, yb + j, ny_full, ref_w, tex[j], opq[j]);
-                    }
-                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
-                        uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];  // this lane owns the pixel
-                        const uint32_t old = *dp;
-                        const uint32_t over = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
-                        *dp = hit[j] ? over : old;
-                    }
+                _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
+                    uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];  // this lane owns the pixel
+                    const uint32_t old = *dp;
+                    const uint32_t over = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
+                    *dp = hit[j] ? over : old;
                 }
-                PG_SYNC();
             }
+            PG_SYNC();
+        }
+        // stage 2: (c0, r1) on the doubly covered rows only, four of them per round; stage 4 below walks the same rows
+        const uint32_t band_seam = (uint32_t)((rowseam >> row0) & ((1ull << BAND_ROWS) - 1ull)) & band_any;
+        for (uint32_t m = band_seam; m != 0;) {
+            int ys[4], cnt = 0;
+            _Pragma("unroll") for (int q = 0; q < 4; q++) {
+                ys[q] = row0;
+                if (m != 0) {
+                    ys[q] = row0 + pg_ctz64((uint64_t)m);
+                    m &= m - 1u;
+                    cnt = q + 1;
+                }
+            }
+            PG_FOR_LANES(l) {
+                const uint32_t ce = lds->ci[0][l];
+                uint32_t tex[4];
+                bool hit[4], opq[4];
+                _Pragma("unroll") for (int q = 0; q < 4; q++) {
+                    opq[q] = false;
+                    tex[q] = 0;
+                    hit[q] = false;
+                    if (q < cnt) hit[q] = pull_fetch<MULTI>(ce, lds->ri[1][ys[q]], 0, 1, l, ys[q], ny_full, ref_w, tex[q], opq[q]);
+                }
+                _Pragma("unroll") for (int q = 0; q < 4; q++) {
+                    if (q < cnt) {
+                        uint32_t *dp = &fb[(ys[q] - row0) * RES_W + l];
+                        const uint32_t old = *dp;
+                        const uint32_t over = opq[q] ? tex[q] : blend(tex[q], old, 256, 255u);
+                        *dp = hit[q] ? over : old;
+                    }
+                }
+            }
+            PG_SYNC();
         }
         if (nseam == 0) return;
-        // stage 3: (c1, r0) and stage 4: (c1, r1): only the doubly covered columns; pixels (seam column k, row) are
-        // laid out linearly over the lanes
-        const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)nseam - 1u) / (uint32_t)nseam);
-        const int npx = nseam * BAND_ROWS;
-        for (int slot_r = 0; slot_r < 2; slot_r++) {
-            if (slot_r == 1 && ((rowseam >> row0) & ((1ull << BAND_ROWS) - 1ull)) == 0) continue;
-            for (int base = 0; base < npx; base += 512) {
+        // stage 3: (c1, r0): the doubly covered columns x the band's rows, laid out linearly over the lanes, four per lane and round
+        {
+            const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)nseam - 1u) / (uint32_t)nseam);
+            const int npx = nseam * BAND_ROWS;
+            for (int base = 0; base < npx; base += 256) {
                 PG_FOR_LANES(l) {
-                    uint32_t tex[8];
-                    int fbi[8];
-                    bool opq[8];
-                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                    uint32_t tex[4];
+                    int fbi[4];
+                    bool opq[4];
+                    _Pragma("unroll") for (int j = 0; j < 4; j++) {
                         const int p = base + j * 64 + l;
                         const bool in = p < npx;
                         const int pc = in ? p : 0;
                         const int yl = (int)(((uint32_t)pc * inv) >> 20);
                         const int x = (int)lds->seamcols[pc - yl * nseam];
-                        const bool hit = pull_fetch<MULTI>(lds->ci[1][x], lds->ri[slot_r][row0 + yl], 1, slot_r, x, row0 + yl, ny_full, ref_w, tex[j], opq[j]) && in;
+                        const bool hit = pull_fetch<MULTI>(lds->ci[1][x], lds->ri[0][row0 + yl], 1, 0, x, row0 + yl, ny_full, ref_w, tex[j], opq[j]) && in;
                         fbi[j] = hit ? yl * RES_W + x : BAND_ROWS * RES_W + l;  // masked-off lanes use the dump row
                     }
-                    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                    _Pragma("unroll") for (int j = 0; j < 4; j++) {
                         const uint32_t old = fb[fbi[j]];
                         fb[fbi[j]] = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
                     }
                 }
                 PG_SYNC();
             }
+        }
+        // stage 4: (c1, r1): doubly covered columns x doubly covered rows; lane = seam column, four rows per round
+        for (uint32_t m = band_seam; m != 0;) {
+            int ys[4], cnt = 0;
+            _Pragma("unroll") for (int q = 0; q < 4; q++) {
+                ys[q] = row0;
+                if (m != 0) {
+                    ys[q] = row0 + pg_ctz64((uint64_t)m);
+                    m &= m - 1u;
+                    cnt = q + 1;
+                }
+            }
+            PG_FOR_LANES(l) {
+                const bool in = l < nseam;
+                const int x = (int)lds->seamcols[in ? l : 0];
+                const uint32_t ce = lds->ci[1][x];
+                uint32_t tex[4];
+                int fbi[4];
+                bool opq[4];
+                _Pragma("unroll") for (int q = 0; q < 4; q++) {
+                    opq[q] = false;
+                    tex[q] = 0;
+                    fbi[q] = BAND_ROWS * RES_W + l;
+                    if (q < cnt) {
+                        const bool hit = pull_fetch<MULTI>(ce, lds->ri[1][ys[q]], 1, 1, x, ys[q], ny_full, ref_w, tex[q], opq[q]) && in;
+                        fbi[q] = hit ? (ys[q] - row0) * RES_W + x : BAND_ROWS * RES_W + l;
+                    }
+                }
+                _Pragma("unroll") for (int q = 0; q < 4; q++) {
+                    if (q < cnt) {
+                        const uint32_t old = fb[fbi[q]];
+                        fb[fbi[q]] = opq[q] ? tex[q] : blend(tex[q], old, 256, 255u);
+                    }
+                }
+            }
+            PG_SYNC();
         }
     }
 
@@ -1636,14 +1707,14 @@ struct Renderer {
         const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
         const bool use_axes = GameDrawsGrid<Game>::value && nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
         int ix_ref = 0, iy_ref = 0;
-        uint64_t colseam = 0, rowseam = 0;
+        uint64_t colseam = 0, rowseam = 0, rowany = ~0ull;
         phase(9);
         build_type_table();
         phase(10);
         bool pull = false, pull_multi = false;
         int pull_nfill = 0, pull_ncell = nx * ny_full;
         if constexpr (GameDrawsGrid<Game>::value)
-            pull = use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, pull_multi, pull_nfill);
+            pull = use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, pull_multi, pull_nfill);
 
         if (use_axes && !pull) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);  // only the per-cell path reads the axis tables
 
@@ -1710,8 +1781,8 @@ struct Renderer {
             phase(2);
             if constexpr (GameDrawsGrid<Game>::value)
                 if (pull && !(d.debug_flags & 2)) {
-                    if (pull_multi) draw_tiles_pull<true>(ny_full, colseam, rowseam);
-                    else draw_tiles_pull<false>(ny_full, colseam, rowseam);
+                    if (pull_multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany);
+                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany);
                     if constexpr (GameHasGridFills<Game>::value) {
                         for (int base = 0; base < pull_nfill; base += 64) {
                             CmdRegs r;
@@ -1850,15 +1921,12 @@ struct Renderer {
             PG_FOR_LANES(l) {
                 const uint32_t *p = &fb[base + 4 * l];
                 const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
-                // bytes: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3   (pixel word = 0xffRRGGBB)
-                const uint32_t r0 = (p0 >> 16) & 0xff, g0 = (p0 >> 8) & 0xff, b0 = p0 & 0xff;
-                const uint32_t r1 = (p1 >> 16) & 0xff, g1 = (p1 >> 8) & 0xff, b1 = p1 & 0xff;
-                const uint32_t r2 = (p2 >> 16) & 0xff, g2 = (p2 >> 8) & 0xff, b2 = p2 & 0xff;
-                const uint32_t r3 = (p3 >> 16) & 0xff, g3 = (p3 >> 8) & 0xff, b3 = p3 & 0xff;
+                // bytes: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3   (pixel word = 0xffRRGGBB, i.e. bytes B G R A): one byte
+                // permute per output dword
                 uint32_t *o = out + (base / 4) * 3 + 3 * l;
-                o[0] = r0 | (g0 << 8) | (b0 << 16) | (r1 << 24);
-                o[1] = g1 | (b1 << 8) | (r2 << 16) | (g2 << 24);
-                o[2] = b2 | (r3 << 8) | (g3 << 16) | (b3 << 24);
+                o[0] = pg_perm(p1, p0, 0x06000102u);
+                o[1] = pg_perm(p2, p1, 0x05060001u);
+                o[2] = pg_perm(p3, p2, 0x04050600u);
             }
         }
     }

@@ -90,6 +90,13 @@ PG_DEV float pg_fabsf(float x) { return fabsf(x); }
 PG_DEV float pg_roundf(float x) { return roundf(x); }
 PG_DEV double pg_fabs(double x) { return fabs(x); }
 PG_DEV double pg_pow(double x, double y) { return pow(x, y); }  // glibc, as the reference
+// v_perm_b32: byte i of the result is byte sel[i] of the 8-byte value (hi << 32 | lo) (selectors 0-7 only)
+PG_DEV uint32_t pg_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) r |= (uint32_t)((v >> (8 * ((sel >> (8 * i)) & 7u))) & 0xffu) << (8 * i);
+    return r;
+}
 
 #else
 
@@ -135,6 +142,7 @@ PG_DEV float pg_roundf(float x) { return __builtin_roundf(x); }  // half away fr
 PG_DEV double pg_fabs(double x) { return __builtin_fabs(x); }
 // ROCm device libm (OCML), < 1 ulp in double; the caller narrows the result to float (bit-exactness notes); sin / cos / atan2 are restated in pg_math.h
 PG_DEV double pg_pow(double x, double y) { return pow(x, y); }
+PG_DEV uint32_t pg_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
 #endif
 
