@@ -118,12 +118,12 @@ class OracleEnv:
     def __init__(self, num, env_name, rand_seed=0, num_levels=0, start_level=0, distribution_mode=1,
                  center_agent=True, use_backgrounds=True, use_monochrome_assets=False, restrict_themes=False,
                  paint_vel_info=False, use_sequential_levels=False, debug_mode=0, resource_root=None, atlas_path=None,
-                 env_offset=0, env_stride=1):
+                 env_offset=0, env_stride=1, use_generated_assets=False):
         self.L = lib()
         self.gid = load_images(env_name, resource_root, atlas_path)
         self.num = num
         o = PgoOptions(rand_seed, num_levels, start_level, distribution_mode, int(center_agent), int(use_backgrounds),
-                       int(use_monochrome_assets), int(restrict_themes), 0, int(paint_vel_info),
+                       int(use_monochrome_assets), int(restrict_themes), int(use_generated_assets), int(paint_vel_info),
                        int(use_sequential_levels), debug_mode)
         self.h = C.c_void_p(self.L.pgo_make_strided(self.gid, num, C.byref(o), env_offset, env_stride))
         self.rgb = np.zeros((num, 64, 64, 3), np.uint8)
