@@ -5427,6 +5427,19 @@ void pgo_test_draw_ellipse(double x, double y, double w, double h, int pen, int 
     for (int i = 0; i < RES_W * RES_H; i++) out[i] = (uint8_t)(px[i] & 3u);
 }
 
+void pgo_test_generated_asset(int game_id, int type, uint32_t *out4096) {
+    Game g;
+    memset(&g, 0, sizeof(g));
+    g.game_id = game_id;
+    gen_assets_init(game_id);
+    memcpy(out4096, generated_asset(&g, type)->px, sizeof(uint32_t) * 4096);
+}
+void pgo_test_generated_background(int seed, uint32_t *out250000) {
+    Rng r;
+    rng_seed(&r, seed);
+    ag_generate_resource(&r, out250000, 500, 500, 1, 50, 1);
+}
+
 static void game_draw(Game *g, uint32_t *dst) { /* BAG:979-1012,921-970 */
     for (int i = 0; i < RES_W * RES_H; i++) dst[i] = 0xff000000u; /* fillRect black */
     if (g->game_id == GAME_STARPILOT) { /* game_draw override starpilot.cpp:108-124 */

@@ -70,6 +70,10 @@ void pgo_dump_scalars(PgoVec *v, int env, int32_t *out16);
 /* test hook: the Qt 5.9 ellipse restatement (midpoint or path route) on a cleared 64 x 64 canvas; out[64*64]: 0 untouched,
  * 1 brush, 2 pen */
 void pgo_test_draw_ellipse(double x, double y, double w, double h, int pen, int brush, uint8_t *out);
+/* test hooks: AssetGen (use_generated_assets): the 64 x 64 sprite of an object type of a game (ARGB words), and a 500 x 500
+ * background painted from a generator seeded with `seed` */
+void pgo_test_generated_asset(int game_id, int type, uint32_t *out4096);
+void pgo_test_generated_background(int seed, uint32_t *out250000);
 
 #ifdef __cplusplus
 }

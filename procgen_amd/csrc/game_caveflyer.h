@@ -39,6 +39,7 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
     }
 
     static constexpr int GOAL = 1, OBSTACLE = 2, TARGET = 3, PLAYER_BULLET = 4, ENEMY = 5, CAVEWALL = 8, EXHAUST = 9;
+    PG_HOSTDEV static bool use_block_asset(int t) { return t == CAVEWALL; }  // caveflyer.cpp:81-83: generated as a rect texture (use_generated_assets)
     static constexpr int MARKER = 250;  // the reference's transient 1003 (never visible outside game_reset); any unused id does
 
     static void construct(EnvHdr &G) {  // caveflyer.cpp:27-30

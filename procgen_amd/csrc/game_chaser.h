@@ -24,6 +24,7 @@ struct Chaser : BagDefaults<Chaser> {
     PG_DEV static int slots_needed_next_step(E &e) { return 2 * e.G.n_ents + 2; }
 
     static constexpr int LARGE_ORB = 2, ENEMY_WEAK = 3, ENEMY_EGG = 4, MAZE_WALL = 5, ENEMY = 6, ENEMY2 = 7, ENEMY3 = 8, MARKER = 1001, ORB = 1002;
+    PG_HOSTDEV static bool use_block_asset(int t) { return t == MAZE_WALL; }  // chaser.cpp:74-76: generated as a rect texture (use_generated_assets)
     static constexpr float ORB_REWARD = 0.04f, ORB_DIM = 0.3f;
     static constexpr int EAT_TIMEOUT = 75, EGG_TIMEOUT = 50;
     static constexpr int INVALID_IDX = -2;

@@ -24,6 +24,7 @@ struct Climber {
     // object ids climber.cpp:12-24
     static constexpr int COIN = 1, ENEMY = 5, ENEMY1 = 6, ENEMY2 = 7, PLAYER_JUMP = 9, PLAYER_RIGHT1 = 12, PLAYER_RIGHT2 = 13;
     static constexpr int WALL_MID = 15, WALL_TOP = 16, ENEMY_BARRIER = 19;
+    PG_HOSTDEV static bool use_block_asset(int t) { return t == WALL_MID || t == WALL_TOP; }  // climber.cpp:128-130: generated as a rect texture (use_generated_assets)
     static constexpr float PATROL_RANGE = 4;
     static constexpr int NUM_WALL_THEMES = 4;
 

@@ -39,6 +39,7 @@ struct CoinRun {
     static constexpr int GOAL = 1, SAW = 2, SAW2 = 3, ENEMY = 5, ENEMY1 = 6, ENEMY2 = 7;
     static constexpr int PLAYER_JUMP = 9, PLAYER_RIGHT1 = 12, PLAYER_RIGHT2 = 13;
     static constexpr int WALL_MID = 15, WALL_TOP = 16, LAVA_MID = 17, LAVA_TOP = 18, ENEMY_BARRIER = 19, CRATE = 20;
+    PG_HOSTDEV static bool use_block_asset(int t) { return t == WALL_MID || t == WALL_TOP; }  // coinrun.cpp:183-185: generated as a rect texture (use_generated_assets)
     static constexpr int NUM_GROUND_THEMES = 6;
 
     // game scalars in EnvHdr (coinrun.cpp:40-47)

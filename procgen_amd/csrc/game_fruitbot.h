@@ -23,6 +23,7 @@ struct FruitBot : BagDefaults<FruitBot> {
     PG_DEV static int slots_needed_next_step(E &e) { return e.G.n_ents + 1 + 1; }
 
     static constexpr int BARRIER = 1, OUT_OF_BOUNDS_WALL = 2, PLAYER_BULLET = 3, BAD_OBJ = 4, GOOD_OBJ = 7, LOCKED_DOOR = 10, LOCK = 11, PRESENT = 12;
+    PG_HOSTDEV static bool use_block_asset(int t) { return t == BARRIER || t == LOCKED_DOOR || t == PRESENT; }  // fruitbot.cpp:137-139: generated as a rect texture (use_generated_assets)
     static constexpr int KEY_DURATION = 8;
     static constexpr float DOOR_ASPECT_RATIO = 3.25f;
 

@@ -21,6 +21,7 @@ struct Heist : BagDefaults<Heist> {
     PG_DEV static int slots_needed_next_step(E &) { return 0; }
 
     static constexpr int LOCKED_DOOR = 1, KEY = 2, EXIT = 9, KEY_ON_RING = 11;
+    PG_HOSTDEV static bool use_block_asset(int t) { return t == WALL_OBJ || t == LOCKED_DOOR; }  // heist.cpp:62-64: generated as a rect texture (use_generated_assets)
 
 #define HS_NUM_KEYS(G) (G).gsi0
 #define HS_WORLD_DIM(G) (G).gsi1

@@ -50,6 +50,7 @@ struct Jumper : BagDefaults<Jumper> {
 #define JP_COMPASS_DIM(G) (G).gsf0
 
     PG_DEV static bool is_wall(int t) { return t == CAVEWALL || t == CAVEWALL_TOP; }
+    PG_HOSTDEV static bool use_block_asset(int t) { return t == CAVEWALL || t == CAVEWALL_TOP; }  // jumper.cpp:107-109
 
     static void construct(EnvHdr &G) { construct_defaults(G); }  // jumper.cpp:41-44
     // jumper.cpp:201-231: what the distribution mode fixes

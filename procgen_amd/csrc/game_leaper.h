@@ -25,6 +25,7 @@ struct Leaper : BagDefaults<Leaper> {
     PG_DEV static int slots_needed_next_step(E &e) { return e.G.n_ents + e.G.gsi1 + e.G.gsi3 + 3; }  // (gsi1 / gsi3 = LP_N_ROAD / LP_N_WATER)  // one spawn per lane and step at most
 
     static constexpr int LOG = 1, ROAD = 2, WATER = 3, CAR = 4, FINISH_LINE = 5;
+    PG_HOSTDEV static bool use_block_asset(int t) { return t == WATER || t == ROAD; }  // leaper.cpp:87-89: generated as a rect texture (use_generated_assets)
     static constexpr float MONSTER_RADIUS = 0.25f, LOG_RADIUS = 0.45f;
     static constexpr int NSTEP = 5;
     static constexpr float MAX_SPEED = (float)(2 / (NSTEP - 1.0));

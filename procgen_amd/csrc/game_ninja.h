@@ -22,6 +22,7 @@ struct Ninja : BagDefaults<Ninja> {
     PG_DEV static int slots_needed_next_step(E &e) { return 2 * e.G.n_ents + 2; }  // every star may add an explosion, + one new star
 
     static constexpr int GOAL = 1, BOMB = 6, THROWING_STAR = 7, PLAYER_JUMP = 9, PLAYER_RIGHT1 = 12, PLAYER_RIGHT2 = 13, FIRE = 14, WALL_MID = 20;
+    PG_HOSTDEV static bool use_block_asset(int t) { return t == WALL_MID; }  // ninja.cpp:135-137: generated as a rect texture (use_generated_assets)
     static constexpr int NUM_WALL_THEMES = 3;
 
 #define NJ_HAS_SUPPORT(G) (G).gsi0

@@ -142,6 +142,17 @@ struct GameHostTables<Game, decltype((void)Game::HOST_TABLE_WORDS)> {
     static int build(const GameOptions &o, uint32_t *out, int max_words) { return Game::host_tables(o, out, max_words); }
 };
 
+// use_block_asset (BAG:404-406 and the games' overrides): the object types whose generated asset is a rect texture
+// (use_generated_assets); every other type gets a shape on transparent ground
+template <class Game, class = void>
+struct GameBlockAsset {
+    static bool is(int) { return false; }
+};
+template <class Game>
+struct GameBlockAsset<Game, decltype((void)&Game::use_block_asset)> {
+    static bool is(int t) { return Game::use_block_asset(t); }
+};
+
 // A game declares PAR_SMART = true and par_smart_type_ok(type) for the smart_step entity types (a) whose basic_step_object
 // has no side effect beyond the object itself when no entity can block or reflect it, and (b) that no smart entity's
 // sub_step scan can ever hit (may_interact(any smart type, type) is false): step_entities then steps all such objects of an

@@ -12,6 +12,7 @@
 #include "assets.h"
 #include "games.h"
 #include "pg_math.h"
+#include "pg_assetgen.h"
 #include "pg_render.h"
 #include "host_state.h"
 #include "state_io.h"
@@ -269,6 +270,33 @@ void emu_qt_path_ellipse(double x, double y, double w, double h, int pen, int br
     if (pen) qtpath::stroke_ellipse(m, x, y, w, h, RES_W, RES_H);
     for (int yy = 0; yy < RES_H; yy++)
         for (int xx = 0; xx < RES_W; xx++) out[yy * RES_W + xx] = ((m.pen[yy] >> xx) & 1) ? 2 : (((m.brush[yy] >> xx) & 1) ? 1 : 0);
+}
+// pg_assetgen.h on the host: the sprite of an object type as libenv_make paints it, and a background from a generator seeded with `seed`
+struct EmuMT {
+    HostMT m;
+    uint32_t u32() { return m.next(); }
+};
+void emu_generated_asset(const char *game, int type, uint32_t *out4096) {
+    const int gid = game_id_from_name(game);
+    bool block = false;
+#define PG_X(Game) \
+    if (gid == Game::GAME_ID) block = GameBlockAsset<Game>::is(type);
+    PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
+    EmuMT rng;
+    rng.m.seed((int)(hash_str_uint32(game) + (uint32_t)type));
+    int cnt[64], xa[64];
+    assetgen::MemPainter mp{out4096, 64, 64, cnt, xa, 0u, 0u};
+    assetgen::Gen<EmuMT, assetgen::MemPainter> gen{rng, mp};
+    gen.generate_resource(64, 64, 0, 5, block);
+}
+void emu_generated_background(int seed, uint32_t *out250000) {
+    EmuMT rng;
+    rng.m.seed(seed);
+    std::vector<int> cnt(500), xa(500);
+    assetgen::MemPainter mp{out250000, 500, 500, cnt.data(), xa.data(), 0u, 0u};
+    assetgen::Gen<EmuMT, assetgen::MemPainter> gen{rng, mp};
+    gen.generate_resource(500, 500, 1, 50, true);
 }
 long long emu_counter(int k) { return pg_emu_counters()[k]; }
 void emu_path_counts(void *h, long long *out) {
