@@ -5434,6 +5434,10 @@ void pgo_test_generated_asset(int game_id, int type, uint32_t *out4096) {
     gen_assets_init(game_id);
     memcpy(out4096, generated_asset(&g, type)->px, sizeof(uint32_t) * 4096);
 }
+void pgo_dump_background(PgoVec *v, int env, uint32_t *out250000) {
+    if (!v->games[env].gen_bg.px) fatal("no generated background");
+    memcpy(out250000, v->games[env].gen_bg.px, sizeof(uint32_t) * 250000);
+}
 void pgo_test_generated_background(int seed, uint32_t *out250000) {
     Rng r;
     rng_seed(&r, seed);

@@ -74,6 +74,7 @@ void pgo_test_draw_ellipse(double x, double y, double w, double h, int pen, int 
  * background painted from a generator seeded with `seed` */
 void pgo_test_generated_asset(int game_id, int type, uint32_t *out4096);
 void pgo_test_generated_background(int seed, uint32_t *out250000);
+void pgo_dump_background(PgoVec *v, int env, uint32_t *out250000); /* use_generated_assets: env's current background canvas */
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,8 @@
 #include "assets.h"
 
+#include "host_state.h"
+#include "pg_assetgen.h"
+
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -10,6 +13,49 @@ namespace pgamd {
 
 static const char *GAME_NAMES[NUM_GAMES] = {"bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot",
                                              "heist", "jumper", "leaper", "maze", "miner", "ninja", "plunder", "starpilot"};
+
+uint32_t hash_str_uint32(const std::string &str) {  // reference src/vecgame.cpp:156-167
+    uint32_t hash = 0x811c9dc5u;
+    for (unsigned char c : str) {
+        hash ^= c;
+        hash *= 0x1000193u;
+    }
+    return hash;
+}
+
+void generate_game_assets(const std::string &game_name, bool (*use_block_asset)(int type), HostAssets *out) {
+    GameAssetsDev &t = out->table;
+    memset(&t, 0, sizeof(t));
+    out->pixels.assign((size_t)MAX_ASSETS * 64 * 64, 0u);
+    out->image_names.clear();
+    struct Mt {
+        HostMT m;
+        uint32_t u32() { return m.next(); }
+    };
+    for (int type = 0; type < MAX_ASSETS; type++) {
+        Mt rng;
+        rng.m.seed((int)(hash_str_uint32(game_name) + (uint32_t)type));  // asset_rand_gen.seed(fixed_asset_seed + type), BAG:101
+        int cnt[64], xa[64];
+        assetgen::MemPainter mp{out->pixels.data() + (size_t)type * 4096, 64, 64, cnt, xa, 0u, 0u};
+        assetgen::Gen<Mt, assetgen::MemPainter> gen{rng, mp};
+        gen.generate_resource(64, 64, 0, 5, use_block_asset(type));
+        t.img[type].off = (uint32_t)type * 4096u;
+        t.img[type].w = t.img[type].h = 64;
+        bool opaque = true;
+        for (int k = 0; k < 4096; k++) opaque = opaque && (out->pixels[(size_t)type * 4096 + k] >> 24) == 0xffu;
+        t.img[type].opaque = opaque ? 1u : 0u;
+        for (int th = 0; th < MAX_IMAGE_THEMES; th++) t.type_theme_img[type][th] = (int16_t)type;
+        t.type_num_themes[type] = 1;
+        out->image_names.push_back("generated:" + std::to_string(type));
+    }
+    t.img[MAX_ASSETS].off = 0;  // the background canvas: pixels in DevCtx::gen_bg
+    t.img[MAX_ASSETS].w = t.img[MAX_ASSETS].h = 500;
+    t.img[MAX_ASSETS].opaque = 1;
+    out->image_names.push_back("generated:background|bg");
+    t.n_bg = 1;
+    t.bg_img[0] = (int16_t)MAX_ASSETS;
+    t.ref_w = t.ref_h = 64;
+}
 
 int game_id_from_name(const std::string &name) {
     for (int i = 0; i < NUM_GAMES; i++)

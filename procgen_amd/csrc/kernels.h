@@ -30,6 +30,7 @@ struct GameEntry {
     int grid_bytes;
     void (*init_state)(int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
     int (*host_tables)(const GameOptions &opt, uint32_t *out, int max_words);  // GameHostTables<Game>::build (pg_env.h)
+    bool (*use_block_asset)(int type);  // GameBlockAsset<Game>::is (pg_env.h)
 };
 constexpr int MAX_GAME_TABLE_WORDS = 1024;
 // mode 0: initial reset + first observation of every env; mode 1: one step
@@ -40,6 +41,8 @@ int game_tier_for(int game_id, int slots_needed);
 void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes);
 void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
 int game_host_tables(int game_id, const GameOptions &opt, uint32_t *out, int max_words);
+bool (*game_use_block_asset(int game_id))(int);
+hipError_t launch_paint_backgrounds(const DevCtx &d, int env_base, int count, hipStream_t stream);  // use_generated_assets (pg_bgpaint.h); no-op otherwise
 // device math self-tests (kernels.hip)
 hipError_t selftest_bigfish_radius(const float *d_in, float *d_out, int n);
 hipError_t selftest_sincos(uint32_t first_bits, int n, double *d_sin, double *d_cos);

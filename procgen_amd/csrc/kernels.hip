@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "pg_bgpaint.h"
+#include "pg_env.h"
 #include "pg_math.h"
 #include "wave.h"
 
@@ -60,6 +62,31 @@ void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, i
 int game_host_tables(int game_id, const GameOptions &opt, uint32_t *out, int max_words) {
     const GameEntry *e = find(game_id);
     return e ? e->host_tables(opt, out, max_words) : 0;
+}
+
+bool (*game_use_block_asset(int game_id))(int) {
+    const GameEntry *e = find(game_id);
+    return e ? e->use_block_asset : nullptr;
+}
+
+// ---- use_generated_assets: the backgrounds of the episodes that began this step (pg_bgpaint.h), one wave per env of the chunk;
+// an env without a request leaves at once
+__global__ __launch_bounds__(64) void paint_backgrounds(DevCtx d, int env_base) {
+    __shared__ BgPaintLds lds;
+    const int env = env_base + (int)blockIdx.x;
+    const int skip = d.bg_req[2 * env + 1];
+    if (skip < 0) return;
+    int err = 0;
+    paint_background(d.gen_bg + (size_t)env * GEN_BG_WORDS, d.bg_req[2 * env], skip, &lds, &err);
+    if (threadIdx.x == 0) {
+        d.bg_req[2 * env + 1] = -1;
+        if (err) atomicOr(d.error, (int)PGE_ASSERT);
+    }
+}
+hipError_t launch_paint_backgrounds(const DevCtx &d, int env_base, int count, hipStream_t stream) {
+    if (!d.gen_bg || count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(paint_backgrounds, dim3(count), dim3(64), 0, stream, d, env_base);
+    return hipGetLastError();
 }
 
 // ---- device math self-tests (procgen_amd_selftest_*, include/procgen_amd.h): the exact device functions the game

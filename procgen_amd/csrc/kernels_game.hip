@@ -76,11 +76,17 @@ __global__ __launch_bounds__(64) void reset_list(DevCtx d, int chunk, int env_ba
     }
 }
 
-template <class Game>
+// GEN: the handle runs with use_generated_assets (sprites on Qt's generic span route, per-env background canvases; pg_render.h)
+template <class Game, bool GEN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GameRenderMinWaves<PG_GAME>::value))) void render(DevCtx d, int env_base) {
     __shared__ RenderLdsT<Game> lds;
-    Renderer<Game> r(d, env_base + (int)blockIdx.x, &lds);
+    Renderer<Game, GEN> r(d, env_base + (int)blockIdx.x, &lds);
     r.render_env();
+}
+template <class Game>
+static void launch_render(const DevCtx &d, int env_base, int count, hipStream_t st) {
+    if (d.gen_bg) hipLaunchKernelGGL((render<Game, true>), dim3(count), dim3(64), 0, st, d, env_base);
+    else hipLaunchKernelGGL((render<Game, false>), dim3(count), dim3(64), 0, st, d, env_base);
 }
 
 // One step of a handle.  The envs are stepped by up to three kinds of kernel that touch disjoint envs (route table):
@@ -116,7 +122,8 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         } else {
             if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode, 0);
         }
-        if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, 0);
+        PG_TRY(launch_paint_backgrounds(d, 0, d.num_envs, ls.main));
+        if (!(d.debug_flags & 16)) launch_render<Game>(d, 0, d.num_envs, ls.main);
         return hipGetLastError();
     }
     // At most four streams: the runtime deals a process's streams round-robin onto four hardware queues, and two streams on one
@@ -167,7 +174,8 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
             // the episodes this chunk's step kernel (and the list kernels, for its envs) ended: next level, outputs, routing
             if (mode != 0) hipLaunchKernelGGL(reset_list<Game>, dim3(count < 1024 ? count : 1024), dim3(64), 0, st, d, c, base);
         }
-        if (!(d.debug_flags & 16)) hipLaunchKernelGGL(render<Game>, dim3(count), dim3(64), 0, st, d, base);
+        PG_TRY(launch_paint_backgrounds(d, base, count, st));  // (after the list kernels: their envs lie in every chunk)
+        if (!(d.debug_flags & 16)) launch_render<Game>(d, base, count, st);
     }
     for (int k = 0; k < 2; k++) {
         PG_TRY(hipEventRecord(ls.lane_done[k], ls.lane[k]));
@@ -179,7 +187,7 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
 
 template <class Game>
 static hipError_t render_one(const DevCtx &d, int env, hipStream_t stream) {  // re-renders one env (after set_state)
-    hipLaunchKernelGGL(render<Game>, dim3(1), dim3(64), 0, stream, d, env);
+    launch_render<Game>(d, env, 1, stream);
     return hipGetLastError();
 }
 
@@ -191,6 +199,7 @@ const GameEntry *PG_CAT(game_entry_, PG_GAME)() {
         PG_GAME::GAME_ID,    launch_game<PG_GAME>,       render_one<PG_GAME>,     PG_GAME::ENT_CAP_T0, PG_GAME::ENT_CAP_T1,
         PG_GAME::ENT_CAP_T2, game_grid_bytes<PG_GAME>(), init_env_state<PG_GAME>,
         GameHostTables<PG_GAME>::build,
+        GameBlockAsset<PG_GAME>::is,
     };
     return &e;
 }

@@ -280,7 +280,6 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     opts.consume_int("debug_mode", &o.debug_mode);
     opts.consume_int("game_type", &game_type);
     opts.ensure_empty();
-    if (o.use_generated_assets) fatal("use_generated_assets is not provided by the HIP stepper\n");
     level_seed_range(num_levels, start_level, &o.level_seed_low, &o.level_seed_high);
 
     // tensortypes: reference src/vecgame.cpp:212-268
@@ -358,7 +357,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     // assets: baked pack next to the library (procgen_amd/data/<game>.atlas) or the PNG tree at resource_root
     std::string data_dir = getenv("PROCGEN_AMD_DATA_DIR") ? getenv("PROCGEN_AMD_DATA_DIR") : this_library_dir() + "/../../data";
     std::string err;
-    if (!load_game_assets(game_id, resource_root, data_dir + "/" + env_name + ".atlas", &assets, &err)) fatal("failed to load images %s\n", err.c_str());
+    if (o.use_generated_assets) generate_game_assets(env_name, game_use_block_asset(kernel_id), &assets);
+    else if (!load_game_assets(game_id, resource_root, data_dir + "/" + env_name + ".atlas", &assets, &err)) fatal("failed to load images %s\n", err.c_str());
     d_assets = dev_alloc<GameAssetsDev>(1);
     HIP_CHECK(hipMemcpy(d_assets, &assets.table, sizeof(GameAssetsDev), hipMemcpyHostToDevice));
     d_pixels = dev_alloc<uint32_t>(assets.pixels.size());
@@ -405,6 +405,16 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d_reset_count = dev_alloc<int>(2 * MAX_CHUNKS);
     d.assets = d_assets;
     d.pixels = d_pixels;
+    if (o.use_generated_assets) {
+        // every env owns a 500 x 500 RGB32 background canvas, repainted by each episode's reset (reference BAG:58-63,769-773)
+        const size_t bytes = N * (size_t)GEN_BG_WORDS * 4;
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        if (bytes + (1ull << 30) > free_b) fatal("use_generated_assets needs %zu MB of device memory for %d background canvases (1 MB each); %zu MB free\n", bytes >> 20, num_envs, free_b >> 20);
+        d.gen_bg = dev_alloc<uint32_t>(N * (size_t)GEN_BG_WORDS);
+        d.bg_req = dev_alloc<int>(N * 2);
+        HIP_CHECK(hipMemset(d.bg_req, 0xff, N * 2 * sizeof(int)));
+    }
     {
         std::vector<uint32_t> tab(MAX_GAME_TABLE_WORDS);
         const int nw = game_host_tables(kernel_id, d.opt, tab.data(), MAX_GAME_TABLE_WORDS);
@@ -448,6 +458,8 @@ VecGame::~VecGame() {
     if (registered_obs && !ob_ptr.empty()) (void)hipHostUnregister(ob_ptr[0]);
     (void)hipFree(d_assets);
     (void)hipFree(d_pixels);
+    if (d.gen_bg) (void)hipFree(d.gen_bg);
+    if (d.bg_req) (void)hipFree(d.bg_req);
     if (d_game_tables) (void)hipFree(d_game_tables);
     (void)hipFree(d.hdr);
     (void)hipFree(d.rng);
@@ -600,6 +612,7 @@ void VecGame::snapshot(int e, EnvSnapshot *s) {
 }
 
 int VecGame::get_state(int e, char *data, int length) {  // reference src/vecgame.cpp:438-445
+    if (d.opt.use_generated_assets) fatal("fassert failed '!options.use_generated_assets' (BasicAbstractGame::serialize)\n");  // BAG:1176
     if (!buffers_set) fatal("get_state called before libenv_set_buffers\n");
     if (e < 0 || e >= num_envs) fatal("get_state: env index %d out of range\n", e);
     use_device();
@@ -613,6 +626,7 @@ int VecGame::get_state(int e, char *data, int length) {  // reference src/vecgam
 }
 
 void VecGame::set_state(int e, const char *data, int length) {  // reference src/vecgame.cpp:447-456
+    if (d.opt.use_generated_assets) fatal("fassert failed '!options.use_generated_assets' (BasicAbstractGame::deserialize)\n");  // BAG:1238
     if (!buffers_set) fatal("set_state called before libenv_set_buffers\n");
     if (e < 0 || e >= num_envs) fatal("set_state: env index %d out of range\n", e);
     use_device();

@@ -112,6 +112,9 @@ constexpr int MAX_CHUNKS = 8;
 constexpr int LIST_COUNTERS = MAX_CHUNKS * 3;  // [chunk][tier] (NUM_TIERS == 3)  // env chunks of one step (step of chunk c+1 overlaps the render of chunk c)
 constexpr int ROUTE_RESET = 4;  // EnvHdr::big only: a NO_RESET step kernel ended the episode, the reset kernel of the same step takes over
 
+constexpr int GEN_BG_DIM = 500;  // use_generated_assets: the per-env background canvas (reference BAG:62)
+constexpr int GEN_BG_WORDS = GEN_BG_DIM * GEN_BG_DIM;
+
 // ---- sprite atlas in HBM ----
 struct ImgDesc {
     uint32_t off;  // first pixel (0xAARRGGBB words) in the atlas blob
@@ -150,6 +153,10 @@ struct DevCtx {
     const GameAssetsDev *assets;
     const uint32_t *pixels;
     const uint32_t *game_tables;  // Game::host_tables' words (null when the game has none)
+    // use_generated_assets (null otherwise): per-env 500 x 500 background canvases and the requests the reset path leaves
+    // for the background kernel (pg_bgpaint.h): {level seed, rand_gen draws made since the reseed}, skip < 0 = nothing to paint
+    uint32_t *gen_bg;  // [num_envs][GEN_BG_WORDS]
+    int *bg_req;       // [num_envs][2]
     // routing between the arena tiers of the step kernel: envs whose entity table may outgrow tier 0's LDS arena
     // are listed for the tier-1 / tier-2 kernels of the NEXT step (double-buffered by step parity)
     // List (tier, list chunk c) starts at big_list[tier * num_envs + c * chunk_envs], its length is

@@ -14,6 +14,7 @@
 #pragma once
 #include <type_traits>
 
+#include "pg_assetgen.h"
 #include "pg_defs.h"
 #include "wave.h"
 
@@ -218,6 +219,7 @@ struct Env {
     PG_LANE_VAR(uint32_t, rc_words);
     const uint32_t *rc_buf = nullptr;
     int rc_base = 0;
+    int rg_twists = 0;  // twists of rand_gen since rand_seed (draws since the reseed = (rg_twists - 1) * 624 + rand_idx)
 
     // profiling aid (PROCGEN_AMD_DEBUG & 2048): wave cycles spent since the previous mark are charged to phase k
     long long t_mark = 0, t_start = 0;
@@ -441,6 +443,7 @@ struct Env {
         rg_cur = a;
         rg_in_lds = true;
         G.rand_idx = MT_N;
+        rg_twists = 0;
     }
     PG_DEV uint32_t rand_u32() {
         if (G.rand_idx >= MT_N) {
@@ -450,6 +453,7 @@ struct Env {
             rg_in_lds = true;
             G.rand_idx = 0;
             rc_buf = nullptr;
+            rg_twists++;
         }
         // The generator state lives in HBM (home or scratch): a draw used to be one dependent ~1 us round trip, and level
         // generators make hundreds to thousands of them (leaper's reset: 400 spawn rounds of up to nine draws, 1.5 ms of
@@ -498,6 +502,7 @@ struct Env {
             mt_twist(rg_cur, dst);
             rg_cur = dst;
             rg_in_lds = true;
+            rg_twists++;
             const int rest = count - first;
             PG_FOR_LANES(l) {
                 if (l >= first && l < count) PG_LV(out, l) = mt_temper(dst[l - first]);
@@ -518,6 +523,10 @@ struct Env {
         uint32_t range = (uint32_t)(high - low);
         return (int)((uint32_t)low + (x % range));
     }
+    struct EnvRng {  // rand_gen as pg_assetgen.h's Rng policy
+        Env *e;
+        PG_DEV uint32_t u32() { return e->rand_u32(); }
+    };
     PG_DEV int randn(int high) { return (int)(rand_u32() % (uint32_t)high); }             // randgen.cpp:13-17
     PG_DEV float rand01() { return (float)((double)rand_u32() / 4294967296.0); }          // randgen.cpp:19-23
     // one draw from level_seed_rand_gen (state stays in HBM; a twist goes through scratch A)
@@ -1427,6 +1436,22 @@ struct Env {
         if (!(G.main_width > 0 && G.main_height > 0)) fail(PGE_ASSERT);
         G.bg_pct_x = rand01();
         G.background_index = randn(d.assets->n_bg);
+        if (d.opt.use_generated_assets) {
+            // BAG:769-773: AssetGen bggen(&rand_gen) paints this episode's background.  Here only its draws are made (the
+            // generator without a painter); the background kernel re-seeds from the level seed, skips the draws made so far
+            // and paints (pg_bgpaint.h)
+            const int drawn = rg_twists > 0 ? (rg_twists - 1) * MT_N + G.rand_idx : 0;
+            PG_FOR_LANES(l) {
+                if (l == 0) {
+                    d.bg_req[2 * env] = G.current_level_seed;
+                    d.bg_req[2 * env + 1] = drawn;
+                }
+            }
+            EnvRng er{this};
+            assetgen::NoPainter np;
+            assetgen::Gen<EnvRng, assetgen::NoPainter> gen{er, np};
+            gen.generate_resource(500, 500, 1, 50, true);
+        }
         G.n_ents = 0;
         float ax, ay;
         const float a_r = 0.4f;

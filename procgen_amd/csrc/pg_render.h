@@ -31,7 +31,14 @@ struct DrawCmd {  // uniform (scalar) view of one command
     uint32_t basex, srcy0, ix, iy;
     uint32_t src;  // first pixel of the source image in the atlas blob
     uint32_t aux;  // source width (13 bits) | mirrored<<13 | opaque<<14 | rotated<<15 | const_alpha(0..256)<<16
+    uint32_t e0, e1;  // Renderer<Game, GEN = true> only (see cmd_image_generic)
 };
+// Commands of a GEN renderer (use_generated_assets): a sprite is a 64 x 64 QImage::Format_ARGB32, which Qt draws through its
+// generic span route (tests/tools/qt_generic_image_probe.py).  For the untransformed painter the command keeps the pixel
+// box in geom, fx at the box's first column in basex and its per-column step in ix (16.16, fetchTransformed), and the two
+// doubles of the row mapping fy(y) = int((i22 * (y + .5) + idy) * 65536): i22 in (srcy0, iy), idy in (e0, e1).  The
+// background stays an RGB32 image on the fast path; aux bit 27 says its pixels are the env's canvas (DevCtx::gen_bg).
+PG_DEV bool cmd_bgcanvas(uint32_t aux) { return ((aux >> 27) & 1u) != 0; }
 // A rotated command (aux bit 15) keeps its bounding box in geom, its source height in iy, the index of its
 // parameter record (RenderLds::rot) in basex; srcy0 / ix are unused.
 // A tiled command (aux bit 25) keeps the bounding box of the entity's rect in geom and the entity's lane in basex;
@@ -155,6 +162,13 @@ struct RenderLdsT {
     uint32_t cellimg[GameDrawsGrid<Game>::value ? GamePullCells<Game>::value : 1];  // window cell -> source image (atlas offset | opaque<<31), CELL_NONE = nothing to draw
     uint32_t rot[GameUsesRotation<Game>::value ? 64 * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane
 };
+template <bool GEN>
+struct CmdExtra {};
+template <>
+struct CmdExtra<true> {
+    PG_LANE_VAR(uint32_t, e0);
+    PG_LANE_VAR(uint32_t, e1);
+};
 constexpr uint32_t CELL_NONE = 0xffffffffu;
 template <int N>
 struct PgInt {
@@ -168,7 +182,7 @@ constexpr uint32_t TYPE_SLOW = 0xfffffffeu;  // typeimg: this type needs the per
 PG_DEV int d2i_x86(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (int)0x80000000; }
 PG_DEV bool q_fuzzy_is_null(double v) { return (v < 0 ? -v : v) <= 0.000000000001; }
 
-template <class Game>
+template <class Game, bool GEN = false>
 struct Renderer {
     const DevCtx &d;
     const int env;
@@ -230,9 +244,14 @@ struct Renderer {
     // qt_scale_image_32bit.  tr.w / tr.h may be negative (a 180 degree rotation arrives as a negative scale).
     PG_DEV void cmd_image(int img_index, bool mirrored, RectD tr, float opacity, uint32_t &geom, uint32_t &basex_o, uint32_t &srcy_o,
                           uint32_t &ix_o, uint32_t &iy_o, uint32_t &src_o, uint32_t &aux_o) const {
-        cmd_image_desc(d.assets->img[img_index], mirrored, tr, opacity, geom, basex_o, srcy_o, ix_o, iy_o, src_o, aux_o);
+        cmd_image_fast(d.assets->img[img_index], mirrored, tr, opacity, geom, basex_o, srcy_o, ix_o, iy_o, src_o, aux_o);
     }
     PG_DEV void cmd_image_desc(const ImgDesc im, bool mirrored, RectD tr, float opacity, uint32_t &geom, uint32_t &basex_o, uint32_t &srcy_o,
+                               uint32_t &ix_o, uint32_t &iy_o, uint32_t &src_o, uint32_t &aux_o) const {
+        static_assert(!GEN, "a GEN renderer's sprites go through cmd_image_generic, its background through cmd_image_fast");
+        cmd_image_fast(im, mirrored, tr, opacity, geom, basex_o, srcy_o, ix_o, iy_o, src_o, aux_o);
+    }
+    PG_DEV void cmd_image_fast(const ImgDesc im, bool mirrored, RectD tr, float opacity, uint32_t &geom, uint32_t &basex_o, uint32_t &srcy_o,
                                uint32_t &ix_o, uint32_t &iy_o, uint32_t &src_o, uint32_t &aux_o) const {
         geom = 0;
         basex_o = srcy_o = ix_o = iy_o = src_o = aux_o = 0;
@@ -273,6 +292,153 @@ struct Renderer {
         iy_o = (uint32_t)iy;
         src_o = im.off;
         aux_o = cmd_aux((int)im.w, mirrored, im.opaque != 0, io);
+    }
+
+    // ---- GEN: Qt's generic span route for QImage::Format_ARGB32 sources (reference BAG:102-107; oracle draw_image_generic) -------
+    PG_DEV static bool q26_equal(double p, double q) { return (int)((p - q) * 64) == 0; }  // qrasterizer.cpp q26Dot6Compare
+    // QRasterizer::rasterizeLine(a, b, width), not antialiased, clip = the frame.  0: nothing; 1: the pixel box (x1, x2, y1, y2
+    // inclusive) of an axis-aligned line; 2: the four corners (top, right, bottom, left) in 26.6 for the scan converter
+    PG_DEV static int rasterize_line(double ax, double ay, double bx, double by, double width, int (&box)[4], int (&qx)[4], int (&qy)[4]) {
+        const int cw = RES_W, ch = RES_H;
+        if ((ax == bx && ay == by) || width == 0) return 0;
+        double pax = ax, pay = ay, pbx = bx, pby = by;
+        const double offx = pg_fabs(by - ay) * width * 0.5, offy = pg_fabs(bx - ax) * width * 0.5;
+        const double cl = 0 - offx, ct = 0 - offy, cr = (cw - 1) + 1 + offx, cb = (ch - 1) + 1 + offy;
+        const bool a_in = cl <= pax && pax <= cr && ct <= pay && pay <= cb, b_in = cl <= pbx && pbx <= cr && ct <= pby && pby <= cb;
+        if (!a_in || !b_in) {
+            double t1 = 0, t2 = 1;
+            for (int i = 0; i < 2; i++) {
+                const double o = i ? pay : pax, dd = i ? pby - pay : pbx - pax, low = i ? ct : cl, high = i ? cb : cr;
+                if (dd == 0) {
+                    if (o <= low || o >= high) return 0;
+                    continue;
+                }
+                const double d_inv = 1 / dd;
+                double t_low = (low - o) * d_inv, t_high = (high - o) * d_inv;
+                if (t_low > t_high) { const double t = t_low; t_low = t_high; t_high = t; }
+                if (t1 < t_low) t1 = t_low;
+                if (t2 > t_high) t2 = t_high;
+                if (t1 >= t2) return 0;
+            }
+            const double npax = pax + (pbx - pax) * t1, npay = pay + (pby - pay) * t1, npbx = pax + (pbx - pax) * t2, npby = pay + (pby - pay) * t2;
+            pax = npax; pay = npay; pbx = npbx; pby = npby;
+        }
+        {
+            const double d0x = ax - bx, d0y = ay - by, w0 = d0x * d0x + d0y * d0y;
+            const double dx = pax - pbx, dy = pay - pby, w = dx * dx + dy * dy;
+            if (w == 0) return 0;
+            width *= pg_sqrt(w0 / w);
+        }
+        if (q26_equal(pay, pby)) {
+            if (q26_equal(pax, pbx)) return 0;
+            const double x = (pax + pbx) * 0.5, dx = pg_fabs(pbx - pax) * 0.5, y = pay, dy = width * dx;
+            pax = x; pay = y - dy;
+            pbx = x; pby = y + dy;
+            width = 1 / width;
+        }
+        if (q26_equal(pax, pbx)) {
+            if (pay > pby) { double t = pax; pax = pbx; pbx = t; t = pay; pay = pby; pby = t; }
+            const double dy = pby - pay, half = 0.5 * width * dy;
+            double left = pax - half, right = pax + half;
+            left = left < 0 ? 0 : (left > cw ? cw : left);
+            right = right < 0 ? 0 : (right > cw ? cw : right);
+            pay = pay < 0 ? 0 : (pay > ch ? ch : pay);
+            pby = pby < 0 ? 0 : (pby > ch ? ch : pby);
+            if (q26_equal(left, right) || q26_equal(pay, pby)) return 0;
+            box[0] = (int)(left + 0.5);
+            box[1] = right < 0.5 ? -1 : (int)(right - 0.5);
+            box[2] = (int)(pay + 0.5);
+            box[3] = pby < 0.5 ? -1 : (int)(pby - 0.5);
+            return (box[1] >= box[0] && box[3] >= box[2]) ? 1 : 0;
+        }
+        if (pay > pby) { double t = pax; pax = pbx; pbx = t; t = pay; pay = pby; pby = t; }
+        const double dlx = (pbx - pax) * (0.5 * width), dly = (pby - pay) * (0.5 * width);
+        const double perpx = dly, perpy = -dlx;
+        double cxs[4], cys[4];  // top, right, bottom, left
+        if (pax < pbx) {
+            cxs[0] = pax + perpx; cys[0] = pay + perpy; cxs[3] = pax - perpx; cys[3] = pay - perpy;
+            cxs[1] = pbx + perpx; cys[1] = pby + perpy; cxs[2] = pbx - perpx; cys[2] = pby - perpy;
+        } else {
+            cxs[0] = pax - perpx; cys[0] = pay - perpy; cxs[3] = pbx - perpx; cys[3] = pby - perpy;
+            cxs[1] = pax + perpx; cys[1] = pay + perpy; cxs[2] = pbx + perpx; cys[2] = pby + perpy;
+        }
+        for (int i = 0; i < 4; i++) {
+            qx[i] = (int)pg_floor(cxs[i] * 64.);
+            qy[i] = (int)pg_floor(cys[i] * 64.);
+        }
+        return 2;
+    }
+    // the span [x1, x2] (inclusive, clipped to the frame) the scan converter gives row y of the four-corner polygon; false: none
+    PG_DEV static bool polygon_row(const int (&qx)[4], const int (&qy)[4], int y, int &x1, int &x2) {
+        int cnt = 0, lo = 0, hi = 0;
+        for (int i = 0; i < 4; i++) {  // QScanConverter::mergeLine, evaluated for this row
+            int a_x = qx[i], a_y = qy[i], b_x = qx[(i + 1) & 3], b_y = qy[(i + 1) & 3];
+            if (a_y > b_y) {
+                int t = a_x; a_x = b_x; b_x = t;
+                t = a_y; a_y = b_y; b_y = t;
+            }
+            int itop = (a_y + 32) >> 6, ibot = (b_y - 32) >> 6;
+            if (itop < 0) itop = 0;
+            if (ibot > RES_H - 1) ibot = RES_H - 1;
+            if (y < itop || y > ibot) continue;
+            int xfp = 32768 + a_x * 1024;
+            if (b_x != a_x) {
+                const int slope = (int)((double)(b_x - a_x) / (double)(b_y - a_y) * 65536.);
+                xfp += (int)(((long long)slope * (long long)((itop << 16) + 32768 - (a_y << 10))) >> 16);
+                xfp += slope * (y - itop);
+            }
+            const int xi = xfp >> 16;
+            if (cnt == 0) lo = hi = xi;
+            else {
+                if (xi < lo) lo = xi;
+                if (xi > hi) hi = xi;
+            }
+            cnt++;
+        }
+        x1 = lo < 0 ? 0 : lo;
+        x2 = (hi > RES_W ? RES_W : hi) - 1;
+        return cnt >= 2 && x2 >= x1;
+    }
+    // p.drawImage(tr, sprite) with the untransformed painter (lane-local set-up)
+    PG_DEV void cmd_image_generic(const ImgDesc im, bool mirrored, RectD tr, float opacity, uint32_t &geom, uint32_t &fx0_o, uint32_t &i22lo, uint32_t &fdx_o,
+                                  uint32_t &i22hi, uint32_t &src_o, uint32_t &aux_o, uint32_t &idylo, uint32_t &idyhi) const {
+        geom = 0;
+        fx0_o = i22lo = fdx_o = i22hi = src_o = aux_o = idylo = idyhi = 0;
+        if (!(tr.w > 0 && tr.h > 0)) return;  // drawImage: r.isEmpty()
+        const double l = tr.x, t = tr.y, rr = tr.x + tr.w, b = tr.y + tr.h;
+        int box[4], qx[4], qy[4];
+        if (rasterize_line((l + l) * 0.5, (t + b) * 0.5, (rr + rr) * 0.5, (t + b) * 0.5, tr.h / tr.w, box, qx, qy) != 1) return;
+        if (box[2] >= row1 || box[3] < row0) return;  // does not touch this wave's band
+        // QSpanData::setupMatrix: inverse of translate(1/65536, 1/65536) * translate(tr.x, tr.y) * scale(tr.w / sw, tr.h / sh)
+        const double dlt = 1.0 / 65536;
+        const double c11 = 1.0 * (tr.w / (double)im.w), c22 = 1.0 * (tr.h / (double)im.h);
+        const double p11 = 1.0 * c11, p22 = 1.0 * c22, p31 = dlt * c11 + tr.x, p32 = dlt * c22 + tr.y;
+        const double i11 = 1. / p11, i22 = 1. / p22, idx = -p31 * i11, idy = -p32 * i22;
+        const int fx0 = (int)((i11 * ((double)box[0] + 0.5) + idx) * 65536.);
+        const int fdx = (int)(i11 * 65536.);
+        geom = (uint32_t)box[0] | ((uint32_t)box[2] << 7) | ((uint32_t)(box[1] - box[0] + 1) << 14) | ((uint32_t)(box[3] - box[2] + 1) << 21);
+        fx0_o = (uint32_t)fx0;
+        fdx_o = (uint32_t)fdx;
+        const uint64_t b22 = __builtin_bit_cast(uint64_t, i22), bdy = __builtin_bit_cast(uint64_t, idy);
+        i22lo = (uint32_t)b22;
+        i22hi = (uint32_t)(b22 >> 32);
+        idylo = (uint32_t)bdy;
+        idyhi = (uint32_t)(bdy >> 32);
+        src_o = im.off;
+        aux_o = cmd_aux((int)im.w, mirrored, im.opaque != 0, opacity_to_io(opacity));
+    }
+    // source texel of frame pixel (column offset lx from the command's box, row y)
+    PG_DEV void sample_xy(const DrawCmd &c, int lx, int y, int sw, int &sxp, int &syp) const {
+        if (GEN && !cmd_bgcanvas(c.aux)) {
+            int px = ((int)c.basex + lx * (int)c.ix) >> 16;
+            const double i22 = words_to_double(c.srcy0, c.iy), idy = words_to_double(c.e0, c.e1);
+            int py = (int)((i22 * ((double)y + 0.5) + idy) * 65536.) >> 16;
+            sxp = px < 0 ? 0 : (px > sw - 1 ? sw - 1 : px);
+            syp = py < 0 ? 0 : (py > 63 ? 63 : py);  // generated sprites are 64 x 64
+        } else {
+            sxp = (int)((c.basex + (uint32_t)lx * c.ix) >> 16);
+            syp = (int)((c.srcy0 + (uint32_t)(y - c.ty1) * c.iy) >> 16);
+        }
     }
 
     // BAG:902-906: p.translate(cx, cy); p.rotate(rotation * 180 / PI); p.drawImage(QRectF(-w/2, -h/2, w, h), img).
@@ -972,8 +1138,10 @@ struct Renderer {
     }
 
     // ---- command execution ----------------------------------------------------------------------------------
-    PG_DEV static DrawCmd unpack(uint32_t geom, uint32_t basex, uint32_t srcy0, uint32_t ix, uint32_t iy, uint32_t src, uint32_t aux) {
+    PG_DEV static DrawCmd unpack(uint32_t geom, uint32_t basex, uint32_t srcy0, uint32_t ix, uint32_t iy, uint32_t src, uint32_t aux, uint32_t e0 = 0, uint32_t e1 = 0) {
         DrawCmd c;
+        c.e0 = e0;
+        c.e1 = e1;
         c.tx1 = (int)(geom & 0x7fu);
         c.ty1 = (int)((geom >> 7) & 0x7fu);
         c.w = (int)((geom >> 14) & 0x7fu);
@@ -999,7 +1167,7 @@ struct Renderer {
             exec_fill(r, c.src);
             return;
         }
-        const uint32_t *src = d.pixels + c.src;
+        const uint32_t *src = (GEN && cmd_bgcanvas(c.aux)) ? d.gen_bg + (size_t)env * GEN_BG_WORDS : d.pixels + c.src;
         const int sw = cmd_src_w(c.aux);
         const bool mirrored = cmd_mirrored(c.aux);
         const bool opaque = cmd_opaque(c.aux);
@@ -1013,12 +1181,12 @@ struct Renderer {
                 PG_FOR_LANES(l) {
                     const bool in = l < c.w;
                     const int lc = in ? l : 0;
-                    const int sxp = (int)((c.basex + (uint32_t)lc * c.ix) >> 16);
-                    const int scol = mirrored ? (sw - 1 - sxp) : sxp;
                     uint32_t tex[WIDE_ROWS];
                     _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
                         const int y = (yb + j) < last ? (yb + j) : last;
-                        tex[j] = src[(int)((c.srcy0 + (uint32_t)(y - c.ty1) * c.iy) >> 16) * sw + scol];
+                        int sxp, syp;
+                        sample_xy(c, lc, y, sw, sxp, syp);
+                        tex[j] = src[syp * sw + (mirrored ? (sw - 1 - sxp) : sxp)];
                     }
                     _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
                         const bool ok = in && (yb + j) <= last;
@@ -1042,8 +1210,8 @@ struct Renderer {
                             const int pyb = (int)(((uint32_t)p * inv) >> 20);
                             const int px = p - pyb * c.w;
                             const int y = y0 + pyb;
-                            const int sxp = (int)((c.basex + (uint32_t)px * c.ix) >> 16);
-                            const int syp = (int)((c.srcy0 + (uint32_t)(y - c.ty1) * c.iy) >> 16);
+                            int sxp, syp;
+                            sample_xy(c, px, y, sw, sxp, syp);
                             tex[j] = src[syp * sw + (mirrored ? (sw - 1 - sxp) : sxp)];
                             fbi[j] = (y - row0) * RES_W + c.tx1 + px;
                         }
@@ -1249,7 +1417,133 @@ struct Renderer {
             _Pragma("unroll") for (int j = 0; j < NJ; j++) { fb[fbi[j]] = blend(tex[j], fb[fbi[j]], io, ca); }
         }
     }
+    // GEN: a turned sprite, BAG:897-906: p.translate(cx, cy); p.rotate(deg); p.drawImage(QRectF(-w/2, -h/2, w, h), sprite) on Qt's
+    // generic route.  Everything is worked out again from the entity (wave-uniform doubles); lanes take the pixels of the
+    // bounding box that fall into this band.
+    PG_DEV void exec_generic_rotated(const DrawCmd &c) {
+        const int i = (int)c.basex;
+        const uint32_t mm = meta(i);
+        const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
+        RectD r1;  // get_object_rect BAG:811-817
+        if (mm & MF_ABS_COORDS) {
+            const float vd = G.view_dim;
+            r1.x = (double)((vd * (x - rx)) * G.unit);
+            r1.y = (double)((vd * (y + ry)) * G.unit);
+            r1.w = (double)((2 * vd * rx) * G.unit);
+            r1.h = (double)((2 * vd * ry) * G.unit);
+        } else {
+            r1 = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
+        }
+        const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, 0.0f, r1, nullptr);
+        if (im < 0) return;
+        const ImgDesc imd = d.assets->img[im];
+        const bool mirrored = (mm & MF_REFLECTED) != 0;
+        const int io = opacity_to_io(ef(EF_ALPHA, i));
+        const uint32_t ca = (uint32_t)((io * 255) >> 8);
+        const double cx = r1.x + r1.w / 2, cy = r1.y + r1.h / 2;
+        const double a = (double)(ef(EF_ROTATION, i) * 180 / PG_PI);
+        const RectD r = {-r1.w / 2, -r1.h / 2, r1.w, r1.h};
+        if (!(r.w > 0 && r.h > 0)) return;
+        double sina = 0, cosa = 0;  // QTransform::rotate
+        if (a == 0) cosa = 1;
+        else if (a == 90. || a == -270.) sina = 1.;
+        else if (a == 270. || a == -90.) sina = -1.;
+        else if (a == 180.) cosa = -1.;
+        else {
+            const double b = 0.017453292519943295769 * a;
+            sina = pg_sin_d(b);
+            cosa = pg_cos_d(b);
+        }
+        const double m11 = cosa, m12 = sina, m21 = -sina, m22 = cosa;
+        int type = 0;  // QTransform::type(): 4 rotate, 2 scale, 1 translate, 0 none
+        if (!q_fuzzy_is_null(m12) || !q_fuzzy_is_null(m21)) type = 4;
+        else if (!q_fuzzy_is_null(m11 - 1) || !q_fuzzy_is_null(m22 - 1)) type = 2;
+        else if (!q_fuzzy_is_null(cx) || !q_fuzzy_is_null(cy)) type = 1;
+        // sampling matrix (QSpanData::setupMatrix): copy = m; copy.translate(r.x, r.y); copy.scale(r.w / sw, r.h / sh)
+        double c11 = m11, c12 = m12, c21 = m21, c22 = m22, cdx = cx, cdy = cy;
+        int ctype = type;
+        if (ctype == 0) { cdx = r.x; cdy = r.y; ctype = 1; }
+        else if (ctype == 1) { cdx += r.x; cdy += r.y; }
+        else if (ctype == 2) { cdx += r.x * c11; cdy += r.y * c22; }
+        else { cdx += r.x * c11 + r.y * c21; cdy += r.y * c22 + r.x * c12; }
+        const double scx = r.w / (double)imd.w, scy = r.h / (double)imd.h;
+        if (ctype == 4) { c12 *= scx; c21 *= scy; }
+        c11 *= scx;
+        c22 *= scy;
+        const double dlt = 1.0 / 65536;
+        double i11, i12, i21, i22, idx, idy;
+        if (ctype != 4) {
+            const double p11 = 1.0 * c11, p22 = 1.0 * c22, p31 = dlt * c11 + cdx, p32 = dlt * c22 + cdy;
+            i11 = 1. / p11; i22 = 1. / p22; i12 = 0; i21 = 0;
+            idx = -p31 * i11; idy = -p32 * i22;
+        } else {
+            const double p11 = 1.0 * c11 + 0.0 * c21, p12 = 1.0 * c12 + 0.0 * c22, p21 = 0.0 * c11 + 1.0 * c21, p22 = 0.0 * c12 + 1.0 * c22;
+            const double p31 = dlt * c11 + dlt * c21 + cdx, p32 = dlt * c12 + dlt * c22 + cdy;
+            const double dtr = p11 * p22 - p12 * p21, dinv = 1.0 / dtr;
+            i11 = p22 * dinv; i12 = -p12 * dinv; i21 = -p21 * dinv; i22 = p11 * dinv;
+            idx = (p21 * p32 - p22 * p31) * dinv; idy = (p12 * p31 - p11 * p32) * dinv;
+        }
+        const int fdx = (int)(i11 * 65536.), fdy = (int)(i12 * 65536.);
+        // coverage
+        int kind, box[4] = {0, -1, 0, -1}, qx[4] = {0, 0, 0, 0}, qy[4] = {0, 0, 0, 0};
+        if (type == 2) {  // fillRect_normalized(QRect(qRound of the mapped rect))
+            double bx = m11 * r.x + cx, by = m22 * r.y + cy, ww = m11 * r.w, hh = m22 * r.h;
+            if (ww < 0) { ww = -ww; bx -= ww; }
+            if (hh < 0) { hh = -hh; by -= hh; }
+            box[0] = q_round(bx); box[2] = q_round(by); box[1] = q_round(bx + ww) - 1; box[3] = q_round(by + hh) - 1;
+            if (box[0] < 0) box[0] = 0;
+            if (box[2] < 0) box[2] = 0;
+            if (box[1] > RES_W - 1) box[1] = RES_W - 1;
+            if (box[3] > RES_H - 1) box[3] = RES_H - 1;
+            kind = (box[1] >= box[0] && box[3] >= box[2]) ? 1 : 0;
+        } else {
+            const double l = r.x, t = r.y, rr = r.x + r.w, b = r.y + r.h;
+            double ax = (l + l) * 0.5, ay = (t + b) * 0.5, bx = (rr + rr) * 0.5, by = (t + b) * 0.5;
+            if (type == 1) { ax += cx; ay += cy; bx += cx; by += cy; }
+            else if (type == 4) {
+                const double tax = m11 * ax + m21 * ay + cx, tay = m12 * ax + m22 * ay + cy, tbx = m11 * bx + m21 * by + cx, tby = m12 * bx + m22 * by + cy;
+                ax = tax; ay = tay; bx = tbx; by = tby;
+            }
+            kind = rasterize_line(ax, ay, bx, by, r.h / r.w, box, qx, qy);
+        }
+        if (kind == 0) return;
+        const uint32_t *src = d.pixels + imd.off;
+        const int sw = (int)imd.w, sh = (int)imd.h;
+        const int y0 = c.ty1 > row0 ? c.ty1 : row0;
+        const int y1 = (c.ty1 + c.h) < row1 ? (c.ty1 + c.h) : row1;
+        const int npix = c.w * (y1 - y0);
+        const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)c.w - 1u) / (uint32_t)c.w);
+        for (int base = 0; base < npix; base += 64) {
+            PG_FOR_LANES(l) {
+                const int p = base + l;
+                if (p < npix) {
+                    const int pyb = (int)(((uint32_t)p * inv) >> 20);
+                    const int X = c.tx1 + (p - pyb * c.w), Y = y0 + pyb;
+                    int x1 = box[0], x2 = box[1];
+                    bool in;
+                    if (kind == 1) in = Y >= box[2] && Y <= box[3];
+                    else in = polygon_row(qx, qy, Y, x1, x2);
+                    in = in && X >= x1 && X <= x2;
+                    if (in) {
+                        const double ccx = (double)x1 + 0.5, ccy = (double)Y + 0.5;
+                        const int fx = (int)((i21 * ccy + i11 * ccx + idx) * 65536.) + (X - x1) * fdx;
+                        const int fy = (int)((i22 * ccy + i12 * ccx + idy) * 65536.) + (X - x1) * fdy;
+                        int px = fx >> 16, py = fy >> 16;
+                        px = px < 0 ? 0 : (px > sw - 1 ? sw - 1 : px);
+                        py = py < 0 ? 0 : (py > sh - 1 ? sh - 1 : py);
+                        uint32_t *dp = &fb[(Y - row0) * RES_W + X];
+                        *dp = blend(src[py * sw + (mirrored ? sw - 1 - px : px)], *dp, io, ca);
+                    }
+                }
+            }
+        }
+        PG_SYNC();
+    }
     PG_DEV void exec_rotated(const DrawCmd &c) {
+        if constexpr (GEN) {
+            exec_generic_rotated(c);
+            return;
+        }
         if constexpr (GameUsesRotation<Game>::value) {
             const uint32_t *rp = &lds->rot[(c.basex & 63u) * ROT_WORDS];
 #define PG_ROT(k) ((uint32_t)PG_UNIFORM_I(rp[k]))
@@ -1309,8 +1603,8 @@ struct Renderer {
                     const int y = c[g].ty1 + ly;
                     const bool in = lx < c[g].w && ly < c[g].h && y >= row0 && y < row1;
                     const int sw = cmd_src_w(c[g].aux);
-                    const int sxp = (int)((c[g].basex + (uint32_t)lx * c[g].ix) >> 16);
-                    const int syp = (int)((c[g].srcy0 + (uint32_t)ly * c[g].iy) >> 16);
+                    int sxp, syp;
+                    sample_xy(c[g], lx, y, sw, sxp, syp);
                     const uint32_t addr = cmd_fill(c[g].aux) ? 0u : c[g].src + (uint32_t)(syp * sw + (cmd_mirrored(c[g].aux) ? (sw - 1 - sxp) : sxp));
                     PG_LA(tex, g, l) = cmd_fill(c[g].aux) ? c[g].src : d.pixels[in ? addr : 0u];  // branch-free: masked-off lanes fetch word 0
                     PG_LA(fbi, g, l) = in ? ((y - row0) * RES_W + c[g].tx1 + lx) : (BAND_ROWS * RES_W + l);
@@ -1332,7 +1626,7 @@ struct Renderer {
     }
 
     // one draw command per lane, produced by a set-up section and consumed by run_batch()
-    struct CmdRegs {
+    struct CmdRegs : CmdExtra<GEN> {
         PG_LANE_VAR(uint32_t, geom);
         PG_LANE_VAR(uint32_t, basex);
         PG_LANE_VAR(uint32_t, srcy);
@@ -1342,8 +1636,26 @@ struct Renderer {
         PG_LANE_VAR(uint32_t, aux);
     };
     PG_DEV static DrawCmd read_cmd(const CmdRegs &r, int k) {
-        return unpack(PG_READLANE(r.geom, k), PG_READLANE(r.basex, k), PG_READLANE(r.srcy, k), PG_READLANE(r.ix, k), PG_READLANE(r.iy, k),
-                      PG_READLANE(r.src, k), PG_READLANE(r.aux, k));
+        if constexpr (GEN)
+            return unpack(PG_READLANE(r.geom, k), PG_READLANE(r.basex, k), PG_READLANE(r.srcy, k), PG_READLANE(r.ix, k), PG_READLANE(r.iy, k),
+                          PG_READLANE(r.src, k), PG_READLANE(r.aux, k), PG_READLANE(r.e0, k), PG_READLANE(r.e1, k));
+        else
+            return unpack(PG_READLANE(r.geom, k), PG_READLANE(r.basex, k), PG_READLANE(r.srcy, k), PG_READLANE(r.ix, k), PG_READLANE(r.iy, k),
+                          PG_READLANE(r.src, k), PG_READLANE(r.aux, k));
+    }
+    // lane l's command := nothing
+    PG_DEV static void clear_cmd(CmdRegs &r, int l) {
+        PG_LV(r.geom, l) = 0;
+        PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.src, l) = PG_LV(r.aux, l) = 0;
+        if constexpr (GEN) PG_LV(r.e0, l) = PG_LV(r.e1, l) = 0;
+    }
+    // lane l's command := p.drawImage(tr, image) with the untransformed painter
+    PG_DEV void emit_image(CmdRegs &r, int l, const ImgDesc im, bool mirrored, RectD tr, float opacity) {
+        if constexpr (GEN)
+            cmd_image_generic(im, mirrored, tr, opacity, PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l),
+                              PG_LV(r.e0, l), PG_LV(r.e1, l));
+        else
+            cmd_image_fast(im, mirrored, tr, opacity, PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
     }
     // executes the commands in lane order; runs of small commands go eight at a time
     template <bool NESTED = false>
@@ -1407,8 +1719,7 @@ struct Renderer {
         for (int base = 0; base < num_tiles; base += 64) {
             CmdRegs r;
             PG_FOR_LANES(l) {
-                PG_LV(r.geom, l) = 0;
-                PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.src, l) = PG_LV(r.aux, l) = 0;
+                clear_cmd(r, l);
                 const int t = base + l;
                 if (t < num_tiles) {
                     RectD tr;
@@ -1421,7 +1732,7 @@ struct Renderer {
                     }
                     tr.w = (double)tile_width;
                     tr.h = (double)tile_height;
-                    cmd_image_desc(imd, mirrored, tr, alpha, PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                    emit_image(r, l, imd, mirrored, tr, alpha);
                 }
             }
             run_batch<true>(r);
@@ -1445,8 +1756,7 @@ struct Renderer {
         PG_FOR_LANES(l) {
             const int i = base + l;
             const int rot_slot = rot_base >= 0 ? rot_base + pg_popc64(rotmask & pg_mask_lt(l)) : l;
-            PG_LV(r.geom, l) = 0;
-            PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.src, l) = PG_LV(r.aux, l) = 0;
+            clear_cmd(r, l);
             if (i < n && Game::should_draw_entity(*this, i)) {
                 const uint32_t mm = meta(i);
                 const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
@@ -1498,8 +1808,22 @@ struct Renderer {
                                 rp[13] = (mm & MF_REFLECTED) ? 1u : 0u;
                             }
                         }
-                    } else if (rotation == 0) cmd_image(im, (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
-                    else cmd_image_rotated(rot_slot, im, (mm & MF_REFLECTED) != 0, r1, rotation, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                    } else if (rotation == 0) emit_image(r, l, d.assets->img[im], (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i));
+                    else if constexpr (GEN) {
+                        // a turned generated sprite: coverage and sampling come from the painter matrix (exec_generic_rotated works
+                        // them out again from the entity); here only a bounding box for the band test: the rect's circumcircle
+                        const double ccx = r1.x + r1.w / 2, ccy = r1.y + r1.h / 2, rad = 0.5 * pg_sqrt(r1.w * r1.w + r1.h * r1.h) + 2;
+                        int bx1 = (int)pg_floor(ccx - rad), bx2 = (int)pg_ceil(ccx + rad), by1 = (int)pg_floor(ccy - rad), by2 = (int)pg_ceil(ccy + rad);
+                        if (bx1 < 0) bx1 = 0;
+                        if (by1 < 0) by1 = 0;
+                        if (bx2 > RES_W) bx2 = RES_W;
+                        if (by2 > RES_H) by2 = RES_H;
+                        if (bx2 > bx1 && by2 > by1) {
+                            PG_LV(r.geom, l) = (uint32_t)bx1 | ((uint32_t)by1 << 7) | ((uint32_t)(bx2 - bx1) << 14) | ((uint32_t)(by2 - by1) << 21);
+                            PG_LV(r.basex, l) = (uint32_t)i;
+                            PG_LV(r.aux, l) = 1u << 15;
+                        }
+                    } else cmd_image_rotated(rot_slot, im, (mm & MF_REFLECTED) != 0, r1, rotation, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                 }
             }
         }
@@ -1513,9 +1837,10 @@ struct Renderer {
     static constexpr int CMD_SETS = GameRenderCmdSets<Game>::value;
     static_assert(CMD_SETS == 1 || CMD_SETS == 2, "one or two register sets");
     PG_DEV bool compact_entities(CmdRegs (&er)[CMD_SETS], uint64_t (&ezm)[CMD_SETS][3]) {
-        uint32_t *stage = fb;  // [8 words][64 * CMD_SETS slots]
+        uint32_t *stage = fb;  // [8 (GEN: 10) words][64 * CMD_SETS slots]
         constexpr int SLOTS = 64 * CMD_SETS;
         static_assert(8 * SLOTS <= BAND_ROWS * RES_W + 64, "staging area");
+        if constexpr (GEN && 10 * SLOTS > BAND_ROWS * RES_W + 64) return false;  // (two sets of ten-word commands do not fit: draw_entities() sets up per band)
         const int n = G.n_ents;
         int total = 0, rot_count = 0;
         for (int base = 0; base < n; base += 64) {
@@ -1538,6 +1863,10 @@ struct Renderer {
                     stage[5 * SLOTS + slot] = PG_LV(r.src, l);
                     stage[6 * SLOTS + slot] = PG_LV(r.aux, l);
                     stage[7 * SLOTS + slot] = ((zm[0] >> l) & 1ull) ? 0u : (((zm[1] >> l) & 1ull) ? 1u : 2u);
+                    if constexpr (GEN) {
+                        stage[8 * SLOTS + slot] = PG_LV(r.e0, l);
+                        stage[9 * SLOTS + slot] = PG_LV(r.e1, l);
+                    }
                 }
             }
             total += cnt;
@@ -1555,6 +1884,10 @@ struct Renderer {
                 PG_LV(er[k].iy, l) = in ? stage[4 * SLOTS + si] : 0u;
                 PG_LV(er[k].src, l) = in ? stage[5 * SLOTS + si] : 0u;
                 PG_LV(er[k].aux, l) = in ? stage[6 * SLOTS + si] : 0u;
+                if constexpr (GEN) {
+                    PG_LV(er[k].e0, l) = in ? stage[8 * SLOTS + si] : 0u;
+                    PG_LV(er[k].e1, l) = in ? stage[9 * SLOTS + si] : 0u;
+                }
             }
             _Pragma("unroll") for (int z = 0; z < 3; z++) ezm[k][z] = PG_BALLOT(l, (k * 64 + l) < total && stage[7 * SLOTS + k * 64 + l] == (uint32_t)z);
         }
@@ -1612,7 +1945,8 @@ struct Renderer {
         int bgt_ia = 0, bgt_ib = 0, bgt_img = 0;
         auto add_bg = [&](int bgi, const RectD &rc) {
             uint32_t g, bx, sy, ix, iy, sr, au;
-            cmd_image(bgi, false, rc, 1.0f, g, bx, sy, ix, iy, sr, au);
+            cmd_image(bgi, false, rc, 1.0f, g, bx, sy, ix, iy, sr, au);  // RGB32 source: the scale path also with generated assets
+            if (GEN) au |= 1u << 27;
             if (g != 0) {
                 if (nbg >= MAXBG) {
                     fail(PGE_UNSUPPORTED_DRAW);
@@ -1681,10 +2015,7 @@ struct Renderer {
         uint64_t ezmask[CMD_SETS][3];
         _Pragma("unroll") for (int k = 0; k < CMD_SETS; k++) {
             ezmask[k][0] = ezmask[k][1] = ezmask[k][2] = 0;
-            PG_FOR_LANES(l) {
-                PG_LV(er[k].geom, l) = 0;
-                PG_LV(er[k].basex, l) = PG_LV(er[k].srcy, l) = PG_LV(er[k].ix, l) = PG_LV(er[k].iy, l) = PG_LV(er[k].src, l) = PG_LV(er[k].aux, l) = 0;
-            }
+            PG_FOR_LANES(l) { clear_cmd(er[k], l); }
         }
         if (one_chunk) setup_entities(0, er[0], ezmask[0]);
         else if (!force_chunks) one_chunk = compact_entities(er, ezmask);
@@ -1705,7 +2036,8 @@ struct Renderer {
         const int nx = win_hx - win_lx + 1;
         const int ny_full = win_hy - win_ly + 1;
         const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
-        const bool use_axes = GameDrawsGrid<Game>::value && nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
+        // (GEN: every cell is its own generic drawImage, set up lane-parallel per band: neither axis tables nor the pull form)
+        const bool use_axes = !GEN && GameDrawsGrid<Game>::value && nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
         int ix_ref = 0, iy_ref = 0;
         uint64_t colseam = 0, rowseam = 0, rowany = ~0ull;
         phase(9);
@@ -1714,7 +2046,7 @@ struct Renderer {
         bool pull = false, pull_multi = false;
         int pull_nfill = 0, pull_ncell = nx * ny_full;
         if constexpr (GameDrawsGrid<Game>::value)
-            pull = use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, pull_multi, pull_nfill);
+            pull = !GEN && use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, pull_multi, pull_nfill);
 
         if (use_axes && !pull) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);  // only the per-cell path reads the axis tables
 
@@ -1747,6 +2079,7 @@ struct Renderer {
                         if (bgt_many) {
                             const RectD tr = {bgt_x, bgt_y + (double)(bgt_h * (bg_first + k)), bgt_w, (double)bgt_h};
                             cmd_image(bgt_img, false, tr, 1.0f, g, bx, sy, ix, iy, sr, au);
+                            if (GEN) au |= 1u << 27;
                         }
                     }
                     const DrawCmd bc = unpack(g, bx, sy, ix, iy, sr, au);
@@ -1802,8 +2135,7 @@ struct Renderer {
                 CmdRegs r;
                 PG_FOR_LANES(l) {
                     const int cidx = base + l;
-                    PG_LV(r.geom, l) = 0;
-                    PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = PG_LV(r.src, l) = PG_LV(r.aux, l) = 0;
+                    clear_cmd(r, l);
                     if (cidx < ncell) {
                         const int cx = (int)(((uint32_t)cidx * ny_inv) >> 20);  // cidx / ny (exact for cidx < 4096)
                         const int cy = cidx - cx * ny;
@@ -1863,7 +2195,7 @@ struct Renderer {
                                         }
                                     }
                                 } else {
-                                    cmd_image(im, false, r2, 1.0f, PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                                    emit_image(r, l, imd, false, r2, 1.0f);
                                 }
                             }
                         }

@@ -112,14 +112,6 @@ bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h
 
 }  // namespace
 
-uint32_t hash_str_uint32(const std::string &str) {  // reference src/vecgame.cpp:156-167
-    uint32_t hash = 0x811c9dc5u;
-    for (unsigned char c : str) {
-        hash ^= c;
-        hash *= 0x1000193u;
-    }
-    return hash;
-}
 
 bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvSnapshot &s, char *data, int length, int *written, std::string *err) {
     Writer w{data, 0, (size_t)(length < 0 ? 0 : length)};

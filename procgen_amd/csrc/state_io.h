@@ -23,5 +23,4 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
 // Parses a reference byte stream into the snapshot (sizes of s.ents / s.rng / s.grid must be pre-set).
 bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, const char *data, int length, std::string *err);
 
-uint32_t hash_str_uint32(const std::string &str);  // FNV-1a of a game name: fixed_asset_seed (reference src/vecgame.cpp:156-167,324-327)
 }  // namespace pgamd

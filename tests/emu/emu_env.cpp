@@ -13,6 +13,7 @@
 #include "games.h"
 #include "pg_math.h"
 #include "pg_assetgen.h"
+#include "pg_bgpaint.h"
 #include "pg_render.h"
 #include "host_state.h"
 #include "state_io.h"
@@ -34,6 +35,8 @@ struct EmuVec {
     std::vector<float> rew;
     HostAssets assets;
     std::vector<uint32_t> game_tables;
+    std::vector<uint32_t> gen_bg;  // use_generated_assets
+    std::vector<int> bg_req;
     int use_small;
     int dev_error = 0;
     int game_id = -1;
@@ -76,8 +79,24 @@ static void run_all(EmuVec *v, int mode) {
             run_env<Game, GameSplit<Game>::RESET_CAP>(v, e, mode);  // "reset_grid" / the tier-0 grid in mode 0
         }
     }
+    if (v->d.gen_bg) {  // "paint_backgrounds": the episodes that began this step
+        static BgPaintLds blds;
+        for (int e = 0; e < v->n; e++) {
+            const int skip = v->bg_req[2 * e + 1];
+            if (skip < 0) continue;
+            int err = 0;
+            paint_background(v->gen_bg.data() + (size_t)e * GEN_BG_WORDS, v->bg_req[2 * e], skip, &blds, &err);
+            v->bg_req[2 * e + 1] = -1;
+            if (err) v->dev_error |= PGE_ASSERT;
+        }
+    }
     static RenderLdsT<Game> rlds;
     for (int e = 0; e < v->n; e++) {  // "render kernel": one wave per env
+        if (v->d.gen_bg) {
+            Renderer<Game, true> r(v->d, e, &rlds);
+            r.render_env();
+            continue;
+        }
         Renderer<Game> r(v->d, e, &rlds);
         r.render_env();
     }
@@ -87,7 +106,7 @@ extern "C" {
 
 void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, int num_levels, int start_level, int distribution_mode,
                int center_agent, int use_backgrounds, int restrict_themes, int use_sequential_levels, int debug_mode, const char *resource_root,
-               const char *atlas_path, int use_small, int use_monochrome_assets, int paint_vel_info) {
+               const char *atlas_path, int use_small, int use_monochrome_assets, int paint_vel_info, int use_generated_assets) {
     EmuVec *v = new EmuVec();
     v->n = num_envs;
     v->use_small = use_small;
@@ -104,7 +123,14 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     }
     v->game_id = game_id;
     v->kernel_id = gid;
-    if (!load_game_assets(game_id, resource_root ? resource_root : "", atlas_path ? atlas_path : "", &v->assets, &err)) {
+    if (use_generated_assets) {
+        bool (*block)(int) = nullptr;
+#define PG_X(Game) \
+    if (gid == Game::GAME_ID) block = GameBlockAsset<Game>::is;
+        PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
+        generate_game_assets(game, block, &v->assets);
+    } else if (!load_game_assets(game_id, resource_root ? resource_root : "", atlas_path ? atlas_path : "", &v->assets, &err)) {
         fprintf(stderr, "emu: %s\n", err.c_str());
         return nullptr;
     }
@@ -140,6 +166,7 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.opt.restrict_themes = restrict_themes;
     d.opt.use_monochrome_assets = use_monochrome_assets;
     d.opt.paint_vel_info = paint_vel_info;
+    d.opt.use_generated_assets = use_generated_assets;
     d.opt.distribution_mode = distribution_mode;
     d.opt.use_sequential_levels = use_sequential_levels;
     d.opt.debug_mode = debug_mode;
@@ -164,6 +191,12 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.assets = &v->assets.table;
     d.pixels = v->assets.pixels.data();
     d.error = &v->dev_error;
+    if (use_generated_assets) {
+        v->gen_bg.assign((size_t)num_envs * GEN_BG_WORDS, 0u);
+        v->bg_req.assign((size_t)num_envs * 2, -1);
+        d.gen_bg = v->gen_bg.data();
+        d.bg_req = v->bg_req.data();
+    }
     v->game_tables.assign(1024, 0);
     int nw = 0;
 #define PG_X(Game) \
@@ -298,6 +331,7 @@ void emu_generated_background(int seed, uint32_t *out250000) {
     assetgen::Gen<EmuMT, assetgen::MemPainter> gen{rng, mp};
     gen.generate_resource(500, 500, 1, 50, true);
 }
+void emu_dump_background(void *h, int env, uint32_t *out) { memcpy(out, ((EmuVec *)h)->gen_bg.data() + (size_t)env * GEN_BG_WORDS, sizeof(uint32_t) * GEN_BG_WORDS); }
 long long emu_counter(int k) { return pg_emu_counters()[k]; }
 void emu_path_counts(void *h, long long *out) {
     EmuVec *v = (EmuVec *)h;

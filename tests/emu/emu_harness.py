@@ -42,7 +42,7 @@ def lib():
         build()
         L = C.CDLL(LIB)
         L.emu_make.restype = C.c_void_p
-        L.emu_make.argtypes = [C.c_char_p] + [C.c_int] * 11 + [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.emu_make.argtypes = [C.c_char_p] + [C.c_int] * 11 + [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.emu_free.argtypes = [C.c_void_p]
         L.emu_init.argtypes = [C.c_void_p]
         L.emu_step.argtypes = [C.c_void_p, C.c_void_p]
@@ -61,7 +61,7 @@ def lib():
 class EmuEnv:
     def __init__(self, num, env_name, rand_seed=0, env_offset=0, num_levels=0, start_level=0, distribution_mode=1,
                  center_agent=True, use_backgrounds=True, restrict_themes=False, use_sequential_levels=False, debug_mode=0,
-                 resource_root=None, atlas_path=None, use_small=True, use_monochrome_assets=False, paint_vel_info=False):
+                 resource_root=None, atlas_path=None, use_small=True, use_monochrome_assets=False, paint_vel_info=False, use_generated_assets=False):
         self.L = lib()
         self.num = num
         if atlas_path is None:
@@ -70,7 +70,7 @@ class EmuEnv:
             resource_root = "/root/reference/procgen/data/assets/"
         self.h = C.c_void_p(self.L.emu_make(env_name.encode(), num, rand_seed, env_offset, num_levels, start_level, distribution_mode,
                                             int(center_agent), int(use_backgrounds), int(restrict_themes), int(use_sequential_levels),
-                                            debug_mode, resource_root.encode(), atlas_path.encode(), int(use_small), int(use_monochrome_assets), int(paint_vel_info)))
+                                            debug_mode, resource_root.encode(), atlas_path.encode(), int(use_small), int(use_monochrome_assets), int(paint_vel_info), int(use_generated_assets)))
         assert self.h, "emu_make failed"
         self.rgb = np.zeros((num, 64, 64, 3), np.uint8)
         self.rew = np.zeros(num, np.float32)

@@ -151,7 +151,36 @@ def option_matrix(n=6, t_steps=60):
     return res
 
 
+def generated_assets(n=4, t_steps=60):
+    """use_generated_assets=True (reference src/assetgen.cpp, BAG:79-123,769-773): <game>/{rew, first, level_seed, crc} for all 16 games
+    plus, for four of them, every frame of env 0 (so that a failing CRC can be looked at)."""
+    res = {}
+    for game in ALL_GAMES:
+        env = ref_env.make_ref_env(n, game, rand_seed=19, use_generated_assets=True)
+        rng = np.random.RandomState(2)
+        out = {k: [] for k in ("rew", "first", "level_seed", "crc")}
+        frames = []
+        for t in range(t_steps + 1):
+            rew, ob, first = env.observe()
+            out["rew"].append(rew.copy())
+            out["first"].append(first.astype(np.uint8))
+            out["level_seed"].append(env.info_arrays()["level_seed"].copy())
+            out["crc"].append(np.array([zlib.crc32(ob["rgb"][e].tobytes()) for e in range(n)], dtype=np.uint32))
+            frames.append(ob["rgb"][0].copy())
+            env.act(rng.randint(0, 15, size=(n,), dtype=np.int32))
+        env.close()
+        for k, v in out.items():
+            res[f"{game}/{k}"] = np.array(v)
+        if game in ("coinrun", "starpilot", "fruitbot", "caveflyer"):
+            res[f"{game}/frames0"] = np.array(frames)
+    return res
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["generated"]:
+        np.savez_compressed(os.path.join(HERE, "generated_assets.npz"), **generated_assets())
+        print("generated-assets fixture done")
+        sys.exit(0)
     if sys.argv[1:] == ["options"]:
         np.savez_compressed(os.path.join(HERE, "option_matrix.npz"), **option_matrix())
         print("option matrix done")

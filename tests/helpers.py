@@ -75,3 +75,19 @@ def check_against_option_matrix(g, make, pairs):
         got = rollout(make(game, n, **OPTION_SETS[name]), action_stream(n, steps, seed=1))
         for k in ("rew", "first", "level_seed", "crc"):
             assert np.array_equal(got[k], g[f"{game}/{name}/{k}"]), (game, name, k)
+
+def check_against_generated_assets_fixture(g, make, games):
+    """make(game, n, use_generated_assets=True) -> env; rew / first / level_seed / frame CRCs of tests/golden/generated_assets.npz
+    (compiled reference, make_golden.py generated)."""
+    for game in games:
+        n = g[f"{game}/rew"].shape[1]
+        steps = g[f"{game}/rew"].shape[0] - 1
+        got = rollout(make(game, n, use_generated_assets=True), action_stream(n, steps, seed=2), keep_frames=f"{game}/frames0" in g.files)
+        for k in ("rew", "first", "level_seed"):
+            assert np.array_equal(got[k], g[f"{game}/{k}"]), (game, k)
+        bad = np.argwhere(got["crc"] != g[f"{game}/crc"])
+        if len(bad) and f"{game}/frames0" in g.files:
+            t = int(bad[0][0])
+            diff = (np.asarray(got["frames"][t][0]) != g[f"{game}/frames0"][t]).any(-1).sum()
+            assert False, (game, "frame CRC", len(bad), "first at step", t, "env-0 pixels differing there:", int(diff))
+        assert len(bad) == 0, (game, "frame CRC", len(bad), bad[:4])

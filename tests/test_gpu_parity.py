@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle_env
-from helpers import HIP_LIB, action_stream, assert_rollouts_equal, check_against_option_matrix, hip_memcpy_dtoh, rollout
+from helpers import HIP_LIB, action_stream, assert_rollouts_equal, check_against_generated_assets_fixture, check_against_option_matrix, hip_memcpy_dtoh, rollout
 
 pytestmark = pytest.mark.gpu
 
@@ -286,3 +286,19 @@ def test_forced_reset_action(game):
     b = rollout(make_env(n, game), acts)
     assert_rollouts_equal(a, b, f"forced resets ({game})")
     assert a["first"][1:].sum() > 50
+
+
+def test_generated_assets_match_reference_fixture(golden_dir):
+    """use_generated_assets=True on all 16 games against tests/golden/generated_assets.npz (compiled reference): host-painted sprites,
+    backgrounds painted by the paint_backgrounds kernel, the GEN render kernels."""
+    g = np.load(os.path.join(golden_dir, "generated_assets.npz"))
+    check_against_generated_assets_fixture(g, lambda game, n, **kw: make_env(n, game, rand_seed=19, **kw), GAMES)
+
+
+def test_generated_assets_refuse_state_io():
+    """BasicAbstractGame::serialize / deserialize fassert(!options.use_generated_assets) (BAG:1176,1238): a fatal exit, as in the reference."""
+    code = ("import sys; sys.path.insert(0, %r); from procgen_amd import ProcgenGym3Env; e = ProcgenGym3Env(2, 'coinrun', use_generated_assets=True); e.observe(); "
+            "e.callmethod('get_state')") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import subprocess, sys
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "use_generated_assets" in (r.stdout + r.stderr)

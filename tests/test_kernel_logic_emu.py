@@ -11,7 +11,7 @@ import pytest
 
 import emu_harness
 import oracle_env
-from helpers import action_stream, assert_rollouts_equal, check_against_option_matrix, rollout
+from helpers import action_stream, assert_rollouts_equal, check_against_generated_assets_fixture, check_against_option_matrix, rollout
 
 
 def test_rollout_and_state_round_trip_through_the_emulated_kernels():
@@ -275,3 +275,36 @@ def test_product_qt_path_header_matches_qt_pixels(golden_dir):
         L.emu_qt_path_ellipse(x, y, w, h, 1, 0, out.ctypes.data)
         assert np.array_equal(out == 2, pen_only[i]), ("pen", i, (x, y, w, h))
     assert checked > 1000
+
+
+@pytest.mark.parametrize("games", [["coinrun", "starpilot"], ["fruitbot", "caveflyer", "chaser"], ["jumper", "bossfight", "leaper", "heist"]])
+def test_emulated_generated_assets_match_reference_fixture(golden_dir, games):
+    """use_generated_assets=True through the kernel sources: sprites painted on the host at handle creation (pg_assetgen.h), the reset
+    path consuming the background generator's draws, the background kernel's painter (pg_bgpaint.h) and the GEN renderer."""
+    g = np.load(os.path.join(golden_dir, "generated_assets.npz"))
+    check_against_generated_assets_fixture(g, lambda game, n, **kw: emu_harness.EmuEnv(n, game, rand_seed=19, **kw), games)
+
+
+def test_host_painted_sprites_and_device_style_backgrounds_equal_the_oracles():
+    """pg_assetgen.h on the host (what libenv_make uploads) against the oracle's restatement: every object type of four games,
+    and a few backgrounds from a generator seeded alike."""
+    L = emu_harness.lib()
+    O = oracle_env.lib()
+    O.pgo_test_generated_asset.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    O.pgo_test_generated_background.argtypes = [C.c_int, C.c_void_p]
+    L.emu_generated_asset.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+    L.emu_generated_background.argtypes = [C.c_int, C.c_void_p]
+    for game in ("coinrun", "leaper", "dodgeball", "miner"):
+        gid = O.pgo_game_id(game.encode())
+        for t in range(100):
+            a = np.zeros(4096, np.uint32)
+            b = np.zeros(4096, np.uint32)
+            O.pgo_test_generated_asset(gid, t, a.ctypes.data)
+            L.emu_generated_asset(game.encode(), t, b.ctypes.data)
+            assert np.array_equal(a, b), (game, t)
+    for seed in (1, 77, 123456789):
+        a = np.zeros(250000, np.uint32)
+        b = np.zeros(250000, np.uint32)
+        O.pgo_test_generated_background(seed, a.ctypes.data)
+        L.emu_generated_background(seed, b.ctypes.data)
+        assert np.array_equal(a, b), seed

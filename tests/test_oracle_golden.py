@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_env
-from helpers import action_stream, assert_rollouts_equal, check_against_option_matrix, rollout
+from helpers import action_stream, assert_rollouts_equal, check_against_generated_assets_fixture, check_against_option_matrix, rollout
 
 
 GAMES = ["coinrun", "bigfish", "maze", "climber", "miner", "starpilot", "fruitbot", "leaper", "plunder", "heist", "ninja", "dodgeball", "bossfight", "chaser", "caveflyer", "jumper"]
@@ -133,3 +133,10 @@ def test_oracle_ellipse_restatement_matches_qt_pixels(golden_dir):
         assert np.array_equal(out == 1, brush_only[i]), ("brush", i, (x, y, w, h))
         L.pgo_test_draw_ellipse(x, y, w, h, 1, 0, out.ctypes.data)
         assert np.array_equal(out == 2, pen_only[i]), ("pen", i, (x, y, w, h))
+
+
+def test_oracle_with_generated_assets_matches_reference_fixture(golden_dir):
+    """use_generated_assets=True on all 16 games: AssetGen's painter (fillRect, path / midpoint ellipses), the per-episode 500 x 500
+    backgrounds drawn from rand_gen inside game_reset, and Qt's generic span route for the ARGB32 sprites (rotated ones included)."""
+    g = np.load(os.path.join(golden_dir, "generated_assets.npz"))
+    check_against_generated_assets_fixture(g, lambda game, n, **kw: oracle_env.OracleEnv(n, game, rand_seed=19, **kw), GAMES)
