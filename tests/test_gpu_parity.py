@@ -298,7 +298,7 @@ def test_generated_assets_match_reference_fixture(golden_dir):
 def test_generated_assets_refuse_state_io():
     """BasicAbstractGame::serialize / deserialize fassert(!options.use_generated_assets) (BAG:1176,1238): a fatal exit, as in the reference."""
     code = ("import sys; sys.path.insert(0, %r); from procgen_amd import ProcgenGym3Env; e = ProcgenGym3Env(2, 'coinrun', use_generated_assets=True); e.observe(); "
-            "e.callmethod('get_state')") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            "e.get_state()") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import subprocess, sys
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "use_generated_assets" in (r.stdout + r.stderr)
