@@ -14,7 +14,14 @@
  *                               logical vector of envs over several GPUs / processes
  *   "host_observations"  uint8  1 (default): libenv_observe lands `ob` in the caller's host buffers, as the
  *                               ABI requires; 0: observations stay in HBM (read them through
- *                               procgen_amd_device_buffers), rew/first/info are still landed on the host
+ *                               procgen_amd_device_buffers / procgen_amd_part_buffers), rew/first/info are
+ *                               still landed on the host
+ *   "num_devices"        int32  one handle sharded over that many GPUs of this node (0 = all visible ones;
+ *                               default 1, or $PROCGEN_AMD_NUM_DEVICES): device g owns the contiguous global
+ *                               index range [g * N / G, (g + 1) * N / G); with a comma separated env_name of
+ *                               K games each range is a multiple of K and env n plays names[n % K] whatever
+ *                               the sharding (reference src/vecgame.cpp:295-310).  No collective: every
+ *                               device lands its slice of the caller's buffers.
  */
 #ifndef PROCGEN_AMD_H
 #define PROCGEN_AMD_H
@@ -40,8 +47,21 @@ struct procgen_amd_buffers {
     int32_t *action;              /* [num_envs] actions of the step in flight (written by libenv_act) */
 };
 
-/* fills *out; returns 0 */
+/* fills *out; returns 0.  Single-game, single-device handles only (one part); see procgen_amd_part_buffers. */
 LIBENV_API int procgen_amd_device_buffers(libenv_env *handle, struct procgen_amd_buffers *out);
+
+/* A handle is G device shards x K games = G * K parts (one per game per device; a single-game single-device handle
+ * is one part).  Part p's device arrays hold its envs densely: its env i is global env  first_env + i * env_stride
+ * (env_stride = K).  This is the reader of the observations of joint / multi-device handles with
+ * host_observations = 0 (BASELINE configs[3] / [4] in device-resident mode). */
+struct procgen_amd_part {
+    struct procgen_amd_buffers buffers; /* device_id, num_envs (of the part), stream, ob, rew, ... as above */
+    int first_env;                      /* global index of the part's env 0 */
+    int env_stride;                     /* global indices between two consecutive envs of the part */
+    char game[LIBENV_MAX_NAME_LEN];     /* the game the part's envs play */
+};
+/* returns the number of parts; fills out[0 .. min(max_parts, parts)) when out is not NULL */
+LIBENV_API int procgen_amd_part_buffers(libenv_env *handle, struct procgen_amd_part *out, int max_parts);
 /* switch the D2H landing of observations on/off after construction (same meaning as the option) */
 LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable);
 /* Runs `steps` steps back to back entirely on the device (actions: [steps][num_envs] int32 on the HOST, or

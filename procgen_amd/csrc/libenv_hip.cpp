@@ -332,7 +332,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         const char *lr = getenv("LOCAL_RANK");
         device_id = lr ? atoi(lr) % ndev : 0;
     }
-    if (getenv("PROCGEN_AMD_FAKE_DEVICES")) device_id %= ndev;  // testing aid: several "devices" of a handle on the GPUs there are
+    if (getenv("PROCGEN_AMD_FAKE_DEVICES") && forced_device >= 0) device_id %= ndev;  // testing aid: the shards of a multi-device handle on the GPUs there are (an explicit device_id is never wrapped)
     if (device_id >= ndev) fatal("device_id %d out of range (%d devices)\n", device_id, ndev);
     HIP_CHECK(hipSetDevice(device_id));
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -784,7 +784,11 @@ struct Handle {
 // queue run their kernels one after the other.  A joint handle has one stream per game: with 16 queues its 16-game step
 // takes 1.7 ms instead of 2.5.  The variable is read when the runtime initialises, so this only
 // helps when the library is loaded before the process's first HIP call; an explicit setting is left alone.
-__attribute__((constructor)) static void procgen_amd_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// PROCGEN_AMD_KEEP_HW_QUEUES=1 leaves the variable alone (it changes the stream-to-queue mapping of every HIP user of the process).
+__attribute__((constructor)) static void procgen_amd_default_hw_queues() {
+    const char *keep = getenv("PROCGEN_AMD_KEEP_HW_QUEUES");
+    if (!(keep && atoi(keep) != 0)) setenv("GPU_MAX_HW_QUEUES", "16", 0);
+}
 
 // relative length of one step of a ~1000-env part (profiles/r02_joint_kernel_trace.csv: the slowest kernel chain per game)
 static int part_cost_rank(const std::string &name) {
@@ -817,11 +821,15 @@ LIBENV_API libenv_env *libenv_make(int num_envs, const struct libenv_options opt
     h->num_envs = num_envs;
     std::string env_name;
     int num_devices = 1, device_id = -1;
+    bool devices_from_env = false;
     {
         VecOptions peek(options);
         peek.consume_string("env_name", &env_name);
         const bool has_dev = peek.consume_int("device_id", &device_id);
-        if (!peek.consume_int("num_devices", &num_devices) && !has_dev && getenv("PROCGEN_AMD_NUM_DEVICES")) num_devices = atoi(getenv("PROCGEN_AMD_NUM_DEVICES"));
+        if (!peek.consume_int("num_devices", &num_devices) && !has_dev && getenv("PROCGEN_AMD_NUM_DEVICES")) {
+            num_devices = atoi(getenv("PROCGEN_AMD_NUM_DEVICES"));
+            devices_from_env = true;
+        }
     }
     const std::vector<std::string> names = split_names(env_name);
     const int K = (int)names.size();
@@ -829,6 +837,12 @@ LIBENV_API libenv_env *libenv_make(int num_envs, const struct libenv_options opt
         if (hipGetDeviceCount(&num_devices) != hipSuccess || num_devices <= 0) fatal("no HIP device available: the MI355X stepper cannot run (there is no CPU fallback)\n");
     }
     if (num_devices < 1) fatal("num_devices must be positive (or 0 for all visible devices)\n");
+    if (devices_from_env && num_devices > 1 && num_envs % (num_devices * K) != 0) {
+        // the environment variable shards every handle of the process; one that cannot be cut evenly (a 1-env evaluation
+        // env next to the training vector) stays on one device instead of failing
+        fprintf(stderr, "procgen_amd: PROCGEN_AMD_NUM_DEVICES=%d ignored for a handle of %d envs (not a multiple of %d x %d games): one device\n", num_devices, num_envs, num_devices, K);
+        num_devices = 1;
+    }
     if (K > 1 && num_envs % K != 0) fatal("fassert failed 'num_envs %% num_joint_games == 0'\n");
     h->map.num_envs = num_envs;
     h->map.num_devices = num_devices;
@@ -858,6 +872,15 @@ LIBENV_API libenv_env *libenv_make(int num_envs, const struct libenv_options opt
         for (int p : h->order)
             h->parts[p].reset(new VecGame(h->map.envs_per_part(), VecOptions(options), names[h->map.game_of_part(p)], K, h->map.first_env(p),
                                           num_devices > 1 ? first_device + h->map.device_of_part(p) : -1));
+        {
+            // one stream per part: with the runtime's default of four hardware queues the parts of a 16-game handle run four deep
+            const char *q = getenv("GPU_MAX_HW_QUEUES");
+            static bool warned = false;
+            if (!warned && h->P() > 4 && (!q || atoi(q) < 8)) {
+                warned = true;
+                fprintf(stderr, "procgen_amd: %d parts on %s hardware queues: set GPU_MAX_HW_QUEUES=16 before the process's first HIP call (INTEGRATION.md section 5) for ~1.5x on joint handles\n", h->P(), q ? q : "the default 4");
+            }
+        }
         int threads = h->P() < 8 ? h->P() : 8;
         if (const char *t = getenv("PROCGEN_AMD_HOST_THREADS")) threads = atoi(t);
         if (threads > 1) h->pool.reset(new PartPool(threads));
@@ -962,6 +985,28 @@ LIBENV_API int procgen_amd_device_buffers(libenv_env *handle, struct procgen_amd
     out->level_seed = v->d.level_seed;
     out->action = v->d_action;
     return 0;
+}
+LIBENV_API int procgen_amd_part_buffers(libenv_env *handle, struct procgen_amd_part *out, int max_parts) {
+    Handle *h = (Handle *)handle;
+    for (int p = 0; out && p < h->P() && p < max_parts; p++) {
+        VecGame *v = h->parts[p].get();
+        procgen_amd_buffers &b = out[p].buffers;
+        b.device_id = v->device_id;
+        b.num_envs = v->num_envs;
+        b.stream = (void *)v->stream;
+        b.ob = v->d.obs;
+        b.rew = v->d.rew;
+        b.first = v->d.first;
+        b.prev_level_seed = v->d.prev_level_seed;
+        b.prev_level_complete = v->d.prev_level_complete;
+        b.level_seed = v->d.level_seed;
+        b.action = v->d_action;
+        out[p].first_env = h->P() == 1 ? 0 : h->map.first_env(p);
+        out[p].env_stride = h->P() == 1 ? 1 : h->map.num_games;
+        memset(out[p].game, 0, sizeof(out[p].game));
+        strncpy(out[p].game, game_name_from_id(v->game_id), sizeof(out[p].game) - 1);
+    }
+    return h->P();
 }
 LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable) {
     VecGame *v = ((Handle *)handle)->single();

@@ -159,7 +159,10 @@ class CEnv:
             pad = -(-(item + buffer_padding) // np.dtype(t.dtype).itemsize) * np.dtype(t.dtype).itemsize
             store = np.zeros((n, pad), dtype=np.uint8)
             self._stores.append(store)
-            return store[:, :item].view(t.dtype).reshape((n,) + t.shape)  # a strided view: env e starts at e * pad bytes
+            # a strided view: env e starts at e * pad bytes (built from the buffer directly: .view() on a non-contiguous
+            # array needs numpy >= 1.23)
+            inner = np.zeros(t.shape, dtype=t.dtype).strides
+            return np.ndarray((n,) + tuple(t.shape), dtype=t.dtype, buffer=store, strides=(pad,) + tuple(inner))
 
         self._ob = {t.name: alloc(t) for t in self.ob_types}
         self._ac = {t.name: alloc(t) for t in self.ac_types}

@@ -211,3 +211,28 @@ def test_one_handle_sharded_over_devices_equals_the_single_device_handle(monkeyp
     assert env2.get_state() == sts
     env.close()
     env2.close()
+    # device-resident reader of a multi-part handle (procgen_amd_part_buffers): 2 shards x 3 games = 6 parts whose dense
+    # device arrays, read back part by part, are the frames the same handle lands on the host
+    class Part(C.Structure):
+        _fields_ = [("buffers", DeviceBuffers), ("first_env", C.c_int), ("env_stride", C.c_int), ("game", C.c_char * 128)]
+
+    env = make_env(n, ",".join(names), extra_options={"num_devices": 2})
+    for t in range(5):
+        env.act(acts[t])
+    rew, ob, first = env.observe()
+    env._lib.procgen_amd_part_buffers.argtypes = [C.c_void_p, C.POINTER(Part), C.c_int]
+    env._lib.procgen_amd_part_buffers.restype = C.c_int
+    assert env._lib.procgen_amd_part_buffers(env._handle, None, 0) == 6
+    parts = (Part * 6)()
+    assert env._lib.procgen_amd_part_buffers(env._handle, parts, 6) == 6
+    seen = np.zeros(n, bool)
+    for p in parts:
+        m = p.buffers.num_envs
+        idx = p.first_env + p.env_stride * np.arange(m)
+        assert m == n // 6 and p.env_stride == 3 and p.game.decode() == names[p.first_env % 3]
+        dev_ob = hip_memcpy_dtoh(p.buffers.ob, m * 64 * 64 * 3).reshape(m, 64, 64, 3)
+        dev_rew = hip_memcpy_dtoh(p.buffers.rew, m * 4).view(np.float32)
+        assert np.array_equal(dev_ob, ob["rgb"][idx]) and np.array_equal(dev_rew, rew[idx])
+        seen[idx] = True
+    assert seen.all()
+    env.close()

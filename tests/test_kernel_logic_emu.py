@@ -308,3 +308,19 @@ def test_host_painted_sprites_and_device_style_backgrounds_equal_the_oracles():
         O.pgo_test_generated_background(seed, a.ctypes.data)
         L.emu_generated_background(seed, b.ctypes.data)
         assert np.array_equal(a, b), seed
+
+
+def test_no_capacity_or_draw_shape_exit_under_the_accepted_option_surface():
+    """The renderer's fail(PGE_UNSUPPORTED_DRAW) / capacity exits are not reference semantics and one env reaching one ends the whole
+    handle: every (game, distribution_mode, center_agent) the reference accepts, 6 envs x 120 steps, no device error word.  (The
+    full sweep -- 64 envs x 2000 steps per configuration -- is tests/tools/draw_limits_sweep.py; DESIGN.md has its last result.)"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("draw_limits_sweep", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "draw_limits_sweep.py"))
+    sweep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sweep)
+    n = 0
+    for game, mode, center in sweep.configs():
+        assert sweep.run(game, mode, center, 6, 120, 13) == [], (game, mode, center)
+        n += 1
+    assert n == 2 * (16 * 2 + 4 + 6)
