@@ -219,9 +219,11 @@ struct Jumper : BagDefaults<Jumper> {
         JP_FACING_RIGHT(G) = 1;
         const int maze_dim = w / MAZE_SCALE;
         PG_SYNC();
+        e.mark(0);  // bag_game_reset, reseed
         {
             MazeGenDev<E> mg(e, e.s->scratch.maze, maze_dim);
             mg.generate_maze_no_dead_ends();
+            e.mark(1);  // maze
             for (int base = 0; base < n; base += 64) {  // one draw per cell; walls of the 3x maze are solid with p = .8, corridors with p = .2
                 PG_LANE_VAR(uint32_t, u);
                 e.rand_u32_lanes((n - base) < 64 ? (n - base) : 64, u);
@@ -238,6 +240,7 @@ struct Jumper : BagDefaults<Jumper> {
             PG_SYNC();
         }
         G.grid_dirty = 1;
+        e.mark(2);  // 3x blow-up with per-cell draws
         RoomGenDev<E, 45 * 45> rg(e, e.s->scratch.room);
         auto &m = e.s->scratch.room;
         for (int it = 0; it < 2; it++) rg.update();
@@ -245,7 +248,9 @@ struct Jumper : BagDefaults<Jumper> {
         e.fill_elem(0, h - 1, w, 1, CAVEWALL);
         e.fill_elem(0, 0, 1, h, CAVEWALL);
         e.fill_elem(w - 1, 0, 1, h, CAVEWALL);
+        e.mark(3);  // cellular automaton x 2, border
         const int best = rg.find_best_room();  // flags in f2
+        e.mark(4);  // find_best_room
         if (best <= 0) {
             e.fail(PGE_ASSERT);
             return;
@@ -265,7 +270,9 @@ struct Jumper : BagDefaults<Jumper> {
             return;
         }
         const int agent_cell = nth_index(e, e.randn(ncand), [&](int i) { return is_space_on_ground(e, i % w, i / w); });
+        e.mark(5);  // goal / agent cells
         rg.find_path(agent_cell, goal_cell, m.f3, m.f0);
+        e.mark(6);  // find_path
         if (dm != MemoryMode) {  // should_prune
             rg.copy(m.f1, m.f3);
             rg.expand_room(m.f1, 4, m.f0, m.f2);
@@ -276,6 +283,7 @@ struct Jumper : BagDefaults<Jumper> {
             }
             PG_SYNC();
         }
+        e.mark(7);  // expand_room
         e.add_entity((float)((goal_cell % w) + .5), (float)((goal_cell / w) + .5), 0, 0, (float).5, GOAL);  // spawn_entity_at_idx BAG:577-583
         const float spike_prob = dm == MemoryMode ? 0.0f : (float).2;
         // spikes: a placed spike can only disqualify later cells, so candidates are balloted per chunk and re-checked at the visit
@@ -296,6 +304,7 @@ struct Jumper : BagDefaults<Jumper> {
                 }
             }
         }
+        e.mark(8);  // spikes
         // long vertical walls are broken up; an opened cell can create new walls further on, so the chunk's candidates
         // are re-balloted after every change
         for (int base = 0; base < n; base += 64) {
@@ -325,6 +334,7 @@ struct Jumper : BagDefaults<Jumper> {
                 if (from >= 64) break;
             }
         }
+        e.mark(9);  // vertical walls
         const int ag = G.agent;
         e.ex(ag) = (float)((agent_cell % w) + .5);
         e.ey(ag) = (agent_cell / w) + e.ery(ag);

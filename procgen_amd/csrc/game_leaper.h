@@ -227,7 +227,66 @@ struct Leaper : BagDefaults<Leaper> {
         // left it exactly where it was, the remaining rounds only need Entity::step for every entity (a reset used to
         // take 1.5 ms of a lone wave, almost all of it the agent's 400 object steps).
         bool agent_idle = false;
-        for (int i = 0; i < lim; i++) {
+        int total_rounds = (int)lim;  // for (int i = 0; i < lim; i++)
+        if ((float)total_rounds < lim) total_rounds++;
+        for (int i = 0; i < total_rounds; i++) {
+            if (agent_idle) {
+                // Rounds in which no lane makes a spawn attempt (most of them: the attempt probability is a few percent per
+                // lane) consist of one draw per lane and one Entity::step per entity.  The draws of the next 64 / L rounds are
+                // looked at together (wave lane j = round j / L, road / water lane j % L); the leading attempt-free rounds are
+                // then taken at once: their draws skipped, every entity stepped that many times inside one lane section.
+                const int L = LP_N_ROAD(G) + LP_N_WATER(G);
+                int R = L > 0 ? 64 / L : 64;
+                if (R > total_rounds - i) R = total_rounds - i;
+                int k = 0;
+                PG_LANE_VAR(uint32_t, u);
+                if (L == 0) {
+                    k = R;
+                } else if (R > 1 && e.rand_peek_lanes(R * L, u)) {
+                    const int n_road = LP_N_ROAD(G);
+                    const float r0 = pg_opaque_f(G.gsf0), r1 = pg_opaque_f(G.gsf1), r2 = pg_opaque_f(G.gsf2), r3 = pg_opaque_f(G.gsf3), r4 = pg_opaque_f(G.gsf4);
+                    const float w0 = pg_opaque_f(G.gsf5), w1 = pg_opaque_f(G.gsf6), w2 = pg_opaque_f(G.gsf7);
+                    const float w3 = __builtin_bit_cast(float, pg_opaque_i(G.gsi5)), w4 = __builtin_bit_cast(float, pg_opaque_i(G.gsi6));
+                    const uint32_t inv = (uint32_t)(((1u << 16) + (uint32_t)L - 1u) / (uint32_t)L);  // j / L for j < 64
+                    const uint64_t attempts = PG_BALLOT(l, ({
+                                                            bool a = false;
+                                                            if (l < R * L) {
+                                                                const int lane = l - (int)(((uint32_t)l * inv) >> 16) * L;
+                                                                const bool car = lane < n_road;
+                                                                const int kk = car ? lane : lane - n_road;
+                                                                const float speed = car ? (kk == 0 ? r0 : (kk == 1 ? r1 : (kk == 2 ? r2 : (kk == 3 ? r3 : r4))))
+                                                                                        : (kk == 0 ? w0 : (kk == 1 ? w1 : (kk == 2 ? w2 : (kk == 3 ? w3 : w4))));
+                                                                const float spawn_prob = (float)(pg_fabs((double)speed) / (car ? 6.0 : 2.0));
+                                                                a = (float)((double)PG_LV(u, l) / 4294967296.0) < spawn_prob;
+                                                            }
+                                                            a;
+                                                        }));
+                    k = attempts == 0 ? R : (int)(((uint32_t)pg_ctz64(attempts) * inv) >> 16);
+                }
+                if (k > 0) {
+                    e.rand_skip(k * L);
+                    const int n = G.n_ents, a = G.agent;
+                    for (int base = 0; base < n; base += 64) {
+                        PG_FOR_LANES(l) {
+                            const int idx = base + l;
+                            if (idx < n) {
+                                if (idx == a) {
+                                    for (int t = 0; t < k; t++) e.ent_step(idx);
+                                } else {
+                                    float x = e.ex(idx);
+                                    const float vx = e.evx(idx);
+                                    for (int t = 0; t < k; t++) x += vx;
+                                    e.ex(idx) = x;
+                                    e.ei(EF_LIFE_TIME, idx) += k;
+                                }
+                            }
+                        }
+                    }
+                    PG_SYNC();
+                    i += k - 1;
+                    continue;
+                }
+            }
             spawn_entities(e);
             PG_SYNC();
             if (agent_idle) {

@@ -446,6 +446,11 @@ VecGame::~VecGame() {
                 const double denom = k == 6 ? (double)(pc[15] ? pc[15] : 1) : (double)pc[14];
                 fprintf(stderr, "  %-22s %10.1f\n", names[k], (double)pc[k] / denom);
             }
+            if ((d.debug_flags & 16) && pc[15] > 0) {  // Env::mark: level-generator stages (game_*.h game_reset), wave cycles per reset
+                fprintf(stderr, "[reset marks, wave cycles per reset]\n");
+                for (int k = 0; k < 15; k++)
+                    if (pc[16 + k]) fprintf(stderr, "  mark %-2d %12.1f\n", k, (double)pc[16 + k] / (double)pc[15]);
+            }
             if (pc[31] > 0) {
                 static const char *rn[11] = {"set-up: pull tables", "clear + background", "entities z=-1", "grid cells", "entities z=0,1 + hud", "store band",
                                              "set-up: header", "set-up: background", "set-up: entities", "set-up: window + axes", "set-up: type table"};

@@ -236,6 +236,11 @@ struct Env {
 #endif
     }
 
+    // profiling aid for level generators (PROCGEN_AMD_DEBUG = 2048 + 16: the render kernel is off and its counter slots are free):
+    // wave cycles since the previous mark / phase go to slot 16 + j; printed at libenv_close as "reset marks"
+    PG_DEV void mark(int j) {
+        if (d.debug_flags & 16) phase(16 + j);
+    }
     PG_DEV Env(const DevCtx &d_, int env_, LdsT *s_) : d(d_), env(env_), s(s_) {
         rg_home = d.rng + (size_t)env * MT_SLOTS * MT_STRIDE;
         rg_cur = rg_home;
@@ -469,7 +474,7 @@ struct Env {
         G.rand_idx += 1;
         return mt_temper(z);
     }
-    // The next `count` (<= 32) rand_gen draws WITHOUT consuming them: lane l < count gets the l-th (tempered); false when they
+    // The next `count` (<= 64) rand_gen draws WITHOUT consuming them: lane l < count gets the l-th (tempered); false when they
     // would cross a twist (the caller then draws one at a time).  rand_skip consumes draws seen this way.
     PG_DEV bool rand_peek_lanes(int count, PG_LANE_REF(uint32_t, out)) {
         const int idx = G.rand_idx;
