@@ -148,10 +148,13 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
         }
         G.grid_dirty = 1;
         PG_SYNC();
+        e.mark(0);  // bag_game_reset, random fill
         RoomGenDev<E, MAX_CELLS> rg(e, e.s->scratch);
         auto &m = e.s->scratch;
-        for (int it = 0; it < 4; it++) rg.update();
+        rg.update_rows(4, nullptr);
+        e.mark(1);  // cellular automaton x 4
         const int best = rg.find_best_room();  // flags in f2
+        e.mark(2);  // find_best_room
         if (best <= 0) {
             e.fail(PGE_ASSERT);
             return;
@@ -173,10 +176,12 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
         e.set_flag(goal, MF_COLLIDES, true);
         PG_SYNC();
         // goal path (flags in f3, kept until the end), covered flags in f0
+        e.mark(3);  // agent / goal cells
         rg.find_path(agent_cell, goal_cell, m.f3, m.f0);
+        e.mark(4);  // find_path
         if (e.d.opt.distribution_mode != MemoryMode) {  // should_prune: keep the path widened by 4 rings
             rg.copy(m.f1, m.f3);
-            rg.expand_room(m.f1, 4, m.f0, m.f2);
+            rg.expand_room(m.f1, 4);
             for (int base = 0; base < n; base += 64) {
                 PG_FOR_LANES(l) {
                     if (base + l < n) e.s->grid[base + l] = (cell_t)(m.f1[base + l] ? SPACE : WALL_OBJ);
@@ -184,15 +189,9 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
             }
             PG_SYNC();
         }
-        for (int it = 0; it < 4; it++) {
-            rg.update();
-            for (int base = 0; base < n; base += 64) {
-                PG_FOR_LANES(l) {
-                    if (base + l < n && m.f3[base + l]) e.s->grid[base + l] = (cell_t)SPACE;
-                }
-            }
-            PG_SYNC();
-        }
+        e.mark(5);  // expand_room
+        rg.update_rows(4, m.f3);  // four passes, the path put back to SPACE after each
+        e.mark(6);  // smoothing
         for (int base = 0; base < n; base += 64) {  // path -> MARKER, remaining walls -> CAVEWALL
             PG_FOR_LANES(l) {
                 if (base + l < n) {
@@ -202,6 +201,7 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
             }
         }
         PG_SYNC();
+        e.mark(7);  // markers, cave walls
         const int nfree = e.count_cells([](int v) { return v == SPACE; });
         const int chunk_size = nfree / 80;
         const int num_objs = 3 * chunk_size;
@@ -234,6 +234,7 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
             }
         }
         PG_SYNC();
+        e.mark(8);  // objects
         G.out_of_bounds_object = CAVEWALL;
         G.visibility = e.d.opt.distribution_mode == EasyMode ? 10.0f : 16.0f;
         G.grid_dirty = 1;

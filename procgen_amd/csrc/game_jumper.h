@@ -243,7 +243,7 @@ struct Jumper : BagDefaults<Jumper> {
         e.mark(2);  // 3x blow-up with per-cell draws
         RoomGenDev<E, 45 * 45> rg(e, e.s->scratch.room);
         auto &m = e.s->scratch.room;
-        for (int it = 0; it < 2; it++) rg.update();
+        rg.update_rows(2, nullptr);
         e.fill_elem(0, 0, w, 1, CAVEWALL);  // border cells
         e.fill_elem(0, h - 1, w, 1, CAVEWALL);
         e.fill_elem(0, 0, 1, h, CAVEWALL);
@@ -275,7 +275,7 @@ struct Jumper : BagDefaults<Jumper> {
         e.mark(6);  // find_path
         if (dm != MemoryMode) {  // should_prune
             rg.copy(m.f1, m.f3);
-            rg.expand_room(m.f1, 4, m.f0, m.f2);
+            rg.expand_room(m.f1, 4);
             for (int base = 0; base < n; base += 64) {
                 PG_FOR_LANES(l) {
                     if (base + l < n) e.s->grid[base + l] = (cell_t)(m.f1[base + l] ? SPACE : CAVEWALL);

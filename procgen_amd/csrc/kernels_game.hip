@@ -80,11 +80,16 @@ __global__ __launch_bounds__(64) void reset_list(DevCtx d, int chunk, int env_ba
 template <class Game, bool GEN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GameRenderMinWaves<PG_GAME>::value))) void render(DevCtx d, int env_base) {
     __shared__ RenderLdsT<Game> lds;
+    if (d.clear_lists && blockIdx.x == 0 && threadIdx.x < LIST_COUNTERS) const_cast<int *>(d.big_count)[threadIdx.x] = 0;
     Renderer<Game, GEN> r(d, env_base + (int)blockIdx.x, &lds);
     r.render_env();
 }
+// clear_lists: this is the step's render of env 0 (every list kernel of the step is done when a render kernel starts); a
+// hipMemsetAsync per step instead was two fill kernels, each tens of microseconds on a busy device with many handles
 template <class Game>
-static void launch_render(const DevCtx &d, int env_base, int count, hipStream_t st) {
+static void launch_render(const DevCtx &d0, int env_base, int count, hipStream_t st, bool clear_lists = false) {
+    DevCtx d = d0;
+    d.clear_lists = clear_lists ? 1 : 0;
     if (d.gen_bg) hipLaunchKernelGGL((render<Game, true>), dim3(count), dim3(64), 0, st, d, env_base);
     else hipLaunchKernelGGL((render<Game, false>), dim3(count), dim3(64), 0, st, d, env_base);
 }
@@ -123,7 +128,7 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
             if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode, 0);
         }
         PG_TRY(launch_paint_backgrounds(d, 0, d.num_envs, ls.main));
-        if (!(d.debug_flags & 16)) launch_render<Game>(d, 0, d.num_envs, ls.main);
+        if (!(d.debug_flags & 16)) launch_render<Game>(d, 0, d.num_envs, ls.main, true);
         return hipGetLastError();
     }
     // At most four streams: the runtime deals a process's streams round-robin onto four hardware queues, and two streams on one
@@ -175,7 +180,7 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
             if (mode != 0) hipLaunchKernelGGL(reset_list<Game>, dim3(count < 1024 ? count : 1024), dim3(64), 0, st, d, c, base);
         }
         PG_TRY(launch_paint_backgrounds(d, base, count, st));  // (after the list kernels: their envs lie in every chunk)
-        if (!(d.debug_flags & 16)) launch_render<Game>(d, base, count, st);
+        if (!(d.debug_flags & 16)) launch_render<Game>(d, base, count, st, c == 0);
     }
     for (int k = 0; k < 2; k++) {
         PG_TRY(hipEventRecord(ls.lane_done[k], ls.lane[k]));

@@ -529,15 +529,15 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
     launch(0);  // initial reset + first frame (reference src/vecgame.cpp:346-357)
 }
 
-// the device work of one step: counter memset + the step / reset / render kernels (what procgen_amd_time_steps brackets)
+// the device work of one step: the step / reset / render kernels (what procgen_amd_time_steps brackets)
 void VecGame::launch_kernels(int mode) {
     if (route_dirty) flush_routes();
     route_mirror_valid = false;
     bind_routing();
-    {   // next counts + error are adjacent in either parity: [A | error] or [error | B]
-        int *first = d.next_big_count < d.error ? d.next_big_count : d.error;
-        HIP_CHECK(hipMemsetAsync(first, 0, (LIST_COUNTERS + 1) * sizeof(int), stream));
-    }
+    // The next lists' counters are zero already: they were the lists the step before read, and its render kernel cleared them
+    // (DevCtx::clear_lists).  The error word is never cleared: the first error ends the run.  Only with the render kernel
+    // switched off for profiling does the host clear them.
+    if (d.debug_flags & 16) HIP_CHECK(hipMemsetAsync(d.next_big_count, 0, LIST_COUNTERS * sizeof(int), stream));
     LaunchStreams ls = streams();
     for (int c = 0; c < MAX_CHUNKS; c++)
         for (int t = 0; t < NUM_TIERS; t++) ls.list_count[c][t] = mode == 0 ? 0 : host_list_count[c][t];

@@ -166,7 +166,7 @@ struct DevCtx {
     const int *big_list;   // [NUM_TIERS][num_envs] env ids the list kernels handle this step
     const int *big_count;  // [MAX_CHUNKS][NUM_TIERS]
     int *next_big_list;    // filled during this step
-    int *next_big_count;   // zeroed by the host before the step
+    int *next_big_count;   // zero when the step starts: the render kernel of the step before cleared them (they were its big_count)
     int chunk_envs;        // envs per chunk (a multiple of TILE_ENVS)
     // tier that owns each env THIS step (written during the previous step, so it is stable while the step kernels of
     // the three tiers run concurrently: an env re-routed by a fast kernel is not picked up again by a slower one)
@@ -178,7 +178,8 @@ struct DevCtx {
     int *reset_list;        // [num_envs]: the envs of chunk c are appended from index c * reset_chunk_envs on
     int *reset_count;       // [MAX_CHUNKS] per env chunk, this step
     int *next_reset_count;  // [MAX_CHUNKS] the next step's counters (double-buffered by step parity), zeroed by this step's lane kernel
-    int *error;            // [1] OR of the per-env error codes raised this step (0 = none)
+    int *error;            // [1] OR of the per-env error codes raised so far (0 = none; sticky: the host stops at the first one)
+    int clear_lists;       // render kernel: zero big_count[] (nobody reads it any more this step; it is the next step's next_big_count)
     unsigned long long *phase_cycles;  // [4096][32] PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step (0-15) and render (16-31) kernels (null otherwise)
     int debug_flags;       // PROCGEN_AMD_DEBUG: phase ablation bits for profiling only (0 in normal operation)
 };

@@ -94,40 +94,78 @@ struct MazeGenDev {
             const int lo = w * 64;
             alive[w] = nw >= lo + 64 ? ~0ull : (nw > lo ? ((1ull << (nw - lo)) - 1ull) : 0ull);
         }
+        // a lone wave pays for every instruction of this loop in full, so it is kept short: the draws come 64 at a time with
+        // their moduli taken in the lanes, and only the live words of the mask are looked at
+        PG_LANE_VAR(int, draws);
         for (int remaining = nw; remaining > 0; remaining--) {
-            int n = e.randn(remaining);
-            // n-th alive wall in original order == walls[n] of the reference's shrinking vector
-            int widx = 0;
+            const int done = nw - remaining;
+            if ((done & 63) == 0) {
+                PG_LANE_VAR(uint32_t, u);
+                const int cnt = remaining < 64 ? remaining : 64;
+                e.rand_u32_lanes(cnt, u);
+                PG_FOR_LANES(l) { PG_LV(draws, l) = l < cnt ? (int)(PG_LV(u, l) % (uint32_t)(remaining - l)) : 0; }  // randn(walls.size())
+            }
+            int n = PG_READLANE(draws, done & 63);
+            // n-th alive wall in original order == walls[n] of the reference's shrinking vector: word by popcounts, bit by a
+            // six-step select
+            uint64_t word = 0;
+            int wsel = 0;
+            bool found = false;
             _Pragma("unroll") for (int w = 0; w < 8; w++) {
-                const int c = pg_popc64(alive[w]);
-                if (n >= 0) {
+                if (!found && w * 64 < nw) {
+                    const int c = pg_popc64(alive[w]);
                     if (n < c) {
-                        uint64_t word = alive[w];
-                        for (int k = 0; k < n; k++) word &= word - 1;
-                        const int b = pg_ctz64(word);
-                        widx = w * 64 + b;
-                        alive[w] &= ~(1ull << b);
-                        n = -1;
+                        word = alive[w];
+                        wsel = w;
+                        found = true;
                     } else {
                         n -= c;
                     }
                 }
             }
-            const uint32_t wall = m.walls[widx];
+            int pos = 0;
+            _Pragma("unroll") for (int width = 32; width >= 1; width >>= 1) {
+                const int c = pg_popc64((word >> pos) & ((1ull << width) - 1ull));
+                if (n >= c) {
+                    n -= c;
+                    pos += width;
+                }
+            }
+            _Pragma("unroll") for (int w = 0; w < 8; w++) {
+                if (w == wsel) alive[w] &= ~(1ull << pos);
+            }
+            const uint32_t wall = (uint32_t)PG_UNIFORM_I(m.walls[wsel * 64 + pos]);
             const int x1 = (int)(wall & 31u), y1 = (int)((wall >> 5) & 31u), x2 = (int)((wall >> 10) & 31u), y2 = (int)((wall >> 15) & 31u);
-            const int s0_idx = (int)m.label[md * y1 + x1];
-            const int s1_idx = (int)m.label[md * y2 + x2];
             const int x0 = (x1 + x2) / 2, y0 = (y1 + y2) / 2;
             const int center = md * y0 + x0;
-            const bool can_remove = grid_at(x0 + MAZE_OFFSET, y0 + MAZE_OFFSET) == WALL_OBJ && s0_idx != s1_idx;
+            const int g1 = (y1 + MAZE_OFFSET) * ad + x1 + MAZE_OFFSET, g0 = (y0 + MAZE_OFFSET) * ad + x0 + MAZE_OFFSET, g2 = (y2 + MAZE_OFFSET) * ad + x2 + MAZE_OFFSET;
+            // one LDS trip for everything the decision needs
+            const int s0_idx = (int)m.label[md * y1 + x1];
+            const int s1_idx = (int)m.label[md * y2 + x2];
+            const int o1 = (int)m.mgrid[g1], o2 = (int)m.mgrid[g2];
+            const int s0u = PG_UNIFORM_I(s0_idx), s1u = PG_UNIFORM_I(s1_idx);
+            // (the wall's own cell is still a wall: every wall comes up once, and nothing else opens it)
+            const bool can_remove = s0u != s1u;
             if (can_remove) {
-                set_free_cell(x1, y1);
-                set_free_cell(x0, y0);
-                set_free_cell(x2, y2);
+                // set_free_cell(x1, y1), (x0, y0), (x2, y2) mazegen.cpp:26-34 in one go (the centre is a wall, so it is new)
+                const bool new1 = PG_UNIFORM_I(o1) != SPACE, new2 = PG_UNIFORM_I(o2) != SPACE;
+                const int nf = num_free_cells;
+                PG_FOR_LANES(l) {
+                    if (l == 0) {
+                        m.mgrid[g1] = (uint16_t)SPACE;
+                        m.mgrid[g0] = (uint16_t)SPACE;
+                        m.mgrid[g2] = (uint16_t)SPACE;
+                        int k = nf;
+                        if (new1) m.free_cells[k++] = (uint16_t)(md * y1 + x1);
+                        m.free_cells[k++] = (uint16_t)center;
+                        if (new2) m.free_cells[k++] = (uint16_t)(md * y2 + x2);
+                    }
+                }
+                num_free_cells = nf + 1 + (new1 ? 1 : 0) + (new2 ? 1 : 0);
                 for (int base = 0; base < md * md; base += 64) {
                     PG_FOR_LANES(l) {
                         const int i = base + l;
-                        if (i < md * md && ((int)m.label[i] == s0_idx || i == center)) m.label[i] = (uint16_t)s1_idx;
+                        if (i < md * md && ((int)m.label[i] == s0u || i == center)) m.label[i] = (uint16_t)s1u;
                     }
                 }
                 PG_SYNC();
@@ -241,21 +279,31 @@ struct MazeGenDev {
         return n;
     }
 
-    PG_DEV void generate_maze_no_dead_ends() {  // mazegen.cpp:189-209: sequential (each opened wall changes later neighbour counts)
+    // mazegen.cpp:189-209: sequential (each opened wall changes later neighbour counts, and an opened cell further on is
+    // itself visited).  The dead ends of a 64-cell chunk are found with one ballot over the grid as it stands; after every
+    // opened wall the rest of the chunk is balloted again, so each visit sees what the reference's cell-by-cell walk sees.
+    PG_DEV void generate_maze_no_dead_ends() {
         generate_maze();
+        e.mark(10);
         const int nc = array_dim * array_dim;
-        for (int i = 0; i < nc; i++) {
-            if (get_obj_u(i) != SPACE) continue;
-            int adj[4];
-            if (get_neighbors(i, SPACE, adj) == 1) {
+        for (int base = 0; base < nc; base += 64) {
+            int from = 0;
+            for (;;) {
+                const uint64_t dead = PG_BALLOT(l, l >= from && (base + l) < nc && get_obj(base + l) == SPACE && count_neighbors(base + l, SPACE) == 1 &&
+                                                       count_neighbors(base + l, WALL_OBJ) > 0);
+                if (!dead) break;
+                const int lane = pg_ctz64(dead);
+                const int i = base + lane;
                 int wl[4];
                 const int nw = get_neighbors(i, WALL_OBJ, wl);
-                if (nw > 0) {
-                    const int n = e.randn(nw);
-                    const int cell = n == 0 ? wl[0] : (n == 1 ? wl[1] : (n == 2 ? wl[2] : wl[3]));
-                    m.mgrid[cell] = (uint16_t)SPACE;
-                    PG_SYNC();
+                const int n = e.randn(nw);
+                const int cell = n == 0 ? wl[0] : (n == 1 ? wl[1] : (n == 2 ? wl[2] : wl[3]));
+                PG_FOR_LANES(l) {
+                    if (l == 0) m.mgrid[cell] = (uint16_t)SPACE;
                 }
+                PG_SYNC();
+                from = lane + 1;
+                if (from >= 64) break;
             }
         }
     }

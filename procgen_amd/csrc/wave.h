@@ -82,6 +82,11 @@ PG_DEV uint32_t pg_atomic_or(uint32_t *p, uint32_t v) {
 PG_DEV int pg_popc64(uint64_t m) { return __builtin_popcountll(m); }
 PG_DEV int pg_clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
 PG_DEV int pg_ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
+PG_DEV uint64_t pg_brev64(uint64_t m) {
+    uint64_t r = 0;
+    for (int i = 0; i < 64; i++) r |= ((m >> i) & 1ull) << (63 - i);
+    return r;
+}
 PG_DEV double pg_sqrt(double x) { return sqrt(x); }
 PG_DEV double pg_floor(double x) { return floor(x); }
 PG_DEV float pg_floorf(float x) { return floorf(x); }
@@ -133,6 +138,7 @@ PG_DEV uint32_t pg_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 PG_DEV int pg_popc64(uint64_t m) { return __popcll(m); }
 PG_DEV int pg_clz64(uint64_t m) { return m ? __clzll((long long)m) : 64; }
 PG_DEV int pg_ctz64(uint64_t m) { return m ? (__ffsll((long long)m) - 1) : 64; }
+PG_DEV uint64_t pg_brev64(uint64_t m) { return __brevll(m); }
 PG_DEV double pg_sqrt(double x) { return __builtin_sqrt(x); }   // IEEE correctly rounded (no fast-math)
 PG_DEV double pg_floor(double x) { return __builtin_floor(x); }
 PG_DEV float pg_floorf(float x) { return __builtin_floorf(x); }

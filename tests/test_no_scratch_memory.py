@@ -16,8 +16,8 @@ import pytest
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "procgen_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
-GAMES = ["CoinRun", "Plunder", "Leaper", "FruitBot"]
-SPLIT_RESET = {"Leaper"}
+GAMES = ["CoinRun", "Plunder", "Leaper", "FruitBot", "Jumper", "CaveFlyer"]
+SPLIT_RESET = {"Leaper", "Jumper", "CaveFlyer"}
 
 
 def _scratch_bytes(game, tmp):
@@ -27,9 +27,9 @@ def _scratch_bytes(game, tmp):
     text = open(out).read()
     names = re.findall(r"^\s+\.name:\s+(\S+)", text, re.M)
     sizes = [int(x) for x in re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", text, re.M)]
-    # step_tier0, two step_list tiers, render; games with split resets (pg_env.h GameSplit) add reset_grid and reset_list
+    # step_tier0, two step_list tiers, render for baked and for generated assets; games with split resets (pg_env.h GameSplit) add reset_grid and reset_list
     kinds = sorted(re.sub(r"^_ZN5pgamd\d+([a-z_0-9]+?)I.*$", r"\1", n) for n in names)
-    expect = ["render", "step_list", "step_list", "step_tier0"] + (["reset_grid", "reset_list"] if game in SPLIT_RESET else [])
+    expect = ["render", "render", "step_list", "step_list", "step_tier0"] + (["reset_grid", "reset_list"] if game in SPLIT_RESET else [])
     assert len(names) == len(sizes) and kinds == sorted(expect), (game, names)
     return dict(zip(names, sizes))
 
