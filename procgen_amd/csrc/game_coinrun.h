@@ -102,6 +102,19 @@ struct CoinRun {
         }
         return is_blocked(e, e.etype(src), ttype, is_horizontal);  // BAG:494-496
     }
+    static constexpr bool BLOCKED_ENTS_HAS_EFFECT = true;  // (is_on_crate above)
+    template <class E>
+    PG_DEV static bool is_blocked_ents_peek(E &e, int src, int target, bool is_horizontal) {  // the predicate without the write
+        const int ttype = e.etype(target);
+        if (ttype == CRATE && !is_horizontal) {
+            const int ag = e.G.agent;
+            if (e.evy(ag) >= 0) return false;
+            if (e.G.action_vy < 0) return false;
+            if (CR_LAST_AGENT_Y(e.G) < (e.ey(target) + e.ery(target) + e.ery(ag))) return false;
+            return true;
+        }
+        return is_blocked(e, e.etype(src), ttype, is_horizontal);
+    }
     // superset of the (obj type, entity type) pairs for which is_blocked_ents or will_reflect can be true
     template <class E>
     PG_DEV static bool may_interact(E &e, int src_type, int target_type, bool is_horizontal) {

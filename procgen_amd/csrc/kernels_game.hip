@@ -17,6 +17,23 @@
 
 namespace pgamd {
 
+// profiling aid (PROCGEN_AMD_DEBUG & 8192): when was this env's workgroup resident, and where.  Per env 32 words:
+// [0] step start, [1] step end (100 MHz clock), [2] kernel kind << 32 | HW_ID; [3] first; [4], [5], [6] the same for the render kernel; [8..23] this step's phase cycles (with & 2048)
+__device__ inline void trace_wave(const DevCtx &d, int env, int base, bool end, int kind) {
+    if (d.wave_trace && threadIdx.x == 0) {
+        unsigned long long *t = d.wave_trace + (size_t)env * 32 + base;
+        if (end) {
+            t[1] = wall_clock64();
+            if (base == 0) t[3] = d.first[env];
+        } else {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            t[0] = wall_clock64();
+            t[2] = ((unsigned long long)kind << 32) | hw;
+        }
+    }
+}
+
 // Occupancy hint of the render kernel (RENDER_MIN_WAVES in a policy); the default leaves the register allocation alone.
 // Tried for coinrun (133 -> 128 VGPRs, a fourth wave per SIMD): +2..4 % steps/s, but the 104 B of spill per lane showed
 // up as +54 % WRITE_SIZE, so no policy sets it.
@@ -36,10 +53,14 @@ template <class Game>
 __global__ __launch_bounds__(64) void step_tier0(DevCtx d, int mode, int env_base) {
     __shared__ typename StepEnv<Game, Game::ENT_CAP_T0>::LdsT lds;
     if (GameSplit<Game>::value && blockIdx.x == 0 && threadIdx.x == 0) d.next_reset_count[d.reset_first > 0 ? (env_base >= d.reset_first ? 1 : 0) : env_base / d.reset_chunk_envs] = 0;
+    // (a resident grid walking the chunk with a stride was tried: the loop form costs 60 VGPRs -- 121 -> 181, two waves per SIMD
+    // instead of four -- and the dispatcher keeps the arenas full anyway, tools/gpu/micro/residency.hip)
     const int env = env_base + (int)blockIdx.x;
     if (mode != 0 && d.route[env] != 0) return;  // owned by a larger arena this step
+    trace_wave(d, env, 0, false, 0);
     StepEnv<Game, Game::ENT_CAP_T0> e(d, env, &lds);
     e.run(mode);
+    trace_wave(d, env, 0, true, 0);
 }
 
 // SPLIT_RESET games: the initial reset + first observation of every env (mode 0) needs the level generator's arena
@@ -58,9 +79,11 @@ __global__ __launch_bounds__(64) void step_list(DevCtx d, int mode, int chunk) {
     for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
         const int env = list[k];
         if (d.route[env] != TIER) continue;  // set_state moved this env to another tier after the list was built
+        trace_wave(d, env, 0, false, TIER);
         StepEnv<Game, CAP> e(d, env, &lds);
         e.run(mode);
         __syncthreads();
+        trace_wave(d, env, 0, true, TIER);
     }
 }
 
@@ -81,8 +104,10 @@ template <class Game, bool GEN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GameRenderMinWaves<PG_GAME>::value))) void render(DevCtx d, int env_base) {
     __shared__ RenderLdsT<Game> lds;
     if (d.clear_lists && blockIdx.x == 0 && threadIdx.x < LIST_COUNTERS) const_cast<int *>(d.big_count)[threadIdx.x] = 0;
+    trace_wave(d, env_base + (int)blockIdx.x, 4, false, 8);
     Renderer<Game, GEN> r(d, env_base + (int)blockIdx.x, &lds);
     r.render_env();
+    trace_wave(d, env_base + (int)blockIdx.x, 4, true, 8);
 }
 // clear_lists: this is the step's render of env 0 (every list kernel of the step is done when a render kernel starts); a
 // hipMemsetAsync per step instead was two fill kernels, each tens of microseconds on a busy device with many handles

@@ -426,6 +426,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     }
     d.debug_flags = getenv("PROCGEN_AMD_DEBUG") ? atoi(getenv("PROCGEN_AMD_DEBUG")) : 0;
     if (d.debug_flags & 2048) d.phase_cycles = dev_alloc<unsigned long long>(32 * 4096);
+    if (d.debug_flags & 8192) d.wave_trace = dev_alloc<unsigned long long>(N * 32);
     HIP_CHECK(hipHostMalloc((void **)&h_action, N * 4 + 16, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_small, small_bytes + 16, hipHostMallocDefault));
 }
@@ -433,6 +434,17 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
 VecGame::~VecGame() {
     (void)hipSetDevice(device_id);
     if (stream) (void)hipStreamSynchronize(stream);
+    if (d.wave_trace) {  // PROCGEN_AMD_DEBUG & 8192: residency trace of the last step's workgroups -> $PROCGEN_AMD_TRACE_FILE (tools/gpu/wave_trace.py reads it)
+        std::vector<unsigned long long> raw((size_t)num_envs * 32);
+        const char *path = getenv("PROCGEN_AMD_TRACE_FILE");
+        if (hipMemcpy(raw.data(), d.wave_trace, raw.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(path ? path : "wave_trace.bin", "wb")) {
+                fwrite(raw.data(), 8, raw.size(), f);
+                fclose(f);
+            }
+        }
+        (void)hipFree(d.wave_trace);
+    }
     if (d.phase_cycles) {  // PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step kernels, per env-step
         std::vector<unsigned long long> raw(32 * 4096);
         unsigned long long pc[32] = {0};

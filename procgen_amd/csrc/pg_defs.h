@@ -180,6 +180,7 @@ struct DevCtx {
     int *next_reset_count;  // [MAX_CHUNKS] the next step's counters (double-buffered by step parity), zeroed by this step's lane kernel
     int *error;            // [1] OR of the per-env error codes raised so far (0 = none; sticky: the host stops at the first one)
     int clear_lists;       // render kernel: zero big_count[] (nobody reads it any more this step; it is the next step's next_big_count)
+    unsigned long long *wave_trace;    // [num_envs][32] PROCGEN_AMD_DEBUG & 8192: 100 MHz timestamps of the last step's workgroups: step start / end / kind+HW_ID, render start / end / HW_ID (null otherwise)
     unsigned long long *phase_cycles;  // [4096][32] PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step (0-15) and render (16-31) kernels (null otherwise)
     int debug_flags;       // PROCGEN_AMD_DEBUG: phase ablation bits for profiling only (0 in normal operation)
 };

@@ -184,6 +184,18 @@ struct GameHasBlockHook<Game, decltype((void)Game::HAS_BLOCK_HOOK)> {
     static constexpr bool value = Game::HAS_BLOCK_HOOK;
 };
 
+// BLOCKED_ENTS_HAS_EFFECT and is_blocked_ents_peek(e, src, target, h): the game's is_blocked_ents writes game state (coinrun's
+// is_on_crate); the peek is the same predicate without the write (Env::push_fixed_point asks before it knows the reference
+// would have asked)
+template <class Game, class = void>
+struct GameBlockedEntsEffect {
+    static constexpr bool value = false;
+};
+template <class Game>
+struct GameBlockedEntsEffect<Game, decltype((void)Game::BLOCKED_ENTS_HAS_EFFECT)> {
+    static constexpr bool value = Game::BLOCKED_ENTS_HAS_EFFECT;
+};
+
 #define PG_SYNC_E() PG_SYNC()  // memory ordering between two lane sections of the wave that owns this env
 
 // WITH_SCRATCH = false: the arena of a step kernel that never generates a level (games with SPLIT_RESET, see GameSplit)
@@ -229,6 +241,7 @@ struct Env {
         if (d.phase_cycles) {
             const long long t = (long long)__builtin_readcyclecounter();
             if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + k + 32 * (env & 4095), (unsigned long long)(t - t_mark));
+            if (d.wave_trace && PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.wave_trace + (size_t)env * 32 + 8 + k, (unsigned long long)(t - t_mark));  // this env, this step
             t_mark = (long long)__builtin_readcyclecounter();
         }
 #else
@@ -236,6 +249,14 @@ struct Env {
 #endif
     }
 
+    // profiling aid (PROCGEN_AMD_DEBUG & 8192): per-env counters of this step in the trace record (slots 24..31)
+    PG_DEV void trace_add(int k, unsigned long long v) {
+#if !defined(PGAMD_WAVE_EMU)
+        if (d.wave_trace && d.phase_cycles && PG_LANE_ID() == 0) d.wave_trace[(size_t)env * 32 + 24 + k] += v;
+#else
+        (void)k; (void)v;
+#endif
+    }
     // profiling aid for level generators (PROCGEN_AMD_DEBUG = 2048 + 16: the render kernel is off and its counter slots are free):
     // wave cycles since the previous mark / phase go to slot 16 + j; printed at libenv_close as "reset marks"
     PG_DEV void mark(int j) {
@@ -573,6 +594,135 @@ struct Env {
 
     // ======================================================================================================
     // sub_step / push_obj: BAG:240-372.  The recursion (depth <= 5) is unrolled through the template depth.
+    // ---- pruning the push recursion ----------------------------------------------------------------------------------
+    // An object that touches k blocking entities at once (coinrun's agent on a pile of crates) is pushed out by each of them
+    // at every level of the recursion: sub_step -> k x push_obj -> k x sub_step ... down to depth 5, ~k^5 calls, nearly all of
+    // them asking for a displacement of zero from a position that no longer changes.  On a CPU that is microseconds; a lone
+    // wave spent 1.3 M cycles on it (0.55 ms: 500 pushes in one env-step, 0.19 % of coinrun's env-steps -- and every step of
+    // 65 536 envs waited for those, profiles/r03_wave_residency_*.txt).
+    // The recursion only ever moves the object that is stepping (push_obj's target is the scanning object), and the hooks it
+    // consults are functions of that object's x, y, vx, vy and of values that are constant while it steps (their only side
+    // effect, coinrun's is_on_crate = 1, is idempotent).  So a nested sub_step is a function of (x, y, vx, vy, displacement,
+    // depth), and one that ran without changing a bit of the object is a no-op: so is the same call again from the same state
+    // at the same or a deeper level (induction over the remaining depth: it makes the same probes, finds the same hits, and
+    // its own nested calls are the same calls one level further down).  Such calls are remembered (8 records in the upper
+    // half of the lane scratch) and skipped; everything else runs as before.  PUSH_MEMO_OK: no hook writes entity words.
+    static constexpr bool PUSH_MEMO_OK = !GameHasBlockHook<Game>::value;
+    uint32_t push_chg = 0;  // times the recursion changed a bit of the stepping object
+    int memo_n = 0;         // records in use (reset per object step)
+    PG_DEV void obj_write(float &ref, float v) {
+        if (__builtin_bit_cast(uint32_t, (float)ref) != __builtin_bit_cast(uint32_t, v)) {
+            ref = v;
+            push_chg++;
+        }
+    }
+    // record r = s->tmp[64 + 8 r ..]: x, y, vx, vy, displacement (bit patterns), axis | depth << 1
+    PG_DEV bool memo_hit(int obj, float disp, bool is_horizontal, int depth) {
+        if (memo_n == 0) return false;
+        const uint32_t bx = __builtin_bit_cast(uint32_t, (float)ex(obj)), by = __builtin_bit_cast(uint32_t, (float)ey(obj));
+        const uint32_t bvx = __builtin_bit_cast(uint32_t, (float)evx(obj)), bvy = __builtin_bit_cast(uint32_t, (float)evy(obj));
+        const uint32_t bd = __builtin_bit_cast(uint32_t, disp);
+        const int n = memo_n < 8 ? memo_n : 8;
+        return PG_BALLOT(l, ({
+                             bool hit = false;
+                             if (l < n) {
+                                 const uint32_t *r = s->tmp + 64 + 8 * l;
+                                 hit = r[0] == bx && r[1] == by && r[2] == bvx && r[3] == bvy && r[4] == bd && (int)(r[5] & 1u) == (is_horizontal ? 1 : 0) && (int)(r[5] >> 1) <= depth;
+                             }
+                             hit;
+                         })) != 0;
+    }
+    PG_DEV void memo_insert(int obj, float disp, bool is_horizontal, int depth) {
+        const uint32_t bx = __builtin_bit_cast(uint32_t, (float)ex(obj)), by = __builtin_bit_cast(uint32_t, (float)ey(obj));
+        const uint32_t bvx = __builtin_bit_cast(uint32_t, (float)evx(obj)), bvy = __builtin_bit_cast(uint32_t, (float)evy(obj));
+        uint32_t *r = s->tmp + 64 + 8 * (memo_n & 7);
+        PG_FOR_LANES(l) {
+            if (l == 0) {
+                r[0] = bx; r[1] = by; r[2] = bvx; r[3] = bvy;
+                r[4] = __builtin_bit_cast(uint32_t, disp);
+                r[5] = (is_horizontal ? 1u : 0u) | ((uint32_t)depth << 1);
+            }
+        }
+        memo_n++;
+        PG_SYNC_E();
+    }
+
+    // The fixed point of the recursion, recognised before descending: inside sub_step(obj, a) at a depth >= 1 whose grid half
+    // changed nothing, if every entity the scan would visit blocks `obj` and would push it by exactly `a` again (same axis, same
+    // displacement bits -- in practice zero) and the velocity component a push clears is already +0, then every nested call is
+    // this same call at the same state one level down; at depth 5 it makes no nested calls and changes nothing, so by induction
+    // none of them changes anything at any depth.  The k^5 (or, for one hit, 5) nested calls are skipped; the hook's side
+    // effects are applied in visiting order.  Returns true when the scan is settled that way (block2 = true).
+    PG_DEV bool peek_blocked(int obj, int j, bool is_horizontal) {
+        if constexpr (GameBlockedEntsEffect<Game>::value) return Game::is_blocked_ents_peek(*this, obj, j, is_horizontal);
+        else return Game::is_blocked_ents(*this, obj, j, is_horizontal);
+    }
+    PG_DEV bool push_fixed_point(int obj, float _vx, float _vy, bool is_horizontal, int scan_axes, int otype, float orx, float ory) {
+        const int n = ((scan_axes >> (is_horizontal ? 0 : 1)) & 1) ? G.n_ents : 0;
+        if (n == 0) return false;
+        if (__builtin_bit_cast(uint32_t, (float)(is_horizontal ? evx(obj) : evy(obj))) != 0u) return false;
+        const float cx = ex(obj), cy = ey(obj);
+        const uint32_t dispb = __builtin_bit_cast(uint32_t, is_horizontal ? _vx : _vy);
+        bool any = false;
+        for (int c = (n - 1) >> 6; c >= 0; c--) {
+            // per lane: 0 = not visited, 1 = blocks and pushes by `a` again, 2 = anything else
+            PG_LANE_VAR(int, code);
+            PG_FOR_LANES(l) {
+                const int idx = (c << 6) + l;
+                int cd = 0;
+                if (idx < n && idx != obj) {
+                    const uint32_t mm = meta(idx);
+                    if (!(mm & MF_WILL_ERASE) && Game::may_interact(*this, otype, meta_type(mm), is_horizontal)) {
+                        const float tx = (orx + erx(idx)) + POS_EPS;
+                        const float ty = (ory + ery(idx)) + POS_EPS;
+                        if ((pg_fabsf(cx - ex(idx)) < tx) && (pg_fabsf(cy - ey(idx)) < ty)) {
+                            cd = 2;
+                            if (peek_blocked(obj, idx, is_horizontal)) {
+                                // push_obj(src = idx, target = obj): BAG:240-250
+                                const float rsum = is_horizontal ? (erx(idx) + orx) : (ery(idx) + ory);
+                                float t;
+                                if (is_horizontal) t = (float)((double)ex(idx) + sign_d((double)(cx - ex(idx))) * (double)rsum - (double)cx);
+                                else t = (float)((double)ey(idx) + sign_d((double)(cy - ey(idx))) * (double)rsum - (double)cy);
+                                const bool same_axis = is_horizontal ? (t != 0) : true;  // (a zero horizontal push is a vertical call)
+                                if (same_axis && __builtin_bit_cast(uint32_t, t) == dispb) cd = 1;
+                            }
+                        }
+                    }
+                }
+                PG_LV(code, l) = cd;
+            }
+            if (PG_BALLOT(l, PG_LV(code, l) == 2) != 0) return false;
+            any = any || PG_BALLOT(l, PG_LV(code, l) == 1) != 0;
+        }
+        if (!any) return false;
+        if constexpr (GameBlockedEntsEffect<Game>::value) {
+            for (int c = (n - 1) >> 6; c >= 0; c--) {
+                uint64_t m = PG_BALLOT(l, ({
+                                           const int idx = (c << 6) + l;
+                                           bool hit = false;
+                                           if (idx < n && idx != obj) {
+                                               const uint32_t mm = meta(idx);
+                                               if (!(mm & MF_WILL_ERASE) && Game::may_interact(*this, otype, meta_type(mm), is_horizontal)) {
+                                                   const float tx = (orx + erx(idx)) + POS_EPS;
+                                                   const float ty = (ory + ery(idx)) + POS_EPS;
+                                                   hit = (pg_fabsf(cx - ex(idx)) < tx) && (pg_fabsf(cy - ey(idx)) < ty);
+                                               }
+                                           }
+                                           hit;
+                                       }));
+                while (m) {
+                    const int jl = pg_highest(m);
+                    m &= ~(1ull << jl);
+                    (void)Game::is_blocked_ents(*this, obj, (c << 6) + jl, is_horizontal);
+                }
+            }
+        }
+#if defined(PGAMD_WAVE_EMU)
+        pg_emu_counters()[6] += 1;  // scans settled as fixed points
+#endif
+        return true;
+    }
+
     template <int DEPTH>
     PG_DEV void push_obj(int src, int target, bool is_horizontal, int scan_axes) {  // BAG:240-268
         float rsum = is_horizontal ? (erx(src) + erx(target)) : (ery(src) + ery(target));
@@ -581,9 +731,29 @@ struct Env {
         float t_vx = 0, t_vy = 0;
         if (is_horizontal) t_vx = (float)((double)ex(src) + sign_d((double)delx) * (double)rsum - (double)ex(target));
         else t_vy = (float)((double)ey(src) + sign_d((double)dely) * (double)rsum - (double)ey(target));
-        if constexpr (DEPTH < 5) sub_step<DEPTH + 1>(target, t_vx, t_vy, scan_axes);
-        if (is_horizontal) evx(target) = 0;
-        else evy(target) = 0;
+        if constexpr (DEPTH < 5) {
+            if constexpr (PUSH_MEMO_OK) {
+                // (sub_step's axis is `_vx != 0`: a zero horizontal displacement is a vertical call)
+                const bool axis_h = t_vx != 0;
+                const float disp = axis_h ? t_vx : t_vy;
+                if ((d.debug_flags & 65536) || !memo_hit(target, disp, axis_h, DEPTH + 1)) {
+                    const uint32_t c0 = push_chg;
+                    sub_step<DEPTH + 1>(target, t_vx, t_vy, scan_axes);
+                    if (push_chg == c0 && !(d.debug_flags & 65536)) memo_insert(target, disp, axis_h, DEPTH + 1);
+#if defined(PGAMD_WAVE_EMU)
+                    pg_emu_counters()[5] += 1;  // nested sub_steps run
+#endif
+                } else {
+#if defined(PGAMD_WAVE_EMU)
+                    pg_emu_counters()[6] += 1;  // ... skipped
+#endif
+                }
+            } else {
+                sub_step<DEPTH + 1>(target, t_vx, t_vy, scan_axes);
+            }
+        }
+        if (is_horizontal) obj_write(evx(target), 0.0f);
+        else obj_write(evy(target), 0.0f);
     }
 
     // scan_axes: bit 0 / bit 1 = some entity could block or reflect `obj` on a horizontal / vertical move
@@ -591,6 +761,7 @@ struct Env {
     template <int DEPTH>
     PG_DEV bool sub_step(int obj, float _vx, float _vy, int scan_axes) {  // BAG:270-372
         if (eflag(obj, MF_WILL_ERASE)) return false;
+        const uint32_t chg_in = push_chg;
         const int otype = etype(obj);
         const float orx = erx(obj), ory = ery(obj);
         float ny = ey(obj) + _vy;
@@ -626,13 +797,13 @@ struct Env {
                 float delta;
                 if (_vx < 0) delta = (float)(pg_ceil((double)(nx - orx)) - (double)(nx - orx));
                 else delta = (float)(pg_floor((double)(nx + orx)) - (double)(nx + orx));
-                evx(obj) = -1 * evx(obj);
+                obj_write(evx(obj), -1 * evx(obj));
                 nx = nx + 2 * delta;
             } else {
                 float delta;
                 if (_vy < 0) delta = (float)(pg_ceil((double)(ny - ory)) - (double)(ny - ory));
                 else delta = (float)(pg_floor((double)(ny + ory)) - (double)(ny + ory));
-                evy(obj) = -1 * evy(obj);
+                obj_write(evy(obj), -1 * evy(obj));
                 ny = ny + 2 * delta;
             }
         } else if (block) {
@@ -644,10 +815,13 @@ struct Env {
                 else ny = (float)(_vy > 0 ? (pg_floor((double)(ny + ory)) - (double)ory) : (pg_ceil((double)(ny - ory)) + (double)ory));
             }
         }
-        ex(obj) = nx;
-        ey(obj) = ny;
+        obj_write(ex(obj), nx);
+        obj_write(ey(obj), ny);
         PG_SYNC_E();
 
+        if constexpr (PUSH_MEMO_OK && DEPTH >= 1 && DEPTH < 5) {
+            if (push_chg == chg_in && !(d.debug_flags & 65536) && push_fixed_point(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory)) return true;
+        }
         return entity_scan<DEPTH>(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory) || block;
     }
 
@@ -695,17 +869,18 @@ struct Env {
                     if (is_horizontal) {
                         float delx = ex(j) - ex(obj);
                         float rsum = erx(j) + orx;
-                        ex(obj) += _vx > 0 ? -2 * (rsum - delx) : 2 * (rsum + delx);
-                        evx(obj) = -1 * evx(obj);
+                        obj_write(ex(obj), ex(obj) + (_vx > 0 ? -2 * (rsum - delx) : 2 * (rsum + delx)));
+                        obj_write(evx(obj), -1 * evx(obj));
                     } else {
                         float dely = ey(j) - ey(obj);
                         float rsum = ery(j) + ory;
-                        ey(obj) += _vy > 0 ? -2 * (rsum - dely) : 2 * (rsum + dely);
-                        evy(obj) = -1 * evy(obj);
+                        obj_write(ey(obj), ey(obj) + (_vy > 0 ? -2 * (rsum - dely) : 2 * (rsum + dely)));
+                        obj_write(evy(obj), -1 * evy(obj));
                     }
                     moved = true;
                 }
                 if (curr_block) {
+                    trace_add(2, 1);
                     push_obj<DEPTH>(j, obj, is_horizontal, scan_axes);
                     moved = true;
                 }
@@ -841,8 +1016,17 @@ struct Env {
         if (!any_hit) return block;
         R.eventful = true;
         obj_flush(obj, R);
+#if !defined(PGAMD_WAVE_EMU)
+        const long long t_scan0 = d.wave_trace ? (long long)__builtin_readcyclecounter() : 0;
+#endif
         const bool block2 = entity_scan<0>(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory);
         PG_SYNC_E();
+#if !defined(PGAMD_WAVE_EMU)
+        if (d.wave_trace) {
+            trace_add(1, 1);
+            trace_add(3, (unsigned long long)((long long)__builtin_readcyclecounter() - t_scan0));
+        }
+#endif
         R.x = ex(obj); R.y = ey(obj); R.vx = evx(obj); R.vy = evy(obj);
         return block || block2;
     }
@@ -1105,6 +1289,7 @@ struct Env {
     // (WAVE_UNIFORM = false: no profiling marks, which assume a uniform call).
     template <bool WAVE_UNIFORM>
     PG_DEV void bso_core(int obj, int scan_axes) {
+        if constexpr (WAVE_UNIFORM) memo_n = 0;  // (push recursion records belong to one object's step)
         int num_sub_steps;
         {
             const float vx = evx(obj), vy = evy(obj);
@@ -1129,6 +1314,7 @@ struct Env {
         for (int st = 0; st < num_sub_steps; st++) {
             bool block_x = false, block_y = false;
             R.eventful = false;
+            trace_add(0, 1);
             for (int h = 0; h < 2; h++) {  // one call site for sub_step_top
                 const bool xaxis = (h == 0) == step_x_first;
                 const float dvx = xaxis ? R.vx * pct : 0.0f;
@@ -1850,6 +2036,7 @@ struct Env {
     PG_DEV void run(int mode) {
 #if !defined(PGAMD_WAVE_EMU)
         if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
+        if (d.phase_cycles && d.wave_trace && PG_LANE_ID() < 24) d.wave_trace[(size_t)env * 32 + 8 + PG_LANE_ID()] = 0;
 #endif
         load_env(mode != 2);  // a reset starts from an empty entity table (whose old size may exceed this arena)
         phase(0);

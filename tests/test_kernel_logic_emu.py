@@ -77,6 +77,30 @@ def test_long_horizon_over_timeouts_and_generator_twists(game, steps):
     assert a["first"][1000:1002].any(), "an episode must have ended by timeout"
 
 
+def test_push_recursion_is_pruned_without_changing_a_bit():
+    """An object touching several blocking entities is pushed out by each of them at every level of the reference's depth-5
+    recursion (BAG:240-268 / 337-369): ~k^5 nested sub_steps that change nothing, 1.3 M wave cycles on the device.  The kernels
+    recognise the fixed point and remember no-op calls (pg_env.h push_fixed_point / memo_hit); entity tables must stay identical
+    to the oracle's after every step, with the pruning really taken and the nested calls cut several times over."""
+    L = emu_harness.lib()
+    L.emu_counter.restype = C.c_longlong
+    n, steps = 160, 260
+    acts = action_stream(n, steps, seed=11)
+    orc = oracle_env.OracleEnv(n, "coinrun", rand_seed=23)
+    emu = emu_harness.EmuEnv(n, "coinrun", rand_seed=23)
+    run0, cut0 = L.emu_counter(5), L.emu_counter(6)
+    for t in range(steps):
+        orc.act(acts[t])
+        emu.act(acts[t])
+        r1, o1, f1 = orc.observe()
+        r2, o2, f2 = emu.observe()
+        assert np.array_equal(r1, r2) and np.array_equal(f1, f2), f"step {t}"
+        for e in range(n):
+            assert np.array_equal(orc.entities(e), emu.entities(e)), f"entities env {e} step {t}"
+    run, cut = L.emu_counter(5) - run0, L.emu_counter(6) - cut0
+    assert cut > 1000 and run < 4 * cut, (run, cut)
+
+
 def test_independent_smart_entities_are_stepped_side_by_side():
     """pg_env.h GameParSmart (coinrun: the agent and the walking enemies): smart entities that nothing can block or reflect
     this step take one lane each in a parallel pass of step_entities.  Heavy levels (many enemies) against the oracle,
