@@ -146,6 +146,7 @@ struct DevCtx {
     // boundary buffers (device side)
     const int32_t *action;  // [num_envs]
     uint8_t *obs;           // [num_envs][64][64][3]
+    uint8_t *human;         // [num_envs][512][512][3] the render_human info frame (pg_human.h); null unless the handle was made with render_human
     float *rew;             // [num_envs]
     int32_t *prev_level_seed, *level_seed;  // [num_envs]
     uint8_t *first, *prev_level_complete;   // [num_envs]

@@ -1,0 +1,647 @@
+// pg_human.h -- the render_human frame: 512 x 512 x 3, antialiased, smooth pixmap transform (reference src/vecgame.cpp:270-282,
+// 363-376: VecGame::observe renders every env a second time at RENDER_RES with Game::render_to_buf(..., antialias = true),
+// src/game.cpp:77-91).  Not a hot path -- the reference draws these frames one env after the other on the Python thread, for
+// interactive.py and gym's render_mode="rgb_array" -- but a second rasterizer: with QPainter::Antialiasing and
+// SmoothPixmapTransform every drawImage / fillRect of game_draw (BAG:979-1012) leaves Qt's fast paths and goes through
+//   coverage : QRasterizer::rasterizeLine(a, b, h / w), antialiased (16.16 fixed point, 8-bit coverage per pixel),
+//   sampling : fetchTransformedBilinearARGB32PM over the spans of a row that touch (one run per row),
+//   blend    : comp_func_SourceOver (comp_func_Source for an RGB32 source) with const_alpha = (coverage * intOpacity) >> 8.
+// All three are restated here and pinned against PyQt5 5.9.7 by tests/tools/qt_smooth_aa_probe.py; whole frames are compared
+// with the compiled reference (tests/golden/render_human.npz).
+//
+// Execution: one wavefront per (env, band of HUMAN_BAND rows); the band lives in LDS as 0xffRRGGBB words.  Drawables are
+// walked in the painter's order in wave-uniform code (rect -> line -> clip -> coverage set-up in doubles, as Qt does it);
+// the lanes take the pixels of a row's run, 64 at a time.  Game policies are the ones the 64 x 64 renderer uses
+// (image_for_type, theme_for_grid_obj, adjusted_image_rect, tile_aspect_ratio, draw_overlay, ...).
+#pragma once
+#include "pg_render.h"
+
+namespace pgamd {
+
+constexpr int HUMAN_RES = 512;                        // reference src/game.h:26 RENDER_RES
+constexpr int HUMAN_BAND = 32;                        // rows per workgroup
+constexpr int HUMAN_BANDS = HUMAN_RES / HUMAN_BAND;
+constexpr size_t HUMAN_BYTES = (size_t)HUMAN_RES * HUMAN_RES * 3;
+
+struct HumanLds {
+    uint32_t fb[HUMAN_BAND * HUMAN_RES];
+};
+
+#if defined(PGAMD_WAVE_EMU) && defined(PG_HUMAN_TRACE)
+inline int *pg_human_trace_xy() {
+    static int xy[2] = {-1, -1};
+    static bool init = false;
+    if (!init) {
+        init = true;
+        if (const char *e = getenv("PG_HUMAN_TRACE")) sscanf(e, "%d,%d", &xy[0], &xy[1]);
+    }
+    return xy;
+}
+#endif
+namespace human {
+
+PG_DEV int f16(double v) { return (int)(v * 65536.0); }                                     // FloatToQ16Dot16
+PG_DEV int mul16(int a, int b) { return (int)(((long long)a * (long long)b) >> 16); }       // Q16Dot16Multiply
+PG_DEV uint32_t bmul(uint32_t x, uint32_t a) {                                           // qdrawhelper_p.h BYTE_MUL
+    uint32_t t = (x & 0xff00ffu) * a;
+    t = (t + ((t >> 8) & 0xff00ffu) + 0x800080u) >> 8;
+    t &= 0xff00ffu;
+    x = ((x >> 8) & 0xff00ffu) * a;
+    x = (x + ((x >> 8) & 0xff00ffu) + 0x800080u);
+    x &= 0xff00ff00u;
+    return x | t;
+}
+PG_DEV uint32_t interpolate_pixel_255(uint32_t x, uint32_t a, uint32_t y, uint32_t b) {     // qdrawhelper_p.h INTERPOLATE_PIXEL_255
+    uint32_t t = (x & 0xff00ffu) * a + (y & 0xff00ffu) * b;
+    t = (t + ((t >> 8) & 0xff00ffu) + 0x800080u) >> 8;
+    t &= 0xff00ffu;
+    x = ((x >> 8) & 0xff00ffu) * a + ((y >> 8) & 0xff00ffu) * b;
+    x = (x + ((x >> 8) & 0xff00ffu) + 0x800080u);
+    x &= 0xff00ff00u;
+    return x | t;
+}
+// per channel (a * (256 - d) + b * d) >> 8 -- INTERPOLATE_PIXEL_256 and the intermediate-buffer form of the scale-up fetch
+PG_DEV uint32_t lerp256(uint32_t a, uint32_t b, uint32_t dd) {
+    const uint32_t id = 256u - dd;
+    const uint32_t rb = (((a & 0xff00ffu) * id + (b & 0xff00ffu) * dd) >> 8) & 0xff00ffu;
+    const uint32_t ag = (((a >> 8) & 0xff00ffu) * id + ((b >> 8) & 0xff00ffu) * dd) & 0xff00ff00u;
+    return rb | ag;
+}
+PG_DEV uint32_t interp8(uint32_t tl, uint32_t tr, uint32_t bl, uint32_t br, uint32_t dx, uint32_t dy) {  // 8-bit distances: rows first, then columns
+    return lerp256(lerp256(tl, bl, dy), lerp256(tr, br, dy), dx);
+}
+PG_DEV uint32_t interp16(uint32_t tl, uint32_t tr, uint32_t bl, uint32_t br, uint32_t dx, uint32_t dy) {  // interpolate_4_pixels_16 (distances 0..16)
+    const uint32_t dxy = dx * dy;
+    const uint32_t w0 = 256u - 16u * dx - 16u * dy + dxy, w1 = 16u * dx - dxy, w2 = 16u * dy - dxy, w3 = dxy;
+    const uint32_t rb = ((tl & 0xff00ffu) * w0 + (tr & 0xff00ffu) * w1 + (bl & 0xff00ffu) * w2 + (br & 0xff00ffu) * w3) >> 8;
+    const uint32_t ag = ((tl >> 8) & 0xff00ffu) * w0 + ((tr >> 8) & 0xff00ffu) * w1 + ((bl >> 8) & 0xff00ffu) * w2 + ((br >> 8) & 0xff00ffu) * w3;
+    return (rb & 0xff00ffu) | (ag & 0xff00ff00u);
+}
+
+// What QRasterizer::rasterizeLine leaves of an axis-aligned line: columns [iLeft, iRight] with the 16.16 coverage factors of the
+// left / inner / right columns, rows [iTop, iBottom] of the line's 16.16 extent [yPa, yPb].
+struct AxisCoverage {
+    int iLeft, iRight, covLeft, covRight;  // covLeft: coverage factor (x 255, 16.16) of column iLeft; inner columns 255 << 16
+    int iTop, iBottom, yPa, yPb;
+    bool single;                           // iLeft == iRight (Qt adds the two partial widths there)
+};
+
+}  // namespace human
+
+template <class Game>
+struct HumanRenderer {
+    static constexpr int FRAME_W = HUMAN_RES, FRAME_H = HUMAN_RES;
+    const DevCtx &d;
+    const int env;
+    HumanLds *lds;
+    uint32_t *fb;
+    EnvHdr G;
+    const uint32_t *ge;
+    int ecap;
+    const typename Game::cell_t *gg;
+    int row0, row1;  // this workgroup's band
+
+    PG_DEV HumanRenderer(const DevCtx &d_, int env_, HumanLds *lds_, int band) : d(d_), env(env_), lds(lds_), fb(lds_->fb) {
+        ge = d.ents + ent_table_base(env, d.ent_cap);
+        ecap = d.ent_cap;
+        gg = reinterpret_cast<const typename Game::cell_t *>(d.grid + (size_t)env * d.grid_bytes);
+        row0 = band * HUMAN_BAND;
+        row1 = row0 + HUMAN_BAND;
+    }
+
+    // the accessors the game policies use (same names as Renderer / Env)
+    PG_DEV float ef(int field, int i) const { return __builtin_bit_cast(float, ge[(uint32_t)(field * ecap + i)]); }
+    PG_DEV uint32_t meta(int i) const { return ge[(uint32_t)(EF_META * ecap + i)]; }
+    PG_DEV float ex(int i) const { return ef(EF_X, i); }
+    PG_DEV float ey(int i) const { return ef(EF_Y, i); }
+    PG_DEV float evx(int i) const { return ef(EF_VX, i); }
+    PG_DEV float evy(int i) const { return ef(EF_VY, i); }
+    PG_DEV float erx(int i) const { return ef(EF_RX, i); }
+    PG_DEV float ery(int i) const { return ef(EF_RY, i); }
+    PG_DEV int etype(int i) const { return meta_type(meta(i)); }
+    PG_DEV void fail(int code) {
+        if (G.error == 0) G.error = code;
+    }
+    PG_DEV int get_obj(int x, int y) const {  // BAG:180-185
+        if (!(0 <= y && y < G.main_height && 0 <= x && x < G.main_width)) return G.out_of_bounds_object;
+        return (int)gg[y * G.main_width + x];
+    }
+    PG_DEV RectD get_screen_rect(float x, float y, float dx, float dy, float render_eps) const {  // BAG:799-801
+        RectD r;
+        r.x = (double)((x - render_eps) * G.unit - G.x_off);
+        r.y = (double)((G.view_dim - y - render_eps) * G.unit + G.y_off);
+        r.w = (double)((dx + 2 * render_eps) * G.unit);
+        r.h = (double)((dy + 2 * render_eps) * G.unit);
+        return r;
+    }
+    PG_DEV RectD get_abs_rect(float x, float y, float dx, float dy) const {  // BAG:803-805
+        RectD r;
+        r.x = (double)(x * G.unit);
+        r.y = (double)(y * G.unit);
+        r.w = (double)(dx * G.unit);
+        r.h = (double)(dy * G.unit);
+        return r;
+    }
+
+    // ---- QRasterizer::rasterizeLine, antialiased, clip = the frame ------------------------------------------------------------
+    // the common head: clips the line to the (widened) frame and rescales the relative width; false: nothing to draw
+    PG_DEV static bool clip_line(double ax, double ay, double bx, double by, double &width, double &pax, double &pay, double &pbx, double &pby) {
+        const int cw = HUMAN_RES, ch = HUMAN_RES;
+        if ((ax == bx && ay == by) || width == 0) return false;
+        pax = ax; pay = ay; pbx = bx; pby = by;
+        const double offx = pg_fabs(by - ay) * width * 0.5, offy = pg_fabs(bx - ax) * width * 0.5;
+        const double cl = 0 - offx, ct = 0 - offy, cr = (cw - 1) + 1 + offx, cb = (ch - 1) + 1 + offy;
+        const bool a_in = cl <= pax && pax <= cr && ct <= pay && pay <= cb, b_in = cl <= pbx && pbx <= cr && ct <= pby && pby <= cb;
+        if (!a_in || !b_in) {
+            double t1 = 0, t2 = 1;
+            for (int i = 0; i < 2; i++) {
+                const double o = i ? pay : pax, dd = i ? pby - pay : pbx - pax, low = i ? ct : cl, high = i ? cb : cr;
+                if (dd == 0) {
+                    if (o <= low || o >= high) return false;
+                    continue;
+                }
+                const double d_inv = 1 / dd;
+                double t_low = (low - o) * d_inv, t_high = (high - o) * d_inv;
+                if (t_low > t_high) { const double t = t_low; t_low = t_high; t_high = t; }
+                if (t1 < t_low) t1 = t_low;
+                if (t2 > t_high) t2 = t_high;
+                if (t1 >= t2) return false;
+            }
+            const double npax = pax + (pbx - pax) * t1, npay = pay + (pby - pay) * t1, npbx = pax + (pbx - pax) * t2, npby = pay + (pby - pay) * t2;
+            pax = npax; pay = npay; pbx = npbx; pby = npby;
+        }
+        const double d0x = ax - bx, d0y = ay - by, w0 = d0x * d0x + d0y * d0y;
+        const double dx = pax - pbx, dy = pay - pby, w = dx * dx + dy * dy;
+        if (w == 0) return false;
+        width *= pg_sqrt(w0 / w);
+        return true;
+    }
+    PG_DEV static bool q26_equal(double p, double q) { return (int)((p - q) * 64) == 0; }  // q26Dot6Compare
+    // 0: nothing; 1: axis-aligned (cov filled in); 2: a general line (pa, pb, width returned for the trapezoid walker)
+    PG_DEV static int rasterize_line(double ax, double ay, double bx, double by, double width, human::AxisCoverage &cov, double (&gl)[5]) {
+        using namespace human;
+        const int cw = HUMAN_RES, ch = HUMAN_RES;
+        double pax, pay, pbx, pby;
+        if (!clip_line(ax, ay, bx, by, width, pax, pay, pbx, pby)) return 0;
+        if (q26_equal(pay, pby)) {
+            if (q26_equal(pax, pbx)) return 0;
+            const double x = (pax + pbx) * 0.5, dx = pg_fabs(pbx - pax) * 0.5, y = pay, dy = width * dx;
+            pax = x; pay = y - dy;
+            pbx = x; pby = y + dy;
+            width = 1 / width;
+        }
+        if (!q26_equal(pax, pbx)) {
+            gl[0] = pax; gl[1] = pay; gl[2] = pbx; gl[3] = pby; gl[4] = width;
+            return 2;
+        }
+        if (pay > pby) { const double t = pay; pay = pby; pby = t; }
+        const double dy = pby - pay, half = 0.5 * width * dy;
+        double left = pax - half, right = pax + half;
+        left = left < 0 ? 0 : (left > cw ? cw : left);
+        right = right < 0 ? 0 : (right > cw ? cw : right);
+        pay = pay < 0 ? 0 : (pay > ch ? ch : pay);
+        pby = pby < 0 ? 0 : (pby > ch ? ch : pby);
+        if (q26_equal(left, right) || q26_equal(pay, pby)) return 0;
+        cov.iLeft = (int)left;
+        cov.iRight = (int)right;
+        const int leftWidth = ((cov.iLeft + 1) << 16) - f16(left), rightWidth = f16(right) - (cov.iRight << 16);
+        cov.single = cov.iLeft == cov.iRight;
+        cov.covLeft = (cov.single ? leftWidth + rightWidth : leftWidth) * 255;
+        cov.covRight = rightWidth * 255;
+        cov.iTop = (int)pay;
+        cov.iBottom = (int)pby;
+        cov.yPa = f16(pay);
+        cov.yPb = f16(pby);
+        return 1;
+    }
+
+    // ---- source of a drawImage: bilinear texture fetch -------------------------------------------------------------------------
+    struct Texture {
+        uint32_t off;
+        int w, h;
+        bool mirrored;   // a reflected sprite (BAG:121 keeps a mirrored copy): column x of it is column w - 1 - x of the atlas image
+        bool rgb32;      // no alpha channel (backgrounds): at opacity 1 getOperator turns SourceOver into Source (QSpanData::initTexture: hasAlpha = image.hasAlphaChannel() || intOpacity != 256)
+        double m11, m12, m21, m22, dx, dy;  // QSpanData::setupMatrix: inverse of translate(1/65536) * painter matrix * rect mapping
+    };
+    PG_DEV uint32_t texel(const Texture &t, int x, int y) const {
+        return d.pixels[t.off + (uint32_t)(y * t.w + (t.mirrored ? t.w - 1 - x : x))];
+    }
+    // fetchTransformedBilinearARGB32PM<BlendTransformedBilinear> for pixel b of the run that starts at column x0 of row y (the
+    // spans of a row that touch are fetched as one run; the pixel's place in the run selects the code path Qt's SSE2 build takes)
+    PG_DEV uint32_t fetch_scale(const Texture &t, int y, int x0, int length, int b) const {
+        using namespace human;
+        const int fdx = (int)(t.m11 * 65536.0);
+        const double cx = x0 + 0.5, cy = y + 0.5;
+        const int fx0 = (int)((t.m21 * cy + t.m11 * cx + t.dx) * 65536.0) - 32768;
+        const int fy = (int)((t.m22 * cy + t.m12 * cx + t.dy) * 65536.0) - 32768;
+        int y1 = fy >> 16, y2;
+        if (y1 < 0) y1 = y2 = 0;
+        else if (y1 >= t.h - 1) y1 = y2 = t.h - 1;
+        else y2 = y1 + 1;
+        const int fx = fx0 + b * fdx;
+        int x1 = fx >> 16, x2;
+        if (x1 < 0) x1 = x2 = 0;
+        else if (x1 >= t.w - 1) x1 = x2 = t.w - 1;
+        else x2 = x1 + 1;
+        bool four_bit = false;
+        if (!(fdx > 0 && fdx <= 65536) && !((fdx < 0 && fdx > -(65536 / 8)) || pg_fabs(t.m22) < (1. / 8.))) {
+            // scale down: scalar head while the column pair is clamped, groups of four with rounded 4-bit distances while the
+            // whole group stays inside the image, scalar tail
+            int head = 0;
+            if (fdx > 0) {
+                if (fx0 < 0) head = (int)(((long long)(-fx0) + fdx - 1) / fdx);
+                else if ((fx0 >> 16) >= t.w - 1) head = length;
+            } else {
+                // (fdx < 0 does not occur: mirrored sprites are mirrored copies, BAG:121)
+                head = length;
+            }
+            if (head > length) head = length;
+            if (head < length) {
+                const long long fxh = (long long)fx0 + (long long)head * fdx;
+                long long bounded = length;
+                const long long lim = head + ((long long)(t.w - 1) * 65536 - fxh) / fdx;
+                if (lim < bounded) bounded = lim;
+                bounded -= 3;
+                if (bounded > head) {
+                    const long long groups = (bounded - head + 3) / 4;
+                    four_bit = b >= head && b < head + groups * 4;
+                }
+            }
+        }
+        if (four_bit) {
+            x1 = fx >> 16;  // inside the image by construction
+            x2 = x1 + 1;
+            return interp16(texel(t, x1, y1), texel(t, x2, y1), texel(t, x1, y2), texel(t, x2, y2), (uint32_t)(((fx & 0xffff) + 0x800) >> 12), (uint32_t)(((fy & 0xffff) + 0x800) >> 12));
+        }
+        return interp8(texel(t, x1, y1), texel(t, x2, y1), texel(t, x1, y2), texel(t, x2, y2), (uint32_t)((fx & 0xffff) >> 8), (uint32_t)((fy & 0xffff) >> 8));
+    }
+
+    // blend one fetched (or solid) source pixel into the band: comp_func_SourceOver / comp_func_Source with const_alpha
+    PG_DEV static uint32_t blend(uint32_t dst, uint32_t s, uint32_t ca, bool source_mode) {
+        using namespace human;
+        if (source_mode) return ca == 255 ? s : interpolate_pixel_255(s, ca, dst, 255 - ca);
+        if (ca != 255) s = bmul(s, ca);
+        return s + bmul(dst, 255 - (s >> 24));
+    }
+
+    // The spans of an axis-aligned line, row by row: [left column][inner columns][right column], spans of coverage 0 dropped,
+    // the ones that touch merged into a run for the fetch.  src(y, x0, length, b) yields the source pixel.
+    template <class Src>
+    PG_DEV void fill_axis(const human::AxisCoverage &c, int io, bool source_mode, Src src) {
+        using namespace human;
+        int ya = c.iTop, yb = c.iBottom;
+        if (ya < row0) ya = row0;
+        if (yb > row1 - 1) yb = row1 - 1;
+        if (yb > HUMAN_RES - 1) yb = HUMAN_RES - 1;
+        for (int y = ya; y <= yb; y++) {
+            const int yFP = y << 16;
+            const int hi = yFP + 65536 < c.yPb ? yFP + 65536 : c.yPb, lo = yFP > c.yPa ? yFP : c.yPa;
+            const int rowHeight = hi - lo;
+            // spans: (x, len, coverage)
+            int sx[3], sl[3], sc[3], n = 0;
+            {
+                int cvL = mul16(rowHeight, c.covLeft) >> 16;
+                if (c.single) {
+                    if (cvL) { sx[n] = c.iLeft; sl[n] = 1; sc[n] = cvL; n++; }
+                } else {
+                    const int cvM = mul16(rowHeight, 255 << 16) >> 16, cvR = mul16(rowHeight, c.covRight) >> 16;
+                    const bool left_full = c.covLeft == 65536 * 255;  // leftWidth == 1: Qt folds the inner columns into the first span
+                    if (left_full) {
+                        if (cvL) { sx[n] = c.iLeft; sl[n] = c.iRight - c.iLeft; sc[n] = cvL; n++; }
+                    } else {
+                        if (cvL) { sx[n] = c.iLeft; sl[n] = 1; sc[n] = cvL; n++; }
+                        if (c.iRight - c.iLeft > 1 && cvM) { sx[n] = c.iLeft + 1; sl[n] = c.iRight - c.iLeft - 1; sc[n] = cvM; n++; }
+                    }
+                    if (c.covRight != 0 && cvR) { sx[n] = c.iRight; sl[n] = 1; sc[n] = cvR; n++; }
+                }
+            }
+            int i = 0;
+            while (i < n) {
+                int j = i + 1, right = sx[i] + sl[i];
+                while (j < n && sx[j] == right) { right += sl[j]; j++; }
+                const int x0 = sx[i], length = right - x0;
+                // per-pixel coverage of the run: the spans i..j-1 (at most three)
+                const int e0 = sx[i] + sl[i], c0 = sc[i];
+                const int e1 = (i + 1 < j) ? sx[i + 1] + sl[i + 1] : e0, c1 = (i + 1 < j) ? sc[i + 1] : c0;
+                const int c2 = (i + 2 < j) ? sc[i + 2] : c1;
+                uint32_t *rowp = fb + (y - row0) * HUMAN_RES;
+                for (int base = 0; base < length; base += 64) {
+                    PG_FOR_LANES(l) {
+                        const int b = base + l;
+                        if (b < length) {
+                            const int x = x0 + b;
+                            const int cv = x < e0 ? c0 : (x < e1 ? c1 : c2);
+                            const uint32_t ca = (uint32_t)((cv * io) >> 8);
+                            const uint32_t s = src(y, x0, length, b);
+#if defined(PGAMD_WAVE_EMU) && defined(PG_HUMAN_TRACE)
+                            if (x == pg_human_trace_xy()[0] && y == pg_human_trace_xy()[1])
+                                fprintf(stderr, "trace (%d,%d): run x0 %d len %d b %d cov %d io %d src %08x dst %08x -> %08x mode %d\n", x, y, x0, length, b, cv, io, s, rowp[x], blend(rowp[x], s, ca, source_mode), (int)source_mode);
+#endif
+                            rowp[x] = blend(rowp[x], s, ca, source_mode);
+                        }
+                    }
+                }
+                i = j;
+            }
+        }
+        PG_SYNC();
+    }
+
+    // QPainter::fillRect(QRectF, QColor) under Antialiasing (untransformed painter): the rect's mid line, width h / w
+    PG_DEV void exec_fill(const RectD &r, uint32_t color) {
+        human::AxisCoverage c;
+        double gl[5];
+        const double l = r.x, t = r.y, rr = r.x + r.w, bb = r.y + r.h;
+        // QRectF::normalized is what fillRect hands on; the rects drawn here have positive extents
+        const int kind = rasterize_line((l + l) * 0.5, (t + bb) * 0.5, (rr + rr) * 0.5, (t + bb) * 0.5, r.h / r.w, c, gl);
+        if (kind != 1) return;
+        // comp_func_solid_SourceOver / _Source: colour * coverage + dst * (255 - coverage), the two products rounded on their own
+        fill_axis(c, 256, false, [color](int, int, int, int) { return color; });
+    }
+
+    // QPainter::drawImage(QRectF, QImage), painter untransformed
+    PG_DEV void draw_image_rect(const ImgDesc im, bool mirrored, bool rgb32, const RectD &r, float opacity) {
+        if (!(r.w > 0) || !(r.h > 0)) return;  // QRectF::isEmpty
+        if (r.w == (double)im.w && r.h == (double)im.h) {
+            // not stretched (translate only): QRasterPaintEngine::drawImage takes fillRect_normalized over the ROUNDED rect with the
+            // untransformed image filler -- neither antialiasing nor filtering (e.g. a 512 x 512 background over the 512 frame)
+            double o = (double)opacity;
+            if (o < 0) o = 0;
+            if (o > 1) o = 1;
+            const int io = (int)(o * 256);
+            const uint32_t ca = (uint32_t)((255 * io) >> 8);
+            const bool source_mode = rgb32 && io == 256;
+            const int x1 = q_round(r.x), y1 = q_round(r.y), x2 = q_round(r.x + r.w), y2 = q_round(r.y + r.h);
+            int ya = y1 < row0 ? row0 : y1, yb = y2 > row1 ? row1 : y2;
+            const int xa = x1 < 0 ? 0 : x1, xb = x2 > HUMAN_RES ? HUMAN_RES : x2;
+            for (int y = ya; y < yb; y++) {
+                const int sy = y - y1;
+                if (sy < 0 || sy >= (int)im.h) continue;
+                uint32_t *rowp = fb + (y - row0) * HUMAN_RES;
+                for (int base = xa; base < xb; base += 64) {
+                    PG_FOR_LANES(l) {
+                        const int x = base + l, sx = x - x1;
+                        if (x < xb && sx >= 0 && sx < (int)im.w) {
+                            const uint32_t s = d.pixels[im.off + (uint32_t)(sy * im.w + (mirrored ? im.w - 1 - sx : sx))];
+                            rowp[x] = blend(rowp[x], s, ca, source_mode);
+                        }
+                    }
+                }
+            }
+            PG_SYNC();
+            return;
+        }
+        human::AxisCoverage c;
+        double gl[5];
+        const double l = r.x, t = r.y, rr = r.x + r.w, bb = r.y + r.h;
+        const int kind = rasterize_line((l + l) * 0.5, (t + bb) * 0.5, (rr + rr) * 0.5, (t + bb) * 0.5, r.h / r.w, c, gl);
+        if (kind != 1) return;
+#if defined(PGAMD_WAVE_EMU) && defined(PG_HUMAN_TRACE)
+        if (rgb32 && row0 == 0) fprintf(stderr, "bg rect %.17g %.17g %.17g %.17g -> iLeft %d iRight %d covL %d covR %d top %d bottom %d yPa %d yPb %d unit %.9g\n", r.x, r.y, r.w, r.h, c.iLeft, c.iRight, c.covLeft, c.covRight, c.iTop, c.iBottom, c.yPa, c.yPb, (double)G.unit);
+#endif
+        if (c.iBottom < row0 || c.iTop >= row1) return;
+        Texture tx;
+        tx.off = im.off;
+        tx.w = im.w;
+        tx.h = im.h;
+        tx.mirrored = mirrored;
+        tx.rgb32 = rgb32;
+        {
+            const double scx = r.w / (double)im.w, scy = r.h / (double)im.h, dd = 1.0 / 65536;
+            const double m11 = 1.0 * scx, m22 = 1.0 * scy, m31 = dd * scx + r.x, m32 = dd * scy + r.y;
+            tx.m11 = 1.0 / m11;
+            tx.m22 = 1.0 / m22;
+            tx.m12 = 0;
+            tx.m21 = 0;
+            tx.dx = -m31 * tx.m11;
+            tx.dy = -m32 * tx.m22;
+        }
+        double o = (double)opacity;
+        if (o < 0) o = 0;
+        if (o > 1) o = 1;
+        const int io = (int)(o * 256);
+        fill_axis(c, io, rgb32 && io == 256, [this, &tx](int y, int x0, int length, int b) { return fetch_scale(tx, y, x0, length, b); });
+    }
+
+    // tile_image BAG:840-869
+    PG_DEV void tile_image(const ImgDesc im, bool mirrored, bool rgb32, const RectD &rect, float tile_ratio, float opacity) {
+        if (tile_ratio != 0) {
+            if (tile_ratio < 0) {
+                tile_ratio = -1 * tile_ratio;
+                int num_tiles = (int)(rect.h / (rect.w * (double)tile_ratio));
+                if (num_tiles < 1) num_tiles = 1;
+                const float tile_height = (float)(rect.h / num_tiles), tile_width = (float)rect.w;
+                for (int i = 0; i < num_tiles; i++) {
+                    const RectD tr = {rect.x, rect.y + (double)(tile_height * i), (double)tile_width, (double)tile_height};
+                    if (tr.y + tr.h < row0 - 2 || tr.y > row1 + 2) continue;
+                    draw_image_rect(im, mirrored, rgb32, tr, opacity);
+                }
+            } else {
+                int num_tiles = (int)(rect.w / (rect.h * (double)tile_ratio));
+                if (num_tiles < 1) num_tiles = 1;
+                const float tile_width = (float)(rect.w / num_tiles), tile_height = (float)rect.h;
+                if (rect.y + rect.h < row0 - 2 || rect.y > row1 + 2) return;
+                for (int i = 0; i < num_tiles; i++) {
+                    const RectD tr = {rect.x + (double)(tile_width * i), rect.y, (double)tile_width, (double)tile_height};
+                    if (tr.x + tr.w < -2 || tr.x > HUMAN_RES + 2) continue;
+                    draw_image_rect(im, mirrored, rgb32, tr, opacity);
+                }
+            }
+        } else {
+            draw_image_rect(im, mirrored, rgb32, rect, opacity);
+        }
+    }
+
+    // draw_image BAG:877-913
+    PG_DEV void draw_image(RectD base_rect, float rotation, bool is_reflected, int base_type, int theme, float alpha, float tile_ratio) {
+        const int img_type = Game::image_for_type(*this, base_type);
+        if (img_type < 0) return;
+        if (d.opt.use_monochrome_assets || img_type >= USE_ASSET_THRESHOLD) {  // draw_grid_obj BAG:915-919, color_for_type BAG:455-481
+            if constexpr (GameHasGridFills<Game>::value) {  // a game's own draw_grid_obj (chaser.cpp:112-119)
+                if (Game::is_grid_fill(*this, img_type)) {
+                    RectD out;
+                    uint32_t color;
+                    Game::grid_fill(*this, img_type, base_rect, out, color);
+                    exec_fill(out, color);
+                    return;
+                }
+            }
+            if (img_type == SPACE) return;
+            if (!d.opt.use_monochrome_assets || img_type >= 64) {
+                fail(PGE_UNSUPPORTED_DRAW);
+                return;
+            }
+            int th = theme;
+            if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) th = 0;
+            const int k = 4, kcubed = 64, chunk = 64;
+            int new_type = (29 * (img_type + 1)) % kcubed;
+            new_type = (new_type + 19 * th) % kcubed;
+            const uint32_t cr = (uint32_t)(chunk * (new_type / (k * k) + 1) - 1), cg = (uint32_t)(chunk * ((new_type / k) % k + 1) - 1), cb = (uint32_t)(chunk * (new_type % k + 1) - 1);
+            exec_fill(base_rect, 0xff000000u | (cr << 16) | (cg << 8) | cb);
+            return;
+        }
+        const RectD rect = Game::adjusted_image_rect(img_type, base_rect);
+        int mt = theme;
+        if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;  // BAG:450-453
+        const int img = (mt >= 0 && mt < MAX_IMAGE_THEMES) ? (int)d.assets->type_theme_img[img_type][mt] : -1;
+        if (img < 0) {
+            fail(PGE_THEME);
+            return;
+        }
+        const ImgDesc im = d.assets->img[img];
+        if (rotation == 0) {
+            tile_image(im, is_reflected, false, rect, tile_ratio, alpha);
+        } else {
+            draw_image_rotated(im, is_reflected, rect, rotation, alpha);
+        }
+    }
+    PG_DEV void draw_image_rotated(const ImgDesc, bool, const RectD &, float, float) { fail(PGE_UNSUPPORTED_DRAW); }
+    // jumper's compass (drawEllipse / drawLine under Antialiasing: Qt's gray raster and its antialiased cosmetic stroker) is not
+    // restated: libenv_make refuses render_human for jumper, these only keep the policy's draw_overlay compiling
+    PG_DEV void exec_ellipse(int, int, int, int, bool, uint32_t, uint32_t) { fail(PGE_UNSUPPORTED_DRAW); }
+    PG_DEV void exec_row_masks(const uint32_t *, int, int, uint32_t, uint32_t) { fail(PGE_UNSUPPORTED_DRAW); }
+    PG_DEV void exec_line(int, int, int, int, uint32_t) { fail(PGE_UNSUPPORTED_DRAW); }
+
+    PG_DEV void draw_entities(int render_z) {  // BAG:1052-1066
+        const int n = G.n_ents;
+        for (int i = 0; i < n; i++) {
+            const uint32_t mm = meta(i);
+            if (meta_render_z(mm) != render_z) continue;
+            if (!Game::should_draw_entity(*this, i)) continue;
+            const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
+            RectD r1;  // get_object_rect BAG:811-817
+            if (mm & MF_ABS_COORDS) r1 = get_abs_rect(G.view_dim * (x - rx), G.view_dim * (y + ry), 2 * G.view_dim * rx, 2 * G.view_dim * ry);
+            else r1 = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
+            // nothing of it in this band?  (the sprite's rect may be adjusted or turned: its circumcircle, generously)
+            {
+                const double rad = (pg_fabs(r1.w) + pg_fabs(r1.h)) * 2 + 4, cy = r1.y + r1.h / 2;
+                if (cy + rad < row0 || cy - rad > row1) continue;
+            }
+            const float tile_ratio = Game::tile_aspect_ratio(*this, i);
+            draw_image(r1, ef(EF_ROTATION, i), (mm & MF_REFLECTED) != 0, meta_image_type(mm), meta_image_theme(mm), ef(EF_ALPHA, i), tile_ratio);
+        }
+    }
+
+    // game_draw BAG:1009-1012 at rect_height = 512
+    PG_DEV void render_band() {
+        {
+            const EnvHdr *h = d.hdr + env;
+#define PG_X(type, name) G.name = h->name;
+            PG_HDR_FIELDS(PG_X)
+#undef PG_X
+        }
+        // prepare_for_drawing(512) BAG:819-838: centre, visibility and view_dim are what the step kernel left for the 64-pixel frame
+        {
+            const float raw_unit = 64 / G.visibility;
+            G.unit = (float)((double)raw_unit * ((double)(float)HUMAN_RES / 64.0));
+            G.view_dim = (float)(64.0 / (double)raw_unit);
+            G.x_off = G.unit * (G.center_x - G.view_dim / 2);
+            G.y_off = G.unit * (G.center_y - G.view_dim / 2);
+        }
+        for (int base = 0; base < HUMAN_BAND * HUMAN_RES; base += 64) {
+            PG_FOR_LANES(l) { fb[base + l] = 0xff000000u; }  // p.fillRect(rect, QColor(0, 0, 0))
+        }
+        PG_SYNC();
+        // draw_background BAG:979-1007
+        if (d.opt.use_backgrounds) {
+            const int bgi = (int)d.assets->bg_img[G.background_index];
+            const ImgDesc bim = d.assets->img[bgi];
+            if constexpr (GameCustomBackground<Game>::value) {
+                RectD rects[4];
+                const int nr = Game::background_rects(*this, rects);
+                for (int k = 0; k < 4; k++)
+                    if (k < nr && rects[k].w > 0) draw_image_rect(bim, false, true, rects[k], 1.0f);
+            } else {
+                const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);
+                if (G.bg_tile_ratio < 0) {
+                    tile_image(bim, false, true, main_rect, G.bg_tile_ratio, 1.0f);
+                } else {
+                    const float bgw = (float)bim.w, bgh = (float)bim.h;
+                    const float bg_ar = bgw / bgh;
+                    const float world_ar = (float)(G.main_width * 1.0 / G.main_height);
+                    const float extra_w = bg_ar - world_ar;
+                    const float offset_x = G.bg_pct_x * extra_w;
+                    draw_image_rect(bim, false, true, adjust_rect(main_rect, (double)(-offset_x), 0, (double)(bg_ar / world_ar), 1), 1.0f);
+                }
+            }
+        }
+        // draw_foreground BAG:921-970
+        draw_entities(-1);
+        if constexpr (GameDrawsGrid<Game>::value) {
+            int low_x, high_x, low_y, high_y;
+            if (Game::center_agent(d.opt)) {
+                const float margin = (float)(G.visibility / 2.0 + 1);
+                low_x = (int)(G.center_x - margin);
+                high_x = (int)(G.center_x + margin);
+                low_y = (int)(G.center_y - margin);
+                high_y = (int)(G.center_y + margin);
+            } else {
+                low_x = 0;
+                high_x = G.main_width - 1;
+                low_y = 0;
+                high_y = G.main_height - 1;
+            }
+            for (int x = low_x; x <= high_x; x++) {
+                for (int y = low_y; y <= high_y; y++) {
+                    const int type = get_obj(x, y);
+                    if (type == INVALID_OBJ) continue;
+                    const RectD r2 = get_screen_rect((float)x, (float)(y + 1), 1, 1, RENDER_EPS);
+                    if (r2.y + 2 * r2.h < row0 - 2 || r2.y - r2.h > row1 + 2) continue;  // (adjusted_image_rect stretches a cell image by less than its own height)
+                    const int theme = Game::theme_for_grid_obj(*this, type);
+                    draw_image(r2, 0, false, type, theme, 1.0f, 0.0f);
+                }
+            }
+        }
+        draw_entities(0);
+        draw_entities(1);
+        if (G.has_useful_vel_info && d.opt.paint_vel_info) {  // BAG:960-969, to_shade reference src/qt-utils.h:21-28
+            const float infodim = (float)(HUMAN_RES * .2);
+            const int ag = G.agent;
+            int s1 = (int)((float)(.5 * (double)evx(ag) / (double)G.maxspeed + .5) * 255);
+            int s2 = (int)((float)(.5 * (double)evy(ag) / (double)G.max_jump + .5) * 255);
+            s1 = s1 < 0 ? 0 : (s1 > 255 ? 255 : s1);
+            s2 = s2 < 0 ? 0 : (s2 > 255 ? 255 : s2);
+            const RectD d2 = {0, 0, (double)infodim, (double)infodim}, d3 = {(double)infodim, 0, (double)infodim, (double)infodim};
+            exec_fill(d2, 0xff000000u | ((uint32_t)s1 << 16) | ((uint32_t)s1 << 8) | (uint32_t)s1);
+            exec_fill(d3, 0xff000000u | ((uint32_t)s2 << 16) | ((uint32_t)s2 << 8) | (uint32_t)s2);
+        }
+        if constexpr (GameHasOverlay<Game>::value) Game::draw_overlay(*this);
+        PG_SYNC();
+        store_band();
+        if (G.error) {
+#if defined(PGAMD_WAVE_EMU)
+            if (d.error) *d.error |= G.error;
+#else
+            if (PG_LANE_ID() == 0) atomicOr(d.error, G.error);
+#endif
+        }
+        // get_state serializes the camera scalars of the LAST frame drawn, which is this one (reference src/vecgame.cpp:363-376)
+        if (row0 == 0) {
+            EnvHdr *h = d.hdr + env;
+            PG_FOR_LANES(l) {
+                if (l == 0) {
+                    h->unit = G.unit;
+                    h->x_off = G.x_off;
+                    h->y_off = G.y_off;
+                }
+            }
+        }
+    }
+
+    // bgr32_to_rgb888 (reference src/game.cpp:8-23) into the env's info "rgb" frame
+    PG_DEV void store_band() {
+        uint32_t *out = reinterpret_cast<uint32_t *>(d.human + (size_t)env * HUMAN_BYTES + (size_t)row0 * HUMAN_RES * 3);
+        for (int base = 0; base < HUMAN_BAND * HUMAN_RES; base += 256) {
+            PG_FOR_LANES(l) {
+                const uint32_t *p = &fb[base + 4 * l];
+                const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+                uint32_t *o = out + (base / 4) * 3 + 3 * l;
+                o[0] = pg_perm(p1, p0, 0x06000102u);
+                o[1] = pg_perm(p2, p1, 0x05060001u);
+                o[2] = pg_perm(p3, p2, 0x04050600u);
+            }
+        }
+    }
+};
+
+}  // namespace pgamd

@@ -15,6 +15,7 @@
 #include "pg_assetgen.h"
 #include "pg_bgpaint.h"
 #include "pg_render.h"
+#include "pg_human.h"
 #include "host_state.h"
 #include "state_io.h"
 
@@ -282,6 +283,27 @@ int emu_set_state(void *h, int env, const char *data, int length) {
     return 0;
 }
 // pg_math.h restatements, exposed for tests/test_device_math.py
+// the render_human frame of one env (pg_human.h): every band "workgroup" in turn; out = 512 x 512 x 3 bytes
+int emu_render_human(void *h, int env, uint8_t *out) {
+    EmuVec *v = (EmuVec *)h;
+    std::vector<uint8_t> frames((size_t)v->n * HUMAN_BYTES);
+    v->d.human = frames.data();
+    static HumanLds hl;
+    bool ok = false;
+#define PG_X(Game)                                          \
+    if (v->kernel_id == Game::GAME_ID) {                    \
+        ok = true;                                          \
+        for (int b = 0; b < HUMAN_BANDS; b++) {             \
+            HumanRenderer<Game> r(v->d, env, &hl, b);       \
+            r.render_band();                                \
+        }                                                   \
+    }
+    PG_FOR_EACH_GAME(PG_X)
+#undef PG_X
+    memcpy(out, frames.data() + (size_t)env * HUMAN_BYTES, HUMAN_BYTES);
+    v->d.human = nullptr;
+    return ok ? 0 : -1;
+}
 void emu_atan2f_array(const float *y, const float *x, float *out, int n) {
     for (int i = 0; i < n; i++) out[i] = pg_atan2f(y[i], x[i]);
 }

@@ -29,7 +29,7 @@ def build(force=False):
         if force or not fresh():
             tmp = LIB + f".tmp{os.getpid()}"
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-march=ivybridge", "-fno-strict-aliasing", "-fPIC",
-                                   "-shared", "-I" + CSRC] + srcs + ["-lz", "-o", tmp])
+                                   "-shared", "-I" + CSRC] + (["-DPG_HUMAN_TRACE"] if os.environ.get("PG_HUMAN_TRACE") else []) + srcs + ["-lz", "-o", tmp])
             os.replace(tmp, LIB)
 
 
@@ -51,6 +51,7 @@ def lib():
             getattr(L, f).argtypes = [C.c_void_p, C.c_int]
         L.emu_get_state.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
         L.emu_set_state.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+        L.emu_render_human.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_path_counts.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_dump_entities.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_dump_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -94,6 +95,12 @@ class EmuEnv:
 
     def info_arrays(self):
         return self.info
+
+    def render_human(self, env):
+        """the 512 x 512 x 3 render_human frame of one env (pg_human.h), drawn from the env's current state"""
+        out = np.zeros((512, 512, 3), np.uint8)
+        assert self.L.emu_render_human(self.h, env, out.ctypes.data) == 0
+        return out
 
     def entities(self, env):
         n = self.L.emu_num_entities(self.h, env)

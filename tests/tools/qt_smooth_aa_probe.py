@@ -179,8 +179,12 @@ def interp16(tl, tr, bl, br, dx, dy):  # interpolate_4_pixels_16
     return out
 
 
+def interp8(tl, tr, bl, br, dx, dy):  # interpolate_4_pixels (8-bit distances): rows first, then columns
+    return lerp256(lerp256(tl, bl, dy), lerp256(tr, br, dy), dx)
+
+
 def fetch_bilinear_scale(src, y, x0, length, i11, i22, idx, idy):
-    """fetchTransformedBilinearARGB32PM<BlendTransformedBilinear>, fdy == 0"""
+    """fetchTransformedBilinearARGB32PM<BlendTransformedBilinear>, fdy == 0, one call per span (x0, length)"""
     sh, sw = src.shape
     fdx = c_int(i11 * 65536.)
     cx = x0 + 0.5; cy = y + 0.5
@@ -195,41 +199,108 @@ def fetch_bilinear_scale(src, y, x0, length, i11, i22, idx, idy):
         if x1 < 0: return 0, 0
         if x1 >= sw - 1: return sw - 1, sw - 1
         return x1, x1 + 1
-    for i in range(length):
+    def px4(fx):
         x1, x2 = bx(fx >> 16)
-        tl, tr, bl, br = int(src[y1, x1]), int(src[y1, x2]), int(src[y2, x1]), int(src[y2, x2])
-        if 0 < fdx <= 65536:
-            dy = (fy & 0xffff) >> 8; dx = (fx & 0xffff) >> 8
-            l = lerp256(tl, bl, dy); r = lerp256(tr, br, dy)
-            # columns: rb >> 8, ag masked (same per channel)
-            out.append(lerp256(l, r, dx))
-        elif (fdx < 0 and fdx > -(65536 // 8)) or abs(i22) < 1. / 8.:
-            dy = (fy & 0xffff) >> 8; dx = (fx & 0xffff) >> 8
-            t = lerp256(tl, tr, dx); b = lerp256(bl, br, dx)
-            out.append(lerp256(t, b, dy))
-        else:
-            dy = (fy & 0xffff) >> 12; dx = (fx & 0xffff) >> 12
-            out.append(interp16(tl, tr, bl, br, dx, dy))
-        fx += fdx
+        return int(src[y1, x1]), int(src[y1, x2]), int(src[y2, x1]), int(src[y2, x2]), x1, x2
+    if 0 < fdx <= 65536:  # scale up on x: rows blended first (8-bit disty), then columns (8-bit distx)
+        for i in range(length):
+            tl, tr, bl, br, _, _ = px4(fx)
+            out.append(interp8(tl, tr, bl, br, (fx & 0xffff) >> 8, (fy & 0xffff) >> 8))
+            fx += fdx
+    elif (fdx < 0 and fdx > -(65536 // 8)) or abs(i22) < 1. / 8.:  # scale up more than 8x
+        for i in range(length):
+            tl, tr, bl, br, _, _ = px4(fx)
+            out.append(interp8(tl, tr, bl, br, (fx & 0xffff) >> 8, (fy & 0xffff) >> 8))
+            fx += fdx
+    else:  # scale down: scalar prolog while clamped, SSE2 groups of four with rounded 4-bit distances, scalar tail
+        b = 0
+        while b < length:
+            tl, tr, bl, br, x1, x2 = px4(fx)
+            if x1 != x2:
+                break
+            out.append(interp8(tl, tr, bl, br, (fx & 0xffff) >> 8, (fy & 0xffff) >> 8)); fx += fdx; b += 1
+        bounded = length
+        if fdx > 0:
+            bounded = min(bounded, b + c_int(((sw - 1) * 65536 - fx) / fdx))
+        elif fdx < 0:
+            bounded = min(bounded, b + c_int((0 - fx) / fdx))
+        bounded -= 3
+        dy4 = ((fy & 0xffff) + 0x800) >> 12
+        while b < bounded:
+            for k in range(4):
+                x1 = fx >> 16
+                out.append(interp16(int(src[y1, x1]), int(src[y1, x1 + 1]), int(src[y2, x1]), int(src[y2, x1 + 1]), ((fx & 0xffff) + 0x800) >> 12, dy4))
+                fx += fdx
+            b += 4
+        while b < length:
+            tl, tr, bl, br, _, _ = px4(fx)
+            out.append(interp8(tl, tr, bl, br, (fx & 0xffff) >> 8, (fy & 0xffff) >> 8)); fx += fdx; b += 1
     return out
 
 
-def model_draw_image(dst, src, rx, ry, rw, rh, opacity=1.0):
+def interpolate_pixel_255(x, a, y, b):
+    t = (x & 0xff00ff) * a + (y & 0xff00ff) * b
+    t = (t + ((t >> 8) & 0xff00ff) + 0x800080) >> 8
+    t &= 0xff00ff
+    x = ((x >> 8) & 0xff00ff) * a + ((y >> 8) & 0xff00ff) * b
+    x = (x + ((x >> 8) & 0xff00ff) + 0x800080)
+    x &= 0xff00ff00
+    return (x | t) & 0xffffffff
+
+
+def blend_runs(dst, spans, fetch, io, opaque_source):
+    """blend_src_generic / handleSpans: the spans of one row that touch are fetched as ONE run (which matters: the fetch
+    treats the head, the groups of four and the tail of a run differently), then blended span by span with
+    const_alpha = (coverage * intOpacity) >> 8.  A source without alpha channel turns SourceOver into Source
+    (getOperator): d = INTERPOLATE_PIXEL_255(s, ca, d, 255 - ca)."""
+    i = 0
+    while i < len(spans):
+        y, x, ln, cov = spans[i]
+        j = i + 1; right = x + ln
+        while j < len(spans) and spans[j][0] == y and spans[j][1] == right:
+            right += spans[j][2]; j += 1
+        px = fetch(y, x, right - x)
+        for k in range(i, j):
+            _, sx, sl, sc = spans[k]
+            ca = (sc * io) >> 8
+            for t in range(sl):
+                s_ = px[sx - x + t]; d_ = int(dst[y, sx + t])
+                if opaque_source:
+                    dst[y, sx + t] = s_ if ca == 255 else interpolate_pixel_255(s_, ca, d_, 255 - ca)
+                else:
+                    dst[y, sx + t] = source_over(d_, s_, ca)
+        i = j
+
+
+def model_draw_image(dst, src, rx, ry, rw, rh, opacity=1.0, opaque_source=False):
     ch, cw = dst.shape
     sh, sw = src.shape
     if rw <= 0 or rh <= 0:
+        return
+    io = c_int(min(max(opacity, 0.0), 1.0) * 256)
+    if rw == sw and rh == sh:
+        # not stretched (QRasterPaintEngine::drawImage, translate only): fillRect_normalized over the ROUNDED rect with the
+        # untransformed image filler -- no antialiasing, no filtering: source pixel (x - qRound(r.x), y - qRound(r.y))
+        qr = lambda v: int(v + 0.5) if v >= 0 else int(v - float(int(v - 1)) + 0.5) + int(v - 1)
+        x1, y1, x2, y2 = qr(rx), qr(ry), qr(rx + rw), qr(ry + rh)
+        ca = (255 * io) >> 8
+        for y in range(max(y1, 0), min(y2, ch)):
+            for x in range(max(x1, 0), min(x2, cw)):
+                sx, sy = x - x1, y - y1
+                if 0 <= sx < sw and 0 <= sy < sh:
+                    s_ = int(src[sy, sx]); d_ = int(dst[y, x])
+                    if opaque_source and io == 256:
+                        dst[y, x] = s_
+                    else:
+                        dst[y, x] = source_over(d_, s_, ca)
         return
     l, t, r_, b_ = rx, ry, rx + rw, ry + rh
     ax, ay = (l + l) * 0.5, (t + b_) * 0.5
     bx, by = (r_ + r_) * 0.5, (t + b_) * 0.5
     spans = aa_line_spans(ax, ay, bx, by, rh / rw, cw, ch)
     i11, i22, idx, idy = setup_matrix(rx, ry, rw, rh, sw, sh)
-    io = c_int(min(max(opacity, 0.0), 1.0) * 256)
-    for (y, x, ln, cov) in spans:
-        px = fetch_bilinear_scale(src, y, x, ln, i11, i22, idx, idy)
-        ca = (cov * io) >> 8
-        for i in range(ln):
-            dst[y, x + i] = source_over(int(dst[y, x + i]), px[i], ca)
+    # QSpanData::initTexture: hasAlpha = image.hasAlphaChannel() || intOpacity != 256
+    blend_runs(dst, spans, lambda y, x, n: fetch_bilinear_scale(src, y, x, n, i11, i22, idx, idy), io, opaque_source and io == 256)
 
 
 def model_fill_rect(dst, rx, ry, rw, rh, color):
@@ -254,15 +325,16 @@ def qt_setup():
 def np_to_qimage(a, fmt):
     from PyQt5.QtGui import QImage
     a = np.ascontiguousarray(a.astype(np.uint32))
-    img = QImage(a.data, a.shape[1], a.shape[0], a.shape[1] * 4, fmt)
-    img._keep = a
+    raw = a.tobytes()
+    img = QImage(raw, a.shape[1], a.shape[0], a.shape[1] * 4, fmt)
+    img._keep = raw
     return img
 
 
 def qt_draw(dst0, ops):
     QImage, QPainter, QColor, QRectF = qt_setup()
-    buf = np.ascontiguousarray(dst0.astype(np.uint32))
-    img = QImage(buf.data, buf.shape[1], buf.shape[0], buf.shape[1] * 4, QImage.Format_RGB32)
+    h, w = dst0.shape
+    img = np_to_qimage(dst0, QImage.Format_RGB32).copy()
     p = QPainter(img)
     p.setRenderHint(QPainter.Antialiasing, True)
     p.setRenderHint(QPainter.SmoothPixmapTransform, True)
@@ -279,7 +351,8 @@ def qt_draw(dst0, ops):
             _, r, c = op
             p.fillRect(QRectF(*r), QColor((c >> 16) & 255, (c >> 8) & 255, c & 255, c >> 24))
     p.end()
-    return buf
+    ptr = img.constBits(); ptr.setsize(w * h * 4)
+    return np.frombuffer(bytes(ptr), np.uint32).reshape(h, w).copy()
 
 
 def rand_src(rng, sw, sh, premul_alpha):
@@ -315,6 +388,8 @@ def main():
         rx = rng.uniform(-rw * 0.5, CW - rw * 0.5); ry = rng.uniform(-rh * 0.5, CH - rh * 0.5)
         if rng.randint(0, 4) == 0:
             rx = float(int(rx)); ry = float(int(ry))
+        if case % 7 == 3:  # drawn 1 : 1 -> Qt's untransformed route
+            rw, rh = float(sw), float(sh)
         if kind == 2:
             rx, ry, rw, rh = float(np.float32(rx)), float(np.float32(ry)), float(np.float32(rw)), float(np.float32(rh))
         opacity = 1.0 if rng.randint(0, 3) else float(np.float32(rng.uniform(0, 1)))
@@ -325,7 +400,7 @@ def main():
         else:
             fmt = QImage.Format_ARGB32_Premultiplied if premul else QImage.Format_RGB32
             got = qt_draw(dst0, [("image", src, fmt, (rx, ry, rw, rh), opacity)])
-            want = dst0.copy().astype(np.uint32); model_draw_image(want, src, rx, ry, rw, rh, opacity)
+            want = dst0.copy().astype(np.uint32); model_draw_image(want, src, rx, ry, rw, rh, opacity, not premul)
         g = got.view(np.uint8).reshape(CH, CW, 4)[..., :3].astype(int); w = want.view(np.uint8).reshape(CH, CW, 4)[..., :3].astype(int)
         d = np.abs(g - w)
         if d.max() > 0:
