@@ -522,12 +522,12 @@ struct StarPilot {
     // candidates = the tiles around the one under screen column 0 (tile_image BAG:854-865 with tile_ratio 1)
     template <class R>
     PG_DEV static int background_rects(R &r, RectD (&rects)[4]) {
-        const float scale = (float)(RES_H / r.G.main_height);
+        const float scale = (float)(R::FRAME_H / r.G.main_height);
         const float bg_k = 3;
         const float t = (float)r.G.cur_time;
         const float char_dim = 5;  // BAG:24
         const float x_off = -t * scale * HP_SLOW_V * 2 / char_dim;
-        const RectD rect = {(double)x_off, (double)(-RES_H * (bg_k - 1) / 2), (double)(RES_H * bg_k * 18.0f), (double)(RES_H * bg_k)};
+        const RectD rect = {(double)x_off, (double)(-R::FRAME_H * (bg_k - 1) / 2), (double)(R::FRAME_H * bg_k * 18.0f), (double)(R::FRAME_H * bg_k)};
         int num_tiles = (int)(rect.w / (rect.h * (double)1.0f));
         if (num_tiles < 1) num_tiles = 1;
         const float tile_width = (float)(rect.w / num_tiles);

@@ -226,41 +226,58 @@ struct HumanRenderer {
     PG_DEV uint32_t texel(const Texture &t, int x, int y) const {
         return d.pixels[t.off + (uint32_t)(y * t.w + (t.mirrored ? t.w - 1 - x : x))];
     }
-    // fetchTransformedBilinearARGB32PM<BlendTransformedBilinear> for pixel b of the run that starts at column x0 of row y (the
-    // spans of a row that touch are fetched as one run; the pixel's place in the run selects the code path Qt's SSE2 build takes)
-    PG_DEV uint32_t fetch_scale(const Texture &t, int y, int x0, int length, int b) const {
+    // fetchTransformedBilinearARGB32PM<BlendTransformedBilinear> for pixel b of the run that starts at column x0 of row y.  The
+    // spans of a row that touch are fetched as one run, and the pixel's place in the run selects the code path of Qt's SSE2 build:
+    //   * 8-bit distances, rows blended first, throughout: scaling up on x (0 < fdx <= 1) or zooming more than 8 times;
+    //   * otherwise a scalar head (8-bit) while a coordinate pair is clamped at the image border, then groups of FOUR pixels with
+    //     rounded 4-bit distances for as long as the whole group stays inside the image, then a scalar tail (8-bit).
+    // [lo, hi]: the pixels b of [0, length) whose coordinate f0 + b * fd lies in [0, (n - 1) << 16), i.e. whose pair is not clamped
+    PG_DEV static void unclamped_range(long long f0, long long fd, int n, int length, long long &lo, long long &hi) {
+        const long long lim = (long long)(n - 1) << 16;
+        lo = 0;
+        hi = (long long)length - 1;
+        if (fd == 0) {
+            if (!(f0 >= 0 && f0 < lim)) hi = -1;
+            return;
+        }
+        // floor / ceil division by a positive divisor
+        auto fdiv = [](long long a, long long q) { return a >= 0 ? a / q : -((-a + q - 1) / q); };
+        auto cdiv = [](long long a, long long q) { return a >= 0 ? (a + q - 1) / q : -((-a) / q); };
+        if (fd > 0) {
+            const long long l2 = cdiv(-f0, fd), h2 = fdiv(lim - 1 - f0, fd);  // f0 + b fd >= 0 ; f0 + b fd <= lim - 1
+            if (l2 > lo) lo = l2;
+            if (h2 < hi) hi = h2;
+        } else {
+            const long long q = -fd;
+            const long long l2 = cdiv(f0 - (lim - 1), q), h2 = fdiv(f0, q);  // f0 - b q <= lim - 1 ; f0 - b q >= 0
+            if (l2 > lo) lo = l2;
+            if (h2 < hi) hi = h2;
+        }
+    }
+    PG_DEV uint32_t fetch(const Texture &t, int y, int x0, int length, int b) const {
         using namespace human;
-        const int fdx = (int)(t.m11 * 65536.0);
+        const int fdx = (int)(t.m11 * 65536.0), fdy = (int)(t.m12 * 65536.0);
         const double cx = x0 + 0.5, cy = y + 0.5;
         const int fx0 = (int)((t.m21 * cy + t.m11 * cx + t.dx) * 65536.0) - 32768;
-        const int fy = (int)((t.m22 * cy + t.m12 * cx + t.dy) * 65536.0) - 32768;
-        int y1 = fy >> 16, y2;
-        if (y1 < 0) y1 = y2 = 0;
-        else if (y1 >= t.h - 1) y1 = y2 = t.h - 1;
-        else y2 = y1 + 1;
-        const int fx = fx0 + b * fdx;
-        int x1 = fx >> 16, x2;
-        if (x1 < 0) x1 = x2 = 0;
-        else if (x1 >= t.w - 1) x1 = x2 = t.w - 1;
-        else x2 = x1 + 1;
+        const int fy0 = (int)((t.m22 * cy + t.m12 * cx + t.dy) * 65536.0) - 32768;
+        const int fx = fx0 + b * fdx, fy = fy0 + b * fdy;
+        bool eight;
+        if (fdy == 0) eight = (fdx > 0 && fdx <= 65536) || (fdx < 0 && fdx > -(65536 / 8)) || pg_fabs(t.m22) < (1. / 8.);
+        else eight = pg_fabs(t.m11) < (1. / 8.) || pg_fabs(t.m22) < (1. / 8.);
         bool four_bit = false;
-        if (!(fdx > 0 && fdx <= 65536) && !((fdx < 0 && fdx > -(65536 / 8)) || pg_fabs(t.m22) < (1. / 8.))) {
-            // scale down: scalar head while the column pair is clamped, groups of four with rounded 4-bit distances while the
-            // whole group stays inside the image, scalar tail
-            int head = 0;
-            if (fdx > 0) {
-                if (fx0 < 0) head = (int)(((long long)(-fx0) + fdx - 1) / fdx);
-                else if ((fx0 >> 16) >= t.w - 1) head = length;
-            } else {
-                // (fdx < 0 does not occur: mirrored sprites are mirrored copies, BAG:121)
-                head = length;
-            }
-            if (head > length) head = length;
-            if (head < length) {
-                const long long fxh = (long long)fx0 + (long long)head * fdx;
+        if (!eight) {
+            long long xl, xh, yl = 0, yh = (long long)length - 1;
+            unclamped_range(fx0, fdx, t.w, length, xl, xh);
+            if (fdy != 0) unclamped_range(fy0, fdy, t.h, length, yl, yh);
+            const long long jl = xl > yl ? xl : yl, jh = xh < yh ? xh : yh;
+            if (jl <= jh) {
+                const long long head = jl;
+                const long long fxh = (long long)fx0 + head * fdx, fyh = (long long)fy0 + head * fdy;
                 long long bounded = length;
-                const long long lim = head + ((long long)(t.w - 1) * 65536 - fxh) / fdx;
-                if (lim < bounded) bounded = lim;
+                if (fdx > 0) { const long long v = head + (((long long)(t.w - 1) << 16) - fxh) / fdx; if (v < bounded) bounded = v; }
+                else if (fdx < 0) { const long long v = head + (0 - fxh) / fdx; if (v < bounded) bounded = v; }
+                if (fdy > 0) { const long long v = head + (((long long)(t.h - 1) << 16) - fyh) / fdy; if (v < bounded) bounded = v; }
+                else if (fdy < 0) { const long long v = head + (0 - fyh) / fdy; if (v < bounded) bounded = v; }
                 bounded -= 3;
                 if (bounded > head) {
                     const long long groups = (bounded - head + 3) / 4;
@@ -268,12 +285,16 @@ struct HumanRenderer {
                 }
             }
         }
-        if (four_bit) {
-            x1 = fx >> 16;  // inside the image by construction
-            x2 = x1 + 1;
-            return interp16(texel(t, x1, y1), texel(t, x2, y1), texel(t, x1, y2), texel(t, x2, y2), (uint32_t)(((fx & 0xffff) + 0x800) >> 12), (uint32_t)(((fy & 0xffff) + 0x800) >> 12));
-        }
-        return interp8(texel(t, x1, y1), texel(t, x2, y1), texel(t, x1, y2), texel(t, x2, y2), (uint32_t)((fx & 0xffff) >> 8), (uint32_t)((fy & 0xffff) >> 8));
+        int x1 = fx >> 16, x2, y1 = fy >> 16, y2;
+        if (x1 < 0) x1 = x2 = 0;
+        else if (x1 >= t.w - 1) x1 = x2 = t.w - 1;
+        else x2 = x1 + 1;
+        if (y1 < 0) y1 = y2 = 0;
+        else if (y1 >= t.h - 1) y1 = y2 = t.h - 1;
+        else y2 = y1 + 1;
+        const uint32_t tl = texel(t, x1, y1), tr = texel(t, x2, y1), bl = texel(t, x1, y2), br = texel(t, x2, y2);
+        if (four_bit) return interp16(tl, tr, bl, br, (uint32_t)(((fx & 0xffff) + 0x800) >> 12), (uint32_t)(((fy & 0xffff) + 0x800) >> 12));
+        return interp8(tl, tr, bl, br, (uint32_t)((fx & 0xffff) >> 8), (uint32_t)((fy & 0xffff) >> 8));
     }
 
     // blend one fetched (or solid) source pixel into the band: comp_func_SourceOver / comp_func_Source with const_alpha
@@ -302,7 +323,8 @@ struct HumanRenderer {
             {
                 int cvL = mul16(rowHeight, c.covLeft) >> 16;
                 if (c.single) {
-                    if (cvL) { sx[n] = c.iLeft; sl[n] = 1; sc[n] = cvL; n++; }
+                    // (Qt adds the two partial widths of a rect inside one pixel column: up to 2 x 255, kept in QT_FT_Span's unsigned char)
+                    if (cvL) { sx[n] = c.iLeft; sl[n] = 1; sc[n] = cvL & 0xff; n++; }
                 } else {
                     const int cvM = mul16(rowHeight, 255 << 16) >> 16, cvR = mul16(rowHeight, c.covRight) >> 16;
                     const bool left_full = c.covLeft == 65536 * 255;  // leftWidth == 1: Qt folds the inner columns into the first span
@@ -343,6 +365,207 @@ struct HumanRenderer {
                 }
                 i = j;
             }
+        }
+        PG_SYNC();
+    }
+
+    // ---- a general (turned) line: QRasterizer::rasterizeLine's antialiased trapezoid walker ------------------------------------------
+    PG_DEV static double safe_div(double x, double y) { return y == 0 ? (x > 0 ? 1e9 : -1e9) : x / y; }                       // qSafeDivide
+    PG_DEV static int sf16(double x) { return human::f16(x < -32768.0 ? -32768.0 : (x > 32767.0 ? 32767.0 : x)); }             // qSafeFloatToQ16Dot16
+    PG_DEV static int fmul16(int a, int b) { return (int)((uint32_t)a * (uint32_t)b) >> 16; }                                  // Q16Dot16FastMultiply (32-bit product)
+    PG_DEV static int intersect_pixel_fp(int x, int top, int bottom, int leftIntersectX, int rightIntersectX, int slope, int invSlope) {
+        using namespace human;
+        const int leftX = x << 16, rightX = (x << 16) + 65536;
+        int leftIntersectY, rightIntersectY;
+        if (slope > 0) {
+            leftIntersectY = top + mul16(leftX - leftIntersectX, invSlope);
+            rightIntersectY = leftIntersectY + invSlope;
+        } else {
+            leftIntersectY = top + mul16(leftX - rightIntersectX, invSlope);
+            rightIntersectY = leftIntersectY + invSlope;
+        }
+        if (leftIntersectX >= leftX && rightIntersectX <= rightX) return mul16(bottom - top, leftIntersectX - leftX + ((rightIntersectX - leftIntersectX) >> 1));
+        if (leftIntersectX >= rightX) return bottom - top;
+        if (leftIntersectX >= leftX) {
+            if (slope > 0) return (bottom - top) - fmul16((rightX - leftIntersectX) >> 1, rightIntersectY - top);
+            return (bottom - top) - fmul16((rightX - leftIntersectX) >> 1, bottom - rightIntersectY);
+        }
+        if (rightIntersectX <= leftX) return 0;
+        if (rightIntersectX <= rightX) {
+            if (slope > 0) return fmul16((rightIntersectX - leftX) >> 1, bottom - leftIntersectY);
+            return fmul16((rightIntersectX - leftX) >> 1, leftIntersectY - top);
+        }
+        if (slope > 0) return (bottom - rightIntersectY) + ((rightIntersectY - leftIntersectY) >> 1);
+        return (rightIntersectY - top) + ((leftIntersectY - rightIntersectY) >> 1);
+    }
+    struct GenRow {  // one row of the walker: everything the coverage of a pixel depends on
+        int yFP, iLeftFP, iRightFP;
+        int rowTop, rowBottom, rowBottomLeft, rowBottomRight, rowTopLeft, rowTopRight, rowHeight;
+        int topLeftAf, topLeftBf, topRightAf, topRightBf, bottomLeftAf, bottomLeftBf, bottomRightAf, bottomRightBf;
+        int tlFP, trFP, blFP, brFP, itlFP, itrFP, iblFP, ibrFP;
+        int leftMin, leftMax, rightMin, rightMax;
+        PG_DEV int right_excluded(int x) const {
+            int e = 0;
+            if (yFP <= iRightFP && rowBottomRight > rowTop) e += (rowBottomRight - rowTop) - intersect_pixel_fp(x, rowTop, rowBottomRight, topRightAf, bottomRightAf, trFP, itrFP);
+            if (yFP >= iRightFP && rowBottom > rowTopRight) e += (rowBottom - rowTopRight) - intersect_pixel_fp(x, rowTopRight, rowBottom, bottomRightBf, topRightBf, brFP, ibrFP);
+            return e;
+        }
+        PG_DEV int coverage(int x) const {  // 0..255; x in [leftMin, rightMax]
+            int cov16;
+            if (x <= leftMax) {
+                int excluded = 0;
+                if (yFP <= iLeftFP && rowBottomLeft > rowTop) excluded += intersect_pixel_fp(x, rowTop, rowBottomLeft, bottomLeftAf, topLeftAf, tlFP, itlFP);
+                if (yFP >= iLeftFP && rowBottom > rowTopLeft) excluded += intersect_pixel_fp(x, rowTopLeft, rowBottom, topLeftBf, bottomLeftBf, blFP, iblFP);
+                if (x >= rightMin) excluded += right_excluded(x);
+                cov16 = rowHeight - excluded;
+            } else if (x < rightMin) {
+                cov16 = rowHeight;
+            } else {
+                cov16 = rowHeight - right_excluded(x);
+            }
+            return (255 * cov16) >> 16;
+        }
+    };
+    // gl = {pa.x, pa.y, pb.x, pb.y, width} as rasterize_line left them
+    template <class Src>
+    PG_DEV void fill_general(const double (&gl)[5], int io, bool source_mode, Src src) {
+        using namespace human;
+        double pax = gl[0], pay = gl[1], pbx = gl[2], pby = gl[3];
+        const double width = gl[4];
+        if (pay > pby) {
+            double t = pax; pax = pbx; pbx = t;
+            t = pay; pay = pby; pby = t;
+        }
+        const double dlx = (pbx - pax) * (0.5 * width), dly = (pby - pay) * (0.5 * width);
+        const double perpx = dly, perpy = -dlx;
+        double tx, ty, lx, ly, rx, ry, bx, by;
+        if (pax < pbx) {
+            tx = pax + perpx; ty = pay + perpy; lx = pax - perpx; ly = pay - perpy; rx = pbx + perpx; ry = pby + perpy; bx = pbx - perpx; by = pby - perpy;
+        } else {
+            tx = pax - perpx; ty = pay - perpy; lx = pbx - perpx; ly = pby - perpy; rx = pax + perpx; ry = pay + perpy; bx = pbx + perpx; by = pby + perpy;
+        }
+        // snapTo26Dot6Grid: the four corners, DOWN to multiples of 1/64
+        tx = pg_floor(tx * 64) * (1 / 64.); ty = pg_floor(ty * 64) * (1 / 64.);
+        lx = pg_floor(lx * 64) * (1 / 64.); ly = pg_floor(ly * 64) * (1 / 64.);
+        rx = pg_floor(rx * 64) * (1 / 64.); ry = pg_floor(ry * 64) * (1 / 64.);
+        bx = pg_floor(bx * 64) * (1 / 64.); by = pg_floor(by * 64) * (1 / 64.);
+        const int clipB = HUMAN_RES - 1, clipR = HUMAN_RES - 1;
+        const double topBound = ty < 0 ? 0 : (ty > clipB ? clipB : ty), bottomBound = by < 0 ? 0 : (by > clipB ? clipB : by);
+        const double tlS = safe_div(lx - tx, ly - ty), blS = safe_div(bx - lx, by - ly), trS = safe_div(rx - tx, ry - ty), brS = safe_div(bx - rx, by - ry);
+        GenRow g;
+        g.tlFP = sf16(tlS); g.trFP = sf16(trS); g.blFP = sf16(blS); g.brFP = sf16(brS);
+        g.itlFP = sf16(safe_div(1, tlS)); g.itrFP = sf16(safe_div(1, trS)); g.iblFP = sf16(safe_div(1, blS)); g.ibrFP = sf16(safe_div(1, brS));
+        const int iTopFP = (int)topBound << 16, iBottomFP = (int)bottomBound << 16;
+        g.iLeftFP = (int)ly << 16;
+        g.iRightFP = (int)ry << 16;
+        int leftAf = sf16(tx + ((int)topBound - ty) * tlS), rightAf = sf16(tx + ((int)topBound - ty) * trS), leftBf = 0, rightBf = 0;
+        if (g.iLeftFP < iTopFP) leftBf = sf16(lx + ((int)topBound - ly) * blS);
+        if (g.iRightFP < iTopFP) rightBf = sf16(rx + ((int)topBound - ry) * brS);
+        const int yTopFP = sf16(ty), yLeftFP = sf16(ly), yRightFP = sf16(ry), yBottomFP = sf16(by);
+        int rowTop = iTopFP > yTopFP ? iTopFP : yTopFP;
+        int topLeftAf = leftAf + mul16(g.tlFP, rowTop - iTopFP), topRightAf = rightAf + mul16(g.trFP, rowTop - iTopFP);
+        for (int yFP = iTopFP; yFP <= iBottomFP; yFP += 65536) {
+            const int y = yFP >> 16;
+            if (y >= row1) break;
+            g.yFP = yFP;
+            g.rowTop = rowTop;
+            g.rowBottomLeft = yFP + 65536 < yLeftFP ? yFP + 65536 : yLeftFP;
+            g.rowBottomRight = yFP + 65536 < yRightFP ? yFP + 65536 : yRightFP;
+            g.rowTopLeft = yFP > yLeftFP ? yFP : yLeftFP;
+            g.rowTopRight = yFP > yRightFP ? yFP : yRightFP;
+            g.rowBottom = yFP + 65536 < yBottomFP ? yFP + 65536 : yBottomFP;
+            g.topLeftAf = topLeftAf;
+            g.topRightAf = topRightAf;
+            if (yFP == g.iLeftFP) {
+                leftBf = sf16(lx + (y - ly) * blS);
+                g.topLeftBf = leftBf + mul16(g.blFP, g.rowTopLeft - yFP);
+                g.bottomLeftAf = leftAf + mul16(g.tlFP, g.rowBottomLeft - yFP);
+            } else {
+                g.topLeftBf = leftBf;
+                g.bottomLeftAf = leftAf + g.tlFP;
+            }
+            if (yFP == g.iRightFP) {
+                rightBf = sf16(rx + (y - ry) * brS);
+                g.topRightBf = rightBf + mul16(g.brFP, g.rowTopRight - yFP);
+                g.bottomRightAf = rightAf + mul16(g.trFP, g.rowBottomRight - yFP);
+            } else {
+                g.topRightBf = rightBf;
+                g.bottomRightAf = rightAf + g.trFP;
+            }
+            if (yFP == iBottomFP) {
+                g.bottomLeftBf = leftBf + mul16(g.blFP, g.rowBottom - yFP);
+                g.bottomRightBf = rightBf + mul16(g.brFP, g.rowBottom - yFP);
+            } else {
+                g.bottomLeftBf = leftBf + g.blFP;
+                g.bottomRightBf = rightBf + g.brFP;
+            }
+            auto bound = [clipR](int v) { return v < 0 ? 0 : (v > clipR ? clipR : v); };
+            auto mx = [](int a, int b) { return a > b ? a : b; };
+            auto mn = [](int a, int b) { return a < b ? a : b; };
+            if (yFP < g.iLeftFP) { g.leftMin = g.bottomLeftAf >> 16; g.leftMax = g.topLeftAf >> 16; }
+            else if (yFP == g.iLeftFP) { g.leftMin = mx(g.bottomLeftAf, g.topLeftBf) >> 16; g.leftMax = mx(g.topLeftAf, g.bottomLeftBf) >> 16; }
+            else { g.leftMin = g.topLeftBf >> 16; g.leftMax = g.bottomLeftBf >> 16; }
+            g.leftMin = bound(g.leftMin);
+            g.leftMax = bound(g.leftMax);
+            if (yFP < g.iRightFP) { g.rightMin = g.topRightAf >> 16; g.rightMax = g.bottomRightAf >> 16; }
+            else if (yFP == g.iRightFP) { g.rightMin = mn(g.topRightAf, g.bottomRightBf) >> 16; g.rightMax = mx(g.bottomRightAf, g.topRightBf) >> 16; }
+            else { g.rightMin = g.bottomRightBf >> 16; g.rightMax = g.topRightBf >> 16; }
+            g.rightMin = bound(g.rightMin);
+            g.rightMax = bound(g.rightMax);
+            if (g.leftMax > g.rightMax) g.leftMax = g.rightMax;
+            if (g.rightMin < g.leftMin) g.rightMin = g.leftMin;
+            g.rowHeight = g.rowBottom - g.rowTop;
+            if (y >= row0) {
+                // the spans of this row in Qt's order: single pixels leftMin..leftMax, the full span up to rightMin, single pixels up to
+                // rightMax; spans of coverage 0 are dropped, the ones that touch form a run for the fetch
+                const int last = g.rightMax > g.leftMax ? g.rightMax : g.leftMax;
+                const int mid_cov = (255 * g.rowHeight) >> 16;
+                int run = -1;  // first column of the open run
+                uint32_t *rowp = fb + (y - row0) * HUMAN_RES;
+                auto flush = [&](int xe) {  // the run [run, xe)
+                    if (run < 0 || xe <= run) return;
+                    const int x0 = run, length = xe - run;
+                    for (int base = 0; base < length; base += 64) {
+                        PG_FOR_LANES(l) {
+                            const int b = base + l;
+                            if (b < length) {
+                                const int x = x0 + b;
+                                const int cv = g.coverage(x);
+                                const uint32_t ca = (uint32_t)((cv * io) >> 8);
+                                rowp[x] = blend(rowp[x], src(y, x0, length, b), ca, source_mode);
+                            }
+                        }
+                    }
+                };
+                int x = g.leftMin;
+                while (x <= last) {
+                    if (x > g.leftMax && x < g.rightMin) {  // the full span
+                        if (mid_cov != 0) {
+                            if (run < 0) run = x;
+                        } else {
+                            flush(x);
+                            run = -1;
+                        }
+                        x = g.rightMin;
+                        continue;
+                    }
+                    if (g.coverage(x) != 0) {
+                        if (run < 0) run = x;
+                    } else {
+                        flush(x);
+                        run = -1;
+                    }
+                    x++;
+                }
+                flush(last + 1);
+            }
+            leftAf += g.tlFP;
+            leftBf += g.blFP;
+            rightAf += g.trFP;
+            rightBf += g.brFP;
+            topLeftAf = leftAf;
+            topRightAf = rightAf;
+            rowTop = yFP + 65536;
         }
         PG_SYNC();
     }
@@ -420,7 +643,7 @@ struct HumanRenderer {
         if (o < 0) o = 0;
         if (o > 1) o = 1;
         const int io = (int)(o * 256);
-        fill_axis(c, io, rgb32 && io == 256, [this, &tx](int y, int x0, int length, int b) { return fetch_scale(tx, y, x0, length, b); });
+        fill_axis(c, io, rgb32 && io == 256, [this, &tx](int y, int x0, int length, int b) { return fetch(tx, y, x0, length, b); });
     }
 
     // tile_image BAG:840-869
@@ -495,7 +718,94 @@ struct HumanRenderer {
             draw_image_rotated(im, is_reflected, rect, rotation, alpha);
         }
     }
-    PG_DEV void draw_image_rotated(const ImgDesc, bool, const RectD &, float, float) { fail(PGE_UNSUPPORTED_DRAW); }
+    // BAG:902-906: p.translate(cx, cy); p.rotate(rotation * 180 / PI); p.drawImage(QRectF(-w/2, -h/2, w, h), img)
+    PG_DEV void draw_image_rotated(const ImgDesc im, bool mirrored, const RectD &adjusted, float rotation, float opacity) {
+        const double w = adjusted.w, h = adjusted.h;
+        if (!(w > 0) || !(h > 0)) return;
+        const double cx = adjusted.x + adjusted.w / 2, cy = adjusted.y + adjusted.h / 2;
+        const double a = (double)(rotation * 180 / PG_PI);
+        double sina = 0, cosa = 0;  // QTransform::rotate
+        if (a == 0) cosa = 1;
+        else if (a == 90. || a == -270.) sina = 1.;
+        else if (a == 270. || a == -90.) sina = -1.;
+        else if (a == 180.) cosa = -1.;
+        else {
+            const double b = 0.017453292519943295769 * a;
+            sina = pg_sin_d(b);
+            cosa = pg_cos_d(b);
+        }
+        const double m11 = cosa, m12 = sina, m21 = -sina, m22 = cosa, mdx = cx, mdy = cy;
+        // QTransform::type(): 3 rotate, 2 scale, 1 translate, 0 none
+        int typ;
+        if (!q_fuzzy_is_null(m12) || !q_fuzzy_is_null(m21)) typ = 3;
+        else if (!q_fuzzy_is_null(m11 - 1) || !q_fuzzy_is_null(m22 - 1)) typ = 2;
+        else if (!q_fuzzy_is_null(mdx) || !q_fuzzy_is_null(mdy)) typ = 1;
+        else typ = 0;
+        auto map = [&](double x, double y, double &ox, double &oy) {  // QTransform::map
+            if (typ == 0) { ox = x; oy = y; }
+            else if (typ == 1) { ox = x + mdx; oy = y + mdy; }
+            else if (typ == 2) { ox = m11 * x + mdx; oy = m22 * y + mdy; }
+            else { ox = m11 * x + m21 * y + mdx; oy = m12 * x + m22 * y + mdy; }
+        };
+        const double rx = -w / 2, ry = -h / 2;
+        // the texture matrix: copy = matrix; copy.translate(r.x, r.y); copy.scale(r.w / sw, r.h / sh); inverse of translate(1/65536) * copy
+        Texture tx;
+        tx.off = im.off;
+        tx.w = im.w;
+        tx.h = im.h;
+        tx.mirrored = mirrored;
+        tx.rgb32 = false;
+        {
+            double c11 = m11, c12 = m12, c21 = m21, c22 = m22, cdx = mdx, cdy = mdy;
+            int ctyp;
+            if (typ == 0) { cdx = rx; cdy = ry; ctyp = 1; }
+            else if (typ == 1) { cdx += rx; cdy += ry; ctyp = 1; }
+            else if (typ == 2) { cdx += rx * c11; cdy += ry * c22; ctyp = 2; }
+            else { cdx += rx * c11 + ry * c21; cdy += ry * c22 + rx * c12; ctyp = 3; }
+            const double scx = w / (double)im.w, scy = h / (double)im.h;
+            if (ctyp == 3) { c12 *= scx; c21 *= scy; }
+            c11 *= scx;
+            c22 *= scy;
+            if (ctyp < 2) ctyp = 2;
+            const double dd = 1.0 / 65536;
+            if (ctyp == 2) {
+                const double p11 = 1.0 * c11, p22 = 1.0 * c22, p31 = dd * c11 + cdx, p32 = dd * c22 + cdy;
+                tx.m11 = 1. / p11;
+                tx.m22 = 1. / p22;
+                tx.m12 = tx.m21 = 0;
+                tx.dx = -p31 * tx.m11;
+                tx.dy = -p32 * tx.m22;
+            } else {
+                const double p11 = 1.0 * c11 + 0.0 * c21, p12 = 1.0 * c12 + 0.0 * c22, p21 = 0.0 * c11 + 1.0 * c21, p22 = 0.0 * c12 + 1.0 * c22;
+                const double p31 = dd * c11 + dd * c21 + cdx, p32 = dd * c12 + dd * c22 + cdy;
+                const double dtr = p11 * p22 - p12 * p21, dinv = 1.0 / dtr;
+                tx.m11 = p22 * dinv;
+                tx.m12 = -p12 * dinv;
+                tx.m21 = -p21 * dinv;
+                tx.m22 = p11 * dinv;
+                tx.dx = (p21 * p32 - p22 * p31) * dinv;
+                tx.dy = (p12 * p31 - p11 * p32) * dinv;
+            }
+        }
+        double o = (double)opacity;
+        if (o < 0) o = 0;
+        if (o > 1) o = 1;
+        const int io = (int)(o * 256);
+        double ax, ay, bx, by;
+        const double l = rx, t = ry, rr = rx + w, bb = ry + h;
+        map((l + l) * 0.5, (t + bb) * 0.5, ax, ay);
+        map((rr + rr) * 0.5, (t + bb) * 0.5, bx, by);
+        human::AxisCoverage c;
+        double gl[5];
+        const int kind = rasterize_line(ax, ay, bx, by, h / w, c, gl);
+        auto srcf = [this, &tx](int y, int x0, int length, int b) { return fetch(tx, y, x0, length, b); };
+        if (kind == 1) {
+            if (c.iBottom < row0 || c.iTop >= row1) return;
+            fill_axis(c, io, false, srcf);
+        } else if (kind == 2) {
+            fill_general(gl, io, false, srcf);
+        }
+    }
     // jumper's compass (drawEllipse / drawLine under Antialiasing: Qt's gray raster and its antialiased cosmetic stroker) is not
     // restated: libenv_make refuses render_human for jumper, these only keep the policy's draw_overlay compiling
     PG_DEV void exec_ellipse(int, int, int, int, bool, uint32_t, uint32_t) { fail(PGE_UNSUPPORTED_DRAW); }

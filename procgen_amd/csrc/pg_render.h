@@ -187,6 +187,7 @@ struct Renderer {
     const DevCtx &d;
     const int env;
     typedef RenderLdsT<Game> RenderLds;
+    static constexpr int FRAME_W = RES_W, FRAME_H = RES_H;  // (pg_human.h's renderer draws the same policies at 512 x 512)
     static constexpr int WIDE_ROWS = GameWideRows<Game>::value;
     static_assert(BAND_ROWS % WIDE_ROWS == 0, "fetch batches tile the band");
     RenderLds *lds;

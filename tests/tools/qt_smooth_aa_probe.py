@@ -111,7 +111,7 @@ def aa_line_spans(ax, ay, bx, by, width, cw=CW, ch=CH):
     spans = []
     def add(x, ln, y, cov):
         if cov and ln and 0 <= y < ch:
-            spans.append((y, x, ln, cov))
+            spans.append((y, x, ln, cov & 0xff))  # QT_FT_Span::coverage is an unsigned char
     if q26eq(pax, pbx):
         if pay > pby:
             pax, pay, pbx, pby = pbx, pby, pax, pay
@@ -413,3 +413,344 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---- rotated painter (BAG:902-906: translate, rotate, drawImage on the centred rect) ---------------------------------------
+def i32(v):
+    v &= 0xffffffff
+    return v - (1 << 32) if v & 0x80000000 else v
+
+
+def fmul(a, b):  # Q16Dot16FastMultiply: 32-bit product
+    return i32(a * b) >> 16
+
+
+def intersect_pixel_fp(x, top, bottom, leftIntersectX, rightIntersectX, slope, invSlope):
+    leftX = x << 16; rightX = (x << 16) + 65536
+    if slope > 0:
+        leftIntersectY = top + mul16(leftX - leftIntersectX, invSlope)
+        rightIntersectY = leftIntersectY + invSlope
+    else:
+        leftIntersectY = top + mul16(leftX - rightIntersectX, invSlope)
+        rightIntersectY = leftIntersectY + invSlope
+    if leftIntersectX >= leftX and rightIntersectX <= rightX:
+        return mul16(bottom - top, leftIntersectX - leftX + ((rightIntersectX - leftIntersectX) >> 1))
+    elif leftIntersectX >= rightX:
+        return bottom - top
+    elif leftIntersectX >= leftX:
+        if slope > 0:
+            return (bottom - top) - fmul((rightX - leftIntersectX) >> 1, rightIntersectY - top)
+        else:
+            return (bottom - top) - fmul((rightX - leftIntersectX) >> 1, bottom - rightIntersectY)
+    elif rightIntersectX <= leftX:
+        return 0
+    elif rightIntersectX <= rightX:
+        if slope > 0:
+            return fmul((rightIntersectX - leftX) >> 1, bottom - leftIntersectY)
+        else:
+            return fmul((rightIntersectX - leftX) >> 1, leftIntersectY - top)
+    else:
+        if slope > 0:
+            return (bottom - rightIntersectY) + ((rightIntersectY - leftIntersectY) >> 1)
+        else:
+            return (rightIntersectY - top) + ((leftIntersectY - rightIntersectY) >> 1)
+
+
+def safe_div(x, y):  # qSafeDivide
+    if y == 0:
+        return 1e9 if x > 0 else -1e9
+    return x / y
+
+
+def sF16(x):  # qSafeFloatToQ16Dot16
+    return F16(min(max(x, -32768.0), 32767.0))
+
+
+def aa_line_spans_any(ax, ay, bx, by, width, cw=CW, ch=CH):
+    """QRasterizer::rasterizeLine, antialiased, any direction.  General lines: the four corners are snapped DOWN to the 26.6
+    grid (snapTo26Dot6Grid), every edge keeps its own slope, a 16.16 trapezoid walker with intersectPixelFP gives the coverage"""
+    c = clip_line(ax, ay, bx, by, width, cw, ch)
+    if c is None:
+        return []
+    pax, pay, pbx, pby, w2 = c
+    if q26eq(pay, pby) or q26eq(pax, pbx):
+        return aa_line_spans(ax, ay, bx, by, width, cw, ch)
+    width = w2
+    if pay > pby:
+        pax, pay, pbx, pby = pbx, pby, pax, pay
+    dlx = (pbx - pax) * (0.5 * width); dly = (pby - pay) * (0.5 * width)
+    perpx, perpy = dly, -dlx
+    if pax < pbx:
+        top = (pax + perpx, pay + perpy); left = (pax - perpx, pay - perpy); right = (pbx + perpx, pby + perpy); bottom = (pbx - perpx, pby - perpy)
+    else:
+        top = (pax - perpx, pay - perpy); left = (pbx - perpx, pby - perpy); right = (pax + perpx, pay + perpy); bottom = (pbx + perpx, pby + perpy)
+    snap = lambda p: (math.floor(p[0] * 64) * (1 / 64.), math.floor(p[1] * 64) * (1 / 64.))  # snapTo26Dot6Grid
+    top, left, right, bottom = snap(top), snap(left), snap(right), snap(bottom)
+    clipT, clipB, clipL, clipR = 0, ch - 1, 0, cw - 1
+    topBound = min(max(top[1], float(clipT)), float(clipB)); bottomBound = min(max(bottom[1], float(clipT)), float(clipB))
+    tlS = safe_div(left[0] - top[0], left[1] - top[1]); blS = safe_div(bottom[0] - left[0], bottom[1] - left[1])
+    trS = safe_div(right[0] - top[0], right[1] - top[1]); brS = safe_div(bottom[0] - right[0], bottom[1] - right[1])
+    tlFP, trFP, blFP, brFP = sF16(tlS), sF16(trS), sF16(blS), sF16(brS)
+    itlFP, itrFP, iblFP, ibrFP = sF16(safe_div(1, tlS)), sF16(safe_div(1, trS)), sF16(safe_div(1, blS)), sF16(safe_div(1, brS))
+    spans = []
+    def add(x, ln, y, cov):
+        if cov and ln and 0 <= y < ch:
+            spans.append((y, x, ln, cov))
+    iTopFP = c_int(topBound) << 16; iLeftFP = c_int(left[1]) << 16; iRightFP = c_int(right[1]) << 16; iBottomFP = c_int(bottomBound) << 16
+    leftIntersectAf = sF16(top[0] + (c_int(topBound) - top[1]) * tlS)
+    rightIntersectAf = sF16(top[0] + (c_int(topBound) - top[1]) * trS)
+    leftIntersectBf = 0; rightIntersectBf = 0
+    if iLeftFP < iTopFP:
+        leftIntersectBf = sF16(left[0] + (c_int(topBound) - left[1]) * blS)
+    if iRightFP < iTopFP:
+        rightIntersectBf = sF16(right[0] + (c_int(topBound) - right[1]) * brS)
+    yTopFP = sF16(top[1]); yLeftFP = sF16(left[1]); yRightFP = sF16(right[1]); yBottomFP = sF16(bottom[1])
+    rowTop = max(iTopFP, yTopFP)
+    topLeftIntersectAf = leftIntersectAf + mul16(tlFP, rowTop - iTopFP)
+    topRightIntersectAf = rightIntersectAf + mul16(trFP, rowTop - iTopFP)
+    yFP = iTopFP
+    bound = lambda v: min(max(v, clipL), clipR)
+    while yFP <= iBottomFP:
+        rowBottomLeft = min(yFP + 65536, yLeftFP); rowBottomRight = min(yFP + 65536, yRightFP)
+        rowTopLeft = max(yFP, yLeftFP); rowTopRight = max(yFP, yRightFP)
+        rowBottom = min(yFP + 65536, yBottomFP)
+        if yFP == iLeftFP:
+            y = yFP >> 16
+            leftIntersectBf = sF16(left[0] + (y - left[1]) * blS)
+            topLeftIntersectBf = leftIntersectBf + mul16(blFP, rowTopLeft - yFP)
+            bottomLeftIntersectAf = leftIntersectAf + mul16(tlFP, rowBottomLeft - yFP)
+        else:
+            topLeftIntersectBf = leftIntersectBf
+            bottomLeftIntersectAf = leftIntersectAf + tlFP
+        if yFP == iRightFP:
+            y = yFP >> 16
+            rightIntersectBf = sF16(right[0] + (y - right[1]) * brS)
+            topRightIntersectBf = rightIntersectBf + mul16(brFP, rowTopRight - yFP)
+            bottomRightIntersectAf = rightIntersectAf + mul16(trFP, rowBottomRight - yFP)
+        else:
+            topRightIntersectBf = rightIntersectBf
+            bottomRightIntersectAf = rightIntersectAf + trFP
+        if yFP == iBottomFP:
+            bottomLeftIntersectBf = leftIntersectBf + mul16(blFP, rowBottom - yFP)
+            bottomRightIntersectBf = rightIntersectBf + mul16(brFP, rowBottom - yFP)
+        else:
+            bottomLeftIntersectBf = leftIntersectBf + blFP
+            bottomRightIntersectBf = rightIntersectBf + brFP
+        if yFP < iLeftFP:
+            leftMin = bottomLeftIntersectAf >> 16; leftMax = topLeftIntersectAf >> 16
+        elif yFP == iLeftFP:
+            leftMin = max(bottomLeftIntersectAf, topLeftIntersectBf) >> 16; leftMax = max(topLeftIntersectAf, bottomLeftIntersectBf) >> 16
+        else:
+            leftMin = topLeftIntersectBf >> 16; leftMax = bottomLeftIntersectBf >> 16
+        leftMin = bound(leftMin); leftMax = bound(leftMax)
+        if yFP < iRightFP:
+            rightMin = topRightIntersectAf >> 16; rightMax = bottomRightIntersectAf >> 16
+        elif yFP == iRightFP:
+            rightMin = min(topRightIntersectAf, bottomRightIntersectBf) >> 16; rightMax = max(bottomRightIntersectAf, topRightIntersectBf) >> 16
+        else:
+            rightMin = bottomRightIntersectBf >> 16; rightMax = topRightIntersectBf >> 16
+        rightMin = bound(rightMin); rightMax = bound(rightMax)
+        if leftMax > rightMax: leftMax = rightMax
+        if rightMin < leftMin: rightMin = leftMin
+        rowHeight = rowBottom - rowTop
+        yy = yFP >> 16
+        def right_excl(x):
+            e = 0
+            if yFP <= iRightFP and rowBottomRight > rowTop:
+                e += (rowBottomRight - rowTop) - intersect_pixel_fp(x, rowTop, rowBottomRight, topRightIntersectAf, bottomRightIntersectAf, trFP, itrFP)
+            if yFP >= iRightFP and rowBottom > rowTopRight:
+                e += (rowBottom - rowTopRight) - intersect_pixel_fp(x, rowTopRight, rowBottom, bottomRightIntersectBf, topRightIntersectBf, brFP, ibrFP)
+            return e
+        x = leftMin
+        while x <= leftMax:
+            excluded = 0
+            if yFP <= iLeftFP and rowBottomLeft > rowTop:
+                excluded += intersect_pixel_fp(x, rowTop, rowBottomLeft, bottomLeftIntersectAf, topLeftIntersectAf, tlFP, itlFP)
+            if yFP >= iLeftFP and rowBottom > rowTopLeft:
+                excluded += intersect_pixel_fp(x, rowTopLeft, rowBottom, topLeftIntersectBf, bottomLeftIntersectBf, blFP, iblFP)
+            if x >= rightMin:
+                excluded += right_excl(x)
+            add(x, 1, yy, (255 * (rowHeight - excluded)) >> 16)
+            x += 1
+        if x < rightMin:
+            add(x, rightMin - x, yy, (255 * rowHeight) >> 16)
+            x = rightMin
+        while x <= rightMax:
+            add(x, 1, yy, (255 * (rowHeight - right_excl(x))) >> 16)
+            x += 1
+        leftIntersectAf += tlFP; leftIntersectBf += blFP
+        rightIntersectAf += trFP; rightIntersectBf += brFP
+        topLeftIntersectAf = leftIntersectAf; topRightIntersectAf = rightIntersectAf
+        yFP += 65536
+        rowTop = yFP
+    return spans
+
+
+def q_fuzzy_is_null(v):
+    return abs(v) <= 0.000000000001
+
+
+def painter_matrix(cx, cy, deg):
+    """QTransform after translate(cx, cy); rotate(deg): (m11, m12, m21, m22, dx, dy, type)"""
+    a = deg
+    sina = cosa = 0.0
+    if a == 0: cosa = 1.0
+    elif a == 90. or a == -270.: sina = 1.
+    elif a == 270. or a == -90.: sina = -1.
+    elif a == 180.: cosa = -1.
+    else:
+        b = 0.017453292519943295769 * a
+        sina = math.sin(b); cosa = math.cos(b)
+    m11, m12, m21, m22, mdx, mdy = cosa, sina, -sina, cosa, cx, cy
+    if not q_fuzzy_is_null(m12) or not q_fuzzy_is_null(m21): typ = 'rotate'
+    elif not q_fuzzy_is_null(m11 - 1) or not q_fuzzy_is_null(m22 - 1): typ = 'scale'
+    elif not q_fuzzy_is_null(mdx) or not q_fuzzy_is_null(mdy): typ = 'translate'
+    else: typ = 'none'
+    return m11, m12, m21, m22, mdx, mdy, typ
+
+
+def map_point(M, x, y):
+    m11, m12, m21, m22, mdx, mdy, typ = M
+    if typ == 'none': return x, y
+    if typ == 'translate': return x + mdx, y + mdy
+    if typ == 'scale': return m11 * x + mdx, m22 * y + mdy
+    return m11 * x + m21 * y + mdx, m12 * x + m22 * y + mdy
+
+
+def model_fill_rotated(dst, cx, cy, w, h, deg, color):
+    ch, cw = dst.shape
+    M = painter_matrix(cx, cy, deg)
+    rx, ry, rw, rh = -w / 2, -h / 2, w, h
+    l, t, r_, b_ = rx, ry, rx + rw, ry + rh
+    ax, ay = map_point(M, (l + l) * 0.5, (t + b_) * 0.5)
+    bx, by = map_point(M, (r_ + r_) * 0.5, (t + b_) * 0.5)
+    for (y, x, ln, cov) in aa_line_spans_any(ax, ay, bx, by, rh / rw, cw, ch):
+        for i in range(ln):
+            dst[y, x + i] = source_over(int(dst[y, x + i]), color, cov)
+
+
+def qt_fill_rotated(dst0, cx, cy, w, h, deg, c):
+    QImage, QPainter, QColor, QRectF = qt_setup()
+    hh, ww = dst0.shape
+    img = np_to_qimage(dst0, QImage.Format_RGB32).copy()
+    p = QPainter(img)
+    p.setRenderHint(QPainter.Antialiasing, True); p.setRenderHint(QPainter.SmoothPixmapTransform, True)
+    p.translate(cx, cy); p.rotate(deg)
+    p.fillRect(QRectF(-w / 2, -h / 2, w, h), QColor((c >> 16) & 255, (c >> 8) & 255, c & 255, c >> 24))
+    p.end()
+    ptr = img.constBits(); ptr.setsize(ww * hh * 4)
+    return np.frombuffer(bytes(ptr), np.uint32).reshape(hh, ww).copy()
+
+
+def rotated_matrices(cx, cy, w, h, deg, sw, sh):
+    """painter matrix M and the texture matrix (inverse of translate(1/65536) * M * translate(r) * scale(r / s))"""
+    M = painter_matrix(cx, cy, deg)
+    m11, m12, m21, m22, mdx, mdy, typ = M
+    rx, ry, rw, rh = -w / 2, -h / 2, w, h
+    c11, c12, c21, c22, cdx, cdy = m11, m12, m21, m22, mdx, mdy
+    if typ == 'none': cdx, cdy = rx, ry; ctyp = 'translate'
+    elif typ == 'translate': cdx += rx; cdy += ry; ctyp = 'translate'
+    elif typ == 'scale': cdx += rx * c11; cdy += ry * c22; ctyp = 'scale'
+    else: cdx += rx * c11 + ry * c21; cdy += ry * c22 + rx * c12; ctyp = 'rotate'
+    scx, scy = rw / sw, rh / sh
+    if ctyp == 'rotate':
+        c12 *= scx; c21 *= scy
+    c11 *= scx; c22 *= scy
+    if ctyp in ('none', 'translate'): ctyp = 'scale'
+    d = 1.0 / 65536
+    if ctyp == 'scale':
+        p11 = 1.0 * c11; p22 = 1.0 * c22; p31 = d * c11 + cdx; p32 = d * c22 + cdy
+        i11 = 1. / p11; i22 = 1. / p22; i12 = i21 = 0.0
+        idx = -p31 * i11; idy = -p32 * i22
+    else:
+        p11 = 1.0 * c11 + 0.0 * c21; p12 = 1.0 * c12 + 0.0 * c22
+        p21 = 0.0 * c11 + 1.0 * c21; p22 = 0.0 * c12 + 1.0 * c22
+        p31 = d * c11 + d * c21 + cdx; p32 = d * c12 + d * c22 + cdy
+        dtr = p11 * p22 - p12 * p21
+        dinv = 1.0 / dtr
+        i11 = p22 * dinv; i12 = -p12 * dinv; i21 = -p21 * dinv; i22 = p11 * dinv
+        idx = (p21 * p32 - p22 * p31) * dinv; idy = (p12 * p31 - p11 * p32) * dinv
+    return M, (i11, i12, i21, i22, idx, idy)
+
+
+def fetch_bilinear_any(src, y, x0, length, T):
+    """fetchTransformedBilinearARGB32PM<BlendTransformedBilinear>, any affine matrix (fast_matrix)"""
+    i11, i12, i21, i22, idx, idy = T
+    sh, sw = src.shape
+    fdx = c_int(i11 * 65536.); fdy = c_int(i12 * 65536.)
+    if fdy == 0:
+        assert i21 == 0 or True
+    cx = x0 + 0.5; cy = y + 0.5
+    fx = c_int((i21 * cy + i11 * cx + idx) * 65536.) - 32768
+    fy = c_int((i22 * cy + i12 * cx + idy) * 65536.) - 32768
+    if fdy == 0:
+        return fetch_bilinear_scale_fxfy(src, length, fx, fy, fdx, i22)
+    def bnd(v, n):
+        if v < 0: return 0, 0
+        if v >= n - 1: return n - 1, n - 1
+        return v, v + 1
+    def scalar(fx, fy):
+        x1, x2 = bnd(fx >> 16, sw); y1, y2 = bnd(fy >> 16, sh)
+        return interp8(int(src[y1, x1]), int(src[y1, x2]), int(src[y2, x1]), int(src[y2, x2]), (fx & 0xffff) >> 8, (fy & 0xffff) >> 8)
+    out = []
+    if abs(i11) < 1. / 8. or abs(i22) < 1. / 8.:  # zooming more than 8 times: 8-bit distances throughout
+        for i in range(length):
+            out.append(scalar(fx, fy)); fx += fdx; fy += fdy
+        return out
+    b = 0
+    while b < length:  # head: while a coordinate pair is clamped
+        x1, x2 = bnd(fx >> 16, sw); y1, y2 = bnd(fy >> 16, sh)
+        if x1 != x2 and y1 != y2:
+            break
+        out.append(scalar(fx, fy)); fx += fdx; fy += fdy; b += 1
+    bounded = length
+    if fdx > 0: bounded = min(bounded, b + c_int(((sw - 1) * 65536 - fx) / fdx))
+    elif fdx < 0: bounded = min(bounded, b + c_int((0 - fx) / fdx))
+    if fdy > 0: bounded = min(bounded, b + c_int(((sh - 1) * 65536 - fy) / fdy))
+    elif fdy < 0: bounded = min(bounded, b + c_int((0 - fy) / fdy))
+    bounded -= 3
+    while b < bounded:  # groups of four, rounded 4-bit distances
+        for k in range(4):
+            x1 = fx >> 16; y1 = fy >> 16
+            out.append(interp16(int(src[y1, x1]), int(src[y1, x1 + 1]), int(src[y1 + 1, x1]), int(src[y1 + 1, x1 + 1]),
+                                ((fx & 0xffff) + 0x800) >> 12, ((fy & 0xffff) + 0x800) >> 12))
+            fx += fdx; fy += fdy
+        b += 4
+    while b < length:
+        out.append(scalar(fx, fy)); fx += fdx; fy += fdy; b += 1
+    return out
+
+
+def fetch_bilinear_scale_fxfy(src, length, fx, fy, fdx, i22):
+    raise NotImplementedError("a painter turned by 180 degrees keeps fdy == 0: handled by the caller")
+
+
+def model_draw_rotated(dst, src, cx, cy, w, h, deg, opacity=1.0):
+    ch, cw = dst.shape
+    sh, sw = src.shape
+    if w <= 0 or h <= 0:
+        return
+    M, T = rotated_matrices(cx, cy, w, h, deg, sw, sh)
+    rx, ry, rw, rh = -w / 2, -h / 2, w, h
+    l, t, r_, b_ = rx, ry, rx + rw, ry + rh
+    ax, ay = map_point(M, (l + l) * 0.5, (t + b_) * 0.5)
+    bx, by = map_point(M, (r_ + r_) * 0.5, (t + b_) * 0.5)
+    spans = aa_line_spans_any(ax, ay, bx, by, rh / rw, cw, ch)
+    io = c_int(min(max(opacity, 0.0), 1.0) * 256)
+    blend_runs(dst, spans, lambda y, x, n: fetch_bilinear_any(src, y, x, n, T), io, False)
+
+
+def qt_draw_rotated(dst0, src, cx, cy, w, h, deg, opacity):
+    QImage, QPainter, QColor, QRectF = qt_setup()
+    hh, ww = dst0.shape
+    img = np_to_qimage(dst0, QImage.Format_RGB32).copy()
+    q = np_to_qimage(src, QImage.Format_ARGB32_Premultiplied)
+    p = QPainter(img)
+    p.setRenderHint(QPainter.Antialiasing, True); p.setRenderHint(QPainter.SmoothPixmapTransform, True)
+    if opacity != 1:
+        p.setOpacity(opacity)
+    p.translate(cx, cy); p.rotate(deg)
+    p.drawImage(QRectF(-w / 2, -h / 2, w, h), q)
+    p.end()
+    ptr = img.constBits(); ptr.setsize(ww * hh * 4)
+    return np.frombuffer(bytes(ptr), np.uint32).reshape(hh, ww).copy()
