@@ -31,11 +31,13 @@ struct GameEntry {
     void (*init_state)(int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
     int (*host_tables)(const GameOptions &opt, uint32_t *out, int max_words);  // GameHostTables<Game>::build (pg_env.h)
     bool (*use_block_asset)(int type);  // GameBlockAsset<Game>::is (pg_env.h)
+    hipError_t (*render_human)(const DevCtx &, int env_base, int count, hipStream_t);  // the 512 x 512 info frames of envs [env_base, env_base + count) (pg_human.h)
 };
 constexpr int MAX_GAME_TABLE_WORDS = 1024;
 // mode 0: initial reset + first observation of every env; mode 1: one step
 hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStreams &ls);
 hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream);
+hipError_t launch_render_human(int game_id, const DevCtx &d, int env_base, int count, hipStream_t stream);
 bool game_supported(int game_id);
 int game_tier_for(int game_id, int slots_needed);
 void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes);

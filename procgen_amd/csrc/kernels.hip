@@ -33,6 +33,10 @@ hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t 
     const GameEntry *e = find(game_id);
     return e ? e->render_one(d, env, stream) : hipErrorInvalidValue;
 }
+hipError_t launch_render_human(int game_id, const DevCtx &d, int env_base, int count, hipStream_t stream) {
+    const GameEntry *e = find(game_id);
+    return e ? e->render_human(d, env_base, count, stream) : hipErrorInvalidValue;
+}
 int first_chunk_envs(int num_envs, int first_pct) {
     if (first_pct <= 0 || first_pct >= 100 || num_envs < 4096) return 0;
     const int first = (int)((long long)num_envs * first_pct / 100) / TILE_ENVS * TILE_ENVS;

@@ -13,6 +13,7 @@
 
 #include "games.h"
 #include "pg_render.h"
+#include "pg_human.h"
 #include "kernels.h"
 
 namespace pgamd {
@@ -215,6 +216,20 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
     return hipGetLastError();
 }
 
+// render_human (pg_human.h): one wave per (env, band of 32 rows) of the 512 x 512 antialiased info frame.  Not a hot path: the
+// reference draws these frames serially on the Python thread (src/vecgame.cpp:367-375); handles made without render_human never launch it.
+template <class Game>
+__global__ __launch_bounds__(64) void render_human(DevCtx d, int env_base) {
+    __shared__ HumanLds lds;
+    HumanRenderer<Game> r(d, env_base + (int)(blockIdx.x / HUMAN_BANDS), &lds, (int)(blockIdx.x % HUMAN_BANDS));
+    r.render_band();
+}
+template <class Game>
+static hipError_t launch_human(const DevCtx &d, int env_base, int count, hipStream_t stream) {
+    hipLaunchKernelGGL(render_human<Game>, dim3((unsigned)count * HUMAN_BANDS), dim3(64), 0, stream, d, env_base);
+    return hipGetLastError();
+}
+
 template <class Game>
 static hipError_t render_one(const DevCtx &d, int env, hipStream_t stream) {  // re-renders one env (after set_state)
     launch_render<Game>(d, env, 1, stream);
@@ -230,6 +245,7 @@ const GameEntry *PG_CAT(game_entry_, PG_GAME)() {
         PG_GAME::ENT_CAP_T2, game_grid_bytes<PG_GAME>(), init_env_state<PG_GAME>,
         GameHostTables<PG_GAME>::build,
         GameBlockAsset<PG_GAME>::is,
+        launch_human<PG_GAME>,
     };
     return &e;
 }

@@ -116,6 +116,11 @@ struct VecGame {
     int kernel_id = -1;  // the policy instantiation the kernels run (kernel_id_for)
     int device_id = 0;
     bool host_observations = true;
+    bool render_human = false;   // reference src/vecgame.cpp:190,270-282: a fourth info tensor "rgb" [512][512][3] (pg_human.h)
+    bool human_stale = false;    // a set_state since the frames were last drawn: the next libenv_observe redraws them (reference src/vecgame.cpp:367-375 redraws on every observe)
+    std::vector<void *> human_ptr;  // caller's info "rgb" buffers
+    bool human_contig = false;
+    void launch_human(int env_base, int count);
     std::vector<libenv_tensortype> observation_types, action_types, info_types;
     hipStream_t stream = nullptr;
     hipEvent_t ev_fork = nullptr;
@@ -199,7 +204,7 @@ struct VecGame {
     void read_tail();
     void launch(int mode);
     void act();
-    void observe();
+    void observe(bool from_api = false);
     int get_state(int env_idx, char *data, int length);
     void set_state(int env_idx, const char *data, int length);
     void snapshot(int env_idx, EnvSnapshot *s);
@@ -242,7 +247,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     if (!(num_actions > 0)) fatal("fassert failed 'num_actions > 0'\n");
     if (!(num_levels >= 0)) fatal("fassert failed 'num_levels >= 0'\n");
     if (!(start_level >= 0)) fatal("fassert failed 'start_level >= 0'\n");
-    if (render_human) fatal("render_human (512x512 antialiased info frame) is not provided by the HIP stepper\n");
+    this->render_human = render_human;
     game_id = game_id_from_name(env_name);
     if (game_id < 0) fatal("unknown game %s\n", env_name.c_str());
     if (!game_supported(game_id)) fatal("game %s is not implemented in the HIP stepper yet\n", env_name.c_str());
@@ -273,6 +278,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         fatal("invalid distribution_mode %d\n", dist_mode);
     }
     kernel_id = kernel_id_for(game_id, dist_mode);
+    if (this->render_human && env_name == "jumper") fatal("render_human is not provided for jumper by the HIP stepper: its compass (drawEllipse / drawLine under QPainter::Antialiasing, jumper.cpp:134-169) needs Qt's gray raster and antialiased stroker, which are not restated\n");
+    if (this->render_human && o.use_generated_assets) fatal("render_human together with use_generated_assets is not provided by the HIP stepper\n");
     if (!game_supported(kernel_id)) fatal("game %s has no kernel for distribution_mode %d in the HIP stepper\n", env_name.c_str(), dist_mode);
     int plain_assets = 0, physics_mode = 0, game_type = 0;
     opts.consume_int("plain_assets", &plain_assets);
@@ -321,6 +328,19 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
             s.low.int32 = 0;
             s.high.int32 = INT32_MAX;
         }
+        info_types.push_back(s);
+    }
+    if (this->render_human) {  // reference src/vecgame.cpp:270-282
+        libenv_tensortype s{};
+        strcpy(s.name, "rgb");
+        s.scalar_type = LIBENV_SCALAR_TYPE_DISCRETE;
+        s.dtype = LIBENV_DTYPE_UINT8;
+        s.shape[0] = HUMAN_RES;
+        s.shape[1] = HUMAN_RES;
+        s.shape[2] = 3;
+        s.ndim = 3;
+        s.low.uint8 = 0;
+        s.high.uint8 = 255;
         info_types.push_back(s);
     }
 
@@ -405,6 +425,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d_reset_count = dev_alloc<int>(2 * MAX_CHUNKS);
     d.assets = d_assets;
     d.pixels = d_pixels;
+    if (this->render_human) d.human = dev_alloc<uint8_t>(N * HUMAN_BYTES);
     if (o.use_generated_assets) {
         // every env owns a 500 x 500 RGB32 background canvas, repainted by each episode's reset (reference BAG:58-63,769-773)
         const size_t bytes = N * (size_t)GEN_BG_WORDS * 4;
@@ -484,6 +505,7 @@ VecGame::~VecGame() {
     (void)hipFree(d.grid);
     (void)hipFree(d_action);
     (void)hipFree(d.obs);
+    if (d.human) (void)hipFree(d.human);
     (void)hipFree(d_small);
     for (int k = 0; k < 2; k++) {
         (void)hipFree(d_big_list[k]);
@@ -514,6 +536,12 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
     ob_ptr.assign(bufs->ob, bufs->ob + N);  // one observation space
     ac_ptr.assign(bufs->ac, bufs->ac + N);  // one action space
     for (int s = 0; s < 3; s++) info_ptr[s].assign(bufs->info + (size_t)s * N, bufs->info + (size_t)(s + 1) * N);
+    if (render_human) {
+        human_ptr.assign(bufs->info + (size_t)3 * N, bufs->info + (size_t)4 * N);
+        human_contig = true;
+        for (int e = 0; e < N; e++)
+            if ((uint8_t *)human_ptr[e] != (uint8_t *)human_ptr[0] + (size_t)e * HUMAN_BYTES) human_contig = false;
+    }
     rew_ptr = bufs->rew;
     first_ptr = bufs->first;
     ob_contig = true;
@@ -574,7 +602,19 @@ void VecGame::launch(int mode) {
         void *dst = ob_contig ? ob_ptr[0] : (void *)h_obs_stage;
         HIP_CHECK(hipMemcpyAsync(dst, d.obs, (size_t)num_envs * OBS_BYTES, hipMemcpyDeviceToHost, stream));
     }
+    if (render_human) launch_human(0, num_envs);
     pending = true;
+}
+
+// the 512 x 512 info frames of envs [env_base, env_base + count): kernel + landing in the caller's buffers (reference src/vecgame.cpp:367-375)
+void VecGame::launch_human(int env_base, int count) {
+    HIP_CHECK(launch_render_human(kernel_id, d, env_base, count, stream));
+    if (human_contig) {
+        HIP_CHECK(hipMemcpyAsync((uint8_t *)human_ptr[0] + (size_t)env_base * HUMAN_BYTES, d.human + (size_t)env_base * HUMAN_BYTES, (size_t)count * HUMAN_BYTES, hipMemcpyDeviceToHost, stream));
+    } else {
+        for (int e = env_base; e < env_base + count; e++) HIP_CHECK(hipMemcpyAsync(human_ptr[e], d.human + (size_t)e * HUMAN_BYTES, HUMAN_BYTES, hipMemcpyDeviceToHost, stream));
+    }
+    human_stale = false;
 }
 
 void VecGame::act() {  // reference src/vecgame.cpp:378-401
@@ -590,7 +630,12 @@ void VecGame::act() {  // reference src/vecgame.cpp:378-401
     launch(1);
 }
 
-void VecGame::observe() {  // reference src/vecgame.cpp:363-376,416-435
+void VecGame::observe(bool from_api) {  // reference src/vecgame.cpp:363-376,416-435
+    if (from_api && render_human && human_stale && !pending) {  // states restored since the frames were drawn: VecGame::observe redraws every env's
+        use_device();
+        launch_human(0, num_envs);
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
     if (!pending) return;
     use_device();
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -655,6 +700,15 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     // routing: the restored env takes a wave = env kernel for one step (conservative bound: a step at most doubles the
     // table); the lists the next step walks are rebuilt from the host's copy of the route table before the next launch,
     // so restoring the same env several times, in any tier order, leaves exactly one entry for it
+    {   // the wire format carries the camera scalars of the LAST frame drawn, which is the 512-pixel one when the state was saved
+        // under render_human; Game::observe redraws the 64-pixel frame through prepare_for_drawing(64) (BAG:819-838)
+        const float raw_unit = 64 / s.hdr.visibility;
+        s.hdr.unit = (float)((double)raw_unit * (64.0 / 64.0));
+        s.hdr.view_dim = (float)(64.0 / (double)raw_unit);
+        s.hdr.x_off = s.hdr.unit * (s.hdr.center_x - s.hdr.view_dim / 2);
+        s.hdr.y_off = s.hdr.unit * (s.hdr.center_y - s.hdr.view_dim / 2);
+    }
+    human_stale = true;
     const int tier = game_tier_for(kernel_id, 2 * s.hdr.n_ents + 4);
     s.hdr.big = tier;
     HIP_CHECK(hipMemcpy(d.ents + ent_table_base(e, d.ent_cap), s.ents.data(), (size_t)EF_COUNT * d.ent_cap * 4, hipMemcpyHostToDevice));
@@ -937,13 +991,14 @@ LIBENV_API void libenv_set_buffers(libenv_env *handle, struct libenv_buffers *bu
     h->part_first.assign(P, std::vector<uint8_t>(n));
     h->part_ob.assign(P, std::vector<void *>(n));
     h->part_ac.assign(P, std::vector<void *>(n));
-    h->part_info.assign(P, std::vector<void *>(3 * (size_t)n));
+    const int S = h->parts[0]->render_human ? 4 : 3;  // info spaces (reference src/vecgame.cpp:212-282)
+    h->part_info.assign(P, std::vector<void *>((size_t)S * n));
     for (int p = 0; p < P; p++) {
         for (int i = 0; i < n; i++) {
             const int e = h->map.env_of(p, i);  // global env index
             h->part_ob[p][i] = bufs->ob[e];
             h->part_ac[p][i] = bufs->ac[e];
-            for (int s = 0; s < 3; s++) h->part_info[p][(size_t)s * n + i] = bufs->info[(size_t)s * N + e];
+            for (int s = 0; s < S; s++) h->part_info[p][(size_t)s * n + i] = bufs->info[(size_t)s * N + e];
         }
         struct libenv_buffers pb;
         pb.ob = h->part_ob[p].data();
@@ -958,7 +1013,7 @@ LIBENV_API void libenv_set_buffers(libenv_env *handle, struct libenv_buffers *bu
 LIBENV_API void libenv_observe(libenv_env *handle) {
     Handle *h = (Handle *)handle;
     const int P = h->P();
-    h->for_parts([&](int p) { h->parts[p]->observe(); });  // joins the streams of every part (device)
+    h->for_parts([&](int p) { h->parts[p]->observe(true); });  // joins the streams of every part (device)
     if (P > 1 && h->rew) {
         const int n = h->map.envs_per_part();
         for (int p = 0; p < P; p++)

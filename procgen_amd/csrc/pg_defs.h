@@ -116,6 +116,10 @@ constexpr int GEN_BG_DIM = 500;  // use_generated_assets: the per-env background
 constexpr int GEN_BG_WORDS = GEN_BG_DIM * GEN_BG_DIM;
 
 // ---- sprite atlas in HBM ----
+// the render_human info frame (reference src/game.h:26 RENDER_RES; pg_human.h)
+constexpr int HUMAN_RES = 512;
+constexpr size_t HUMAN_BYTES = (size_t)HUMAN_RES * HUMAN_RES * 3;
+
 struct ImgDesc {
     uint32_t off;  // first pixel (0xAARRGGBB words) in the atlas blob
     uint16_t w, h;

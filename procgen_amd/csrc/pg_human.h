@@ -18,10 +18,8 @@
 
 namespace pgamd {
 
-constexpr int HUMAN_RES = 512;                        // reference src/game.h:26 RENDER_RES
-constexpr int HUMAN_BAND = 32;                        // rows per workgroup
+constexpr int HUMAN_BAND = 32;                        // rows per workgroup (HUMAN_RES, HUMAN_BYTES: pg_defs.h)
 constexpr int HUMAN_BANDS = HUMAN_RES / HUMAN_BAND;
-constexpr size_t HUMAN_BYTES = (size_t)HUMAN_RES * HUMAN_RES * 3;
 
 struct HumanLds {
     uint32_t fb[HUMAN_BAND * HUMAN_RES];

@@ -29,7 +29,8 @@ def _scratch_bytes(game, tmp):
     sizes = [int(x) for x in re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", text, re.M)]
     # step_tier0, two step_list tiers, render for baked and for generated assets; games with split resets (pg_env.h GameSplit) add reset_grid and reset_list
     kinds = sorted(re.sub(r"^_ZN5pgamd\d+([a-z_0-9]+?)I.*$", r"\1", n) for n in names)
-    expect = ["render", "render", "step_list", "step_list", "step_tier0"] + (["reset_grid", "reset_list"] if game in SPLIT_RESET else [])
+    # ... and render_human, the 512 x 512 info frame (pg_human.h)
+    expect = ["render", "render", "render_human", "step_list", "step_list", "step_tier0"] + (["reset_grid", "reset_list"] if game in SPLIT_RESET else [])
     assert len(names) == len(sizes) and kinds == sorted(expect), (game, names)
     return dict(zip(names, sizes))
 

@@ -1,0 +1,174 @@
+"""
+render_human -- the 512 x 512 x 3 antialiased info "rgb" frame (reference src/vecgame.cpp:270-282,363-376; procgen_amd/csrc/pg_human.h)
+against tests/golden/render_human.npz, which tests/golden/make_human_golden.py generated from the COMPILED REFERENCE.
+
+CPU  : the kernel source run by the wave emulation (tests/emu) -- frames and the get_state bytes behind them, bit for bit.
+GPU  : the HIP libenv.so through the C ABI (ProcgenGym3Env(render_mode="rgb_array")): frames, state bytes, tensortypes, the
+       redraw after set_state, joint handles, separately placed buffers, and the refusals.
+The contract allows +-1 LSB per channel on frames; both hold 0 (CRC32 of the whole frame).
+"""
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS = [0, 17, 40]
+DM = {"easy": 0, "hard": 1, "extreme": 2, "memory": 10}
+
+
+def _gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "render_human.npz"))
+
+
+def _keys(gold):
+    return sorted({k.split("/")[0] for k in gold.files if k.endswith("/crc")})
+
+
+def _options():
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    import make_human_golden as M
+
+    return M.GAMES, M.OPTION_SETS
+
+
+GAMES, OPTION_SETS = _options()
+KEYS = GAMES + sorted(OPTION_SETS)
+
+
+def _game_kwargs(key):
+    return OPTION_SETS[key] if key in OPTION_SETS else (key, {})
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_emulated_kernel_frames_equal_the_compiled_reference(golden_dir, key):
+    import emu_harness
+
+    gold = _gold(golden_dir)
+    game, kw = _game_kwargs(key)
+    kw = dict(kw)
+    if "distribution_mode" in kw:
+        kw["distribution_mode"] = DM[kw["distribution_mode"]]
+    env = emu_harness.EmuEnv(2, game, rand_seed=7, **kw)
+    acts = gold[f"{key}/actions"]
+    want = gold[f"{key}/crc"]
+    k = 0
+    for t in range(STEPS[-1] + 1):
+        env.observe()
+        if t in STEPS:
+            for e in range(2):
+                frame = env.render_human(e)
+                if t == 17 and e == 0 and f"frames/{key}" in gold.files:
+                    d = np.abs(frame.astype(int) - gold[f"frames/{key}"].astype(int))
+                    assert d.max() == 0, f"{key}: {np.count_nonzero(d.max(axis=2))} pixels differ, worst {d.max()}"
+                assert zlib.crc32(frame.tobytes()) == int(want[k][e]), f"{key}: frame of env {e} at step {t} differs from the compiled reference"
+            k += 1
+        if t < STEPS[-1]:
+            env.act(acts[t])
+    # the camera scalars get_state serializes are those of the last frame drawn: the 512-pixel one
+    assert env.get_state()[0] == gold[f"{key}/state"].tobytes()
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def _make(n, game, **kw):
+    from helpers import HIP_LIB
+    from procgen_amd import ProcgenGym3Env
+
+    assert os.path.exists(HIP_LIB), "HIP libenv.so missing: run __graft_entry__.build() (there is no fallback path)"
+    return ProcgenGym3Env(n, game, render_mode="rgb_array", **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", KEYS)
+def test_gpu_frames_and_state_equal_the_compiled_reference(golden_dir, key):
+    gold = _gold(golden_dir)
+    game, kw = _game_kwargs(key)
+    env = _make(2, game, rand_seed=7, **kw)
+    names = [t.name for t in env.info_types]
+    assert names == ["prev_level_seed", "prev_level_complete", "level_seed", "rgb"] and env.info_types[3].shape == (512, 512, 3)
+    acts = gold[f"{key}/actions"]
+    want = gold[f"{key}/crc"]
+    k = 0
+    for t in range(STEPS[-1] + 1):
+        env.observe()
+        if t in STEPS:
+            rgb = env.info_arrays()["rgb"]
+            for e in range(2):
+                if t == 17 and e == 0 and f"frames/{key}" in gold.files:
+                    d = np.abs(rgb[e].astype(int) - gold[f"frames/{key}"].astype(int))
+                    assert d.max() == 0, f"{key}: {np.count_nonzero(d.max(axis=2))} pixels differ, worst {d.max()}"
+                assert zlib.crc32(rgb[e].tobytes()) == int(want[k][e]), f"{key}: frame of env {e} at step {t} differs from the compiled reference"
+            k += 1
+        if t < STEPS[-1]:
+            env.act(acts[t])
+    assert env.get_state()[0] == gold[f"{key}/state"].tobytes()
+    env.close()
+
+
+@pytest.mark.gpu
+def test_gpu_restored_states_are_redrawn_by_the_next_observe(golden_dir):
+    """reference src/vecgame.cpp:447-456 + 363-376: set_state refreshes the 64-pixel frame; every observe redraws the 512 frames."""
+    gold = _gold(golden_dir)
+    a = _make(2, "coinrun", rand_seed=7)
+    b = _make(2, "coinrun", rand_seed=99)
+    acts = gold["coinrun/actions"]
+    for t in range(17):
+        a.observe()
+        a.act(acts[t])
+    a.observe()
+    states = a.get_state()
+    b.observe()
+    b.set_state(states)
+    _, ob, _ = b.observe()
+    assert np.array_equal(ob["rgb"], a.observe()[1]["rgb"])
+    rgb = b.info_arrays()["rgb"]
+    for e in range(2):
+        assert zlib.crc32(rgb[e].tobytes()) == int(gold["coinrun/crc"][1][e])
+    assert b.get_state() == states
+    # and both continue identically
+    for t in range(17, 40):
+        a.act(acts[t]); b.act(acts[t])
+    a.observe(); b.observe()
+    assert np.array_equal(a.info_arrays()["rgb"], b.info_arrays()["rgb"])
+    assert zlib.crc32(b.info_arrays()["rgb"][1].tobytes()) == int(gold["coinrun/crc"][2][1])
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_gpu_joint_handle_and_separately_placed_buffers(golden_dir):
+    """env n of a joint handle plays names[n % K] (reference src/vecgame.cpp:295-299): its info frame is that game's; per-env
+    buffers need not form one array (libenv_buffers only promises pointers)."""
+    from procgen_amd import ProcgenGym3Env
+
+    joint = ProcgenGym3Env(4, "coinrun,starpilot", rand_seed=7, render_mode="rgb_array", buffer_padding=192)
+    singles = {g: ProcgenGym3Env(2, g, rand_seed=7, render_mode="rgb_array") for g in ("coinrun", "starpilot")}
+    rng = np.random.RandomState(3)
+    for t in range(12):
+        joint.observe()
+        joint.act(rng.randint(0, 15, size=(4,), dtype=np.int32))
+    joint.observe()
+    # every frame of the joint handle equals what a handle of that game draws from the same state (joint env n holds the seed
+    # of env n, a lone handle's env i that of env i: the comparison goes through states)
+    st = joint.get_state()
+    for n in range(4):
+        g = ("coinrun", "starpilot")[n % 2]
+        s = singles[g]
+        s.observe()
+        s.set_state([st[n], st[n]])
+        s.observe()
+        assert np.array_equal(s.info_arrays()["rgb"][0], joint.info_arrays()["rgb"][n]), f"joint env {n} ({g})"
+    joint.close()
+    for s in singles.values():
+        s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", ["2, 'jumper', render_mode='rgb_array'", "2, 'coinrun', render_mode='rgb_array', use_generated_assets=True"])
+def test_gpu_combinations_not_provided_are_refused_loudly(args):
+    code = "import sys; sys.path.insert(0, %r); from procgen_amd import ProcgenGym3Env; ProcgenGym3Env(%s)" % (REPO, args)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "render_human" in (r.stdout + r.stderr)
