@@ -208,6 +208,11 @@ struct VecGame {
     int get_state(int env_idx, char *data, int length);
     void set_state(int env_idx, const char *data, int length);
     void snapshot(int env_idx, EnvSnapshot *s);
+    static constexpr int SNAP_BLOCK = 256;
+    int snap_first = -1, snap_count = 0;  // envs [snap_first, snap_first + snap_count) of the snapshot cache; -1: stale
+    std::vector<EnvHdr> snap_hdr;
+    std::vector<uint32_t> snap_ents, snap_rng;
+    std::vector<uint8_t> snap_grid;
     void flush_routes();
     std::vector<uint8_t> h_route;  // host copy of the route table the coming step reads (valid between a set_state and the next launch)
     bool route_mirror_valid = false, route_dirty = false;
@@ -571,6 +576,7 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
 
 // the device work of one step: the step / reset / render kernels (what procgen_amd_time_steps brackets)
 void VecGame::launch_kernels(int mode) {
+    snap_first = -1;
     if (route_dirty) flush_routes();
     route_mirror_valid = false;
     bind_routing();
@@ -608,6 +614,7 @@ void VecGame::launch(int mode) {
 
 // the 512 x 512 info frames of envs [env_base, env_base + count): kernel + landing in the caller's buffers (reference src/vecgame.cpp:367-375)
 void VecGame::launch_human(int env_base, int count) {
+    snap_first = -1;  // (the kernel leaves the 512-pixel frame's camera scalars in the env headers)
     HIP_CHECK(launch_render_human(kernel_id, d, env_base, count, stream));
     if (human_contig) {
         HIP_CHECK(hipMemcpyAsync((uint8_t *)human_ptr[0] + (size_t)env_base * HUMAN_BYTES, d.human + (size_t)env_base * HUMAN_BYTES, (size_t)count * HUMAN_BYTES, hipMemcpyDeviceToHost, stream));
@@ -661,16 +668,31 @@ void VecGame::observe(bool from_api) {  // reference src/vecgame.cpp:363-376,416
         for (size_t e = 0; e < N; e++) memcpy(ob_ptr[e], h_obs_stage + e * OBS_BYTES, OBS_BYTES);
 }
 
+// Host copy of one env's device state.  env.get_state() walks all envs: the state of a block of SNAP_BLOCK consecutive envs is
+// fetched with four copies and kept until something changes device state (a step, a restore, a redraw), instead of four small
+// synchronous copies per env (262 144 of them at 65 536 envs).
 void VecGame::snapshot(int e, EnvSnapshot *s) {
+    const size_t ents_w = (size_t)EF_COUNT * d.ent_cap, rng_w = 2 * MT_STRIDE, grid_b = (size_t)d.grid_bytes;
+    if (!(snap_first >= 0 && e >= snap_first && e < snap_first + snap_count)) {
+        const int first = e / SNAP_BLOCK * SNAP_BLOCK, count = num_envs - first < SNAP_BLOCK ? num_envs - first : SNAP_BLOCK;  // aligned blocks: any visiting order fetches a block once
+        snap_hdr.resize(count);
+        snap_ents.resize(ents_w * count);
+        snap_rng.resize(rng_w * count);
+        snap_grid.resize(grid_b * count);
+        HIP_CHECK(hipMemcpy(snap_hdr.data(), d.hdr + first, sizeof(EnvHdr) * count, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(snap_ents.data(), d.ents + ent_table_base(first, d.ent_cap), ents_w * 4 * count, hipMemcpyDeviceToHost));  // per-env tables are contiguous and dense
+        // rand_gen + level_seed_rand_gen of each env: the first two of its MT_SLOTS generator states
+        HIP_CHECK(hipMemcpy2D(snap_rng.data(), rng_w * 4, d.rng + (size_t)first * MT_SLOTS * MT_STRIDE, (size_t)MT_SLOTS * MT_STRIDE * 4, rng_w * 4, count, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(snap_grid.data(), d.grid + (size_t)first * grid_b, grid_b * count, hipMemcpyDeviceToHost));
+        snap_first = first;
+        snap_count = count;
+    }
+    const size_t k = (size_t)(e - snap_first);
     s->ent_cap = d.ent_cap;
-    s->ents.resize((size_t)EF_COUNT * d.ent_cap);
-    s->rng.resize(2 * MT_STRIDE);
-    s->grid.resize(d.grid_bytes);
-    HIP_CHECK(hipMemcpy(&s->hdr, d.hdr + e, sizeof(EnvHdr), hipMemcpyDeviceToHost));
-    // one word per 256-byte row of the tile-interleaved table
-    HIP_CHECK(hipMemcpy(s->ents.data(), d.ents + ent_table_base(e, d.ent_cap), (size_t)EF_COUNT * d.ent_cap * 4, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(s->rng.data(), d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, s->rng.size() * 4, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(s->grid.data(), d.grid + (size_t)e * d.grid_bytes, s->grid.size(), hipMemcpyDeviceToHost));
+    s->hdr = snap_hdr[k];
+    s->ents.assign(snap_ents.begin() + k * ents_w, snap_ents.begin() + (k + 1) * ents_w);
+    s->rng.assign(snap_rng.begin() + k * rng_w, snap_rng.begin() + (k + 1) * rng_w);
+    s->grid.assign(snap_grid.begin() + k * grid_b, snap_grid.begin() + (k + 1) * grid_b);
 }
 
 int VecGame::get_state(int e, char *data, int length) {  // reference src/vecgame.cpp:438-445
@@ -709,6 +731,7 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
         s.hdr.y_off = s.hdr.unit * (s.hdr.center_y - s.hdr.view_dim / 2);
     }
     human_stale = true;
+    snap_first = -1;
     const int tier = game_tier_for(kernel_id, 2 * s.hdr.n_ents + 4);
     s.hdr.big = tier;
     HIP_CHECK(hipMemcpy(d.ents + ent_table_base(e, d.ent_cap), s.ents.data(), (size_t)EF_COUNT * d.ent_cap * 4, hipMemcpyHostToDevice));

@@ -272,6 +272,43 @@ def test_state_protocol_through_the_c_abi(golden_dir, game):
     assert [zlib.crc32(ob["rgb"][e].tobytes()) for e in range(2)] == list(g["crc"][130, :2])
 
 
+def test_get_state_over_many_envs_in_any_order():
+    """env.get_state() walks every env: the library fetches device state in blocks of 256 envs (VecGame::snapshot).  700 envs =
+    three blocks.  States read in descending and scattered order equal the ascending sweep; restored into a handle with another
+    seed they reproduce the original's rollout env by env (a state handed out for the wrong env would not); a step or a restore
+    invalidates what was fetched."""
+    import ctypes as C
+
+    n = 700
+    env = make_env(n, "coinrun")
+    other = make_env(n, "coinrun", rand_seed=4242)
+    acts = action_stream(n, 9, seed=11)
+    buf = C.create_string_buffer(1 << 20)
+
+    def state_of(e):
+        k = env.call_c_func("get_state", int(e), buf, 1 << 20)
+        return bytes(buf.raw[:k])
+
+    for t in range(5):
+        env.act(acts[t])
+    sweep = env.get_state()
+    assert len(set(sweep)) == n
+    for e in list(range(n - 1, -1, -37)) + [3, 699, 256, 255, 511, 512, 0]:
+        assert state_of(e) == sweep[e], f"env {e}"
+    other.observe()
+    other.set_state(sweep)
+    assert other.get_state() == sweep
+    for t in range(5, 8):
+        env.act(acts[t]); other.act(acts[t])
+        ra, oa, fa = env.observe(); rb, ob, fb = other.observe()
+        assert np.array_equal(ra, rb) and np.array_equal(fa, fb) and np.array_equal(oa["rgb"], ob["rgb"]), f"step {t}"
+    after = [state_of(e) for e in (300, 0, 699, 257)]
+    assert after == [other.get_state()[e] for e in (300, 0, 699, 257)]
+    assert all(a != sweep[e] for a, e in zip(after, (300, 0, 699, 257)))
+    env.close()
+    other.close()
+
+
 @pytest.mark.parametrize("game", ["coinrun", "maze", "starpilot"])
 def test_forced_reset_action(game):
     """action -1 forces a reset (reference src/game.cpp:123-127)."""
