@@ -312,12 +312,12 @@ struct HumanRenderer {
         if (ya < row0) ya = row0;
         if (yb > row1 - 1) yb = row1 - 1;
         if (yb > HUMAN_RES - 1) yb = HUMAN_RES - 1;
-        for (int y = ya; y <= yb; y++) {
-            const int yFP = y << 16;
-            const int hi = yFP + 65536 < c.yPb ? yFP + 65536 : c.yPb, lo = yFP > c.yPa ? yFP : c.yPa;
-            const int rowHeight = hi - lo;
-            // spans: (x, len, coverage)
-            int sx[3], sl[3], sc[3], n = 0;
+        // QSpanBuffer hands the spans of a draw to the blend function in batches of 256 (SPAN_BUFFER_SIZE), and touching spans only
+        // form a run within a batch: the index of a row's first span in the draw decides where a run is cut.  Rows between the
+        // first and the last all have the same spans.
+        auto spans_of = [&c](int rowHeight, int (&sx)[3], int (&sl)[3], int (&sc)[3]) {
+            using namespace human;
+            int n = 0;
             {
                 int cvL = mul16(rowHeight, c.covLeft) >> 16;
                 if (c.single) {
@@ -335,10 +335,28 @@ struct HumanRenderer {
                     if (c.covRight != 0 && cvR) { sx[n] = c.iRight; sl[n] = 1; sc[n] = cvR; n++; }
                 }
             }
+            return n;
+        };
+        auto row_height = [&c](int y) {
+            const int yFP = y << 16;
+            const int hi = yFP + 65536 < c.yPb ? yFP + 65536 : c.yPb, lo = yFP > c.yPa ? yFP : c.yPa;
+            return hi - lo;
+        };
+        int n_top, n_mid;
+        {
+            int tx[3], tl[3], tc[3];
+            n_top = spans_of(row_height(c.iTop), tx, tl, tc);
+            n_mid = spans_of(65536, tx, tl, tc);
+        }
+        for (int y = ya; y <= yb; y++) {
+            const int rowHeight = row_height(y);
+            int sx[3], sl[3], sc[3];
+            const int n = spans_of(rowHeight, sx, sl, sc);
+            const int first_span = y == c.iTop ? 0 : n_top + (y - c.iTop - 1) * n_mid;  // index of this row's first span in the draw
             int i = 0;
             while (i < n) {
                 int j = i + 1, right = sx[i] + sl[i];
-                while (j < n && sx[j] == right) { right += sl[j]; j++; }
+                while (j < n && sx[j] == right && ((first_span + j) >> 8) == ((first_span + i) >> 8)) { right += sl[j]; j++; }
                 const int x0 = sx[i], length = right - x0;
                 // per-pixel coverage of the run: the spans i..j-1 (at most three)
                 const int e0 = sx[i] + sl[i], c0 = sc[i];
@@ -462,6 +480,7 @@ struct HumanRenderer {
         const int yTopFP = sf16(ty), yLeftFP = sf16(ly), yRightFP = sf16(ry), yBottomFP = sf16(by);
         int rowTop = iTopFP > yTopFP ? iTopFP : yTopFP;
         int topLeftAf = leftAf + mul16(g.tlFP, rowTop - iTopFP), topRightAf = rightAf + mul16(g.trFP, rowTop - iTopFP);
+        int span_idx = 0;  // spans of this draw so far
         for (int yFP = iTopFP; yFP <= iBottomFP; yFP += 65536) {
             const int y = yFP >> 16;
             if (y >= row1) break;
@@ -513,15 +532,17 @@ struct HumanRenderer {
             if (g.leftMax > g.rightMax) g.leftMax = g.rightMax;
             if (g.rightMin < g.leftMin) g.rightMin = g.leftMin;
             g.rowHeight = g.rowBottom - g.rowTop;
-            if (y >= row0) {
+            {
                 // the spans of this row in Qt's order: single pixels leftMin..leftMax, the full span up to rightMin, single pixels up to
-                // rightMax; spans of coverage 0 are dropped, the ones that touch form a run for the fetch
+                // rightMax; spans of coverage 0 are dropped, the ones that touch form a run for the fetch -- within one batch of 256
+                // spans of the draw (QSpanBuffer's flush), which is why rows above this band are walked too: they count
+                const bool draw = y >= row0;
                 const int last = g.rightMax > g.leftMax ? g.rightMax : g.leftMax;
                 const int mid_cov = (255 * g.rowHeight) >> 16;
                 int run = -1;  // first column of the open run
-                uint32_t *rowp = fb + (y - row0) * HUMAN_RES;
+                uint32_t *rowp = fb + (draw ? (y - row0) : 0) * HUMAN_RES;
                 auto flush = [&](int xe) {  // the run [run, xe)
-                    if (run < 0 || xe <= run) return;
+                    if (!draw || run < 0 || xe <= run) return;
                     const int x0 = run, length = xe - run;
                     for (int base = 0; base < length; base += 64) {
                         PG_FOR_LANES(l) {
@@ -535,24 +556,27 @@ struct HumanRenderer {
                         }
                     }
                 };
-                int x = g.leftMin;
-                while (x <= last) {
-                    if (x > g.leftMax && x < g.rightMin) {  // the full span
-                        if (mid_cov != 0) {
-                            if (run < 0) run = x;
-                        } else {
+                auto span = [&](int x, bool nonzero) {  // the next span of the draw starts at column x
+                    if (nonzero) {
+                        if ((span_idx & 255) == 0 && run >= 0) {  // a new batch: the open run ends here
                             flush(x);
                             run = -1;
                         }
-                        x = g.rightMin;
-                        continue;
-                    }
-                    if (g.coverage(x) != 0) {
+                        span_idx++;
                         if (run < 0) run = x;
                     } else {
                         flush(x);
                         run = -1;
                     }
+                };
+                int x = g.leftMin;
+                while (x <= last) {
+                    if (x > g.leftMax && x < g.rightMin) {  // the full span
+                        span(x, mid_cov != 0);
+                        x = g.rightMin;
+                        continue;
+                    }
+                    span(x, g.coverage(x) != 0);
                     x++;
                 }
                 flush(last + 1);

@@ -250,14 +250,16 @@ def interpolate_pixel_255(x, a, y, b):
 
 def blend_runs(dst, spans, fetch, io, opaque_source):
     """blend_src_generic / handleSpans: the spans of one row that touch are fetched as ONE run (which matters: the fetch
-    treats the head, the groups of four and the tail of a run differently), then blended span by span with
+    treats the head, the groups of four and the tail of a run differently; a run never crosses a multiple of 256 in the draw's span
+    count, QSpanBuffer's flush), then blended span by span with
     const_alpha = (coverage * intOpacity) >> 8.  A source without alpha channel turns SourceOver into Source
     (getOperator): d = INTERPOLATE_PIXEL_255(s, ca, d, 255 - ca)."""
     i = 0
     while i < len(spans):
         y, x, ln, cov = spans[i]
         j = i + 1; right = x + ln
-        while j < len(spans) and spans[j][0] == y and spans[j][1] == right:
+        # (QSpanBuffer hands the spans on in batches of 256 -- SPAN_BUFFER_SIZE -- and runs only form within a batch)
+        while j < len(spans) and spans[j][0] == y and spans[j][1] == right and j // 256 == i // 256:
             right += spans[j][2]; j += 1
         px = fetch(y, x, right - x)
         for k in range(i, j):
