@@ -1,6 +1,6 @@
 # round 3 final checkpoint on one MI355X, most important first (the call may be cut by the GPU budget):
 #   smoke, whole GPU suite (4 workers), default bench line (with cpu_baseline), kernel trace + timeline, HBM traffic PMC passes,
-#   per-phase wave cycles, instruction mix, the 16 games alone, the 16-game joint handle
+#   per-phase wave cycles, instruction mix, the 16 games alone, the 16-game joint handle (profiles/r03_final_* come from this script)
 # usage: bash tools/gpu/r3_final.sh [tag]
 TAG=${1:-r3_final}
 R=$GRAFT_REPO_ROOT
