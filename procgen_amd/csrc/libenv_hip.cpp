@@ -405,6 +405,10 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         std::vector<EnvHdr> hdr(N);
         std::vector<uint32_t> rng(N * MT_SLOTS * MT_STRIDE);
         game_init_state(kernel_id, num_envs, rand_seed, env_offset, env_stride, hdr.data(), rng.data());
+        for (auto &h : hdr) {  // reference src/vecgame.cpp:316-317 (every game starts with the handle's range)
+            h.level_seed_low = o.level_seed_low;
+            h.level_seed_high = o.level_seed_high;
+        }
         HIP_CHECK(hipMemcpy(d.hdr, hdr.data(), N * sizeof(EnvHdr), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d.rng, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
     }

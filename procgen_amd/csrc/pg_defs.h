@@ -69,6 +69,7 @@ struct GameOptions {
     X(int, error)      /* first failed reference fassert / capacity overflow (0 = none) -> host fatal() */        \
     X(int, big)        /* arena tier (0,1,2) that must step this env next: smallest LDS entity table that fits */      \
     X(int, grid_dirty)                                                                                            \
+    X(int, level_seed_low) X(int, level_seed_high) /* per env: set_state adopts the range a state was saved under (reference src/game.cpp:247-248) */ \
     /* game-specific scalars (meaning defined by the game policy, e.g. game_coinrun.h) */                         \
     X(int, gsi0) X(int, gsi1) X(int, gsi2) X(int, gsi3) X(int, gsi4) X(int, gsi5) X(int, gsi6) X(int, gsi7)       \
     X(float, gsf0) X(float, gsf1) X(float, gsf2) X(float, gsf3) X(float, gsf4) X(float, gsf5) X(float, gsf6) X(float, gsf7)

@@ -1828,8 +1828,8 @@ struct Env {
                 G.current_level_seed = (int32_t)((uint32_t)G.current_level_seed + 997u);
             } else {
                 const uint32_t x = level_seed_u32();
-                const uint32_t range = (uint32_t)(d.opt.level_seed_high - d.opt.level_seed_low);
-                G.current_level_seed = (int)((uint32_t)d.opt.level_seed_low + (x % range));
+                const uint32_t range = (uint32_t)(G.level_seed_high - G.level_seed_low);
+                G.current_level_seed = (int)((uint32_t)G.level_seed_low + (x % range));
             }
             G.episodes_remaining = 1;
         } else {

@@ -133,8 +133,8 @@ bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvS
     w.i(0);  // plain_assets
     w.i(0);  // physics_mode
     w.i(h.grid_step);
-    w.i(opt.level_seed_low);
-    w.i(opt.level_seed_high);
+    w.i(s.hdr.level_seed_low);
+    w.i(s.hdr.level_seed_high);
     w.i(0);  // game_type
     w.i(game_n);
     write_rng(w, true, s.rng.data() + MT_STRIDE, h.lvl_rand_idx);  // level_seed_rand_gen
@@ -407,8 +407,9 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
     r.i();  // plain_assets
     r.i();  // physics_mode
     h.grid_step = r.i();
-    const int lo = r.i(), hi = r.i();
-    if (lo != opt.level_seed_low || hi != opt.level_seed_high) return bad("set_state: the state was saved under a different num_levels/start_level");
+    h.level_seed_low = r.i();  // adopted per env, as the reference does (src/game.cpp:247-248): the env goes on drawing its levels from the range the state was saved under
+    h.level_seed_high = r.i();
+    if (!(h.level_seed_high > h.level_seed_low)) return bad("set_state: empty level seed range");
     r.i();  // game_type
     r.i();  // game_n
     int seeded;

@@ -176,6 +176,10 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     d.reset_chunk_envs = d.chunk_envs;
     d.reset_first = 0;
     level_seed_range(num_levels, start_level, &d.opt.level_seed_low, &d.opt.level_seed_high);
+    for (auto &h : v->hdr) {
+        h.level_seed_low = d.opt.level_seed_low;
+        h.level_seed_high = d.opt.level_seed_high;
+    }
     d.hdr = v->hdr.data();
     d.rng = v->rng.data();
     d.ents = v->ents.data();

@@ -60,3 +60,40 @@ def test_get_state_is_non_perturbing_and_roundtrips():
 
     crc = np.array([[zlib.crc32(f[e].tobytes()) for e in range(3)] for f in out], dtype=np.uint32)
     assert np.array_equal(crc, a["crc"])
+
+
+def _replay_cross_range(gold, game, env):
+    import zlib
+
+    env.observe()
+    env.set_state([gold[f"{game}/state0"].tobytes(), gold[f"{game}/state1"].tobytes()])
+    acts = gold[f"{game}/actions"]
+    for t in range(len(acts) + 1):
+        rew, ob, first = env.observe()
+        assert np.array_equal(rew, gold[f"{game}/rew"][t]) and np.array_equal(first.astype(np.uint8), gold[f"{game}/first"][t]), f"{game} step {t}"
+        assert np.array_equal(env.info_arrays()["level_seed"], gold[f"{game}/level_seed"][t]), f"{game} step {t}: level seeds"
+        assert [zlib.crc32(ob["rgb"][e].tobytes()) for e in range(2)] == list(gold[f"{game}/crc"][t]), f"{game} step {t}: frames"
+        if t < len(acts):
+            env.act(acts[t])
+    assert env.get_state() == [gold[f"{game}/end0"].tobytes(), gold[f"{game}/end1"].tobytes()]
+
+
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bigfish"])
+def test_restored_envs_keep_the_level_seed_range_they_were_saved_under(golden_dir, game):
+    """reference src/game.cpp:247-248: deserialize adopts level_seed_low / high per env.  tests/golden/cross_range_state.npz (compiled
+    reference): states saved under num_levels=3, start_level=100 restored into a num_levels=0 handle keep drawing levels 100..102."""
+    gold = np.load(os.path.join(golden_dir, "cross_range_state.npz"))
+    env = emu_harness.EmuEnv(2, game, rand_seed=77, num_levels=0)
+    _replay_cross_range(gold, game, env)
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", ["coinrun", "maze", "bigfish"])
+def test_gpu_restored_envs_keep_the_level_seed_range_they_were_saved_under(golden_dir, game):
+    from procgen_amd import ProcgenGym3Env
+
+    gold = np.load(os.path.join(golden_dir, "cross_range_state.npz"))
+    env = ProcgenGym3Env(2, game, rand_seed=77, num_levels=0)
+    _replay_cross_range(gold, game, env)
+    env.close()
