@@ -414,6 +414,8 @@ struct HumanRenderer {
         if (slope > 0) return (bottom - rightIntersectY) + ((rightIntersectY - leftIntersectY) >> 1);
         return (rightIntersectY - top) + ((leftIntersectY - rightIntersectY) >> 1);
     }
+    // (Qt 5.9 calls intersectPixelFP without checking that the part of the row it is asked about is non-empty: a side corner just above
+    // a clipped first row contributes a negative exclusion there.  Later Qt versions guard these calls; 5.9.7 is what the reference ships.)
     struct GenRow {  // one row of the walker: everything the coverage of a pixel depends on
         int yFP, iLeftFP, iRightFP;
         int rowTop, rowBottom, rowBottomLeft, rowBottomRight, rowTopLeft, rowTopRight, rowHeight;
@@ -422,16 +424,16 @@ struct HumanRenderer {
         int leftMin, leftMax, rightMin, rightMax;
         PG_DEV int right_excluded(int x) const {
             int e = 0;
-            if (yFP <= iRightFP && rowBottomRight > rowTop) e += (rowBottomRight - rowTop) - intersect_pixel_fp(x, rowTop, rowBottomRight, topRightAf, bottomRightAf, trFP, itrFP);
-            if (yFP >= iRightFP && rowBottom > rowTopRight) e += (rowBottom - rowTopRight) - intersect_pixel_fp(x, rowTopRight, rowBottom, bottomRightBf, topRightBf, brFP, ibrFP);
+            if (yFP <= iRightFP) e += (rowBottomRight - rowTop) - intersect_pixel_fp(x, rowTop, rowBottomRight, topRightAf, bottomRightAf, trFP, itrFP);
+            if (yFP >= iRightFP) e += (rowBottom - rowTopRight) - intersect_pixel_fp(x, rowTopRight, rowBottom, bottomRightBf, topRightBf, brFP, ibrFP);
             return e;
         }
         PG_DEV int coverage(int x) const {  // 0..255; x in [leftMin, rightMax]
             int cov16;
             if (x <= leftMax) {
                 int excluded = 0;
-                if (yFP <= iLeftFP && rowBottomLeft > rowTop) excluded += intersect_pixel_fp(x, rowTop, rowBottomLeft, bottomLeftAf, topLeftAf, tlFP, itlFP);
-                if (yFP >= iLeftFP && rowBottom > rowTopLeft) excluded += intersect_pixel_fp(x, rowTopLeft, rowBottom, topLeftBf, bottomLeftBf, blFP, iblFP);
+                if (yFP <= iLeftFP) excluded += intersect_pixel_fp(x, rowTop, rowBottomLeft, bottomLeftAf, topLeftAf, tlFP, itlFP);
+                if (yFP >= iLeftFP) excluded += intersect_pixel_fp(x, rowTopLeft, rowBottom, topLeftBf, bottomLeftBf, blFP, iblFP);
                 if (x >= rightMin) excluded += right_excluded(x);
                 cov16 = rowHeight - excluded;
             } else if (x < rightMin) {
