@@ -15,7 +15,9 @@ Qt 5.9 route (qpaintengine_raster.cpp, qrasterizer.cpp, qdrawhelper.cpp), restat
              (interpolate_4_pixels_16) unless the zoom exceeds 8x (8-bit interpolate_4_pixels); source coordinates clamped.
   blend    : comp_func_SourceOver with const_alpha = (coverage * intOpacity) >> 8.
 usage: qt_smooth_aa_probe.py [n_cases] [seed] [untransformed|fills|images|all]
-Last run (seed 1): untransformed 300 cases, turned fills 400, turned images 120: 0 misses.
+Last runs: seed 1: untransformed 300 cases, turned fills 400, turned images 120: 0 misses; seeds 2 and 3 (100-150 cases each): one turned fill
+with ONE differing pixel in row 0 (a side corner less than a pixel above the clipped first row plus a nearly horizontal edge: Qt's unguarded
+intersectPixelFP works on an inverted row there and the wrapped coverage byte comes out 8 lower than the restatement's).
 """
 import os, sys, math
 os.environ["QT_QPA_PLATFORM"] = "offscreen"
