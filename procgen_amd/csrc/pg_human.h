@@ -428,7 +428,9 @@ struct HumanRenderer {
             if (yFP >= iRightFP) e += (rowBottom - rowTopRight) - intersect_pixel_fp(x, rowTopRight, rowBottom, bottomRightBf, topRightBf, brFP, ibrFP);
             return e;
         }
-        PG_DEV int coverage(int x) const {  // 0..255; x in [leftMin, rightMax]
+        // x in [leftMin, rightMax].  Normally 0..255; on a degenerate first row (a side corner just above the clip, see above) the unguarded
+        // exclusions can push it outside: Qt tests the int for zero and then keeps its low byte (QT_FT_Span::coverage is an unsigned char)
+        PG_DEV int coverage(int x) const {
             int cov16;
             if (x <= leftMax) {
                 int excluded = 0;
@@ -551,7 +553,7 @@ struct HumanRenderer {
                             const int b = base + l;
                             if (b < length) {
                                 const int x = x0 + b;
-                                const int cv = g.coverage(x);
+                                const int cv = g.coverage(x) & 0xff;
                                 const uint32_t ca = (uint32_t)((cv * io) >> 8);
                                 rowp[x] = blend(rowp[x], src(y, x0, length, b), ca, source_mode);
                             }

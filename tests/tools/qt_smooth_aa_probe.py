@@ -15,9 +15,7 @@ Qt 5.9 route (qpaintengine_raster.cpp, qrasterizer.cpp, qdrawhelper.cpp), restat
              (interpolate_4_pixels_16) unless the zoom exceeds 8x (8-bit interpolate_4_pixels); source coordinates clamped.
   blend    : comp_func_SourceOver with const_alpha = (coverage * intOpacity) >> 8.
 usage: qt_smooth_aa_probe.py [n_cases] [seed] [untransformed|fills|images|all]
-Last runs: seed 1: untransformed 300 cases, turned fills 400, turned images 120: 0 misses; seeds 2 and 3 (100-150 cases each): one turned fill
-with ONE differing pixel in row 0 (a side corner less than a pixel above the clipped first row plus a nearly horizontal edge: Qt's unguarded
-intersectPixelFP works on an inverted row there and the wrapped coverage byte comes out 8 lower than the restatement's).
+Last runs (seeds 1, 2, 3; 100-400 cases per mode): 0 misses.
 """
 import os, sys, math
 os.environ["QT_QPA_PLATFORM"] = "offscreen"
@@ -499,7 +497,7 @@ def aa_line_spans_any(ax, ay, bx, by, width, cw=CW, ch=CH):
     spans = []
     def add(x, ln, y, cov):
         if cov and ln and 0 <= y < ch:
-            spans.append((y, x, ln, cov))
+            spans.append((y, x, ln, cov & 0xff))  # QT_FT_Span::coverage is an unsigned char: a degenerate first row can hand it a negative int
     iTopFP = c_int(topBound) << 16; iLeftFP = c_int(left[1]) << 16; iRightFP = c_int(right[1]) << 16; iBottomFP = c_int(bottomBound) << 16
     leftIntersectAf = sF16(top[0] + (c_int(topBound) - top[1]) * tlS)
     rightIntersectAf = sF16(top[0] + (c_int(topBound) - top[1]) * trS)
