@@ -885,7 +885,7 @@ struct HumanRenderer {
             if constexpr (GameCustomBackground<Game>::value) {
                 RectD rects[4];
                 const int nr = Game::background_rects(*this, rects);
-                for (int k = 0; k < 4; k++)
+                _Pragma("unroll") for (int k = 0; k < 4; k++)  // constant indices: a running index would put the array in scratch memory
                     if (k < nr && rects[k].w > 0) draw_image_rect(bim, false, true, rects[k], 1.0f);
             } else {
                 const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);

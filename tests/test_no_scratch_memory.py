@@ -16,7 +16,7 @@ import pytest
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "procgen_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
-GAMES = ["CoinRun", "Plunder", "Leaper", "FruitBot", "Jumper", "CaveFlyer"]
+GAMES = ["CoinRun", "Plunder", "Leaper", "FruitBot", "Jumper", "CaveFlyer", "StarPilot"]
 SPLIT_RESET = {"Leaper", "Jumper", "CaveFlyer"}
 
 
