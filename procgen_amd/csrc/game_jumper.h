@@ -30,6 +30,7 @@ struct Jumper : BagDefaults<Jumper> {
     typedef JumperScratch Scratch;
     static constexpr int MAX_CELLS = 45 * 45;  // jumper.cpp:201-217 (memory mode)
     static constexpr bool HAS_OVERLAY = true;
+    static constexpr bool HAS_HUMAN_OVERLAY = true;  // the compass under render_human: antialiased path draws (pg_human.h, pg_aapath.h)
     static constexpr int ENT_CAP_T0 = 64, ENT_CAP_T1 = 128, ENT_CAP_T2 = 256;  // agent, goal, spikes (~10-40), <= 8 trails
     // the level generator's scratch dominates the arena: step kernels without it, resets in the reset kernel (pg_env.h GameSplit)
     static constexpr bool SPLIT_RESET = true;
@@ -396,6 +397,54 @@ struct Jumper : BagDefaults<Jumper> {
     }
     template <class E>
     PG_DEV static int theme_for_grid_obj(E &e, int type) { return is_wall(type) ? JP_WALL_THEME(e.G) : 0; }  // jumper.cpp:102-107
+
+    // draw_compass jumper.cpp:134-169 on the 512-pixel antialiased frame (render_human): the same calls, other Qt routes --
+    // drawEllipse fills through the gray raster and strokes with the antialiased cosmetic stroker (pen width 1), the needle is a
+    // rasterizeLine with a square cap (pen width 2 * compass_dim pixels), the bar an antialiased fillRect
+    template <class R>
+    PG_DEV static void draw_overlay_human(R &r) {
+        const EnvHdr &G = r.G;
+        if (r.d.opt.distribution_mode == MemoryMode) return;
+        const int n = G.n_ents;
+        int goal = -1;
+        for (int c = 0; c < ((n + 63) >> 6) && goal < 0; c++) {
+            const uint64_t m = PG_BALLOT(l, ((c << 6) + l) < n && r.etype((c << 6) + l) == GOAL);
+            if (m) goal = (c << 6) + pg_highest(m);
+        }
+        if (goal < 0) {
+            r.fail(PGE_ASSERT);
+            return;
+        }
+        const int ag = G.agent;
+        const float cd = JP_COMPASS_DIM(G);
+        const float cxf = (float)((double)(G.view_dim - cd) - .25);
+        double crv[4];
+        compass_rect(G.unit, G.view_dim, cd, crv);
+        const RectD cr_ = {crv[0], crv[1], crv[2], crv[3]};
+        r.aa_fill_ellipse(cr_, 0xffa8a69eu);    // set_pen_brush_color(p, clock_color): brush ...
+        r.aa_stroke_ellipse(cr_, 0xffa8a69eu);  // ... and a pen of width 1
+        const float pen_thickness = (float)(R::FRAME_W / (256.0 / (double)cd));
+        const int thickness = (int)pen_thickness;  // set_pen_brush_color(QPainter &, QColor, int thickness)
+        const float cx = (float)(cr_.x + cr_.w / 2);
+        const float cy = (float)(cr_.y + cr_.h / 2);
+        const float cr = (float)(cr_.w / 2 * .95);
+        const float theta = (float)pg_atan2_d((double)(r.ey(goal) - r.ey(ag)), (double)(r.ex(goal) - r.ex(ag)));  // get_theta BAG:233-238
+        if (thickness < 2) {  // (a pen of width <= 1 would be the cosmetic stroker's line: never the case at 512 pixels, 2 * compass_dim >= 4)
+            r.fail(PGE_UNSUPPORTED_DRAW);
+            return;
+        }
+        r.aa_wide_line((int)cx, (int)cy, (int)((double)cx + (double)cr * pg_cos_d((double)theta)), (int)((double)cy - (double)cr * pg_sin_d((double)theta)), (double)thickness, 0xfffcba03u);
+        const float ddx = r.ex(ag) - r.ex(goal), ddy = r.ey(ag) - r.ey(goal);
+        const float dist = (float)pg_sqrt((double)(ddx * ddx + ddy * ddy));  // get_distance BAG:133-143
+        const float dist_pct = (float)((double)dist / (G.main_width * pg_sqrt(2.0)));
+        const float bar_thickness = cd / 8;
+        r.exec_fill(r.get_abs_rect(cxf, (float)(.25 + (double)cd), cd * dist_pct, bar_thickness), 0xfffcba03u);
+        if (JP_JUMP_DELTA(G) < 0 && !JP_HAS_SUPPORT(G)) {
+            const RectD r1 = r.get_screen_rect(r.ex(ag) - r.erx(ag), r.ey(ag) + r.ery(ag), 2 * r.erx(ag), 2 * r.ery(ag), 0);
+            const RectD sh = {(double)(int)r1.x, (double)(int)(r1.y + r1.h * (5.0 / 6)), (double)(int)r1.w, (double)(int)(r1.h / 3)};  // QRect(int, int, int, int)
+            r.aa_fill_ellipse(sh, 0x78787878u);  // QColor(255, 255, 255, 120), premultiplied; Qt::NoPen
+        }
+    }
 
     // draw_compass jumper.cpp:134-169 (skipped in memory mode :171-178)
     template <class R>

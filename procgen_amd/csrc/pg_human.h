@@ -15,6 +15,7 @@
 // (image_for_type, theme_for_grid_obj, adjusted_image_rect, tile_aspect_ratio, draw_overlay, ...).
 #pragma once
 #include "pg_render.h"
+#include "pg_aapath.h"
 
 namespace pgamd {
 
@@ -23,6 +24,7 @@ constexpr int HUMAN_BANDS = HUMAN_RES / HUMAN_BAND;
 
 struct HumanLds {
     uint32_t fb[HUMAN_BAND * HUMAN_RES];
+    int area[HUMAN_RES + 2], cover[HUMAN_RES + 2];  // the gray raster's cells of one pixel row (pg_aapath.h; jumper's compass)
 };
 
 #if defined(PGAMD_WAVE_EMU) && defined(PG_HUMAN_TRACE)
@@ -86,6 +88,16 @@ struct AxisCoverage {
 
 }  // namespace human
 
+// a game whose overlay needs other draws at 512 pixels than at 64 declares HAS_HUMAN_OVERLAY and draw_overlay_human(r)
+template <class Game, class = void>
+struct GameHasHumanOverlay {
+    static constexpr bool value = false;
+};
+template <class Game>
+struct GameHasHumanOverlay<Game, decltype((void)Game::HAS_HUMAN_OVERLAY)> {
+    static constexpr bool value = Game::HAS_HUMAN_OVERLAY;
+};
+
 template <class Game>
 struct HumanRenderer {
     static constexpr int FRAME_W = HUMAN_RES, FRAME_H = HUMAN_RES;
@@ -143,10 +155,15 @@ struct HumanRenderer {
 
     // ---- QRasterizer::rasterizeLine, antialiased, clip = the frame ------------------------------------------------------------
     // the common head: clips the line to the (widened) frame and rescales the relative width; false: nothing to draw
-    PG_DEV static bool clip_line(double ax, double ay, double bx, double by, double &width, double &pax, double &pay, double &pbx, double &pby) {
+    PG_DEV static bool clip_line(double ax, double ay, double bx, double by, double &width, double &pax, double &pay, double &pbx, double &pby, bool square_cap = false) {
         const int cw = HUMAN_RES, ch = HUMAN_RES;
         if ((ax == bx && ay == by) || width == 0) return false;
         pax = ax; pay = ay; pbx = bx; pby = by;
+        if (square_cap) {  // the line grows by half its width at either end
+            const double ddx = pbx - pax, ddy = pby - pay;
+            pax -= (0.5 * width) * ddx; pay -= (0.5 * width) * ddy;
+            pbx += (0.5 * width) * ddx; pby += (0.5 * width) * ddy;
+        }
         const double offx = pg_fabs(by - ay) * width * 0.5, offy = pg_fabs(bx - ax) * width * 0.5;
         const double cl = 0 - offx, ct = 0 - offy, cr = (cw - 1) + 1 + offx, cb = (ch - 1) + 1 + offy;
         const bool a_in = cl <= pax && pax <= cr && ct <= pay && pay <= cb, b_in = cl <= pbx && pbx <= cr && ct <= pby && pby <= cb;
@@ -176,11 +193,11 @@ struct HumanRenderer {
     }
     PG_DEV static bool q26_equal(double p, double q) { return (int)((p - q) * 64) == 0; }  // q26Dot6Compare
     // 0: nothing; 1: axis-aligned (cov filled in); 2: a general line (pa, pb, width returned for the trapezoid walker)
-    PG_DEV static int rasterize_line(double ax, double ay, double bx, double by, double width, human::AxisCoverage &cov, double (&gl)[5]) {
+    PG_DEV static int rasterize_line(double ax, double ay, double bx, double by, double width, human::AxisCoverage &cov, double (&gl)[5], bool square_cap = false) {
         using namespace human;
         const int cw = HUMAN_RES, ch = HUMAN_RES;
         double pax, pay, pbx, pby;
-        if (!clip_line(ax, ay, bx, by, width, pax, pay, pbx, pby)) return 0;
+        if (!clip_line(ax, ay, bx, by, width, pax, pay, pbx, pby, square_cap)) return 0;
         if (q26_equal(pay, pby)) {
             if (q26_equal(pax, pbx)) return 0;
             const double x = (pax + pbx) * 0.5, dx = pg_fabs(pbx - pax) * 0.5, y = pay, dy = width * dx;
@@ -254,8 +271,28 @@ struct HumanRenderer {
     }
     PG_DEV uint32_t fetch(const Texture &t, int y, int x0, int length, int b) const {
         using namespace human;
-        const int fdx = (int)(t.m11 * 65536.0), fdy = (int)(t.m12 * 65536.0);
         const double cx = x0 + 0.5, cy = y + 0.5;
+        // QSpanData::setupMatrix: the 16.16 walk below is only taken while the inverse matrix is small ("fast_matrix"); a sprite scaled
+        // down ~20 times a few hundred pixels from the origin has an inverse translation beyond 1e4 and gets floating-point source
+        // coordinates per pixel with 8-bit distances instead (jumper's memory mode without center_agent: an 11-pixel agent)
+        if (!(t.m11 * t.m11 + t.m21 * t.m21 < 1e4 && t.m12 * t.m12 + t.m22 * t.m22 < 1e4 && pg_fabs(t.dx) < 1e4 && pg_fabs(t.dy) < 1e4)) {
+            double sfx = t.m21 * cy + t.m11 * cx + t.dx, sfy = t.m22 * cy + t.m12 * cx + t.dy;
+            for (int i = 0; i < b; i++) {  // (accumulated as Qt does: fx += fdx per pixel)
+                sfx += t.m11;
+                sfy += t.m12;
+            }
+            const double px = sfx - 0.5, py = sfy - 0.5;
+            int x1 = (int)px - (px < 0 ? 1 : 0), y1 = (int)py - (py < 0 ? 1 : 0), x2, y2;
+            const int distx = (int)((px - x1) * 256), disty = (int)((py - y1) * 256);
+            if (x1 < 0) x1 = x2 = 0;
+            else if (x1 >= t.w - 1) x1 = x2 = t.w - 1;
+            else x2 = x1 + 1;
+            if (y1 < 0) y1 = y2 = 0;
+            else if (y1 >= t.h - 1) y1 = y2 = t.h - 1;
+            else y2 = y1 + 1;
+            return interp8(texel(t, x1, y1), texel(t, x2, y1), texel(t, x1, y2), texel(t, x2, y2), (uint32_t)distx, (uint32_t)disty);
+        }
+        const int fdx = (int)(t.m11 * 65536.0), fdy = (int)(t.m12 * 65536.0);
         const int fx0 = (int)((t.m21 * cy + t.m11 * cx + t.dx) * 65536.0) - 32768;
         const int fy0 = (int)((t.m22 * cy + t.m12 * cx + t.dy) * 65536.0) - 32768;
         const int fx = fx0 + b * fdx, fy = fy0 + b * fdy;
@@ -596,6 +633,96 @@ struct HumanRenderer {
         PG_SYNC();
     }
 
+    // ---- antialiased path draws (pg_aapath.h): jumper's compass ------------------------------------------------------------------------------
+    // QPainter::drawEllipse with a brush, NoPen part: Qt's gray raster over the flattened outline, row by row of this band
+    PG_DEV void aa_fill_ellipse(const RectD &r, uint32_t premul) {
+        if (qtpath::fill_culled(r.x, r.y, r.w, r.h, HUMAN_RES, HUMAN_RES)) return;
+        qtpath::Arc arc;
+        qtpath::arc_points(r.x, r.y, r.w, r.h, arc);
+        aapath::RowExtent ext{0, 0, 0};
+        qtpath::flatten(arc, ext);
+        int ya = ext.min_y >> 6, yb = (ext.max_y + 63) >> 6;
+        if (ya < row0) ya = row0;
+        if (yb > row1 - 1) yb = row1 - 1;
+        int *area = lds->area, *cover = lds->cover;
+        for (int y = ya; y <= yb; y++) {
+            for (int base = 0; base < HUMAN_RES + 2; base += 64) {
+                PG_FOR_LANES(l) {
+                    if (base + l < HUMAN_RES + 2) {
+                        area[base + l] = 0;
+                        cover[base + l] = 0;
+                    }
+                }
+            }
+            PG_SYNC();
+            aapath::RowCells cells;
+            cells.init(area, cover, HUMAN_RES, y);
+            qtpath::flatten(arc, cells);  // (the outline is closed: its last point is its first)
+            cells.record();
+            PG_SYNC();
+            // gray_sweep of this row
+            uint32_t *rowp = fb + (y - row0) * HUMAN_RES;
+            auto hline = [&](int x0, int ar, int count) {
+                const int cv = aapath::RowCells::coverage(ar);
+                if (!cv) return;
+                int xa = x0 < 0 ? 0 : x0, xb = x0 + count > HUMAN_RES ? HUMAN_RES : x0 + count;
+                for (int base = xa; base < xb; base += 64) {
+                    PG_FOR_LANES(l) {
+                        const int x = base + l;
+                        if (x < xb) rowp[x] = blend(rowp[x], premul, (uint32_t)cv, false);
+                    }
+                }
+            };
+            int cov = 0, x = 0;
+            for (int cx = cells.min_x; cx <= cells.max_x; cx++) {
+                const int ca = area[cx + 1], cc = cover[cx + 1];
+                if (!(ca | cc)) continue;
+                if (cx > x && cov != 0) hline(x, cov * (aapath::ONE_PIXEL * 2), cx - x);
+                cov += cc;
+                const int ar = cov * (aapath::ONE_PIXEL * 2) - ca;
+                if (ar != 0 && cx >= 0) hline(cx, ar, 1);
+                x = cx + 1;
+            }
+            if (cov != 0) hline(x, cov * (aapath::ONE_PIXEL * 2), HUMAN_RES - x);
+            PG_SYNC();
+        }
+    }
+    // ... its pen of width 1: QCosmeticStroker's antialiased line walker over the subdivided cubics
+    struct PenSink {
+        HumanRenderer &r;
+        uint32_t color;
+        PG_DEV void pixel(int x, int y, int coverage) {
+            if (x < 0 || x > HUMAN_RES - 1 || y < r.row0 || y > r.row1 - 1) return;
+            uint32_t *p = r.fb + (y - r.row0) * HUMAN_RES + x;
+            const uint32_t c = human::bmul(color, (uint32_t)coverage);  // drawPixelARGB32
+            PG_FOR_LANES(l) {
+                if (l == 0) *p = c + human::bmul(*p, 255 - (c >> 24));
+            }
+            PG_SYNC();
+        }
+    };
+    PG_DEV void aa_stroke_ellipse(const RectD &r, uint32_t color) {
+        PenSink sink{*this, color};
+        aapath::CosmeticAA<PenSink> st{sink, -1.0, HUMAN_RES + 1.0, -1.0, HUMAN_RES + 1.0};
+        st.ellipse(r.x, r.y, r.w, r.h);
+    }
+    // QPainter::drawLine(int, int, int, int) with a solid pen wider than 1 (QRasterPaintEngine::stroke, LinesHint): rasterizeLine with QPen's
+    // default square cap; a zero-length line is a pen-wide dash
+    PG_DEV void aa_wide_line(int x1, int y1, int x2, int y2, double pen_width, uint32_t color) {
+        human::AxisCoverage c;
+        double gl[5];
+        int kind;
+        if (x1 == x2 && y1 == y2) {
+            kind = rasterize_line(x1 - pen_width * 0.5, (double)y1, x1 + pen_width * 0.5, (double)y1, 1.0, c, gl);
+        } else {
+            const double dx = (double)(x2 - x1), dy = (double)(y2 - y1);
+            kind = rasterize_line((double)x1, (double)y1, (double)x2, (double)y2, pen_width / pg_sqrt(dx * dx + dy * dy), c, gl, true);
+        }
+        auto src = [color](int, int, int, int) { return color; };
+        if (kind == 1) fill_axis(c, 256, false, src);
+        else if (kind == 2) fill_general(gl, 256, false, src);
+    }
+
     // QPainter::fillRect(QRectF, QColor) under Antialiasing (untransformed painter): the rect's mid line, width h / w
     PG_DEV void exec_fill(const RectD &r, uint32_t color) {
         human::AxisCoverage c;
@@ -646,6 +773,8 @@ struct HumanRenderer {
         const int kind = rasterize_line((l + l) * 0.5, (t + bb) * 0.5, (rr + rr) * 0.5, (t + bb) * 0.5, r.h / r.w, c, gl);
         if (kind != 1) return;
 #if defined(PGAMD_WAVE_EMU) && defined(PG_HUMAN_TRACE)
+        if (!rgb32 && pg_human_trace_xy()[1] >= row0 && pg_human_trace_xy()[1] < row1 && pg_human_trace_xy()[0] >= c.iLeft && pg_human_trace_xy()[0] <= c.iRight && pg_human_trace_xy()[1] >= c.iTop && pg_human_trace_xy()[1] <= c.iBottom)
+            fprintf(stderr, "sprite %dx%d mirrored %d rect %.17g %.17g %.17g %.17g opacity %g\n", (int)im.w, (int)im.h, (int)mirrored, r.x, r.y, r.w, r.h, (double)opacity);
         if (rgb32 && row0 == 0) fprintf(stderr, "bg rect %.17g %.17g %.17g %.17g -> iLeft %d iRight %d covL %d covR %d top %d bottom %d yPa %d yPb %d unit %.9g\n", r.x, r.y, r.w, r.h, c.iLeft, c.iRight, c.covLeft, c.covRight, c.iTop, c.iBottom, c.yPa, c.yPb, (double)G.unit);
 #endif
         if (c.iBottom < row0 || c.iTop >= row1) return;
@@ -941,7 +1070,8 @@ struct HumanRenderer {
             exec_fill(d2, 0xff000000u | ((uint32_t)s1 << 16) | ((uint32_t)s1 << 8) | (uint32_t)s1);
             exec_fill(d3, 0xff000000u | ((uint32_t)s2 << 16) | ((uint32_t)s2 << 8) | (uint32_t)s2);
         }
-        if constexpr (GameHasOverlay<Game>::value) Game::draw_overlay(*this);
+        if constexpr (GameHasHumanOverlay<Game>::value) Game::draw_overlay_human(*this);  // (draws that need the antialiased path route)
+        else if constexpr (GameHasOverlay<Game>::value) Game::draw_overlay(*this);
         PG_SYNC();
         store_band();
         if (G.error) {

@@ -5,12 +5,12 @@ Generates tests/golden/render_human.npz from the COMPILED REFERENCE (oracle/_ref
 
     python tests/golden/make_human_golden.py
 
-Per game (all but jumper, whose compass needs Qt's path engine under antialiasing): 2 envs, rand_seed 7, actions
+Per game: 2 envs, rand_seed 7, actions
 RandomState(1).randint(0, 15), frames taken at steps 0, 17 and 40:
   <game>/crc      [3][2] CRC32 of each frame's bytes
   <game>/actions  [40][2]
   <game>/state    get_state bytes of env 0 after step 40 (the camera scalars in it are those of the 512-pixel frame)
-  frames/<game>   one full frame (step 17, env 0) for coinrun, starpilot and fruitbot, so that a mismatch can be looked at
+  frames/<game>   one full frame (step 17, env 0) for coinrun, starpilot, fruitbot and jumper, so that a mismatch can be looked at
 Extra option sets for coinrun (center_agent off + paint_vel_info, monochrome assets without backgrounds) under <game>@<k>.
 """
 import os
@@ -26,14 +26,16 @@ sys.path.insert(0, os.path.join(REPO, "oracle"))
 
 import ref_env  # noqa: E402
 
-GAMES = ["bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot", "heist", "leaper", "maze", "miner", "ninja", "plunder", "starpilot"]
+GAMES = ["bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot", "heist", "jumper", "leaper", "maze", "miner", "ninja", "plunder", "starpilot"]
 STEPS = [0, 17, 40]
 OPTION_SETS = {  # key -> (game, kwargs)
     "coinrun@1": ("coinrun", dict(center_agent=False, paint_vel_info=True)),
     "maze@1": ("maze", dict(use_monochrome_assets=True, use_backgrounds=False)),
     "dodgeball@1": ("dodgeball", dict(distribution_mode="memory", restrict_themes=True)),
+    "jumper@1": ("jumper", dict(distribution_mode="easy")),
+    "jumper@2": ("jumper", dict(distribution_mode="memory", center_agent=False)),
 }
-FULL = {"coinrun", "starpilot", "fruitbot"}
+FULL = {"coinrun", "starpilot", "fruitbot", "jumper"}
 
 
 def run(game, kwargs):

@@ -28,3 +28,20 @@ def test_antialiased_smooth_transform_restatement_equals_qt():
     assert "100 cases, 0 with differences" in out, out[-2000:]                 # untransformed drawImage / fillRect
     assert "turned fills: 100 cases, 0 with differences" in out, out[-2000:]   # the antialiased trapezoid walker
     assert "turned images: 100 cases, 0 with differences" in out, out[-2000:]  # rotation branch of the bilinear fetch
+
+
+GRAY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "qt_gray_raster_probe.py")
+
+
+@pytest.mark.skipif(not _has_pyqt(), reason="needs PyQt5 5.9 (the build container's /opt/conda)")
+def test_antialiased_path_restatement_equals_qt():
+    """jumper's compass under render_human (procgen_amd/csrc/pg_aapath.h): gray raster fill, antialiased cosmetic outline; and the
+    square-cap needle (pg_human.h aa_wide_line)"""
+    r = subprocess.run([CONDA_PY, GRAY, "80", "3"], capture_output=True, text=True, cwd="/tmp", timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-2000:]
+    assert "filled antialiased ellipses: 80 cases, 0 with differences" in out, out[-2000:]
+    assert "outlined antialiased ellipses (pen width 1): 80 cases, 0 with differences" in out, out[-2000:]
+    r = subprocess.run([CONDA_PY, PROBE, "120", "2", "lines"], capture_output=True, text=True, cwd="/tmp", timeout=600)
+    out = r.stdout + r.stderr
+    assert "wide lines: 120 cases, 0 with differences" in out, out[-2000:]

@@ -52,11 +52,15 @@ def source_over(d, s, ca):
     return (s + byte_mul(d, 255 - (s >> 24))) & 0xffffffff
 
 
-def clip_line(ax, ay, bx, by, width, cw, ch):
+def clip_line(ax, ay, bx, by, width, cw, ch, square_cap=False):
     """common head of QRasterizer::rasterizeLine: returns (pax, pay, pbx, pby, width) or None"""
     if (ax == bx and ay == by) or width == 0:
         return None
     pax, pay, pbx, pby = ax, ay, bx, by
+    if square_cap:  # the line grows by half its width at either end
+        dx_, dy_ = pbx - pax, pby - pay
+        pax, pay = pax - (0.5 * width) * dx_, pay - (0.5 * width) * dy_
+        pbx, pby = pbx + (0.5 * width) * dx_, pby + (0.5 * width) * dy_
     offx = abs(by - ay) * width * 0.5; offy = abs(bx - ax) * width * 0.5
     cl, ct, cr, cb = 0 - offx, 0 - offy, (cw - 1) + 1 + offx, (ch - 1) + 1 + offy
     def contains(px, py):
@@ -93,9 +97,9 @@ def q26eq(p, q):
     return c_int((p - q) * 64) == 0
 
 
-def aa_line_spans(ax, ay, bx, by, width, cw=CW, ch=CH):
+def aa_line_spans(ax, ay, bx, by, width, cw=CW, ch=CH, square_cap=False):
     """QRasterizer::rasterizeLine, antialiased -> list of (y, x, len, coverage 0..255)"""
-    c = clip_line(ax, ay, bx, by, width, cw, ch)
+    c = clip_line(ax, ay, bx, by, width, cw, ch, square_cap)
     if c is None:
         return []
     pax, pay, pbx, pby, width = c
@@ -184,9 +188,40 @@ def interp8(tl, tr, bl, br, dx, dy):  # interpolate_4_pixels (8-bit distances): 
     return lerp256(lerp256(tl, bl, dy), lerp256(tr, br, dy), dx)
 
 
+def fast_matrix(m11, m12, m21, m22, dx, dy):
+    """QSpanData::setupMatrix: the 16.16 fixed-point fetch is only used while the inverse matrix is small"""
+    return m11 * m11 + m21 * m21 < 1e4 and m12 * m12 + m22 * m22 < 1e4 and abs(dx) < 1e4 and abs(dy) < 1e4
+
+
+def fetch_bilinear_slow(src, y, x0, length, T):
+    """fetchTransformedBilinearARGB32PM without fast_matrix (a strongly scaled-down sprite far from the origin has an inverse
+    translation beyond 1e4): floating-point source coordinates per pixel, 8-bit distances, interpolate_4_pixels"""
+    m11, m12, m21, m22, dx, dy = T
+    sh, sw = src.shape
+    cx = x0 + 0.5; cy = y + 0.5
+    fx = m21 * cy + m11 * cx + dx
+    fy = m22 * cy + m12 * cx + dy
+    out = []
+    def bnd(v, n):
+        if v < 0: return 0, 0
+        if v >= n - 1: return n - 1, n - 1
+        return v, v + 1
+    for i in range(length):
+        px = fx - 0.5; py = fy - 0.5
+        x1 = c_int(px) - (1 if px < 0 else 0); y1 = c_int(py) - (1 if py < 0 else 0)
+        distx = c_int((px - x1) * 256); disty = c_int((py - y1) * 256)
+        x1, x2 = bnd(x1, sw); y1, y2 = bnd(y1, sh)
+        tl, tr, bl, br = int(src[y1, x1]), int(src[y1, x2]), int(src[y2, x1]), int(src[y2, x2])
+        out.append(interp8(tl, tr, bl, br, distx, disty))
+        fx += m11; fy += m12
+    return out
+
+
 def fetch_bilinear_scale(src, y, x0, length, i11, i22, idx, idy):
     """fetchTransformedBilinearARGB32PM<BlendTransformedBilinear>, fdy == 0, one call per span (x0, length)"""
     sh, sw = src.shape
+    if not fast_matrix(i11, 0.0, 0.0, i22, idx, idy):
+        return fetch_bilinear_slow(src, y, x0, length, (i11, 0.0, 0.0, i22, idx, idy))
     fdx = c_int(i11 * 65536.)
     cx = x0 + 0.5; cy = y + 0.5
     fx = c_int((0.0 * cy + i11 * cx + idx) * 65536.) - 32768
@@ -466,17 +501,17 @@ def sF16(x):  # qSafeFloatToQ16Dot16
     return F16(min(max(x, -32768.0), 32767.0))
 
 
-def aa_line_spans_any(ax, ay, bx, by, width, cw=CW, ch=CH):
+def aa_line_spans_any(ax, ay, bx, by, width, cw=CW, ch=CH, square_cap=False):
     """QRasterizer::rasterizeLine, antialiased, any direction.  General lines: the four corners are snapped DOWN to the 26.6
     grid (snapTo26Dot6Grid), every edge keeps its own slope, a 16.16 trapezoid walker with intersectPixelFP gives the coverage.
     (Qt 5.9 has no "is this part of the row empty" guards around intersectPixelFP: a side corner just above a clipped first row
     contributes a negative exclusion there -- later Qt versions guard it; pinned by the turned-fill probe, 400 / 400.)"""
-    c = clip_line(ax, ay, bx, by, width, cw, ch)
+    c = clip_line(ax, ay, bx, by, width, cw, ch, square_cap)
     if c is None:
         return []
     pax, pay, pbx, pby, w2 = c
     if q26eq(pay, pby) or q26eq(pax, pbx):
-        return aa_line_spans(ax, ay, bx, by, width, cw, ch)
+        return aa_line_spans(ax, ay, bx, by, width, cw, ch, square_cap)
     width = w2
     if pay > pby:
         pax, pay, pbx, pby = pbx, pby, pax, pay
@@ -679,6 +714,8 @@ def fetch_bilinear_any(src, y, x0, length, T):
     """fetchTransformedBilinearARGB32PM<BlendTransformedBilinear>, any affine matrix (fast_matrix)"""
     i11, i12, i21, i22, idx, idy = T
     sh, sw = src.shape
+    if not fast_matrix(i11, i12, i21, i22, idx, idy):
+        return fetch_bilinear_slow(src, y, x0, length, (i11, i12, i21, i22, idx, idy))
     fdx = c_int(i11 * 65536.); fdy = c_int(i12 * 65536.)
     if fdy == 0:
         assert i21 == 0 or True
@@ -837,6 +874,55 @@ def probe_turned_images(n, seed):
     print(f"turned images: {n} cases, {miss} with differences, worst {worst}")
 
 
+def model_wide_line(dst, x1, y1, x2, y2, pen_width, color):
+    """QPainter::drawLine(int, int, int, int) with a solid pen wider than 1 under Antialiasing (QRasterPaintEngine::stroke, LinesHint):
+    rasterizeLine(p1, p2, width / length, squareCap) -- QPen's default cap is SquareCap; a zero-length line draws a pen-wide dash"""
+    ch, cw = dst.shape
+    if x1 == x2 and y1 == y2:
+        spans = aa_line_spans_any(x1 - pen_width * 0.5, float(y1), x1 + pen_width * 0.5, float(y1), 1.0, cw, ch)
+    else:
+        length = math.sqrt(float(x2 - x1) ** 2 + float(y2 - y1) ** 2)
+        spans = aa_line_spans_any(float(x1), float(y1), float(x2), float(y2), pen_width / length, cw, ch, square_cap=True)
+    for (y, x, ln, cov) in spans:
+        for i in range(ln):
+            dst[y, x + i] = source_over(int(dst[y, x + i]), color, cov)
+
+
+def qt_wide_line(dst0, x1, y1, x2, y2, pen_width, c):
+    QImage, QPainter, QColor, QRectF = qt_setup()
+    from PyQt5.QtGui import QPen
+    hh, ww = dst0.shape
+    img = np_to_qimage(dst0, QImage.Format_RGB32).copy()
+    p = QPainter(img)
+    p.setRenderHint(QPainter.Antialiasing, True); p.setRenderHint(QPainter.SmoothPixmapTransform, True)
+    p.setPen(QPen(QColor((c >> 16) & 255, (c >> 8) & 255, c & 255), pen_width))
+    p.drawLine(int(x1), int(y1), int(x2), int(y2))
+    p.end()
+    ptr = img.constBits(); ptr.setsize(ww * hh * 4)
+    return np.frombuffer(bytes(ptr), np.uint32).reshape(hh, ww).copy()
+
+
+def probe_wide_lines(n, seed):
+    """jumper's compass needle at 512 pixels: an antialiased line with a pen of 2 * compass_dim pixels"""
+    rng = np.random.RandomState(seed)
+    miss = worst = 0
+    for case in range(n):
+        dst0 = np.full((CH, CW), 0xff000000, np.uint32)
+        x1, y1, x2, y2 = [int(v) for v in rng.randint(-10, CW + 10, size=4)]
+        if case % 7 == 0: x2 = x1
+        if case % 11 == 0: y2 = y1
+        pw = int(rng.randint(2, 9))
+        got = qt_wide_line(dst0, x1, y1, x2, y2, pw, 0xfffcba03)
+        want = dst0.copy(); model_wide_line(want, x1, y1, x2, y2, pw, 0xfffcba03)
+        d = np.abs(got.view(np.uint8).reshape(CH, CW, 4)[..., :3].astype(int) - want.view(np.uint8).reshape(CH, CW, 4)[..., :3].astype(int))
+        if d.max() > 0:
+            miss += 1; worst = max(worst, int(d.max()))
+            ys, xs = np.nonzero(d.max(axis=2))
+            if miss <= 10:
+                print(f"case {case} line ({x1},{y1})-({x2},{y2}) pen {pw}: {len(ys)} px differ, max {d.max()}, first (x={xs[0]},y={ys[0]})")
+    print(f"wide lines: {n} cases, {miss} with differences, worst {worst}")
+
+
 if __name__ == "__main__":
     # usage: qt_smooth_aa_probe.py [n_cases] [seed] [untransformed|fills|images|all]
     n_ = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -848,3 +934,5 @@ if __name__ == "__main__":
         probe_turned_fills(n_, seed_)
     if what in ("images", "all"):
         probe_turned_images(n_, seed_)
+    if what in ("lines",):  # groundwork for jumper's compass under render_human (not in the product yet)
+        probe_wide_lines(n_, seed_)

@@ -16,9 +16,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests", "emu")):
     sys.path.insert(0, p)
 
-ALL = ["bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot", "heist", "leaper", "maze", "miner", "ninja", "plunder", "starpilot"]
+ALL = ["bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot", "heist", "jumper", "leaper", "maze", "miner", "ninja", "plunder", "starpilot"]
 EXT = {"chaser", "dodgeball", "leaper", "starpilot"}
-MEM = {"caveflyer", "dodgeball", "heist", "maze", "miner"}
+MEM = {"caveflyer", "dodgeball", "heist", "jumper", "maze", "miner"}
 MODES = {"easy": 0, "hard": 1, "extreme": 2, "memory": 10}
 
 
