@@ -42,7 +42,7 @@ def test_kernels_use_no_scratch_memory(tmp_path):
     for game, res in zip(GAMES, results):
         for kernel, size in res.items():
             if game == "Jumper" and "render_human" in kernel:
-                # off the hot path and opt-in: jumper's compass under render_human flattens cubics and subdivides them with small
+                # off the hot path: jumper's compass under render_human flattens cubics and subdivides them with small
                 # stacks indexed at run time (pg_qtpath.h flatten, pg_aapath.h CosmeticAA::cubic), which live in scratch
                 assert size <= 2048, f"{game}: {kernel} uses {size} B of scratch per lane"
                 continue
