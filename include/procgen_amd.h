@@ -26,7 +26,7 @@
  * Reference options this library implements with kernels of their own (nothing to pass beyond what procgen/env.py passes):
  *   "render_human" (render_mode="rgb_array"): a fourth info tensor "rgb" uint8 [512][512][3], the antialiased frame of
  *   reference src/vecgame.cpp:270-282,363-376, drawn on the device behind every step and landed in the caller's info
- *   buffers (every game but jumper); "use_generated_assets": AssetGen sprites / backgrounds (reference src/assetgen.cpp).
+ *   buffers; "use_generated_assets": AssetGen sprites / backgrounds (reference src/assetgen.cpp).
  */
 #ifndef PROCGEN_AMD_H
 #define PROCGEN_AMD_H

@@ -4,7 +4,7 @@ against tests/golden/render_human.npz, which tests/golden/make_human_golden.py g
 
 CPU  : the kernel source run by the wave emulation (tests/emu) -- frames and the get_state bytes behind them, bit for bit.
 GPU  : the HIP libenv.so through the C ABI (ProcgenGym3Env(render_mode="rgb_array")): frames, state bytes, tensortypes, the
-       redraw after set_state, joint handles, separately placed buffers, and the refusals.
+       redraw after set_state, joint handles, separately placed buffers, and the one refusal (generated assets).
 The contract allows +-1 LSB per channel on frames; both hold 0 (CRC32 of the whole frame).
 """
 import os
