@@ -283,7 +283,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         fatal("invalid distribution_mode %d\n", dist_mode);
     }
     kernel_id = kernel_id_for(game_id, dist_mode);
-    if (this->render_human && o.use_generated_assets) fatal("render_human together with use_generated_assets is not provided by the HIP stepper\n");
+    if (this->render_human && o.use_generated_assets && !getenv("PROCGEN_AMD_GEN_RENDER_HUMAN"))
+        fatal("render_human together with use_generated_assets is opt-in (set PROCGEN_AMD_GEN_RENDER_HUMAN=1): the kernel equals the reference bit for bit in the CPU emulation (tests/test_render_human.py) but this combination has not run on a GPU yet\n");
     if (!game_supported(kernel_id)) fatal("game %s has no kernel for distribution_mode %d in the HIP stepper\n", env_name.c_str(), dist_mode);
     int plain_assets = 0, physics_mode = 0, game_type = 0;
     opts.consume_int("plain_assets", &plain_assets);

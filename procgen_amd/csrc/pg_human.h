@@ -232,14 +232,37 @@ struct HumanRenderer {
 
     // ---- source of a drawImage: bilinear texture fetch -------------------------------------------------------------------------
     struct Texture {
-        uint32_t off;
+        const uint32_t *base;  // first pixel: the atlas image, or (use_generated_assets) the env's background canvas
         int w, h;
+        bool argb32;     // use_generated_assets: a 64 x 64 Format_ARGB32 sprite (NOT premultiplied): Qt's generic bilinear fetch converts every
+                         // texel (qPremultiply) and uses one formula for all pixels of a run (no SSE2 head / groups / tail)
         bool mirrored;   // a reflected sprite (BAG:121 keeps a mirrored copy): column x of it is column w - 1 - x of the atlas image
         bool rgb32;      // no alpha channel (backgrounds): at opacity 1 getOperator turns SourceOver into Source (QSpanData::initTexture: hasAlpha = image.hasAlphaChannel() || intOpacity != 256)
         double m11, m12, m21, m22, dx, dy;  // QSpanData::setupMatrix: inverse of translate(1/65536) * painter matrix * rect mapping
     };
+    PG_DEV static uint32_t q_premultiply(uint32_t p) {  // qrgb.h qPremultiply
+        const uint32_t a = p >> 24;
+        if (a == 255) return p;
+        if (a == 0) return 0;
+        uint32_t t = (p & 0xff00ffu) * a;
+        t = ((t + ((t >> 8) & 0xff00ffu) + 0x800080u) >> 8) & 0xff00ffu;
+        uint32_t g = ((p >> 8) & 0xffu) * a;
+        g = (g + ((g >> 8) & 0xffu) + 0x80u) & 0xff00u;
+        return g | t | (a << 24);
+    }
     PG_DEV uint32_t texel(const Texture &t, int x, int y) const {
-        return d.pixels[t.off + (uint32_t)(y * t.w + (t.mirrored ? t.w - 1 - x : x))];
+        const uint32_t p = t.base[(uint32_t)(y * t.w + (t.mirrored ? t.w - 1 - x : x))];
+        return t.argb32 ? q_premultiply(p) : p;
+    }
+    // the texture of a draw: generated sprites are ARGB32, the generated background is the env's own 500 x 500 RGB32 canvas
+    PG_DEV void bind_texture(Texture &tx, const ImgDesc im, bool mirrored, bool rgb32) const {
+        const bool gen = d.gen_bg != nullptr;
+        tx.base = (gen && rgb32) ? d.gen_bg + (size_t)env * GEN_BG_WORDS : d.pixels + im.off;
+        tx.w = im.w;
+        tx.h = im.h;
+        tx.argb32 = gen && !rgb32;
+        tx.mirrored = mirrored;
+        tx.rgb32 = rgb32;
     }
     // fetchTransformedBilinearARGB32PM<BlendTransformedBilinear> for pixel b of the run that starts at column x0 of row y.  The
     // spans of a row that touch are fetched as one run, and the pixel's place in the run selects the code path of Qt's SSE2 build:
@@ -299,8 +322,8 @@ struct HumanRenderer {
         bool eight;
         if (fdy == 0) eight = (fdx > 0 && fdx <= 65536) || (fdx < 0 && fdx > -(65536 / 8)) || pg_fabs(t.m22) < (1. / 8.);
         else eight = pg_fabs(t.m11) < (1. / 8.) || pg_fabs(t.m22) < (1. / 8.);
-        bool four_bit = false;
-        if (!eight) {
+        bool four_bit = !eight && t.argb32;  // (the generic fetch of a non-premultiplied source: one formula for the whole run)
+        if (!eight && !t.argb32) {
             long long xl, xh, yl = 0, yh = (long long)length - 1;
             unclamped_range(fx0, fdx, t.w, length, xl, xh);
             if (fdy != 0) unclamped_range(fy0, fdy, t.h, length, yl, yh);
@@ -747,6 +770,8 @@ struct HumanRenderer {
             const int io = (int)(o * 256);
             const uint32_t ca = (uint32_t)((255 * io) >> 8);
             const bool source_mode = rgb32 && io == 256;
+            Texture btx;
+            bind_texture(btx, im, mirrored, rgb32);
             const int x1 = q_round(r.x), y1 = q_round(r.y), x2 = q_round(r.x + r.w), y2 = q_round(r.y + r.h);
             int ya = y1 < row0 ? row0 : y1, yb = y2 > row1 ? row1 : y2;
             const int xa = x1 < 0 ? 0 : x1, xb = x2 > HUMAN_RES ? HUMAN_RES : x2;
@@ -758,7 +783,7 @@ struct HumanRenderer {
                     PG_FOR_LANES(l) {
                         const int x = base + l, sx = x - x1;
                         if (x < xb && sx >= 0 && sx < (int)im.w) {
-                            const uint32_t s = d.pixels[im.off + (uint32_t)(sy * im.w + (mirrored ? im.w - 1 - sx : sx))];
+                            const uint32_t s = texel(btx, sx, sy);
                             rowp[x] = blend(rowp[x], s, ca, source_mode);
                         }
                     }
@@ -779,11 +804,7 @@ struct HumanRenderer {
 #endif
         if (c.iBottom < row0 || c.iTop >= row1) return;
         Texture tx;
-        tx.off = im.off;
-        tx.w = im.w;
-        tx.h = im.h;
-        tx.mirrored = mirrored;
-        tx.rgb32 = rgb32;
+        bind_texture(tx, im, mirrored, rgb32);
         {
             const double scx = r.w / (double)im.w, scy = r.h / (double)im.h, dd = 1.0 / 65536;
             const double m11 = 1.0 * scx, m22 = 1.0 * scy, m31 = dd * scx + r.x, m32 = dd * scy + r.y;
@@ -905,11 +926,7 @@ struct HumanRenderer {
         const double rx = -w / 2, ry = -h / 2;
         // the texture matrix: copy = matrix; copy.translate(r.x, r.y); copy.scale(r.w / sw, r.h / sh); inverse of translate(1/65536) * copy
         Texture tx;
-        tx.off = im.off;
-        tx.w = im.w;
-        tx.h = im.h;
-        tx.mirrored = mirrored;
-        tx.rgb32 = false;
+        bind_texture(tx, im, mirrored, false);
         {
             double c11 = m11, c12 = m12, c21 = m21, c22 = m22, cdx = mdx, cdy = mdy;
             int ctyp;

@@ -34,6 +34,10 @@ OPTION_SETS = {  # key -> (game, kwargs)
     "dodgeball@1": ("dodgeball", dict(distribution_mode="memory", restrict_themes=True)),
     "jumper@1": ("jumper", dict(distribution_mode="easy")),
     "jumper@2": ("jumper", dict(distribution_mode="memory", center_agent=False)),
+    # with generated assets (no state: BasicAbstractGame::serialize asserts !use_generated_assets)
+    "coinrun@gen": ("coinrun", dict(use_generated_assets=True)),
+    "starpilot@gen": ("starpilot", dict(use_generated_assets=True)),
+    "fruitbot@gen": ("fruitbot", dict(use_generated_assets=True)),
 }
 FULL = {"coinrun", "starpilot", "fruitbot", "jumper"}
 
@@ -56,7 +60,7 @@ def run(game, kwargs):
         ac = rng.randint(0, 15, size=(n,), dtype=np.int32)
         acts.append(ac)
         env.act(ac)
-    state = np.frombuffer(env.get_state()[0], dtype=np.uint8).copy()
+    state = np.zeros(0, np.uint8) if kwargs.get("use_generated_assets") else np.frombuffer(env.get_state()[0], dtype=np.uint8).copy()
     env.close()
     return np.array(crc, dtype=np.uint32), np.array(acts, dtype=np.int32), state, full
 

