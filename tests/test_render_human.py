@@ -78,6 +78,27 @@ def test_emulated_kernel_frames_equal_the_compiled_reference(golden_dir, key):
     env.close()
 
 
+def _ref_available():
+    try:
+        import ref_env
+
+        return ref_env.available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(not _ref_available(), reason="needs the compiled reference (oracle/_ref, build container)")
+def test_emulated_kernel_against_the_compiled_reference_in_other_modes():
+    """a reduced form of tests/tools/render_human_sweep.py (every mode x center_agent, 1332 frames, no differing pixel): the modes the
+    committed fixture does not hold, live against the compiled reference"""
+    sys.path.insert(0, os.path.join(REPO, "tests", "tools"))
+    import render_human_sweep as S
+
+    for game, mode, center in (("caveflyer", "memory", False), ("starpilot", "extreme", True), ("jumper", "easy", False), ("fruitbot", "easy", False), ("miner", "memory", True)):
+        tot, bad, worst, npx = S.run(game, mode, center, 2, 40, 20, 31)
+        assert tot == 6 and bad == 0, f"{game} {mode} center_agent={center}: {bad} of {tot} frames differ ({npx} pixels, worst {worst})"
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 def _make(n, game, **kw):
     from helpers import HIP_LIB
