@@ -283,8 +283,6 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         fatal("invalid distribution_mode %d\n", dist_mode);
     }
     kernel_id = kernel_id_for(game_id, dist_mode);
-    if (this->render_human && o.use_generated_assets && !getenv("PROCGEN_AMD_GEN_RENDER_HUMAN"))
-        fatal("render_human together with use_generated_assets is opt-in (set PROCGEN_AMD_GEN_RENDER_HUMAN=1): the kernel equals the reference bit for bit in the CPU emulation (tests/test_render_human.py) but this combination has not run on a GPU yet\n");
     if (!game_supported(kernel_id)) fatal("game %s has no kernel for distribution_mode %d in the HIP stepper\n", env_name.c_str(), dist_mode);
     int plain_assets = 0, physics_mode = 0, game_type = 0;
     opts.consume_int("plain_assets", &plain_assets);
@@ -434,7 +432,13 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d_reset_count = dev_alloc<int>(2 * MAX_CHUNKS);
     d.assets = d_assets;
     d.pixels = d_pixels;
-    if (this->render_human) d.human = dev_alloc<uint8_t>(N * HUMAN_BYTES);
+    if (this->render_human) {
+        const size_t bytes = N * HUMAN_BYTES;
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        if (bytes + (1ull << 30) > free_b) fatal("render_human needs %zu MB of device memory for %d info frames of 512 x 512 x 3; %zu MB free\n", bytes >> 20, num_envs, free_b >> 20);
+        d.human = dev_alloc<uint8_t>(bytes);
+    }
     if (o.use_generated_assets) {
         // every env owns a 500 x 500 RGB32 background canvas, repainted by each episode's reset (reference BAG:58-63,769-773)
         const size_t bytes = N * (size_t)GEN_BG_WORDS * 4;
@@ -880,12 +884,13 @@ struct Handle {
 
 // The ROCm runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
 // queue run their kernels one after the other.  A joint handle has one stream per game: with 16 queues its 16-game step
-// takes 1.7 ms instead of 2.5.  The variable is read when the runtime initialises, so this only
-// helps when the library is loaded before the process's first HIP call; an explicit setting is left alone.
-// PROCGEN_AMD_KEEP_HW_QUEUES=1 leaves the variable alone (it changes the stream-to-queue mapping of every HIP user of the process).
+// takes 1.7 ms instead of 2.5.  The variable is read when the runtime initialises and changes the
+// stream-to-queue mapping of every HIP user of the process, so loading this library does NOT touch it by default: the Python
+// package (procgen_amd/__init__.py) and bench.py set it, a C / cffi host sets it itself or asks for it with
+// PROCGEN_AMD_SET_HW_QUEUES=1 (opt-in since round 4; libenv_make warns when a many-part handle finds fewer than 8 queues).
 __attribute__((constructor)) static void procgen_amd_default_hw_queues() {
-    const char *keep = getenv("PROCGEN_AMD_KEEP_HW_QUEUES");
-    if (!(keep && atoi(keep) != 0)) setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    const char *want = getenv("PROCGEN_AMD_SET_HW_QUEUES");
+    if (want && atoi(want) != 0) setenv("GPU_MAX_HW_QUEUES", "16", 0);
 }
 
 // relative length of one step of a ~1000-env part (profiles/r02_joint_kernel_trace.csv: the slowest kernel chain per game)
