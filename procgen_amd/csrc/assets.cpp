@@ -55,6 +55,7 @@ void generate_game_assets(const std::string &game_name, bool (*use_block_asset)(
     t.n_bg = 1;
     t.bg_img[0] = (int16_t)MAX_ASSETS;
     t.ref_w = t.ref_h = 64;
+    finish_asset_tables(t);
 }
 
 int game_id_from_name(const std::string &name) {
@@ -437,6 +438,7 @@ bool load_game_assets(int game_id, const std::string &resource_root, const std::
         }
         t.bg_img[i] = (int16_t)idx;
     }
+    finish_asset_tables(t);
     return true;
 }
 

@@ -17,4 +17,7 @@
 #include "game_plunder.h"
 #include "game_starpilot.h"
 
+// (tests/emu can be built for a subset while iterating: -D'PG_FOR_EACH_GAME(X)=X(CoinRun)')
+#ifndef PG_FOR_EACH_GAME
 #define PG_FOR_EACH_GAME(X) X(CoinRun) X(BigFish) X(Maze) X(Climber) X(Miner) X(StarPilot) X(FruitBot) X(Leaper) X(Plunder) X(Heist) X(Ninja) X(Dodgeball) X(BossFight) X(Chaser) X(CaveFlyer) X(Jumper) X(CaveFlyerMemory)
+#endif

@@ -38,9 +38,12 @@ __device__ inline void trace_wave(const DevCtx &d, int env, int base, bool end, 
 // Occupancy hint of the render kernel (RENDER_MIN_WAVES in a policy); the default leaves the register allocation alone.
 // Tried for coinrun (133 -> 128 VGPRs, a fourth wave per SIMD): +2..4 % steps/s, but the 104 B of spill per lane showed
 // up as +54 % WRITE_SIZE, so no policy sets it.
+#ifndef PG_RENDER_WAVES
+#define PG_RENDER_WAVES 1
+#endif
 template <class Game, class = void>
 struct GameRenderMinWaves {
-    static constexpr int value = 1;
+    static constexpr int value = PG_RENDER_WAVES;  // (-DPG_RENDER_WAVES=n: build-time experiment for every game without its own hint)
 };
 template <class Game>
 struct GameRenderMinWaves<Game, decltype((void)Game::RENDER_MIN_WAVES)> {

@@ -135,7 +135,24 @@ struct GameAssetsDev {
     int32_t n_bg;
     int16_t bg_img[MAX_BACKGROUNDS];
     int32_t ref_w, ref_h;  // most common sprite size of the game (renderer's separable tile geometry)
+    // the same tables with the indirection resolved on the host (finish_asset_tables): one dependent load instead of two when a
+    // kernel turns (type, theme) or a background index into an image.  off == IMG_NONE: no such image
+    ImgDesc type_theme_desc[MAX_ASSETS][MAX_IMAGE_THEMES];
+    ImgDesc bg_desc[MAX_BACKGROUNDS];
 };
+constexpr uint32_t IMG_NONE = 0xffffffffu;
+inline void finish_asset_tables(GameAssetsDev &t) {
+    for (int ty = 0; ty < MAX_ASSETS; ty++)
+        for (int th = 0; th < MAX_IMAGE_THEMES; th++) {
+            const int i = t.type_theme_img[ty][th];
+            ImgDesc none{IMG_NONE, 0, 0, 0};
+            t.type_theme_desc[ty][th] = i >= 0 ? t.img[i] : none;
+        }
+    for (int b = 0; b < MAX_BACKGROUNDS; b++) {
+        ImgDesc none{IMG_NONE, 0, 0, 0};
+        t.bg_desc[b] = b < t.n_bg ? t.img[t.bg_img[b]] : none;
+    }
+}
 
 // ---- everything a kernel launch needs ----
 struct DevCtx {

@@ -20,6 +20,16 @@
 
 namespace pgamd {
 
+// Lane sections of the renderer take their lane id through pg_lane_opaque() (wave.h): what they derive from it is recomputed where it
+// is used instead of being hoisted to the top of the kernel and held in registers for a whole frame.  Measured on coinrun (round 4,
+// same box): 134 -> 106 VGPRs, steps/s equal to the hoisting build under an occupancy hint -- the headroom keeps the kernel at four
+// waves per SIMD while its code changes (-DPG_RENDER_HOIST: the other form).
+#if !defined(PG_RENDER_HOIST)
+#define PG_R_LANES(l) PG_FOR_LANES_NOHOIST(l)
+#else
+#define PG_R_LANES(l) PG_FOR_LANES(l)
+#endif
+
 #ifndef PG_BAND_ROWS
 #define PG_BAND_ROWS 16
 #endif
@@ -243,9 +253,25 @@ struct Renderer {
         return (int)(o * 256);
     }
     // qt_scale_image_32bit.  tr.w / tr.h may be negative (a 180 degree rotation arrives as a negative scale).
-    PG_DEV void cmd_image(int img_index, bool mirrored, RectD tr, float opacity, uint32_t &geom, uint32_t &basex_o, uint32_t &srcy_o,
+    PG_DEV void cmd_image(const ImgDesc im, bool mirrored, RectD tr, float opacity, uint32_t &geom, uint32_t &basex_o, uint32_t &srcy_o,
                           uint32_t &ix_o, uint32_t &iy_o, uint32_t &src_o, uint32_t &aux_o) const {
-        cmd_image_fast(d.assets->img[img_index], mirrored, tr, opacity, geom, basex_o, srcy_o, ix_o, iy_o, src_o, aux_o);
+        cmd_image_fast(im, mirrored, tr, opacity, geom, basex_o, srcy_o, ix_o, iy_o, src_o, aux_o);
+    }
+    // (type, theme) -> image descriptor with ONE load: the host resolved the type -> theme -> image indirection into
+    // GameAssetsDev::type_theme_desc.  Branch-free (out-of-range arguments read entry 0 and report IMG_NONE), so that a set-up
+    // section can request the descriptors of all its drawables before it needs the first one.
+    PG_DEV ImgDesc desc_for(int img_type, int theme) const {
+        int mt = theme;
+        if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;  // BAG:450-453
+        const bool ok = img_type >= 0 && img_type < MAX_ASSETS && mt >= 0 && mt < MAX_IMAGE_THEMES;
+        ImgDesc r = d.assets->type_theme_desc[ok ? img_type : 0][ok ? mt : 0];
+        if (!ok) r.off = IMG_NONE;
+        return r;
+    }
+    // the descriptor resolve_image() will want for a drawable of this base type and theme
+    PG_DEV ImgDesc request_desc(int base_type, int theme) {
+        const int img_type = Game::image_for_type(*this, base_type);
+        return desc_for((img_type >= 0 && img_type < USE_ASSET_THRESHOLD) ? img_type : -1, theme);
     }
     PG_DEV void cmd_image_desc(const ImgDesc im, bool mirrored, RectD tr, float opacity, uint32_t &geom, uint32_t &basex_o, uint32_t &srcy_o,
                                uint32_t &ix_o, uint32_t &iy_o, uint32_t &src_o, uint32_t &aux_o) const {
@@ -446,7 +472,7 @@ struct Renderer {
     // QTransform::rotate special-cases 90 / 180 / 270 degrees; QTransform::type() then routes the draw to the
     // scale path (sine fuzzy-null: a 180 degree turn is a negative scale) or to qt_transform_image, whose set-up
     // (inverse 16.16 mapping, three trapezoids with 16.16 edge walkers) is written to the lane's LDS record.
-    PG_DEV void cmd_image_rotated(int lane, int img_index, bool mirrored, RectD adjusted, float rotation, float opacity, uint32_t &geom,
+    PG_DEV void cmd_image_rotated(int lane, const ImgDesc imdesc, bool mirrored, RectD adjusted, float rotation, float opacity, uint32_t &geom,
                                   uint32_t &basex_o, uint32_t &srcy_o, uint32_t &ix_o, uint32_t &iy_o, uint32_t &src_o, uint32_t &aux_o) {
         geom = 0;
         basex_o = srcy_o = ix_o = iy_o = src_o = aux_o = 0;
@@ -483,14 +509,14 @@ struct Renderer {
                 y2 = r.y + r.h;
             }
             const RectD tr = {x1, y1, x2 - x1, y2 - y1};
-            cmd_image(img_index, mirrored, tr, opacity, geom, basex_o, srcy_o, ix_o, iy_o, src_o, aux_o);
+            cmd_image(imdesc, mirrored, tr, opacity, geom, basex_o, srcy_o, ix_o, iy_o, src_o, aux_o);
             return;
         }
         if constexpr (!GameUsesRotation<Game>::value) {
             fail(PGE_UNSUPPORTED_DRAW);
             return;
         } else {
-            const ImgDesc im = d.assets->img[img_index];
+            const ImgDesc im = imdesc;
             double vx[4], vy[4], vu[4], vv[4];
             {
                 const double L = r.x, T = r.y, R = r.x + r.w, B = r.y + r.h;
@@ -609,7 +635,9 @@ struct Renderer {
     // returns the image index, -1 (nothing to draw) or IMG_FILL: draw_grid_obj paints the drawable's base rect with
     // color_for_type (BAG:455-481,915-919; use_monochrome_assets) -- the colour is returned in *fill_color
     static constexpr int IMG_FILL = -2;
-    PG_DEV int resolve_image(int base_type, int theme, float rotation, float tile_ratio, RectD &rect, uint32_t *fill_color = nullptr) {
+    // pre: the descriptor request_desc(base_type, theme) returned earlier (a set-up section requests all its descriptors before
+    // it needs the first), or null: looked up here.  >= 0: *desc is the image.
+    PG_DEV int resolve_image(int base_type, int theme, float rotation, float tile_ratio, RectD &rect, uint32_t *fill_color, ImgDesc *desc, const ImgDesc *pre = nullptr) {
         const int img_type = Game::image_for_type(*this, base_type);
         if (img_type < 0) return -1;
         if (d.opt.use_monochrome_assets || img_type >= USE_ASSET_THRESHOLD) {
@@ -628,10 +656,8 @@ struct Renderer {
             return IMG_FILL;
         }
         rect = Game::adjusted_image_rect(img_type, rect);
-        int mt = theme;
-        if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;  // BAG:450-453
-        const int img = (mt >= 0 && mt < MAX_IMAGE_THEMES) ? (int)d.assets->type_theme_img[img_type][mt] : -1;
-        if (img < 0) {
+        const ImgDesc im = pre ? *pre : desc_for(img_type, theme);
+        if (im.off == IMG_NONE) {
             fail(PGE_THEME);
             return -1;
         }
@@ -640,7 +666,8 @@ struct Renderer {
             fail(PGE_UNSUPPORTED_DRAW);
             return -1;
         }
-        return img;
+        *desc = im;
+        return 0;
     }
 
     // ---- separable geometry of grid cells -------------------------------------------------------------------
@@ -675,7 +702,7 @@ struct Renderer {
             ixu = (int)(65536 / (r0.w / (double)ref_w));
             iyu = (int)(65536 / (r0.h / (double)ref_h));
         }
-        PG_FOR_LANES(l) {
+        PG_R_LANES(l) {
             uint32_t packed = 0, base = 0;
             int step = 0;
             if (l < 32) {
@@ -705,10 +732,15 @@ struct Renderer {
     // Grid object type -> image, once per frame: the asset tables live in HBM and resolving a cell costs two dependent
     // loads; a frame shows a few hundred cells of a handful of types.  Lane t resolves type t without raising errors
     // (types a level does not use may have no asset); anything unusual is left to the per-cell path (TYPE_SLOW).
-    PG_DEV void build_type_table() {
+    // lane l's request for build_type_table (issued ahead, render_env)
+    PG_DEV ImgDesc request_type_desc(int type) {
+        if constexpr (GameDrawsGrid<Game>::value) return request_desc(type, Game::theme_for_grid_obj(*this, type));
+        else return ImgDesc{IMG_NONE, 0, 0, 0};
+    }
+    PG_DEV void build_type_table(PG_LANE_REF(const ImgDesc, pre_td)) {
         if constexpr (GameDrawsGrid<Game>::value) {
             const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 uint32_t v = TYPE_SLOW, any = TYPE_SLOW, sz = 0;
                 const int type = l;
                 bool is_fill = false;
@@ -718,11 +750,8 @@ struct Renderer {
                     if (img_type < 0 || img_type == SPACE) {
                         v = any = CELL_NONE;
                     } else if (img_type < USE_ASSET_THRESHOLD) {
-                        int mt = Game::theme_for_grid_obj(*this, type);
-                        if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;
-                        const int img = (mt >= 0 && mt < MAX_IMAGE_THEMES) ? (int)d.assets->type_theme_img[img_type][mt] : -1;
-                        if (img >= 0) {
-                            const ImgDesc imd = d.assets->img[img];
+                        const ImgDesc imd = PG_LV(pre_td, l);  // = desc_for(img_type, Game::theme_for_grid_obj(*this, type))
+                        if (imd.off != IMG_NONE) {
                             const RectD probe = {1.0, 2.0, 3.0, 5.0};
                             const RectD adj = Game::adjusted_image_rect(img_type, probe);
                             const bool same_rect = adj.x == probe.x && adj.y == probe.y && adj.w == probe.w && adj.h == probe.h;
@@ -748,13 +777,26 @@ struct Renderer {
     // pixel depends on the rect alone; whether that cell has a sample there is per class (Qt drops a last sample
     // that would fall outside the source).  Returns false when the frame needs the per-cell path: solid-colour
     // cells, adjusted rects, more than four sizes, three cells over one pixel.
-    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, uint64_t &colseam, uint64_t &rowseam, uint64_t &rowany, bool &multi, int &nfill_out) {
+    // the grid objects of window cells [q * 64 + l], q < 4 (x-major, as build_pull_tables walks them): its first round of reads, issued ahead
+    PG_DEV void request_window_cells(int win_lx, int nx, int win_ly, int ny_full, PG_LANE_ARR_REF(int, cells0, 4)) const {
+        const int ncell = nx * ny_full;
+        const uint32_t ny_inv = (uint32_t)(((1u << 20) + (uint32_t)ny_full - 1u) / (uint32_t)ny_full);
+        PG_R_LANES(l) {
+            for (int q = 0; q < 4; q++) {
+                const int cidx = q * 64 + l;
+                const int cc = cidx < ncell ? cidx : 0;
+                const int cx = (int)(((uint32_t)cc * ny_inv) >> 20);
+                PG_LA(cells0, q, l) = get_obj(win_lx + cx, win_ly + (cc - cx * ny_full));
+            }
+        }
+    }
+    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, uint64_t &colseam, uint64_t &rowseam, uint64_t &rowany, bool &multi, int &nfill_out, PG_LANE_ARR_REF(const int, cells0, 4)) {
         nfill_out = 0;
         rowany = ~0ull;
         const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
         uint32_t *present = fb;  // scratch: the band buffer is idle during set-up
         uint32_t *span = fb + 64;
-        PG_FOR_LANES(l) {
+        PG_R_LANES(l) {
             present[l] = 0;
             lds->ci[0][l] = lds->ci[1][l] = lds->ri[0][l] = lds->ri[1][l] = 0;
             for (int k = 0; k < 3; k++)
@@ -770,12 +812,12 @@ struct Renderer {
         bool ok = true;
         for (int base4 = 0; base4 < ncell; base4 += 256) {
             PG_LANE_ARR(int, types, 4);
-            PG_FOR_LANES(l) {  // the grid reads of four chunks in flight together
+            PG_R_LANES(l) {  // the grid reads of four chunks in flight together (the first round was requested ahead)
                 for (int q = 0; q < 4; q++) {
                     const int cidx = base4 + q * 64 + l;
                     const int cc = cidx < ncell ? cidx : 0;
                     const int cx = (int)(((uint32_t)cc * ny_inv) >> 20);
-                    PG_LA(types, q, l) = get_obj(win_lx + cx, win_ly + (cc - cx * ny_full));
+                    PG_LA(types, q, l) = base4 == 0 ? PG_LA(cells0, q, l) : get_obj(win_lx + cx, win_ly + (cc - cx * ny_full));
                 }
             }
             for (int q = 0; q < 4 && base4 + q * 64 < ncell; q++) {
@@ -812,7 +854,7 @@ struct Renderer {
         PG_LANE_VAR(uint32_t, key);
         PG_LANE_VAR(uint32_t, cls);
         const uint32_t key0 = ((uint32_t)ref_w << 16) | (uint32_t)ref_h;
-        PG_FOR_LANES(l) {
+        PG_R_LANES(l) {
             PG_LV(key, l) = present[l] ? lds->typesz[l] : key0;
             PG_LV(cls, l) = 0;
         }
@@ -824,14 +866,14 @@ struct Renderer {
             const uint32_t kk = PG_READLANE(key, leader);
             if (ncls >= 4 || (kk >> 16) > 255u || (kk & 0xffffu) > 255u) return false;
             const uint64_t same = PG_BALLOT(l, PG_LV(key, l) == kk);
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 if ((same >> l) & 1ull) PG_LV(cls, l) = (uint32_t)ncls;
             }
             ckey[ncls++] = kk;
             todo &= ~same;
         }
         multi = ncls > 1;
-        PG_FOR_LANES(l) {
+        PG_R_LANES(l) {
             const uint32_t tv = lds->typeany[l];
             if (tv != CELL_NONE && tv != TYPE_SLOW) lds->typeany[l] = tv | (PG_LV(cls, l) << 27);
         }
@@ -839,7 +881,7 @@ struct Renderer {
         uint32_t cellrows = 0;  // bit r: cell row r of the window holds a cell with an image
         for (int base = 0; base < ncell; base += 64) {
             PG_LANE_VAR(uint32_t, has);
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 PG_LV(has, l) = 0;
                 if (base + l < ncell) {
                     const uint32_t t = lds->cellimg[base + l];
@@ -862,7 +904,7 @@ struct Renderer {
             }
         }
         // pixel spans of the cell columns (lanes 0..31) and rows (lanes 32..63): the rect alone decides them
-        PG_FOR_LANES(l) {
+        PG_R_LANES(l) {
             const bool col = l < 32;
             const int idx = col ? l : l - 32;
             uint32_t sp = 0;
@@ -919,7 +961,7 @@ struct Renderer {
                 const uint64_t vis = PG_BALLOT(l, PG_LV(fg, l) != 0);
                 const int cnt = pg_popc64(vis);
                 if (nfill + cnt > fill_cap) return false;
-                PG_FOR_LANES(l) {
+                PG_R_LANES(l) {
                     if ((vis >> l) & 1ull) {
                         const int slot = nfill + pg_popc64(vis & pg_mask_lt(l));
                         lds->cellimg[ncell + 2 * slot] = PG_LV(fg, l);
@@ -931,10 +973,10 @@ struct Renderer {
             nfill_out = nfill;
         }
         PG_LANE_VAR(uint32_t, over);
-        PG_FOR_LANES(l) { PG_LV(over, l) = 0; }
+        PG_R_LANES(l) { PG_LV(over, l) = 0; }
         for (int k = 0; k < ncls; k++) {
             const int cw = (int)(ckey[k] >> 16), ch = (int)(ckey[k] & 0xffffu);
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 const bool col = l < 32;
                 const int idx = col ? l : l - 32;
                 const uint32_t sp = span[l];
@@ -983,7 +1025,7 @@ struct Renderer {
                                    ((e0 >> 31) != 0 && ((cr >> ((e0 >> 12) & 0x1fu)) & 1u) != 0) || ((e1 >> 31) != 0 && ((cr >> ((e1 >> 12) & 0x1fu)) & 1u) != 0);
                                }));
         }
-        PG_FOR_LANES(l) {
+        PG_R_LANES(l) {
             if ((colseam >> l) & 1ull) lds->seamcols[pg_popc64(colseam & pg_mask_lt(l))] = (uint32_t)l;
         }
         PG_SYNC();
@@ -1022,7 +1064,7 @@ struct Renderer {
         // stage 1: (c0, r0), lane = screen column, a band of fetches in flight
         for (int yb = row0; yb < row1; yb += WIDE_ROWS) {
             if (((band_any >> (yb - row0)) & ((1u << WIDE_ROWS) - 1u)) == 0) continue;
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 const uint32_t ce = lds->ci[0][l];
                 uint32_t tex[WIDE_ROWS];
                 bool hit[WIDE_ROWS], opq[WIDE_ROWS];
@@ -1052,7 +1094,7 @@ struct Renderer {
                     cnt = q + 1;
                 }
             }
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 const uint32_t ce = lds->ci[0][l];
                 uint32_t tex[4];
                 bool hit[4], opq[4];
@@ -1079,7 +1121,7 @@ struct Renderer {
             const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)nseam - 1u) / (uint32_t)nseam);
             const int npx = nseam * BAND_ROWS;
             for (int base = 0; base < npx; base += 256) {
-                PG_FOR_LANES(l) {
+                PG_R_LANES(l) {
                     uint32_t tex[4];
                     int fbi[4];
                     bool opq[4];
@@ -1111,7 +1153,7 @@ struct Renderer {
                     cnt = q + 1;
                 }
             }
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 const bool in = l < nseam;
                 const int x = (int)lds->seamcols[in ? l : 0];
                 const uint32_t ce = lds->ci[1][x];
@@ -1179,7 +1221,7 @@ struct Renderer {
         if (c.w > 32) {
             for (int yb = y0; yb < y1; yb += WIDE_ROWS) {  // a whole band of texel fetches in flight
                 const int last = y1 - 1;  // rows past the end re-sample the last row into the dump row (no per-row branches)
-                PG_FOR_LANES(l) {
+                PG_R_LANES(l) {
                     const bool in = l < c.w;
                     const int lc = in ? l : 0;
                     uint32_t tex[WIDE_ROWS];
@@ -1200,7 +1242,7 @@ struct Renderer {
             const int npix = c.w * (y1 - y0);
             const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)c.w - 1u) / (uint32_t)c.w);  // p / w == (p * inv) >> 20 for p < 4096
             for (int base = 0; base < npix; base += 512) {
-                PG_FOR_LANES(l) {
+                PG_R_LANES(l) {
                     uint32_t tex[8];
                     int fbi[8];
                     _Pragma("unroll") for (int j = 0; j < 8; j++) {
@@ -1237,7 +1279,7 @@ struct Renderer {
         if (y2 > row1) y2 = row1;
         if (x1 >= x2 || y1 >= y2) return;
         for (int y = y1; y < y2; y++) {
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 if (l >= x1 && l < x2) fb[(y - row0) * RES_W + l] = color;
             }
         }
@@ -1246,7 +1288,7 @@ struct Renderer {
     // one horizontal span blended onto the band (spans of the ellipse / line primitives; px premultiplied ARGB)
     PG_DEV void exec_span(int sx, int sy, int len, uint32_t px) {
         if (sy < row0 || sy >= row1 || len <= 0) return;
-        PG_FOR_LANES(l) {
+        PG_R_LANES(l) {
             if (l >= sx && l < sx + len) {
                 uint32_t *dp = &fb[(sy - row0) * RES_W + l];
                 *dp = px + byte_mul(*dp, 255u - (px >> 24));
@@ -1258,7 +1300,7 @@ struct Renderer {
     // pixels, then pen pixels over them, both opaque (the jumper compass on a non-integer rect, game_jumper.h host_tables)
     PG_DEV void exec_row_masks(const uint32_t *rows, int y_first, int y_end, uint32_t brush_px, uint32_t pen_px) {
         for (int y = y_first > row0 ? y_first : row0; y < (y_end < row1 ? y_end : row1); y++) {
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 const uint32_t *w = rows + y * 4;
                 const uint32_t b = l < 32 ? w[0] >> l : w[1] >> (l - 32), p = l < 32 ? w[2] >> l : w[3] >> (l - 32);
                 if ((b | p) & 1u) fb[(y - row0) * RES_W + l] = (p & 1u) ? pen_px : brush_px;
@@ -1388,7 +1430,7 @@ struct Renderer {
         const bool mirrored = cmd_mirrored(c.aux);
         const int io = cmd_alpha(c.aux);
         const uint32_t ca = (uint32_t)((io * 255) >> 8);
-        PG_FOR_LANES(l) {
+        PG_R_LANES(l) {
             uint32_t tex[NJ];
             int fbi[NJ];
             _Pragma("unroll") for (int j = 0; j < NJ; j++) {
@@ -1435,9 +1477,9 @@ struct Renderer {
         } else {
             r1 = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
         }
-        const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, 0.0f, r1, nullptr);
+        ImgDesc imd;
+        const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, 0.0f, r1, nullptr, &imd);
         if (im < 0) return;
-        const ImgDesc imd = d.assets->img[im];
         const bool mirrored = (mm & MF_REFLECTED) != 0;
         const int io = opacity_to_io(ef(EF_ALPHA, i));
         const uint32_t ca = (uint32_t)((io * 255) >> 8);
@@ -1515,7 +1557,7 @@ struct Renderer {
         const int npix = c.w * (y1 - y0);
         const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)c.w - 1u) / (uint32_t)c.w);
         for (int base = 0; base < npix; base += 64) {
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 const int p = base + l;
                 if (p < npix) {
                     const int pyb = (int)(((uint32_t)p * inv) >> 20);
@@ -1595,7 +1637,7 @@ struct Renderer {
     PG_DEV void exec_small_group(const DrawCmd (&c)[8], int count) {
         PG_LANE_ARR(uint32_t, tex, 8);
         PG_LANE_ARR(int, fbi, 8);
-        PG_FOR_LANES(l) {
+        PG_R_LANES(l) {
             const int lx = l & 7, ly = l >> 3;
             _Pragma("unroll") for (int g = 0; g < 8; g++) {
                 PG_LA(fbi, g, l) = BAND_ROWS * RES_W + l;  // dump row
@@ -1617,7 +1659,7 @@ struct Renderer {
                 const int io = cmd_alpha(c[g].aux);
                 const uint32_t ca = (uint32_t)((io * 255) >> 8);
                 const bool opaque = cmd_opaque(c[g].aux);
-                PG_FOR_LANES(l) {
+                PG_R_LANES(l) {
                     const int fi = PG_LA(fbi, g, l);
                     fb[fi] = opaque ? PG_LA(tex, g, l) : blend(PG_LA(tex, g, l), fb[fi], io, ca);
                 }
@@ -1719,7 +1761,7 @@ struct Renderer {
         const float tile_height = vertical ? (float)(rect.h / num_tiles) : (float)rect.h;
         for (int base = 0; base < num_tiles; base += 64) {
             CmdRegs r;
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 clear_cmd(r, l);
                 const int t = base + l;
                 if (t < num_tiles) {
@@ -1740,27 +1782,60 @@ struct Renderer {
         }
     }
 
+    // What the set-up of the first 64 entity slots reads from memory, requested before the values are needed: the fields go out
+    // together with the header (their addresses depend on the env alone), the image descriptors together with the frame's other
+    // table lookups (render_env).  A dependent global access costs this kernel ~1.3 k wave cycles, whatever cache serves it.
+    struct EntPre {
+        PG_LANE_VAR(uint32_t, meta);
+        PG_LANE_VAR(uint32_t, x);
+        PG_LANE_VAR(uint32_t, y);
+        PG_LANE_VAR(uint32_t, rx);
+        PG_LANE_VAR(uint32_t, ry);
+        PG_LANE_VAR(uint32_t, rot);
+        PG_LANE_VAR(uint32_t, alpha);
+        PG_LANE_VAR(ImgDesc, desc);
+    };
+    PG_DEV void request_entity_fields(EntPre &p) const {
+        PG_R_LANES(l) {
+            const uint32_t sl = (uint32_t)(l < ecap ? l : 0);
+            PG_LV(p.meta, l) = ge[(uint32_t)(EF_META * ecap) + sl];
+            PG_LV(p.x, l) = ge[(uint32_t)(EF_X * ecap) + sl];
+            PG_LV(p.y, l) = ge[(uint32_t)(EF_Y * ecap) + sl];
+            PG_LV(p.rx, l) = ge[(uint32_t)(EF_RX * ecap) + sl];
+            PG_LV(p.ry, l) = ge[(uint32_t)(EF_RY * ecap) + sl];
+            PG_LV(p.rot, l) = ge[(uint32_t)(EF_ROTATION * ecap) + sl];
+            PG_LV(p.alpha, l) = ge[(uint32_t)(EF_ALPHA * ecap) + sl];
+        }
+    }
     // draw_entities BAG:1052-1066.  Commands of 64 entities are set up once (they do not depend on the layer) and
     // then executed per render_z layer through a lane mask.
     // rot_base >= 0: the chunk's turned entities take consecutive rotation records from rot_base on (compact_entities);
     // otherwise lane l uses record l.  Returns the number of records handed out.
     PG_DEV int setup_entities(int base, CmdRegs &r, uint64_t (&zmask)[3], int rot_base = -1) {
+        EntPre none;
+        return setup_entities_t<false>(base, r, zmask, rot_base, none);
+    }
+    // PRE: base == 0 and the slots' fields / image descriptors were requested ahead (EntPre)
+    template <bool PRE>
+    PG_DEV int setup_entities_t(int base, CmdRegs &r, uint64_t (&zmask)[3], int rot_base, const EntPre &pre) {
         const int n = G.n_ents;
-        for (int z = 0; z < 3; z++) zmask[z] = PG_BALLOT(l, (base + l) < n && meta_render_z(meta(base + l)) == z - 1);
+        for (int z = 0; z < 3; z++) zmask[z] = PG_BALLOT(l, (base + l) < n && meta_render_z(PRE ? PG_LV(pre.meta, l) : meta(base + l)) == z - 1);
         uint64_t rotmask = 0;  // entities that need an LDS record: turned sprites and tiled ones
         if constexpr (GameUsesRotation<Game>::value) {
             if (rot_base >= 0) {
-                rotmask = PG_BALLOT(l, (base + l) < n && (ef(EF_ROTATION, base + l) != 0 || (GameUsesTiledEntities<Game>::value && Game::tile_aspect_ratio(*this, base + l) != 0)));
+                rotmask = PG_BALLOT(l, (base + l) < n && ((PRE ? __builtin_bit_cast(float, PG_LV(pre.rot, l)) : ef(EF_ROTATION, base + l)) != 0 || (GameUsesTiledEntities<Game>::value && Game::tile_aspect_ratio(*this, base + l) != 0)));
                 if (rot_base + pg_popc64(rotmask) > 64) return -1;
             }
         }
-        PG_FOR_LANES(l) {
+        PG_R_LANES(l) {
             const int i = base + l;
             const int rot_slot = rot_base >= 0 ? rot_base + pg_popc64(rotmask & pg_mask_lt(l)) : l;
             clear_cmd(r, l);
             if (i < n && Game::should_draw_entity(*this, i)) {
-                const uint32_t mm = meta(i);
-                const float x = ex(i), y = ey(i), rx = erx(i), ry = ery(i);
+                const uint32_t mm = PRE ? PG_LV(pre.meta, l) : meta(i);
+                const float x = PRE ? __builtin_bit_cast(float, PG_LV(pre.x, l)) : ex(i), y = PRE ? __builtin_bit_cast(float, PG_LV(pre.y, l)) : ey(i);
+                const float rx = PRE ? __builtin_bit_cast(float, PG_LV(pre.rx, l)) : erx(i), ry = PRE ? __builtin_bit_cast(float, PG_LV(pre.ry, l)) : ery(i);
+                const float e_alpha = PRE ? __builtin_bit_cast(float, PG_LV(pre.alpha, l)) : e_alpha;
                 RectD r1;  // get_object_rect BAG:811-817
                 if (mm & MF_ABS_COORDS) {
                     const float vd = G.view_dim;
@@ -1773,8 +1848,9 @@ struct Renderer {
                 }
                 const RectD r1_in = r1;
                 uint32_t fc = 0;
-                const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, 0.0f, r1, &fc);
-                const float rotation = ef(EF_ROTATION, i);
+                ImgDesc imd;
+                const int im = resolve_image(meta_image_type(mm), meta_image_theme(mm), 0.0f, 0.0f, r1, &fc, &imd, PRE ? &PG_LV(pre.desc, l) : nullptr);
+                const float rotation = PRE ? __builtin_bit_cast(float, PG_LV(pre.rot, l)) : ef(EF_ROTATION, i);
                 const float tile_ratio = Game::tile_aspect_ratio(*this, i);
                 if (im == IMG_FILL) cmd_fill_rect(r1_in, fc, PG_LV(r.geom, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                 if (im >= 0) {
@@ -1800,16 +1876,15 @@ struct Renderer {
                                     rp[2 * k] = (uint32_t)bits;
                                     rp[2 * k + 1] = (uint32_t)(bits >> 32);
                                 }
-                                const ImgDesc imd = d.assets->img[im];
                                 rp[8] = imd.off;
                                 rp[9] = (uint32_t)imd.w | ((uint32_t)imd.h << 16);
                                 rp[10] = imd.opaque;
-                                rp[11] = __builtin_bit_cast(uint32_t, ef(EF_ALPHA, i));
+                                rp[11] = __builtin_bit_cast(uint32_t, e_alpha);
                                 rp[12] = __builtin_bit_cast(uint32_t, tile_ratio);
                                 rp[13] = (mm & MF_REFLECTED) ? 1u : 0u;
                             }
                         }
-                    } else if (rotation == 0) emit_image(r, l, d.assets->img[im], (mm & MF_REFLECTED) != 0, r1, ef(EF_ALPHA, i));
+                    } else if (rotation == 0) emit_image(r, l, imd, (mm & MF_REFLECTED) != 0, r1, e_alpha);
                     else if constexpr (GEN) {
                         // a turned generated sprite: coverage and sampling come from the painter matrix (exec_generic_rotated works
                         // them out again from the entity); here only a bounding box for the band test: the rect's circumcircle
@@ -1824,7 +1899,7 @@ struct Renderer {
                             PG_LV(r.basex, l) = (uint32_t)i;
                             PG_LV(r.aux, l) = 1u << 15;
                         }
-                    } else cmd_image_rotated(rot_slot, im, (mm & MF_REFLECTED) != 0, r1, rotation, ef(EF_ALPHA, i), PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
+                    } else cmd_image_rotated(rot_slot, imd, (mm & MF_REFLECTED) != 0, r1, rotation, e_alpha, PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                 }
             }
         }
@@ -1853,7 +1928,7 @@ struct Renderer {
             const uint64_t vis = PG_BALLOT(l, PG_LV(r.geom, l) != 0);
             const int cnt = pg_popc64(vis);
             if (total + cnt > SLOTS) return false;
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 if ((vis >> l) & 1ull) {
                     const int slot = total + pg_popc64(vis & pg_mask_lt(l));
                     stage[0 * SLOTS + slot] = PG_LV(r.geom, l);
@@ -1874,7 +1949,7 @@ struct Renderer {
         }
         PG_SYNC();
         _Pragma("unroll") for (int k = 0; k < CMD_SETS; k++) {
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 const int idx = k * 64 + l;
                 const bool in = idx < total;
                 const int si = in ? idx : 0;
@@ -1925,6 +2000,9 @@ struct Renderer {
 #if !defined(PGAMD_WAVE_EMU)
         if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
 #endif
+        // ---- requests, round 1: what depends on the env index alone -- the header and the fields of the first 64 entity slots
+        EntPre epre;
+        request_entity_fields(epre);
         {
             const EnvHdr *h = d.hdr + env;
 #define PG_X(type, name) G.name = h->name;
@@ -1935,16 +2013,50 @@ struct Renderer {
         // ---- frame-level set-up (rows [0, 64)) ------------------------------------------------------------------
         row0 = 0;
         row1 = RES_H;
+        if (d.debug_flags & 4) G.n_ents = 0;
+        const bool force_chunks = (d.debug_flags & 4096) != 0;  // test aid: every frame through draw_entities()
+        bool one_chunk = G.n_ents <= 64 && !force_chunks;  // or: the visible ones fit the register sets
+        int win_lx, win_hx, win_ly, win_hy;  // BAG:926-939
+        if (Game::center_agent(d.opt)) {
+            const float margin = (float)(G.visibility / 2.0 + 1);
+            win_lx = (int)(G.center_x - margin);
+            win_hx = (int)(G.center_x + margin);
+            win_ly = (int)(G.center_y - margin);
+            win_hy = (int)(G.center_y + margin);
+        } else {
+            win_lx = 0;
+            win_hx = G.main_width - 1;
+            win_ly = 0;
+            win_hy = G.main_height - 1;
+        }
+        const int nx = win_hx - win_lx + 1;
+        const int ny_full = win_hy - win_ly + 1;
+        const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
+        // (GEN: every cell is its own generic drawImage, set up lane-parallel per band: neither axis tables nor the pull form)
+        const bool use_axes = !GEN && GameDrawsGrid<Game>::value && nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
+        const bool try_pull = GameDrawsGrid<Game>::value && !GEN && use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024);
+        // ---- requests, round 2: every table lookup of the set-up, in flight together: the background image, the images of the
+        // entities (lane = slot) and of the grid object types (lane = type), the first 256 window cells
+        const ImgDesc bg_desc = (d.opt.use_backgrounds && !(d.debug_flags & 1)) ? d.assets->bg_desc[G.background_index] : ImgDesc{IMG_NONE, 0, 0, 0};
+        PG_LANE_VAR(ImgDesc, type_desc);
+        PG_LANE_ARR(int, cells0, 4);
+        PG_R_LANES(l) {
+            PG_LV(epre.desc, l) = request_desc(meta_image_type(PG_LV(epre.meta, l)), meta_image_theme(PG_LV(epre.meta, l)));
+            PG_LV(type_desc, l) = request_type_desc(l);
+            for (int q = 0; q < 4; q++) PG_LA(cells0, q, l) = 0;
+        }
+        if (try_pull) request_window_cells(win_lx, nx, win_ly, ny_full, cells0);
         // wave-uniform background commands (one scaled image, or the visible tiles of a game's own background)
-        constexpr int MAXBG = 3;
-        uint32_t bg_geom[MAXBG] = {0, 0, 0}, bg_basex[MAXBG] = {0, 0, 0}, bg_srcy[MAXBG] = {0, 0, 0}, bg_ix[MAXBG] = {0, 0, 0}, bg_iy[MAXBG] = {0, 0, 0}, bg_src[MAXBG] = {0, 0, 0},
-                 bg_aux[MAXBG] = {0, 0, 0};
+        // (one command unless the game tiles its background or draws its own: the slots are scalar registers held across the whole frame)
+        constexpr int MAXBG = (GameTiledBackground<Game>::value || GameCustomBackground<Game>::value) ? 3 : 1;
+        uint32_t bg_geom[MAXBG] = {0}, bg_basex[MAXBG] = {0}, bg_srcy[MAXBG] = {0}, bg_ix[MAXBG] = {0}, bg_iy[MAXBG] = {0}, bg_src[MAXBG] = {0}, bg_aux[MAXBG] = {0};
         int nbg = 0;
         bool bgt_many = false;  // tiled background with more tiles on screen than the register slots above
         double bgt_x = 0, bgt_y = 0, bgt_w = 0;
         float bgt_h = 0;
-        int bgt_ia = 0, bgt_ib = 0, bgt_img = 0;
-        auto add_bg = [&](int bgi, const RectD &rc) {
+        int bgt_ia = 0, bgt_ib = 0;
+        ImgDesc bgt_img = {0, 0, 0, 0};
+        auto add_bg = [&](const ImgDesc &bgi, const RectD &rc) {
             uint32_t g, bx, sy, ix, iy, sr, au;
             cmd_image(bgi, false, rc, 1.0f, g, bx, sy, ix, iy, sr, au);  // RGB32 source: the scale path also with generated assets
             if (GEN) au |= 1u << 27;
@@ -1961,14 +2073,15 @@ struct Renderer {
             if (d.opt.use_backgrounds && !(d.debug_flags & 1)) {
                 RectD rects[4];
                 const int nr = Game::background_rects(*this, rects);
-                const int bgi = (int)d.assets->bg_img[G.background_index];
+                const ImgDesc bgi = bg_desc;
                 _Pragma("unroll") for (int k = 0; k < 4; k++)
                     if (k < nr && rects[k].w > 0) add_bg(bgi, rects[k]);
             }
         } else if (d.opt.use_backgrounds && !(d.debug_flags & 1)) {
             const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);
-            const int bgi = (int)d.assets->bg_img[G.background_index];
-            if (G.bg_tile_ratio < 0) {  // tile_image(main_rect, bg_tile_ratio) BAG:842-853: a column of tiles; only the ones on screen
+            const ImgDesc bgi = bg_desc;
+            if (!GameTiledBackground<Game>::value && G.bg_tile_ratio < 0) fail(PGE_UNSUPPORTED_DRAW);  // (only fruitbot's constructor sets it)
+            if (GameTiledBackground<Game>::value && G.bg_tile_ratio < 0) {  // tile_image(main_rect, bg_tile_ratio) BAG:842-853: a column of tiles; only the ones on screen
                 const float tile_ratio = -1 * G.bg_tile_ratio;
                 int num_tiles = (int)(main_rect.h / (main_rect.w * (double)tile_ratio));
                 if (num_tiles < 1) num_tiles = 1;
@@ -1997,7 +2110,7 @@ struct Renderer {
                     add_bg(bgi, tr);
                 }
             } else {
-            const ImgDesc bim = d.assets->img[bgi];
+            const ImgDesc bim = bgi;
             const float bgw = (float)bim.w, bgh = (float)bim.h;
             const float bg_ar = bgw / bgh;
             const float world_ar = (float)(G.main_width * 1.0 / G.main_height);
@@ -2008,56 +2121,35 @@ struct Renderer {
             }
         }
         phase(7);
-        // common case (<= 64 entities): their commands are built once and kept in registers for all passes
-        if (d.debug_flags & 4) G.n_ents = 0;
-        const bool force_chunks = (d.debug_flags & 4096) != 0;  // test aid: every frame through draw_entities()
-        bool one_chunk = G.n_ents <= 64 && !force_chunks;  // or: the visible ones fit the register sets
-        CmdRegs er[CMD_SETS];
-        uint64_t ezmask[CMD_SETS][3];
-        _Pragma("unroll") for (int k = 0; k < CMD_SETS; k++) {
-            ezmask[k][0] = ezmask[k][1] = ezmask[k][2] = 0;
-            PG_FOR_LANES(l) { clear_cmd(er[k], l); }
-        }
-        if (one_chunk) setup_entities(0, er[0], ezmask[0]);
-        else if (!force_chunks) one_chunk = compact_entities(er, ezmask);
-        phase(8);
-        int win_lx, win_hx, win_ly, win_hy;  // BAG:926-939
-        if (Game::center_agent(d.opt)) {
-            const float margin = (float)(G.visibility / 2.0 + 1);
-            win_lx = (int)(G.center_x - margin);
-            win_hx = (int)(G.center_x + margin);
-            win_ly = (int)(G.center_y - margin);
-            win_hy = (int)(G.center_y + margin);
-        } else {
-            win_lx = 0;
-            win_hx = G.main_width - 1;
-            win_ly = 0;
-            win_hy = G.main_height - 1;
-        }
-        const int nx = win_hx - win_lx + 1;
-        const int ny_full = win_hy - win_ly + 1;
-        const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
-        // (GEN: every cell is its own generic drawImage, set up lane-parallel per band: neither axis tables nor the pull form)
-        const bool use_axes = !GEN && GameDrawsGrid<Game>::value && nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
         int ix_ref = 0, iy_ref = 0;
         uint64_t colseam = 0, rowseam = 0, rowany = ~0ull;
         phase(9);
-        build_type_table();
+        build_type_table(type_desc);
         phase(10);
         bool pull = false, pull_multi = false;
         int pull_nfill = 0, pull_ncell = nx * ny_full;
         if constexpr (GameDrawsGrid<Game>::value)
-            pull = !GEN && use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024) && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, pull_multi, pull_nfill);
+            pull = try_pull && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, pull_multi, pull_nfill, cells0);
 
         if (use_axes && !pull) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);  // only the per-cell path reads the axis tables
 
+        // common case (<= 64 entities): their commands are built once and kept in registers for all passes
+        CmdRegs er[CMD_SETS];
+        uint64_t ezmask[CMD_SETS][3];
+        _Pragma("unroll") for (int k = 0; k < CMD_SETS; k++) {
+            ezmask[k][0] = ezmask[k][1] = ezmask[k][2] = 0;
+            PG_R_LANES(l) { clear_cmd(er[k], l); }
+        }
+        if (one_chunk) setup_entities_t<true>(0, er[0], ezmask[0], -1, epre);
+        else if (!force_chunks) one_chunk = compact_entities(er, ezmask);
+        phase(8);
         phase(0);
         // ---- passes -------------------------------------------------------------------------------------------------
         for (int band = 0; band < NUM_BANDS; band++) {
             row0 = band * BAND_ROWS;
             row1 = row0 + BAND_ROWS;
             for (int base = 0; base < BAND_ROWS * RES_W; base += 64) {
-                PG_FOR_LANES(l) { fb[base + l] = 0xff000000u; }  // p.fillRect(rect, QColor(0,0,0))
+                PG_R_LANES(l) { fb[base + l] = 0xff000000u; }  // p.fillRect(rect, QColor(0,0,0))
             }
             PG_SYNC();
             {
@@ -2120,7 +2212,7 @@ struct Renderer {
                     if constexpr (GameHasGridFills<Game>::value) {
                         for (int base = 0; base < pull_nfill; base += 64) {
                             CmdRegs r;
-                            PG_FOR_LANES(l) {
+                            PG_R_LANES(l) {
                                 const bool in = base + l < pull_nfill;
                                 const int si = pull_ncell + 2 * (in ? base + l : 0);
                                 PG_LV(r.geom, l) = in ? lds->cellimg[si] : 0u;
@@ -2134,7 +2226,7 @@ struct Renderer {
                 }
             for (int base = 0; base < ((pull || (d.debug_flags & 2)) ? 0 : ncell); base += 64) {
                 CmdRegs r;
-                PG_FOR_LANES(l) {
+                PG_R_LANES(l) {
                     const int cidx = base + l;
                     clear_cmd(r, l);
                     if (cidx < ncell) {
@@ -2175,10 +2267,10 @@ struct Renderer {
                             RectD r2 = get_screen_rect((float)x, (float)(y + 1), 1, 1, RENDER_EPS);
                             const RectD r2_in = r2;
                             uint32_t fc = 0;
-                            const int im = resolve_image(type, theme, 0.0f, 0.0f, r2, &fc);
+                            ImgDesc imd;
+                            const int im = resolve_image(type, theme, 0.0f, 0.0f, r2, &fc, &imd);
                             if (im == IMG_FILL) cmd_fill_rect(r2_in, fc, PG_LV(r.geom, l), PG_LV(r.src, l), PG_LV(r.aux, l));
                             if (im >= 0) {
-                                const ImgDesc imd = d.assets->img[im];
                                 const bool same_rect = r2.x == r2_in.x && r2.y == r2_in.y && r2.w == r2_in.w && r2.h == r2_in.h;
                                 if (use_axes && same_rect && (int)imd.w == ref_w && (int)imd.h == ref_h) {
                                     const int ry = y - win_ly;  // row index in the frame-level axis table
@@ -2251,7 +2343,7 @@ struct Renderer {
     PG_DEV void store_band() {
         uint32_t *out = reinterpret_cast<uint32_t *>(d.obs + (size_t)env * OBS_BYTES + (size_t)row0 * RES_W * 3);
         for (int base = 0; base < BAND_ROWS * RES_W; base += 256) {
-            PG_FOR_LANES(l) {
+            PG_R_LANES(l) {
                 const uint32_t *p = &fb[base + 4 * l];
                 const uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
                 // bytes: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3   (pixel word = 0xffRRGGBB, i.e. bytes B G R A): one byte

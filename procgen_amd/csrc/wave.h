@@ -48,6 +48,7 @@ struct PgEmuLaneScope {
 #define PG_FOR_LANES(l) \
     if (PgEmuLaneScope pg_scope_{}; true) \
         for (int l = 0; l < 64 && ((pg_emu_lane() = l), true); ++l)
+#define PG_FOR_LANES_NOHOIST(l) PG_FOR_LANES(l)
 #define PG_BALLOT(l, pred)                              \
     ({                                                  \
         uint64_t m_ = 0;                                \
@@ -72,6 +73,7 @@ struct PgEmuLaneScope {
 #define PG_READLANE(v, k) v[k]
 #define PG_LANE_ARR(T, v, N) T v[N][64]
 #define PG_LA(v, j, l) v[j][l]
+#define PG_LANE_ARR_REF(T, v, N) T (&v)[N][64]
 #define PG_SHFL(v, l, src) v[(src) & 63]  // inside a lane section: the value lane `src` holds (v is only read in that section)
 // atomic OR on a 32-bit word shared by the wave's lanes, returns the old value (the emulation's lanes run one after the other)
 PG_DEV uint32_t pg_atomic_or(uint32_t *p, uint32_t v) {
@@ -108,7 +110,21 @@ PG_DEV uint32_t pg_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
 #include <hip/hip_runtime.h>
 #define PG_DEV __device__ __forceinline__
 #define PG_LANE_ID() ((int)(threadIdx.x & 63u))
+// PG_FOR_LANES_NOHOIST: the lane id of the section is taken through an empty asm, so what the section derives from it (LDS /
+// global addresses, row and column indices) cannot be hoisted out of the loops around the section.  Left to itself LLVM's LICM
+// moves those few-instruction values to the top of the kernel and keeps them in VGPRs for its whole length -- ~60 of the render
+// kernel's 128 registers (tools/asm/vgpr_liveness.py).  That is the right trade while the register count stays below an
+// occupancy step (measured, round 4: taking every section's lane id this way cut the render kernel from 138 to 111 VGPRs and
+// step_list from 208 to 154, both without reaching the next step, and cost 3-8 % steps/s in re-computed addresses), so only
+// sections that run rarely, and whose hoisted values would push a kernel over a step, use this form.
+__device__ __forceinline__ int pg_lane_opaque() {
+    int l = (int)(threadIdx.x & 63u);
+    __asm__ volatile("" : "+v"(l));
+    __builtin_assume(l >= 0 && l < 64);
+    return l;
+}
 #define PG_FOR_LANES(l) for (int l = PG_LANE_ID(), pg_once_ = 1; pg_once_; pg_once_ = 0)
+#define PG_FOR_LANES_NOHOIST(l) for (int l = pg_lane_opaque(), pg_once_ = 1; pg_once_; pg_once_ = 0)
 #define PG_BALLOT(l, pred)                              \
     ({                                                  \
         const int l = PG_LANE_ID();                     \
@@ -125,6 +141,7 @@ PG_DEV uint32_t pg_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
 #define PG_LV(v, l) v
 #define PG_LANE_ARR(T, v, N) T v[N]
 #define PG_LA(v, j, l) v[j]
+#define PG_LANE_ARR_REF(T, v, N) T (&v)[N]
 // 32-bit integer lane values only (a float would be value-converted, not bit-copied)
 #define PG_READLANE(v, k)                                                                                      \
     ({                                                                                                         \

@@ -10,7 +10,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-LIB = os.path.join(HERE, "libemu.so")
+# PG_EMU_GAMES="CoinRun,BigFish": a quick build of a few policies while iterating on the kernels (its own file; the tests use the full one)
+_SUBSET = os.environ.get("PG_EMU_GAMES", "")
+LIB = os.path.join(HERE, "libemu.so" if not _SUBSET else "libemu_" + _SUBSET.replace(",", "_") + ".so")
 CSRC = os.path.join(REPO, "procgen_amd", "csrc")
 
 
@@ -29,7 +31,8 @@ def build(force=False):
         if force or not fresh():
             tmp = LIB + f".tmp{os.getpid()}"
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-march=ivybridge", "-fno-strict-aliasing", "-fPIC",
-                                   "-shared", "-I" + CSRC] + (["-DPG_HUMAN_TRACE"] if os.environ.get("PG_HUMAN_TRACE") else []) + srcs + ["-lz", "-o", tmp])
+                                   "-shared", "-I" + CSRC] + (["-DPG_HUMAN_TRACE"] if os.environ.get("PG_HUMAN_TRACE") else [])
+                                  + (["-DPG_FOR_EACH_GAME(X)=" + " ".join(f"X({g})" for g in _SUBSET.split(","))] if _SUBSET else []) + srcs + ["-lz", "-o", tmp])
             os.replace(tmp, LIB)
 
 
