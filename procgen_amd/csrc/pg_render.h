@@ -1073,6 +1073,7 @@ struct Renderer {
                     tex[j] = 0;
                     hit[j] = pull_fetch<MULTI>(ce, lds->ri[0][yb + j], 0, 0, l, yb + j, ny_full, ref_w, tex[j], opq[j]);
                 }
+                dma_join();  // (the band's background rows, requested before these texels)
                 _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
                     uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];  // this lane owns the pixel
                     const uint32_t old = *dp;
@@ -1104,6 +1105,7 @@ struct Renderer {
                     hit[q] = false;
                     if (q < cnt) hit[q] = pull_fetch<MULTI>(ce, lds->ri[1][ys[q]], 0, 1, l, ys[q], ny_full, ref_w, tex[q], opq[q]);
                 }
+                dma_join();
                 _Pragma("unroll") for (int q = 0; q < 4; q++) {
                     if (q < cnt) {
                         uint32_t *dp = &fb[(ys[q] - row0) * RES_W + l];
@@ -1134,6 +1136,7 @@ struct Renderer {
                         const bool hit = pull_fetch<MULTI>(lds->ci[1][x], lds->ri[0][row0 + yl], 1, 0, x, row0 + yl, ny_full, ref_w, tex[j], opq[j]) && in;
                         fbi[j] = hit ? yl * RES_W + x : BAND_ROWS * RES_W + l;  // masked-off lanes use the dump row
                     }
+                    dma_join();
                     _Pragma("unroll") for (int j = 0; j < 4; j++) {
                         const uint32_t old = fb[fbi[j]];
                         fb[fbi[j]] = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
@@ -1169,6 +1172,7 @@ struct Renderer {
                         fbi[q] = hit ? (ys[q] - row0) * RES_W + x : BAND_ROWS * RES_W + l;
                     }
                 }
+                dma_join();
                 _Pragma("unroll") for (int q = 0; q < 4; q++) {
                     if (q < cnt) {
                         const uint32_t old = fb[fbi[q]];
@@ -1231,6 +1235,7 @@ struct Renderer {
                         sample_xy(c, lc, y, sw, sxp, syp);
                         tex[j] = src[syp * sw + (mirrored ? (sw - 1 - sxp) : sxp)];
                     }
+                    dma_join();
                     _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
                         const bool ok = in && (yb + j) <= last;
                         uint32_t *dp = &fb[ok ? ((yb + j - row0) * RES_W + c.tx1 + l) : (BAND_ROWS * RES_W + l)];
@@ -1259,6 +1264,7 @@ struct Renderer {
                             fbi[j] = (y - row0) * RES_W + c.tx1 + px;
                         }
                     }
+                    dma_join();
                     _Pragma("unroll") for (int j = 0; j < 8; j++) {
                         if (fbi[j] >= 0) fb[fbi[j]] = opaque ? tex[j] : blend(tex[j], fb[fbi[j]], io, ca);
                     }
@@ -1267,6 +1273,30 @@ struct Renderer {
         }
         PG_SYNC();
     }
+    // The background of a band without a register in between: an opaque, unmirrored scaled image wider than half the frame (what
+    // draw_background draws, BAG:979-1007) has lane = screen column, and row y of the band is 64 consecutive words of fb -- exactly the
+    // shape of an LDS-DMA load (lane l's texel lands at row base + 4 l).  One instruction per row, no VALU work per pixel, and the
+    // whole band's rows are in flight while the wave goes on to request the band's first cell / sprite texels: whoever reads or
+    // writes fb next joins the copies (dma_join) after issuing its own fetches.
+    PG_DEV bool bg_dma_ok(const DrawCmd &c) const {
+        return !GEN && !(d.debug_flags & 131072) && c.w > 32 && cmd_opaque(c.aux) && !cmd_mirrored(c.aux) && !cmd_fill(c.aux) && !cmd_rotated(c.aux) && !cmd_tiled(c.aux);
+    }
+    PG_DEV void exec_bg_dma(const DrawCmd &c) {
+        const uint32_t *src = d.pixels + c.src;
+        const int sw = cmd_src_w(c.aux);
+        const int y0 = c.ty1 > row0 ? c.ty1 : row0;
+        const int y1 = (c.ty1 + c.h) < row1 ? (c.ty1 + c.h) : row1;
+        PG_R_LANES(l) {
+            const bool in = l < c.w;
+            const uint32_t *col = src + (int)((c.basex + (uint32_t)(in ? l : 0) * c.ix) >> 16);
+            for (int y = y0; y < y1; y++) {
+                const int syp = (int)((c.srcy0 + (uint32_t)(y - c.ty1) * c.iy) >> 16);
+                uint32_t *row = &fb[(y - row0) * RES_W + c.tx1];
+                if (in) PG_DMA_DWORD(col + syp * sw, row, l);
+            }
+        }
+    }
+    PG_DEV void dma_join() { PG_DMA_JOIN(); }
     // QPainter::fillRect(QRectF, QColor) without antialiasing: [qRound(left), qRound(right)) x [qRound(top), qRound(bottom)),
     // normalized, opaque colour (used by the games' HUD overlays)
     PG_DEV void exec_fill(RectD r, uint32_t color) {
@@ -1278,6 +1308,7 @@ struct Renderer {
         if (y1 < row0) y1 = row0;
         if (y2 > row1) y2 = row1;
         if (x1 >= x2 || y1 >= y2) return;
+        dma_join();
         for (int y = y1; y < y2; y++) {
             PG_R_LANES(l) {
                 if (l >= x1 && l < x2) fb[(y - row0) * RES_W + l] = color;
@@ -1288,6 +1319,7 @@ struct Renderer {
     // one horizontal span blended onto the band (spans of the ellipse / line primitives; px premultiplied ARGB)
     PG_DEV void exec_span(int sx, int sy, int len, uint32_t px) {
         if (sy < row0 || sy >= row1 || len <= 0) return;
+        dma_join();
         PG_R_LANES(l) {
             if (l >= sx && l < sx + len) {
                 uint32_t *dp = &fb[(sy - row0) * RES_W + l];
@@ -1299,6 +1331,7 @@ struct Renderer {
     // a shape rasterised ahead of time into two 64-bit masks per frame row, words [row][brush lo, hi, pen lo, hi]: brush
     // pixels, then pen pixels over them, both opaque (the jumper compass on a non-integer rect, game_jumper.h host_tables)
     PG_DEV void exec_row_masks(const uint32_t *rows, int y_first, int y_end, uint32_t brush_px, uint32_t pen_px) {
+        dma_join();
         for (int y = y_first > row0 ? y_first : row0; y < (y_end < row1 ? y_end : row1); y++) {
             PG_R_LANES(l) {
                 const uint32_t *w = rows + y * 4;
@@ -1457,6 +1490,7 @@ struct Renderer {
                 tex[j] = src[in ? (vv * sw + (mirrored ? (sw - 1 - uu) : uu)) : 0];
                 fbi[j] = in ? ((Y - row0) * RES_W + X) : (BAND_ROWS * RES_W + l);  // masked-off lanes use the dump row
             }
+            dma_join();
             _Pragma("unroll") for (int j = 0; j < NJ; j++) { fb[fbi[j]] = blend(tex[j], fb[fbi[j]], io, ca); }
         }
     }
@@ -1654,6 +1688,7 @@ struct Renderer {
                 }
             }
         }
+        dma_join();
         _Pragma("unroll") for (int g = 0; g < 8; g++) {
             if (g < count) {
                 const int io = cmd_alpha(c[g].aux);
@@ -1701,11 +1736,19 @@ struct Renderer {
             cmd_image_fast(im, mirrored, tr, opacity, PG_LV(r.geom, l), PG_LV(r.basex, l), PG_LV(r.srcy, l), PG_LV(r.ix, l), PG_LV(r.iy, l), PG_LV(r.src, l), PG_LV(r.aux, l));
     }
     // executes the commands in lane order; runs of small commands go eight at a time
+    // lane_mask2: a second selection that is drawn after the first one, each in lane order -- the entities of the next render_z
+    // layer (nothing is painted between z = 0 and z = 1, BAG:957-958), so that groups of small sprites and their one wait for texels
+    // span both layers
     template <bool NESTED = false>
-    PG_DEV void run_batch(const CmdRegs &r, uint64_t lane_mask = ~0ull) {
+    PG_DEV void run_batch(const CmdRegs &r, uint64_t lane_mask = ~0ull, uint64_t lane_mask2 = 0) {
         // commands that exist, are selected by the caller, and touch the rows of the current pass
-        uint64_t valid = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && (int)((PG_LV(r.geom, l) >> 7) & 0x7fu) < row1 &&
-                                          (int)(((PG_LV(r.geom, l) >> 7) & 0x7fu) + ((PG_LV(r.geom, l) >> 21) & 0x7fu)) > row0) & lane_mask;
+        const uint64_t touch = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && (int)((PG_LV(r.geom, l) >> 7) & 0x7fu) < row1 &&
+                                                (int)(((PG_LV(r.geom, l) >> 7) & 0x7fu) + ((PG_LV(r.geom, l) >> 21) & 0x7fu)) > row0);
+        uint64_t valid = touch & lane_mask, valid2 = touch & lane_mask2;
+        if (valid == 0) {
+            valid = valid2;
+            valid2 = 0;
+        }
         const uint64_t small = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && ((PG_LV(r.geom, l) >> 14) & 0x7fu) <= 8u && ((PG_LV(r.geom, l) >> 21) & 0x7fu) <= 8u &&
                                                 !cmd_rotated(PG_LV(r.aux, l)) && !cmd_tiled(PG_LV(r.aux, l)));
         while (valid) {
@@ -1723,6 +1766,10 @@ struct Renderer {
                         valid &= valid - 1;
                         c[g] = read_cmd(r, kk);
                         count = g + 1;
+                        if (valid == 0) {  // the first selection is drawn: go on with the second
+                            valid = valid2;
+                            valid2 = 0;
+                        }
                     }
                 }
                 exec_small_group(c, count);
@@ -1734,6 +1781,10 @@ struct Renderer {
                     else exec_tiled(c);
                 } else if (cmd_rotated(c.aux)) exec_rotated(c);
                 else exec_large(c);
+                if (valid == 0) {
+                    valid = valid2;
+                    valid2 = 0;
+                }
             }
         }
     }
@@ -1835,7 +1886,7 @@ struct Renderer {
                 const uint32_t mm = PRE ? PG_LV(pre.meta, l) : meta(i);
                 const float x = PRE ? __builtin_bit_cast(float, PG_LV(pre.x, l)) : ex(i), y = PRE ? __builtin_bit_cast(float, PG_LV(pre.y, l)) : ey(i);
                 const float rx = PRE ? __builtin_bit_cast(float, PG_LV(pre.rx, l)) : erx(i), ry = PRE ? __builtin_bit_cast(float, PG_LV(pre.ry, l)) : ery(i);
-                const float e_alpha = PRE ? __builtin_bit_cast(float, PG_LV(pre.alpha, l)) : e_alpha;
+                const float e_alpha = PRE ? __builtin_bit_cast(float, PG_LV(pre.alpha, l)) : ef(EF_ALPHA, i);
                 RectD r1;  // get_object_rect BAG:811-817
                 if (mm & MF_ABS_COORDS) {
                     const float vd = G.view_dim;
@@ -2148,10 +2199,19 @@ struct Renderer {
         for (int band = 0; band < NUM_BANDS; band++) {
             row0 = band * BAND_ROWS;
             row1 = row0 + BAND_ROWS;
-            for (int base = 0; base < BAND_ROWS * RES_W; base += 64) {
-                PG_R_LANES(l) { fb[base + l] = 0xff000000u; }  // p.fillRect(rect, QColor(0,0,0))
+            // a single background image that reaches every pixel of the band needs no black underneath (p.fillRect(rect, QColor(0,0,0)))
+            const DrawCmd bc0 = unpack(bg_geom[0], bg_basex[0], bg_srcy[0], bg_ix[0], bg_iy[0], bg_src[0], bg_aux[0]);
+            const bool bg_dma = nbg == 1 && !bgt_many && bg_dma_ok(bc0);
+            const bool bg_full = bg_dma && bc0.tx1 == 0 && bc0.w == RES_W && bc0.ty1 <= row0 && bc0.ty1 + bc0.h >= row1;
+            if (!bg_full) {
+                for (int base = 0; base < BAND_ROWS * RES_W; base += 64) {
+                    PG_R_LANES(l) { fb[base + l] = 0xff000000u; }  // p.fillRect(rect, QColor(0,0,0))
+                }
             }
             PG_SYNC();
+            if (bg_dma) {
+                if (bc0.ty1 < row1 && bc0.ty1 + bc0.h > row0) exec_bg_dma(bc0);
+            } else
             {
                 // background commands of this pass: the frame's register slots, or -- with more tiles on screen than slots --
                 // the tiles that can touch these rows, each set up here (wave-uniform) and fed to the same blit
@@ -2191,19 +2251,21 @@ struct Renderer {
             // only cell rows whose (inflated) rect can reach these rows: screen y falls as cell y grows.  Conservative
             // by a full cell either side; cells outside the range draw nothing here, and dropping them keeps the
             // x-major order of the rest (BAG:941-955).
-            int low_y = win_ly, high_y = win_hy;
-            {
+            int low_y = win_ly, ny = 0, ncell = 0;
+            uint32_t ny_inv = 0;
+            const int low_x = win_lx;
+            if (GameDrawsGrid<Game>::value && !(pull || (d.debug_flags & 2))) {  // (the pull form walks screen rows, not cells)
+                int high_y = win_hy;
                 const float inv_unit = 1.0f / G.unit;
                 const int cy_hi = (int)pg_ceil((double)(G.view_dim - ((float)row0 - G.y_off) * inv_unit)) + 1;
                 const int cy_lo = (int)pg_floor((double)(G.view_dim - ((float)row1 - G.y_off) * inv_unit)) - 2;
                 if (cy_lo > low_y) low_y = cy_lo;
                 if (cy_hi < high_y) high_y = cy_hi;
+                ny = high_y - low_y + 1;
+                ncell = (ny > 0 && nx > 0) ? nx * ny : 0;
+                ny_inv = ny > 0 ? (uint32_t)(((1u << 20) + (uint32_t)ny - 1u) / (uint32_t)ny) : 0u;
+                if (ncell > 4096) fail(PGE_ASSERT);
             }
-            const int low_x = win_lx;
-            const int ny = high_y - low_y + 1;
-            const int ncell = (GameDrawsGrid<Game>::value && ny > 0 && nx > 0) ? nx * ny : 0;
-            const uint32_t ny_inv = ny > 0 ? (uint32_t)(((1u << 20) + (uint32_t)ny - 1u) / (uint32_t)ny) : 0u;
-            if (ncell > 4096) fail(PGE_ASSERT);
             phase(2);
             if constexpr (GameDrawsGrid<Game>::value)
                 if (pull && !(d.debug_flags & 2)) {
@@ -2224,7 +2286,7 @@ struct Renderer {
                         }
                     }
                 }
-            for (int base = 0; base < ((pull || (d.debug_flags & 2)) ? 0 : ncell); base += 64) {
+            for (int base = 0; base < ncell; base += 64) {
                 CmdRegs r;
                 PG_R_LANES(l) {
                     const int cidx = base + l;
@@ -2298,12 +2360,14 @@ struct Renderer {
             }
             phase(3);
             if (one_chunk) {
-                if (ezmask[0][1]) run_batch(er[0], ezmask[0][1]);
-                if constexpr (CMD_SETS > 1)
+                if constexpr (CMD_SETS == 1) {
+                    if (ezmask[0][1] | ezmask[0][2]) run_batch(er[0], ezmask[0][1], ezmask[0][2]);  // z = 0, then z = 1, in one pass
+                } else {
+                    if (ezmask[0][1]) run_batch(er[0], ezmask[0][1]);
                     if (ezmask[CMD_SETS - 1][1]) run_batch(er[CMD_SETS - 1], ezmask[CMD_SETS - 1][1]);
-                if (ezmask[0][2]) run_batch(er[0], ezmask[0][2]);
-                if constexpr (CMD_SETS > 1)
+                    if (ezmask[0][2]) run_batch(er[0], ezmask[0][2]);
                     if (ezmask[CMD_SETS - 1][2]) run_batch(er[CMD_SETS - 1], ezmask[CMD_SETS - 1][2]);
+                }
             } else {
                 draw_entities(0);
                 draw_entities(1);
@@ -2341,6 +2405,7 @@ struct Renderer {
     // bgr32_to_rgb888 + the ob write of Game::observe (reference src/game.cpp:8-23,159): 4 pixels -> 3 dwords per
     // lane; each wave-wide store instruction covers 768 contiguous bytes of the observation buffer.
     PG_DEV void store_band() {
+        dma_join();
         uint32_t *out = reinterpret_cast<uint32_t *>(d.obs + (size_t)env * OBS_BYTES + (size_t)row0 * RES_W * 3);
         for (int base = 0; base < BAND_ROWS * RES_W; base += 256) {
             PG_R_LANES(l) {

@@ -49,6 +49,10 @@ struct PgEmuLaneScope {
     if (PgEmuLaneScope pg_scope_{}; true) \
         for (int l = 0; l < 64 && ((pg_emu_lane() = l), true); ++l)
 #define PG_FOR_LANES_NOHOIST(l) PG_FOR_LANES(l)
+// global -> LDS copy of one dword per lane without a register in between (global_load_lds_dword on the GPU): lane l's word lands at
+// lds_base[l].  The copy is asynchronous there: pg_dma_join() before the LDS words are read or overwritten.
+#define PG_DMA_DWORD(gptr, lds_base, l) ((lds_base)[l] = *(gptr))
+#define PG_DMA_JOIN() ((void)0)
 #define PG_BALLOT(l, pred)                              \
     ({                                                  \
         uint64_t m_ = 0;                                \
@@ -125,6 +129,11 @@ __device__ __forceinline__ int pg_lane_opaque() {
 }
 #define PG_FOR_LANES(l) for (int l = PG_LANE_ID(), pg_once_ = 1; pg_once_; pg_once_ = 0)
 #define PG_FOR_LANES_NOHOIST(l) for (int l = pg_lane_opaque(), pg_once_ = 1; pg_once_; pg_once_ = 0)
+// LDS-DMA: the lane's dword goes from global memory to lds_base + 4 * lane (the LDS address is wave-uniform, M0) without passing
+// through a VGPR; completion is counted by vmcnt like any other load
+#define PG_DMA_DWORD(gptr, lds_base, l) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lds_base), 4, 0, 0)
+#define PG_DMA_JOIN() __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define PG_BALLOT(l, pred)                              \
     ({                                                  \
         const int l = PG_LANE_ID();                     \
