@@ -19,6 +19,14 @@ Extra objects on the JSON line:
                  box's host cores (rank 0, N=1 only).
   host_landed  : the PCIe-inclusive rate of the same loop through the unmodified libenv ABI (observations copied into
                  the caller's host array every step) -- reported beside `value`, never as it.
+  steady_state : `value` is a cold-start figure (steps 20-220 after a synchronized reset of all envs).  A trainer sees the
+                 desynchronised steady state: --steady-warmup more steps (default 1500: past coinrun's 1000-step timeout) are run
+                 untimed, then 200 are timed; with the rate go the resets per env-step and how many envs each LDS arena tier of the
+                 step kernel owns there.  `value` stays the cold-start figure so that rounds remain comparable.
+
+  --dry-multi    runs the N > 1 launch path without N GPUs: every rank uses device 0, gloo carries the barrier and the MAX
+                 reduction (tests/test_multi_gpu_paths.py).  No scaling number is meant by it.
+  --shard-crc    adds "shard_crc": per rank the CRC32 of its envs' last observations (host copy after the timed region).
 """
 import os
 
@@ -128,6 +136,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--devices-in-process", type=int, default=1,
                     help="single-process mode: ONE libenv handle of devices x num-envs envs sharded over that many GPUs of this process (num_devices option; no torch.distributed)")
+    ap.add_argument("--steady-warmup", type=int, default=1500, help="untimed steps before the steady_state measurement (0: skip it)")
+    ap.add_argument("--steady-steps", type=int, default=200)
+    ap.add_argument("--dry-multi", action="store_true", help="N > 1 ranks on ONE GPU (device 0 for every rank, gloo): exercises the launch path only")
+    ap.add_argument("--shard-crc", action="store_true", help="report the CRC32 of every rank's last observations")
     args = ap.parse_args()
 
     import torch
@@ -137,12 +149,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
+    device = 0 if args.dry_multi else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dry_multi:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
@@ -162,7 +178,7 @@ def main():
         env = ProcgenGym3Env(n, args.game, rand_seed=23, extra_options={"num_devices": D, "host_observations": bool(args.host_landed)})
     else:
         env = ProcgenGym3Env(n, args.game, rand_seed=23, extra_options={
-            "device_id": local_rank, "env_offset": rank * n, "host_observations": bool(args.host_landed)})
+            "device_id": device, "env_offset": rank * n, "host_observations": bool(args.host_landed)})
     rng = np.random.RandomState(rank)
     acts = rng.randint(0, 15, size=(args.warmup + args.steps, n), dtype=np.int32)
     env.observe()
@@ -177,9 +193,22 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.dry_multi else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    shard_crc = None
+    if args.shard_crc:  # the CRC32 of this rank's last observations (its shard of the logical vector), gathered on rank 0
+        import zlib
+
+        from procgen_amd import torch_view
+
+        mine = [zlib.crc32(v.ob.cpu().numpy().tobytes()) for v in torch_view.device_views(env)]
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            shard_crc = [c for g in gathered for c in g]
+        else:
+            shard_crc = mine
 
     # the same loop with the observations landed in the caller's (pinned) host array through the unmodified libenv ABI:
     # the PCIe-inclusive rate (never `value`), on a bounded number of steps
@@ -209,6 +238,34 @@ def main():
         kernel_ms = dt / args.steps * 1e3
     else:
         kernel_ms = env._lib.procgen_amd_time_steps(env._handle, k_steps, kacts.ctypes.data)
+
+    # the desynchronised steady state a trainer sees (see the module docstring); single-part handles on rank 0's clock
+    steady = None
+    if args.steady_warmup > 0 and not joint and D == 1 and world == 1:
+        srng = np.random.RandomState(1000 + rank)
+        for t in range(args.steady_warmup):
+            env.act(srng.randint(0, 15, size=(n,), dtype=np.int32))
+        env.observe()
+        sacts = srng.randint(0, 15, size=(args.steady_steps, n), dtype=np.int32)
+        tiers = (C.c_int * 3)()
+        env._lib.procgen_amd_tier_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        env._lib.procgen_amd_tier_counts(env._handle, tiers)
+        resets = 0
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for t in range(args.steady_steps):
+            env.act(sacts[t])
+            _, _, first = env.observe()
+            resets += int(np.count_nonzero(first))
+        torch.cuda.synchronize()
+        sdt = time.perf_counter() - t2
+        steady = {"value": round(n * args.steady_steps / sdt, 1), "unit": "env steps/sec", "ms_per_step": round(sdt / args.steady_steps * 1e3, 4),
+                  "steps": args.steady_steps, "warmup": args.warmup + args.steps + args.steady_warmup,
+                  "resets_per_env_step": round(resets / (n * args.steady_steps), 6),
+                  "arena_tier_envs": {"tier0": tiers[0], "tier1": tiers[1], "tier2": tiers[2]},
+                  "kernel_ms_per_step": round(env._lib.procgen_amd_time_steps(env._handle, min(50, args.steady_steps), np.ascontiguousarray(sacts[:min(50, args.steady_steps)]).ctypes.data), 4),
+                  "note": "same loop, measured after the warm-up: episodes desynchronised, entity tables and reset rate at their long-run level"}
+
     env.close()
 
     if rank == 0:
@@ -239,6 +296,12 @@ def main():
             line["roofline"]["launch"] = "one step = the step + render kernels of all games of the joint handle (wall time of the step, kernels of different games overlap)"
         if host_landed is not None:
             line["host_landed"] = host_landed
+        if steady is not None:
+            line["steady_state"] = steady
+        if shard_crc is not None:
+            line["shard_crc"] = shard_crc
+        if args.dry_multi:
+            line["config"]["dry_multi"] = "every rank on device 0, gloo: launch-path check, not a scaling measurement"
         if world == 1 and D == 1 and not args.no_cpu_baseline and not joint:
             line["cpu_baseline"] = cpu_baseline(args.game)
         print(json.dumps(line), flush=True)

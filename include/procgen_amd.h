@@ -74,6 +74,11 @@ LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable
  * measured with HIP events on the library's own stream.  Used by bench.py for the roofline figure. */
 LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const int32_t *actions_or_null);
 
+/* How many envs of the coming step each LDS arena tier of the step kernel owns (single-part handles): out[0..2] = tier 0, 1, 2.
+ * Tiers 1 / 2 are the envs whose entity table may outgrow the smaller arena; the split drifts with the
+ * horizon of a rollout (trails, spawned objects), which is why bench.py's steady_state object reports it.  Returns num_envs. */
+LIBENV_API int procgen_amd_tier_counts(libenv_env *handle, int *out);
+
 /* Device math self-tests (no handle, current HIP device; host pointers in and out): the exact device functions the game
  * kernels call, over caller-chosen inputs, so that a test can sweep a whole input domain against the host libm.
  *   bigfish_radius: out[i] = the fish radius bigfish computes from the rand01() draw r01[i] (pow, reference

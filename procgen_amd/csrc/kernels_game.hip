@@ -36,10 +36,14 @@ __device__ inline void trace_wave(const DevCtx &d, int env, int base, bool end, 
 }
 
 // Occupancy hint of the render kernel (RENDER_MIN_WAVES in a policy); the default leaves the register allocation alone.
-// Tried for coinrun (133 -> 128 VGPRs, a fourth wave per SIMD): +2..4 % steps/s, but the 104 B of spill per lane showed
-// up as +54 % WRITE_SIZE, so no policy sets it.
+// Round 1 tried it for coinrun (133 -> 128 VGPRs): the 104 B of spill per lane showed up as +54 % WRITE_SIZE.  Round 4: with the
+// renderer's lane ids opaque to LICM (pg_render.h) and its LDS tables overlaid (8068 B), coinrun's kernel fits 96 VGPRs without
+// scratch, i.e. five waves per SIMD: +3 % steps/s on the same box (tools/gpu/r4_occ.sh), so CoinRun sets 5.
 #ifndef PG_RENDER_WAVES
 #define PG_RENDER_WAVES 1
+#endif
+#ifndef PG_RENDER_TRACE
+#define PG_RENDER_TRACE 0
 #endif
 template <class Game, class = void>
 struct GameRenderMinWaves {
@@ -105,13 +109,15 @@ __global__ __launch_bounds__(64) void reset_list(DevCtx d, int chunk, int env_ba
 
 // GEN: the handle runs with use_generated_assets (sprites on Qt's generic span route, per-env background canvases; pg_render.h)
 template <class Game, bool GEN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GameRenderMinWaves<PG_GAME>::value))) void render(DevCtx d, int env_base) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GEN ? 1 : GameRenderMinWaves<PG_GAME>::value))) void render(DevCtx d, int env_base) {
     __shared__ RenderLdsT<Game> lds;
     if (d.clear_lists && blockIdx.x == 0 && threadIdx.x < LIST_COUNTERS) const_cast<int *>(d.big_count)[threadIdx.x] = 0;
-    trace_wave(d, env_base + (int)blockIdx.x, 4, false, 8);
+    // (the residency trace of the render kernel is a build option, -DPG_RENDER_TRACE=1: its two calls cost coinrun's renderer the
+    // three registers that separate 96 VGPRs from a spill at five waves per SIMD)
+    if (PG_RENDER_TRACE) trace_wave(d, env_base + (int)blockIdx.x, 4, false, 8);
     Renderer<Game, GEN> r(d, env_base + (int)blockIdx.x, &lds);
     r.render_env();
-    trace_wave(d, env_base + (int)blockIdx.x, 4, true, 8);
+    if (PG_RENDER_TRACE) trace_wave(d, env_base + (int)blockIdx.x, 4, true, 8);
 }
 // clear_lists: this is the step's render of env 0 (every list kernel of the step is done when a render kernel starts); a
 // hipMemsetAsync per step instead was two fill kernels, each tens of microseconds on a busy device with many handles

@@ -1112,6 +1112,19 @@ LIBENV_API int procgen_amd_part_buffers(libenv_env *handle, struct procgen_amd_p
     }
     return h->P();
 }
+LIBENV_API int procgen_amd_tier_counts(libenv_env *handle, int *out) {
+    VecGame *v = ((Handle *)handle)->single();
+    v->observe();
+    int t1 = 0, t2 = 0;
+    for (int c = 0; c < MAX_CHUNKS; c++) {
+        t1 += v->host_list_count[c][1];
+        t2 += v->host_list_count[c][2];
+    }
+    out[0] = v->num_envs - t1 - t2;
+    out[1] = t1;
+    out[2] = t2;
+    return v->num_envs;
+}
 LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable) {
     VecGame *v = ((Handle *)handle)->single();
     v->observe();

@@ -160,13 +160,14 @@ constexpr int ROT_WORDS = 24;  // u0 v0 dudx dudy dvdx dvdy | 3 x (from_y to_y x
 template <class Game>
 struct RenderLdsT {
     uint32_t fb[BAND_ROWS * RES_W + 64];  // the band being rasterized, 0xffRRGGBB (+ a dump row for masked-off lanes)
-    uint32_t ax[128];                // per-column / per-row tile geometry (setup_tile_axes)
+    // Tables that are never alive together share their words (the arena bounds how many frames a CU renders at a time: 8 KB is the
+    // step from four to five waves per SIMD): the per-cell path's axis table `ax` (setup_tile_axes) lies over ci -- a frame is drawn in
+    // pull form or cell by cell --, typesz (read while the pull tables are built) over seamcols (written when they are done), and
+    // typeany (set-up only) over fb's dump row (band passes only); see Renderer::ax / typeany / typesz.
     uint32_t ci[2][64];              // screen column -> the (at most two) cell columns covering it
     uint32_t ri[2][64];              // screen row    -> the (at most two) cell rows covering it
     uint32_t seamcols[64];           // screen columns covered by two cell columns
     uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of this frame (build_type_table)
-    uint32_t typeany[GameDrawsGrid<Game>::value ? 64 : 1];    // ... of any size: atlas offset | size class<<27 | opaque<<31 (pull form)
-    uint32_t typesz[GameDrawsGrid<Game>::value ? 64 : 1];     // its width<<16 | height
     uint8_t srcx[GameDrawsGrid<Game>::value ? 3 : 1][2][64];    // size classes 1..3: screen column -> source column, per covering slot
     uint16_t srcyw[GameDrawsGrid<Game>::value ? 3 : 1][2][64];  // size classes 1..3: screen row -> source row * image width
     uint32_t cellimg[GameDrawsGrid<Game>::value ? GamePullCells<Game>::value : 1];  // window cell -> source image (atlas offset | opaque<<31), CELL_NONE = nothing to draw
@@ -202,14 +203,16 @@ struct Renderer {
     static_assert(BAND_ROWS % WIDE_ROWS == 0, "fetch batches tile the band");
     RenderLds *lds;
     uint32_t *fb;  // the band being rasterized: BAND_ROWS x 64 words of 0xffRRGGBB
-    uint32_t *ax;  // tile-axis scratch (see setup_tile_axes)
+    uint32_t *ax;  // tile-axis scratch (see setup_tile_axes): 128 words over ci
+    uint32_t *typeany;  // grid object type -> cell image of any size: atlas offset | size class<<27 | opaque<<31 (pull form); over fb's dump row
+    uint32_t *typesz;   // its width<<16 | height; over seamcols
     EnvHdr G;
     const uint32_t *ge;  // this env's entity table in HBM
     int ecap;
     const typename Game::cell_t *gg;
     int row0, row1;  // band rows [row0, row1)
 
-    PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(lds_->ax) {
+    PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(&lds_->ci[0][0]), typeany(lds_->fb + BAND_ROWS * RES_W), typesz(lds_->seamcols) {
         ge = d.ents + ent_table_base(env, d.ent_cap);
         ecap = d.ent_cap;
         gg = reinterpret_cast<const typename Game::cell_t *>(d.grid + (size_t)env * d.grid_bytes);
@@ -764,8 +767,8 @@ struct Renderer {
                     }
                 }
                 lds->typeimg[l] = v;
-                lds->typeany[l] = any;
-                lds->typesz[l] = sz;
+                typeany[l] = any;
+                typesz[l] = sz;
             }
             PG_SYNC();
         }
@@ -832,7 +835,7 @@ struct Renderer {
                                                        if (is_fill) {
                                                            v = CELL_FILL;
                                                        } else if (type >= 0 && type < 64) {
-                                                           const uint32_t tv = lds->typeany[type];
+                                                           const uint32_t tv = typeany[type];
                                                            if (tv == TYPE_SLOW) b = true;
                                                            else if (tv != CELL_NONE) {
                                                                v = (uint32_t)type;
@@ -855,7 +858,7 @@ struct Renderer {
         PG_LANE_VAR(uint32_t, cls);
         const uint32_t key0 = ((uint32_t)ref_w << 16) | (uint32_t)ref_h;
         PG_R_LANES(l) {
-            PG_LV(key, l) = present[l] ? lds->typesz[l] : key0;
+            PG_LV(key, l) = present[l] ? typesz[l] : key0;
             PG_LV(cls, l) = 0;
         }
         uint32_t ckey[4] = {key0, key0, key0, key0};
@@ -874,8 +877,8 @@ struct Renderer {
         }
         multi = ncls > 1;
         PG_R_LANES(l) {
-            const uint32_t tv = lds->typeany[l];
-            if (tv != CELL_NONE && tv != TYPE_SLOW) lds->typeany[l] = tv | (PG_LV(cls, l) << 27);
+            const uint32_t tv = typeany[l];
+            if (tv != CELL_NONE && tv != TYPE_SLOW) typeany[l] = tv | (PG_LV(cls, l) << 27);
         }
         PG_SYNC();
         uint32_t cellrows = 0;  // bit r: cell row r of the window holds a cell with an image
@@ -886,7 +889,7 @@ struct Renderer {
                 if (base + l < ncell) {
                     const uint32_t t = lds->cellimg[base + l];
                     if (t != CELL_NONE && t != CELL_FILL) {
-                        lds->cellimg[base + l] = lds->typeany[t];
+                        lds->cellimg[base + l] = typeany[t];
                         PG_LV(has, l) = 1;
                     }
                 }

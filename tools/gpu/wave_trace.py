@@ -1,4 +1,5 @@
-"""Reads a PROCGEN_AMD_DEBUG=8192 residency trace (per env: step start / end / kind<<32|HW_ID, render start / end / HW_ID; 100 MHz
+"""Reads a PROCGEN_AMD_DEBUG=8192 residency trace (the render kernel records its part only in a library built with EXTRA=-DPG_RENDER_TRACE=1)
+ (per env: step start / end / kind<<32|HW_ID, render start / end / HW_ID; 100 MHz
 ticks) and prints, for the last step: kernel spans, mean workgroup lifetimes, resident workgroups over time, per-CU spread."""
 import sys
 import numpy as np
