@@ -131,7 +131,7 @@ struct BigFish {
         const int ag = G.agent;
         BF_FISH_EATEN(G) = 0;
         float start_r = (float).5;
-        if (e.d.opt.distribution_mode == EasyMode) start_r = 1;
+        if (e.opt.distribution_mode == EasyMode) start_r = 1;
         BF_R_INC(G) = (FISH_MAX_R - start_r) / FISH_QUOTA;
         e.erx(ag) = start_r;
         e.ery(ag) = start_r;

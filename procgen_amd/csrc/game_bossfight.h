@@ -185,7 +185,7 @@ struct BossFight : BagDefaults<BossFight> {
         EnvHdr &G = e.G;
         BF_DAMAGED_UNTIL(G) = 0;
         BF_LAST_FIRE_TIME(G) = 0;
-        const int max_extra_invulnerable = e.d.opt.distribution_mode == EasyMode ? 1 : 3;
+        const int max_extra_invulnerable = e.opt.distribution_mode == EasyMode ? 1 : 3;
         const int boss = e.add_entity((float)(G.main_width / 2), (float)(G.main_height / 2), 0, 0, BOSS_R, BOSS);
         e.choose_random_theme(boss);
         e.match_aspect_ratio(boss);
@@ -257,7 +257,7 @@ struct BossFight : BagDefaults<BossFight> {
             BF_LAST_FIRE_TIME(G) = G.cur_time;
         }
         const int ct = G.cur_time;
-        const float bv = boss_bullet_vel(e.d.opt);
+        const float bv = boss_bullet_vel(e.opt);
         if (BF_DAMAGED_UNTIL(G) >= ct) {  // damaged_mode :309-315
             if (ct % 3 == 0) {
                 const float pos_x = e.ex(boss) + (2 * BF_RAND_PCT_X(G) - 1) * e.erx(boss);

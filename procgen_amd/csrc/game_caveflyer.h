@@ -48,7 +48,7 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
     }
     template <class E>
     PG_DEV static void choose_world_dim(E &e) {  // caveflyer.cpp:131-146
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         const int wd = dm == EasyMode ? 30 : (dm == HardMode ? 40 : (dm == MemoryMode ? 60 : 20));
         if (wd * wd > MAX_CELLS) e.fail(PGE_ASSERT);
         e.G.main_width = wd;
@@ -179,7 +179,7 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
         e.mark(3);  // agent / goal cells
         rg.find_path(agent_cell, goal_cell, m.f3, m.f0);
         e.mark(4);  // find_path
-        if (e.d.opt.distribution_mode != MemoryMode) {  // should_prune: keep the path widened by 4 rings
+        if (e.opt.distribution_mode != MemoryMode) {  // should_prune: keep the path widened by 4 rings
             rg.copy(m.f1, m.f3);
             rg.expand_room(m.f1, 4);
             for (int base = 0; base < n; base += 64) {
@@ -236,7 +236,7 @@ struct CaveFlyerT : BagDefaults<CaveFlyerT<CELLS, KERNEL_ID>> {
         PG_SYNC();
         e.mark(8);  // objects
         G.out_of_bounds_object = CAVEWALL;
-        G.visibility = e.d.opt.distribution_mode == EasyMode ? 10.0f : 16.0f;
+        G.visibility = e.opt.distribution_mode == EasyMode ? 10.0f : 16.0f;
         G.grid_dirty = 1;
     }
 

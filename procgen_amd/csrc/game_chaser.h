@@ -48,7 +48,7 @@ struct Chaser : BagDefaults<Chaser> {
     template <class E>
     PG_DEV static void choose_world_dim(E &e) {  // chaser.cpp:132-135 (maze_dim is set first by game_reset :141-156)
         EnvHdr &G = e.G;
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         if (dm == EasyMode) { CH_MAZE_DIM(G) = 11; CH_TOTAL_ENEMIES(G) = 3; }
         else if (dm == HardMode) { CH_MAZE_DIM(G) = 13; CH_TOTAL_ENEMIES(G) = 3; }
         else if (dm == ExtremeMode) { CH_MAZE_DIM(G) = 19; CH_TOTAL_ENEMIES(G) = 5; }
@@ -135,7 +135,7 @@ struct Chaser : BagDefaults<Chaser> {
     PG_DEV static void game_reset(E &e) {  // chaser.cpp:137-264
         e.bag_game_reset();
         EnvHdr &G = e.G;
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         const int extra_orb_sign = dm == EasyMode ? 0 : (dm == HardMode ? -1 : 1);
         const int md = CH_MAZE_DIM(G);
         int ag = G.agent;

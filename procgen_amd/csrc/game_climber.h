@@ -60,7 +60,7 @@ struct Climber {
 
     template <class E>
     PG_DEV static void choose_world_dim(E &e) {  // climber.cpp:230-233
-        e.G.main_width = e.d.opt.distribution_mode == EasyMode ? 16 : 20;
+        e.G.main_width = e.opt.distribution_mode == EasyMode ? 16 : 20;
         e.G.main_height = 64;
     }
 
@@ -176,7 +176,7 @@ struct Climber {
         int curr_x = e.randn(G.main_width - 4) + 2;
         int curr_y = 0;
         const int margin_x = 3;
-        const float enemy_prob = e.d.opt.distribution_mode == EasyMode ? (float).2 : (float).5;
+        const float enemy_prob = e.opt.distribution_mode == EasyMode ? (float).2 : (float).5;
         for (int i = 0; i < num_platforms; i++) {
             const int max_dy = (int)(G.max_jump * G.max_jump / (2 * CLB_GRAVITY(G)));  // choose_delta_y :164-169
             const int min_dy = 3;

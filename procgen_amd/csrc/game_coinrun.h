@@ -279,16 +279,16 @@ struct CoinRun {
         int curr_x = 5, curr_y = 1;
         const int pit_threshold = dif;
         const int danger_type = e.randn(3);
-        const bool allow_pit = (e.d.opt.debug_mode & (1 << 1)) == 0;
-        const bool allow_crate = (e.d.opt.debug_mode & (1 << 2)) == 0;
-        const bool allow_dy = (e.d.opt.debug_mode & (1 << 3)) == 0;
+        const bool allow_pit = (e.opt.debug_mode & (1 << 1)) == 0;
+        const bool allow_crate = (e.opt.debug_mode & (1 << 2)) == 0;
+        const bool allow_dy = (e.opt.debug_mode & (1 << 3)) == 0;
         const int w = G.main_width;
         const float _max_dy = G.max_jump * G.max_jump / (2 * CR_GRAVITY(G));
         const float _max_dx = G.maxspeed * 2 * G.max_jump / CR_GRAVITY(G);
         const int max_dy = (int)((double)_max_dy - .5);
         const int max_dx = (int)((double)_max_dx - .5);
         bool allow_monsters = true;
-        if (e.d.opt.distribution_mode == EasyMode) allow_monsters = false;
+        if (e.opt.distribution_mode == EasyMode) allow_monsters = false;
         for (int section_idx = 0; section_idx < num_sections; section_idx++) {
             if (curr_x + 15 >= w) break;
             int dy = e.randn(4) + 1 + (int)(dif / 3);
@@ -376,7 +376,7 @@ struct CoinRun {
         G.maxspeed = (float).5;
         CR_HAS_SUPPORT(G) = 0;
         CR_FACING_RIGHT(G) = 1;
-        if (e.d.opt.distribution_mode == EasyMode) {
+        if (e.opt.distribution_mode == EasyMode) {
             e.set_image_theme(ag, 0);
             CR_WALL_THEME(G) = 0;
             G.background_index = 0;

@@ -44,7 +44,7 @@ struct FruitBot : BagDefaults<FruitBot> {
 
     template <class E>
     PG_DEV static void choose_world_dim(E &e) {  // fruitbot.cpp:152-160
-        e.G.main_width = e.d.opt.distribution_mode == EasyMode ? 10 : 20;
+        e.G.main_width = e.opt.distribution_mode == EasyMode ? 10 : 20;
         e.G.main_height = 60;
     }
     PG_DEV static bool will_reflect(int src, int target) { return src == BAD_OBJ && (target == BARRIER || target == WALL_OBJ); }  // :80-82
@@ -143,7 +143,7 @@ struct FruitBot : BagDefaults<FruitBot> {
         int num_walls = 10, object_group_size = 6;
         float door_prob = (float).125;
         float min_pct = (float).1;
-        if (e.d.opt.distribution_mode == EasyMode) {
+        if (e.opt.distribution_mode == EasyMode) {
             num_walls = 5;
             object_group_size = 2;
             door_prob = 0;

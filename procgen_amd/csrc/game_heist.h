@@ -39,7 +39,7 @@ struct Heist : BagDefaults<Heist> {
     }
     template <class E>
     PG_DEV static void choose_world_dim(E &e) {  // heist.cpp:95-110
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         int wd = HS_WORLD_DIM(e.G);
         if (dm == EasyMode) wd = 9;
         else if (dm == HardMode) wd = 13;
@@ -84,7 +84,7 @@ struct Heist : BagDefaults<Heist> {
         const int max_diff = (world_dim - min_maze_dim) / 2;
         const int difficulty = e.randn(max_diff + 1);
         int num_keys;
-        if (e.d.opt.distribution_mode == MemoryMode) num_keys = e.randn(4);
+        if (e.opt.distribution_mode == MemoryMode) num_keys = e.randn(4);
         else num_keys = difficulty + e.randn(2);
         if (num_keys > 3) num_keys = 3;
         HS_NUM_KEYS(G) = num_keys;

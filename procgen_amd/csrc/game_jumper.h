@@ -61,7 +61,7 @@ struct Jumper : BagDefaults<Jumper> {
     template <class E>
     PG_DEV static void choose_world_dim(E &e) {  // jumper.cpp:201-217, preceded by game_reset's prologue :219-231
         EnvHdr &G = e.G;
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         G.visibility = mode_visibility(dm);
         JP_COMPASS_DIM(G) = mode_compass_dim(dm);
         if (dm == MemoryMode) G.timeout = 2000;
@@ -79,7 +79,7 @@ struct Jumper : BagDefaults<Jumper> {
     }
     // game tables: [0..7] the compass rect (4 doubles) the masks were made for, then per frame row the brush mask and the
     // pen mask (bit x = column x), 64 x 2 x 64 bits.  Empty when the rect is integer aligned (midpoint route) or in memory mode.
-    static constexpr int TABLE_WORDS = 8 + RES_H * 4, HOST_TABLE_WORDS = TABLE_WORDS;
+    static constexpr int TABLE_WORDS = 8 + RES_H * 4, HOST_TABLE_WORDS = 2 * TABLE_WORDS;  // one table per center_agent setting (a per-env option)
     struct MaskSink {
         uint64_t brush[RES_H], pen[RES_H];
         int cnt[RES_H], xa[RES_H];
@@ -96,6 +96,14 @@ struct Jumper : BagDefaults<Jumper> {
         void pixel(int x, int y) { pen[y] |= 1ull << x; }
     };
     static int host_tables(const GameOptions &o, uint32_t *out, int max_words) {
+        if (max_words < 2 * TABLE_WORDS) return 0;
+        memset(out, 0, 2 * TABLE_WORDS * sizeof(uint32_t));
+        GameOptions a = o, b = o;
+        b.center_agent = !o.center_agent;  // envs restored from a state saved under the other setting (set_state adopts it per env)
+        const int na = host_table_one(a, out, TABLE_WORDS), nb = host_table_one(b, out + TABLE_WORDS, TABLE_WORDS);
+        return (na || nb) ? 2 * TABLE_WORDS : 0;
+    }
+    static int host_table_one(const GameOptions &o, uint32_t *out, int max_words) {
         if (o.distribution_mode == MemoryMode || max_words < TABLE_WORDS) return 0;
         // BAG::prepare_for_drawing for a 64-pixel frame: jumper keeps BAG's choose_center and min_visibility = 0
         const float world = (float)mode_world_dim(o.distribution_mode);
@@ -210,7 +218,7 @@ struct Jumper : BagDefaults<Jumper> {
         EnvHdr &G = e.G;
         typedef typename E::cell_t cell_t;
         const int n = G.main_width * G.main_height, w = G.main_width, h = G.main_height;
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         G.out_of_bounds_object = WALL_OBJ;
         JP_WALL_THEME(G) = e.randn(NUM_WALL_THEMES);
         JP_JUMP_COUNT(G) = 0;
@@ -404,7 +412,7 @@ struct Jumper : BagDefaults<Jumper> {
     template <class R>
     PG_DEV static void draw_overlay_human(R &r) {
         const EnvHdr &G = r.G;
-        if (r.d.opt.distribution_mode == MemoryMode) return;
+        if (r.opt.distribution_mode == MemoryMode) return;
         const int n = G.n_ents;
         int goal = -1;
         for (int c = 0; c < ((n + 63) >> 6) && goal < 0; c++) {
@@ -450,7 +458,7 @@ struct Jumper : BagDefaults<Jumper> {
     template <class R>
     PG_DEV static void draw_overlay(R &r) {
         const EnvHdr &G = r.G;
-        if (r.d.opt.distribution_mode == MemoryMode) return;
+        if (r.opt.distribution_mode == MemoryMode) return;
         const int n = G.n_ents;
         int goal = -1;
         for (int c = 0; c < ((n + 63) >> 6) && goal < 0; c++) {
@@ -472,10 +480,11 @@ struct Jumper : BagDefaults<Jumper> {
         } else {
             // Qt's path route: the handle's precomputed row masks -- valid for exactly this rect
             const uint32_t *t = r.d.game_tables;
-            bool same = t != nullptr;
-            if (same) {
-                const double *tr = (const double *)t;
-                same = tr[0] == cr_.x && tr[1] == cr_.y && tr[2] == cr_.w && tr[3] == cr_.h;
+            bool same = false;
+            for (int k = 0; k < 2 && t != nullptr && !same; k++) {  // the handle's two tables (host_tables)
+                const double *tr = (const double *)(r.d.game_tables + k * TABLE_WORDS);
+                same = tr[0] == cr_.x && tr[1] == cr_.y && tr[2] == cr_.w && tr[3] == cr_.h && tr[2] != 0;
+                if (same) t = r.d.game_tables + k * TABLE_WORDS;
             }
             if (!same) {
                 r.fail(PGE_ASSERT);

@@ -70,7 +70,7 @@ struct Leaper : BagDefaults<Leaper> {
     }
     template <class E>
     PG_DEV static void choose_world_dim(E &e) {  // leaper.cpp:103-116
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         const int wd = dm == EasyMode ? 9 : (dm == HardMode ? 15 : 20);
         e.G.main_width = wd;
         e.G.main_height = wd;
@@ -183,13 +183,13 @@ struct Leaper : BagDefaults<Leaper> {
     template <class E>
     PG_DEV static float randrange(E &e, float low, float high) { return e.rand01() * (high - low) + low; }  // randgen.cpp:29-31
     template <class E>
-    PG_DEV static int choose_extra_space(E &e) { return e.d.opt.distribution_mode == EasyMode ? 0 : e.randn(2); }  // leaper.cpp:118-120
+    PG_DEV static int choose_extra_space(E &e) { return e.opt.distribution_mode == EasyMode ? 0 : e.randn(2); }  // leaper.cpp:118-120
 
     template <class E>
     PG_DEV static void game_reset(E &e) {  // leaper.cpp:122-175
         e.bag_game_reset();
         EnvHdr &G = e.G;
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         const int ag = G.agent;
         e.ey(ag) = e.ery(ag);
         float min_car_speed = 0.05f, max_car_speed = 0.2f, min_log_speed = 0.05f, max_log_speed = 0.1f;

@@ -44,7 +44,7 @@ struct Maze {
     template <class E>
     PG_DEV static void choose_world_dim(E &e) {  // maze.cpp:40-53
         EnvHdr &G = e.G;
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         if (dm == EasyMode) MZ_WORLD_DIM(G) = 15;
         else if (dm == HardMode) MZ_WORLD_DIM(G) = 25;
         else if (dm == MemoryMode) MZ_WORLD_DIM(G) = 31;

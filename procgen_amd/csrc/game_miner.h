@@ -49,7 +49,7 @@ struct Miner {
     }
     template <class E>
     PG_DEV static void choose_world_dim(E &e) {  // miner.cpp:116-129
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         int dim = e.G.main_width;
         if (dm == EasyMode) dim = 10;
         else if (dm == HardMode) dim = 20;

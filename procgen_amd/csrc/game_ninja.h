@@ -133,7 +133,7 @@ struct Ninja : BagDefaults<Ninja> {
         int min_gap = difficulty - 1;
         int min_plat_w = 1;
         int inc_dy = 4;
-        if (e.d.opt.distribution_mode == EasyMode) {
+        if (e.opt.distribution_mode == EasyMode) {
             min_gap -= 1;
             if (min_gap < 0) min_gap = 0;
             min_plat_w = 3;
@@ -216,7 +216,7 @@ struct Ninja : BagDefaults<Ninja> {
         e.ery(ag) = (float).5;
         e.ex(ag) = 1 + e.erx(ag);
         e.ey(ag) = G.main_height / 2 + e.ery(ag);
-        if (e.d.opt.distribution_mode == EasyMode) {
+        if (e.opt.distribution_mode == EasyMode) {
             G.max_jump = (float)1.25;
             NJ_JUMP_CHARGE_INC(G) = 1;
             G.visibility = 10;

@@ -107,7 +107,7 @@ struct Plunder : BagDefaults<Plunder> {
         e.set_image_type(ag, SHIP);
         PL_JUICE_LEFT(G) = 1;
         PL_TARGETS_HIT(G) = 0;
-        const float rs = r_scale(e.d.opt);
+        const float rs = r_scale(e.opt);
         {   // RandGen::choose_n (reference src/randgen.cpp:49-69) of all six indices: remaining elements as 3-bit fields
             uint32_t rem = 0;
             for (int i = 0; i < NUM_TOTAL_SHIP_TYPES; i++) rem |= (uint32_t)i << (3 * i);
@@ -129,7 +129,7 @@ struct Plunder : BagDefaults<Plunder> {
             if ((double)e.rand01() < .5) PL_LANE_DIRS(G) |= 1 << i;
             set_lane_vel(G, i, (float)(.15 + .1 * (double)e.rand01()));
         }
-        const int num_panels = e.d.opt.distribution_mode == EasyMode ? 0 : e.randn(4);
+        const int num_panels = e.opt.distribution_mode == EasyMode ? 0 : e.randn(4);
         const float panel_width = 1.2f;
         PG_SYNC();
         for (int i = 0; i < num_panels; i++)
@@ -168,7 +168,7 @@ struct Plunder : BagDefaults<Plunder> {
         EnvHdr &G = e.G;
         PL_JUICE_LEFT(G) -= 0.0015f;
         if (e.rand01() < SPAWN_PROB) {
-            const float ent_r = r_scale(e.d.opt);
+            const float ent_r = r_scale(e.opt);
             const int lane = e.randn(NUM_LANES);
             const float ent_y = (float)((lane * .11 + .4) * (double)(G.main_height / 2 - ent_r) + (double)(G.main_height / 2));
             const bool moves_right = ((PL_LANE_DIRS(G) >> lane) & 1) != 0;

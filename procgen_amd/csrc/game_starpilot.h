@@ -189,7 +189,7 @@ struct StarPilot {
     template <class E>
     PG_DEV static void add_spawners(E &e) {  // starpilot.cpp:229-325
         EnvHdr &G = e.G;
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         uint32_t *aux = e.aux();
         StarScratch &sc = e.s->scratch;
         float total_prob_weight = 0;
@@ -404,7 +404,7 @@ struct StarPilot {
     PG_DEV static void game_reset(E &e) {  // starpilot.cpp:327-339
         e.bag_game_reset();
         EnvHdr &G = e.G;
-        G.maxspeed = e.d.opt.distribution_mode == ExtremeMode ? (float)0.5 : (float)0.75;  // init_hps
+        G.maxspeed = e.opt.distribution_mode == ExtremeMode ? (float)0.5 : (float)0.75;  // init_hps
         SP_N_SPAWNERS(G) = 0;
         SP_NEXT_SPAWN_TIME(G) = -1;
         add_spawners(e);
@@ -419,7 +419,7 @@ struct StarPilot {
     PG_DEV static void game_step(E &e) {  // starpilot.cpp:363-430
         e.bag_game_step();
         EnvHdr &G = e.G;
-        const int dm = e.d.opt.distribution_mode;
+        const int dm = e.opt.distribution_mode;
         const bool is_firing = G.special_action != 0;
         PG_SYNC();
         {

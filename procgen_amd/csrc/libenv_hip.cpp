@@ -120,6 +120,7 @@ struct VecGame {
     bool human_stale = false;    // a set_state since the frames were last drawn: the next libenv_observe redraws them (reference src/vecgame.cpp:367-375 redraws on every observe)
     std::vector<void *> human_ptr;  // caller's info "rgb" buffers
     bool human_contig = false;
+    size_t human_stride = 0;  // > 0: the caller's frames lie at this uniform distance (bytes)
     void launch_human(int env_base, int count);
     std::vector<libenv_tensortype> observation_types, action_types, info_types;
     hipStream_t stream = nullptr;
@@ -207,7 +208,7 @@ struct VecGame {
     void observe(bool from_api = false);
     int get_state(int env_idx, char *data, int length);
     void set_state(int env_idx, const char *data, int length);
-    void snapshot(int env_idx, EnvSnapshot *s);
+    void snapshot(int env_idx, EnvSnapshot *s, bool single = false);
     static constexpr int SNAP_BLOCK = 256;
     int snap_first = -1, snap_count = 0;  // envs [snap_first, snap_first + snap_count) of the snapshot cache; -1: stale
     std::vector<EnvHdr> snap_hdr;
@@ -406,6 +407,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         for (auto &h : hdr) {  // reference src/vecgame.cpp:316-317 (every game starts with the handle's range)
             h.level_seed_low = o.level_seed_low;
             h.level_seed_high = o.level_seed_high;
+            h.opt_bits = env_option_bits(o);  // per env as well: set_state adopts the options a state was saved under (reference src/game.cpp:233-246)
+            h.opt_debug_mode = o.debug_mode;
         }
         HIP_CHECK(hipMemcpy(d.hdr, hdr.data(), N * sizeof(EnvHdr), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d.rng, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
@@ -554,6 +557,12 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
         human_contig = true;
         for (int e = 0; e < N; e++)
             if ((uint8_t *)human_ptr[e] != (uint8_t *)human_ptr[0] + (size_t)e * HUMAN_BYTES) human_contig = false;
+        if (!human_contig && N > 1 && (uint8_t *)human_ptr[1] > (uint8_t *)human_ptr[0]) {
+            human_stride = (size_t)((uint8_t *)human_ptr[1] - (uint8_t *)human_ptr[0]);
+            for (int e = 0; e < N; e++)
+                if ((uint8_t *)human_ptr[e] != (uint8_t *)human_ptr[0] + (size_t)e * human_stride) human_stride = 0;
+            if (human_stride < HUMAN_BYTES) human_stride = 0;
+        }
     }
     rew_ptr = bufs->rew;
     first_ptr = bufs->first;
@@ -589,8 +598,9 @@ void VecGame::launch_kernels(int mode) {
     route_mirror_valid = false;
     bind_routing();
     // The next lists' counters are zero already: they were the lists the step before read, and its render kernel cleared them
-    // (DevCtx::clear_lists).  The error word is never cleared: the first error ends the run.  Only with the render kernel
-    // switched off for profiling does the host clear them.
+    // (DevCtx::clear_lists).  A step never clears the error word: the first error ends the run (set_state clears it before it
+    // draws the restored env, to tell that draw's errors apart).  Only with the render kernel switched off for profiling does the
+    // host clear the counters.
     if (d.debug_flags & 16) HIP_CHECK(hipMemsetAsync(d.next_big_count, 0, LIST_COUNTERS * sizeof(int), stream));
     LaunchStreams ls = streams();
     for (int c = 0; c < MAX_CHUNKS; c++)
@@ -626,6 +636,8 @@ void VecGame::launch_human(int env_base, int count) {
     HIP_CHECK(launch_render_human(kernel_id, d, env_base, count, stream));
     if (human_contig) {
         HIP_CHECK(hipMemcpyAsync((uint8_t *)human_ptr[0] + (size_t)env_base * HUMAN_BYTES, d.human + (size_t)env_base * HUMAN_BYTES, (size_t)count * HUMAN_BYTES, hipMemcpyDeviceToHost, stream));
+    } else if (human_stride > 0) {  // per-env buffers at a uniform distance (padded arrays): one strided copy
+        HIP_CHECK(hipMemcpy2DAsync(human_ptr[env_base], human_stride, d.human + (size_t)env_base * HUMAN_BYTES, HUMAN_BYTES, HUMAN_BYTES, (size_t)count, hipMemcpyDeviceToHost, stream));
     } else {
         for (int e = env_base; e < env_base + count; e++) HIP_CHECK(hipMemcpyAsync(human_ptr[e], d.human + (size_t)e * HUMAN_BYTES, HUMAN_BYTES, hipMemcpyDeviceToHost, stream));
     }
@@ -679,8 +691,20 @@ void VecGame::observe(bool from_api) {  // reference src/vecgame.cpp:363-376,416
 // Host copy of one env's device state.  env.get_state() walks all envs: the state of a block of SNAP_BLOCK consecutive envs is
 // fetched with four copies and kept until something changes device state (a step, a restore, a redraw), instead of four small
 // synchronous copies per env (262 144 of them at 65 536 envs).
-void VecGame::snapshot(int e, EnvSnapshot *s) {
+// single: the caller is about to change device state (set_state), so a block fetched now would be thrown away: only env e moves
+void VecGame::snapshot(int e, EnvSnapshot *s, bool single) {
     const size_t ents_w = (size_t)EF_COUNT * d.ent_cap, rng_w = 2 * MT_STRIDE, grid_b = (size_t)d.grid_bytes;
+    if (single && !(snap_first >= 0 && e >= snap_first && e < snap_first + snap_count)) {
+        s->ent_cap = d.ent_cap;
+        s->ents.resize(ents_w);
+        s->rng.resize(rng_w);
+        s->grid.resize(grid_b);
+        HIP_CHECK(hipMemcpy(&s->hdr, d.hdr + e, sizeof(EnvHdr), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(s->ents.data(), d.ents + ent_table_base(e, d.ent_cap), ents_w * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(s->rng.data(), d.rng + (size_t)e * MT_SLOTS * MT_STRIDE, rng_w * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(s->grid.data(), d.grid + (size_t)e * grid_b, grid_b, hipMemcpyDeviceToHost));
+        return;
+    }
     if (!(snap_first >= 0 && e >= snap_first && e < snap_first + snap_count)) {
         const int first = e / SNAP_BLOCK * SNAP_BLOCK, count = num_envs - first < SNAP_BLOCK ? num_envs - first : SNAP_BLOCK;  // aligned blocks: any visiting order fetches a block once
         snap_hdr.resize(count);
@@ -724,7 +748,7 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     use_device();
     observe();
     EnvSnapshot s;
-    snapshot(e, &s);  // fields the wire format does not carry keep their current values
+    snapshot(e, &s, true);  // fields the wire format does not carry keep their current values
     std::string err;
     if (!deserialize_state(game_id, d.opt, &s, data, length, &err)) fatal("%s\n", err.c_str());
     // routing: the restored env takes a wave = env kernel for one step (conservative bound: a step at most doubles the
@@ -1169,8 +1193,8 @@ LIBENV_API void procgen_amd_selftest_sincos_scaled(const uint32_t *bits, int n, 
     (void)hipFree(d_c);
 }
 
-// average device time of one step's launch sequence -- exactly what libenv_act enqueues (VecGame::launch_kernels: counter
-// memset, list / reset / step / render kernels, empty lists skipped) -- over the given number of rounds, measured
+// average device time of one step's launch sequence -- exactly what libenv_act enqueues (VecGame::launch_kernels: list / reset /
+// step / render kernels, empty lists skipped) -- over the given number of rounds, measured
 // with HIP events on the library's stream (bench.py roofline leg)
 LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const int32_t *actions_or_null) {
     VecGame *v = ((Handle *)handle)->single();

@@ -36,12 +36,37 @@ inline int kernel_id_for(int game_id, int distribution_mode) { return (game_id =
 
 enum DistributionMode : int { EasyMode = 0, HardMode = 1, ExtremeMode = 2, MemoryMode = 10 };
 
+#if defined(__HIPCC__)
+#define PG_HOSTDEV_EARLY __host__ __device__
+#else
+#define PG_HOSTDEV_EARLY
+#endif
 // ---- options common to every env of a handle (reference src/game.h:45-60, src/vecgame.cpp:183-190) ----
 struct GameOptions {
     int paint_vel_info, use_generated_assets, use_monochrome_assets, restrict_themes, use_backgrounds, center_agent;
     int debug_mode, distribution_mode, use_sequential_levels;
     int level_seed_low, level_seed_high;
 };
+
+// Options a state carries and the reference adopts per env on deserialize (reference src/game.cpp:233-246).  Those that choose
+// no kernel instantiation live in every env's header (EnvHdr::opt_bits / opt_debug_mode) and override the handle's GameOptions
+// when a kernel binds an env; distribution_mode and use_generated_assets stay per handle (they select kernels, LDS arenas, assets).
+enum EnvOptBit : int { EOB_PAINT_VEL_INFO = 1, EOB_MONOCHROME = 2, EOB_RESTRICT_THEMES = 4, EOB_BACKGROUNDS = 8, EOB_CENTER_AGENT = 16, EOB_SEQUENTIAL = 32 };
+PG_HOSTDEV_EARLY inline int env_option_bits(const GameOptions &o) {
+    return (o.paint_vel_info ? EOB_PAINT_VEL_INFO : 0) | (o.use_monochrome_assets ? EOB_MONOCHROME : 0) | (o.restrict_themes ? EOB_RESTRICT_THEMES : 0) |
+           (o.use_backgrounds ? EOB_BACKGROUNDS : 0) | (o.center_agent ? EOB_CENTER_AGENT : 0) | (o.use_sequential_levels ? EOB_SEQUENTIAL : 0);
+}
+PG_HOSTDEV_EARLY inline GameOptions env_options(const GameOptions &handle, int bits, int debug_mode) {
+    GameOptions o = handle;
+    o.paint_vel_info = (bits & EOB_PAINT_VEL_INFO) != 0;
+    o.use_monochrome_assets = (bits & EOB_MONOCHROME) != 0;
+    o.restrict_themes = (bits & EOB_RESTRICT_THEMES) != 0;
+    o.use_backgrounds = (bits & EOB_BACKGROUNDS) != 0;
+    o.center_agent = (bits & EOB_CENTER_AGENT) != 0;
+    o.use_sequential_levels = (bits & EOB_SEQUENTIAL) != 0;
+    o.debug_mode = debug_mode;
+    return o;
+}
 
 // ---- per-env scalar state: one record per env in HBM (Game + BasicAbstractGame + game scalars) ----
 // Field names follow the reference members (reference src/game.h:62-111, src/basic-abstract-game.h:110-160).
@@ -70,6 +95,7 @@ struct GameOptions {
     X(int, big)        /* arena tier (0,1,2) that must step this env next: smallest LDS entity table that fits */      \
     X(int, grid_dirty)                                                                                            \
     X(int, level_seed_low) X(int, level_seed_high) /* per env: set_state adopts the range a state was saved under (reference src/game.cpp:247-248) */ \
+    X(int, opt_bits) X(int, opt_debug_mode) /* per env: the game options that select no kernel (env_option_bits); set_state adopts them (reference src/game.cpp:233-246) */ \
     /* game-specific scalars (meaning defined by the game policy, e.g. game_coinrun.h) */                         \
     X(int, gsi0) X(int, gsi1) X(int, gsi2) X(int, gsi3) X(int, gsi4) X(int, gsi5) X(int, gsi6) X(int, gsi7)       \
     X(float, gsf0) X(float, gsf1) X(float, gsf2) X(float, gsf3) X(float, gsf4) X(float, gsf5) X(float, gsf6) X(float, gsf7)

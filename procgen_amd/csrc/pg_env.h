@@ -220,6 +220,7 @@ struct Env {
     static constexpr bool NO_RESET = NO_RESET_MODE;
     typedef Lds<Game, CAP, !NO_RESET_MODE> LdsT;
     const DevCtx &d;
+    GameOptions opt;  // this env's options: the handle's, with the per-env ones of its header (pg_defs.h env_options), bound by load_env
     const int env;
     LdsT *s;
     EnvHdr G;
@@ -1627,7 +1628,7 @@ struct Env {
         if (!(G.main_width > 0 && G.main_height > 0)) fail(PGE_ASSERT);
         G.bg_pct_x = rand01();
         G.background_index = randn(d.assets->n_bg);
-        if (d.opt.use_generated_assets) {
+        if (opt.use_generated_assets) {
             // BAG:769-773: AssetGen bggen(&rand_gen) paints this episode's background.  Here only its draws are made (the
             // generator without a painter); the background kernel re-seeds from the level seed, skips the draws made so far
             // and paints (pg_bgpaint.h)
@@ -1673,7 +1674,7 @@ struct Env {
     // asset_aspect_ratios[img_idx] comes from the image of the MASKED theme (initialize_asset_if_necessary BAG:82-86,114):
     // with restrict_themes every theme of a type has the aspect ratio of theme 0
     PG_DEV int aspect_theme(uint32_t mm) const {
-        return (d.opt.restrict_themes && !Game::should_preserve_type_themes(meta_image_type(mm))) ? 0 : meta_image_theme(mm);
+        return (opt.restrict_themes && !Game::should_preserve_type_themes(meta_image_type(mm))) ? 0 : meta_image_theme(mm);
     }
     PG_DEV void match_aspect_ratio(int i) {  // BAG:1014-1023 (match_width), aspect ratio BAG:114
         const uint32_t mm = meta(i);
@@ -1824,7 +1825,7 @@ struct Env {
     // Game::reset reference src/game.cpp:93-118
     PG_DEV void game_reset_full() {
         if (G.episodes_remaining == 0) {
-            if (d.opt.use_sequential_levels && G.level_complete) {
+            if (opt.use_sequential_levels && G.level_complete) {
                 G.current_level_seed = (int32_t)((uint32_t)G.current_level_seed + 997u);
             } else {
                 const uint32_t x = level_seed_u32();
@@ -1885,7 +1886,7 @@ struct Env {
         if (initial) {
             G.initial_reset_complete = 1;
         } else {
-            if (d.opt.use_sequential_levels && G.level_complete) G.done = 0;
+            if (opt.use_sequential_levels && G.level_complete) G.done = 0;
             G.episode_done = G.done;
         }
     }
@@ -1895,7 +1896,7 @@ struct Env {
     PG_DEV void prepare_for_drawing(float rect_height) {  // BAG:819-838
         G.center_x = (float)(G.main_width * .5);
         G.center_y = (float)(G.main_height * .5);
-        if (Game::center_agent(d.opt)) {
+        if (Game::center_agent(opt)) {
             Game::choose_center(*this, G.center_x, G.center_y);
         } else {
             G.visibility = (float)(G.main_width > G.main_height ? G.main_width : G.main_height);
@@ -1930,6 +1931,7 @@ struct Env {
             PG_HDR_FIELDS(PG_X)
 #undef PG_X
         }
+        opt = env_options(d.opt, G.opt_bits, G.opt_debug_mode);
         const int n = with_entities ? G.n_ents : 0;
         const uint32_t *ge = d.ents + ent_table_base(env, d.ent_cap);
         const uint32_t fstride = (uint32_t)d.ent_cap;  // words between two fields of one slot

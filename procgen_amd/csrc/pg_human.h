@@ -102,6 +102,7 @@ template <class Game>
 struct HumanRenderer {
     static constexpr int FRAME_W = HUMAN_RES, FRAME_H = HUMAN_RES;
     const DevCtx &d;
+    GameOptions opt;  // this env's options (pg_defs.h env_options)
     const int env;
     HumanLds *lds;
     uint32_t *fb;
@@ -855,7 +856,7 @@ struct HumanRenderer {
     PG_DEV void draw_image(RectD base_rect, float rotation, bool is_reflected, int base_type, int theme, float alpha, float tile_ratio) {
         const int img_type = Game::image_for_type(*this, base_type);
         if (img_type < 0) return;
-        if (d.opt.use_monochrome_assets || img_type >= USE_ASSET_THRESHOLD) {  // draw_grid_obj BAG:915-919, color_for_type BAG:455-481
+        if (opt.use_monochrome_assets || img_type >= USE_ASSET_THRESHOLD) {  // draw_grid_obj BAG:915-919, color_for_type BAG:455-481
             if constexpr (GameHasGridFills<Game>::value) {  // a game's own draw_grid_obj (chaser.cpp:112-119)
                 if (Game::is_grid_fill(*this, img_type)) {
                     RectD out;
@@ -866,12 +867,12 @@ struct HumanRenderer {
                 }
             }
             if (img_type == SPACE) return;
-            if (!d.opt.use_monochrome_assets || img_type >= 64) {
+            if (!opt.use_monochrome_assets || img_type >= 64) {
                 fail(PGE_UNSUPPORTED_DRAW);
                 return;
             }
             int th = theme;
-            if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) th = 0;
+            if (opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) th = 0;
             const int k = 4, kcubed = 64, chunk = 64;
             int new_type = (29 * (img_type + 1)) % kcubed;
             new_type = (new_type + 19 * th) % kcubed;
@@ -881,7 +882,7 @@ struct HumanRenderer {
         }
         const RectD rect = Game::adjusted_image_rect(img_type, base_rect);
         int mt = theme;
-        if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;  // BAG:450-453
+        if (opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;  // BAG:450-453
         const int img = (mt >= 0 && mt < MAX_IMAGE_THEMES) ? (int)d.assets->type_theme_img[img_type][mt] : -1;
         if (img < 0) {
             fail(PGE_THEME);
@@ -1012,6 +1013,7 @@ struct HumanRenderer {
             PG_HDR_FIELDS(PG_X)
 #undef PG_X
         }
+        opt = env_options(d.opt, G.opt_bits, G.opt_debug_mode);
         // prepare_for_drawing(512) BAG:819-838: centre, visibility and view_dim are what the step kernel left for the 64-pixel frame
         {
             const float raw_unit = 64 / G.visibility;
@@ -1025,7 +1027,7 @@ struct HumanRenderer {
         }
         PG_SYNC();
         // draw_background BAG:979-1007
-        if (d.opt.use_backgrounds) {
+        if (opt.use_backgrounds) {
             const int bgi = (int)d.assets->bg_img[G.background_index];
             const ImgDesc bim = d.assets->img[bgi];
             if constexpr (GameCustomBackground<Game>::value) {
@@ -1051,7 +1053,7 @@ struct HumanRenderer {
         draw_entities(-1);
         if constexpr (GameDrawsGrid<Game>::value) {
             int low_x, high_x, low_y, high_y;
-            if (Game::center_agent(d.opt)) {
+            if (Game::center_agent(opt)) {
                 const float margin = (float)(G.visibility / 2.0 + 1);
                 low_x = (int)(G.center_x - margin);
                 high_x = (int)(G.center_x + margin);
@@ -1076,7 +1078,7 @@ struct HumanRenderer {
         }
         draw_entities(0);
         draw_entities(1);
-        if (G.has_useful_vel_info && d.opt.paint_vel_info) {  // BAG:960-969, to_shade reference src/qt-utils.h:21-28
+        if (G.has_useful_vel_info && opt.paint_vel_info) {  // BAG:960-969, to_shade reference src/qt-utils.h:21-28
             const float infodim = (float)(HUMAN_RES * .2);
             const int ag = G.agent;
             int s1 = (int)((float)(.5 * (double)evx(ag) / (double)G.maxspeed + .5) * 255);

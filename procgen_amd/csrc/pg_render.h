@@ -196,6 +196,7 @@ PG_DEV bool q_fuzzy_is_null(double v) { return (v < 0 ? -v : v) <= 0.00000000000
 template <class Game, bool GEN = false>
 struct Renderer {
     const DevCtx &d;
+    GameOptions opt;  // this env's options (pg_defs.h env_options), bound when the header has been read
     const int env;
     typedef RenderLdsT<Game> RenderLds;
     static constexpr int FRAME_W = RES_W, FRAME_H = RES_H;  // (pg_human.h's renderer draws the same policies at 512 x 512)
@@ -265,7 +266,7 @@ struct Renderer {
     // section can request the descriptors of all its drawables before it needs the first one.
     PG_DEV ImgDesc desc_for(int img_type, int theme) const {
         int mt = theme;
-        if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;  // BAG:450-453
+        if (opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) mt = 0;  // BAG:450-453
         const bool ok = img_type >= 0 && img_type < MAX_ASSETS && mt >= 0 && mt < MAX_IMAGE_THEMES;
         ImgDesc r = d.assets->type_theme_desc[ok ? img_type : 0][ok ? mt : 0];
         if (!ok) r.off = IMG_NONE;
@@ -643,14 +644,14 @@ struct Renderer {
     PG_DEV int resolve_image(int base_type, int theme, float rotation, float tile_ratio, RectD &rect, uint32_t *fill_color, ImgDesc *desc, const ImgDesc *pre = nullptr) {
         const int img_type = Game::image_for_type(*this, base_type);
         if (img_type < 0) return -1;
-        if (d.opt.use_monochrome_assets || img_type >= USE_ASSET_THRESHOLD) {
+        if (opt.use_monochrome_assets || img_type >= USE_ASSET_THRESHOLD) {
             if (img_type == SPACE) return -1;
-            if (!d.opt.use_monochrome_assets || img_type >= 64 || !fill_color) {  // fassert(false) BAG:477 / fassert(type < kcubed) BAG:465
+            if (!opt.use_monochrome_assets || img_type >= 64 || !fill_color) {  // fassert(false) BAG:477 / fassert(type < kcubed) BAG:465
                 fail(PGE_UNSUPPORTED_DRAW);
                 return -1;
             }
             int th = theme;
-            if (d.opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) th = 0;
+            if (opt.restrict_themes && !Game::should_preserve_type_themes(img_type)) th = 0;
             const int k = 4, kcubed = 64, chunk = 64;
             int new_type = (29 * (img_type + 1)) % kcubed;
             new_type = (new_type + 19 * th) % kcubed;
@@ -748,7 +749,7 @@ struct Renderer {
                 const int type = l;
                 bool is_fill = false;
                 if constexpr (GameHasGridFills<Game>::value) is_fill = Game::is_grid_fill(*this, type);
-                if (!is_fill && !d.opt.use_monochrome_assets) {
+                if (!is_fill && !opt.use_monochrome_assets) {
                     const int img_type = Game::image_for_type(*this, type);
                     if (img_type < 0 || img_type == SPACE) {
                         v = any = CELL_NONE;
@@ -2063,6 +2064,7 @@ struct Renderer {
             PG_HDR_FIELDS(PG_X)
 #undef PG_X
         }
+        opt = env_options(d.opt, G.opt_bits, G.opt_debug_mode);
         phase(6);
         // ---- frame-level set-up (rows [0, 64)) ------------------------------------------------------------------
         row0 = 0;
@@ -2071,7 +2073,7 @@ struct Renderer {
         const bool force_chunks = (d.debug_flags & 4096) != 0;  // test aid: every frame through draw_entities()
         bool one_chunk = G.n_ents <= 64 && !force_chunks;  // or: the visible ones fit the register sets
         int win_lx, win_hx, win_ly, win_hy;  // BAG:926-939
-        if (Game::center_agent(d.opt)) {
+        if (Game::center_agent(opt)) {
             const float margin = (float)(G.visibility / 2.0 + 1);
             win_lx = (int)(G.center_x - margin);
             win_hx = (int)(G.center_x + margin);
@@ -2091,7 +2093,7 @@ struct Renderer {
         const bool try_pull = GameDrawsGrid<Game>::value && !GEN && use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024);
         // ---- requests, round 2: every table lookup of the set-up, in flight together: the background image, the images of the
         // entities (lane = slot) and of the grid object types (lane = type), the first 256 window cells
-        const ImgDesc bg_desc = (d.opt.use_backgrounds && !(d.debug_flags & 1)) ? d.assets->bg_desc[G.background_index] : ImgDesc{IMG_NONE, 0, 0, 0};
+        const ImgDesc bg_desc = (opt.use_backgrounds && !(d.debug_flags & 1)) ? d.assets->bg_desc[G.background_index] : ImgDesc{IMG_NONE, 0, 0, 0};
         PG_LANE_VAR(ImgDesc, type_desc);
         PG_LANE_ARR(int, cells0, 4);
         PG_R_LANES(l) {
@@ -2124,14 +2126,14 @@ struct Renderer {
             }
         };
         if constexpr (GameCustomBackground<Game>::value) {
-            if (d.opt.use_backgrounds && !(d.debug_flags & 1)) {
+            if (opt.use_backgrounds && !(d.debug_flags & 1)) {
                 RectD rects[4];
                 const int nr = Game::background_rects(*this, rects);
                 const ImgDesc bgi = bg_desc;
                 _Pragma("unroll") for (int k = 0; k < 4; k++)
                     if (k < nr && rects[k].w > 0) add_bg(bgi, rects[k]);
             }
-        } else if (d.opt.use_backgrounds && !(d.debug_flags & 1)) {
+        } else if (opt.use_backgrounds && !(d.debug_flags & 1)) {
             const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);
             const ImgDesc bgi = bg_desc;
             if (!GameTiledBackground<Game>::value && G.bg_tile_ratio < 0) fail(PGE_UNSUPPORTED_DRAW);  // (only fruitbot's constructor sets it)
@@ -2375,7 +2377,7 @@ struct Renderer {
                 draw_entities(0);
                 draw_entities(1);
             }
-            if (G.has_useful_vel_info && d.opt.paint_vel_info) {  // BAG:960-969, to_shade reference src/qt-utils.h:21-28
+            if (G.has_useful_vel_info && opt.paint_vel_info) {  // BAG:960-969, to_shade reference src/qt-utils.h:21-28
                 const float infodim = (float)(RES_H * .2);
                 const int ag = G.agent;
                 int s1 = (int)((float)(.5 * (double)evx(ag) / (double)G.maxspeed + .5) * 255);

@@ -113,9 +113,10 @@ bool effective_center_agent(int game_id, const GameOptions &opt, const EnvHdr &h
 }  // namespace
 
 
-bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvSnapshot &s, char *data, int length, int *written, std::string *err) {
+bool serialize_state(int game_id, const GameOptions &handle_opt, int game_n, const EnvSnapshot &s, char *data, int length, int *written, std::string *err) {
     Writer w{data, 0, (size_t)(length < 0 ? 0 : length)};
     const EnvHdr &h = s.hdr;
+    const GameOptions opt = env_options(handle_opt, h.opt_bits, h.opt_debug_mode);  // the env's own options (reference: every Game has its own)
     const std::string name = game_name_from_id(game_id);
     // Game::serialize reference src/game.cpp:170-229
     w.i(0);  // SERIALIZE_VERSION
@@ -395,14 +396,24 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
     };
     if (r.i() != 0) return bad("fassert failed 'SERIALIZE_VERSION == b->read_int()'");
     if (r.s() != game_name_from_id(game_id)) return bad("fassert failed 'game_name == b->read_string()'");
-    // options are per-handle here (one GameOptions for every env of a handle); a state saved under other options is refused
+    // reference src/game.cpp:233-246: the env adopts the options the state was saved under.  Those that select no kernel are per env here
+    // (EnvHdr::opt_bits / opt_debug_mode); distribution_mode and use_generated_assets choose the kernel instantiation, its LDS arenas and
+    // the assets of the whole handle, so a state that differs in them is refused, with the reason
     int o[9];
     for (int k = 0; k < 9; k++) o[k] = r.i();
-    const bool cen = o[5] != 0;
-    if (o[0] != opt.paint_vel_info || o[1] != opt.use_generated_assets || o[2] != opt.use_monochrome_assets || o[3] != opt.restrict_themes ||
-        o[4] != opt.use_backgrounds || o[6] != opt.debug_mode || o[7] != opt.distribution_mode || o[8] != opt.use_sequential_levels)
-        return bad("set_state: the state was saved under different game options than this handle's");
-    (void)cen;
+    if (o[7] != opt.distribution_mode) return bad("set_state: the state was saved under another distribution_mode than this handle's (the mode selects the kernels of the handle; make a handle with that mode)");
+    if (o[1] != opt.use_generated_assets) return bad("set_state: the state was saved under another use_generated_assets setting than this handle's (the option selects the assets and kernels of the handle)");
+    {
+        GameOptions eo = opt;
+        eo.paint_vel_info = o[0] != 0;
+        eo.use_monochrome_assets = o[2] != 0;
+        eo.restrict_themes = o[3] != 0;
+        eo.use_backgrounds = o[4] != 0;
+        eo.center_agent = o[5] != 0;
+        eo.use_sequential_levels = o[8] != 0;
+        h.opt_bits = env_option_bits(eo);
+        h.opt_debug_mode = o[6];
+    }
     r.i();  // use_easy_jump
     r.i();  // plain_assets
     r.i();  // physics_mode

@@ -179,6 +179,8 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
     for (auto &h : v->hdr) {
         h.level_seed_low = d.opt.level_seed_low;
         h.level_seed_high = d.opt.level_seed_high;
+        h.opt_bits = env_option_bits(d.opt);
+        h.opt_debug_mode = d.opt.debug_mode;
     }
     d.hdr = v->hdr.data();
     d.rng = v->rng.data();

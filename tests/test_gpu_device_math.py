@@ -29,6 +29,7 @@ def host(tmp_path_factory):
     L.count_sincos_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_long, C.c_void_p]
     L.collect_sincos_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_long, C.c_void_p, C.c_long, C.c_void_p]
     L.ref_sincos_scaled.argtypes = [C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_void_p]
+    L.count_puff_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_long, C.c_float, C.c_float, C.c_int, C.c_void_p]
     return L
 
 
@@ -123,3 +124,24 @@ def test_scaled_sin_cos_at_every_angle_where_the_doubles_differ(dev, host):
         bad = int((gs.view(np.uint32) != rs.view(np.uint32)).sum() + (gc.view(np.uint32) != rc.view(np.uint32)).sum())
         assert bad == 0, f"speed {speed}: {bad} of {2 * len(cand)} velocity components differ from the host libm"
     print(f"\\n{k} float angles with a last-bit difference in double; float(trig * speed) identical for all of them at speeds {SPEEDS}")
+
+
+def test_caveflyer_exhaust_puff_position_at_every_angle_where_the_doubles_differ(dev, host):
+    """The one trig call site whose result reaches serialized state through a position-dependent operand (reference
+    src/games/caveflyer.cpp:275; game_caveflyer.h set_action_xy): float(x - r * trig(theta)), r = the agent's radius (0.4f in every mode,
+    rx = ry), x = its position.  At every float angle 0 <= |theta| < 1024 where the device's sin or cos differs from the host libm's in the
+    last bit of the double, the expression is evaluated on the device's doubles and on the host's for 2048 positions across the largest
+    world (60 cells, memory mode) and the 65 floats around the wall contact x = r (tests/tools/libm_sweep.c count_puff_mismatches): no
+    puff position differs."""
+    chunk = 1 << 24
+    hi = int(np.float32(1024.0).view(np.uint32))
+    s = np.empty(chunk, np.float64)
+    c = np.empty(chunk, np.float64)
+    counts = (C.c_long * 4)()
+    for b0 in range(0, hi, chunk):
+        n = min(chunk, hi - b0)
+        dev.procgen_amd_selftest_sincos(b0, n, s.ctypes.data, c.ctypes.data)
+        host.count_puff_mismatches(s.ctypes.data, c.ctypes.data, b0, n, 0.4, 60.0, 2048, counts)
+    angles, products, evals, bad = list(counts)
+    print(f"\\ncaveflyer puff: {angles} angles with a last-bit difference, {products} differing products r * trig, {evals} positions evaluated, {bad} differing")
+    assert angles > 0 and evals > 0 and bad == 0

@@ -97,3 +97,70 @@ def test_gpu_restored_envs_keep_the_level_seed_range_they_were_saved_under(golde
     env = ProcgenGym3Env(2, game, rand_seed=77, num_levels=0)
     _replay_cross_range(gold, game, env)
     env.close()
+
+
+# ---- options adopted per env (reference src/game.cpp:233-246) --------------------------------------------------------------------------
+def _cross_option_cases():
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_cross_option_golden as M
+
+    return M.CASES
+
+
+CROSS_OPTION_CASES = _cross_option_cases()
+
+
+def _replay_cross_option(gold, name, env):
+    import zlib
+
+    env.observe()
+    env.set_state([gold[f"{name}/state0"].tobytes(), gold[f"{name}/state1"].tobytes()])
+    acts = gold[f"{name}/actions"]
+    for t in range(len(acts) + 1):
+        rew, ob, first = env.observe()
+        assert np.array_equal(rew, gold[f"{name}/rew"][t]) and np.array_equal(first.astype(np.uint8), gold[f"{name}/first"][t]), f"{name} step {t}"
+        assert np.array_equal(env.info_arrays()["level_seed"], gold[f"{name}/level_seed"][t]), f"{name} step {t}: level seeds"
+        assert [zlib.crc32(ob["rgb"][e].tobytes()) for e in range(2)] == list(gold[f"{name}/crc"][t]), f"{name} step {t}: frames"
+        if t < len(acts):
+            env.act(acts[t])
+    assert env.get_state() == [gold[f"{name}/end0"].tobytes(), gold[f"{name}/end1"].tobytes()]
+
+
+@pytest.mark.parametrize("name", sorted(CROSS_OPTION_CASES))
+def test_restored_envs_keep_the_game_options_they_were_saved_under(golden_dir, name):
+    """reference src/game.cpp:233-246: deserialize adopts the serialized options per env.  tests/golden/cross_option_state.npz (compiled
+    reference): states saved under one option set, restored into a handle made with another, continue -- steps, forced resets, frames,
+    end states -- exactly as in the reference.  Here: the kernel sources in the CPU emulation."""
+    game, _saved, made = CROSS_OPTION_CASES[name]
+    gold = np.load(os.path.join(golden_dir, "cross_option_state.npz"))
+    env = emu_harness.EmuEnv(2, game, rand_seed=88, **made)
+    _replay_cross_option(gold, name, env)
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CROSS_OPTION_CASES))
+def test_gpu_restored_envs_keep_the_game_options_they_were_saved_under(golden_dir, name):
+    from procgen_amd import ProcgenGym3Env
+
+    game, _saved, made = CROSS_OPTION_CASES[name]
+    gold = np.load(os.path.join(golden_dir, "cross_option_state.npz"))
+    env = ProcgenGym3Env(2, game, rand_seed=88, **made)
+    _replay_cross_option(gold, name, env)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_gpu_states_of_another_distribution_mode_are_refused_with_the_reason(golden_dir):
+    """what still cannot be adopted per env: distribution_mode (and use_generated_assets) select the kernel instantiation of a handle"""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from procgen_amd import ProcgenGym3Env; "
+            "a = ProcgenGym3Env(1, 'coinrun', distribution_mode='easy'); a.observe(); st = a.get_state(); "
+            "b = ProcgenGym3Env(1, 'coinrun', distribution_mode='hard'); b.observe(); b.set_state(st)") % repo
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "distribution_mode" in (r.stdout + r.stderr)
