@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <stdarg.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -39,6 +40,16 @@ namespace {
     vprintf(fmt, args);
     va_end(args);
     fflush(stdout);
+    if (const char *path = getenv("PROCGEN_AMD_FATAL_LOG")) {  // the message also goes to a file: a test runner that loses the dying process's stdout still has it
+        if (FILE *f = fopen(path, "a")) {
+            va_list again;
+            va_start(again, fmt);
+            fprintf(f, "[pid %d] fatal: ", (int)getpid());
+            vfprintf(f, fmt, again);
+            va_end(again);
+            fclose(f);
+        }
+    }
     exit(EXIT_FAILURE);
 }
 
