@@ -1682,13 +1682,41 @@ struct Renderer {
                 PG_LA(tex, g, l) = 0;
                 if (g < count) {  // wave-uniform
                     const int y = c[g].ty1 + ly;
-                    const bool in = lx < c[g].w && ly < c[g].h && y >= row0 && y < row1;
                     const int sw = cmd_src_w(c[g].aux);
-                    int sxp, syp;
-                    sample_xy(c[g], lx, y, sw, sxp, syp);
-                    const uint32_t addr = cmd_fill(c[g].aux) ? 0u : c[g].src + (uint32_t)(syp * sw + (cmd_mirrored(c[g].aux) ? (sw - 1 - sxp) : sxp));
+                    // where the lane's pixel of command g comes from: an upright sprite's 16.16 walk, or -- a turned sprite whose bounding
+                    // box fits the footprint (bossfight's bullets, round 4) -- the clamped inverse mapping of the pixel, when its row
+                    // falls into one of the command's three trapezoids and its column into that row's span (exec_rotated_pass; the
+                    // record is read where it is used, so that eight such sprites, or a mix with upright ones, share one wait for texels)
+                    bool in = lx < c[g].w && ly < c[g].h && y >= row0 && y < row1;
+                    uint32_t addr;
+                    int fi = (y - row0) * RES_W + c[g].tx1 + lx;
+                    bool turned = false;
+                    if constexpr (GameUsesRotation<Game>::value && !GEN) turned = cmd_rotated(c[g].aux);
+                    if (turned) {
+                        if constexpr (GameUsesRotation<Game>::value && !GEN) {
+                            const uint32_t *rp = &lds->rot[(c[g].basex & 63u) * ROT_WORDS];
+                            const int X = c[g].tx1 + lx, sh = (int)c[g].iy;
+                            const uint32_t Y = (uint32_t)y;
+                            const bool s0 = Y >= rp[6] && Y < rp[7], s1 = Y >= rp[12] && Y < rp[13], s2 = Y >= rp[18] && Y < rp[19];
+                            const uint32_t *tp = rp + (s0 ? 6 : (s1 ? 12 : 18));
+                            const uint32_t k = Y - tp[0];
+                            int from_x = (int)(tp[2] + k * tp[3]) >> 16, to_x = (int)(tp[4] + k * tp[5]) >> 16;
+                            if (from_x < 0) from_x = 0;
+                            if (to_x > RES_W) to_x = RES_W;
+                            in = in && (s0 || s1 || s2) && X >= from_x && X < to_x;
+                            int uu = (int)((uint32_t)X * rp[2] + Y * rp[3] + rp[0]) >> 16;
+                            int vv = (int)((uint32_t)X * rp[4] + Y * rp[5] + rp[1]) >> 16;
+                            uu = uu < 0 ? 0 : (uu > sw - 1 ? sw - 1 : uu);
+                            vv = vv < 0 ? 0 : (vv > sh - 1 ? sh - 1 : vv);
+                            addr = c[g].src + (uint32_t)(vv * sw + (cmd_mirrored(c[g].aux) ? (sw - 1 - uu) : uu));
+                        }
+                    } else {
+                        int sxp, syp;
+                        sample_xy(c[g], lx, y, sw, sxp, syp);
+                        addr = cmd_fill(c[g].aux) ? 0u : c[g].src + (uint32_t)(syp * sw + (cmd_mirrored(c[g].aux) ? (sw - 1 - sxp) : sxp));
+                    }
                     PG_LA(tex, g, l) = cmd_fill(c[g].aux) ? c[g].src : d.pixels[in ? addr : 0u];  // branch-free: masked-off lanes fetch word 0
-                    PG_LA(fbi, g, l) = in ? ((y - row0) * RES_W + c[g].tx1 + lx) : (BAND_ROWS * RES_W + l);
+                    PG_LA(fbi, g, l) = in ? fi : (BAND_ROWS * RES_W + l);
                 }
             }
         }
@@ -1753,8 +1781,9 @@ struct Renderer {
             valid = valid2;
             valid2 = 0;
         }
+        // (a turned sprite joins the groups of small ones when the game has rotation records and its bounding box fits; GEN draws them on Qt's generic route)
         const uint64_t small = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && ((PG_LV(r.geom, l) >> 14) & 0x7fu) <= 8u && ((PG_LV(r.geom, l) >> 21) & 0x7fu) <= 8u &&
-                                                !cmd_rotated(PG_LV(r.aux, l)) && !cmd_tiled(PG_LV(r.aux, l)));
+                                                (!cmd_rotated(PG_LV(r.aux, l)) || (GameUsesRotation<Game>::value && !GEN && !(d.debug_flags & 524288))) && !cmd_tiled(PG_LV(r.aux, l)));
         while (valid) {
             const int k = pg_ctz64(valid);
             if ((small >> k) & 1ull) {
