@@ -1562,14 +1562,20 @@ struct Env {
                 new_agent = CAP - 1;
             }
             if (keep != valid || kept != base) {
-                for (int f = 0; f < EF_COUNT; f++) {
-                    PG_FOR_LANES(l) { s->tmp[l] = s->ent[f * CAP + base + l]; }
-                    PG_SYNC_E();
-                    PG_FOR_LANES(l) {
-                        if (keep & (1ull << l)) s->ent[f * CAP + kept + pg_popc64(keep & pg_mask_lt(l))] = s->tmp[l];
-                    }
-                    PG_SYNC_E();
+                // the chunk's 21 fields travel through registers in one round -- all reads, one fence, all writes (a slot only moves
+                // down) -- instead of field by field through a staging row (42 fences; coinrun erases an expired trail in most steps)
+                PG_LANE_ARR(uint32_t, v, EF_COUNT);
+                PG_FOR_LANES(l) {
+                    _Pragma("unroll") for (int f = 0; f < EF_COUNT; f++) PG_LA(v, f, l) = s->ent[f * CAP + base + l];
                 }
+                PG_SYNC_E();
+                PG_FOR_LANES(l) {
+                    if (keep & (1ull << l)) {
+                        const int dst = kept + pg_popc64(keep & pg_mask_lt(l));
+                        _Pragma("unroll") for (int f = 0; f < EF_COUNT; f++) s->ent[f * CAP + dst] = PG_LA(v, f, l);
+                    }
+                }
+                PG_SYNC_E();
             }
             kept += pg_popc64(keep);
         }
@@ -1924,7 +1930,36 @@ struct Env {
 
     // ======================================================================================================
     // HBM <-> LDS staging of one env
+    // Requests first, uses after: the grid slab and the first SPEC entity slots are asked for before the header is read (their
+    // addresses depend on the env alone; most envs hold fewer than 16 entities -- coinrun's median is 7 -- and a speculative slot
+    // costs no extra sector: a field's 16 words are one 64-byte line), so a step starts with one round trip to memory, not three.
+    static constexpr int SPEC = 16;
     PG_DEV void load_env(bool with_entities = true) {
+        const uint32_t *ge = d.ents + ent_table_base(env, d.ent_cap);
+        const uint32_t fstride = (uint32_t)d.ent_cap;  // words between two fields of one slot
+        constexpr int NV = (int)((sizeof(cell_t) * Game::MAX_CELLS + 15) / 16);  // whole grid slab, 16 B per lane per access
+        constexpr int NVL = (NV + 63) / 64;
+        const pg_u4 *gg = reinterpret_cast<const pg_u4 *>(d.grid + (size_t)env * d.grid_bytes);
+        PG_LANE_ARR(uint32_t, ev, EF_COUNT);
+        PG_LANE_ARR(uint32_t, gvx, NVL);  // (four scalar arrays: an array of 16-byte structs stays in scratch memory)
+        PG_LANE_ARR(uint32_t, gvy, NVL);
+        PG_LANE_ARR(uint32_t, gvz, NVL);
+        PG_LANE_ARR(uint32_t, gvw, NVL);
+        PG_FOR_LANES(l) {
+            _Pragma("unroll") for (int f = 0; f < EF_COUNT; f++) PG_LA(ev, f, l) = 0;
+            if (with_entities && l < SPEC) {
+                const uint32_t *gp = ge + (uint32_t)l;
+                _Pragma("unroll") for (int f = 0; f < EF_COUNT; f++) PG_LA(ev, f, l) = gp[f * fstride];
+            }
+            _Pragma("unroll") for (int k = 0; k < NVL; k++) {
+                const int i = k * 64 + l;
+                const pg_u4 q = gg[i < NV ? i : 0];
+                PG_LA(gvx, k, l) = q.x;
+                PG_LA(gvy, k, l) = q.y;
+                PG_LA(gvz, k, l) = q.z;
+                PG_LA(gvw, k, l) = q.w;
+            }
+        }
         {
             const EnvHdr *h = d.hdr + env;  // wave-uniform address
 #define PG_X(type, name) G.name = h->name;
@@ -1933,11 +1968,14 @@ struct Env {
         }
         opt = env_options(d.opt, G.opt_bits, G.opt_debug_mode);
         const int n = with_entities ? G.n_ents : 0;
-        const uint32_t *ge = d.ents + ent_table_base(env, d.ent_cap);
-        const uint32_t fstride = (uint32_t)d.ent_cap;  // words between two fields of one slot
+        PG_FOR_LANES(l) {
+            if (l < SPEC && l < n) {
+                _Pragma("unroll") for (int f = 0; f < EF_COUNT; f++) s->ent[f * CAP + l] = PG_LA(ev, f, l);
+            }
+        }
         for (int base = 0; base < n; base += 64) {
             PG_FOR_LANES(l) {
-                if (base + l < n) {
+                if (base + l < n && base + l >= SPEC) {
                     uint32_t v[EF_COUNT];  // all field loads in flight before the first LDS store (the loops must stay unrolled:
                                            // rolled, every load waits for the previous one)
                     const uint32_t *gp = ge + (uint32_t)(base + l);
@@ -1946,13 +1984,12 @@ struct Env {
                 }
             }
         }
-        {   // whole grid slab, 16 B per lane per access
-            constexpr int NV = (int)((sizeof(cell_t) * Game::MAX_CELLS + 15) / 16);
-            const pg_u4 *gg = reinterpret_cast<const pg_u4 *>(d.grid + (size_t)env * d.grid_bytes);
+        {
             pg_u4 *lg = reinterpret_cast<pg_u4 *>(s->grid);
-            for (int base = 0; base < NV; base += 64) {
-                PG_FOR_LANES(l) {
-                    if (base + l < NV) lg[base + l] = gg[base + l];
+            PG_FOR_LANES(l) {
+                _Pragma("unroll") for (int k = 0; k < NVL; k++) {
+                    const int i = k * 64 + l;
+                    if (i < NV) lg[i] = pg_u4{PG_LA(gvx, k, l), PG_LA(gvy, k, l), PG_LA(gvz, k, l), PG_LA(gvw, k, l)};
                 }
             }
         }
