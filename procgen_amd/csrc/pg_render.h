@@ -2270,7 +2270,16 @@ struct Renderer {
                         }
                     }
                     const DrawCmd bc = unpack(g, bx, sy, ix, iy, sr, au);
-                    if (g != 0 && bc.ty1 < row1 && bc.ty1 + bc.h > row0) exec_large(bc);
+                    if (g != 0 && bc.ty1 < row1 && bc.ty1 + bc.h > row0) {
+                        // several background images (fruitbot's column of tiles, starpilot's own rects) go by LDS-DMA as well; two of them
+                        // may share a pixel row (each is rounded on its own), so all but the last are joined before the next is issued
+                        if (bg_dma_ok(bc)) {
+                            exec_bg_dma(bc);
+                            if (k + 1 < bg_count) dma_join();
+                        } else {
+                            exec_large(bc);
+                        }
+                    }
                 }
             }
             phase(1);
