@@ -88,6 +88,42 @@ def test_sixteen_game_joint_handle_at_its_one_gpu_share():
         assert_rollouts_equal(ref, got, f"joint handle, {game}")
 
 
+def test_full_size_long_horizon_against_a_strided_oracle_sample():
+    """BASELINE configs[1] at its full size over a long horizon: coinrun, 65536 envs, 1200 steps -- past the 1000-step timeout, so every
+    episode has ended at least once, the envs are desynchronised, trail-heavy envs sit in the tier-1 / tier-2 arenas and the reset rate is
+    at its long-run level (the state bench.py's steady_state object measures).  A strided sample of 256 envs (every 256th) is replayed by
+    the oracle: rew / first / info at every step, the sample's frames every 100 steps and at the end."""
+    game, n, m, steps = "coinrun", 65536, 256, 1200
+    stride = n // m
+    idx = np.arange(m) * stride
+    env = make_env(n, game, extra_options={"host_observations": False})
+    b = DeviceBuffers()
+    env._lib.procgen_amd_device_buffers.argtypes = [C.c_void_p, C.POINTER(DeviceBuffers)]
+    assert env._lib.procgen_amd_device_buffers(env._handle, C.byref(b)) == 0 and b.num_envs == n
+    orc = oracle_env.OracleEnv(m, game, rand_seed=23, env_offset=0, env_stride=stride)
+    rng = np.random.RandomState(77)
+    episodes = 0
+    for t in range(steps + 1):
+        rew, _, first = env.observe()
+        orew, oob, ofirst = orc.observe()
+        assert np.array_equal(rew[idx], orew) and np.array_equal(first[idx], ofirst), f"rew / first at step {t}"
+        for k, v in orc.info_arrays().items():
+            assert np.array_equal(env.info_arrays()[k][idx], v), f"{k} at step {t}"
+        if t % 100 == 0 or t == steps:
+            for j, e in enumerate(idx):
+                frame = hip_memcpy_dtoh(b.ob + int(e) * 12288, 12288).reshape(64, 64, 3)
+                assert np.array_equal(frame, oob["rgb"][j]), f"frame of env {e} at step {t}"
+        if t:
+            episodes += int(ofirst.sum())
+        if t < steps:
+            ac = rng.randint(0, 15, size=(n,), dtype=np.int32)
+            env.act(ac)
+            orc.act(ac[idx])
+    env.close()
+    orc.close()
+    assert episodes >= m, f"only {episodes} episode ends in the sample: the horizon did not desynchronise it"
+
+
 def noop_heavy_actions(n, steps, seed, p_noop=0.97):
     rng = np.random.RandomState(seed)
     out = []
