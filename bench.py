@@ -270,7 +270,7 @@ def main():
 
     if rank == 0:
         traffic = None  # HBM bytes per launch (= one step) from the committed rocprofv3 PMC passes, same workload only
-        tpath = os.path.join(REPO, "profiles", "r03_hbm_traffic.json")
+        tpath = os.path.join(REPO, "profiles", "r04_hbm_traffic.json")
         if os.path.exists(tpath) and args.game == "coinrun":
             tj = json.load(open(tpath))
             if tj.get("num_envs") == n:

@@ -215,6 +215,9 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
             if (mode != 0) hipLaunchKernelGGL(reset_list<Game>, dim3(count < 1024 ? count : 1024), dim3(64), 0, st, d, c, base);
         }
         PG_TRY(launch_paint_backgrounds(d, base, count, st));  // (after the list kernels: their envs lie in every chunk)
+        // rew / first / info of this chunk's envs, and the list counters, are final here (step, list and reset kernels done): what the
+        // early download of the step's small outputs waits for (libenv_hip.cpp VecGame::launch)
+        if (ls.outputs_done[c]) PG_TRY(hipEventRecord(ls.outputs_done[c], st));
         if (!(d.debug_flags & 16)) launch_render<Game>(d, base, count, st, c == 0);
     }
     for (int k = 0; k < 2; k++) {
