@@ -33,6 +33,7 @@ struct GameEntry {
     int (*host_tables)(const GameOptions &opt, uint32_t *out, int max_words);  // GameHostTables<Game>::build (pg_env.h)
     bool (*use_block_asset)(int type);  // GameBlockAsset<Game>::is (pg_env.h)
     hipError_t (*render_human)(const DevCtx &, int env_base, int count, hipStream_t);  // the 512 x 512 info frames of envs [env_base, env_base + count) (pg_human.h)
+    bool split_reset;  // GameSplit<Game>::value: ended episodes are finished by reset_list kernels behind the step kernels
 };
 constexpr int MAX_GAME_TABLE_WORDS = 1024;
 // mode 0: initial reset + first observation of every env; mode 1: one step
@@ -45,6 +46,7 @@ void game_limits(int game_id, int *ent_cap_hbm, int *grid_bytes);
 void game_init_state(int game_id, int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
 int game_host_tables(int game_id, const GameOptions &opt, uint32_t *out, int max_words);
 bool (*game_use_block_asset(int game_id))(int);
+bool game_split_reset(int game_id);
 hipError_t launch_paint_backgrounds(const DevCtx &d, int env_base, int count, hipStream_t stream);  // use_generated_assets (pg_bgpaint.h); no-op otherwise
 // device math self-tests (kernels.hip)
 hipError_t selftest_bigfish_radius(const float *d_in, float *d_out, int n);

@@ -68,6 +68,10 @@ int game_host_tables(int game_id, const GameOptions &opt, uint32_t *out, int max
     return e ? e->host_tables(opt, out, max_words) : 0;
 }
 
+bool game_split_reset(int game_id) {
+    const GameEntry *e = find(game_id);
+    return e ? e->split_reset : false;
+}
 bool (*game_use_block_asset(int game_id))(int) {
     const GameEntry *e = find(game_id);
     return e ? e->use_block_asset : nullptr;

@@ -258,6 +258,7 @@ const GameEntry *PG_CAT(game_entry_, PG_GAME)() {
         GameHostTables<PG_GAME>::build,
         GameBlockAsset<PG_GAME>::is,
         launch_human<PG_GAME>,
+        GameSplit<PG_GAME>::value,
     };
     return &e;
 }

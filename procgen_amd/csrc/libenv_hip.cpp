@@ -393,7 +393,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         for (int c = 0; c < MAX_CHUNKS; c++) HIP_CHECK(hipEventCreateWithFlags(&ev_step[c], hipEventDisableTiming));
         for (int k = 0; k < 3; k++) HIP_CHECK(hipEventCreateWithFlags(&ev_side[k], hipEventDisableTiming));
         const char *es = getenv("PROCGEN_AMD_EARLY_SMALL");
-        if (!(es && atoi(es) == 0) && !getenv("PROCGEN_AMD_DEBUG")) {
+        // (not for the split-reset games: their outputs are final only behind the reset kernels, and the extra stream cost jumper 7 %)
+        if (!(es && atoi(es) == 0) && !getenv("PROCGEN_AMD_DEBUG") && !game_split_reset(kernel_id)) {
             HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&ev_small, hipEventDisableTiming));
             for (int c = 0; c < MAX_CHUNKS; c++) HIP_CHECK(hipEventCreateWithFlags(&ev_out[c], hipEventDisableTiming));

@@ -45,9 +45,24 @@ struct EmuVec {
     long long wave_steps = 0, split_resets = 0;  // env-steps taken, and how many of them went on to the reset kernel (SPLIT_RESET games)
 };
 
+// PG_EMU_POISON_LDS=1: every "workgroup" starts on an LDS arena full of pseudo-random words, as on a GPU that other processes' kernels
+// share (LDS is not cleared between workgroups): a read of a word the kernel has not written shows up as a mismatch against the oracle
+template <class T>
+static void poison_lds(T *lds) {
+    if (!getenv("PG_EMU_POISON_LDS")) return;
+    static uint64_t x = 0x9e3779b97f4a7c15ull;
+    uint32_t *w = reinterpret_cast<uint32_t *>(lds);
+    for (size_t i = 0; i < sizeof(T) / 4; i++) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        w[i] = (uint32_t)(x >> 16);
+    }
+}
 template <class Game, int CAP>
 static void run_env(EmuVec *v, int env, int mode) {
     static Lds<Game, CAP> lds;  // one "workgroup" at a time
+    poison_lds(&lds);
     Env<Game, CAP> e(v->d, env, &lds);
     e.run(mode);
 }
@@ -56,6 +71,7 @@ template <class Game, int CAP>
 static void run_step_env(EmuVec *v, int env) {
     if constexpr (GameSplit<Game>::value) {
         static Lds<Game, CAP, false> lds;
+        poison_lds(&lds);
         Env<Game, CAP, true> e(v->d, env, &lds);
         e.run(1);
         if (v->hdr[env].big == ROUTE_RESET) {
@@ -94,10 +110,12 @@ static void run_all(EmuVec *v, int mode) {
     static RenderLdsT<Game> rlds;
     for (int e = 0; e < v->n; e++) {  // "render kernel": one wave per env
         if (v->d.gen_bg) {
+            poison_lds(&rlds);
             Renderer<Game, true> r(v->d, e, &rlds);
             r.render_env();
             continue;
         }
+        poison_lds(&rlds);
         Renderer<Game> r(v->d, e, &rlds);
         r.render_env();
     }

@@ -348,3 +348,18 @@ def test_no_capacity_or_draw_shape_exit_under_the_accepted_option_surface():
         assert sweep.run(game, mode, center, 6, 120, 13) == [], (game, mode, center)
         n += 1
     assert n == 2 * (16 * 2 + 4 + 6)
+
+
+@pytest.mark.parametrize("game,kw", [("coinrun", {}), ("bossfight", {}), ("fruitbot", {}), ("maze", {"distribution_mode": 10}), ("jumper", {"distribution_mode": 0}),
+                                     ("caveflyer", {"distribution_mode": 10}), ("chaser", {"distribution_mode": 2}), ("leaper", {}), ("dodgeball", {}), ("starpilot", {})])
+def test_kernels_read_no_lds_word_they_did_not_write(monkeypatch, game, kw):
+    """LDS is not cleared between workgroups: on a GPU that other processes' kernels share, a workgroup finds whatever the previous one --
+    any process's -- left there.  PG_EMU_POISON_LDS fills every emulated workgroup's arena (step, reset and render kernels) with
+    pseudo-random words before it runs; a word read before it was written would then show as a mismatch against the oracle.  (Round 4:
+    looked for after rare failures that only ever appeared with four test processes sharing the GPU; none found.)"""
+    monkeypatch.setenv("PG_EMU_POISON_LDS", "1")
+    n, steps = 10, 220
+    acts = action_stream(n, steps, seed=13)
+    a = rollout(oracle_env.OracleEnv(n, game, rand_seed=29, **kw), acts)
+    b = rollout(emu_harness.EmuEnv(n, game, rand_seed=29, **kw), acts)
+    assert_rollouts_equal(a, b, f"{game} {kw} on poisoned LDS")
