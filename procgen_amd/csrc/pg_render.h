@@ -162,15 +162,19 @@ struct RenderLdsT {
     uint32_t fb[BAND_ROWS * RES_W + 64];  // the band being rasterized, 0xffRRGGBB (+ a dump row for masked-off lanes)
     // Tables that are never alive together share their words (the arena bounds how many frames a CU renders at a time: 8 KB is the
     // step from four to five waves per SIMD): the per-cell path's axis table `ax` (setup_tile_axes) lies over ci -- a frame is drawn in
-    // pull form or cell by cell --, typesz (read while the pull tables are built) over seamcols (written when they are done), and
-    // typeany (set-up only) over fb's dump row (band passes only); see Renderer::ax / typeany / typesz.
+    // pull form or cell by cell --, typesz (read while the pull tables are built) over seamcols (written when they are done); see
+    // Renderer::ax / typesz.
     uint32_t ci[2][64];              // screen column -> the (at most two) cell columns covering it
     uint32_t ri[2][64];              // screen row    -> the (at most two) cell rows covering it
     uint32_t seamcols[64];           // screen columns covered by two cell columns
     uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of this frame (build_type_table)
     uint8_t srcx[GameDrawsGrid<Game>::value ? 3 : 1][2][64];    // size classes 1..3: screen column -> source column, per covering slot
     uint16_t srcyw[GameDrawsGrid<Game>::value ? 3 : 1][2][64];  // size classes 1..3: screen row -> source row * image width
-    uint32_t cellimg[GameDrawsGrid<Game>::value ? GamePullCells<Game>::value : 1];  // window cell -> source image (atlas offset | opaque<<31), CELL_NONE = nothing to draw
+    // window cell -> grid object type (CELL8_NONE: nothing to draw); the type's image is typeany[type].  One byte per cell (round 4; a word
+    // per cell with the image in it cost the games with large windows 4 KB of the arena, i.e. two of eleven resident frames per CU)
+    uint8_t cellimg[GameDrawsGrid<Game>::value ? GamePullCells<Game>::value : 4];
+    uint32_t typeany[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of any size: atlas offset | size class<<27 | opaque<<31 (pull form)
+    uint32_t fillcmd[GameHasGridFills<Game>::value ? 2 * 256 : 1];  // solid-colour cells of a pull-form frame: (geom, colour) pairs
     uint32_t rot[GameUsesRotation<Game>::value ? 64 * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane
 };
 template <bool GEN>
@@ -181,6 +185,7 @@ struct CmdExtra<true> {
     PG_LANE_VAR(uint32_t, e1);
 };
 constexpr uint32_t CELL_NONE = 0xffffffffu;
+constexpr uint8_t CELL8_NONE = 0xffu, CELL8_FILL = 0xfeu;  // RenderLdsT::cellimg codes beside the type ids 0..63
 template <int N>
 struct PgInt {
     static constexpr int value = N;
@@ -205,7 +210,7 @@ struct Renderer {
     RenderLds *lds;
     uint32_t *fb;  // the band being rasterized: BAND_ROWS x 64 words of 0xffRRGGBB
     uint32_t *ax;  // tile-axis scratch (see setup_tile_axes): 128 words over ci
-    uint32_t *typeany;  // grid object type -> cell image of any size: atlas offset | size class<<27 | opaque<<31 (pull form); over fb's dump row
+    uint32_t *typeany;  // = lds->typeany
     uint32_t *typesz;   // its width<<16 | height; over seamcols
     EnvHdr G;
     const uint32_t *ge;  // this env's entity table in HBM
@@ -213,7 +218,7 @@ struct Renderer {
     const typename Game::cell_t *gg;
     int row0, row1;  // band rows [row0, row1)
 
-    PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(&lds_->ci[0][0]), typeany(lds_->fb + BAND_ROWS * RES_W), typesz(lds_->seamcols) {
+    PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(&lds_->ci[0][0]), typeany(lds_->typeany), typesz(lds_->seamcols) {
         ge = d.ents + ent_table_base(env, d.ent_cap);
         ecap = d.ent_cap;
         gg = reinterpret_cast<const typename Game::cell_t *>(d.grid + (size_t)env * d.grid_bytes);
@@ -830,16 +835,16 @@ struct Renderer {
                                                    bool b = false;
                                                    if (cidx < ncell) {
                                                        const int type = PG_LA(types, q, l);
-                                                       uint32_t v = CELL_NONE;
+                                                       uint8_t v = CELL8_NONE;
                                                        bool is_fill = false;
                                                        if constexpr (GameHasGridFills<Game>::value) is_fill = Game::is_grid_fill(*this, type);
                                                        if (is_fill) {
-                                                           v = CELL_FILL;
+                                                           v = CELL8_FILL;
                                                        } else if (type >= 0 && type < 64) {
                                                            const uint32_t tv = typeany[type];
                                                            if (tv == TYPE_SLOW) b = true;
                                                            else if (tv != CELL_NONE) {
-                                                               v = (uint32_t)type;
+                                                               v = (uint8_t)type;
                                                                present[type] = 1;  // several lanes may store the same 1
                                                            }
                                                        } else if (type != INVALID_OBJ && type != SPACE) {
@@ -888,11 +893,8 @@ struct Renderer {
             PG_R_LANES(l) {
                 PG_LV(has, l) = 0;
                 if (base + l < ncell) {
-                    const uint32_t t = lds->cellimg[base + l];
-                    if (t != CELL_NONE && t != CELL_FILL) {
-                        lds->cellimg[base + l] = typeany[t];
-                        PG_LV(has, l) = 1;
-                    }
+                    const uint8_t t = lds->cellimg[base + l];
+                    if (t != CELL8_NONE && t != CELL8_FILL) PG_LV(has, l) = 1;  // (the cell keeps its type id: pull_fetch goes through typeany)
                 }
             }
             // cells are x-major (index = column * ny_full + row): fold the chunk's mask onto the rows, column by column
@@ -928,7 +930,7 @@ struct Renderer {
             // image cells only if no neighbouring cell's rect reaches the pixels they paint (their own cell draws
             // nothing else): then no draw order between them and anything else in the grid pass is observable.
             int nfill = 0;
-            const int fill_cap = (GamePullCells<Game>::value - ncell) / 2;
+            const int fill_cap = 256;  // RenderLdsT::fillcmd (more solid-colour cells on screen: the per-cell path draws the frame)
             for (int base = 0; base < ncell; base += 64) {
                 PG_LANE_VAR(uint32_t, fg);
                 PG_LANE_VAR(uint32_t, fcol);
@@ -937,7 +939,7 @@ struct Renderer {
                                                         const int cidx = base + l;
                                                         PG_LV(fg, l) = 0;
                                                         PG_LV(fcol, l) = 0;
-                                                        if (cidx < ncell && lds->cellimg[cidx] == CELL_FILL) {
+                                                        if (cidx < ncell && lds->cellimg[cidx] == CELL8_FILL) {
                                                             const int cx = (int)(((uint32_t)cidx * ny_inv) >> 20);
                                                             const int cy = cidx - cx * ny_full;
                                                             const int x = win_lx + cx, y = win_ly + cy;
@@ -957,7 +959,7 @@ struct Renderer {
                                                             }
                                                             PG_LV(fg, l) = g;
                                                             PG_LV(fcol, l) = sc;
-                                                            lds->cellimg[cidx] = CELL_NONE;
+                                                            lds->cellimg[cidx] = CELL8_NONE;
                                                         }
                                                         bad;
                                                     }));
@@ -968,8 +970,8 @@ struct Renderer {
                 PG_R_LANES(l) {
                     if ((vis >> l) & 1ull) {
                         const int slot = nfill + pg_popc64(vis & pg_mask_lt(l));
-                        lds->cellimg[ncell + 2 * slot] = PG_LV(fg, l);
-                        lds->cellimg[ncell + 2 * slot + 1] = PG_LV(fcol, l);
+                        lds->fillcmd[2 * slot] = PG_LV(fg, l);
+                        lds->fillcmd[2 * slot + 1] = PG_LV(fcol, l);
                     }
                 }
                 nfill += cnt;
@@ -1042,7 +1044,8 @@ struct Renderer {
     PG_DEV bool pull_fetch(uint32_t ce, uint32_t re, int sc, int sr, int x, int y, int ny_full, int ref_w, uint32_t &tex, bool &opaque) const {
         const uint32_t both = ce & re;
         const bool covered = (both >> 31) != 0;
-        const uint32_t cell = lds->cellimg[((ce >> 12) & 0x1fu) * (uint32_t)ny_full + ((re >> 12) & 0x1fu)];
+        const uint32_t ct = lds->cellimg[((ce >> 12) & 0x1fu) * (uint32_t)ny_full + ((re >> 12) & 0x1fu)];
+        const uint32_t cell = ct < 64u ? typeany[ct & 63u] : CELL_NONE;
         opaque = (cell >> 31) != 0;
         const bool v0 = ((both >> 30) & 1u) != 0;
         uint32_t rel = (re & 0xfffu) * (uint32_t)ref_w + (ce & 0xfffu);
@@ -2212,7 +2215,7 @@ struct Renderer {
         build_type_table(type_desc);
         phase(10);
         bool pull = false, pull_multi = false;
-        int pull_nfill = 0, pull_ncell = nx * ny_full;
+        int pull_nfill = 0;
         if constexpr (GameDrawsGrid<Game>::value)
             pull = try_pull && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, pull_multi, pull_nfill, cells0);
 
@@ -2319,9 +2322,9 @@ struct Renderer {
                             CmdRegs r;
                             PG_R_LANES(l) {
                                 const bool in = base + l < pull_nfill;
-                                const int si = pull_ncell + 2 * (in ? base + l : 0);
-                                PG_LV(r.geom, l) = in ? lds->cellimg[si] : 0u;
-                                PG_LV(r.src, l) = in ? lds->cellimg[si + 1] : 0u;
+                                const int si = 2 * (in ? base + l : 0);
+                                PG_LV(r.geom, l) = in ? lds->fillcmd[si] : 0u;
+                                PG_LV(r.src, l) = in ? lds->fillcmd[si + 1] : 0u;
                                 PG_LV(r.aux, l) = cmd_aux(1, false, true, 256) | (1u << 26);
                                 PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = 0;
                             }
