@@ -13,6 +13,7 @@ struct MinerScratch {
 
 struct Miner {
     static constexpr int GAME_ID = GAME_MINER;
+    static constexpr int RENDER_MIN_WAVES = 5;  // the renderer fits 96 VGPRs without scratch and 8136 B of LDS: five waves per SIMD (kernels_game.hip)
     static constexpr const char *NAME = "miner";
     typedef uint8_t cell_t;
     static constexpr int MAX_CELLS = 35 * 35;  // memory mode (miner.cpp:124-126)

@@ -9,6 +9,7 @@ namespace pgamd {
 
 struct Ninja : BagDefaults<Ninja> {
     static constexpr int GAME_ID = GAME_NINJA;
+    static constexpr int RENDER_MIN_WAVES = 5;  // the renderer fits 96 VGPRs without scratch and 8136 B of LDS: five waves per SIMD (kernels_game.hip)
     // pg_env.h GameParSmart: blocking / reflecting targets of this game are wall types only, never a smart entity's type,
     // and the hooks basic_step_object calls touch nothing but the moving object
     static constexpr bool PAR_SMART = true;

@@ -162,11 +162,11 @@ struct RenderLdsT {
     uint32_t fb[BAND_ROWS * RES_W + 64];  // the band being rasterized, 0xffRRGGBB (+ a dump row for masked-off lanes)
     // Tables that are never alive together share their words (the arena bounds how many frames a CU renders at a time: 8 KB is the
     // step from four to five waves per SIMD): the per-cell path's axis table `ax` (setup_tile_axes) lies over ci -- a frame is drawn in
-    // pull form or cell by cell --, typesz (read while the pull tables are built) over seamcols (written when they are done); see
-    // Renderer::ax / typesz.
+    // pull form or cell by cell --, typesz (set-up only) over words 128..191 of the band buffer (idle during the set-up; build_pull_tables
+    // keeps its scratch in words 0..127, the entity commands are staged there only after the pull tables are done); see Renderer::ax / typesz.
     uint32_t ci[2][64];              // screen column -> the (at most two) cell columns covering it
     uint32_t ri[2][64];              // screen row    -> the (at most two) cell rows covering it
-    uint32_t seamcols[64];           // screen columns covered by two cell columns
+    uint8_t seamcols[64];            // screen columns covered by two cell columns
     uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of this frame (build_type_table)
     uint8_t srcx[GameDrawsGrid<Game>::value ? 3 : 1][2][64];    // size classes 1..3: screen column -> source column, per covering slot
     uint16_t srcyw[GameDrawsGrid<Game>::value ? 3 : 1][2][64];  // size classes 1..3: screen row -> source row * image width
@@ -211,14 +211,14 @@ struct Renderer {
     uint32_t *fb;  // the band being rasterized: BAND_ROWS x 64 words of 0xffRRGGBB
     uint32_t *ax;  // tile-axis scratch (see setup_tile_axes): 128 words over ci
     uint32_t *typeany;  // = lds->typeany
-    uint32_t *typesz;   // its width<<16 | height; over seamcols
+    uint32_t *typesz;   // its width<<16 | height; over fb[128..191]
     EnvHdr G;
     const uint32_t *ge;  // this env's entity table in HBM
     int ecap;
     const typename Game::cell_t *gg;
     int row0, row1;  // band rows [row0, row1)
 
-    PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(&lds_->ci[0][0]), typeany(lds_->typeany), typesz(lds_->seamcols) {
+    PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(&lds_->ci[0][0]), typeany(lds_->typeany), typesz(lds_->fb + 128) {
         ge = d.ents + ent_table_base(env, d.ent_cap);
         ecap = d.ent_cap;
         gg = reinterpret_cast<const typename Game::cell_t *>(d.grid + (size_t)env * d.grid_bytes);
@@ -1032,7 +1032,7 @@ struct Renderer {
                                }));
         }
         PG_R_LANES(l) {
-            if ((colseam >> l) & 1ull) lds->seamcols[pg_popc64(colseam & pg_mask_lt(l))] = (uint32_t)l;
+            if ((colseam >> l) & 1ull) lds->seamcols[pg_popc64(colseam & pg_mask_lt(l))] = (uint8_t)l;
         }
         PG_SYNC();
         return true;
