@@ -492,6 +492,11 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     if (d.debug_flags & 8192) d.wave_trace = dev_alloc<unsigned long long>(N * 32);
     HIP_CHECK(hipHostMalloc((void **)&h_action, N * 4 + 16, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_small, small_bytes + 16, hipHostMallocDefault));
+    // dev_alloc clears its arrays with hipMemset, i.e. on the NULL stream, and this handle's kernels run on non-blocking streams, which the
+    // null stream does not order itself against.  Whether hipMemset returns only when the fill is done is the runtime's business (CUDA's
+    // contract says it need not); recycled device memory holding a previous handle's data under a fill that lands late would explain the rare
+    // failures seen in long-lived test processes under GPU sharing.  One join here makes the question moot.
+    HIP_CHECK(hipDeviceSynchronize());
 }
 
 VecGame::~VecGame() {
