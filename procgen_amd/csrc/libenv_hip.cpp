@@ -837,6 +837,7 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     HIP_CHECK(hipMemcpy(d.prev_level_seed + e, &s.hdr.prev_level_seed, 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.prev_level_complete + e, &plc, 1, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.level_seed + e, &s.hdr.current_level_seed, 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipStreamSynchronize(nullptr));  // the uploads above ran on the null stream: joined before the handle's (non-blocking) stream reads them
     HIP_CHECK(hipMemsetAsync(d.error, 0, sizeof(int), stream));
     HIP_CHECK(launch_render_one(kernel_id, d, e, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -863,6 +864,7 @@ void VecGame::flush_routes() {
     HIP_CHECK(hipMemcpy(d_route[cur], h_route.data(), num_envs, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d_big_list[cur], lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d_big_count[cur], count, sizeof(count), hipMemcpyHostToDevice));
+    HIP_CHECK(hipStreamSynchronize(nullptr));  // (null-stream uploads, read next by kernels on the handle's non-blocking streams)
     memcpy(host_list_count, count, sizeof(count));
     route_dirty = false;
 }
