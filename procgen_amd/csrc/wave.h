@@ -53,7 +53,6 @@ struct PgEmuLaneScope {
 // lds_base[l].  The copy is asynchronous there: pg_dma_join() before the LDS words are read or overwritten.
 #define PG_DMA_DWORD(gptr, lds_base, l) ((lds_base)[l] = *(gptr))
 #define PG_DMA_JOIN() ((void)0)
-#define PG_SCHED_FENCE() ((void)0)
 #define PG_BALLOT(l, pred)                              \
     ({                                                  \
         uint64_t m_ = 0;                                \
@@ -137,7 +136,6 @@ __device__ __forceinline__ int pg_lane_opaque() {
 #define PG_DMA_JOIN() __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // nothing is scheduled across this point: keeps the loads of the next unrolled iteration from being hoisted over this one's arithmetic
 // (and their results from piling up in registers)
-#define PG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PG_BALLOT(l, pred)                              \
     ({                                                  \
         const int l = PG_LANE_ID();                     \
