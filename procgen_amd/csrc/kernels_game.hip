@@ -114,10 +114,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GEN ? 1 : Ga
     if (d.clear_lists && blockIdx.x == 0 && threadIdx.x < LIST_COUNTERS) const_cast<int *>(d.big_count)[threadIdx.x] = 0;
     // (the residency trace of the render kernel is a build option, -DPG_RENDER_TRACE=1: its two calls cost coinrun's renderer the
     // three registers that separate 96 VGPRs from a spill at five waves per SIMD)
-    if (PG_RENDER_TRACE) trace_wave(d, env_base + (int)blockIdx.x, 4, false, 8);
-    Renderer<Game, GEN> r(d, env_base + (int)blockIdx.x, &lds);
+    const int slot = env_base + (int)blockIdx.x;
+    const int env = d.render_order ? __builtin_amdgcn_readfirstlane(d.render_order[slot]) : slot;  // (kept in a scalar register: every address of the frame derives from it)
+    if (PG_RENDER_TRACE) trace_wave(d, env, 4, false, 8);
+    Renderer<Game, GEN> r(d, env, &lds);
     r.render_env();
-    if (PG_RENDER_TRACE) trace_wave(d, env_base + (int)blockIdx.x, 4, true, 8);
+    if (PG_RENDER_TRACE) trace_wave(d, env, 4, true, 8);
 }
 // clear_lists: this is the step's render of env 0 (every list kernel of the step is done when a render kernel starts); a
 // hipMemsetAsync per step instead was two fill kernels, each tens of microseconds on a busy device with many handles
@@ -244,7 +246,9 @@ static hipError_t launch_human(const DevCtx &d, int env_base, int count, hipStre
 
 template <class Game>
 static hipError_t render_one(const DevCtx &d, int env, hipStream_t stream) {  // re-renders one env (after set_state)
-    launch_render<Game>(d, env, 1, stream);
+    DevCtx d1 = d;
+    d1.render_order = nullptr;  // (env is the env itself here, not a slot of a chunk launch)
+    launch_render<Game>(d1, env, 1, stream);
     return hipGetLastError();
 }
 

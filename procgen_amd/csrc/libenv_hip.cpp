@@ -186,6 +186,12 @@ struct VecGame {
     int *d_reset_list = nullptr;   // SPLIT_RESET games: envs whose episode a step kernel ended this step (consumed by the reset kernel)
     int *d_reset_count = nullptr;  // [2][MAX_CHUNKS], double-buffered by step parity (a step kernel zeroes the next step's)
     uint8_t *d_route[2] = {nullptr, nullptr};
+    // PROCGEN_AMD_RENDER_ORDER=K (experiment, off by default): every K steps the render kernel's workgroup -> env map of each launch
+    // chunk is re-sorted by background image, images dealt to the XCDs (workgroup j runs on XCD j mod 8, each with its own L2)
+    int render_order_period = 0;
+    int *d_render_order = nullptr;
+    std::vector<int> h_bg_index, h_render_order;
+    void rebuild_render_order();
     void bind_routing() {  // double-buffered by step parity: this step reads [cur], fills [nxt]
         const int cur = (int)(step_count & 1), nxt = cur ^ 1;
         d.big_list = d_big_list[cur];
@@ -459,6 +465,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     }
     d_reset_list = dev_alloc<int>(N);
     d_reset_count = dev_alloc<int>(2 * MAX_CHUNKS);
+    if (const char *ro = getenv("PROCGEN_AMD_RENDER_ORDER")) render_order_period = atoi(ro);
+    if (render_order_period > 0 && !d.opt.use_generated_assets) d_render_order = dev_alloc<int>(N);  // (bound to d.render_order by the first rebuild)
     d.assets = d_assets;
     d.pixels = d_pixels;
     if (this->render_human) {
@@ -560,6 +568,7 @@ VecGame::~VecGame() {
     }
     (void)hipFree(d_reset_list);
     (void)hipFree(d_reset_count);
+    if (d_render_order) (void)hipFree(d_render_order);
     if (h_action) (void)hipHostFree(h_action);
     if (h_small) (void)hipHostFree(h_small);
     if (h_obs_stage) (void)hipHostFree(h_obs_stage);
@@ -624,6 +633,60 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
     }
     buffers_set = true;
     launch(0);  // initial reset + first frame (reference src/vecgame.cpp:346-357)
+}
+
+// PROCGEN_AMD_RENDER_ORDER: called between steps (the handle's streams are idle).  Each launch chunk's env range (the ranges of
+// launch_game, kernels_game.hip) is permuted on its own: a chunk's render kernel is ordered behind that chunk's step kernel only.
+void VecGame::rebuild_render_order() {
+    const int N = num_envs;
+    h_bg_index.resize(N);
+    h_render_order.resize(N);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipMemcpy2D(h_bg_index.data(), sizeof(int), &d.hdr[0].background_index, sizeof(EnvHdr), sizeof(int), (size_t)N, hipMemcpyDeviceToHost));
+    int bounds[MAX_CHUNKS + 1] = {0};
+    int nb = 1;
+    if (N < 4096) {
+        bounds[1] = N;
+    } else {
+        const int nchunk = chunks > 1 ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1;
+        const int per = chunk_envs_for(N, nchunk);
+        const int first = (nchunk == 2 && first_pct > 0) ? first_chunk_envs(N, first_pct) : 0;
+        nb = 0;
+        for (int c = 0; c < nchunk; c++) {
+            const int base = first > 0 ? (c == 0 ? 0 : first) : c * per;
+            if (base >= N) break;
+            bounds[nb++] = base;
+        }
+        bounds[nb] = N;
+    }
+    constexpr int XCDS = 8;
+    std::vector<int> queue[XCDS];
+    for (int c = 0; c < nb; c++) {
+        const int b = bounds[c], e = bounds[c + 1];
+        std::vector<std::pair<int, int>> keyed;  // (image, env): images ascending, envs ascending within an image
+        keyed.reserve((size_t)(e - b));
+        for (int i = b; i < e; i++) keyed.push_back({h_bg_index[i] < 0 ? 0 : h_bg_index[i], i});
+        std::sort(keyed.begin(), keyed.end());
+        for (auto &q : queue) q.clear();
+        for (auto &k : keyed) queue[k.first % XCDS].push_back(k.second);
+        size_t head[XCDS] = {};
+        size_t tail[XCDS];
+        for (int x = 0; x < XCDS; x++) tail[x] = queue[x].size();
+        for (int j = 0; j < e - b; j++) {
+            int x = j % XCDS;
+            if (head[x] < tail[x]) {
+                h_render_order[b + j] = queue[x][head[x]++];
+                continue;
+            }
+            int longest = 0;  // this XCD's images are drawn: it takes from the back of the longest queue left
+            for (int y = 1; y < XCDS; y++)
+                if (tail[y] - head[y] > tail[longest] - head[longest]) longest = y;
+            h_render_order[b + j] = queue[longest][--tail[longest]];
+        }
+    }
+    HIP_CHECK(hipMemcpy(d_render_order, h_render_order.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
+    HIP_CHECK(hipStreamSynchronize(nullptr));  // (null-stream upload; the render kernels run on non-blocking streams)
+    d.render_order = d_render_order;
 }
 
 // the device work of one step: the step / reset / render kernels (what procgen_amd_time_steps brackets)
@@ -694,6 +757,7 @@ void VecGame::act() {  // reference src/vecgame.cpp:378-401
     if (!buffers_set) fatal("libenv_act called before libenv_set_buffers\n");
     use_device();
     observe();  // wait_for_stepping_threads()
+    if (d_render_order && step_count % (uint64_t)render_order_period == 0) rebuild_render_order();
     const int N = num_envs;
     // the action values are only valid for the duration of this call (reference src/vecgame.cpp:387-388)
     if (ac_contig) memcpy(h_action, ac_ptr[0], (size_t)N * 4);
@@ -1258,6 +1322,7 @@ LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const in
     HIP_CHECK(hipEventCreate(&e1));
     float total_ms = 0.f;
     for (int s = 0; s < steps; s++) {
+        if (v->d_render_order && v->step_count % (uint64_t)v->render_order_period == 0) v->rebuild_render_order();
         if (actions_or_null) HIP_CHECK(hipMemcpyAsync(v->d_action, actions_or_null + (size_t)s * v->num_envs, (size_t)v->num_envs * 4, hipMemcpyHostToDevice, v->stream));
         HIP_CHECK(hipEventRecord(e0, v->stream));
         v->launch_kernels(1);

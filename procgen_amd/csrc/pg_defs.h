@@ -228,6 +228,9 @@ struct DevCtx {
     int *reset_count;       // [MAX_CHUNKS] per env chunk, this step
     int *next_reset_count;  // [MAX_CHUNKS] the next step's counters (double-buffered by step parity), zeroed by this step's lane kernel
     int *error;            // [1] OR of the per-env error codes raised so far (0 = none; sticky: the host stops at the first one)
+    // launch order of the render kernel (experiment, PROCGEN_AMD_RENDER_ORDER; null = identity): workgroup j of a chunk's launch draws env
+    // render_order[env_base + j], a permutation of that chunk's env range sorted by background image
+    const int *render_order;  // [num_envs]
     int clear_lists;       // render kernel: zero big_count[] (nobody reads it any more this step; it is the next step's next_big_count)
     unsigned long long *wave_trace;    // [num_envs][32] PROCGEN_AMD_DEBUG & 8192: 100 MHz timestamps of the last step's workgroups: step start / end / kind+HW_ID, render start / end / HW_ID (null otherwise)
     unsigned long long *phase_cycles;  // [4096][32] PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step (0-15) and render (16-31) kernels (null otherwise)
