@@ -635,19 +635,15 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
     launch(0);  // initial reset + first frame (reference src/vecgame.cpp:346-357)
 }
 
-// PROCGEN_AMD_RENDER_ORDER: called between steps (the handle's streams are idle).  Each launch chunk's env range (the ranges of
-// launch_game, kernels_game.hip) is permuted on its own: a chunk's render kernel is ordered behind that chunk's step kernel only.
-void VecGame::rebuild_render_order() {
-    const int N = num_envs;
-    h_bg_index.resize(N);
-    h_render_order.resize(N);
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipMemcpy2D(h_bg_index.data(), sizeof(int), &d.hdr[0].background_index, sizeof(EnvHdr), sizeof(int), (size_t)N, hipMemcpyDeviceToHost));
+// PROCGEN_AMD_RENDER_ORDER: the render kernel's workgroup -> env map.  Each launch chunk's env range (the ranges of launch_game,
+// kernels_game.hip) is permuted on its own -- a chunk's render kernel is ordered behind that chunk's step kernel only --: envs sorted by
+// background image, image i dealt to XCD i mod 8 (workgroup j of a launch runs on XCD j mod 8, each XCD has its own L2); an XCD whose
+// images are drawn takes from the back of the longest queue left.  Pure host code (procgen_amd_selftest_render_order tests it without a GPU).
+static void build_render_order(const int *bg_index, int N, int chunks, int first_pct, int *order) {
     int bounds[MAX_CHUNKS + 1] = {0};
     int nb = 1;
-    if (N < 4096) {
-        bounds[1] = N;
-    } else {
+    bounds[1] = N;
+    if (N >= 4096) {
         const int nchunk = chunks > 1 ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1;
         const int per = chunk_envs_for(N, nchunk);
         const int first = (nchunk == 2 && first_pct > 0) ? first_chunk_envs(N, first_pct) : 0;
@@ -665,7 +661,7 @@ void VecGame::rebuild_render_order() {
         const int b = bounds[c], e = bounds[c + 1];
         std::vector<std::pair<int, int>> keyed;  // (image, env): images ascending, envs ascending within an image
         keyed.reserve((size_t)(e - b));
-        for (int i = b; i < e; i++) keyed.push_back({h_bg_index[i] < 0 ? 0 : h_bg_index[i], i});
+        for (int i = b; i < e; i++) keyed.push_back({bg_index[i] < 0 ? 0 : bg_index[i], i});
         std::sort(keyed.begin(), keyed.end());
         for (auto &q : queue) q.clear();
         for (auto &k : keyed) queue[k.first % XCDS].push_back(k.second);
@@ -673,17 +669,27 @@ void VecGame::rebuild_render_order() {
         size_t tail[XCDS];
         for (int x = 0; x < XCDS; x++) tail[x] = queue[x].size();
         for (int j = 0; j < e - b; j++) {
-            int x = j % XCDS;
+            const int x = j % XCDS;
             if (head[x] < tail[x]) {
-                h_render_order[b + j] = queue[x][head[x]++];
+                order[b + j] = queue[x][head[x]++];
                 continue;
             }
-            int longest = 0;  // this XCD's images are drawn: it takes from the back of the longest queue left
+            int longest = 0;
             for (int y = 1; y < XCDS; y++)
                 if (tail[y] - head[y] > tail[longest] - head[longest]) longest = y;
-            h_render_order[b + j] = queue[longest][--tail[longest]];
+            order[b + j] = queue[longest][--tail[longest]];
         }
     }
+}
+
+// called between steps (the handle's streams are idle)
+void VecGame::rebuild_render_order() {
+    const int N = num_envs;
+    h_bg_index.resize(N);
+    h_render_order.resize(N);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipMemcpy2D(h_bg_index.data(), sizeof(int), &d.hdr[0].background_index, sizeof(EnvHdr), sizeof(int), (size_t)N, hipMemcpyDeviceToHost));
+    build_render_order(h_bg_index.data(), N, chunks, first_pct, h_render_order.data());
     HIP_CHECK(hipMemcpy(d_render_order, h_render_order.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
     HIP_CHECK(hipStreamSynchronize(nullptr));  // (null-stream upload; the render kernels run on non-blocking streams)
     d.render_order = d_render_order;
@@ -1275,6 +1281,9 @@ LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable
     v->host_observations = enable != 0;
 }
 // Device math self-tests: no handle; run on the current device.  Host pointers in, host pointers out.
+LIBENV_API void procgen_amd_selftest_render_order(const int *bg_index, int num_envs, int chunks, int first_pct, int *out) {
+    build_render_order(bg_index, num_envs, chunks, chunks == 2 && first_chunk_envs(num_envs, first_pct) > 0 ? first_pct : 0, out);  // (as the constructor settles first_pct)
+}
 LIBENV_API void procgen_amd_selftest_bigfish_radius(const float *r01, float *out, int n) {
     float *d_in = nullptr, *d_out = nullptr;
     HIP_CHECK(hipMalloc((void **)&d_in, (size_t)n * 4));
