@@ -155,6 +155,22 @@ struct GameCustomBackground<Game, decltype((void)Game::CUSTOM_BACKGROUND)> {
 
 // parameter record of one rotated command (qt_transform_image): inverse mapping + three trapezoids
 constexpr int ROT_WORDS = 24;  // u0 v0 dudx dudy dvdx dvdy | 3 x (from_y to_y x_l dx_l x_r dx_r)
+// Rotation / tile records per render workgroup.  64 (default): a chunk's lane l owns record l.  A build with -DPG_ROT_POOL=n (n < 64; an
+// experiment prepared at the end of round 4, checked in the emulation, not yet measured) hands records only to the turned / tiled entities that
+// can reach the rows being drawn, n at a time: 16 takes 4.6 KB off the arena of the games with rotation (14.3 -> 9.7 KB: 11 -> 16 frames per CU).
+#ifndef PG_ROT_POOL
+#define PG_ROT_POOL 64
+#endif
+static_assert(PG_ROT_POOL >= 1 && PG_ROT_POOL <= 64, "records are addressed by six bits");
+// a policy with many turned sprites on screen (bossfight's bullets) asks for a multiple: ROT_POOL_FACTOR
+template <class Game, class = void>
+struct GameRotPool {
+    static constexpr int value = PG_ROT_POOL;
+};
+template <class Game>
+struct GameRotPool<Game, decltype((void)Game::ROT_POOL_FACTOR)> {
+    static constexpr int value = PG_ROT_POOL * Game::ROT_POOL_FACTOR < 64 ? PG_ROT_POOL * Game::ROT_POOL_FACTOR : 64;
+};
 
 // LDS arena of one render workgroup (one wave)
 template <class Game>
@@ -175,7 +191,7 @@ struct RenderLdsT {
     uint8_t cellimg[GameDrawsGrid<Game>::value ? GamePullCells<Game>::value : 4];
     uint32_t typeany[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of any size: atlas offset | size class<<27 | opaque<<31 (pull form)
     uint32_t fillcmd[GameHasGridFills<Game>::value ? 2 * 256 : 1];  // solid-colour cells of a pull-form frame: (geom, colour) pairs
-    uint32_t rot[GameUsesRotation<Game>::value ? 64 * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane
+    uint32_t rot[GameUsesRotation<Game>::value ? GameRotPool<Game>::value * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane (by pool slot: ROT_POOL)
 };
 template <bool GEN>
 struct CmdExtra {};
@@ -1902,13 +1918,65 @@ struct Renderer {
         EntPre none;
         return setup_entities_t<false>(base, r, zmask, rot_base, none);
     }
-    // PRE: base == 0 and the slots' fields / image descriptors were requested ahead (EntPre)
+    static constexpr int ROT_POOL = GameRotPool<Game>::value;
+    static constexpr bool ROT_POOLED = GameUsesRotation<Game>::value && ROT_POOL < 64;
+    // ROT_POOLED: can this entity's turned sprite / row of tiles reach the rows [row0, row1)?  Conservative and cheap (float, nothing shared
+    // with the exact rect arithmetic of the lane section: the first version, the exact rect's circumcircle in fp64, cost the kernels 25-30
+    // VGPRs): the centre of get_object_rect's rect (BAG:799-817) and three times its half-extents plus three pixels -- a turned rect's
+    // corners lie on the circumcircle (BAG:902-906), a row of tiles fills the rect (each tile rounded on its own), and no
+    // adjusted_image_rect of a game moves or grows a rect beyond that.
     template <bool PRE>
-    PG_DEV int setup_entities_t(int base, CmdRegs &r, uint64_t (&zmask)[3], int rot_base, const EntPre &pre) {
+    PG_DEV bool record_maybe_visible(const EntPre &pre, int i, int l) const {
+        (void)l;
+        const uint32_t mm = PRE ? PG_LV(pre.meta, l) : meta(i);
+        const float x = PRE ? __builtin_bit_cast(float, PG_LV(pre.x, l)) : ex(i), y = PRE ? __builtin_bit_cast(float, PG_LV(pre.y, l)) : ey(i);
+        const float rx = PRE ? __builtin_bit_cast(float, PG_LV(pre.rx, l)) : erx(i), ry = PRE ? __builtin_bit_cast(float, PG_LV(pre.ry, l)) : ery(i);
+        const bool abs_coords = (mm & MF_ABS_COORDS) != 0;
+        const float sc = abs_coords ? G.view_dim * G.unit : G.unit;
+        const float cxs = abs_coords ? x * sc : x * sc - G.x_off;
+        const float cys = abs_coords ? (y + 2 * ry) * sc : (G.view_dim - y) * sc + G.y_off;
+        const float rad = 3 * ((rx < 0 ? -rx : rx) + (ry < 0 ? -ry : ry)) * sc + 3;
+        return cxs + rad > 0 && cxs - rad < (float)RES_W && cys + rad > (float)row0 && cys - rad < (float)row1;
+    }
+    PG_DEV RectD object_rect(uint32_t mm, float x, float y, float rx, float ry) const {  // get_object_rect BAG:811-817
+        RectD r1;
+        if (mm & MF_ABS_COORDS) {
+            const float vd = G.view_dim;
+            r1.x = (double)((vd * (x - rx)) * G.unit);
+            r1.y = (double)((vd * (y + ry)) * G.unit);
+            r1.w = (double)((2 * vd * rx) * G.unit);
+            r1.h = (double)((2 * vd * ry) * G.unit);
+        } else {
+            r1 = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
+        }
+        return r1;
+    }
+    // PRE: base == 0 and the slots' fields / image descriptors were requested ahead (EntPre)
+    // ROT_POOLED only: `lanes` = the lanes of the chunk to set up (the others get no command); with `resume`, a window that needs more records
+    // than the pool has left is cut in front of the first entity that does not fit and *resume = that lane (64: the window was set up whole)
+    template <bool PRE>
+    PG_DEV int setup_entities_t(int base, CmdRegs &r, uint64_t (&zmask)[3], int rot_base, const EntPre &pre, uint64_t lanes = ~0ull, int *resume = nullptr) {
         const int n = G.n_ents;
         for (int z = 0; z < 3; z++) zmask[z] = PG_BALLOT(l, (base + l) < n && meta_render_z(PRE ? PG_LV(pre.meta, l) : meta(base + l)) == z - 1);
         uint64_t rotmask = 0;  // entities that need an LDS record: turned sprites and tiled ones
-        if constexpr (GameUsesRotation<Game>::value) {
+        if constexpr (ROT_POOLED) {
+            if (rot_base < 0) rot_base = 0;
+            rotmask = PG_BALLOT(l, ((lanes >> l) & 1ull) && (base + l) < n && ((PRE ? __builtin_bit_cast(float, PG_LV(pre.rot, l)) : ef(EF_ROTATION, base + l)) != 0 || (GameUsesTiledEntities<Game>::value && Game::tile_aspect_ratio(*this, base + l) != 0)) &&
+                                       record_maybe_visible<PRE>(pre, base + l, l));
+            if (resume) *resume = 64;
+            if (rot_base + pg_popc64(rotmask) > ROT_POOL) {
+                if (!resume) return -1;
+                uint64_t m = rotmask;
+                for (int k = rot_base; k < ROT_POOL; k++) m &= m - 1;  // (the records that fit)
+                const int cut = pg_ctz64(m);
+                lanes &= pg_mask_lt(cut);
+                rotmask &= pg_mask_lt(cut);
+                *resume = cut;
+#if defined(PGAMD_WAVE_EMU)
+                pg_emu_counters()[7] += 1;  // windows cut for want of records
+#endif
+            }
+        } else if constexpr (GameUsesRotation<Game>::value) {
             if (rot_base >= 0) {
                 rotmask = PG_BALLOT(l, (base + l) < n && ((PRE ? __builtin_bit_cast(float, PG_LV(pre.rot, l)) : ef(EF_ROTATION, base + l)) != 0 || (GameUsesTiledEntities<Game>::value && Game::tile_aspect_ratio(*this, base + l) != 0)));
                 if (rot_base + pg_popc64(rotmask) > 64) return -1;
@@ -1918,21 +1986,20 @@ struct Renderer {
             const int i = base + l;
             const int rot_slot = rot_base >= 0 ? rot_base + pg_popc64(rotmask & pg_mask_lt(l)) : l;
             clear_cmd(r, l);
-            if (i < n && Game::should_draw_entity(*this, i)) {
+            bool wanted = i < n && Game::should_draw_entity(*this, i);
+            if constexpr (ROT_POOLED) {
+                // outside the window; or a turned / tiled entity without a record: it cannot reach the rows being drawn
+                wanted = wanted && ((lanes >> l) & 1ull);
+                if (wanted && !((rotmask >> l) & 1ull) &&
+                    ((PRE ? __builtin_bit_cast(float, PG_LV(pre.rot, l)) : ef(EF_ROTATION, i)) != 0 || (GameUsesTiledEntities<Game>::value && Game::tile_aspect_ratio(*this, i) != 0)))
+                    wanted = false;
+            }
+            if (wanted) {
                 const uint32_t mm = PRE ? PG_LV(pre.meta, l) : meta(i);
                 const float x = PRE ? __builtin_bit_cast(float, PG_LV(pre.x, l)) : ex(i), y = PRE ? __builtin_bit_cast(float, PG_LV(pre.y, l)) : ey(i);
                 const float rx = PRE ? __builtin_bit_cast(float, PG_LV(pre.rx, l)) : erx(i), ry = PRE ? __builtin_bit_cast(float, PG_LV(pre.ry, l)) : ery(i);
                 const float e_alpha = PRE ? __builtin_bit_cast(float, PG_LV(pre.alpha, l)) : ef(EF_ALPHA, i);
-                RectD r1;  // get_object_rect BAG:811-817
-                if (mm & MF_ABS_COORDS) {
-                    const float vd = G.view_dim;
-                    r1.x = (double)((vd * (x - rx)) * G.unit);
-                    r1.y = (double)((vd * (y + ry)) * G.unit);
-                    r1.w = (double)((2 * vd * rx) * G.unit);
-                    r1.h = (double)((2 * vd * ry) * G.unit);
-                } else {
-                    r1 = get_screen_rect(x - rx, y + ry, 2 * rx, 2 * ry, 0);
-                }
+                RectD r1 = object_rect(mm, x, y, rx, ry);
                 const RectD r1_in = r1;
                 uint32_t fc = 0;
                 ImgDesc imd;
@@ -2064,8 +2131,20 @@ struct Renderer {
             if (!any) continue;
             CmdRegs r;
             uint64_t zmask[3];
-            setup_entities(base, r, zmask);
-            run_batch(r, zmask[render_z + 1]);
+            if constexpr (ROT_POOLED) {
+                // windows of the chunk, in draw order, each with at most ROT_POOL turned / tiled entities that can reach this band
+                EntPre none;
+                int lo = 0;
+                while (lo < 64) {
+                    int next = 64;
+                    setup_entities_t<false>(base, r, zmask, 0, none, lo ? ~pg_mask_lt(lo) : ~0ull, &next);
+                    run_batch(r, zmask[render_z + 1]);
+                    lo = next;
+                }
+            } else {
+                setup_entities(base, r, zmask);
+                run_batch(r, zmask[render_z + 1]);
+            }
         }
     }
 
@@ -2228,8 +2307,13 @@ struct Renderer {
             ezmask[k][0] = ezmask[k][1] = ezmask[k][2] = 0;
             PG_R_LANES(l) { clear_cmd(er[k], l); }
         }
-        if (one_chunk) setup_entities_t<true>(0, er[0], ezmask[0], -1, epre);
-        else if (!force_chunks) one_chunk = compact_entities(er, ezmask);
+        if (one_chunk) {
+            const int k = setup_entities_t<true>(0, er[0], ezmask[0], -1, epre);
+            if (ROT_POOLED && k < 0) one_chunk = false;  // more turned / tiled sprites on screen than records: per band (draw_entities)
+#if defined(PGAMD_WAVE_EMU)
+            if (ROT_POOLED && k < 0) pg_emu_counters()[7] += 1000000;  // frames sent to the per-band path for want of records
+#endif
+        } else if (!force_chunks) one_chunk = compact_entities(er, ezmask);
         phase(8);
         phase(0);
         // ---- passes -------------------------------------------------------------------------------------------------

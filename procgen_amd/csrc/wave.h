@@ -35,7 +35,8 @@ inline int &pg_emu_lane() {
     return lane;
 }
 // event counters the harness reads back (which code paths a test really took); slot 0: objects stepped by the parallel pass,
-// 1-4: bso_free_objects rounds / sub_steps evaluated / calls / objects
+// 1-4: bso_free_objects rounds / sub_steps evaluated / calls / objects; 5-6: nested sub_steps run / skipped; 7: -DPG_ROT_POOL builds of the
+// renderer: windows cut for want of rotation records + 1e6 x frames sent to the per-band path
 inline long long *pg_emu_counters() {
     static long long c[8] = {0};
     return c;

@@ -12,7 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 # PG_EMU_GAMES="CoinRun,BigFish": a quick build of a few policies while iterating on the kernels (its own file; the tests use the full one)
 _SUBSET = os.environ.get("PG_EMU_GAMES", "")
-LIB = os.path.join(HERE, "libemu.so" if not _SUBSET else "libemu_" + _SUBSET.replace(",", "_") + ".so")
+# PG_EMU_DEFS="-DPG_ROT_POOL=2": the kernel sources with build-time experiment switches (its own file again)
+_DEFS = os.environ.get("PG_EMU_DEFS", "").split()
+_TAG = ("_" + _SUBSET.replace(",", "_") if _SUBSET else "") + "".join("_" + "".join(ch for ch in d if ch.isalnum()) for d in _DEFS)
+LIB = os.path.join(HERE, "libemu" + _TAG + ".so")
 CSRC = os.path.join(REPO, "procgen_amd", "csrc")
 
 
@@ -31,7 +34,7 @@ def build(force=False):
         if force or not fresh():
             tmp = LIB + f".tmp{os.getpid()}"
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-march=ivybridge", "-fno-strict-aliasing", "-fPIC",
-                                   "-shared", "-I" + CSRC] + (["-DPG_HUMAN_TRACE"] if os.environ.get("PG_HUMAN_TRACE") else [])
+                                   "-shared", "-I" + CSRC] + _DEFS + (["-DPG_HUMAN_TRACE"] if os.environ.get("PG_HUMAN_TRACE") else [])
                                   + (["-DPG_FOR_EACH_GAME(X)=" + " ".join(f"X({g})" for g in _SUBSET.split(","))] if _SUBSET else []) + srcs + ["-lz", "-o", tmp])
             os.replace(tmp, LIB)
 

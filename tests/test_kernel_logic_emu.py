@@ -363,3 +363,23 @@ def test_kernels_read_no_lds_word_they_did_not_write(monkeypatch, game, kw):
     a = rollout(oracle_env.OracleEnv(n, game, rand_seed=29, **kw), acts)
     b = rollout(emu_harness.EmuEnv(n, game, rand_seed=29, **kw), acts)
     assert_rollouts_equal(a, b, f"{game} {kw} on poisoned LDS")
+
+
+def test_rotation_record_pool_build_variant_draws_the_same_frames():
+    """-DPG_ROT_POOL=n (pg_render.h; an experiment for the LDS-bound renderers, default 64 = off): turned / tiled entities that can reach the
+    rows being drawn share n records, frames with more of them fall back to the per-band path and cut their chunks into windows.  Built
+    with n = 2, so that every fallback runs all the time, the four games with the most turned / tiled sprites must still match the oracle
+    bit for bit -- through the default path, the per-band path forced for every frame (debug flag 4096) and without the pull form (1024)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, PG_EMU_GAMES="FruitBot,Dodgeball,StarPilot,Leaper", PG_EMU_DEFS="-DPG_ROT_POOL=2")
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "quick_emu.py")
+    for game, extra, dbg in (("fruitbot", [], None), ("dodgeball", [], None), ("starpilot", ["distribution_mode=2"], None), ("leaper", [], "1024"), ("dodgeball", [], "4096"),
+                             ("fruitbot", ["center_agent=False"], None)):
+        e = dict(env)
+        if dbg:
+            e["PROCGEN_AMD_DEBUG"] = dbg
+        r = subprocess.run([sys.executable, tool, game, "8", "150"] + extra, env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        assert "rotation-record pool:" in r.stdout and " 0 mismatching steps" in r.stdout, r.stdout[-600:]  # (the fallbacks did run)

@@ -36,5 +36,10 @@ for t in range(steps + 1):
         break
     if t < steps:
         orc.act(acts[t]); emu.act(acts[t])
+import ctypes
+emu.L.emu_counter.restype = ctypes.c_longlong
+c7 = emu.L.emu_counter(7)
+if c7:
+    print(f"rotation-record pool: {c7 // 1000000} frames sent to the per-band path, {c7 % 1000000} windows cut")
 print(f"{game} {kw}: {n} envs x {steps} steps, {bad} mismatching steps, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
