@@ -1961,8 +1961,16 @@ struct Renderer {
         uint64_t rotmask = 0;  // entities that need an LDS record: turned sprites and tiled ones
         if constexpr (ROT_POOLED) {
             if (rot_base < 0) rot_base = 0;
-            rotmask = PG_BALLOT(l, ((lanes >> l) & 1ull) && (base + l) < n && ((PRE ? __builtin_bit_cast(float, PG_LV(pre.rot, l)) : ef(EF_ROTATION, base + l)) != 0 || (GameUsesTiledEntities<Game>::value && Game::tile_aspect_ratio(*this, base + l) != 0)) &&
-                                       record_maybe_visible<PRE>(pre, base + l, l));
+            // (the test runs in a lane section of the renderer's kind, its lane id opaque to LICM, and the ballot reads a flag: inside the
+            // ballot itself the same arithmetic cost the kernels ten more VGPRs)
+            PG_LANE_VAR(uint32_t, needs);
+            PG_R_LANES(l) {
+                PG_LV(needs, l) = (((lanes >> l) & 1ull) && (base + l) < n && ((PRE ? __builtin_bit_cast(float, PG_LV(pre.rot, l)) : ef(EF_ROTATION, base + l)) != 0 || (GameUsesTiledEntities<Game>::value && Game::tile_aspect_ratio(*this, base + l) != 0)) &&
+                                   record_maybe_visible<PRE>(pre, base + l, l))
+                                      ? 1u
+                                      : 0u;
+            }
+            rotmask = PG_BALLOT(l, PG_LV(needs, l) != 0);
             if (resume) *resume = 64;
             if (rot_base + pg_popc64(rotmask) > ROT_POOL) {
                 if (!resume) return -1;
