@@ -688,7 +688,10 @@ void VecGame::rebuild_render_order() {
     h_bg_index.resize(N);
     h_render_order.resize(N);
     HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipMemcpy2D(h_bg_index.data(), sizeof(int), &d.hdr[0].background_index, sizeof(EnvHdr), sizeof(int), (size_t)N, hipMemcpyDeviceToHost));
+    // (the whole header array in one contiguous copy, 18 MB at 65 536 envs: a 2-D copy of one word per header may run row by row)
+    std::vector<EnvHdr> hdrs((size_t)N);
+    HIP_CHECK(hipMemcpy(hdrs.data(), d.hdr, (size_t)N * sizeof(EnvHdr), hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; i++) h_bg_index[i] = hdrs[(size_t)i].background_index;
     build_render_order(h_bg_index.data(), N, chunks, first_pct, h_render_order.data());
     HIP_CHECK(hipMemcpy(d_render_order, h_render_order.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
     HIP_CHECK(hipStreamSynchronize(nullptr));  // (null-stream upload; the render kernels run on non-blocking streams)
