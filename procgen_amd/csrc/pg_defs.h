@@ -6,6 +6,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// Per-phase cycle counters of the kernels (PROCGEN_AMD_DEBUG & 2048, DevCtx::phase_cycles).  -DPG_PHASE_PROFILE=0 compiles them out: the
+// counter address lives in a VGPR pair for the whole kernel (or in scratch, where an occupancy hint leaves no room for it).
+#ifndef PG_PHASE_PROFILE
+#define PG_PHASE_PROFILE 1
+#endif
+
 namespace pgamd {
 
 constexpr int RES_W = 64;

@@ -239,7 +239,7 @@ struct Env {
     bool needs_reset = false;  // NO_RESET: this step ended the episode
     PG_DEV void phase(int k) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles) {
+        if (PG_PHASE_PROFILE && d.phase_cycles) {
             const long long t = (long long)__builtin_readcyclecounter();
             if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + k + 32 * (env & 4095), (unsigned long long)(t - t_mark));
             if (d.wave_trace && PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.wave_trace + (size_t)env * 32 + 8 + k, (unsigned long long)(t - t_mark));  // this env, this step
@@ -253,7 +253,7 @@ struct Env {
     // profiling aid (PROCGEN_AMD_DEBUG & 8192): per-env counters of this step in the trace record (slots 24..31)
     PG_DEV void trace_add(int k, unsigned long long v) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.wave_trace && d.phase_cycles && PG_LANE_ID() == 0) d.wave_trace[(size_t)env * 32 + 24 + k] += v;
+        if (PG_PHASE_PROFILE && d.wave_trace && d.phase_cycles && PG_LANE_ID() == 0) d.wave_trace[(size_t)env * 32 + 24 + k] += v;
 #else
         (void)k; (void)v;
 #endif
@@ -1885,7 +1885,7 @@ struct Env {
                 game_reset_full();
                 phase(6);
 #if !defined(PGAMD_WAVE_EMU)
-                if (d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 15 + 32 * (env & 4095), 1ull);
+                if (PG_PHASE_PROFILE && d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 15 + 32 * (env & 4095), 1ull);
 #endif
             }
         }
@@ -2074,8 +2074,8 @@ struct Env {
     // step kernel took up to the end of the episode (mode 2) of this env
     PG_DEV void run(int mode) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
-        if (d.phase_cycles && d.wave_trace && PG_LANE_ID() < 24) d.wave_trace[(size_t)env * 32 + 8 + PG_LANE_ID()] = 0;
+        if (PG_PHASE_PROFILE && d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
+        if (PG_PHASE_PROFILE && d.phase_cycles && d.wave_trace && PG_LANE_ID() < 24) d.wave_trace[(size_t)env * 32 + 8 + PG_LANE_ID()] = 0;
 #endif
         load_env(mode != 2);  // a reset starts from an empty entity table (whose old size may exceed this arena)
         phase(0);
@@ -2108,7 +2108,7 @@ struct Env {
         store_env();
         phase(8);
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles && mode != 0 && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 14 + 32 * (env & 4095), 1ull);
+        if (PG_PHASE_PROFILE && d.phase_cycles && mode != 0 && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 14 + 32 * (env & 4095), 1ull);
 #endif
     }
 };

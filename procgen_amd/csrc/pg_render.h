@@ -2161,7 +2161,7 @@ struct Renderer {
     long long t_mark = 0;
     PG_DEV void phase(int k) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles) {
+        if (PG_PHASE_PROFILE && d.phase_cycles) {
             const long long t = (long long)__builtin_readcyclecounter();
             if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + k, (unsigned long long)(t - t_mark));
             t_mark = (long long)__builtin_readcyclecounter();
@@ -2172,7 +2172,7 @@ struct Renderer {
     }
     PG_DEV void render_env() {
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
+        if (PG_PHASE_PROFILE && d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
 #endif
         // ---- requests, round 1: what depends on the env index alone -- the header and the fields of the first 64 entity slots
         EntPre epre;
@@ -2529,7 +2529,7 @@ struct Renderer {
             phase(5);
         }
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + 15, 1ull);
+        if (PG_PHASE_PROFILE && d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + 15, 1ull);
 #endif
         if (G.error) {
 #if defined(PGAMD_WAVE_EMU)
