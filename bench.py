@@ -19,10 +19,13 @@ Extra objects on the JSON line:
                  box's host cores (rank 0, N=1 only).
   host_landed  : the PCIe-inclusive rate of the same loop through the unmodified libenv ABI (observations copied into
                  the caller's host array every step) -- reported beside `value`, never as it.
-  steady_state : `value` is a cold-start figure (steps 20-220 after a synchronized reset of all envs).  A trainer sees the
-                 desynchronised steady state: --steady-warmup more steps (default 1500: past coinrun's 1000-step timeout) are run
-                 untimed, then 200 are timed; with the rate go the resets per env-step and how many envs each LDS arena tier of the
-                 step kernel owns there.  `value` stays the cold-start figure so that rounds remain comparable.
+  value        : measured in the STEADY STATE since round 5: before the W warm-up and K timed steps, --steady-warmup steps (default 1500:
+                 past coinrun's 1000-step timeout) are run untimed, so that episodes are desynchronised and entity tables / reset rate are
+                 at their long-run level -- the regime a trainer sees.  `steady_state` holds the resets per env-step and the envs per LDS
+                 arena tier there; `cold_start` the first steps after the synchronized reset (what rounds 1-4 quoted; --steady-warmup 0
+                 makes `value` that again).
+  roofline     : kernel_ms_per_step comes from HIP events around every libenv_act of the timed loop itself (the same K steps as
+                 ms_per_step), dominant_kernel from events around each render launch on its own stream.
 
   --dry-multi    runs the N > 1 launch path without N GPUs: every rank uses device 0, gloo carries the barrier and the MAX
                  reduction (tests/test_multi_gpu_paths.py).  No scaling number is meant by it.
@@ -121,6 +124,9 @@ def cpu_baseline(game="coinrun", budget_s=24.0):
             "sweep": {k: round(v[0], 1) for k, v in tried.items()}}
 
 
+KERNEL_POLICY = {"bigfish": "BigFish", "bossfight": "BossFight", "caveflyer": "CaveFlyerT<1600, 2>", "chaser": "Chaser", "climber": "Climber", "coinrun": "CoinRun",
+                 "dodgeball": "Dodgeball", "fruitbot": "FruitBot", "heist": "Heist", "jumper": "Jumper", "leaper": "Leaper", "maze": "Maze", "miner": "Miner",
+                 "ninja": "Ninja", "plunder": "Plunder", "starpilot": "StarPilot"}  # the policy class a game's kernels are instantiated with (procgen_amd/csrc/game_*.h)
 ALL_GAMES = ["bigfish", "bossfight", "caveflyer", "chaser", "climber", "coinrun", "dodgeball", "fruitbot", "heist", "jumper", "leaper", "maze", "miner",
              "ninja", "plunder", "starpilot"]  # reference procgen/env.py ENV_NAMES
 
@@ -136,8 +142,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--devices-in-process", type=int, default=1,
                     help="single-process mode: ONE libenv handle of devices x num-envs envs sharded over that many GPUs of this process (num_devices option; no torch.distributed)")
-    ap.add_argument("--steady-warmup", type=int, default=1500, help="untimed steps before the steady_state measurement (0: skip it)")
-    ap.add_argument("--steady-steps", type=int, default=200)
+    ap.add_argument("--steady-warmup", type=int, default=1500, help="untimed pre-rollout before the W warm-up and K timed steps (0: measure the cold start, as rounds 1-4 did)")
     ap.add_argument("--dry-multi", action="store_true", help="N > 1 ranks on ONE GPU (device 0 for every rank, gloo): exercises the launch path only")
     ap.add_argument("--shard-crc", action="store_true", help="report the CRC32 of every rank's last observations")
     args = ap.parse_args()
@@ -179,23 +184,71 @@ def main():
     else:
         env = ProcgenGym3Env(n, args.game, rand_seed=23, extra_options={
             "device_id": device, "env_offset": rank * n, "host_observations": bool(args.host_landed)})
+    single = not joint and D == 1  # single-part handle: the event-timing and tier-count hooks exist
+    if single:
+        env._lib.procgen_amd_kernel_timing.restype = C.c_double
+        env._lib.procgen_amd_kernel_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        env._lib.procgen_amd_tier_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+
+    def timed_loop(acts, warm, steps):
+        """`warm` untimed steps, then exactly `steps` timed ones between two barriers; the device time of a step's kernels (HIP events
+        around every libenv_act's launch sequence, procgen_amd_kernel_timing) comes from the SAME steps.  Returns (wall seconds -- MAX over
+        ranks --, device ms per step, [render ms per launch, render launches per step], episode resets seen)."""
+        for t in range(warm):
+            env.act(acts[t])
+            env.observe()
+        barrier()
+        if single:
+            env._lib.procgen_amd_kernel_timing(env._handle, 1, None, None)
+        resets = 0
+        t0 = time.perf_counter()
+        for t in range(warm, warm + steps):
+            env.act(acts[t])
+            _, _, first = env.observe()
+            resets += int(np.count_nonzero(first))
+        barrier()
+        dt = time.perf_counter() - t0
+        if single:
+            nsteps = C.c_int(0)
+            rinfo = (C.c_double * 2)()
+            kms = env._lib.procgen_amd_kernel_timing(env._handle, 0, C.byref(nsteps), rinfo)
+            assert nsteps.value == steps, (nsteps.value, steps)
+            render = [rinfo[0], rinfo[1]]
+        else:  # a joint / sharded handle overlaps its parts' kernels: the wall time of the step stands in
+            kms, render = dt / steps * 1e3, None
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.dry_multi else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, kms, render, resets
+
     rng = np.random.RandomState(rank)
-    acts = rng.randint(0, 15, size=(args.warmup + args.steps, n), dtype=np.int32)
     env.observe()
-    for t in range(args.warmup):
-        env.act(acts[t])
+    # (1) cold start, a side object: the first steps after the synchronized reset of every env (no resets yet, almost every env in the
+    #     smallest arena tier) -- what rounds 1-4 reported as `value`
+    cold = None
+    pre = args.steady_warmup
+    if pre > 0:
+        cs = min(args.steps, 100)
+        cacts = rng.randint(0, 15, size=(args.warmup + cs, n), dtype=np.int32)
+        cdt, ckms, _, _ = timed_loop(cacts, args.warmup, cs)
+        cold = {"value": round(n * world * cs / cdt, 1), "unit": "env steps/sec", "ms_per_step": round(cdt / cs * 1e3, 4), "steps": cs, "warmup": args.warmup,
+                "kernel_ms_per_step": round(ckms, 4), "roofline_frac": round(ALGO_BYTES_PER_ENV_STEP * n / (ckms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "the first steps after the synchronized reset of all envs: no resets, entity tables small (rounds 1-4 quoted this as `value`)"}
+        # (2) the rollout a trainer is in: past coinrun's 1000-step timeout every episode has ended at least once, the envs are
+        #     desynchronised, trail-heavy envs sit in the larger arena tiers and the reset rate is at its long-run level
+        srng = np.random.RandomState(1000 + rank)
+        done = args.warmup + cs
+        for t in range(max(pre - done, 0)):
+            env.act(srng.randint(0, 15, size=(n,), dtype=np.int32))
         env.observe()
-    barrier()
-    t0 = time.perf_counter()
-    for t in range(args.warmup, args.warmup + args.steps):
-        env.act(acts[t])
-        env.observe()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.dry_multi else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    # (3) the measurement: W warm-up steps, then exactly K timed steps
+    acts = rng.randint(0, 15, size=(args.warmup + args.steps, n), dtype=np.int32)
+    tiers = None
+    if single:
+        tiers = (C.c_int * 3)()
+        env._lib.procgen_amd_tier_counts(env._handle, tiers)
+    dt, kernel_ms, render_info, resets = timed_loop(acts, args.warmup, args.steps)
     shard_crc = None
     if args.shard_crc:  # the CRC32 of this rank's last observations (its shard of the logical vector), gathered on rank 0
         import zlib
@@ -229,52 +282,20 @@ def main():
                        "note": "observations copied D2H into the caller's registered host array every step (libenv ABI as gym3 uses it); PCIe Gen5 x16 bounds this at ~5.1 M steps/s per GPU"}
         env._lib.procgen_amd_set_host_observations(env._handle, 0)
 
-    # dominant kernel: device time of one step's launch sequence, HIP events on the library's own stream
-    env._lib.procgen_amd_time_steps.restype = C.c_double
-    env._lib.procgen_amd_time_steps.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-    k_steps = min(50, args.steps)
-    kacts = np.ascontiguousarray(acts[:k_steps])
-    if joint or D > 1:  # the per-step event timing hook is a single-part extension; a joint / sharded handle overlaps its parts' kernels
-        kernel_ms = dt / args.steps * 1e3
-    else:
-        kernel_ms = env._lib.procgen_amd_time_steps(env._handle, k_steps, kacts.ctypes.data)
-
-    # the desynchronised steady state a trainer sees (see the module docstring); single-part handles on rank 0's clock
-    steady = None
-    if args.steady_warmup > 0 and not joint and D == 1 and world == 1:
-        srng = np.random.RandomState(1000 + rank)
-        for t in range(args.steady_warmup):
-            env.act(srng.randint(0, 15, size=(n,), dtype=np.int32))
-        env.observe()
-        sacts = srng.randint(0, 15, size=(args.steady_steps, n), dtype=np.int32)
-        tiers = (C.c_int * 3)()
-        env._lib.procgen_amd_tier_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
-        env._lib.procgen_amd_tier_counts(env._handle, tiers)
-        resets = 0
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for t in range(args.steady_steps):
-            env.act(sacts[t])
-            _, _, first = env.observe()
-            resets += int(np.count_nonzero(first))
-        torch.cuda.synchronize()
-        sdt = time.perf_counter() - t2
-        steady = {"value": round(n * args.steady_steps / sdt, 1), "unit": "env steps/sec", "ms_per_step": round(sdt / args.steady_steps * 1e3, 4),
-                  "steps": args.steady_steps, "warmup": args.warmup + args.steps + args.steady_warmup,
-                  "resets_per_env_step": round(resets / (n * args.steady_steps), 6),
-                  "arena_tier_envs": {"tier0": tiers[0], "tier1": tiers[1], "tier2": tiers[2]},
-                  "kernel_ms_per_step": round(env._lib.procgen_amd_time_steps(env._handle, min(50, args.steady_steps), np.ascontiguousarray(sacts[:min(50, args.steady_steps)]).ctypes.data), 4),
-                  "note": "same loop, measured after the warm-up: episodes desynchronised, entity tables and reset rate at their long-run level"}
-
     env.close()
 
     if rank == 0:
-        traffic = None  # HBM bytes per launch (= one step) from the committed rocprofv3 PMC passes, same workload only
-        tpath = os.path.join(REPO, "profiles", "r04_hbm_traffic.json")
-        if os.path.exists(tpath) and args.game == "coinrun":
-            tj = json.load(open(tpath))
-            if tj.get("num_envs") == n:
-                traffic = round(tj["hbm_bytes_per_step_upper"])
+        # HBM bytes per launch (= one step): rocprofv3 PMC passes need their own runs (one counter set per pass), so this is the committed
+        # summary of the latest profile of the same workload -- a static figure, named as such
+        traffic = traffic_source = None
+        for tname in ("r05_hbm_traffic.json", "r04_hbm_traffic.json"):
+            tpath = os.path.join(REPO, "profiles", tname)
+            if os.path.exists(tpath) and args.game == "coinrun":
+                tj = json.load(open(tpath))
+                if tj.get("num_envs") == n:
+                    traffic = round(tj["hbm_bytes_per_step_upper"])
+                    traffic_source = f"profiles/{tname} (static: separate rocprofv3 --pmc passes of this workload in the steady state, upper bound per the gfx950 FETCH_SIZE note; raw {round(tj['hbm_bytes_per_step_raw'])})"
+                    break
         total_steps = n * world * args.steps
         value = total_steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
@@ -287,17 +308,29 @@ def main():
                                    f"observations {'landed on host (PCIe inclusive)' if args.host_landed else 'resident in HBM'}",
                        "num_envs_per_gpu": n // D, "sharding": (f"one handle, num_devices={D} contiguous index ranges, no collective" if D > 1 else f"env_offset shards x{world}, no collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "launch": "one step = exactly what libenv_act enqueues (counter memset, step grids + list kernels, render kernels) over all envs of this GPU",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                         "launch": "one step = exactly what libenv_act enqueues (step grids + list kernels, render kernels) over all envs of this GPU; HIP events on the library's stream around every libenv_act of the timed loop itself",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "kernel_ms_per_step": round(kernel_ms, 4), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
         }
+        if render_info is not None and render_info[1] > 0:
+            gname = KERNEL_POLICY.get(args.game, args.game)
+            line["roofline"]["dominant_kernel"] = {
+                "name": f"pgamd::render<{gname}, false>", "avg_us": round(render_info[0] * 1e3, 1), "launches_per_step": round(render_info[1], 2),
+                "source": "HIP events around each launch of the kernel on the stream it is launched on, same timed steps (procgen_amd_kernel_timing); its launches overlap the step kernels of the other chunk",
+                "achieved_GBs_observation_write": round(12288 * n / max(render_info[1], 1e-9) / (render_info[0] * 1e-3) / 1e9, 1)}
+        if pre > 0:
+            line["config"]["pre_rollout_steps"] = max(pre, args.warmup + min(args.steps, 100))
+            line["config"]["regime"] = "steady state: timed after the pre-rollout (episodes desynchronised, reset rate and arena tiers at their long-run level)"
+            line["steady_state"] = {"resets_per_env_step": round(resets / (n * args.steps), 6),
+                                    "arena_tier_envs": {"tier0": tiers[0], "tier1": tiers[1], "tier2": tiers[2]} if tiers is not None else None,
+                                    "note": "`value` IS the steady-state figure since round 5 (the verdict of round 4 used it); `cold_start` keeps the earlier rounds' regime"}
+        if cold is not None:
+            line["cold_start"] = cold
         if joint:
             line["roofline"]["launch"] = "one step = the step + render kernels of all games of the joint handle (wall time of the step, kernels of different games overlap)"
         if host_landed is not None:
             line["host_landed"] = host_landed
-        if steady is not None:
-            line["steady_state"] = steady
         if shard_crc is not None:
             line["shard_crc"] = shard_crc
         if args.dry_multi:

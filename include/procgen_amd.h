@@ -74,6 +74,14 @@ LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable
  * measured with HIP events on the library's own stream.  Used by bench.py for the roofline figure. */
 LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const int32_t *actions_or_null);
 
+/* Device time of the steps of the CALLER's own libenv_act / libenv_observe loop.  enable = 1: from now on every libenv_act brackets its
+ * kernels with two HIP events on the library's stream (counters reset); enable = 0: stop.  Either call returns the mean device
+ * milliseconds per step of the steps timed so far and their number in *steps_out (may be NULL).  bench.py times its measured loop this
+ * way, so that the device time and the wall time of a step come from the same steps.  render_out (may be NULL): [0] the mean duration in
+ * milliseconds of one launch of the render kernel -- the dominant kernel -- taken from events around each of its launches on the stream
+ * it is launched on, [1] its launches per step.  Single-part handles. */
+LIBENV_API double procgen_amd_kernel_timing(libenv_env *handle, int enable, int *steps_out, double *render_out);
+
 /* How many envs of the coming step each LDS arena tier of the step kernel owns (single-part handles): out[0..2] = tier 0, 1, 2.
  * Tiers 1 / 2 are the envs whose entity table may outgrow the smaller arena; the split drifts with the
  * horizon of a rollout (trails, spawned objects), which is why bench.py's steady_state object reports it.  Returns num_envs. */
@@ -94,6 +102,12 @@ LIBENV_API void procgen_amd_selftest_sincos_scaled(const uint32_t *bits, int n, 
  * the env workgroup j draws, for the background image indices bg_index[num_envs] and the handle's launch chunks (PROCGEN_AMD_CHUNKS,
  * PROCGEN_AMD_FIRST_PCT; defaults 2 and 75).  A permutation of every launch chunk's env range. */
 LIBENV_API void procgen_amd_selftest_render_order(const int *bg_index, int num_envs, int chunks, int first_pct, int *out);
+
+/* get_state of the envs [first, first + count) in one call: the states are packed back to back into data[0, capacity), state k at
+ * data[offsets[k], offsets[k + 1]) (offsets has count + 1 entries).  Returns the number of states that fit (>= 1); call again from
+ * first + that for the rest.  Same bytes as get_state; what env.get_state() of the Python mirror uses (the reference's loop,
+ * procgen/env.py:138-146, crosses cffi once per env with a 1 MiB buffer each). */
+LIBENV_API int procgen_amd_get_states(libenv_env *handle, int first, int count, char *data, long long capacity, long long *offsets);
 
 /* reference src/vecgame.cpp:437-457 (declared to cffi by reference procgen/env.py:132-135) */
 LIBENV_API int get_state(libenv_env *handle, int env_idx, char *data, int length);

@@ -15,6 +15,7 @@ struct LaunchStreams {
     hipEvent_t side_done[3];
     hipEvent_t step_done[MAX_CHUNKS];
     hipEvent_t outputs_done[MAX_CHUNKS];  // recorded on a chunk's stream when its envs' small outputs are final (null: not wanted)
+    hipEvent_t render_t0[MAX_CHUNKS], render_t1[MAX_CHUNKS];  // null: off.  Recorded around chunk c's render launch on its stream (procgen_amd_kernel_timing: the dominant kernel's own duration)
     int first_pct;            // experiment: share of the first of two chunks in percent (0 = even)
     int order;                // launch-order variant (PROCGEN_AMD_ORDER, see launch_game)
     int chunks;               // 1 = everything on `main`

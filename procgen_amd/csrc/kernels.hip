@@ -88,7 +88,14 @@ __global__ __launch_bounds__(64) void paint_backgrounds(DevCtx d, int env_base) 
     paint_background(d.gen_bg + (size_t)env * GEN_BG_WORDS, d.bg_req[2 * env], skip, &lds, &err);
     if (threadIdx.x == 0) {
         d.bg_req[2 * env + 1] = -1;
-        if (err) atomicOr(d.error, (int)PGE_ASSERT);
+        if (err) {
+            atomicOr(d.error, (int)PGE_ASSERT);
+            int *w = d.error + ERROR_INFO_OFFSET;
+            if (atomicCAS(w, 0, env + 1) == 0) {
+                w[1] = pg_error_word(PGE_ASSERT, __LINE__);
+                w[2] = ERR_KIND_BGPAINT;
+            }
+        }
     }
 }
 hipError_t launch_paint_backgrounds(const DevCtx &d, int env_base, int count, hipStream_t stream) {

@@ -165,7 +165,9 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
             if (!(d.debug_flags & 32) || mode == 0) hipLaunchKernelGGL(step_tier0<Game>, dim3(d.num_envs), dim3(64), 0, ls.main, d, mode, 0);
         }
         PG_TRY(launch_paint_backgrounds(d, 0, d.num_envs, ls.main));
+        if (ls.render_t0[0]) PG_TRY(hipEventRecord(ls.render_t0[0], ls.main));
         if (!(d.debug_flags & 16)) launch_render<Game>(d, 0, d.num_envs, ls.main, true);
+        if (ls.render_t1[0]) PG_TRY(hipEventRecord(ls.render_t1[0], ls.main));
         return hipGetLastError();
     }
     // At most four streams: the runtime deals a process's streams round-robin onto four hardware queues, and two streams on one
@@ -220,7 +222,9 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         // rew / first / info of this chunk's envs, and the list counters, are final here (step, list and reset kernels done): what the
         // early download of the step's small outputs waits for (libenv_hip.cpp VecGame::launch)
         if (ls.outputs_done[c]) PG_TRY(hipEventRecord(ls.outputs_done[c], st));
+        if (ls.render_t0[c]) PG_TRY(hipEventRecord(ls.render_t0[c], st));
         if (!(d.debug_flags & 16)) launch_render<Game>(d, base, count, st, c == 0);
+        if (ls.render_t1[c]) PG_TRY(hipEventRecord(ls.render_t1[c], st));
     }
     for (int k = 0; k < 2; k++) {
         PG_TRY(hipEventRecord(ls.lane_done[k], ls.lane[k]));

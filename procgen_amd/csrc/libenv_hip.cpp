@@ -13,8 +13,10 @@
 #include <algorithm>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -121,6 +123,56 @@ T *dev_alloc(size_t count) {
     return (T *)p;
 }
 
+// The sprite atlas of a game is read-only and the same for every handle of the process that plays the game with the same assets: the
+// decoded images are kept once per process (a 16-game x 8-device handle has 128 parts; coinrun's pack alone decodes to 230 MB) and the
+// device copy once per device, shared by the parts (and handles) that sit there.  Entries live as long as a part holds them.
+struct DeviceAtlas {
+    std::shared_ptr<const HostAssets> host;
+    int device = 0;
+    GameAssetsDev *d_assets = nullptr;
+    uint32_t *d_pixels = nullptr;
+    ~DeviceAtlas() {
+        (void)hipSetDevice(device);
+        if (d_assets) (void)hipFree(d_assets);
+        if (d_pixels) (void)hipFree(d_pixels);
+    }
+};
+static std::mutex g_atlas_mutex;
+static std::map<std::string, std::weak_ptr<const HostAssets>> g_host_atlas;
+static std::map<std::string, std::weak_ptr<DeviceAtlas>> g_device_atlas;
+// (the caller has selected `device`)
+static std::shared_ptr<DeviceAtlas> shared_atlas(int device, const std::string &key, const std::function<void(HostAssets *)> &load) {
+    std::lock_guard<std::mutex> lk(g_atlas_mutex);
+    const std::string dkey = std::to_string(device) + "|" + key;
+    if (auto have = g_device_atlas[dkey].lock()) return have;
+    std::shared_ptr<const HostAssets> host = g_host_atlas[key].lock();
+    if (!host) {
+        auto fresh = std::make_shared<HostAssets>();
+        load(fresh.get());
+        host = fresh;
+        g_host_atlas[key] = host;
+    }
+    auto da = std::make_shared<DeviceAtlas>();
+    da->host = host;
+    da->device = device;
+    da->d_assets = dev_alloc<GameAssetsDev>(1);
+    HIP_CHECK(hipMemcpy(da->d_assets, &host->table, sizeof(GameAssetsDev), hipMemcpyHostToDevice));
+    da->d_pixels = dev_alloc<uint32_t>(host->pixels.size());
+    HIP_CHECK(hipMemcpy(da->d_pixels, host->pixels.data(), host->pixels.size() * 4, hipMemcpyHostToDevice));
+    g_device_atlas[dkey] = da;
+    return da;
+}
+
+// BAG:819-838 prepare_for_drawing(64): the camera scalars that depend on the frame height, for the 64-pixel observation frame (centre
+// and visibility do not depend on it)
+static void camera_scalars_of_the_observation_frame(EnvHdr *h) {
+    const float raw_unit = 64 / h->visibility;
+    h->unit = (float)((double)raw_unit * (64.0 / 64.0));
+    h->view_dim = (float)(64.0 / (double)raw_unit);
+    h->x_off = h->unit * (h->center_x - h->view_dim / 2);
+    h->y_off = h->unit * (h->center_y - h->view_dim / 2);
+}
+
 struct VecGame {
     int num_envs = 0;
     int game_id = -1;    // assets, state wire format
@@ -128,6 +180,7 @@ struct VecGame {
     int device_id = 0;
     bool host_observations = true;
     bool render_human = false;   // reference src/vecgame.cpp:190,270-282: a fourth info tensor "rgb" [512][512][3] (pg_human.h)
+    bool api_observed = true;    // libenv_observe has been called since the last libenv_act (render_human: whose camera scalars get_state sees)
     bool human_stale = false;    // a set_state since the frames were last drawn: the next libenv_observe redraws them (reference src/vecgame.cpp:367-375 redraws on every observe)
     std::vector<void *> human_ptr;  // caller's info "rgb" buffers
     bool human_contig = false;
@@ -163,18 +216,20 @@ struct VecGame {
         }
         for (int c = 0; c < MAX_CHUNKS; c++) ls.step_done[c] = ev_step[c];
         for (int c = 0; c < MAX_CHUNKS; c++) ls.outputs_done[c] = early_small ? ev_out[c] : nullptr;
+        for (int c = 0; c < MAX_CHUNKS; c++) {
+            ls.render_t0[c] = time_kernels ? tk_r0[c] : nullptr;
+            ls.render_t1[c] = time_kernels ? tk_r1[c] : nullptr;
+        }
         ls.order = order;
         ls.first_pct = first_pct;
         ls.chunks = chunks;
         return ls;
     }
     DevCtx d{};
-    HostAssets assets;
-    GameAssetsDev *d_assets = nullptr;
-    uint32_t *d_pixels = nullptr;
+    std::shared_ptr<DeviceAtlas> atlas;  // sprite atlas on this part's device, shared with every other part that plays the same game there
     uint32_t *d_game_tables = nullptr;
     int32_t *d_action = nullptr;
-    // [rew f32 N | prev_level_seed i32 N | level_seed i32 N | first u8 N | prev_level_complete u8 N | list counts A i32 x LIST_COUNTERS | error i32 | list counts B]
+    // [rew f32 N | prev_level_seed i32 N | level_seed i32 N | first u8 N | prev_level_complete u8 N | list counts A i32 x LIST_COUNTERS | error i32 | list counts B | error info i32 x ERROR_INFO_WORDS]
     // The tail doubles as the tier-list counters (double-buffered A / B) so that one memset clears "next counts + error" and
     // the one download per step tells the host which list kernels have work next step.
     uint8_t *d_small = nullptr;
@@ -227,10 +282,19 @@ struct VecGame {
     void set_buffers(struct libenv_buffers *bufs);
     void launch_kernels(int mode);
     void read_tail();
+    [[noreturn]] void report_device_error(int err, const int *info, const char *when);
+    void check_late_error();
+    // procgen_amd_kernel_timing: HIP events around the kernels of every libenv_act of the caller's own loop (bench.py: the device time of
+    // a step and the wall time of a step then come from the SAME steps)
+    bool time_kernels = false, tk_pending = false;
+    hipEvent_t tk_e0 = nullptr, tk_e1 = nullptr, tk_r0[MAX_CHUNKS] = {}, tk_r1[MAX_CHUNKS] = {};
+    double tk_sum_ms = 0, tk_render_ms = 0;
+    int tk_steps = 0, tk_render_launches = 0;
+    int *h_late_error = nullptr;  // pinned: the error word and its info record as they stand behind the render kernels (early_small handles)
     void launch(int mode);
     void act();
     void observe(bool from_api = false);
-    int get_state(int env_idx, char *data, int length);
+    int get_state(int env_idx, char *data, int length, bool may_not_fit = false);
     void set_state(int env_idx, const char *data, int length);
     void snapshot(int env_idx, EnvSnapshot *s, bool single = false);
     static constexpr int SNAP_BLOCK = 256;
@@ -400,11 +464,17 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         for (int k = 0; k < 3; k++) HIP_CHECK(hipEventCreateWithFlags(&ev_side[k], hipEventDisableTiming));
         const char *es = getenv("PROCGEN_AMD_EARLY_SMALL");
         // (not for the split-reset games: their outputs are final only behind the reset kernels, and the extra stream cost jumper 7 %)
-        if (!(es && atoi(es) == 0) && !getenv("PROCGEN_AMD_DEBUG") && !game_split_reset(kernel_id)) {
+        // (and only with a hardware queue to spare: main + two chunk streams take three of the runtime's default four, a fifth stream then
+        // shares a queue with one of them and its copy can serialise behind a render kernel -- the A/B that found the gain ran with 16)
+        const char *hq = getenv("GPU_MAX_HW_QUEUES");
+        const bool spare_queue = hq && atoi(hq) >= 5;
+        if (!(es && atoi(es) == 0) && (spare_queue || (es && atoi(es) != 0)) && !getenv("PROCGEN_AMD_DEBUG") && !game_split_reset(kernel_id)) {
             HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&ev_small, hipEventDisableTiming));
             for (int c = 0; c < MAX_CHUNKS; c++) HIP_CHECK(hipEventCreateWithFlags(&ev_out[c], hipEventDisableTiming));
             early_small = true;
+            HIP_CHECK(hipHostMalloc((void **)&h_late_error, (1 + ERROR_INFO_WORDS) * sizeof(int), hipHostMallocDefault));
+            memset(h_late_error, 0, (1 + ERROR_INFO_WORDS) * sizeof(int));
         }
     }
     if (const char *c = getenv("PROCGEN_AMD_CHUNKS")) chunks = atoi(c) > 0 ? (atoi(c) < MAX_CHUNKS ? atoi(c) : MAX_CHUNKS) : 1;
@@ -413,12 +483,17 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     // assets: baked pack next to the library (procgen_amd/data/<game>.atlas) or the PNG tree at resource_root
     std::string data_dir = getenv("PROCGEN_AMD_DATA_DIR") ? getenv("PROCGEN_AMD_DATA_DIR") : this_library_dir() + "/../../data";
     std::string err;
-    if (o.use_generated_assets) generate_game_assets(env_name, game_use_block_asset(kernel_id), &assets);
-    else if (!load_game_assets(game_id, resource_root, data_dir + "/" + env_name + ".atlas", &assets, &err)) fatal("failed to load images %s\n", err.c_str());
-    d_assets = dev_alloc<GameAssetsDev>(1);
-    HIP_CHECK(hipMemcpy(d_assets, &assets.table, sizeof(GameAssetsDev), hipMemcpyHostToDevice));
-    d_pixels = dev_alloc<uint32_t>(assets.pixels.size());
-    HIP_CHECK(hipMemcpy(d_pixels, assets.pixels.data(), assets.pixels.size() * 4, hipMemcpyHostToDevice));
+    {
+        const std::string atlas_path = data_dir + "/" + env_name + ".atlas";
+        const int kid = kernel_id, gid = game_id;
+        const bool gen = o.use_generated_assets != 0;
+        const std::string key = env_name + "|" + (gen ? "generated|" + std::to_string(kid) : atlas_path + "|" + resource_root);
+        atlas = shared_atlas(device_id, key, [&](HostAssets *out) {
+            std::string err;
+            if (gen) generate_game_assets(env_name, game_use_block_asset(kid), out);
+            else if (!load_game_assets(gid, resource_root, atlas_path, out, &err)) fatal("failed to load images %s\n", err.c_str());
+        });
+    }
 
     // per-env state in HBM
     const size_t N = (size_t)num_envs;
@@ -448,7 +523,7 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d_action = dev_alloc<int32_t>(N);
     d.action = d_action;
     d.obs = dev_alloc<uint8_t>(N * OBS_BYTES);
-    small_bytes = N * 14 + 4 + (2 * LIST_COUNTERS + 1) * sizeof(int);
+    small_bytes = N * 14 + 4 + (2 * LIST_COUNTERS + 1 + ERROR_INFO_WORDS) * sizeof(int);
     d_small = dev_alloc<uint8_t>(small_bytes);
     d.rew = (float *)d_small;
     d.prev_level_seed = (int32_t *)(d_small + 4 * N);
@@ -457,7 +532,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d.prev_level_complete = d_small + 13 * N;
     tail_off = (14 * N + 3) & ~(size_t)3;
     d.error = (int *)(d_small + tail_off) + LIST_COUNTERS;
-    small_bytes = tail_off + (2 * LIST_COUNTERS + 1) * sizeof(int);
+    static_assert(ERROR_INFO_OFFSET == LIST_COUNTERS + 1, "the error record lies behind the second counter block");
+    small_bytes = tail_off + (2 * LIST_COUNTERS + 1 + ERROR_INFO_WORDS) * sizeof(int);
     for (int k = 0; k < 2; k++) {
         d_big_list[k] = dev_alloc<int>(N * NUM_TIERS);
         d_big_count[k] = (int *)(d_small + tail_off) + (LIST_COUNTERS + 1) * k;  // A, then the error word, then B
@@ -467,13 +543,14 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d_reset_count = dev_alloc<int>(2 * MAX_CHUNKS);
     if (const char *ro = getenv("PROCGEN_AMD_RENDER_ORDER")) render_order_period = atoi(ro);
     if (render_order_period > 0 && !d.opt.use_generated_assets) d_render_order = dev_alloc<int>(N);  // (bound to d.render_order by the first rebuild)
-    d.assets = d_assets;
-    d.pixels = d_pixels;
+    d.assets = atlas->d_assets;
+    d.pixels = atlas->d_pixels;
     if (this->render_human) {
         const size_t bytes = N * HUMAN_BYTES;
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        if (bytes + (1ull << 30) > free_b) fatal("render_human needs %zu MB of device memory for %d info frames of 512 x 512 x 3; %zu MB free\n", bytes >> 20, num_envs, free_b >> 20);
+        // (a headroom check for large requests only: a small handle on a shared, nearly full GPU still gets its few MB or hipMalloc's own error)
+        if (bytes > (256ull << 20) && bytes + (1ull << 30) > free_b) fatal("render_human needs %zu MB of device memory for %d info frames of 512 x 512 x 3; %zu MB free\n", bytes >> 20, num_envs, free_b >> 20);
         d.human = dev_alloc<uint8_t>(bytes);
     }
     if (o.use_generated_assets) {
@@ -549,8 +626,7 @@ VecGame::~VecGame() {
         (void)hipFree(d.phase_cycles);
     }
     if (registered_obs && !ob_ptr.empty()) (void)hipHostUnregister(ob_ptr[0]);
-    (void)hipFree(d_assets);
-    (void)hipFree(d_pixels);
+    atlas.reset();
     if (d.gen_bg) (void)hipFree(d.gen_bg);
     if (d.bg_req) (void)hipFree(d.bg_req);
     if (d_game_tables) (void)hipFree(d_game_tables);
@@ -571,6 +647,7 @@ VecGame::~VecGame() {
     if (d_render_order) (void)hipFree(d_render_order);
     if (h_action) (void)hipHostFree(h_action);
     if (h_small) (void)hipHostFree(h_small);
+    if (h_late_error) (void)hipHostFree(h_late_error);
     if (h_obs_stage) (void)hipHostFree(h_obs_stage);
     for (int k = 0; k < 2; k++) {
         if (ev_lane[k]) (void)hipEventDestroy(ev_lane[k]);
@@ -587,6 +664,12 @@ VecGame::~VecGame() {
         if (ev_out[c]) (void)hipEventDestroy(ev_out[c]);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (tk_e0) (void)hipEventDestroy(tk_e0);
+    if (tk_e1) (void)hipEventDestroy(tk_e1);
+    for (int c = 0; c < MAX_CHUNKS; c++) {
+        if (tk_r0[c]) (void)hipEventDestroy(tk_r0[c]);
+        if (tk_r1[c]) (void)hipEventDestroy(tk_r1[c]);
+    }
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -723,11 +806,56 @@ void VecGame::read_tail() {
     const int *cnt = tail + (LIST_COUNTERS + 1) * (int)(step_count & 1);  // the lists the step just run filled are the ones the next step reads
     for (int c = 0; c < MAX_CHUNKS; c++)
         for (int t = 0; t < NUM_TIERS; t++) host_list_count[c][t] = cnt[c * NUM_TIERS + t];
-    if (err && !d.debug_flags) fatal("device-side check failed (code %d: 1 entity table overflow, 2 grid index out of range, 3 fassert, 4 asset theme, 5 unsupported draw)\n", err);
+    if (err && !d.debug_flags) report_device_error(err, tail + 2 * LIST_COUNTERS + 1, "a step");
+}
+
+// The first device-side check that failed ends the run, like the reference's fassert (src/cpp-utils.h:9-11).  The message names the
+// env that raised it, the source line of the check and the kernel, and the fatal log (PROCGEN_AMD_FATAL_LOG) also gets the env's whole
+// header and its routing entries: what a post-mortem of a failure that does not reproduce needs.
+void VecGame::report_device_error(int err, const int *info, const char *when) {
+    std::string extra;
+    const int env = info[0] - 1;
+    if (env >= 0 && env < num_envs) {
+        char buf[512];
+        const int kind = info[2];
+        const char *kname = kind >= ERR_KIND_BGPAINT ? "paint_backgrounds" : kind >= ERR_KIND_HUMAN ? "render_human" : kind >= ERR_KIND_RENDER ? "render" : "step / reset kernel with an entity arena of";
+        snprintf(buf, sizeof buf, "  first reporter: env %d (global index %d), check at source line %d (code %d) in %s %d; n_ents %d agent %d; handle: %d envs, game %d, launch #%llu\n",
+                 env, env_offset + env * env_stride, info[1] >> 8, info[1] & 0xff, kname, kind % ERR_KIND_RENDER, info[3], info[4], num_envs, game_id, (unsigned long long)step_count);
+        extra = buf;
+        (void)hipDeviceSynchronize();
+        EnvHdr h;
+        uint8_t r0 = 0, r1 = 0;
+        if (hipMemcpy(&h, d.hdr + env, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(&r0, d_route[0] + env, 1, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(&r1, d_route[1] + env, 1, hipMemcpyDeviceToHost) == hipSuccess) {
+            extra += "  header now:";
+#define PG_X(type, name) snprintf(buf, sizeof buf, std::is_same<type, float>::value ? " " #name "=%g" : " " #name "=%.0f", (double)h.name); extra += buf;
+            PG_HDR_FIELDS(PG_X)
+#undef PG_X
+            snprintf(buf, sizeof buf, "\n  route[0]=%d route[1]=%d (this launch read route[%d]); list counts the host launched with:", r0, r1, (int)((step_count + 1) & 1));
+            extra += buf;
+            for (int t = 0; t < NUM_TIERS; t++) {
+                snprintf(buf, sizeof buf, " t%d=%d", t, host_list_count[0][t]);
+                extra += buf;
+            }
+            extra += "\n";
+        }
+    }
+    fatal("device-side check failed during %s (code %d: 1 entity table overflow, 2 grid index out of range, 3 fassert, 4 asset theme, 5 unsupported draw)\n%s", when, err, extra.c_str());
+}
+
+// early_small handles: the error word as it stands behind the render kernels (the early download left before they ran)
+void VecGame::check_late_error() {
+    if (!h_late_error) return;
+    if (h_late_error[0] && !d.debug_flags) report_device_error(h_late_error[0], h_late_error + 1, "a step's frames");
 }
 
 void VecGame::launch(int mode) {
+    if (time_kernels) HIP_CHECK(hipEventRecord(tk_e0, stream));
     launch_kernels(mode);
+    if (time_kernels) {
+        HIP_CHECK(hipEventRecord(tk_e1, stream));  // (main has joined the chunk streams: behind every kernel of the step)
+        tk_pending = true;
+    }
     if (early_small) {
         // behind every step kernel of the step (chunk grids on the lane streams, list kernels), not behind the render kernels.  The error
         // word travels with it: an error a render kernel of this step raises reaches the host one step later (the word is sticky).
@@ -737,6 +865,11 @@ void VecGame::launch(int mode) {
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, copy_stream));
         HIP_CHECK(hipEventRecord(ev_small, copy_stream));
         small_in_flight = true;
+        // ... and once more behind the render kernels (main has joined the chunk streams): an error a render kernel of THIS step raises
+        // ends the run at this step's libenv_observe, before the caller sees the frame (two small copies; the error word and its record
+        // are not adjacent -- the second list-counter block lies between them)
+        HIP_CHECK(hipMemcpyAsync(h_late_error, d.error, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(h_late_error + 1, (d.error + ERROR_INFO_OFFSET), ERROR_INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost, stream));
     } else {
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
     }
@@ -766,6 +899,7 @@ void VecGame::act() {  // reference src/vecgame.cpp:378-401
     if (!buffers_set) fatal("libenv_act called before libenv_set_buffers\n");
     use_device();
     observe();  // wait_for_stepping_threads()
+    api_observed = false;
     if (d_render_order && step_count % (uint64_t)render_order_period == 0) rebuild_render_order();
     const int N = num_envs;
     // the action values are only valid for the duration of this call (reference src/vecgame.cpp:387-388)
@@ -777,6 +911,7 @@ void VecGame::act() {  // reference src/vecgame.cpp:378-401
 }
 
 void VecGame::observe(bool from_api) {  // reference src/vecgame.cpp:363-376,416-435
+    if (from_api) api_observed = true;
     if (from_api && render_human && human_stale && !pending) {  // states restored since the frames were drawn: VecGame::observe redraws every env's
         use_device();
         launch_human(0, num_envs);
@@ -808,9 +943,28 @@ void VecGame::observe(bool from_api) {  // reference src/vecgame.cpp:363-376,416
             *(int32_t *)info_ptr[2][e] = ls[e];
         }
     }
-    if (early_small) HIP_CHECK(hipStreamSynchronize(stream));  // (the render kernels, the landing of the frames)
+    if (early_small) {
+        HIP_CHECK(hipStreamSynchronize(stream));  // (the render kernels, the landing of the frames)
+        check_late_error();
+    }
     if (host_observations && !ob_contig)
         for (size_t e = 0; e < N; e++) memcpy(ob_ptr[e], h_obs_stage + e * OBS_BYTES, OBS_BYTES);
+    if (tk_pending) {  // (the stream is joined: both events have completed)
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, tk_e0, tk_e1));
+        tk_sum_ms += ms;
+        tk_steps++;
+        const int nchunk = num_envs < 4096 ? 1 : (chunks > 1 ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1);  // (the render launches of launch_game)
+        for (int c = 0; c < nchunk; c++) {
+            if (hipEventElapsedTime(&ms, tk_r0[c], tk_r1[c]) == hipSuccess) {
+                tk_render_ms += ms;
+                tk_render_launches++;
+            } else {
+                (void)hipGetLastError();  // (a chunk without envs records nothing)
+            }
+        }
+        tk_pending = false;
+    }
 }
 
 // Host copy of one env's device state.  env.get_state() walks all envs: the state of a block of SNAP_BLOCK consecutive envs is
@@ -852,7 +1006,8 @@ void VecGame::snapshot(int e, EnvSnapshot *s, bool single) {
     s->grid.assign(snap_grid.begin() + k * grid_b, snap_grid.begin() + (k + 1) * grid_b);
 }
 
-int VecGame::get_state(int e, char *data, int length) {  // reference src/vecgame.cpp:438-445
+// may_not_fit: a buffer too small for the state returns -1 instead of ending the process (procgen_amd_get_states packs states back to back)
+int VecGame::get_state(int e, char *data, int length, bool may_not_fit) {  // reference src/vecgame.cpp:438-445
     if (d.opt.use_generated_assets) fatal("fassert failed '!options.use_generated_assets' (BasicAbstractGame::serialize)\n");  // BAG:1176
     if (!buffers_set) fatal("get_state called before libenv_set_buffers\n");
     if (e < 0 || e >= num_envs) fatal("get_state: env index %d out of range\n", e);
@@ -860,9 +1015,16 @@ int VecGame::get_state(int e, char *data, int length) {  // reference src/vecgam
     observe();  // wait_for_stepping_threads()
     EnvSnapshot s;
     snapshot(e, &s);
+    // render_human, between libenv_act and libenv_observe: the reference's stepping thread has drawn the 64-pixel frame only -- the 512-pixel
+    // ones are drawn by VecGame::observe (src/vecgame.cpp:363-376) -- so its get_state carries the 64-pixel frame's camera scalars.  Here the
+    // info frames were drawn behind the step already and left theirs in the header: serialize what the reference would
+    if (render_human && !api_observed) camera_scalars_of_the_observation_frame(&s.hdr);
     int written = 0;
     std::string err;
-    if (!serialize_state(game_id, d.opt, env_offset + e * env_stride, s, data, length, &written, &err)) fatal("%s\n", err.c_str());
+    if (!serialize_state(game_id, d.opt, env_offset + e * env_stride, s, data, length, &written, &err)) {
+        if (may_not_fit) return -1;
+        fatal("%s\n", err.c_str());
+    }
     return written;
 }
 
@@ -879,14 +1041,9 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     // routing: the restored env takes a wave = env kernel for one step (conservative bound: a step at most doubles the
     // table); the lists the next step walks are rebuilt from the host's copy of the route table before the next launch,
     // so restoring the same env several times, in any tier order, leaves exactly one entry for it
-    {   // the wire format carries the camera scalars of the LAST frame drawn, which is the 512-pixel one when the state was saved
-        // under render_human; Game::observe redraws the 64-pixel frame through prepare_for_drawing(64) (BAG:819-838)
-        const float raw_unit = 64 / s.hdr.visibility;
-        s.hdr.unit = (float)((double)raw_unit * (64.0 / 64.0));
-        s.hdr.view_dim = (float)(64.0 / (double)raw_unit);
-        s.hdr.x_off = s.hdr.unit * (s.hdr.center_x - s.hdr.view_dim / 2);
-        s.hdr.y_off = s.hdr.unit * (s.hdr.center_y - s.hdr.view_dim / 2);
-    }
+    // the wire format carries the camera scalars of the LAST frame drawn, which is the 512-pixel one when the state was saved
+    // under render_human; Game::observe redraws the 64-pixel frame through prepare_for_drawing(64) (BAG:819-838)
+    camera_scalars_of_the_observation_frame(&s.hdr);
     human_stale = true;
     snap_first = -1;
     const int tier = game_tier_for(kernel_id, 2 * s.hdr.n_ents + 4);
@@ -911,12 +1068,25 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     HIP_CHECK(hipMemcpy(d.prev_level_complete + e, &plc, 1, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.level_seed + e, &s.hdr.current_level_seed, 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipStreamSynchronize(nullptr));  // the uploads above ran on the null stream: joined before the handle's (non-blocking) stream reads them
+    {   // an error a kernel raised since the last download (a render kernel of the last step on a handle without the late check) must not
+        // be lost to the clear below: the first device error ends the run
+        int old[1 + ERROR_INFO_WORDS] = {0};
+        HIP_CHECK(hipMemcpy(old, d.error, sizeof(int), hipMemcpyDeviceToHost));
+        if (old[0] && !d.debug_flags) {
+            HIP_CHECK(hipMemcpy(old + 1, (d.error + ERROR_INFO_OFFSET), ERROR_INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost));
+            report_device_error(old[0], old + 1, "the last step's frames");
+        }
+    }
     HIP_CHECK(hipMemsetAsync(d.error, 0, sizeof(int), stream));
+    HIP_CHECK(hipMemsetAsync((d.error + ERROR_INFO_OFFSET), 0, ERROR_INFO_WORDS * sizeof(int), stream));
     HIP_CHECK(launch_render_one(kernel_id, d, e, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    int dev_err = 0;
-    HIP_CHECK(hipMemcpy(&dev_err, d.error, sizeof(int), hipMemcpyDeviceToHost));
-    if (dev_err && !d.debug_flags) fatal("device-side check failed while drawing a restored state (code %d)\n", dev_err);
+    int dev_err[1 + ERROR_INFO_WORDS] = {0};
+    HIP_CHECK(hipMemcpy(dev_err, d.error, sizeof(int), hipMemcpyDeviceToHost));
+    if (dev_err[0] && !d.debug_flags) {
+        HIP_CHECK(hipMemcpy(dev_err + 1, (d.error + ERROR_INFO_OFFSET), ERROR_INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost));
+        report_device_error(dev_err[0], dev_err + 1, "the drawing of a restored state");
+    }
     rew_ptr[e] = s.hdr.reward;
     first_ptr[e] = first;
     *(int32_t *)info_ptr[0][e] = s.hdr.prev_level_seed;
@@ -1044,11 +1214,13 @@ __attribute__((constructor)) static void procgen_amd_default_hw_queues() {
     if (want && atoi(want) != 0) setenv("GPU_MAX_HW_QUEUES", "16", 0);
 }
 
-// relative length of one step of a ~1000-env part (profiles/r02_joint_kernel_trace.csv: the slowest kernel chain per game)
+// relative length of one step of a ~1000-env part: the part's kernel chain (step -> reset_list / list kernels -> render) in units of
+// ~50 us, from the joint handle's kernel trace (profiles/r03_kernel_trace_all16_joint.csv, the generators of round 3 included:
+// leaper 68 + 565 + 111 us, jumper 55 + 345 + 150, coinrun 250 + 122 with its list kernels beside, ... chaser 56 + 86)
 static int part_cost_rank(const std::string &name) {
     static const struct { const char *name; int cost; } table[] = {
-        {"leaper", 16}, {"jumper", 12}, {"caveflyer", 9}, {"coinrun", 4}, {"bossfight", 3}, {"maze", 3}, {"heist", 2}, {"fruitbot", 2},
-        {"dodgeball", 2}, {"starpilot", 2}, {"climber", 2}, {"miner", 1}, {"ninja", 1}, {"chaser", 1}, {"bigfish", 1}, {"plunder", 1}};
+        {"leaper", 15}, {"jumper", 11}, {"coinrun", 10}, {"bossfight", 10}, {"caveflyer", 9}, {"heist", 7}, {"fruitbot", 7}, {"starpilot", 6},
+        {"maze", 6}, {"ninja", 5}, {"dodgeball", 4}, {"miner", 4}, {"plunder", 4}, {"bigfish", 4}, {"climber", 3}, {"chaser", 3}};
     for (const auto &t : table)
         if (name == t.name) return t.cost;
     return 1;
@@ -1116,7 +1288,9 @@ LIBENV_API libenv_env *libenv_make(int num_envs, const struct libenv_options opt
         for (int p = 0; p < P; p++) by_cost[p] = p;
         auto cost = [&](int p) { return part_cost_rank(names[h->map.game_of_part(p)]); };
         std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return cost(a) > cost(b); });
-        const int Q = 4;
+        // (the queues the runtime really has: GPU_MAX_HW_QUEUES as the process set it, 4 when unset)
+        int Q = 4;
+        if (const char *q = getenv("GPU_MAX_HW_QUEUES")) Q = atoi(q) > 0 ? (atoi(q) < 64 ? atoi(q) : 64) : 4;
         for (int r = 0; r * Q < P; r++)
             for (int q = 0; q < Q; q++) {
                 const int k = r * Q + ((r & 1) ? Q - 1 - q : q);
@@ -1135,7 +1309,12 @@ LIBENV_API libenv_env *libenv_make(int num_envs, const struct libenv_options opt
                 fprintf(stderr, "procgen_amd: %d parts on %s hardware queues: set GPU_MAX_HW_QUEUES=16 before the process's first HIP call (INTEGRATION.md section 5) for ~1.5x on joint handles\n", h->P(), q ? q : "the default 4");
             }
         }
-        int threads = h->P() < 8 ? h->P() : 8;
+        // issuing threads: one per part up to the host's cores (a 16-game x 8-device handle has 128 parts, ~10 runtime calls each per
+        // step), at most 32 -- the runtime serialises calls per device, more threads than that only contend
+        int threads = h->P();
+        const int cores = (int)std::thread::hardware_concurrency();
+        if (cores > 0 && threads > cores) threads = cores;
+        if (threads > 32) threads = 32;
         if (const char *t = getenv("PROCGEN_AMD_HOST_THREADS")) threads = atoi(t);
         if (threads > 1) h->pool.reset(new PartPool(threads));
     }
@@ -1219,6 +1398,27 @@ LIBENV_API int get_state(libenv_env *handle, int env_idx, char *data, int length
     if (env_idx < 0 || env_idx >= h->num_envs) fatal("get_state: env index %d out of range\n", env_idx);
     return h->parts[h->map.part_of(env_idx)]->get_state(h->map.index_in_part(env_idx), data, length);
 }
+// get_state of envs [first, first + count), packed back to back: state k occupies data[offsets[k], offsets[k + 1]).  Returns how many
+// states fit into `capacity` bytes (the caller goes on from there); the device state of 256 consecutive envs of a part moves in four
+// copies (VecGame::snapshot), and the caller crosses the FFI once per block instead of once per env.
+LIBENV_API int procgen_amd_get_states(libenv_env *handle, int first, int count, char *data, long long capacity, long long *offsets) {
+    Handle *h = (Handle *)handle;
+    if (first < 0 || count < 0 || first + count > h->num_envs) fatal("procgen_amd_get_states: envs [%d, %d) out of range\n", first, first + count);
+    long long off = 0;
+    offsets[0] = 0;
+    for (int k = 0; k < count; k++) {
+        const int e = first + k;
+        const long long room = capacity - off;
+        const int n = h->parts[h->map.part_of(e)]->get_state(h->map.index_in_part(e), data + off, room > 0x7fffffffLL ? 0x7fffffff : (int)room, true);
+        if (n < 0) {
+            if (k == 0) fatal("procgen_amd_get_states: %lld bytes do not hold one state\n", capacity);
+            return k;
+        }
+        off += n;
+        offsets[k + 1] = off;
+    }
+    return count;
+}
 LIBENV_API void set_state(libenv_env *handle, int env_idx, char *data, int length) {
     Handle *h = (Handle *)handle;
     if (env_idx < 0 || env_idx >= h->num_envs) fatal("set_state: env index %d out of range\n", env_idx);
@@ -1262,6 +1462,31 @@ LIBENV_API int procgen_amd_part_buffers(libenv_env *handle, struct procgen_amd_p
         strncpy(out[p].game, game_name_from_id(v->game_id), sizeof(out[p].game) - 1);
     }
     return h->P();
+}
+LIBENV_API double procgen_amd_kernel_timing(libenv_env *handle, int enable, int *steps_out, double *render_out) {
+    VecGame *v = ((Handle *)handle)->single();
+    v->use_device();
+    v->observe();
+    const double mean = v->tk_steps > 0 ? v->tk_sum_ms / v->tk_steps : 0.0;
+    if (steps_out) *steps_out = v->tk_steps;
+    if (render_out) {
+        render_out[0] = v->tk_render_launches > 0 ? v->tk_render_ms / v->tk_render_launches : 0.0;
+        render_out[1] = v->tk_steps > 0 ? (double)v->tk_render_launches / v->tk_steps : 0.0;
+    }
+    if (enable) {
+        if (!v->tk_e0) {
+            HIP_CHECK(hipEventCreate(&v->tk_e0));
+            HIP_CHECK(hipEventCreate(&v->tk_e1));
+            for (int c = 0; c < MAX_CHUNKS; c++) {
+                HIP_CHECK(hipEventCreate(&v->tk_r0[c]));
+                HIP_CHECK(hipEventCreate(&v->tk_r1[c]));
+            }
+        }
+        v->tk_sum_ms = v->tk_render_ms = 0;
+        v->tk_steps = v->tk_render_launches = 0;
+    }
+    v->time_kernels = enable != 0;
+    return mean;
 }
 LIBENV_API int procgen_amd_tier_counts(libenv_env *handle, int *out) {
     VecGame *v = ((Handle *)handle)->single();

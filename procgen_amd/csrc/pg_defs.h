@@ -143,6 +143,9 @@ inline size_t ent_table_words(int num_envs, int ent_cap) { return (size_t)num_en
 // values of the route table (which step kernel owns an env this step): 0..2 = the kernel with LDS arena tier 0..2
 constexpr int MAX_CHUNKS = 8;
 constexpr int LIST_COUNTERS = MAX_CHUNKS * 3;  // [chunk][tier] (NUM_TIERS == 3)  // env chunks of one step (step of chunk c+1 overlaps the render of chunk c)
+constexpr int ERROR_INFO_WORDS = 8;
+constexpr int ERROR_INFO_OFFSET = MAX_CHUNKS * 3 + 1;  // words from DevCtx::error to the record: the second list-counter block lies between them (libenv_hip.cpp d_small)
+constexpr int ERR_KIND_RENDER = 100000, ERR_KIND_HUMAN = 200000, ERR_KIND_BGPAINT = 300000;  // DevCtx::error_info[2] (a step / reset kernel reports its entity arena size)
 constexpr int ROUTE_RESET = 4;  // EnvHdr::big only: a NO_RESET step kernel ended the episode, the reset kernel of the same step takes over
 
 constexpr int GEN_BG_DIM = 500;  // use_generated_assets: the per-env background canvas (reference BAG:62)
@@ -234,6 +237,10 @@ struct DevCtx {
     int *reset_count;       // [MAX_CHUNKS] per env chunk, this step
     int *next_reset_count;  // [MAX_CHUNKS] the next step's counters (double-buffered by step parity), zeroed by this step's lane kernel
     int *error;            // [1] OR of the per-env error codes raised so far (0 = none; sticky: the host stops at the first one)
+    // error + ERROR_INFO_OFFSET, [ERROR_INFO_WORDS] (device builds; no pointer of its own: a kernel argument is live for a whole kernel, and the
+    // render kernels have no scalar register to spare): who raised the first one, claimed with a compare-and-swap on word 0: env + 1,
+    // code | source line << 8, kernel kind (a step kernel's arena size; ERR_KIND_*), n_ents, agent.  The host prints it with the env's
+    // header when it ends the run (libenv_hip.cpp VecGame::report_device_error).
     // launch order of the render kernel (experiment, PROCGEN_AMD_RENDER_ORDER; null = identity): workgroup j of a chunk's launch draws env
     // render_order[env_base + j], a permutation of that chunk's env range sorted by background image
     const int *render_order;  // [num_envs]

@@ -28,6 +28,26 @@ constexpr float RENDER_EPS = 0.02f;                              // BAG:14
 
 // error codes stored in EnvHdr::error (host turns them into the reference's fatal()/fassert exit)
 enum PgError : int { PGE_NONE = 0, PGE_ENT_OVERFLOW = 1, PGE_GRID_OOB = 2, PGE_ASSERT = 3, PGE_THEME = 4, PGE_UNSUPPORTED_DRAW = 5 };
+// EnvHdr::error = code | source line of the fail() that raised it << 8 (the line is what a post-mortem needs: "code 3" alone names six
+// call sites of the step kernels and a dozen in the game policies).  The handle-wide word DevCtx::error is the OR of the codes alone.
+PG_DEV int pg_error_word(int code, int line) { return code | (line << 8); }
+// called by lane 0 of an env's wave when the env carries an error: OR the code into the handle's sticky word and, for the first
+// reporter, leave who and where (the record behind the word, pg_defs.h ERROR_INFO_OFFSET; the emulation's error word stands alone)
+PG_DEV void pg_report_error(const DevCtx &d, int env, int error_word, int kind, int n_ents, int agent) {
+#if defined(PGAMD_WAVE_EMU)
+    (void)env; (void)kind; (void)n_ents; (void)agent;
+    if (d.error) *d.error |= (error_word & 0xff);
+#else
+    atomicOr(d.error, error_word & 0xff);
+    int *w = d.error + ERROR_INFO_OFFSET;
+    if (atomicCAS(w, 0, env + 1) == 0) {
+        w[1] = error_word;
+        w[2] = kind;
+        w[3] = n_ents;
+        w[4] = agent;
+    }
+#endif
+}
 
 // ---- EF_META packing -------------------------------------------------------------------------------------
 constexpr uint32_t M_TYPE_MASK = 0x3ffu;
@@ -288,8 +308,8 @@ struct Env {
     PG_DEV void set_image_theme(int i, int t) { meta(i) = (meta(i) & ~(0xfu << M_THEME_SHIFT)) | (((uint32_t)t & 0xfu) << M_THEME_SHIFT); }
     PG_DEV void set_render_z(int i, int z) { meta(i) = (meta(i) & ~(3u << M_Z_SHIFT)) | (((uint32_t)(z + 1) & 3u) << M_Z_SHIFT); }
 
-    PG_DEV void fail(int code) {
-        if (G.error == 0) G.error = code;
+    PG_DEV void fail(int code, int line = __builtin_LINE()) {
+        if (G.error == 0) G.error = pg_error_word(code, line);
     }
     // the game's aux words of this env in HBM (see GameAux)
     PG_DEV uint32_t *aux() { return reinterpret_cast<uint32_t *>(d.grid + (size_t)env * d.grid_bytes + game_cell_bytes<Game>()); }
@@ -1836,7 +1856,9 @@ struct Env {
             } else {
                 const uint32_t x = level_seed_u32();
                 const uint32_t range = (uint32_t)(G.level_seed_high - G.level_seed_low);
-                G.current_level_seed = (int)((uint32_t)G.level_seed_low + (x % range));
+                // range 0 (only a restored state can carry it, reference src/game.cpp:247-248): the reference's `x % range` ends the process
+                if (range == 0) fail(PGE_ASSERT);
+                G.current_level_seed = (int)((uint32_t)G.level_seed_low + (range ? x % range : 0u));
             }
             G.episodes_remaining = 1;
         } else {
@@ -2045,7 +2067,7 @@ struct Env {
     PG_DEV void queue_reset() {
 #if !defined(PGAMD_WAVE_EMU)
         if (PG_LANE_ID() == 0) {
-            if (G.error) atomicOr(d.error, G.error);
+            if (G.error) pg_report_error(d, env, G.error, CAP, G.n_ents, G.agent);
             const int c = d.reset_first > 0 ? (env >= d.reset_first ? 1 : 0) : env / d.reset_chunk_envs;
             const size_t base = d.reset_first > 0 ? (c ? (size_t)d.reset_first : 0) : (size_t)c * d.reset_chunk_envs;
             d.reset_list[base + atomicAdd(d.reset_count + c, 1)] = env;
@@ -2056,7 +2078,7 @@ struct Env {
     // tell the next step which kernel owns this env, and surface error codes to the host
     PG_DEV void publish_routing() {
 #if defined(PGAMD_WAVE_EMU)
-        if (G.error && d.error) *d.error |= G.error;
+        if (G.error) pg_report_error(d, env, G.error, CAP, G.n_ents, G.agent);
 #else
         if (PG_LANE_ID() == 0) {
             if (d.next_route) d.next_route[env] = (uint8_t)G.big;
@@ -2065,7 +2087,7 @@ struct Env {
                 const int slot = atomicAdd(d.next_big_count + c * NUM_TIERS + t, 1);
                 d.next_big_list[(size_t)t * d.num_envs + (size_t)c * d.chunk_envs + slot] = env;
             }
-            if (G.error) atomicOr(d.error, G.error);
+            if (G.error) pg_report_error(d, env, G.error, CAP, G.n_ents, G.agent);
         }
 #endif
     }

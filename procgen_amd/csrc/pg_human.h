@@ -130,8 +130,8 @@ struct HumanRenderer {
     PG_DEV float erx(int i) const { return ef(EF_RX, i); }
     PG_DEV float ery(int i) const { return ef(EF_RY, i); }
     PG_DEV int etype(int i) const { return meta_type(meta(i)); }
-    PG_DEV void fail(int code) {
-        if (G.error == 0) G.error = code;
+    PG_DEV void fail(int code, int line = __builtin_LINE()) {
+        if (G.error == 0) G.error = pg_error_word(code, line);
     }
     PG_DEV int get_obj(int x, int y) const {  // BAG:180-185
         if (!(0 <= y && y < G.main_height && 0 <= x && x < G.main_width)) return G.out_of_bounds_object;
@@ -1095,9 +1095,9 @@ struct HumanRenderer {
         store_band();
         if (G.error) {
 #if defined(PGAMD_WAVE_EMU)
-            if (d.error) *d.error |= G.error;
+            pg_report_error(d, env, G.error, ERR_KIND_HUMAN, 0, 0);
 #else
-            if (PG_LANE_ID() == 0) atomicOr(d.error, G.error);
+            if (PG_LANE_ID() == 0) pg_report_error(d, env, G.error, ERR_KIND_HUMAN, 0, 0);
 #endif
         }
         // get_state serializes the camera scalars of the LAST frame drawn, which is this one (reference src/vecgame.cpp:363-376)

@@ -252,7 +252,7 @@ struct Renderer {
     PG_DEV float erx(int i) const { return ef(EF_RX, i); }
     PG_DEV float ery(int i) const { return ef(EF_RY, i); }
     PG_DEV int etype(int i) const { return meta_type(meta(i)); }
-    PG_DEV void fail(int code) {
+    PG_DEV void fail(int code) {  // (the code alone: a line number per call site, as the step kernels record, costs this kernel the registers it does not have)
         if (G.error == 0) G.error = code;
     }
     PG_DEV int get_obj(int x, int y) const {  // BAG:180-185
@@ -2530,12 +2530,17 @@ struct Renderer {
         }
 #if !defined(PGAMD_WAVE_EMU)
         if (PG_PHASE_PROFILE && d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + 15, 1ull);
+#else
+        if (pg_emu_dma_outstanding() != 0) {  // (a band whose background copies nobody joined: store_band always does)
+            fprintf(stderr, "render_env: %d LDS-DMA words still in flight at the end of the frame\n", pg_emu_dma_outstanding());
+            abort();
+        }
 #endif
         if (G.error) {
 #if defined(PGAMD_WAVE_EMU)
-            if (d.error) *d.error |= G.error;
+            pg_report_error(d, env, G.error, ERR_KIND_RENDER, 0, 0);
 #else
-            if (PG_LANE_ID() == 0) atomicOr(d.error, G.error);
+            if (PG_LANE_ID() == 0) pg_report_error(d, env, G.error, ERR_KIND_RENDER, 0, 0);
 #endif
         }
     }

@@ -420,7 +420,9 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
     h.grid_step = r.i();
     h.level_seed_low = r.i();  // adopted per env, as the reference does (src/game.cpp:247-248): the env goes on drawing its levels from the range the state was saved under
     h.level_seed_high = r.i();
-    if (!(h.level_seed_high > h.level_seed_low)) return bad("set_state: empty level seed range");
+    // (an empty range is adopted like any other, as the reference does: its next reset that draws a level seed divides by the range,
+    // RandGen::randint src/randgen.cpp:6-11 called from src/game.cpp:101 -- a zero range ends the process there (SIGFPE; here the device-side
+    // check of game_reset_full), a negative one wraps in unsigned arithmetic, which the kernels' draw restates)
     r.i();  // game_type
     r.i();  // game_n
     int seeded;

@@ -52,8 +52,44 @@ struct PgEmuLaneScope {
 #define PG_FOR_LANES_NOHOIST(l) PG_FOR_LANES(l)
 // global -> LDS copy of one dword per lane without a register in between (global_load_lds_dword on the GPU): lane l's word lands at
 // lds_base[l].  The copy is asynchronous there: pg_dma_join() before the LDS words are read or overwritten.
-#define PG_DMA_DWORD(gptr, lds_base, l) ((lds_base)[l] = *(gptr))
-#define PG_DMA_JOIN() ((void)0)
+// The emulation models the asynchrony at its worst: the words are read at once but LAND at the join, in issue order.  A reader of the
+// LDS words that forgot the join sees the old contents, a writer that forgot it is overwritten by the late copy -- either way the CPU
+// goldens differ, instead of only a GPU run being able to tell (round-4 advisor finding).  pg_emu_dma_outstanding() lets a kernel's
+// end assert that nothing is left in flight.
+struct PgEmuDmaWord {
+    uint32_t *dst;
+    uint32_t val;
+};
+inline PgEmuDmaWord *pg_emu_dma_queue(int **count) {
+    static thread_local PgEmuDmaWord q[64 * 64];
+    static thread_local int n = 0;
+    *count = &n;
+    return q;
+}
+inline void pg_emu_dma_push(uint32_t *dst, uint32_t val) {
+    int *n;
+    PgEmuDmaWord *q = pg_emu_dma_queue(&n);
+    if (*n >= 64 * 64) {
+        fprintf(stderr, "wave emulation: more than 4096 LDS-DMA words in flight\n");
+        abort();
+    }
+    q[*n].dst = dst;
+    q[*n].val = val;
+    ++*n;
+}
+inline void pg_emu_dma_flush() {
+    int *n;
+    PgEmuDmaWord *q = pg_emu_dma_queue(&n);
+    for (int i = 0; i < *n; i++) *q[i].dst = q[i].val;
+    *n = 0;
+}
+inline int pg_emu_dma_outstanding() {
+    int *n;
+    (void)pg_emu_dma_queue(&n);
+    return *n;
+}
+#define PG_DMA_DWORD(gptr, lds_base, l) pg_emu_dma_push(&(lds_base)[l], *(gptr))
+#define PG_DMA_JOIN() pg_emu_dma_flush()
 #define PG_BALLOT(l, pred)                              \
     ({                                                  \
         uint64_t m_ = 0;                                \

@@ -95,13 +95,33 @@ class BaseProcgenEnv(CEnv):
         super().__init__(lib_dir=lib_dir, num=num, options=options, buffer_padding=buffer_padding)
 
     def get_state(self):
+        """reference procgen/env.py:138-146, one entry per env.  Libraries with the batched hook (procgen_amd_get_states,
+        include/procgen_amd.h) are asked for 256 envs at a time; any other libenv.so (the compiled reference) per env."""
         import ctypes as C
 
-        buf = C.create_string_buffer(MAX_STATE_SIZE)
+        if not hasattr(self._lib, "procgen_amd_get_states"):
+            buf = C.create_string_buffer(MAX_STATE_SIZE)
+            result = []
+            for env_idx in range(self.num):
+                n = self.call_c_func("get_state", env_idx, buf, MAX_STATE_SIZE)
+                result.append(C.string_at(buf, n))
+            return result
+        fn = self._lib.procgen_amd_get_states
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
+        block = 256
+        cap = 32 * MAX_STATE_SIZE
+        buf = np.empty(cap, dtype=np.uint8)
+        offs = np.zeros(block + 1, dtype=np.int64)
         result = []
-        for env_idx in range(self.num):
-            n = self.call_c_func("get_state", env_idx, buf, MAX_STATE_SIZE)
-            result.append(bytes(buf.raw[:n]))
+        first = 0
+        while first < self.num:
+            want = min(block, self.num - first)
+            got = fn(self._handle, first, want, buf.ctypes.data, cap, offs.ctypes.data)
+            assert got >= 1
+            raw = buf[: offs[got]].tobytes()
+            result.extend(raw[offs[k]:offs[k + 1]] for k in range(got))
+            first += got
         return result
 
     def set_state(self, states):

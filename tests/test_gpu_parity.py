@@ -339,3 +339,18 @@ def test_generated_assets_refuse_state_io():
     import subprocess, sys
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "use_generated_assets" in (r.stdout + r.stderr)
+
+
+def test_lds_dma_background_equals_the_register_path(monkeypatch):
+    """The band's background rows travel global memory -> LDS asynchronously (pg_render.h exec_bg_dma, global_load_lds_dword); every later
+    reader or writer of the band buffer must join them first.  PROCGEN_AMD_DEBUG=131072 switches the DMA off (the same rows through
+    registers, exec_large): the frames of all 16 games must not change -- a missing join on some path would show as stale or overwritten
+    pixels only on the device (the emulation lands the words at the join, tests/emu; this is the hardware's own ordering)."""
+    n, steps = 64, 60
+    for game in GAMES:
+        acts = action_stream(n, steps, seed=9)
+        want = rollout(make_env(n, game), acts)
+        monkeypatch.setenv("PROCGEN_AMD_DEBUG", "131072")
+        got = rollout(make_env(n, game), acts)
+        monkeypatch.delenv("PROCGEN_AMD_DEBUG")
+        assert_rollouts_equal(want, got, f"{game}: LDS-DMA background vs the register path")

@@ -88,6 +88,29 @@ def test_sixteen_game_joint_handle_at_its_one_gpu_share():
         assert_rollouts_equal(ref, got, f"joint handle, {game}")
 
 
+def test_sixteen_games_over_eight_device_shards(monkeypatch):
+    """BASELINE configs[4] in its whole shape on the one GPU there is: ONE handle, num_devices = 8 x 16 games = 128 parts (each a
+    VecGame with its own stream and 128 envs), PROCGEN_AMD_FAKE_DEVICES mapping the eight shards onto the visible device(s).  Device g
+    owns the global indices [2048 g, 2048 (g + 1)), env n plays names[n % 16] whatever the sharding (reference src/vecgame.cpp:295-314);
+    a strided sample of 32 envs per game -- four in every shard -- x 120 steps equals per-game oracle runs of exactly those envs."""
+    monkeypatch.setenv("PROCGEN_AMD_FAKE_DEVICES", "1")
+    K, G, n, per_game, steps = len(GAMES), 8, 16384, 32, 120
+    rng = np.random.RandomState(43)
+    acts = [rng.randint(0, 15, size=(n,), dtype=np.int32) for _ in range(steps)]
+    env = make_env(n, ",".join(GAMES), extra_options={"num_devices": G})
+    env._lib.procgen_amd_part_buffers.restype = C.c_int
+    env._lib.procgen_amd_part_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    assert env._lib.procgen_amd_part_buffers(env._handle, None, 0) == G * K
+    joint = rollout(env, acts)
+    for k, game in enumerate(GAMES):
+        stride = K * (n // K // per_game)  # 32 envs of this game, spread over the whole vector: n // G // stride = 4 per shard
+        idx = np.arange(per_game) * stride + k
+        assert len(set(idx // (n // G))) == G
+        ref = rollout(oracle_env.OracleEnv(per_game, game, rand_seed=23, env_offset=k, env_stride=stride), [a[idx] for a in acts])
+        got = {key: joint[key][:, idx] for key in ref}
+        assert_rollouts_equal(ref, got, f"16 games x 8 shards, {game}")
+
+
 def test_full_size_long_horizon_against_a_strided_oracle_sample():
     """BASELINE configs[1] at its full size over a long horizon: coinrun, 65536 envs, 1200 steps -- past the 1000-step timeout, so every
     episode has ended at least once, the envs are desynchronised, trail-heavy envs sit in the tier-1 / tier-2 arenas and the reset rate is

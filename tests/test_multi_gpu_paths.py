@@ -75,3 +75,18 @@ def test_one_handle_over_devices_path_runs_on_fake_devices():
     assert line["config"]["sharding"] == "one handle, num_devices=2 contiguous index ranges, no collective"
     acts = np.random.RandomState(0).randint(0, 15, size=(WARM + STEPS, 2 * N), dtype=np.int32)
     assert line["shard_crc"] == _single_handle_crcs(acts, [slice(0, N), slice(N, 2 * N)])
+
+
+@pytest.mark.gpu
+def test_one_process_per_gpu_path_with_eight_ranks():
+    """The driver's N = 8 launch (python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8), every rank on device 0: eight
+    env_offset shards of one logical vector, barrier and MAX reduction over eight ranks, one JSON line from rank 0.  Shard r's
+    observation CRC is that of envs [r n, (r + 1) n) of one single-device handle stepped with the same actions."""
+    n, ranks = 512, 8
+    line = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                  "bench.py", "--gpus", str(ranks), "--dry-multi", "--shard-crc", "--num-envs", str(n), "--steps", str(STEPS), "--warmup", str(WARM),
+                  "--no-cpu-baseline", "--steady-warmup", "0"])
+    assert line["n_gpus"] == ranks and line["config"]["sharding"] == f"env_offset shards x{ranks}, no collective" and line["config"]["num_envs_per_gpu"] == n
+    assert abs(line["value"] - ranks * n * STEPS / (line["ms_per_step"] * 1e-3 * STEPS)) / line["value"] < 1e-3
+    acts = np.concatenate([np.random.RandomState(r).randint(0, 15, size=(WARM + STEPS, n), dtype=np.int32) for r in range(ranks)], axis=1)
+    assert line["shard_crc"] == _single_handle_crcs(acts, [slice(r * n, (r + 1) * n) for r in range(ranks)])

@@ -134,6 +134,47 @@ def test_gpu_frames_and_state_equal_the_compiled_reference(golden_dir, key):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("game", ["coinrun", "jumper", "bigfish", "maze"])
+def test_gpu_state_between_act_and_observe_carries_the_observation_frames_camera(golden_dir, game):
+    """reference src/vecgame.cpp:363-376,437-445: get_state between libenv_act and libenv_observe waits for the stepping threads only --
+    the 512-pixel frames are drawn by VecGame::observe -- so its camera scalars are the 64-pixel frame's; after the observe they are
+    the 512-pixel frame's (tests/golden/human_midstate.npz, make_human_midstate_golden.py, compiled reference)."""
+    gold = np.load(os.path.join(golden_dir, "human_midstate.npz"))
+    acts = gold[f"{game}/actions"]
+    env = _make(2, game, rand_seed=7)
+    env.observe()
+    for t in range(10):
+        env.act(acts[t])
+        env.observe()
+    env.act(acts[10])
+    mid = env.call_c_func("get_state", 0, (buf := __import__("ctypes").create_string_buffer(1 << 20)), 1 << 20)
+    assert buf.raw[:mid] == gold[f"{game}/mid_state"].tobytes(), "state between act and observe"
+    env.observe()
+    assert env.get_state()[0] == gold[f"{game}/after_state"].tobytes(), "state after the observe"
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5])
+def test_gpu_info_frames_land_in_padded_caller_buffers(n):
+    """libenv only promises per-env pointers (libenv_buffers): info "rgb" buffers at a uniform distance larger than a frame (padded
+    arrays) are filled by ONE strided copy (hipMemcpy2DAsync, width 786432 B), separately placed ones frame by frame; either way the
+    frames are those a handle with one dense array gets."""
+    acts = np.random.RandomState(3).randint(0, 15, size=(6, n), dtype=np.int32)
+    frames = []
+    for pad in (0, 192):
+        env = _make(n, "starpilot", rand_seed=11, buffer_padding=pad)
+        out = []
+        for a in acts:
+            env.act(a)
+            env.observe()
+            out.append(np.array(env.info_arrays()["rgb"], copy=True))
+        env.close()
+        frames.append(np.array(out))
+    assert frames[0].shape == (6, n, 512, 512, 3) and np.array_equal(frames[0], frames[1])
+
+
+@pytest.mark.gpu
 def test_gpu_restored_states_are_redrawn_by_the_next_observe(golden_dir):
     """reference src/vecgame.cpp:447-456 + 363-376: set_state refreshes the 64-pixel frame; every observe redraws the 512 frames."""
     gold = _gold(golden_dir)
