@@ -143,7 +143,17 @@ struct Chaser : BagDefaults<Chaser> {
         e.ery(ag) = (float).5;
         CH_EAT_TIME(G) = -1 * EAT_TIMEOUT;
         PG_SYNC();
-        MazeGenDev<E> mg(e, e.s->scratch, md);
+        // chaser.cpp:159-162: the generator is made ONCE per Game, at its first reset, with that reset's maze_dim -- the dimension of the
+        // mode the handle was made with -- and kept.  An env restored from a state of another mode (round 5: the mode is adopted per env)
+        // therefore generates mazes of the handle's dimension and copies the corner its own world shows; a smaller generator than the
+        // world is the reference's `fassert(contains(x, y))` (grid.h:41).
+        const int hm = e.d.opt.distribution_mode;
+        const int md_gen = hm == EasyMode ? 11 : (hm == HardMode ? 13 : 19);
+        if (md_gen < md) {
+            e.fail(PGE_ASSERT);
+            return;
+        }
+        MazeGenDev<E> mg(e, e.s->scratch, md_gen);
         mg.generate_maze_no_dead_ends();
         const int extra_quad = e.randn(4);
         // grid <- maze (walls become MAZE_WALL); maze cell (i, j) is grid index j * md + i

@@ -79,7 +79,7 @@ struct Jumper : BagDefaults<Jumper> {
     }
     // game tables: [0..7] the compass rect (4 doubles) the masks were made for, then per frame row the brush mask and the
     // pen mask (bit x = column x), 64 x 2 x 64 bits.  Empty when the rect is integer aligned (midpoint route) or in memory mode.
-    static constexpr int TABLE_WORDS = 8 + RES_H * 4, HOST_TABLE_WORDS = 2 * TABLE_WORDS;  // one table per center_agent setting (a per-env option)
+    static constexpr int TABLE_WORDS = 8 + RES_H * 4, NUM_TABLES = 4, HOST_TABLE_WORDS = NUM_TABLES * TABLE_WORDS;  // one table per (easy / hard mode, center_agent setting): per-env options
     struct MaskSink {
         uint64_t brush[RES_H], pen[RES_H];
         int cnt[RES_H], xa[RES_H];
@@ -96,12 +96,18 @@ struct Jumper : BagDefaults<Jumper> {
         void pixel(int x, int y) { pen[y] |= 1ull << x; }
     };
     static int host_tables(const GameOptions &o, uint32_t *out, int max_words) {
-        if (max_words < 2 * TABLE_WORDS) return 0;
-        memset(out, 0, 2 * TABLE_WORDS * sizeof(uint32_t));
-        GameOptions a = o, b = o;
-        b.center_agent = !o.center_agent;  // envs restored from a state saved under the other setting (set_state adopts it per env)
-        const int na = host_table_one(a, out, TABLE_WORDS), nb = host_table_one(b, out + TABLE_WORDS, TABLE_WORDS);
-        return (na || nb) ? 2 * TABLE_WORDS : 0;
+        if (max_words < HOST_TABLE_WORDS) return 0;
+        memset(out, 0, HOST_TABLE_WORDS * sizeof(uint32_t));
+        // both center_agent settings x the two modes that may draw the compass on a fractional rect (memory mode draws none): the handle's
+        // own options and those of envs restored from states saved under the others (set_state adopts a state's options per env)
+        int any = 0;
+        for (int k = 0; k < NUM_TABLES; k++) {
+            GameOptions v = o;
+            v.center_agent = (k & 1) != 0;
+            v.distribution_mode = (k & 2) ? HardMode : EasyMode;
+            any |= host_table_one(v, out + k * TABLE_WORDS, TABLE_WORDS);
+        }
+        return any ? HOST_TABLE_WORDS : 0;
     }
     static int host_table_one(const GameOptions &o, uint32_t *out, int max_words) {
         if (o.distribution_mode == MemoryMode || max_words < TABLE_WORDS) return 0;
@@ -481,7 +487,7 @@ struct Jumper : BagDefaults<Jumper> {
             // Qt's path route: the handle's precomputed row masks -- valid for exactly this rect
             const uint32_t *t = r.d.game_tables;
             bool same = false;
-            for (int k = 0; k < 2 && t != nullptr && !same; k++) {  // the handle's two tables (host_tables)
+            for (int k = 0; k < NUM_TABLES && t != nullptr && !same; k++) {  // the handle's tables (host_tables)
                 const double *tr = (const double *)(r.d.game_tables + k * TABLE_WORDS);
                 same = tr[0] == cr_.x && tr[1] == cr_.y && tr[2] == cr_.w && tr[3] == cr_.h && tr[2] != 0;
                 if (same) t = r.d.game_tables + k * TABLE_WORDS;

@@ -15,6 +15,7 @@ struct LaunchStreams {
     hipEvent_t side_done[3];
     hipEvent_t step_done[MAX_CHUNKS];
     hipEvent_t outputs_done[MAX_CHUNKS];  // recorded on a chunk's stream when its envs' small outputs are final (null: not wanted)
+    hipEvent_t frames_done[MAX_CHUNKS];   // null: not wanted.  Recorded on chunk c's stream behind its render kernel: the chunk's observations are final (their D2H landing may start)
     hipEvent_t render_t0[MAX_CHUNKS], render_t1[MAX_CHUNKS];  // null: off.  Recorded around chunk c's render launch on its stream (procgen_amd_kernel_timing: the dominant kernel's own duration)
     int first_pct;            // experiment: share of the first of two chunks in percent (0 = even)
     int order;                // launch-order variant (PROCGEN_AMD_ORDER, see launch_game)
@@ -36,7 +37,7 @@ struct GameEntry {
     hipError_t (*render_human)(const DevCtx &, int env_base, int count, hipStream_t);  // the 512 x 512 info frames of envs [env_base, env_base + count) (pg_human.h)
     bool split_reset;  // GameSplit<Game>::value: ended episodes are finished by reset_list kernels behind the step kernels
 };
-constexpr int MAX_GAME_TABLE_WORDS = 1024;
+constexpr int MAX_GAME_TABLE_WORDS = 2048;
 // mode 0: initial reset + first observation of every env; mode 1: one step
 hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStreams &ls);
 hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream);

@@ -225,6 +225,7 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         if (ls.render_t0[c]) PG_TRY(hipEventRecord(ls.render_t0[c], st));
         if (!(d.debug_flags & 16)) launch_render<Game>(d, base, count, st, c == 0);
         if (ls.render_t1[c]) PG_TRY(hipEventRecord(ls.render_t1[c], st));
+        if (ls.frames_done[c]) PG_TRY(hipEventRecord(ls.frames_done[c], st));
     }
     for (int k = 0; k < 2; k++) {
         PG_TRY(hipEventRecord(ls.lane_done[k], ls.lane[k]));

@@ -199,6 +199,13 @@ struct VecGame {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_small = nullptr, ev_out[MAX_CHUNKS] = {};
     bool early_small = false, small_in_flight = false;
+    // Host-landed observations (the unmodified gym3 ABI), large handles: chunk c's slice of the caller's array is copied as soon as chunk
+    // c's render kernel is done, on a stream of its own, while the other chunks still step and draw -- the 805 MB landing of a 65536-env
+    // step takes ten times longer than its kernels, so everything but the first chunk's kernels hides under it (PROCGEN_AMD_OBS_CHUNK_COPY=0: one
+    // copy behind the whole step, as before round 5)
+    hipStream_t obs_stream = nullptr;
+    hipEvent_t ev_frames[MAX_CHUNKS] = {}, ev_obs = nullptr;
+    bool obs_chunk_copy = false;
     int order = 0;  // PROCGEN_AMD_ORDER
     int first_pct = 75;  // PROCGEN_AMD_FIRST_PCT: share of the first of two chunks
     int chunks = 2;  // PROCGEN_AMD_CHUNKS: env range cut in 2 so one chunk's step kernel overlaps the other's render kernel (+6 % measured)
@@ -217,6 +224,7 @@ struct VecGame {
         for (int c = 0; c < MAX_CHUNKS; c++) ls.step_done[c] = ev_step[c];
         for (int c = 0; c < MAX_CHUNKS; c++) ls.outputs_done[c] = early_small ? ev_out[c] : nullptr;
         for (int c = 0; c < MAX_CHUNKS; c++) {
+            ls.frames_done[c] = (obs_chunk_copy && host_observations) ? ev_frames[c] : nullptr;
             ls.render_t0[c] = time_kernels ? tk_r0[c] : nullptr;
             ls.render_t1[c] = time_kernels ? tk_r1[c] : nullptr;
         }
@@ -365,9 +373,9 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     o.distribution_mode = dist_mode;
     if (dist_mode == EasyMode || dist_mode == HardMode) {
     } else if (dist_mode == ExtremeMode) {
-        if (!(env_name == "chaser" || env_name == "dodgeball" || env_name == "leaper" || env_name == "starpilot")) fatal("fassert failed: extreme mode unsupported for %s\n", env_name.c_str());
+        if (!game_has_extreme_mode(game_id)) fatal("fassert failed: extreme mode unsupported for %s\n", env_name.c_str());
     } else if (dist_mode == MemoryMode) {
-        if (!(env_name == "caveflyer" || env_name == "dodgeball" || env_name == "heist" || env_name == "jumper" || env_name == "maze" || env_name == "miner")) fatal("fassert failed: memory mode unsupported for %s\n", env_name.c_str());
+        if (!game_has_memory_mode(game_id)) fatal("fassert failed: memory mode unsupported for %s\n", env_name.c_str());
     } else {
         fatal("invalid distribution_mode %d\n", dist_mode);
     }
@@ -475,6 +483,15 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
             early_small = true;
             HIP_CHECK(hipHostMalloc((void **)&h_late_error, (1 + ERROR_INFO_WORDS) * sizeof(int), hipHostMallocDefault));
             memset(h_late_error, 0, (1 + ERROR_INFO_WORDS) * sizeof(int));
+        }
+    }
+    if (num_envs >= 4096) {
+        const char *oc = getenv("PROCGEN_AMD_OBS_CHUNK_COPY");
+        if (!(oc && atoi(oc) == 0) && !getenv("PROCGEN_AMD_DEBUG")) {
+            HIP_CHECK(hipStreamCreateWithFlags(&obs_stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&ev_obs, hipEventDisableTiming));
+            for (int c = 0; c < MAX_CHUNKS; c++) HIP_CHECK(hipEventCreateWithFlags(&ev_frames[c], hipEventDisableTiming));
+            obs_chunk_copy = true;
         }
     }
     if (const char *c = getenv("PROCGEN_AMD_CHUNKS")) chunks = atoi(c) > 0 ? (atoi(c) < MAX_CHUNKS ? atoi(c) : MAX_CHUNKS) : 1;
@@ -659,6 +676,10 @@ VecGame::~VecGame() {
         if (ev_side[k]) (void)hipEventDestroy(ev_side[k]);
         if (side_stream[k]) (void)hipStreamDestroy(side_stream[k]);
     }
+    if (ev_obs) (void)hipEventDestroy(ev_obs);
+    for (int c = 0; c < MAX_CHUNKS; c++)
+        if (ev_frames[c]) (void)hipEventDestroy(ev_frames[c]);
+    if (obs_stream) (void)hipStreamDestroy(obs_stream);
     if (ev_small) (void)hipEventDestroy(ev_small);
     for (int c = 0; c < MAX_CHUNKS; c++)
         if (ev_out[c]) (void)hipEventDestroy(ev_out[c]);
@@ -873,9 +894,24 @@ void VecGame::launch(int mode) {
     } else {
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
     }
-    if (host_observations) {  // one copy behind the whole step (a copy per chunk behind its render kernel measured 4 % slower: 17.6 vs 16.9 ms)
-        void *dst = ob_contig ? ob_ptr[0] : (void *)h_obs_stage;
-        HIP_CHECK(hipMemcpyAsync(dst, d.obs, (size_t)num_envs * OBS_BYTES, hipMemcpyDeviceToHost, stream));
+    if (host_observations) {
+        uint8_t *dst = ob_contig ? (uint8_t *)ob_ptr[0] : h_obs_stage;
+        if (obs_chunk_copy) {  // chunk by chunk on the copy's own stream, each slice behind its chunk's render kernel (the ranges of launch_game)
+            const int nchunk = chunks > 1 ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1;
+            const int per = chunk_envs_for(num_envs, nchunk);
+            const int first = (nchunk == 2 && first_pct > 0) ? first_chunk_envs(num_envs, first_pct) : 0;
+            for (int c = 0; c < nchunk; c++) {
+                const int base = first > 0 ? (c == 0 ? 0 : first) : c * per;
+                const int count = first > 0 ? (c == 0 ? first : num_envs - first) : ((num_envs - base) < per ? (num_envs - base) : per);
+                if (count <= 0) break;
+                HIP_CHECK(hipStreamWaitEvent(obs_stream, ev_frames[c], 0));
+                HIP_CHECK(hipMemcpyAsync(dst + (size_t)base * OBS_BYTES, d.obs + (size_t)base * OBS_BYTES, (size_t)count * OBS_BYTES, hipMemcpyDeviceToHost, obs_stream));
+            }
+            HIP_CHECK(hipEventRecord(ev_obs, obs_stream));
+            HIP_CHECK(hipStreamWaitEvent(stream, ev_obs, 0));  // (libenv_observe joins `stream`)
+        } else {  // one copy behind the whole step
+            HIP_CHECK(hipMemcpyAsync(dst, d.obs, (size_t)num_envs * OBS_BYTES, hipMemcpyDeviceToHost, stream));
+        }
     }
     if (render_human) launch_human(0, num_envs);
     pending = true;

@@ -41,6 +41,12 @@ constexpr int KERNEL_CAVEFLYER_MEMORY = NUM_GAMES;
 inline int kernel_id_for(int game_id, int distribution_mode) { return (game_id == GAME_CAVEFLYER && distribution_mode == 10) ? KERNEL_CAVEFLYER_MEMORY : game_id; }
 
 enum DistributionMode : int { EasyMode = 0, HardMode = 1, ExtremeMode = 2, MemoryMode = 10 };
+// which games accept the two optional modes (the fasserts of the reference's game constructors / game_reset: chaser.cpp, dodgeball.cpp,
+// leaper.cpp, starpilot.cpp for extreme; caveflyer, dodgeball, heist, jumper, maze, miner for memory)
+inline bool game_has_extreme_mode(int game_id) { return game_id == GAME_CHASER || game_id == GAME_DODGEBALL || game_id == GAME_LEAPER || game_id == GAME_STARPILOT; }
+inline bool game_has_memory_mode(int game_id) {
+    return game_id == GAME_CAVEFLYER || game_id == GAME_DODGEBALL || game_id == GAME_HEIST || game_id == GAME_JUMPER || game_id == GAME_MAZE || game_id == GAME_MINER;
+}
 
 #if defined(__HIPCC__)
 #define PG_HOSTDEV_EARLY __host__ __device__
@@ -54,13 +60,17 @@ struct GameOptions {
     int level_seed_low, level_seed_high;
 };
 
-// Options a state carries and the reference adopts per env on deserialize (reference src/game.cpp:233-246).  Those that choose
-// no kernel instantiation live in every env's header (EnvHdr::opt_bits / opt_debug_mode) and override the handle's GameOptions
-// when a kernel binds an env; distribution_mode and use_generated_assets stay per handle (they select kernels, LDS arenas, assets).
+// Options a state carries and the reference adopts per env on deserialize (reference src/game.cpp:233-246).  They live in every env's
+// header (EnvHdr::opt_bits / opt_debug_mode) and override the handle's GameOptions when a kernel binds an env.  Round 5: the
+// distribution_mode too (bits 8..15 hold mode + 1; 0 = the handle's): every mode a kernel instantiation serves is a run-time value to it,
+// so a state saved under another mode of the same instantiation is adopted like the other options.  Only what selects the instantiation
+// itself stays per handle: use_generated_assets, and caveflyer's memory mode (its own kernels and arenas, kernel_id_for).
 enum EnvOptBit : int { EOB_PAINT_VEL_INFO = 1, EOB_MONOCHROME = 2, EOB_RESTRICT_THEMES = 4, EOB_BACKGROUNDS = 8, EOB_CENTER_AGENT = 16, EOB_SEQUENTIAL = 32 };
+constexpr int EOB_MODE_SHIFT = 8;
 PG_HOSTDEV_EARLY inline int env_option_bits(const GameOptions &o) {
     return (o.paint_vel_info ? EOB_PAINT_VEL_INFO : 0) | (o.use_monochrome_assets ? EOB_MONOCHROME : 0) | (o.restrict_themes ? EOB_RESTRICT_THEMES : 0) |
-           (o.use_backgrounds ? EOB_BACKGROUNDS : 0) | (o.center_agent ? EOB_CENTER_AGENT : 0) | (o.use_sequential_levels ? EOB_SEQUENTIAL : 0);
+           (o.use_backgrounds ? EOB_BACKGROUNDS : 0) | (o.center_agent ? EOB_CENTER_AGENT : 0) | (o.use_sequential_levels ? EOB_SEQUENTIAL : 0) |
+           (((o.distribution_mode + 1) & 0xff) << EOB_MODE_SHIFT);
 }
 PG_HOSTDEV_EARLY inline GameOptions env_options(const GameOptions &handle, int bits, int debug_mode) {
     GameOptions o = handle;
@@ -71,6 +81,8 @@ PG_HOSTDEV_EARLY inline GameOptions env_options(const GameOptions &handle, int b
     o.center_agent = (bits & EOB_CENTER_AGENT) != 0;
     o.use_sequential_levels = (bits & EOB_SEQUENTIAL) != 0;
     o.debug_mode = debug_mode;
+    const int m = (bits >> EOB_MODE_SHIFT) & 0xff;
+    if (m) o.distribution_mode = m - 1;
     return o;
 }
 

@@ -396,12 +396,18 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
     };
     if (r.i() != 0) return bad("fassert failed 'SERIALIZE_VERSION == b->read_int()'");
     if (r.s() != game_name_from_id(game_id)) return bad("fassert failed 'game_name == b->read_string()'");
-    // reference src/game.cpp:233-246: the env adopts the options the state was saved under.  Those that select no kernel are per env here
-    // (EnvHdr::opt_bits / opt_debug_mode); distribution_mode and use_generated_assets choose the kernel instantiation, its LDS arenas and
-    // the assets of the whole handle, so a state that differs in them is refused, with the reason
+    // reference src/game.cpp:233-246: the env adopts the options the state was saved under -- per env here (EnvHdr::opt_bits /
+    // opt_debug_mode), the distribution_mode included when the handle's kernel instantiation serves it (every mode of a game but
+    // caveflyer's memory mode, pg_defs.h kernel_id_for).  use_generated_assets selects the assets and the renderer of the whole handle: a
+    // state that differs in it is refused, with the reason.
     int o[9];
     for (int k = 0; k < 9; k++) o[k] = r.i();
-    if (o[7] != opt.distribution_mode) return bad("set_state: the state was saved under another distribution_mode than this handle's (the mode selects the kernels of the handle; make a handle with that mode)");
+    if (o[7] != opt.distribution_mode) {
+        const bool known = o[7] == EasyMode || o[7] == HardMode || (o[7] == ExtremeMode && game_has_extreme_mode(game_id)) || (o[7] == MemoryMode && game_has_memory_mode(game_id));
+        if (!known) return bad("set_state: the state carries a distribution_mode this game does not have");
+        if (kernel_id_for(game_id, o[7]) != kernel_id_for(game_id, opt.distribution_mode))
+            return bad("set_state: the state was saved under another distribution_mode than this handle's (caveflyer's memory mode has kernels of its own; make a handle with that mode)");
+    }
     if (o[1] != opt.use_generated_assets) return bad("set_state: the state was saved under another use_generated_assets setting than this handle's (the option selects the assets and kernels of the handle)");
     {
         GameOptions eo = opt;
@@ -411,6 +417,7 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
         eo.use_backgrounds = o[4] != 0;
         eo.center_agent = o[5] != 0;
         eo.use_sequential_levels = o[8] != 0;
+        eo.distribution_mode = o[7];
         h.opt_bits = env_option_bits(eo);
         h.opt_debug_mode = o[6];
     }

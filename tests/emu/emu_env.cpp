@@ -222,10 +222,10 @@ void *emu_make(const char *game, int num_envs, int rand_seed, int env_offset, in
         d.gen_bg = v->gen_bg.data();
         d.bg_req = v->bg_req.data();
     }
-    v->game_tables.assign(1024, 0);
+    v->game_tables.assign(2048, 0);
     int nw = 0;
 #define PG_X(Game) \
-    if (gid == Game::GAME_ID) nw = GameHostTables<Game>::build(d.opt, v->game_tables.data(), 1024);
+    if (gid == Game::GAME_ID) nw = GameHostTables<Game>::build(d.opt, v->game_tables.data(), 2048);
     PG_FOR_EACH_GAME(PG_X)
 #undef PG_X
     d.game_tables = nw > 0 ? v->game_tables.data() : nullptr;

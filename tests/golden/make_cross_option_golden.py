@@ -28,6 +28,7 @@ import ref_env  # noqa: E402
 PLAIN = dict(use_backgrounds=False, center_agent=False, paint_vel_info=True)
 MONO = dict(use_monochrome_assets=True, use_sequential_levels=True, num_levels=4, start_level=7)
 RESTRICT = dict(restrict_themes=True)
+EASY, EXTREME, MEMORY = dict(distribution_mode="easy"), dict(distribution_mode="extreme"), dict(distribution_mode="memory")
 # case name -> (game, options the states are saved under, options of the handle they are restored into)
 CASES = {
     "coinrun/plain_into_default": ("coinrun", PLAIN, {}),
@@ -41,6 +42,27 @@ CASES = {
     "climber/mono_into_plain": ("climber", MONO, PLAIN),
     "ninja/restricted_plain_into_restricted": ("ninja", dict(PLAIN, **RESTRICT), RESTRICT),
     "heist/plain_into_default": ("heist", PLAIN, {}),
+    # round 5: the distribution_mode is adopted per env as well (every mode of a game but caveflyer's memory mode runs on the same kernels)
+    "coinrun/easy_into_hard": ("coinrun", EASY, {}),
+    "coinrun/hard_into_easy": ("coinrun", {}, EASY),
+    "bigfish/easy_into_hard": ("bigfish", EASY, {}),
+    "bossfight/easy_into_hard": ("bossfight", EASY, {}),
+    "caveflyer/easy_into_hard": ("caveflyer", EASY, {}),
+    "chaser/hard_into_extreme": ("chaser", {}, EXTREME),
+    "climber/easy_into_hard": ("climber", EASY, {}),
+    "dodgeball/hard_into_memory": ("dodgeball", {}, MEMORY),
+    "dodgeball/memory_into_extreme": ("dodgeball", MEMORY, EXTREME),
+    "fruitbot/hard_into_easy": ("fruitbot", {}, EASY),
+    "heist/memory_into_easy": ("heist", MEMORY, EASY),
+    "jumper/easy_into_hard": ("jumper", EASY, {}),
+    "jumper/hard_into_memory": ("jumper", {}, MEMORY),
+    "jumper/memory_into_easy": ("jumper", MEMORY, EASY),
+    "leaper/extreme_into_easy": ("leaper", EXTREME, EASY),
+    "maze/memory_into_hard": ("maze", MEMORY, {}),
+    "miner/hard_into_memory": ("miner", {}, MEMORY),
+    "ninja/easy_into_hard": ("ninja", EASY, {}),
+    "plunder/hard_into_easy": ("plunder", {}, EASY),
+    "starpilot/extreme_into_hard": ("starpilot", EXTREME, {}),
 }
 T0, T1 = 20, 80
 

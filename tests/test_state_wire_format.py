@@ -135,6 +135,11 @@ def test_restored_envs_keep_the_game_options_they_were_saved_under(golden_dir, n
     end states -- exactly as in the reference.  Here: the kernel sources in the CPU emulation."""
     game, _saved, made = CROSS_OPTION_CASES[name]
     gold = np.load(os.path.join(golden_dir, "cross_option_state.npz"))
+    made = dict(made)
+    if "distribution_mode" in made:  # (the emulation's constructor takes the option's integer value)
+        from procgen_amd.env import DISTRIBUTION_MODE_DICT
+
+        made["distribution_mode"] = DISTRIBUTION_MODE_DICT[made["distribution_mode"]]
     env = emu_harness.EmuEnv(2, game, rand_seed=88, **made)
     _replay_cross_option(gold, name, env)
     env.close()
@@ -154,13 +159,22 @@ def test_gpu_restored_envs_keep_the_game_options_they_were_saved_under(golden_di
 
 @pytest.mark.gpu
 def test_gpu_states_of_another_distribution_mode_are_refused_with_the_reason(golden_dir):
-    """what still cannot be adopted per env: distribution_mode (and use_generated_assets) select the kernel instantiation of a handle"""
+    """what still cannot be adopted per env: caveflyer's memory mode has kernels (and LDS arenas) of its own, and use_generated_assets selects
+    the assets and the renderer of a handle.  Every other mode change is adopted (cross_option_state.npz, the */X_into_Y cases)."""
     import subprocess
     import sys
 
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r); from procgen_amd import ProcgenGym3Env; "
-            "a = ProcgenGym3Env(1, 'coinrun', distribution_mode='easy'); a.observe(); st = a.get_state(); "
-            "b = ProcgenGym3Env(1, 'coinrun', distribution_mode='hard'); b.observe(); b.set_state(st)") % repo
+            "a = ProcgenGym3Env(1, 'caveflyer', distribution_mode='memory'); a.observe(); st = a.get_state(); "
+            "b = ProcgenGym3Env(1, 'caveflyer', distribution_mode='hard'); b.observe(); b.set_state(st)") % repo
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "distribution_mode" in (r.stdout + r.stderr)
+    # a chaser state of a LARGER maze than the handle's mode generates: adopted, and ends the run at the env's next reset as the
+    # reference does (its per-Game MazeGen keeps the first reset's dimension, chaser.cpp:159-162; grid.h:41 fassert)
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; from procgen_amd import ProcgenGym3Env; "
+            "a = ProcgenGym3Env(1, 'chaser', distribution_mode='extreme'); a.observe(); st = a.get_state(); "
+            "b = ProcgenGym3Env(1, 'chaser', distribution_mode='hard'); b.observe(); b.set_state(st); b.observe(); print('restored'); "
+            "b.act(np.array([-1], dtype=np.int32)); b.observe(); print('survived')") % repo
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "restored" in r.stdout and "survived" not in r.stdout and "device-side check failed" in r.stdout
