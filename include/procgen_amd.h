@@ -98,11 +98,6 @@ LIBENV_API void procgen_amd_selftest_sincos(uint32_t first_bits, int n, double *
  *                   every call site that feeds game state (bullet / thrust velocities) */
 LIBENV_API void procgen_amd_selftest_sincos_scaled(const uint32_t *bits, int n, double scale, float *out_sin, float *out_cos);
 
-/* The workgroup -> env map the PROCGEN_AMD_RENDER_ORDER experiment gives the render kernel (host code only, no device needed): out[j] =
- * the env workgroup j draws, for the background image indices bg_index[num_envs] and the handle's launch chunks (PROCGEN_AMD_CHUNKS,
- * PROCGEN_AMD_FIRST_PCT; defaults 2 and 75).  A permutation of every launch chunk's env range. */
-LIBENV_API void procgen_amd_selftest_render_order(const int *bg_index, int num_envs, int chunks, int first_pct, int *out);
-
 /* get_state of the envs [first, first + count) in one call: the states are packed back to back into data[0, capacity), state k at
  * data[offsets[k], offsets[k + 1]) (offsets has count + 1 entries).  Returns the number of states that fit (>= 1); call again from
  * first + that for the rest.  Same bytes as get_state; what env.get_state() of the Python mirror uses (the reference's loop,

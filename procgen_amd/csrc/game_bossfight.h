@@ -14,7 +14,7 @@ struct BossFight : BagDefaults<BossFight> {
     static constexpr int MAX_CELLS = 20 * 20;  // bossfight.cpp:66-67
     static constexpr bool USES_ENTITY_COLLISIONS = true;
     static constexpr bool USES_ROTATION = true;  // bullets and trails spin (vrot)
-    static constexpr int ROT_POOL_FACTOR = 4;  // -DPG_ROT_POOL builds (pg_render.h): dozens of turned bullets on screen at once (at 32 records one frame in six falls back to the per-band path)
+    static constexpr int ROT_POOL_FACTOR = 4;  // (pg_render.h ROT_POOL: 4 x 16 = a record per lane) dozens of turned bullets on screen at once (at 32 records one frame in six falls back to the per-band path)
     static constexpr bool DRAWS_GRID = false;
     static constexpr int ENT_CAP_T0 = 128, ENT_CAP_T1 = 256, ENT_CAP_T2 = 512;
     static constexpr int RENDER_CMD_SETS = 2;  // frames with more than 64 visible entities are common

@@ -16,6 +16,7 @@ struct Heist : BagDefaults<Heist> {
     typedef MazeScratch Scratch;
     static constexpr int MAX_CELLS = 23 * 23;  // heist.cpp:95-110 (memory mode)
     static constexpr bool USES_ROTATION = true;
+    static constexpr int RENDER_MIN_WAVES = 4;  // with the 16-record rotation pool the arena is 9.7 KB: four render waves per SIMD at <= 128 VGPRs measured +10 % over the pool alone (37.3 -> 41.1 M) on the same box (profiles/r05_rot_pool_ab.txt)
     static constexpr int ENT_CAP_T0 = 16, ENT_CAP_T1 = 24, ENT_CAP_T2 = 32;  // agent + 3 keys + 3 doors + exit + 3 ring keys
     template <class E>
     PG_DEV static int slots_needed_next_step(E &) { return 0; }

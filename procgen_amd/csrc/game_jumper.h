@@ -30,6 +30,7 @@ struct Jumper : BagDefaults<Jumper> {
     typedef JumperScratch Scratch;
     static constexpr int MAX_CELLS = 45 * 45;  // jumper.cpp:201-217 (memory mode)
     static constexpr bool HAS_OVERLAY = true;
+    static constexpr int RENDER_MIN_WAVES = 4;  // 132 -> 128 VGPRs with 12 B of scratch (the phase-counter address): four render waves per SIMD measured +13 % on the same box (31.2 -> 35.3 M, profiles/r05_rot_pool_ab.txt)
     static constexpr bool HAS_HUMAN_OVERLAY = true;  // the compass under render_human: antialiased path draws (pg_human.h, pg_aapath.h)
     static constexpr int ENT_CAP_T0 = 64, ENT_CAP_T1 = 128, ENT_CAP_T2 = 256;  // agent, goal, spikes (~10-40), <= 8 trails
     // the level generator's scratch dominates the arena: step kernels without it, resets in the reset kernel (pg_env.h GameSplit)

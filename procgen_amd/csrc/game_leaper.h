@@ -13,6 +13,7 @@ struct Leaper : BagDefaults<Leaper> {
     static constexpr const char *NAME = "leaper";
     static constexpr int MAX_CELLS = 20 * 20;  // leaper.cpp:103-116
     static constexpr bool USES_ROTATION = true;  // cars driving left are turned by 180 degrees (a negative scale), the frog by +-90
+    static constexpr int RENDER_MIN_WAVES = 4;  // with the 16-record rotation pool the arena is 9.7 KB: four render waves per SIMD at <= 128 VGPRs measured +9 % over the pool alone (27.0 -> 29.4 M) on the same box (profiles/r05_rot_pool_ab.txt)
     static constexpr bool USES_TILED_ENTITIES = true;
     static constexpr int WIDE_ROWS = 8;  // 161 instead of 170 VGPRs in the renderer: three waves per SIMD instead of two
     // reset: <= 15 cars x 5 lanes + 16 logs x 5 lanes in the worst case, typically < 90 (its 300-400 spawner rounds never

@@ -29,7 +29,7 @@ struct StarPilot {
     static constexpr int MAX_CELLS = 16 * 16;  // starpilot.cpp:51-52
     static constexpr bool USES_ENTITY_COLLISIONS = true;
     static constexpr bool USES_ROTATION = true;
-    static constexpr int ROT_POOL_FACTOR = 2;  // -DPG_ROT_POOL builds (pg_render.h): at 16 records 0.6 % of the frames fall back to the per-band path
+    static constexpr int ROT_POOL_FACTOR = 2;  // (pg_render.h ROT_POOL: 2 x 16 records) at 16 records 0.6 % of the frames fall back to the per-band path
     static constexpr bool DRAWS_GRID = false;  // the grid holds only SPACE
     static constexpr bool CUSTOM_BACKGROUND = true;
     static constexpr int SPAWN_CAP = 256;

@@ -50,6 +50,8 @@ int game_host_tables(int game_id, const GameOptions &opt, uint32_t *out, int max
 bool (*game_use_block_asset(int game_id))(int);
 bool game_split_reset(int game_id);
 hipError_t launch_paint_backgrounds(const DevCtx &d, int env_base, int count, hipStream_t stream);  // use_generated_assets (pg_bgpaint.h); no-op otherwise
+// render kernel launch order of the envs [base, base + count) of one launch chunk by background image (kernels.hip); scratch: MAX_BACKGROUNDS ints
+hipError_t launch_render_order(const DevCtx &d, int base, int count, int *scratch, int *order, hipStream_t stream);
 // device math self-tests (kernels.hip)
 hipError_t selftest_bigfish_radius(const float *d_in, float *d_out, int n);
 hipError_t selftest_sincos(uint32_t first_bits, int n, double *d_sin, double *d_cos);

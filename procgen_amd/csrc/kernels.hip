@@ -89,18 +89,74 @@ __global__ __launch_bounds__(64) void paint_backgrounds(DevCtx d, int env_base) 
     if (threadIdx.x == 0) {
         d.bg_req[2 * env + 1] = -1;
         if (err) {
-            atomicOr(d.error, (int)PGE_ASSERT);
-            int *w = d.error + ERROR_INFO_OFFSET;
-            if (atomicCAS(w, 0, env + 1) == 0) {
-                w[1] = pg_error_word(PGE_ASSERT, __LINE__);
-                w[2] = ERR_KIND_BGPAINT;
-            }
+            pg_report_error(d, env, pg_error_word(PGE_ASSERT, __LINE__), ERR_KIND_BGPAINT, 0, 0);
         }
     }
 }
 hipError_t launch_paint_backgrounds(const DevCtx &d, int env_base, int count, hipStream_t stream) {
     if (!d.gen_bg || count <= 0) return hipSuccess;
     hipLaunchKernelGGL(paint_backgrounds, dim3(count), dim3(64), 0, stream, d, env_base);
+    return hipGetLastError();
+}
+
+// ---- launch order of the render kernel by background image (PROCGEN_AMD_RENDER_ORDER; libenv_hip.cpp VecGame::rebuild_render_order) ----
+// A counting sort of one launch chunk's envs [base, base + count) by EnvHdr::background_index, on the device: histogram, exclusive scan,
+// scatter.  Sorted position p goes to launch slot (p mod count/8) * 8 + p / (count/8): workgroup j of a launch runs on XCD j mod 8, each
+// XCD has its own L2, so XCD x draws the x-th eighth of the sorted sequence -- a few images, one after the other -- instead of all 62
+// at once.  The order within an image is whatever the atomics give: envs are independent, any permutation draws the same frames.
+constexpr int RO_BINS = MAX_BACKGROUNDS;
+__global__ __launch_bounds__(256) void render_order_hist(const EnvHdr *hdr, int base, int count, int *hist) {
+    __shared__ int h[RO_BINS];
+    if (threadIdx.x < RO_BINS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < count) {
+        int b = hdr[base + i].background_index;
+        b = b < 0 ? 0 : (b >= RO_BINS ? RO_BINS - 1 : b);
+        atomicAdd(&h[b], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < RO_BINS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void render_order_scan(int *hist) {  // counts -> first sorted position of each image (128 values: one thread)
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < RO_BINS; b++) {
+            const int c = hist[b];
+            hist[b] = acc;
+            acc += c;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void render_order_scatter(const EnvHdr *hdr, int base, int count, int *cursor, int *order) {
+    __shared__ int cnt[RO_BINS], start[RO_BINS];
+    if (threadIdx.x < RO_BINS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    int b = 0, local = 0;
+    if (i < count) {
+        b = hdr[base + i].background_index;
+        b = b < 0 ? 0 : (b >= RO_BINS ? RO_BINS - 1 : b);
+        local = atomicAdd(&cnt[b], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < RO_BINS && cnt[threadIdx.x]) start[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]);  // one range per (block, image)
+    __syncthreads();
+    if (i < count) {
+        const int p = start[b] + local;
+        const int per = count >> 3;  // (launch chunks are multiples of 64 envs)
+        const int slot = per > 0 ? (p % per) * 8 + p / per : p;
+        order[base + slot] = base + i;
+    }
+}
+hipError_t launch_render_order(const DevCtx &d, int base, int count, int *scratch, int *order, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(scratch, 0, RO_BINS * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(render_order_hist, dim3(blocks), dim3(256), 0, stream, d.hdr, base, count, scratch);
+    hipLaunchKernelGGL(render_order_scan, dim3(1), dim3(64), 0, stream, scratch);
+    hipLaunchKernelGGL(render_order_scatter, dim3(blocks), dim3(256), 0, stream, d.hdr, base, count, scratch, order);
     return hipGetLastError();
 }
 

@@ -39,15 +39,12 @@ __device__ inline void trace_wave(const DevCtx &d, int env, int base, bool end, 
 // Round 1 tried it for coinrun (133 -> 128 VGPRs): the 104 B of spill per lane showed up as +54 % WRITE_SIZE.  Round 4: with the
 // renderer's lane ids opaque to LICM (pg_render.h) and its LDS tables overlaid (8068 B), coinrun's kernel fits 96 VGPRs without
 // scratch, i.e. five waves per SIMD: +3 % steps/s on the same box (tools/gpu/r4_occ.sh), so CoinRun sets 5.
-#ifndef PG_RENDER_WAVES
-#define PG_RENDER_WAVES 1
-#endif
 #ifndef PG_RENDER_TRACE
 #define PG_RENDER_TRACE 0
 #endif
 template <class Game, class = void>
 struct GameRenderMinWaves {
-    static constexpr int value = PG_RENDER_WAVES;  // (-DPG_RENDER_WAVES=n: build-time experiment for every game without its own hint)
+    static constexpr int value = 1;  // no hint: the register allocation is left alone
 };
 template <class Game>
 struct GameRenderMinWaves<Game, decltype((void)Game::RENDER_MIN_WAVES)> {

@@ -163,6 +163,15 @@ static std::shared_ptr<DeviceAtlas> shared_atlas(int device, const std::string &
     return da;
 }
 
+// Launch order of the render kernel by background image (VecGame::rebuild_render_order): every how many steps a game's handles re-sort it
+// by default; 0 = never (launch slot = env).  Per game, from same-box measurements (profiles/r05_render_order_*): the order cuts the render
+// kernel's HBM fetch traffic by 3-4x for the games that sample a large parallax background, at equal or slightly better speed; games whose
+// frames are cheap enough to be bandwidth-sensitive (bigfish) lose by it -- every resident frame then reads the same image.
+static int default_render_order_period(int game_id) {
+    (void)game_id;
+    return 0;
+}
+
 // BAG:819-838 prepare_for_drawing(64): the camera scalars that depend on the frame height, for the 64-pixel observation frame (centre
 // and visibility do not depend on it)
 static void camera_scalars_of_the_observation_frame(EnvHdr *h) {
@@ -252,8 +261,7 @@ struct VecGame {
     // PROCGEN_AMD_RENDER_ORDER=K (experiment, off by default): every K steps the render kernel's workgroup -> env map of each launch
     // chunk is re-sorted by background image, images dealt to the XCDs (workgroup j runs on XCD j mod 8, each with its own L2)
     int render_order_period = 0;
-    int *d_render_order = nullptr;
-    std::vector<int> h_bg_index, h_render_order;
+    int *d_render_order = nullptr, *d_render_order_scratch = nullptr;
     void rebuild_render_order();
     void bind_routing() {  // double-buffered by step parity: this step reads [cur], fills [nxt]
         const int cur = (int)(step_count & 1), nxt = cur ^ 1;
@@ -291,14 +299,16 @@ struct VecGame {
     void launch_kernels(int mode);
     void read_tail();
     [[noreturn]] void report_device_error(int err, const int *info, const char *when);
-    void check_late_error();
+    void check_late_error(const char *when = "a step");
     // procgen_amd_kernel_timing: HIP events around the kernels of every libenv_act of the caller's own loop (bench.py: the device time of
     // a step and the wall time of a step then come from the SAME steps)
     bool time_kernels = false, tk_pending = false;
     hipEvent_t tk_e0 = nullptr, tk_e1 = nullptr, tk_r0[MAX_CHUNKS] = {}, tk_r1[MAX_CHUNKS] = {};
     double tk_sum_ms = 0, tk_render_ms = 0;
     int tk_steps = 0, tk_render_launches = 0;
-    int *h_late_error = nullptr;  // pinned: the error word and its info record as they stand behind the render kernels (early_small handles)
+    // host-mapped copy of the error record, written by the first kernel that raises a check (pg_env.h pg_report_error): [0] code (written
+    // last), [1] env + 1, [2] code | line << 8, [3] kind, [4] n_ents, [5] agent.  Read after the stream join of every libenv_observe: no copy
+    volatile int *h_error_rec = nullptr;
     void launch(int mode);
     void act();
     void observe(bool from_api = false);
@@ -481,8 +491,6 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
             HIP_CHECK(hipEventCreateWithFlags(&ev_small, hipEventDisableTiming));
             for (int c = 0; c < MAX_CHUNKS; c++) HIP_CHECK(hipEventCreateWithFlags(&ev_out[c], hipEventDisableTiming));
             early_small = true;
-            HIP_CHECK(hipHostMalloc((void **)&h_late_error, (1 + ERROR_INFO_WORDS) * sizeof(int), hipHostMallocDefault));
-            memset(h_late_error, 0, (1 + ERROR_INFO_WORDS) * sizeof(int));
         }
     }
     if (num_envs >= 4096) {
@@ -550,6 +558,17 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     tail_off = (14 * N + 3) & ~(size_t)3;
     d.error = (int *)(d_small + tail_off) + LIST_COUNTERS;
     static_assert(ERROR_INFO_OFFSET == LIST_COUNTERS + 1, "the error record lies behind the second counter block");
+    {
+        int *rec = nullptr;
+        void *rec_dev = nullptr;
+        HIP_CHECK(hipHostMalloc((void **)&rec, 8 * sizeof(int), hipHostMallocMapped));
+        memset(rec, 0, 8 * sizeof(int));
+        HIP_CHECK(hipHostGetDevicePointer(&rec_dev, rec, 0));
+        h_error_rec = rec;
+        const unsigned long long a = (unsigned long long)rec_dev;
+        const int words[2] = {(int)(unsigned)(a & 0xffffffffull), (int)(unsigned)(a >> 32)};
+        HIP_CHECK(hipMemcpy(d.error + ERROR_INFO_OFFSET + 6, words, sizeof(words), hipMemcpyHostToDevice));
+    }
     small_bytes = tail_off + (2 * LIST_COUNTERS + 1 + ERROR_INFO_WORDS) * sizeof(int);
     for (int k = 0; k < 2; k++) {
         d_big_list[k] = dev_alloc<int>(N * NUM_TIERS);
@@ -558,8 +577,12 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     }
     d_reset_list = dev_alloc<int>(N);
     d_reset_count = dev_alloc<int>(2 * MAX_CHUNKS);
-    if (const char *ro = getenv("PROCGEN_AMD_RENDER_ORDER")) render_order_period = atoi(ro);
-    if (render_order_period > 0 && !d.opt.use_generated_assets) d_render_order = dev_alloc<int>(N);  // (bound to d.render_order by the first rebuild)
+    render_order_period = default_render_order_period(game_id);
+    if (const char *ro = getenv("PROCGEN_AMD_RENDER_ORDER")) render_order_period = atoi(ro);  // (0: off)
+    if (render_order_period > 0 && !d.opt.use_generated_assets) {
+        d_render_order = dev_alloc<int>(N);  // (bound to d.render_order by the first rebuild)
+        d_render_order_scratch = dev_alloc<int>(MAX_CHUNKS * MAX_BACKGROUNDS);
+    }
     d.assets = atlas->d_assets;
     d.pixels = atlas->d_pixels;
     if (this->render_human) {
@@ -662,9 +685,10 @@ VecGame::~VecGame() {
     (void)hipFree(d_reset_list);
     (void)hipFree(d_reset_count);
     if (d_render_order) (void)hipFree(d_render_order);
+    if (d_render_order_scratch) (void)hipFree(d_render_order_scratch);
     if (h_action) (void)hipHostFree(h_action);
     if (h_small) (void)hipHostFree(h_small);
-    if (h_late_error) (void)hipHostFree(h_late_error);
+    if (h_error_rec) (void)hipHostFree((void *)h_error_rec);
     if (h_obs_stage) (void)hipHostFree(h_obs_stage);
     for (int k = 0; k < 2; k++) {
         if (ev_lane[k]) (void)hipEventDestroy(ev_lane[k]);
@@ -739,66 +763,20 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
     launch(0);  // initial reset + first frame (reference src/vecgame.cpp:346-357)
 }
 
-// PROCGEN_AMD_RENDER_ORDER: the render kernel's workgroup -> env map.  Each launch chunk's env range (the ranges of launch_game,
-// kernels_game.hip) is permuted on its own -- a chunk's render kernel is ordered behind that chunk's step kernel only --: envs sorted by
-// background image, image i dealt to XCD i mod 8 (workgroup j of a launch runs on XCD j mod 8, each XCD has its own L2); an XCD whose
-// images are drawn takes from the back of the longest queue left.  Pure host code (procgen_amd_selftest_render_order tests it without a GPU).
-static void build_render_order(const int *bg_index, int N, int chunks, int first_pct, int *order) {
-    int bounds[MAX_CHUNKS + 1] = {0};
-    int nb = 1;
-    bounds[1] = N;
-    if (N >= 4096) {
-        const int nchunk = chunks > 1 ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1;
-        const int per = chunk_envs_for(N, nchunk);
-        const int first = (nchunk == 2 && first_pct > 0) ? first_chunk_envs(N, first_pct) : 0;
-        nb = 0;
-        for (int c = 0; c < nchunk; c++) {
-            const int base = first > 0 ? (c == 0 ? 0 : first) : c * per;
-            if (base >= N) break;
-            bounds[nb++] = base;
-        }
-        bounds[nb] = N;
-    }
-    constexpr int XCDS = 8;
-    std::vector<int> queue[XCDS];
-    for (int c = 0; c < nb; c++) {
-        const int b = bounds[c], e = bounds[c + 1];
-        std::vector<std::pair<int, int>> keyed;  // (image, env): images ascending, envs ascending within an image
-        keyed.reserve((size_t)(e - b));
-        for (int i = b; i < e; i++) keyed.push_back({bg_index[i] < 0 ? 0 : bg_index[i], i});
-        std::sort(keyed.begin(), keyed.end());
-        for (auto &q : queue) q.clear();
-        for (auto &k : keyed) queue[k.first % XCDS].push_back(k.second);
-        size_t head[XCDS] = {};
-        size_t tail[XCDS];
-        for (int x = 0; x < XCDS; x++) tail[x] = queue[x].size();
-        for (int j = 0; j < e - b; j++) {
-            const int x = j % XCDS;
-            if (head[x] < tail[x]) {
-                order[b + j] = queue[x][head[x]++];
-                continue;
-            }
-            int longest = 0;
-            for (int y = 1; y < XCDS; y++)
-                if (tail[y] - head[y] > tail[longest] - head[longest]) longest = y;
-            order[b + j] = queue[longest][--tail[longest]];
-        }
-    }
-}
-
-// called between steps (the handle's streams are idle)
+// called between steps (the handle's streams are idle): enqueued on the main stream ahead of the step -- the chunk streams fork from it
+// (launch_game), so every render kernel of the step sees the new order; the sort reads the backgrounds as the last step left them (an
+// episode that begins in this step is drawn from a stale slot once, which costs locality, not correctness)
 void VecGame::rebuild_render_order() {
     const int N = num_envs;
-    h_bg_index.resize(N);
-    h_render_order.resize(N);
-    HIP_CHECK(hipStreamSynchronize(stream));
-    // (the whole header array in one contiguous copy, 18 MB at 65 536 envs: a 2-D copy of one word per header may run row by row)
-    std::vector<EnvHdr> hdrs((size_t)N);
-    HIP_CHECK(hipMemcpy(hdrs.data(), d.hdr, (size_t)N * sizeof(EnvHdr), hipMemcpyDeviceToHost));
-    for (int i = 0; i < N; i++) h_bg_index[i] = hdrs[(size_t)i].background_index;
-    build_render_order(h_bg_index.data(), N, chunks, first_pct, h_render_order.data());
-    HIP_CHECK(hipMemcpy(d_render_order, h_render_order.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
-    HIP_CHECK(hipStreamSynchronize(nullptr));  // (null-stream upload; the render kernels run on non-blocking streams)
+    const int nchunk = N >= 4096 ? (chunks > 1 ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1) : 1;
+    const int per = chunk_envs_for(N, nchunk);
+    const int first = (nchunk == 2 && first_pct > 0) ? first_chunk_envs(N, first_pct) : 0;
+    for (int c = 0; c < nchunk; c++) {  // each launch chunk's env range is permuted on its own: a chunk's render kernel is ordered behind that chunk's step kernel only
+        const int base = first > 0 ? (c == 0 ? 0 : first) : c * per;
+        const int count = first > 0 ? (c == 0 ? first : N - first) : ((N - base) < per ? (N - base) : per);
+        if (count <= 0) break;
+        HIP_CHECK(launch_render_order(d, base, count, d_render_order_scratch + c * MAX_BACKGROUNDS, d_render_order, stream));
+    }
     d.render_order = d_render_order;
 }
 
@@ -864,10 +842,12 @@ void VecGame::report_device_error(int err, const int *info, const char *when) {
     fatal("device-side check failed during %s (code %d: 1 entity table overflow, 2 grid index out of range, 3 fassert, 4 asset theme, 5 unsupported draw)\n%s", when, err, extra.c_str());
 }
 
-// early_small handles: the error word as it stands behind the render kernels (the early download left before they ran)
-void VecGame::check_late_error() {
-    if (!h_late_error) return;
-    if (h_late_error[0] && !d.debug_flags) report_device_error(h_late_error[0], h_late_error + 1, "a step's frames");
+// after the join of a step's streams: did a kernel of this step -- a render kernel included -- raise a check?  (The download of the small
+// outputs carries the device word too, but large handles take it before the render kernels run.)
+void VecGame::check_late_error(const char *when) {
+    if (!h_error_rec || h_error_rec[0] == 0 || d.debug_flags) return;
+    const int info[ERROR_INFO_WORDS] = {h_error_rec[1], h_error_rec[2], h_error_rec[3], h_error_rec[4], h_error_rec[5], 0, 0, 0};
+    report_device_error(h_error_rec[0], info, when);
 }
 
 void VecGame::launch(int mode) {
@@ -886,11 +866,6 @@ void VecGame::launch(int mode) {
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, copy_stream));
         HIP_CHECK(hipEventRecord(ev_small, copy_stream));
         small_in_flight = true;
-        // ... and once more behind the render kernels (main has joined the chunk streams): an error a render kernel of THIS step raises
-        // ends the run at this step's libenv_observe, before the caller sees the frame (two small copies; the error word and its record
-        // are not adjacent -- the second list-counter block lies between them)
-        HIP_CHECK(hipMemcpyAsync(h_late_error, d.error, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(h_late_error + 1, (d.error + ERROR_INFO_OFFSET), ERROR_INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost, stream));
     } else {
         HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, stream));
     }
@@ -979,10 +954,8 @@ void VecGame::observe(bool from_api) {  // reference src/vecgame.cpp:363-376,416
             *(int32_t *)info_ptr[2][e] = ls[e];
         }
     }
-    if (early_small) {
-        HIP_CHECK(hipStreamSynchronize(stream));  // (the render kernels, the landing of the frames)
-        check_late_error();
-    }
+    if (early_small) HIP_CHECK(hipStreamSynchronize(stream));  // (the render kernels, the landing of the frames)
+    check_late_error();
     if (host_observations && !ob_contig)
         for (size_t e = 0; e < N; e++) memcpy(ob_ptr[e], h_obs_stage + e * OBS_BYTES, OBS_BYTES);
     if (tk_pending) {  // (the stream is joined: both events have completed)
@@ -1104,25 +1077,10 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     HIP_CHECK(hipMemcpy(d.prev_level_complete + e, &plc, 1, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d.level_seed + e, &s.hdr.current_level_seed, 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipStreamSynchronize(nullptr));  // the uploads above ran on the null stream: joined before the handle's (non-blocking) stream reads them
-    {   // an error a kernel raised since the last download (a render kernel of the last step on a handle without the late check) must not
-        // be lost to the clear below: the first device error ends the run
-        int old[1 + ERROR_INFO_WORDS] = {0};
-        HIP_CHECK(hipMemcpy(old, d.error, sizeof(int), hipMemcpyDeviceToHost));
-        if (old[0] && !d.debug_flags) {
-            HIP_CHECK(hipMemcpy(old + 1, (d.error + ERROR_INFO_OFFSET), ERROR_INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost));
-            report_device_error(old[0], old + 1, "the last step's frames");
-        }
-    }
-    HIP_CHECK(hipMemsetAsync(d.error, 0, sizeof(int), stream));
-    HIP_CHECK(hipMemsetAsync((d.error + ERROR_INFO_OFFSET), 0, ERROR_INFO_WORDS * sizeof(int), stream));
+    // (any error a kernel raised before this call has ended the run in the observe() above: the host-mapped record is checked at every join)
     HIP_CHECK(launch_render_one(kernel_id, d, e, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    int dev_err[1 + ERROR_INFO_WORDS] = {0};
-    HIP_CHECK(hipMemcpy(dev_err, d.error, sizeof(int), hipMemcpyDeviceToHost));
-    if (dev_err[0] && !d.debug_flags) {
-        HIP_CHECK(hipMemcpy(dev_err + 1, (d.error + ERROR_INFO_OFFSET), ERROR_INFO_WORDS * sizeof(int), hipMemcpyDeviceToHost));
-        report_device_error(dev_err[0], dev_err + 1, "the drawing of a restored state");
-    }
+    check_late_error("the drawing of a restored state");
     rew_ptr[e] = s.hdr.reward;
     first_ptr[e] = first;
     *(int32_t *)info_ptr[0][e] = s.hdr.prev_level_seed;
@@ -1545,9 +1503,6 @@ LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable
     v->host_observations = enable != 0;
 }
 // Device math self-tests: no handle; run on the current device.  Host pointers in, host pointers out.
-LIBENV_API void procgen_amd_selftest_render_order(const int *bg_index, int num_envs, int chunks, int first_pct, int *out) {
-    build_render_order(bg_index, num_envs, chunks, chunks == 2 && first_chunk_envs(num_envs, first_pct) > 0 ? first_pct : 0, out);  // (as the constructor settles first_pct)
-}
 LIBENV_API void procgen_amd_selftest_bigfish_radius(const float *r01, float *out, int n) {
     float *d_in = nullptr, *d_out = nullptr;
     HIP_CHECK(hipMalloc((void **)&d_in, (size_t)n * 4));

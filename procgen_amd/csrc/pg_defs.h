@@ -6,11 +6,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
-// Per-phase cycle counters of the kernels (PROCGEN_AMD_DEBUG & 2048, DevCtx::phase_cycles).  -DPG_PHASE_PROFILE=0 compiles them out: the
-// counter address lives in a VGPR pair for the whole kernel (or in scratch, where an occupancy hint leaves no room for it).
-#ifndef PG_PHASE_PROFILE
-#define PG_PHASE_PROFILE 1
-#endif
+// (Per-phase cycle counters of the kernels: PROCGEN_AMD_DEBUG & 2048, DevCtx::phase_cycles.  They are always compiled in: a build switch
+// that removed them was prepared in round 4 and dropped in round 5 unmeasured -- statically the register allocation moved both ways, a
+// per-kernel lottery, not a win.)
 
 namespace pgamd {
 
@@ -251,8 +249,9 @@ struct DevCtx {
     int *error;            // [1] OR of the per-env error codes raised so far (0 = none; sticky: the host stops at the first one)
     // error + ERROR_INFO_OFFSET, [ERROR_INFO_WORDS] (device builds; no pointer of its own: a kernel argument is live for a whole kernel, and the
     // render kernels have no scalar register to spare): who raised the first one, claimed with a compare-and-swap on word 0: env + 1,
-    // code | source line << 8, kernel kind (a step kernel's arena size; ERR_KIND_*), n_ents, agent.  The host prints it with the env's
-    // header when it ends the run (libenv_hip.cpp VecGame::report_device_error).
+    // code | source line << 8, kernel kind (a step kernel's arena size; ERR_KIND_*), n_ents, agent; words 6 / 7: the device address of the
+    // handle's host-mapped copy of the record (pg_env.h pg_report_error).  The host prints it with the env's header when it ends the run
+    // (libenv_hip.cpp VecGame::report_device_error).
     // launch order of the render kernel (experiment, PROCGEN_AMD_RENDER_ORDER; null = identity): workgroup j of a chunk's launch draws env
     // render_order[env_base + j], a permutation of that chunk's env range sorted by background image
     const int *render_order;  // [num_envs]

@@ -32,7 +32,10 @@ enum PgError : int { PGE_NONE = 0, PGE_ENT_OVERFLOW = 1, PGE_GRID_OOB = 2, PGE_A
 // call sites of the step kernels and a dozen in the game policies).  The handle-wide word DevCtx::error is the OR of the codes alone.
 PG_DEV int pg_error_word(int code, int line) { return code | (line << 8); }
 // called by lane 0 of an env's wave when the env carries an error: OR the code into the handle's sticky word and, for the first
-// reporter, leave who and where (the record behind the word, pg_defs.h ERROR_INFO_OFFSET; the emulation's error word stands alone)
+// reporter (compare-and-swap on the record's word 0, pg_defs.h ERROR_INFO_OFFSET), leave who and where -- in the device record and in
+// the handle's HOST-mapped copy of it, whose address the host left in the record's words 6 / 7: the host reads that copy after the
+// stream join of the same libenv_observe, without a download (an error a render kernel raises ends the run before the caller sees the
+// frame).  The emulation's error word stands alone.
 PG_DEV void pg_report_error(const DevCtx &d, int env, int error_word, int kind, int n_ents, int agent) {
 #if defined(PGAMD_WAVE_EMU)
     (void)env; (void)kind; (void)n_ents; (void)agent;
@@ -45,6 +48,16 @@ PG_DEV void pg_report_error(const DevCtx &d, int env, int error_word, int kind, 
         w[2] = kind;
         w[3] = n_ents;
         w[4] = agent;
+        volatile int *h = reinterpret_cast<volatile int *>(((unsigned long long)(unsigned)w[7] << 32) | (unsigned long long)(unsigned)w[6]);
+        if (h) {
+            h[1] = env + 1;
+            h[2] = error_word;
+            h[3] = kind;
+            h[4] = n_ents;
+            h[5] = agent;
+            __threadfence_system();
+            h[0] = error_word & 0xff;
+        }
     }
 #endif
 }
@@ -259,7 +272,7 @@ struct Env {
     bool needs_reset = false;  // NO_RESET: this step ended the episode
     PG_DEV void phase(int k) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (PG_PHASE_PROFILE && d.phase_cycles) {
+        if (d.phase_cycles) {
             const long long t = (long long)__builtin_readcyclecounter();
             if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + k + 32 * (env & 4095), (unsigned long long)(t - t_mark));
             if (d.wave_trace && PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.wave_trace + (size_t)env * 32 + 8 + k, (unsigned long long)(t - t_mark));  // this env, this step
@@ -273,7 +286,7 @@ struct Env {
     // profiling aid (PROCGEN_AMD_DEBUG & 8192): per-env counters of this step in the trace record (slots 24..31)
     PG_DEV void trace_add(int k, unsigned long long v) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (PG_PHASE_PROFILE && d.wave_trace && d.phase_cycles && PG_LANE_ID() == 0) d.wave_trace[(size_t)env * 32 + 24 + k] += v;
+        if (d.wave_trace && d.phase_cycles && PG_LANE_ID() == 0) d.wave_trace[(size_t)env * 32 + 24 + k] += v;
 #else
         (void)k; (void)v;
 #endif
@@ -1907,7 +1920,7 @@ struct Env {
                 game_reset_full();
                 phase(6);
 #if !defined(PGAMD_WAVE_EMU)
-                if (PG_PHASE_PROFILE && d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 15 + 32 * (env & 4095), 1ull);
+                if (d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 15 + 32 * (env & 4095), 1ull);
 #endif
             }
         }
@@ -2096,8 +2109,8 @@ struct Env {
     // step kernel took up to the end of the episode (mode 2) of this env
     PG_DEV void run(int mode) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (PG_PHASE_PROFILE && d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
-        if (PG_PHASE_PROFILE && d.phase_cycles && d.wave_trace && PG_LANE_ID() < 24) d.wave_trace[(size_t)env * 32 + 8 + PG_LANE_ID()] = 0;
+        if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
+        if (d.phase_cycles && d.wave_trace && PG_LANE_ID() < 24) d.wave_trace[(size_t)env * 32 + 8 + PG_LANE_ID()] = 0;
 #endif
         load_env(mode != 2);  // a reset starts from an empty entity table (whose old size may exceed this arena)
         phase(0);
@@ -2130,7 +2143,7 @@ struct Env {
         store_env();
         phase(8);
 #if !defined(PGAMD_WAVE_EMU)
-        if (PG_PHASE_PROFILE && d.phase_cycles && mode != 0 && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 14 + 32 * (env & 4095), 1ull);
+        if (d.phase_cycles && mode != 0 && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 14 + 32 * (env & 4095), 1ull);
 #endif
     }
 };

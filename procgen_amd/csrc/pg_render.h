@@ -155,14 +155,18 @@ struct GameCustomBackground<Game, decltype((void)Game::CUSTOM_BACKGROUND)> {
 
 // parameter record of one rotated command (qt_transform_image): inverse mapping + three trapezoids
 constexpr int ROT_WORDS = 24;  // u0 v0 dudx dudy dvdx dvdy | 3 x (from_y to_y x_l dx_l x_r dx_r)
-// Rotation / tile records per render workgroup.  64 (default): a chunk's lane l owns record l.  A build with -DPG_ROT_POOL=n (n < 64; an
-// experiment prepared at the end of round 4, checked in the emulation, not yet measured) hands records only to the turned / tiled entities that
-// can reach the rows being drawn, n at a time: 16 takes 4.6 KB off the arena of the games with rotation (14.3 -> 9.7 KB: 11 -> 16 frames per CU).
+// Rotation / tile records per render workgroup: a pool of 16 (round 5; 64 = a record per entity lane, the form of rounds 1-4).  Records go
+// only to the turned / tiled entities that can reach the rows being drawn, 16 at a time; a frame with more of them falls back to the
+// per-band path, which cuts its chunks into windows of at most that many (0-0.2 % of the frames).  It takes 4.6 KB off the arena of the games
+// with rotation (14.3 -> 9.7 KB: 11 -> 16 frames per CU).  Same-box A/B against 64 (profiles/r05_rot_pool_ab.txt, M steps/s): caveflyer
+// 38.6 -> 48.0, heist 34.4 -> 37.3, starpilot 64.6 -> 70.1, plunder 71.8 -> 76.6, leaper 25.1 -> 27.0, dodgeball 24.6 -> 26.1, fruitbot
+// 18.3 -> 20.2; bossfight keeps 64 through its factor (a third of its frames show more than 16 turned bullets).  -DPG_ROT_POOL=2 is the
+// emulation tests' way to force every fallback (tests/test_kernel_logic_emu.py).
 #ifndef PG_ROT_POOL
-#define PG_ROT_POOL 64
+#define PG_ROT_POOL 16
 #endif
 static_assert(PG_ROT_POOL >= 1 && PG_ROT_POOL <= 64, "records are addressed by six bits");
-// a policy with many turned sprites on screen (bossfight's bullets) asks for a multiple: ROT_POOL_FACTOR
+// a policy with many turned sprites on screen (bossfight's bullets, starpilot) asks for a multiple: ROT_POOL_FACTOR
 template <class Game, class = void>
 struct GameRotPool {
     static constexpr int value = PG_ROT_POOL;
@@ -2161,7 +2165,7 @@ struct Renderer {
     long long t_mark = 0;
     PG_DEV void phase(int k) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (PG_PHASE_PROFILE && d.phase_cycles) {
+        if (d.phase_cycles) {
             const long long t = (long long)__builtin_readcyclecounter();
             if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + k, (unsigned long long)(t - t_mark));
             t_mark = (long long)__builtin_readcyclecounter();
@@ -2172,7 +2176,7 @@ struct Renderer {
     }
     PG_DEV void render_env() {
 #if !defined(PGAMD_WAVE_EMU)
-        if (PG_PHASE_PROFILE && d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
+        if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
 #endif
         // ---- requests, round 1: what depends on the env index alone -- the header and the fields of the first 64 entity slots
         EntPre epre;
@@ -2529,7 +2533,7 @@ struct Renderer {
             phase(5);
         }
 #if !defined(PGAMD_WAVE_EMU)
-        if (PG_PHASE_PROFILE && d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + 15, 1ull);
+        if (d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + 15, 1ull);
 #else
         if (pg_emu_dma_outstanding() != 0) {  // (a band whose background copies nobody joined: store_band always does)
             fprintf(stderr, "render_env: %d LDS-DMA words still in flight at the end of the frame\n", pg_emu_dma_outstanding());

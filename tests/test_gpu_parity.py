@@ -354,3 +354,18 @@ def test_lds_dma_background_equals_the_register_path(monkeypatch):
         got = rollout(make_env(n, game), acts)
         monkeypatch.delenv("PROCGEN_AMD_DEBUG")
         assert_rollouts_equal(want, got, f"{game}: LDS-DMA background vs the register path")
+
+
+def test_render_launch_order_by_background_draws_the_same_frames(monkeypatch):
+    """PROCGEN_AMD_RENDER_ORDER=K: every K steps a counting sort on the device (kernels.hip render_order_*) re-maps the render kernel's
+    workgroups to envs by background image.  Envs are independent, so any permutation draws the same frames: a handle with the order
+    rebuilt every 4 steps equals the default handle -- two launch chunks (8192 envs), a single-stream handle (512), a game with a
+    tiled background and one that draws its own."""
+    for game, n, steps in (("coinrun", 8192, 40), ("coinrun", 512, 40), ("fruitbot", 256, 30), ("starpilot", 4096, 30)):
+        acts = action_stream(n, steps, seed=13)
+        monkeypatch.delenv("PROCGEN_AMD_RENDER_ORDER", raising=False)
+        want = rollout(make_env(n, game), acts)
+        monkeypatch.setenv("PROCGEN_AMD_RENDER_ORDER", "4")
+        got = rollout(make_env(n, game), acts)
+        monkeypatch.delenv("PROCGEN_AMD_RENDER_ORDER")
+        assert_rollouts_equal(want, got, f"{game} N={n}: ordered render launch")

@@ -1,5 +1,6 @@
 """
-CPU (hipcc cross-compiles without a GPU): no kernel may use scratch (private) memory.
+CPU (hipcc cross-compiles without a GPU): no kernel may use scratch (private) memory -- but for three render kernels whose occupancy hint
+spills a few dwords and measured faster on the device (SMALL_SPILLS_THAT_PAID).
 
 A `?:` chain over adjacent struct fields or small local arrays is folded by LLVM into one access at a computed
 offset, which pins the whole per-env state struct in scratch memory instead of registers; plunder's and leaper's step
@@ -18,6 +19,10 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 HIPCC = "/opt/rocm/bin/hipcc"
 GAMES = ["CoinRun", "Plunder", "Leaper", "FruitBot", "Jumper", "CaveFlyer", "StarPilot"]
 SPLIT_RESET = {"Leaper", "Jumper", "CaveFlyer"}
+# render<Game, false> kernels whose RENDER_MIN_WAVES = 4 hint costs a small spill (bytes per lane) and was adopted because the same-box A/B
+# said so (profiles/r05_rot_pool_ab.txt: leaper +9 %, fruitbot +11 %, jumper +13 % over the same build without the hint); the limit keeps
+# the spill from growing unnoticed -- a spill in a step kernel, or a larger one here, is still a failure
+SMALL_SPILLS_THAT_PAID = {("Leaper", True): 32, ("FruitBot", True): 192, ("Jumper", True): 16}
 
 
 def _scratch_bytes(game, tmp):
@@ -45,6 +50,11 @@ def test_kernels_use_no_scratch_memory(tmp_path):
                 # off the hot path: jumper's compass under render_human flattens cubics and subdivides them with small
                 # stacks indexed at run time (pg_qtpath.h flatten, pg_aapath.h CosmeticAA::cubic), which live in scratch
                 assert size <= 2048, f"{game}: {kernel} uses {size} B of scratch per lane"
+                continue
+            if (game, "render" in kernel and "render_human" not in kernel and "Lb0" in kernel) in SMALL_SPILLS_THAT_PAID:
+                # a four-wave occupancy hint (RENDER_MIN_WAVES = 4) that spills a few dwords and still measured faster on the device
+                limit = SMALL_SPILLS_THAT_PAID[(game, True)]
+                assert size <= limit, f"{game}: {kernel} uses {size} B of scratch per lane (allowed: {limit})"
                 continue
             assert size == 0, f"{game}: {kernel} uses {size} B of scratch per lane"
     shutil.rmtree(str(tmp_path), ignore_errors=True)

@@ -19,12 +19,13 @@ python bench.py --no-cpu-baseline 2>gpurun_out/${TAG}_bench.err | tail -1 > gpur
 for oc in 0 1; do for ch in 2 4 8; do
   PROCGEN_AMD_OBS_CHUNK_COPY=$oc PROCGEN_AMD_CHUNKS=$ch python bench.py --host-landed --steps 30 --warmup 5 --steady-warmup 0 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('obs_chunk_copy=$oc chunks=$ch', round(d['value']/1e6,3), 'M steps/s host-landed,', d['ms_per_step'], 'ms/step')"
 done; done 2>&1 | tee gpurun_out/${TAG}_host_landed_ab.txt
-# ---- 3 render order
-if [ -n "$RENDER_ORDER_K" ]; then
-  for k in 0 $RENDER_ORDER_K; do
-    PROCGEN_AMD_RENDER_ORDER=$k python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('render_order=$k', round(d['value']/1e6,2), 'M', d['ms_per_step'], 'ms/step, kernels', d['roofline']['kernel_ms_per_step'], 'render', d['roofline'].get('dominant_kernel',{}).get('avg_us'))"
-  done 2>&1 | tee gpurun_out/${TAG}_render_order_bench.txt
-fi
+# same-box A/B against the round-4 library (is the 1 % the first call saw gone with the host-mapped error record?)
+[ -f procgen_amd/csrc/build_r04/libenv.so ] && timeout 300 python tools/gpu/ab_bench.py procgen_amd/csrc/build_r04,procgen_amd/csrc/build coinrun,bigfish,maze 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_ab_vs_r04.txt
+# ---- 3 render order, sorted on the device: same frames, device ms per step off / K=16 / K=64 after 1200 steps
+timeout 900 python tools/gpu/render_order_ab.py coinrun,climber,ninja,jumper,maze,heist,caveflyer,miner,bigfish 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_render_order_ab.txt
+# ---- 3b what the waves wait on (hardware counters)
+bash tools/gpu/stall_counters.sh ${TAG}_stall 2>&1 | tail -45
+cd $R
 # ---- 4 the suite under GPU sharing
 for i in $(seq 1 $RUNS); do
   timeout 900 python -m pytest tests -q -m gpu -n 4 2>&1 | tail -8 > gpurun_out/${TAG}_pytest_parallel_$i.log

@@ -1,4 +1,4 @@
-"""PROCGEN_AMD_RENDER_ORDER on one MI355X: (1) the frames of an ordered handle equal those of a default one, (2) what the order buys.
+"""PROCGEN_AMD_RENDER_ORDER (round 5: the counting sort runs on the device, kernels.hip render_order_*) on one MI355X: (1) the frames of an ordered handle equal those of a default one, (2) what the order buys.
 
 (1) 4096 and 12288 envs (two launch chunks), 150 steps with the order rebuilt every 16: observation CRCs, rewards and firsts against a
     default handle stepped with the same actions.
@@ -19,7 +19,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from procgen_amd import ProcgenGym3Env  # noqa: E402
 
-WARM, KS = 400, (32, 128)
+WARM, KS = 1200, (16, 64)
 
 
 def make(game, n, k):
