@@ -190,10 +190,23 @@ def main():
         env._lib.procgen_amd_kernel_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         env._lib.procgen_amd_tier_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
 
+    def render_kernel_window(acts, steps=20):
+        """the dominant kernel's own duration: events around each of its launches on the stream it is launched on, over a short window of
+        its own right behind the timed loop (four more event records per step are kept out of the timed steps)"""
+        if not single:
+            return None
+        env._lib.procgen_amd_kernel_timing(env._handle, 2, None, None)
+        for t in range(min(steps, len(acts))):
+            env.act(acts[t])
+            env.observe()
+        rinfo = (C.c_double * 2)()
+        env._lib.procgen_amd_kernel_timing(env._handle, 0, None, rinfo)
+        return [rinfo[0], rinfo[1], min(steps, len(acts))]
+
     def timed_loop(acts, warm, steps):
         """`warm` untimed steps, then exactly `steps` timed ones between two barriers; the device time of a step's kernels (HIP events
         around every libenv_act's launch sequence, procgen_amd_kernel_timing) comes from the SAME steps.  Returns (wall seconds -- MAX over
-        ranks --, device ms per step, [render ms per launch, render launches per step], episode resets seen)."""
+        ranks --, device ms per step, None, episode resets seen)."""
         for t in range(warm):
             env.act(acts[t])
             env.observe()
@@ -210,10 +223,9 @@ def main():
         dt = time.perf_counter() - t0
         if single:
             nsteps = C.c_int(0)
-            rinfo = (C.c_double * 2)()
-            kms = env._lib.procgen_amd_kernel_timing(env._handle, 0, C.byref(nsteps), rinfo)
+            kms = env._lib.procgen_amd_kernel_timing(env._handle, 0, C.byref(nsteps), None)
             assert nsteps.value == steps, (nsteps.value, steps)
-            render = [rinfo[0], rinfo[1]]
+            render = None
         else:  # a joint / sharded handle overlaps its parts' kernels: the wall time of the step stands in
             kms, render = dt / steps * 1e3, None
         if world > 1:
@@ -248,7 +260,8 @@ def main():
     if single:
         tiers = (C.c_int * 3)()
         env._lib.procgen_amd_tier_counts(env._handle, tiers)
-    dt, kernel_ms, render_info, resets = timed_loop(acts, args.warmup, args.steps)
+    dt, kernel_ms, _, resets = timed_loop(acts, args.warmup, args.steps)
+    render_info = render_kernel_window(acts)
     shard_crc = None
     if args.shard_crc:  # the CRC32 of this rank's last observations (its shard of the logical vector), gathered on rank 0
         import zlib
@@ -266,23 +279,24 @@ def main():
     # the same loop with the observations landed in the caller's (pinned) host array through the unmodified libenv ABI:
     # the PCIe-inclusive rate (never `value`), on a bounded number of steps
     host_landed = None
+    env.close()
     if not joint and not args.host_landed and world == 1 and D == 1:
-        env._lib.procgen_amd_set_host_observations.argtypes = [C.c_void_p, C.c_int]
-        env._lib.procgen_amd_set_host_observations(env._handle, 1)
+        # a handle made the way an unmodified gym3 caller makes it (host_observations is the default): large handles then step in four
+        # launch chunks and land each chunk's slice while the next ones still draw (libenv_hip.cpp)
+        henv = ProcgenGym3Env(n, args.game, rand_seed=23, extra_options={"device_id": device, "env_offset": rank * n})
         hl_steps = min(args.steps, 40)
+        henv.observe()
         for t in range(3):
-            env.act(acts[t])
-            env.observe()
+            henv.act(acts[t])
+            henv.observe()
         t1 = time.perf_counter()
         for t in range(hl_steps):
-            env.act(acts[t])
-            env.observe()
+            henv.act(acts[t])
+            henv.observe()
         hl_dt = time.perf_counter() - t1
+        henv.close()
         host_landed = {"value": round(n * hl_steps / hl_dt, 1), "unit": "env steps/sec", "ms_per_step": round(hl_dt / hl_steps * 1e3, 4), "steps": hl_steps,
-                       "note": "observations copied D2H into the caller's registered host array every step (libenv ABI as gym3 uses it); PCIe Gen5 x16 bounds this at ~5.1 M steps/s per GPU"}
-        env._lib.procgen_amd_set_host_observations(env._handle, 0)
-
-    env.close()
+                       "note": "a second handle made with host observations, as gym3 makes it: frames copied D2H into the caller's registered host array every step (libenv ABI unmodified), first steps after its reset; PCIe Gen5 x16 bounds this at ~5.1 M steps/s per GPU"}
 
     if rank == 0:
         # HBM bytes per launch (= one step): rocprofv3 PMC passes need their own runs (one counter set per pass), so this is the committed
@@ -317,7 +331,7 @@ def main():
             gname = KERNEL_POLICY.get(args.game, args.game)
             line["roofline"]["dominant_kernel"] = {
                 "name": f"pgamd::render<{gname}, false>", "avg_us": round(render_info[0] * 1e3, 1), "launches_per_step": round(render_info[1], 2),
-                "source": "HIP events around each launch of the kernel on the stream it is launched on, same timed steps (procgen_amd_kernel_timing); its launches overlap the step kernels of the other chunk",
+                "source": f"HIP events around each launch of the kernel on the stream it is launched on, {render_info[2]} steps right behind the timed ones (procgen_amd_kernel_timing); its launches overlap the step kernels of the other chunk",
                 "achieved_GBs_observation_write": round(12288 * n / max(render_info[1], 1e-9) / (render_info[0] * 1e-3) / 1e9, 1)}
         if pre > 0:
             line["config"]["pre_rollout_steps"] = max(pre, args.warmup + min(args.steps, 100))

@@ -75,11 +75,12 @@ LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable
 LIBENV_API double procgen_amd_time_steps(libenv_env *handle, int steps, const int32_t *actions_or_null);
 
 /* Device time of the steps of the CALLER's own libenv_act / libenv_observe loop.  enable = 1: from now on every libenv_act brackets its
- * kernels with two HIP events on the library's stream (counters reset); enable = 0: stop.  Either call returns the mean device
- * milliseconds per step of the steps timed so far and their number in *steps_out (may be NULL).  bench.py times its measured loop this
- * way, so that the device time and the wall time of a step come from the same steps.  render_out (may be NULL): [0] the mean duration in
- * milliseconds of one launch of the render kernel -- the dominant kernel -- taken from events around each of its launches on the stream
- * it is launched on, [1] its launches per step.  Single-part handles. */
+ * kernels with two HIP events on the library's stream (counters reset); enable = 2: also every launch of the render kernel -- the dominant
+ * kernel -- with two events on the stream it is launched on (four more event records per step: a short window of its own, not the timed one);
+ * enable = 0: stop.  Every call returns the mean device milliseconds per step of the steps timed since the last enabling call and their number
+ * in *steps_out (may be NULL); render_out (may be NULL): [0] the mean duration in milliseconds of one render launch, [1] its launches per
+ * step.  bench.py times its measured loop this way, so that the device time and the wall time of a step come from the same steps.
+ * Single-part handles. */
 LIBENV_API double procgen_amd_kernel_timing(libenv_env *handle, int enable, int *steps_out, double *render_out);
 
 /* How many envs of the coming step each LDS arena tier of the step kernel owns (single-part handles): out[0..2] = tier 0, 1, 2.

@@ -167,9 +167,14 @@ static std::shared_ptr<DeviceAtlas> shared_atlas(int device, const std::string &
 // by default; 0 = never (launch slot = env).  Per game, from same-box measurements (profiles/r05_render_order_*): the order cuts the render
 // kernel's HBM fetch traffic by 3-4x for the games that sample a large parallax background, at equal or slightly better speed; games whose
 // frames are cheap enough to be bandwidth-sensitive (bigfish) lose by it -- every resident frame then reads the same image.
+// Measured (profiles/r05_render_order_ab.txt, device ms per step at 65 536 envs, off -> every 16 steps): miner 1.746 -> 1.430 (+22 %),
+// climber 1.130 -> 1.119, ninja 1.272 -> 1.261, coinrun 1.239 -> 1.230, jumper 1.750 -> 1.739 (+0.6-0.9 % each, and coinrun's render FETCH_SIZE
+// 1.73 -> 0.46 GB per 8 steps' launches, L2 hit rate 61 -> 82 %); caveflyer +0.3 %; maze -1.1 %, heist -1.4 %, bigfish -37 %: off.
 static int default_render_order_period(int game_id) {
-    (void)game_id;
-    return 0;
+    switch (game_id) {
+        case GAME_COINRUN: case GAME_CLIMBER: case GAME_NINJA: case GAME_JUMPER: case GAME_MINER: return 16;
+        default: return 0;
+    }
 }
 
 // BAG:819-838 prepare_for_drawing(64): the camera scalars that depend on the frame height, for the 64-pixel observation frame (centre
@@ -234,8 +239,8 @@ struct VecGame {
         for (int c = 0; c < MAX_CHUNKS; c++) ls.outputs_done[c] = early_small ? ev_out[c] : nullptr;
         for (int c = 0; c < MAX_CHUNKS; c++) {
             ls.frames_done[c] = (obs_chunk_copy && host_observations) ? ev_frames[c] : nullptr;
-            ls.render_t0[c] = time_kernels ? tk_r0[c] : nullptr;
-            ls.render_t1[c] = time_kernels ? tk_r1[c] : nullptr;
+            ls.render_t0[c] = (time_kernels && time_render) ? tk_r0[c] : nullptr;
+            ls.render_t1[c] = (time_kernels && time_render) ? tk_r1[c] : nullptr;
         }
         ls.order = order;
         ls.first_pct = first_pct;
@@ -302,7 +307,7 @@ struct VecGame {
     void check_late_error(const char *when = "a step");
     // procgen_amd_kernel_timing: HIP events around the kernels of every libenv_act of the caller's own loop (bench.py: the device time of
     // a step and the wall time of a step then come from the SAME steps)
-    bool time_kernels = false, tk_pending = false;
+    bool time_kernels = false, time_render = false, tk_pending = false;
     hipEvent_t tk_e0 = nullptr, tk_e1 = nullptr, tk_r0[MAX_CHUNKS] = {}, tk_r1[MAX_CHUNKS] = {};
     double tk_sum_ms = 0, tk_render_ms = 0;
     int tk_steps = 0, tk_render_launches = 0;
@@ -313,6 +318,8 @@ struct VecGame {
     void act();
     void observe(bool from_api = false);
     int get_state(int env_idx, char *data, int length, bool may_not_fit = false);
+    bool load_snapshot_block(int env_idx);                              // the 256-env block of env_idx into the snapshot cache (joins the pending step)
+    bool serialize_cached(int env_idx, std::string *out, std::string *err) const;  // env_idx must lie in the cached block; touches no shared state (callable from several threads)
     void set_state(int env_idx, const char *data, int length);
     void snapshot(int env_idx, EnvSnapshot *s, bool single = false);
     static constexpr int SNAP_BLOCK = 256;
@@ -325,6 +332,7 @@ struct VecGame {
     bool route_mirror_valid = false, route_dirty = false;
     int env_offset = 0;
     int env_stride = 1;
+    std::vector<int> game_n;  // Game::game_n of every env: its global index (reference src/vecgame.cpp:317) until a set_state adopts another (src/game.cpp:253)
 };
 
 VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int stride, int index, int forced_device) {
@@ -493,16 +501,22 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
             early_small = true;
         }
     }
-    if (num_envs >= 4096) {
+    // Handles that land their observations on the host (the unmodified ABI) are bound by the 805 MB copy, not by the kernels: four launch
+    // chunks -- each chunk's slice copied on a stream of its own while the next chunks step and draw -- measured 15.09 ms per step against
+    // 15.42 with two chunks and one copy behind the step (65 536 envs, profiles/r05_host_landed_ab.txt; two chunks with per-chunk copies:
+    // 15.63, eight: 15.30).  Device-resident handles keep two chunks (more cost the kernels 15 %) and no such stream.
+    {
         const char *oc = getenv("PROCGEN_AMD_OBS_CHUNK_COPY");
-        if (!(oc && atoi(oc) == 0) && !getenv("PROCGEN_AMD_DEBUG")) {
+        const bool want = host_observations && num_envs >= 32768 && !(oc && atoi(oc) == 0) && !getenv("PROCGEN_AMD_DEBUG");
+        if (want) chunks = 4;
+        if (const char *c = getenv("PROCGEN_AMD_CHUNKS")) chunks = atoi(c) > 0 ? (atoi(c) < MAX_CHUNKS ? atoi(c) : MAX_CHUNKS) : 1;
+        if ((want || (oc && atoi(oc) != 0 && num_envs >= 4096)) && chunks >= 3) {  // (with two chunks one copy behind the whole step is the faster form)
             HIP_CHECK(hipStreamCreateWithFlags(&obs_stream, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&ev_obs, hipEventDisableTiming));
             for (int c = 0; c < MAX_CHUNKS; c++) HIP_CHECK(hipEventCreateWithFlags(&ev_frames[c], hipEventDisableTiming));
             obs_chunk_copy = true;
         }
     }
-    if (const char *c = getenv("PROCGEN_AMD_CHUNKS")) chunks = atoi(c) > 0 ? (atoi(c) < MAX_CHUNKS ? atoi(c) : MAX_CHUNKS) : 1;
     d.chunk_envs = chunk_envs_for(num_envs, 1);  // one list chunk (see DevCtx::big_list)
 
     // assets: baked pack next to the library (procgen_amd/data/<game>.atlas) or the PNG tree at resource_root
@@ -545,6 +559,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         HIP_CHECK(hipMemcpy(d.hdr, hdr.data(), N * sizeof(EnvHdr), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d.rng, rng.data(), rng.size() * 4, hipMemcpyHostToDevice));
     }
+    game_n.resize(N);
+    for (size_t i = 0; i < N; i++) game_n[i] = env_offset + (int)i * env_stride;
     d_action = dev_alloc<int32_t>(N);
     d.action = d_action;
     d.obs = dev_alloc<uint8_t>(N * OBS_BYTES);
@@ -964,7 +980,7 @@ void VecGame::observe(bool from_api) {  // reference src/vecgame.cpp:363-376,416
         tk_sum_ms += ms;
         tk_steps++;
         const int nchunk = num_envs < 4096 ? 1 : (chunks > 1 ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1);  // (the render launches of launch_game)
-        for (int c = 0; c < nchunk; c++) {
+        for (int c = 0; c < nchunk && time_render; c++) {
             if (hipEventElapsedTime(&ms, tk_r0[c], tk_r1[c]) == hipSuccess) {
                 tk_render_ms += ms;
                 tk_render_launches++;
@@ -1015,6 +1031,37 @@ void VecGame::snapshot(int e, EnvSnapshot *s, bool single) {
     s->grid.assign(snap_grid.begin() + k * grid_b, snap_grid.begin() + (k + 1) * grid_b);
 }
 
+bool VecGame::load_snapshot_block(int e) {
+    if (d.opt.use_generated_assets) fatal("fassert failed '!options.use_generated_assets' (BasicAbstractGame::serialize)\n");  // BAG:1176
+    if (!buffers_set) fatal("get_state called before libenv_set_buffers\n");
+    if (e < 0 || e >= num_envs) fatal("get_state: env index %d out of range\n", e);
+    use_device();
+    observe();
+    EnvSnapshot s;
+    snapshot(e, &s);  // (fills the cache; the copy into s is what a lone get_state would use)
+    return true;
+}
+bool VecGame::serialize_cached(int e, std::string *out, std::string *err) const {
+    if (!(snap_first >= 0 && e >= snap_first && e < snap_first + snap_count)) {
+        if (err) *err = "serialize_cached: env outside the cached block";
+        return false;
+    }
+    const size_t ents_w = (size_t)EF_COUNT * d.ent_cap, rng_w = 2 * MT_STRIDE, grid_b = (size_t)d.grid_bytes;
+    const size_t k = (size_t)(e - snap_first);
+    EnvSnapshot s;
+    s.ent_cap = d.ent_cap;
+    s.hdr = snap_hdr[k];
+    s.ents.assign(snap_ents.begin() + k * ents_w, snap_ents.begin() + (k + 1) * ents_w);
+    s.rng.assign(snap_rng.begin() + k * rng_w, snap_rng.begin() + (k + 1) * rng_w);
+    s.grid.assign(snap_grid.begin() + k * grid_b, snap_grid.begin() + (k + 1) * grid_b);
+    if (render_human && !api_observed) camera_scalars_of_the_observation_frame(&s.hdr);
+    out->resize(1 << 20);  // the reference's MAX_STATE_SIZE (procgen/env.py:20)
+    int written = 0;
+    if (!serialize_state(game_id, d.opt, game_n[e], s, &(*out)[0], (int)out->size(), &written, err)) return false;
+    out->resize((size_t)written);
+    return true;
+}
+
 // may_not_fit: a buffer too small for the state returns -1 instead of ending the process (procgen_amd_get_states packs states back to back)
 int VecGame::get_state(int e, char *data, int length, bool may_not_fit) {  // reference src/vecgame.cpp:438-445
     if (d.opt.use_generated_assets) fatal("fassert failed '!options.use_generated_assets' (BasicAbstractGame::serialize)\n");  // BAG:1176
@@ -1030,7 +1077,7 @@ int VecGame::get_state(int e, char *data, int length, bool may_not_fit) {  // re
     if (render_human && !api_observed) camera_scalars_of_the_observation_frame(&s.hdr);
     int written = 0;
     std::string err;
-    if (!serialize_state(game_id, d.opt, env_offset + e * env_stride, s, data, length, &written, &err)) {
+    if (!serialize_state(game_id, d.opt, game_n[e], s, data, length, &written, &err)) {
         if (may_not_fit) return -1;
         fatal("%s\n", err.c_str());
     }
@@ -1046,7 +1093,9 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     EnvSnapshot s;
     snapshot(e, &s, true);  // fields the wire format does not carry keep their current values
     std::string err;
-    if (!deserialize_state(game_id, d.opt, &s, data, length, &err)) fatal("%s\n", err.c_str());
+    int saved_game_n = game_n[e];
+    if (!deserialize_state(game_id, d.opt, &s, data, length, &err, &saved_game_n)) fatal("%s\n", err.c_str());
+    game_n[e] = saved_game_n;  // (Game::game_n is adopted from the state, reference src/game.cpp:253, and written back by get_state; nothing on the device reads it)
     // routing: the restored env takes a wave = env kernel for one step (conservative bound: a step at most doubles the
     // table); the lists the next step walks are rebuilt from the host's copy of the route table before the next launch,
     // so restoring the same env several times, in any tier order, leaves exactly one entry for it
@@ -1400,16 +1449,47 @@ LIBENV_API int procgen_amd_get_states(libenv_env *handle, int first, int count, 
     if (first < 0 || count < 0 || first + count > h->num_envs) fatal("procgen_amd_get_states: envs [%d, %d) out of range\n", first, first + count);
     long long off = 0;
     offsets[0] = 0;
-    for (int k = 0; k < count; k++) {
-        const int e = first + k;
-        const long long room = capacity - off;
-        const int n = h->parts[h->map.part_of(e)]->get_state(h->map.index_in_part(e), data + off, room > 0x7fffffffLL ? 0x7fffffff : (int)room, true);
-        if (n < 0) {
-            if (k == 0) fatal("procgen_amd_get_states: %lld bytes do not hold one state\n", capacity);
-            return k;
+    // Runs of consecutive envs that share a part and a snapshot block (single-part handles: up to 256 envs) are serialized by several host
+    // threads at once out of the block's cached device state -- the byte streams are built field by field (16 KB of grid ints, 5 KB of
+    // generator state, 124 B per entity: ~40 KB per coinrun env), which one thread does at ~10 k states/s.
+    int k = 0;
+    while (k < count) {
+        const int e0 = first + k;
+        VecGame *v = h->parts[h->map.part_of(e0)].get();
+        const int i0 = h->map.index_in_part(e0);
+        v->load_snapshot_block(i0);
+        int run = 1;
+        while (k + run < count && h->map.part_of(first + k + run) == h->map.part_of(e0) && h->map.index_in_part(first + k + run) == i0 + run &&
+               (i0 + run) / VecGame::SNAP_BLOCK == i0 / VecGame::SNAP_BLOCK)
+            run++;
+        std::vector<std::string> out((size_t)run), errs((size_t)run);
+        std::vector<char> ok((size_t)run, 1);
+        int threads = (int)std::thread::hardware_concurrency();
+        threads = threads > 16 ? 16 : (threads < 1 ? 1 : threads);
+        if (threads > run / 8) threads = run / 8 > 0 ? run / 8 : 1;
+        auto work = [&](int t) {
+            for (int j = t; j < run; j += threads) ok[(size_t)j] = v->serialize_cached(i0 + j, &out[(size_t)j], &errs[(size_t)j]) ? 1 : 0;
+        };
+        if (threads <= 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < threads; t++) pool.emplace_back(work, t);
+            work(0);
+            for (auto &th : pool) th.join();
         }
-        off += n;
-        offsets[k + 1] = off;
+        for (int j = 0; j < run; j++) {
+            if (!ok[(size_t)j]) fatal("%s\n", errs[(size_t)j].c_str());
+            const long long n = (long long)out[(size_t)j].size();
+            if (off + n > capacity) {
+                if (k + j == 0) fatal("procgen_amd_get_states: %lld bytes do not hold one state\n", capacity);
+                return k + j;
+            }
+            memcpy(data + off, out[(size_t)j].data(), (size_t)n);
+            off += n;
+            offsets[k + j + 1] = off;
+        }
+        k += run;
     }
     return count;
 }
@@ -1480,6 +1560,7 @@ LIBENV_API double procgen_amd_kernel_timing(libenv_env *handle, int enable, int 
         v->tk_steps = v->tk_render_launches = 0;
     }
     v->time_kernels = enable != 0;
+    v->time_render = enable == 2;
     return mean;
 }
 LIBENV_API int procgen_amd_tier_counts(libenv_env *handle, int *out) {

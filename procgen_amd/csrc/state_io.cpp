@@ -387,7 +387,7 @@ bool serialize_state(int game_id, const GameOptions &handle_opt, int game_n, con
     return true;
 }
 
-bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, const char *data, int length, std::string *err) {
+bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, const char *data, int length, std::string *err, int *game_n_out) {
     Reader r{data, 0, (size_t)(length < 0 ? 0 : length)};
     EnvHdr &h = s->hdr;
     auto bad = [&](const char *what) {
@@ -431,7 +431,10 @@ bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, cons
     // RandGen::randint src/randgen.cpp:6-11 called from src/game.cpp:101 -- a zero range ends the process there (SIGFPE; here the device-side
     // check of game_reset_full), a negative one wraps in unsigned arithmetic, which the kernels' draw restates)
     r.i();  // game_type
-    r.i();  // game_n
+    {
+        const int saved_game_n = r.i();  // game_n: adopted (reference src/game.cpp:253); it only names the env in a warning there, but get_state writes it back
+        if (game_n_out) *game_n_out = saved_game_n;
+    }
     int seeded;
     if (!read_rng(r, &seeded, s->rng.data() + MT_STRIDE, &h.lvl_rand_idx)) return bad("set_state: malformed level_seed_rand_gen");
     if (!read_rng(r, &seeded, s->rng.data(), &h.rand_idx)) return bad("set_state: malformed rand_gen");

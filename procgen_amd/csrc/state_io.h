@@ -21,6 +21,7 @@ struct EnvSnapshot {  // host copy of one env's device state
 // Serializes into the reference's byte stream. Returns false (with *err) when the buffer is too small.
 bool serialize_state(int game_id, const GameOptions &opt, int game_n, const EnvSnapshot &s, char *data, int length, int *written, std::string *err);
 // Parses a reference byte stream into the snapshot (sizes of s.ents / s.rng / s.grid must be pre-set).
-bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, const char *data, int length, std::string *err);
+// game_n_out (may be null): the env index the state was saved at -- the reference adopts it (src/game.cpp:253) and writes it back in get_state
+bool deserialize_state(int game_id, const GameOptions &opt, EnvSnapshot *s, const char *data, int length, std::string *err, int *game_n_out = nullptr);
 
 }  // namespace pgamd

@@ -119,8 +119,8 @@ class BaseProcgenEnv(CEnv):
             want = min(block, self.num - first)
             got = fn(self._handle, first, want, buf.ctypes.data, cap, offs.ctypes.data)
             assert got >= 1
-            raw = buf[: offs[got]].tobytes()
-            result.extend(raw[offs[k]:offs[k + 1]] for k in range(got))
+            mv = memoryview(buf)
+            result.extend(bytes(mv[offs[k]:offs[k + 1]]) for k in range(got))
             first += got
         return result
 

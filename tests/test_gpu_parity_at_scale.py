@@ -88,6 +88,31 @@ def test_sixteen_game_joint_handle_at_its_one_gpu_share():
         assert_rollouts_equal(ref, got, f"joint handle, {game}")
 
 
+def test_host_landed_observations_of_a_large_handle_arrive_chunk_by_chunk():
+    """A handle of >= 32768 envs made with host observations (the gym3 default) steps in four launch chunks and lands every chunk's slice
+    of the caller's array on a copy stream of its own, behind that chunk's render kernel (libenv_hip.cpp VecGame::launch).  Every
+    frame the caller sees must be the frame in the device buffer, and the first 128 envs must be the oracle's."""
+    n, m, steps = 32768, 128, 12
+    env = make_env(n, "coinrun")
+    b = DeviceBuffers()
+    env._lib.procgen_amd_device_buffers.argtypes = [C.c_void_p, C.POINTER(DeviceBuffers)]
+    assert env._lib.procgen_amd_device_buffers(env._handle, C.byref(b)) == 0 and b.num_envs == n
+    orc = oracle_env.OracleEnv(m, "coinrun", rand_seed=23)
+    rng = np.random.RandomState(5)
+    for t in range(steps + 1):
+        rew, ob, first = env.observe()
+        orew, oob, ofirst = orc.observe()
+        dev = hip_memcpy_dtoh(b.ob, n * 12288).reshape(n, 64, 64, 3)
+        assert np.array_equal(ob["rgb"], dev), f"step {t}: host array differs from the device buffer in envs {np.nonzero((ob['rgb'] != dev).reshape(n, -1).any(axis=1))[0][:8]}"
+        assert np.array_equal(ob["rgb"][:m], oob["rgb"]) and np.array_equal(rew[:m], orew) and np.array_equal(first[:m], ofirst), f"step {t}"
+        if t < steps:
+            ac = rng.randint(0, 15, size=(n,), dtype=np.int32)
+            env.act(ac)
+            orc.act(ac[:m])
+    env.close()
+    orc.close()
+
+
 def test_sixteen_games_over_eight_device_shards(monkeypatch):
     """BASELINE configs[4] in its whole shape on the one GPU there is: ONE handle, num_devices = 8 x 16 games = 128 parts (each a
     VecGame with its own stream and 128 envs), PROCGEN_AMD_FAKE_DEVICES mapping the eight shards onto the visible device(s).  Device g

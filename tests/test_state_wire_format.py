@@ -174,7 +174,41 @@ def test_gpu_states_of_another_distribution_mode_are_refused_with_the_reason(gol
     # reference does (its per-Game MazeGen keeps the first reset's dimension, chaser.cpp:159-162; grid.h:41 fassert)
     code = ("import sys; sys.path.insert(0, %r); import numpy as np; from procgen_amd import ProcgenGym3Env; "
             "a = ProcgenGym3Env(1, 'chaser', distribution_mode='extreme'); a.observe(); st = a.get_state(); "
-            "b = ProcgenGym3Env(1, 'chaser', distribution_mode='hard'); b.observe(); b.set_state(st); b.observe(); print('restored'); "
-            "b.act(np.array([-1], dtype=np.int32)); b.observe(); print('survived')") % repo
+            "b = ProcgenGym3Env(1, 'chaser', distribution_mode='hard'); b.observe(); b.set_state(st); b.observe(); print('restored', flush=True); "
+            "b.act(np.array([-1], dtype=np.int32)); b.observe(); print('survived', flush=True)") % repo
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "restored" in r.stdout and "survived" not in r.stdout and "device-side check failed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_gpu_states_restored_at_other_indices_come_back_byte_for_byte():
+    """reference src/game.cpp:193,253: game_n -- the env's index -- is part of the stream, adopted by deserialize and written back by
+    serialize (it only names the env in a warning).  States restored at OTHER indices than they were saved at therefore come back from
+    get_state unchanged (checked on the compiled reference: after set_state([st[1], st[0]]) its get_state returns [st[1], st[0]])."""
+    from procgen_amd import ProcgenGym3Env
+
+    n = 6
+    env = ProcgenGym3Env(n, "coinrun", rand_seed=5)
+    rng = np.random.RandomState(2)
+    for _ in range(7):
+        env.act(rng.randint(0, 15, size=(n,), dtype=np.int32))
+    env.observe()
+    st = env.get_state()
+    assert len(set(st)) == n
+    perm = [3, 0, 5, 1, 2, 4]
+    env.set_state([st[p] for p in perm])
+    assert env.get_state() == [st[p] for p in perm]
+    # ... and the restored envs go on exactly like the envs the states came from
+    twin = ProcgenGym3Env(n, "coinrun", rand_seed=5)
+    rng = np.random.RandomState(2)
+    for _ in range(7):
+        twin.act(rng.randint(0, 15, size=(n,), dtype=np.int32))
+    for _ in range(12):
+        a = rng.randint(0, 15, size=(n,), dtype=np.int32)
+        twin.act(a)
+        env.act(a[perm])
+        _, ob_t, _ = twin.observe()
+        _, ob_e, _ = env.observe()
+        assert np.array_equal(ob_e["rgb"], ob_t["rgb"][perm])
+    env.close()
+    twin.close()

@@ -30,7 +30,7 @@ kb = 1024.0
 raw = (r["FETCH_SIZE"] + r["WRITE_SIZE"] + s0["FETCH_SIZE"] + s0["WRITE_SIZE"] + l1["FETCH_SIZE"] + l1["WRITE_SIZE"] + l2["FETCH_SIZE"] + l2["WRITE_SIZE"]) * kb
 upper = raw + (r["FETCH_SIZE"] + s0["FETCH_SIZE"] + l1["FETCH_SIZE"] + l2["FETCH_SIZE"]) * kb
 doc = {
-    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum (separate passes, tools/gpu/r4_final.sh: steady state, 1500 warm-up steps, 8 profiled steps), coinrun num_envs={n}; raw per-kernel sums in the <tag>_pmc_*.csv files (profiles/); computed by tools/gpu/make_traffic_json.py",
+    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum (separate passes, tools/gpu/r5_final.sh: the default bench.py command, i.e. averaged over its 1500-step pre-rollout and the timed steps), coinrun num_envs={n}; raw per-kernel sums in the <tag>_pmc_*.csv files (profiles/); computed by tools/gpu/make_traffic_json.py",
     "units": "KB (rocprofv3 FETCH_SIZE / WRITE_SIZE are in KB) per STEP = both chunk launches of step_tier0 and render; list kernels per launch",
     "render_per_step": {"FETCH_SIZE_KB": r["FETCH_SIZE"], "WRITE_SIZE_KB": r["WRITE_SIZE"], "TCC_HIT": r["TCC_HIT_sum"], "TCC_MISS": r["TCC_MISS_sum"]},
     "step_tier0_per_step": {"FETCH_SIZE_KB": s0["FETCH_SIZE"], "WRITE_SIZE_KB": s0["WRITE_SIZE"], "TCC_HIT": s0["TCC_HIT_sum"], "TCC_MISS": s0["TCC_MISS_sum"]},

@@ -22,5 +22,6 @@ for e in range(m):
     env.call_c_func("set_state", e, st[(e + 1) % n], len(st[(e + 1) % n]))
 t1 = time.perf_counter()
 print(f"{game} N={n}: set_state of {m} envs {t1 - t0:.2f} s ({m / (t1 - t0):.0f} states/s)", flush=True)
-assert env.get_state()[:m] == [st[(e + 1) % n] for e in range(m)]
+got = env.get_state()[:m]
+assert got == [st[(e + 1) % n] for e in range(m)], "states restored at other indices must come back byte for byte (game_n is adopted, reference src/game.cpp:253)"
 env.close()
