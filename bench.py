@@ -261,7 +261,6 @@ def main():
         tiers = (C.c_int * 3)()
         env._lib.procgen_amd_tier_counts(env._handle, tiers)
     dt, kernel_ms, _, resets = timed_loop(acts, args.warmup, args.steps)
-    render_info = render_kernel_window(acts)
     shard_crc = None
     if args.shard_crc:  # the CRC32 of this rank's last observations (its shard of the logical vector), gathered on rank 0
         import zlib
@@ -276,6 +275,7 @@ def main():
         else:
             shard_crc = mine
 
+    render_info = render_kernel_window(acts)  # (behind the CRCs of the timed loop's last observations)
     # the same loop with the observations landed in the caller's (pinned) host array through the unmodified libenv ABI:
     # the PCIe-inclusive rate (never `value`), on a bounded number of steps
     host_landed = None

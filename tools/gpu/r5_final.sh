@@ -28,3 +28,7 @@ for g in coinrun bigfish maze climber miner starpilot fruitbot leaper plunder he
 python bench.py --game all16 --num-envs 16384 --steps 100 --warmup 20 --no-cpu-baseline --steady-warmup 0 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_all16_joint_16384.json; cut -c1-220 gpurun_out/${TAG}_bench_all16_joint_16384.json
 python bench.py --game bigfish --steps 150 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_bigfish_65536.json; cut -c1-200 gpurun_out/${TAG}_bench_bigfish_65536.json
 python bench.py --game starpilot --num-envs 32768 --steps 150 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_starpilot_32768.json; cut -c1-200 gpurun_out/${TAG}_bench_starpilot_32768.json
+# one more run of the suite with four workers sharing the GPU (the eleventh of the round), fatal log kept
+export PROCGEN_AMD_FATAL_LOG=$R/gpurun_out/${TAG}_fatal.log
+timeout 900 python -m pytest tests -q -m gpu -n 4 2>&1 | tail -4 | tee gpurun_out/${TAG}_pytest_parallel.log
+grep "fatal:" $PROCGEN_AMD_FATAL_LOG | cut -c1-150 | sed 's/\[pid [0-9]*\] //' | sort | uniq -c
