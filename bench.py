@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--game", default="coinrun")
     ap.add_argument("--host-landed", action="store_true", help="also land observations on the host (PCIe-inclusive rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-landed", action="store_true", help="skip the host_landed leg (profiling runs: its handle's launches would mix into the per-kernel averages)")
     ap.add_argument("--devices-in-process", type=int, default=1,
                     help="single-process mode: ONE libenv handle of devices x num-envs envs sharded over that many GPUs of this process (num_devices option; no torch.distributed)")
     ap.add_argument("--steady-warmup", type=int, default=1500, help="untimed pre-rollout before the W warm-up and K timed steps (0: measure the cold start, as rounds 1-4 did)")
@@ -280,7 +281,7 @@ def main():
     # the PCIe-inclusive rate (never `value`), on a bounded number of steps
     host_landed = None
     env.close()
-    if not joint and not args.host_landed and world == 1 and D == 1:
+    if not joint and not args.host_landed and not args.no_host_landed and world == 1 and D == 1:
         # a handle made the way an unmodified gym3 caller makes it (host_observations is the default): large handles then step in four
         # launch chunks and land each chunk's slice while the next ones still draw (libenv_hip.cpp)
         henv = ProcgenGym3Env(n, args.game, rand_seed=23, extra_options={"device_id": device, "env_offset": rank * n})

@@ -1352,9 +1352,12 @@ LIBENV_API libenv_env *libenv_make(int num_envs, const struct libenv_options opt
                 fprintf(stderr, "procgen_amd: %d parts on %s hardware queues: set GPU_MAX_HW_QUEUES=16 before the process's first HIP call (INTEGRATION.md section 5) for ~1.5x on joint handles\n", h->P(), q ? q : "the default 4");
             }
         }
-        // issuing threads: one per part up to the host's cores (a 16-game x 8-device handle has 128 parts, ~10 runtime calls each per
-        // step), at most 32 -- the runtime serialises calls per device, more threads than that only contend
-        int threads = h->P();
+        // issuing threads: the runtime serialises calls per device, so more threads than ~8 per device only contend (the 16 parts of a
+        // one-device joint handle: 16.4 M steps/s with 8 threads, 15.9 with 16, 16.2 with 4 -- profiles/r05_joint_threads_ab.txt); a handle
+        // over G devices gets 2 per device more, up to the host's cores and 32
+        int threads = 8;
+        if (num_devices > 1) threads += 2 * num_devices;
+        if (threads > h->P()) threads = h->P();
         const int cores = (int)std::thread::hardware_concurrency();
         if (cores > 0 && threads > cores) threads = cores;
         if (threads > 32) threads = 32;
