@@ -507,7 +507,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     // 15.63, eight: 15.30).  Device-resident handles keep two chunks (more cost the kernels 15 %) and no such stream.
     {
         const char *oc = getenv("PROCGEN_AMD_OBS_CHUNK_COPY");
-        const bool want = host_observations && num_envs >= 32768 && !(oc && atoi(oc) == 0) && !getenv("PROCGEN_AMD_DEBUG");
+        // (not for the split-reset games: their four-chunk reset lists have only ever been measured and tested with two chunks)
+        const bool want = host_observations && num_envs >= 32768 && !(oc && atoi(oc) == 0) && !getenv("PROCGEN_AMD_DEBUG") && !game_split_reset(kernel_id);
         if (want) chunks = 4;
         if (const char *c = getenv("PROCGEN_AMD_CHUNKS")) chunks = atoi(c) > 0 ? (atoi(c) < MAX_CHUNKS ? atoi(c) : MAX_CHUNKS) : 1;
         if ((want || (oc && atoi(oc) != 0 && num_envs >= 4096)) && chunks >= 3) {  // (with two chunks one copy behind the whole step is the faster form)
