@@ -88,6 +88,19 @@ LIBENV_API double procgen_amd_kernel_timing(libenv_env *handle, int enable, int 
  * horizon of a rollout (trails, spawned objects), which is why bench.py's steady_state object reports it.  Returns num_envs. */
 LIBENV_API int procgen_amd_tier_counts(libenv_env *handle, int *out);
 
+/* The render kernel's launch order (every few steps a counting sort on the device re-maps the render workgroups to envs
+ * by background image, per launch chunk).  out[slot] = the env workgroup `slot` draws; returns the entries written (num_envs), 0 when the
+ * handle launches in env order or max_envs is too small.  chunk_out (may be NULL): [0] = envs of the first launch chunk, [1] = launch chunks.
+ * Single-part handles.  selftest_render_order_slots (host only, no device): out[p] = the launch slot of sorted position p within a chunk of
+ * `count` envs -- a permutation of [0, count) for every count. */
+LIBENV_API int procgen_amd_render_order(libenv_env *handle, int *out, int max_envs, int *chunk_out);
+LIBENV_API void procgen_amd_selftest_render_order_slots(int count, int *out);
+
+/* Display-list games (the frame is drawn by prep -> raster kernels, and by the full renderer for the frames the short
+ * path cannot draw).  out[0] = envs whose current frame came from its record, out[1] = envs whose frame the full renderer drew.  Returns 1,
+ * or 0 for a handle that renders with one kernel (out untouched).  Single-part handles. */
+LIBENV_API int procgen_amd_display_list_frames(libenv_env *handle, int *out);
+
 /* Device math self-tests (no handle, current HIP device; host pointers in and out): the exact device functions the game
  * kernels call, over caller-chosen inputs, so that a test can sweep a whole input domain against the host libm.
  *   bigfish_radius: out[i] = the fish radius bigfish computes from the rand01() draw r01[i] (pow, reference

@@ -6,6 +6,7 @@
 #include "pg_bgpaint.h"
 #include "pg_env.h"
 #include "pg_math.h"
+#include "shard_map.h"
 #include "wave.h"
 
 namespace pgamd {
@@ -72,6 +73,10 @@ bool game_split_reset(int game_id) {
     const GameEntry *e = find(game_id);
     return e ? e->split_reset : false;
 }
+int game_frame_rec_words(int game_id) {
+    const GameEntry *e = find(game_id);
+    return e ? e->frame_rec_words : 0;
+}
 bool (*game_use_block_asset(int game_id))(int) {
     const GameEntry *e = find(game_id);
     return e ? e->use_block_asset : nullptr;
@@ -101,8 +106,8 @@ hipError_t launch_paint_backgrounds(const DevCtx &d, int env_base, int count, hi
 
 // ---- launch order of the render kernel by background image (PROCGEN_AMD_RENDER_ORDER; libenv_hip.cpp VecGame::rebuild_render_order) ----
 // A counting sort of one launch chunk's envs [base, base + count) by EnvHdr::background_index, on the device: histogram, exclusive scan,
-// scatter.  Sorted position p goes to launch slot (p mod count/8) * 8 + p / (count/8): workgroup j of a launch runs on XCD j mod 8, each
-// XCD has its own L2, so XCD x draws the x-th eighth of the sorted sequence -- a few images, one after the other -- instead of all 62
+// scatter.  Sorted position p goes to launch slot render_order_slot(p, count) (shard_map.h): workgroup j of a launch runs on XCD j mod 8,
+// each XCD has its own L2, so XCD x draws the x-th eighth of the sorted sequence -- a few images, one after the other -- instead of all 62
 // at once.  The order within an image is whatever the atomics give: envs are independent, any permutation draws the same frames.
 constexpr int RO_BINS = MAX_BACKGROUNDS;
 __global__ __launch_bounds__(256) void render_order_hist(const EnvHdr *hdr, int base, int count, int *hist) {
@@ -144,9 +149,7 @@ __global__ __launch_bounds__(256) void render_order_scatter(const EnvHdr *hdr, i
     __syncthreads();
     if (i < count) {
         const int p = start[b] + local;
-        const int per = count >> 3;  // (launch chunks are multiples of 64 envs)
-        const int slot = per > 0 ? (p % per) * 8 + p / per : p;
-        order[base + slot] = base + i;
+        order[base + render_order_slot(p, count)] = base + i;  // (shard_map.h: a bijection for any count)
     }
 }
 hipError_t launch_render_order(const DevCtx &d, int base, int count, int *scratch, int *order, hipStream_t stream) {

@@ -13,6 +13,7 @@
 
 #include "games.h"
 #include "pg_render.h"
+#include "pg_prep.h"
 #include "pg_human.h"
 #include "kernels.h"
 
@@ -21,7 +22,7 @@ namespace pgamd {
 // profiling aid (PROCGEN_AMD_DEBUG & 8192): when was this env's workgroup resident, and where.  Per env 32 words:
 // [0] step start, [1] step end (100 MHz clock), [2] kernel kind << 32 | HW_ID; [3] first; [4], [5], [6] the same for the render kernel; [8..23] this step's phase cycles (with & 2048)
 __device__ inline void trace_wave(const DevCtx &d, int env, int base, bool end, int kind) {
-    if (d.wave_trace && threadIdx.x == 0) {
+    if (PG_TRACE(d) && threadIdx.x == 0) {
         unsigned long long *t = d.wave_trace + (size_t)env * 32 + base;
         if (end) {
             t[1] = wall_clock64();
@@ -118,12 +119,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GEN ? 1 : Ga
     r.render_env();
     if (PG_RENDER_TRACE) trace_wave(d, env, 4, true, 8);
 }
+// ---- display-list games (pg_prep.h): prep -> raster (-> render_list for the frames the rasterizer's short path cannot draw) ----
+template <class Game>
+__global__ __launch_bounds__(64) void prep(DevCtx d, int env_base, int count, int chunk) {
+    __shared__ RenderLdsT<Game> lds;
+    const int env0 = env_base + (int)blockIdx.x * PREP_ENVS;
+    const int left = env_base + count - env0;
+    FramePrep<Game> p(d, &lds, d.slow_count + d.step_parity * MAX_CHUNKS + chunk, d.slow_list + env_base);
+    p.run(env0, left < PREP_ENVS ? left : PREP_ENVS);
+}
+template <class Game>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GameRenderMinWaves<PG_GAME>::value))) void raster(DevCtx d, int env_base, int chunk) {
+    __shared__ RenderLdsT<Game> lds;
+    if (d.clear_lists && blockIdx.x == 0 && threadIdx.x < LIST_COUNTERS) const_cast<int *>(d.big_count)[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.slow_count[(d.step_parity ^ 1) * MAX_CHUNKS + chunk] = 0;  // the next step's counter of this chunk
+    const int slot = env_base + (int)blockIdx.x;
+    const int env = d.render_order ? __builtin_amdgcn_readfirstlane(d.render_order[slot]) : slot;
+    if ((d.frame_rec[(size_t)env * FrameRec<Game>::WORDS + FrameRec<Game>::FLAGS] & FrameRec<Game>::F_FAST) == 0) return;  // on the chunk's slow list
+    Renderer<Game, false> r(d, env, &lds);
+    r.raster_env();
+}
+// (no occupancy hint: a fraction of a percent of the frames come here, and render_env inside a loop spills under coinrun's five-wave hint)
+template <class Game>
+__global__ __launch_bounds__(64) void render_list(DevCtx d, int env_base, int chunk) {
+    __shared__ RenderLdsT<Game> lds;
+    const int count = d.slow_count[d.step_parity * MAX_CHUNKS + chunk];
+    for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+        Renderer<Game, false> r(d, __builtin_amdgcn_readfirstlane(d.slow_list[env_base + k]), &lds);
+        r.render_env();
+        __syncthreads();
+    }
+}
 // clear_lists: this is the step's render of env 0 (every list kernel of the step is done when a render kernel starts); a
 // hipMemsetAsync per step instead was two fill kernels, each tens of microseconds on a busy device with many handles
 template <class Game>
-static void launch_render(const DevCtx &d0, int env_base, int count, hipStream_t st, bool clear_lists = false) {
+static void launch_render(const DevCtx &d0, int env_base, int count, hipStream_t st, bool clear_lists = false, int chunk = 0) {
     DevCtx d = d0;
     d.clear_lists = clear_lists ? 1 : 0;
+    if constexpr (GameDisplayList<Game>::value) {
+        if (d.frame_rec && !d.gen_bg) {
+            hipLaunchKernelGGL(prep<Game>, dim3((count + PREP_ENVS - 1) / PREP_ENVS), dim3(64), 0, st, d, env_base, count, chunk);
+            hipLaunchKernelGGL(raster<Game>, dim3(count), dim3(64), 0, st, d, env_base, chunk);
+            hipLaunchKernelGGL(render_list<Game>, dim3(count < 4096 ? count : 4096), dim3(64), 0, st, d, env_base, chunk);  // (workgroups past the list's end leave at once)
+            return;
+        }
+    }
     if (d.gen_bg) hipLaunchKernelGGL((render<Game, true>), dim3(count), dim3(64), 0, st, d, env_base);
     else hipLaunchKernelGGL((render<Game, false>), dim3(count), dim3(64), 0, st, d, env_base);
 }
@@ -220,7 +260,7 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         // early download of the step's small outputs waits for (libenv_hip.cpp VecGame::launch)
         if (ls.outputs_done[c]) PG_TRY(hipEventRecord(ls.outputs_done[c], st));
         if (ls.render_t0[c]) PG_TRY(hipEventRecord(ls.render_t0[c], st));
-        if (!(d.debug_flags & 16)) launch_render<Game>(d, base, count, st, c == 0);
+        if (!(d.debug_flags & 16)) launch_render<Game>(d, base, count, st, c == 0, c);
         if (ls.render_t1[c]) PG_TRY(hipEventRecord(ls.render_t1[c], st));
         if (ls.frames_done[c]) PG_TRY(hipEventRecord(ls.frames_done[c], st));
     }
@@ -250,6 +290,7 @@ template <class Game>
 static hipError_t render_one(const DevCtx &d, int env, hipStream_t stream) {  // re-renders one env (after set_state)
     DevCtx d1 = d;
     d1.render_order = nullptr;  // (env is the env itself here, not a slot of a chunk launch)
+    d1.frame_rec = nullptr;     // (and the full renderer draws it)
     launch_render<Game>(d1, env, 1, stream);
     return hipGetLastError();
 }
@@ -265,6 +306,7 @@ const GameEntry *PG_CAT(game_entry_, PG_GAME)() {
         GameBlockAsset<PG_GAME>::is,
         launch_human<PG_GAME>,
         GameSplit<PG_GAME>::value,
+        GameDisplayList<PG_GAME>::value ? FrameRec<PG_GAME>::WORDS : 0,
     };
     return &e;
 }

@@ -600,6 +600,12 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         d_render_order = dev_alloc<int>(N);  // (bound to d.render_order by the first rebuild)
         d_render_order_scratch = dev_alloc<int>(MAX_CHUNKS * MAX_BACKGROUNDS);
     }
+    // display-list games (pg_prep.h): a frame record per env, and the list of the envs whose frame the full renderer draws
+    if (const int rec_words = game_frame_rec_words(kernel_id); rec_words > 0 && !o.use_generated_assets && !(getenv("PROCGEN_AMD_DISPLAY_LIST") && atoi(getenv("PROCGEN_AMD_DISPLAY_LIST")) == 0)) {
+        d.frame_rec = dev_alloc<uint32_t>(N * (size_t)rec_words);
+        d.slow_list = dev_alloc<int>(N);
+        d.slow_count = dev_alloc<int>(2 * MAX_CHUNKS);
+    }
     d.assets = atlas->d_assets;
     d.pixels = atlas->d_pixels;
     if (this->render_human) {
@@ -701,6 +707,9 @@ VecGame::~VecGame() {
     }
     (void)hipFree(d_reset_list);
     (void)hipFree(d_reset_count);
+    if (d.frame_rec) (void)hipFree(d.frame_rec);
+    if (d.slow_list) (void)hipFree(d.slow_list);
+    if (d.slow_count) (void)hipFree(d.slow_count);
     if (d_render_order) (void)hipFree(d_render_order);
     if (d_render_order_scratch) (void)hipFree(d_render_order_scratch);
     if (h_action) (void)hipHostFree(h_action);
@@ -811,6 +820,7 @@ void VecGame::launch_kernels(int mode) {
     LaunchStreams ls = streams();
     for (int c = 0; c < MAX_CHUNKS; c++)
         for (int t = 0; t < NUM_TIERS; t++) ls.list_count[c][t] = mode == 0 ? 0 : host_list_count[c][t];
+    d.step_parity = (int)(step_count & 1);  // (display-list games: which of the two slow-list counter sets this step fills)
     HIP_CHECK(launch_step(kernel_id, d, mode, ls));
     step_count++;
 }
@@ -1566,6 +1576,45 @@ LIBENV_API double procgen_amd_kernel_timing(libenv_env *handle, int enable, int 
     v->time_kernels = enable != 0;
     v->time_render = enable == 2;
     return mean;
+}
+// the render kernel's launch order as the device holds it (single-part handles): out[slot] = env drawn by workgroup `slot`; returns the number
+// of entries written (num_envs), 0 when the handle launches in env order.  chunk_out (may be NULL): [0] envs of the first launch chunk, [1] chunks.
+LIBENV_API int procgen_amd_render_order(libenv_env *handle, int *out, int max_envs, int *chunk_out) {
+    VecGame *v = ((Handle *)handle)->single();
+    v->observe();
+    HIP_CHECK(hipSetDevice(v->device_id));
+    const int N = v->num_envs;
+    const int nchunk = N >= 4096 ? (v->chunks > 1 ? (v->chunks < MAX_CHUNKS ? v->chunks : MAX_CHUNKS) : 1) : 1;
+    const int first = (nchunk == 2 && v->first_pct > 0) ? first_chunk_envs(N, v->first_pct) : 0;
+    if (chunk_out) {
+        chunk_out[0] = first > 0 ? first : chunk_envs_for(N, nchunk);
+        chunk_out[1] = nchunk;
+    }
+    if (!v->d.render_order || max_envs < N) return 0;
+    HIP_CHECK(hipStreamSynchronize(v->stream));
+    HIP_CHECK(hipMemcpy(out, v->d.render_order, (size_t)N * sizeof(int), hipMemcpyDeviceToHost));
+    return N;
+}
+// display-list games (pg_prep.h; single-part handles): out[0] = envs whose current frame the rasterizer drew from its record, out[1] = envs
+// whose frame went to the full renderer; returns 1, or 0 when the handle renders with one kernel (then out is untouched)
+LIBENV_API int procgen_amd_display_list_frames(libenv_env *handle, int *out) {
+    VecGame *v = ((Handle *)handle)->single();
+    v->observe();
+    const int rec_words = game_frame_rec_words(v->kernel_id);
+    if (!v->d.frame_rec || rec_words <= 0) return 0;
+    HIP_CHECK(hipSetDevice(v->device_id));
+    HIP_CHECK(hipStreamSynchronize(v->stream));
+    std::vector<uint32_t> flags((size_t)v->num_envs);
+    HIP_CHECK(hipMemcpy2D(flags.data(), sizeof(uint32_t), v->d.frame_rec, (size_t)rec_words * sizeof(uint32_t), sizeof(uint32_t), (size_t)v->num_envs, hipMemcpyDeviceToHost));
+    int fast = 0;
+    for (uint32_t f : flags) fast += (int)(f & 1u);
+    out[0] = fast;
+    out[1] = v->num_envs - fast;
+    return 1;
+}
+// host only: out[p] = render_order_slot(p, count) (shard_map.h) for p in [0, count)
+LIBENV_API void procgen_amd_selftest_render_order_slots(int count, int *out) {
+    for (int p = 0; p < count; p++) out[p] = render_order_slot(p, count);
 }
 LIBENV_API int procgen_amd_tier_counts(libenv_env *handle, int *out) {
     VecGame *v = ((Handle *)handle)->single();

@@ -6,9 +6,18 @@
 #include <stddef.h>
 #include <stdint.h>
 
-// (Per-phase cycle counters of the kernels: PROCGEN_AMD_DEBUG & 2048, DevCtx::phase_cycles.  They are always compiled in: a build switch
-// that removed them was prepared in round 4 and dropped in round 5 unmeasured -- statically the register allocation moved both ways, a
-// per-kernel lottery, not a win.)
+// Profiling / ablation apparatus of the kernels (PROCGEN_AMD_DEBUG: phase cycle counters `& 2048`, the residency trace `& 8192`, the
+// ablation bits of DevCtx::debug_flags): the kernels read it through these three macros, and -DPG_RELEASE turns them into constants, so a
+// release build carries none of it (profiles/r06_release_ab.txt: the same-box A/B that decides which build __graft_entry__.build() ships).
+#if defined(PG_RELEASE)
+#define PG_DBG(d, bits) (false)
+#define PG_PHASES(d) (false)
+#define PG_TRACE(d) (false)
+#else
+#define PG_DBG(d, bits) (((d).debug_flags & (bits)) != 0)
+#define PG_PHASES(d) ((d).phase_cycles != nullptr)
+#define PG_TRACE(d) ((d).wave_trace != nullptr)
+#endif
 
 namespace pgamd {
 
@@ -255,6 +264,13 @@ struct DevCtx {
     // launch order of the render kernel (experiment, PROCGEN_AMD_RENDER_ORDER; null = identity): workgroup j of a chunk's launch draws env
     // render_order[env_base + j], a permutation of that chunk's env range sorted by background image
     const int *render_order;  // [num_envs]
+    // display-list games (pg_prep.h; null otherwise): the frame records prep<Game> writes and raster<Game> draws, and the envs of a launch
+    // chunk whose frame goes to the full renderer instead (render_list<Game>): chunk c's entries start at slow_list[its first env], their
+    // count is slow_count[step_parity * MAX_CHUNKS + c]; raster<Game> zeroes the other parity's counter for the next step
+    uint32_t *frame_rec;  // [num_envs][FrameRec<Game>::WORDS]
+    int *slow_list;       // [num_envs]
+    int *slow_count;      // [2][MAX_CHUNKS]
+    int step_parity;
     int clear_lists;       // render kernel: zero big_count[] (nobody reads it any more this step; it is the next step's next_big_count)
     unsigned long long *wave_trace;    // [num_envs][32] PROCGEN_AMD_DEBUG & 8192: 100 MHz timestamps of the last step's workgroups: step start / end / kind+HW_ID, render start / end / HW_ID (null otherwise)
     unsigned long long *phase_cycles;  // [4096][32] PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step (0-15) and render (16-31) kernels (null otherwise)

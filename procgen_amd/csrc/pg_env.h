@@ -272,10 +272,10 @@ struct Env {
     bool needs_reset = false;  // NO_RESET: this step ended the episode
     PG_DEV void phase(int k) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles) {
+        if (PG_PHASES(d)) {
             const long long t = (long long)__builtin_readcyclecounter();
             if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + k + 32 * (env & 4095), (unsigned long long)(t - t_mark));
-            if (d.wave_trace && PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.wave_trace + (size_t)env * 32 + 8 + k, (unsigned long long)(t - t_mark));  // this env, this step
+            if (PG_TRACE(d) && PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.wave_trace + (size_t)env * 32 + 8 + k, (unsigned long long)(t - t_mark));  // this env, this step
             t_mark = (long long)__builtin_readcyclecounter();
         }
 #else
@@ -286,7 +286,7 @@ struct Env {
     // profiling aid (PROCGEN_AMD_DEBUG & 8192): per-env counters of this step in the trace record (slots 24..31)
     PG_DEV void trace_add(int k, unsigned long long v) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.wave_trace && d.phase_cycles && PG_LANE_ID() == 0) d.wave_trace[(size_t)env * 32 + 24 + k] += v;
+        if (PG_TRACE(d) && PG_PHASES(d) && PG_LANE_ID() == 0) d.wave_trace[(size_t)env * 32 + 24 + k] += v;
 #else
         (void)k; (void)v;
 #endif
@@ -294,7 +294,7 @@ struct Env {
     // profiling aid for level generators (PROCGEN_AMD_DEBUG = 2048 + 16: the render kernel is off and its counter slots are free):
     // wave cycles since the previous mark / phase go to slot 16 + j; printed at libenv_close as "reset marks"
     PG_DEV void mark(int j) {
-        if (d.debug_flags & 16) phase(16 + j);
+        if PG_DBG(d, 16) phase(16 + j);
     }
     PG_DEV Env(const DevCtx &d_, int env_, LdsT *s_) : d(d_), env(env_), s(s_) {
         rg_home = d.rng + (size_t)env * MT_SLOTS * MT_STRIDE;
@@ -770,10 +770,10 @@ struct Env {
                 // (sub_step's axis is `_vx != 0`: a zero horizontal displacement is a vertical call)
                 const bool axis_h = t_vx != 0;
                 const float disp = axis_h ? t_vx : t_vy;
-                if ((d.debug_flags & 65536) || !memo_hit(target, disp, axis_h, DEPTH + 1)) {
+                if (PG_DBG(d, 65536) || !memo_hit(target, disp, axis_h, DEPTH + 1)) {
                     const uint32_t c0 = push_chg;
                     sub_step<DEPTH + 1>(target, t_vx, t_vy, scan_axes);
-                    if (push_chg == c0 && !(d.debug_flags & 65536)) memo_insert(target, disp, axis_h, DEPTH + 1);
+                    if (push_chg == c0 && !PG_DBG(d, 65536)) memo_insert(target, disp, axis_h, DEPTH + 1);
 #if defined(PGAMD_WAVE_EMU)
                     pg_emu_counters()[5] += 1;  // nested sub_steps run
 #endif
@@ -854,7 +854,7 @@ struct Env {
         PG_SYNC_E();
 
         if constexpr (PUSH_MEMO_OK && DEPTH >= 1 && DEPTH < 5) {
-            if (push_chg == chg_in && !(d.debug_flags & 65536) && push_fixed_point(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory)) return true;
+            if (push_chg == chg_in && !PG_DBG(d, 65536) && push_fixed_point(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory)) return true;
         }
         return entity_scan<DEPTH>(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory) || block;
     }
@@ -1051,12 +1051,12 @@ struct Env {
         R.eventful = true;
         obj_flush(obj, R);
 #if !defined(PGAMD_WAVE_EMU)
-        const long long t_scan0 = d.wave_trace ? (long long)__builtin_readcyclecounter() : 0;
+        const long long t_scan0 = PG_TRACE(d) ? (long long)__builtin_readcyclecounter() : 0;
 #endif
         const bool block2 = entity_scan<0>(obj, _vx, _vy, is_horizontal, scan_axes, otype, orx, ory);
         PG_SYNC_E();
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.wave_trace) {
+        if (PG_TRACE(d)) {
             trace_add(1, 1);
             trace_add(3, (unsigned long long)((long long)__builtin_readcyclecounter() - t_scan0));
         }
@@ -1308,7 +1308,7 @@ struct Env {
         if (eflag(obj, MF_WILL_ERASE)) return;
         const int scan_axes = bso_scan_axes(obj);
         if constexpr (FREE_OBJECTS_OK) {
-            if (scan_axes == 0 && !G.grid_step && !(d.debug_flags & 32768)) {
+            if (scan_axes == 0 && !G.grid_step && !PG_DBG(d, 32768)) {
                 s->tmp[0] = (uint32_t)obj;
                 PG_SYNC_E();
                 bso_free_objects(0, 1);
@@ -1387,7 +1387,7 @@ struct Env {
             // entities (Entity::step) in the ordered loop below, which keeps only the objects that do interact.
             int ns = 0;
             for (int c = 0; c < ((n0 + 63) >> 6); c++) ns += pg_popc64(PG_BALLOT(l, ((c << 6) + l) < n0 && (meta((c << 6) + l) & MF_SMART_STEP) != 0));
-            if (ns >= 2 && !(d.debug_flags & 32768)) {  // (PROCGEN_AMD_DEBUG & 32768: A/B switch, every object in the ordered loop)
+            if (ns >= 2 && !PG_DBG(d, 32768)) {  // (PROCGEN_AMD_DEBUG & 32768: A/B switch, every object in the ordered loop)
                 int np = 0;
                 for (int c = 0; c < ((n0 + 63) >> 6) && np < 64; c++) {
                     uint64_t m = PG_BALLOT(l, ({
@@ -1642,11 +1642,11 @@ struct Env {
         }
         PG_SYNC_E();
         phase(1);
-        if (!(d.debug_flags & 64)) step_entities();
+        if (!PG_DBG(d, 64)) step_entities();
         phase(2);
-        if (!(d.debug_flags & 128)) collision_pass();
+        if (!PG_DBG(d, 128)) collision_pass();
         phase(3);
-        if (!(d.debug_flags & 256)) erase_if_needed();
+        if (!PG_DBG(d, 256)) erase_if_needed();
         phase(4);
         G.done = G.done || is_out_of_bounds(G.agent);
     }
@@ -1920,7 +1920,7 @@ struct Env {
                 game_reset_full();
                 phase(6);
 #if !defined(PGAMD_WAVE_EMU)
-                if (d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 15 + 32 * (env & 4095), 1ull);
+                if (PG_PHASES(d) && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 15 + 32 * (env & 4095), 1ull);
 #endif
             }
         }
@@ -2109,13 +2109,13 @@ struct Env {
     // step kernel took up to the end of the episode (mode 2) of this env
     PG_DEV void run(int mode) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
-        if (d.phase_cycles && d.wave_trace && PG_LANE_ID() < 24) d.wave_trace[(size_t)env * 32 + 8 + PG_LANE_ID()] = 0;
+        if (PG_PHASES(d)) t_mark = (long long)__builtin_readcyclecounter();
+        if (PG_PHASES(d) && PG_TRACE(d) && PG_LANE_ID() < 24) d.wave_trace[(size_t)env * 32 + 8 + PG_LANE_ID()] = 0;
 #endif
         load_env(mode != 2);  // a reset starts from an empty entity table (whose old size may exceed this arena)
         phase(0);
         if (mode == 1) G.action = d.action[env];  // reference src/vecgame.cpp:388
-        if (d.debug_flags & 512) {
+        if PG_DBG(d, 512) {
             // ablation: staging only
         } else {
             if (mode == 1) game_step_full();
@@ -2143,7 +2143,7 @@ struct Env {
         store_env();
         phase(8);
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles && mode != 0 && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 14 + 32 * (env & 4095), 1ull);
+        if (PG_PHASES(d) && mode != 0 && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 14 + 32 * (env & 4095), 1ull);
 #endif
     }
 };

@@ -184,18 +184,37 @@ struct RenderLdsT {
     // step from four to five waves per SIMD): the per-cell path's axis table `ax` (setup_tile_axes) lies over ci -- a frame is drawn in
     // pull form or cell by cell --, typesz (set-up only) over words 128..191 of the band buffer (idle during the set-up; build_pull_tables
     // keeps its scratch in words 0..127, the entity commands are staged there only after the pull tables are done); see Renderer::ax / typesz.
+    // ---- the pull form's tables.  For a display-list game (pg_prep.h) this block IS the table part of an env's frame record: the prep
+    // kernel builds it here and copies it out word by word, the raster kernel copies it back in; [ci, srcx) is all a frame with one cell
+    // image size needs (TAB_SINGLE_END), the size-class tables follow
     uint32_t ci[2][64];              // screen column -> the (at most two) cell columns covering it
     uint32_t ri[2][64];              // screen row    -> the (at most two) cell rows covering it
     uint8_t seamcols[64];            // screen columns covered by two cell columns
-    uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of this frame (build_type_table)
-    uint8_t srcx[GameDrawsGrid<Game>::value ? 3 : 1][2][64];    // size classes 1..3: screen column -> source column, per covering slot
-    uint16_t srcyw[GameDrawsGrid<Game>::value ? 3 : 1][2][64];  // size classes 1..3: screen row -> source row * image width
     // window cell -> grid object type (CELL8_NONE: nothing to draw); the type's image is typeany[type].  One byte per cell (round 4; a word
     // per cell with the image in it cost the games with large windows 4 KB of the arena, i.e. two of eleven resident frames per CU)
     uint8_t cellimg[GameDrawsGrid<Game>::value ? GamePullCells<Game>::value : 4];
     uint32_t typeany[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of any size: atlas offset | size class<<27 | opaque<<31 (pull form)
     uint32_t fillcmd[GameHasGridFills<Game>::value ? 2 * 256 : 1];  // solid-colour cells of a pull-form frame: (geom, colour) pairs
+    uint8_t srcx[GameDrawsGrid<Game>::value ? 3 : 1][2][64];    // size classes 1..3: screen column -> source column, per covering slot
+    uint16_t srcyw[GameDrawsGrid<Game>::value ? 3 : 1][2][64];  // size classes 1..3: screen row -> source row * image width
+    // ---- end of the record's table part
+    uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of this frame (build_type_table)
     uint32_t rot[GameUsesRotation<Game>::value ? GameRotPool<Game>::value * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane (by pool slot: ROT_POOL)
+};
+// Frame record of a display-list game (pg_prep.h): what prep<Game> leaves in HBM for raster<Game>, per env.  Words:
+//   [0, 16)          header: flags, dims (window rows | visible commands << 8 | grid fills << 16), the pull form's column-seam / row-seam /
+//                    row-any masks, the background command (7 words), the atlas' reference cell width
+//   [CMD, CMD + 512) up to 64 entity commands in draw order, 8 words each: geom basex srcy ix iy src aux | render_z + 1
+//   [TAB, ...)       the pull form's tables exactly as they lie in the render arena (RenderLdsT [ci, typeimg))
+template <class Game>
+struct FrameRec {
+    enum : int { FLAGS = 0, DIMS = 1, COLSEAM = 2, ROWSEAM = 4, ROWANY = 6, BG = 8, REF_W = 15, HDR_WORDS = 16, CMD = 16, CMD_WORDS = 8, TAB = CMD + 64 * CMD_WORDS };
+    enum : uint32_t { F_FAST = 1u, F_PULL = 2u, F_MULTI = 4u };
+    static constexpr int LDS_TAB_WORD0 = (int)(offsetof(RenderLdsT<Game>, ci) / 4);
+    static constexpr int TAB_SINGLE_WORDS = (int)((offsetof(RenderLdsT<Game>, srcx) - offsetof(RenderLdsT<Game>, ci) + 3) / 4);
+    static constexpr int TAB_WORDS = (int)((offsetof(RenderLdsT<Game>, typeimg) - offsetof(RenderLdsT<Game>, ci) + 3) / 4);
+    static constexpr int WORDS = (TAB + (GameDrawsGrid<Game>::value ? TAB_WORDS : 0) + 3) / 4 * 4;  // (records start on 16-byte boundaries)
+    static_assert(offsetof(RenderLdsT<Game>, ci) % 4 == 0 && offsetof(RenderLdsT<Game>, typeimg) % 4 == 0, "the table block is whole words");
 };
 template <bool GEN>
 struct CmdExtra {};
@@ -1082,68 +1101,118 @@ struct Renderer {
         tex = d.pixels[hit ? (cell & 0x7ffffffu) + rel : 0u];
         return hit;
     }
+    // Stages (c0, r0) and (c0, r1) of the pull form: lane = screen column, rows of the band given by `rowmask` (band-relative bits), row
+    // slot sr.  What a pixel ROW needs is wave-uniform: it comes from a lane copy of the band's row entries, one v_readlane per row,
+    // packed so that scalar code takes it apart (covered<<31 | class-0 sample valid<<30 | cell row<<24 | source row * image width).
+    // What a LANE needs -- the image of the cell (its cell column, the row's cell row) -- changes only with the cell row: it is looked
+    // up once per run of pixel rows under one cell row (5 of them for coinrun), not once per pixel; a run whose cell row shows no image
+    // in any column is skipped whole.  Per pixel that leaves: one add, the texel fetch, SourceOver.  (Round 6; the per-pixel lookup chain
+    // of rounds 2-5 -- two LDS reads and ~25 vector instructions a pixel -- was 42 % of the kernel's vector instructions,
+    // profiles/r06_valu_by_phase.txt.)  An opaque cell image needs no case of its own: its texels have alpha 255 and
+    // SourceOver with alpha 255 is the copy (BYTE_MUL(dst, 0) == 0).
     template <bool MULTI>
-    PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam, uint64_t rowany) {
-        const int ref_w = d.assets->ref_w;
-        const int nseam = pg_popc64(colseam);
-        const uint32_t band_any = (uint32_t)((rowany >> row0) & ((1ull << BAND_ROWS) - 1ull));
-        if (band_any == 0) return;  // no cell with an image reaches these rows (sky)
-        // stage 1: (c0, r0), lane = screen column, a band of fetches in flight
-        for (int yb = row0; yb < row1; yb += WIDE_ROWS) {
-            if (((band_any >> (yb - row0)) & ((1u << WIDE_ROWS) - 1u)) == 0) continue;
-            PG_R_LANES(l) {
-                const uint32_t ce = lds->ci[0][l];
-                uint32_t tex[WIDE_ROWS];
-                bool hit[WIDE_ROWS], opq[WIDE_ROWS];
-                _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
-                    opq[j] = false;
-                    tex[j] = 0;
-                    hit[j] = pull_fetch<MULTI>(ce, lds->ri[0][yb + j], 0, 0, l, yb + j, ny_full, ref_w, tex[j], opq[j]);
-                }
-                dma_join();  // (the band's background rows, requested before these texels)
-                _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
-                    uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];  // this lane owns the pixel
-                    const uint32_t old = *dp;
-                    const uint32_t over = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
-                    *dp = hit[j] ? over : old;
-                }
-            }
-            PG_SYNC();
+    PG_DEV void cols_pass(int sr, uint32_t rowmask, int ny_full, int ref_w) {
+        constexpr int R = WIDE_ROWS < 8 ? WIDE_ROWS : 8;  // rows per fetch batch
+        PG_LANE_VAR(uint32_t, rw);
+        PG_R_LANES(l) {
+            const uint32_t re = lds->ri[sr][row0 + (l & (BAND_ROWS - 1))];
+            PG_LV(rw, l) = (re & 0xc0000000u) | (((re >> 12) & 0x1fu) << 24) | (((re & 0xfffu) * (uint32_t)ref_w) & 0xffffffu);
         }
-        // stage 2: (c0, r1) on the doubly covered rows only, four of them per round; stage 4 below walks the same rows
-        const uint32_t band_seam = (uint32_t)((rowseam >> row0) & ((1ull << BAND_ROWS) - 1ull)) & band_any;
-        for (uint32_t m = band_seam; m != 0;) {
-            int ys[4], cnt = 0;
-            _Pragma("unroll") for (int q = 0; q < 4; q++) {
-                ys[q] = row0;
-                if (m != 0) {
-                    ys[q] = row0 + pg_ctz64((uint64_t)m);
-                    m &= m - 1u;
-                    cnt = q + 1;
+        // rows that can draw: covered by a cell row (and, with one image size, holding a sample of it)
+        uint32_t m = rowmask & (uint32_t)PG_BALLOT(l, l < BAND_ROWS && (PG_LV(rw, l) >> 31) != 0 && (MULTI || ((PG_LV(rw, l) >> 30) & 1u) != 0));
+        while (m != 0) {
+            // the next run: up to R rows of `m` under one cell row
+            int ys[R];
+            uint32_t wd[R];
+            int cnt = 0;
+            const int cy = (int)((PG_READLANE(rw, pg_ctz64((uint64_t)m)) >> 24) & 0x1fu);
+            bool open = true;
+            _Pragma("unroll") for (int q = 0; q < R; q++) {
+                ys[q] = 0;
+                wd[q] = 0;
+                if (open && m != 0) {
+                    const int j = pg_ctz64((uint64_t)m);
+                    const uint32_t w = PG_READLANE(rw, j);
+                    if ((int)((w >> 24) & 0x1fu) == cy) {
+                        ys[q] = j;
+                        wd[q] = w;
+                        cnt = q + 1;
+                        m &= m - 1u;
+                    } else {
+                        open = false;
+                    }
                 }
             }
+            // the lane's cell of this cell row
+            PG_LANE_VAR(uint32_t, cbase);
+            PG_LANE_VAR(uint32_t, chit);  // 0: nothing to draw in this column; 1: class 0; 2..4: size class 1..3
             PG_R_LANES(l) {
                 const uint32_t ce = lds->ci[0][l];
-                uint32_t tex[4];
-                bool hit[4], opq[4];
-                _Pragma("unroll") for (int q = 0; q < 4; q++) {
-                    opq[q] = false;
+                const uint32_t ct = lds->cellimg[((ce >> 12) & 0x1fu) * (uint32_t)ny_full + (uint32_t)cy];
+                const uint32_t cell = ct < 64u ? typeany[ct & 63u] : CELL_NONE;
+                bool h = (ce >> 31) != 0 && cell != CELL_NONE;
+                uint32_t b = (cell & 0x7ffffffu) + (ce & 0xfffu), hk = 1u;
+                if (MULTI) {
+                    const uint32_t k = (cell >> 27) & 3u;  // (CELL_NONE reads class 3: in bounds, never a hit)
+                    const uint32_t sx1 = lds->srcx[k ? k - 1u : 0u][0][l];
+                    h = h && (k ? sx1 != 0xffu : ((ce >> 30) & 1u) != 0);
+                    b = k ? (cell & 0x7ffffffu) + sx1 : b;
+                    hk = 1u + k;
+                } else {
+                    h = h && ((ce >> 30) & 1u) != 0;
+                }
+                PG_LV(cbase, l) = h ? b : 0u;  // (a lane without a cell fetches a word near the start of the atlas and blends nothing)
+                PG_LV(chit, l) = h ? (hk | ((cell >> 31) << 3)) : 0u;  // bit 3: the cell's image is opaque
+            }
+            if (PG_BALLOT(l, PG_LV(chit, l) != 0) == 0) continue;  // sky
+            // every image of this cell row opaque (ground, walls, crates: most of a level): its texels replace the pixels, no SourceOver
+            const bool all_opaque = PG_BALLOT(l, PG_LV(chit, l) != 0 && (PG_LV(chit, l) & 8u) == 0) == 0;
+            PG_R_LANES(l) {
+                uint32_t tex[R];
+                bool hit[R];
+                const uint32_t b = PG_LV(cbase, l), hk = PG_LV(chit, l) & 7u;
+                _Pragma("unroll") for (int q = 0; q < R; q++) {
                     tex[q] = 0;
                     hit[q] = false;
-                    if (q < cnt) hit[q] = pull_fetch<MULTI>(ce, lds->ri[1][ys[q]], 0, 1, l, ys[q], ny_full, ref_w, tex[q], opq[q]);
-                }
-                dma_join();
-                _Pragma("unroll") for (int q = 0; q < 4; q++) {
                     if (q < cnt) {
-                        uint32_t *dp = &fb[(ys[q] - row0) * RES_W + l];
-                        const uint32_t old = *dp;
-                        const uint32_t over = opq[q] ? tex[q] : blend(tex[q], old, 256, 255u);
-                        *dp = hit[q] ? over : old;
+                        if (MULTI) {  // a lane of size class k takes its source row from that class's table; Qt may have dropped the row's sample
+                            const uint32_t sy1 = lds->srcyw[hk >= 2u ? hk - 2u : 0u][sr][row0 + ys[q]];
+                            const bool rowhit = hk != 0 && (hk >= 2u ? sy1 != 0xffffu : ((wd[q] >> 30) & 1u) != 0);
+                            const uint32_t t = d.pixels[rowhit ? b + (hk >= 2u ? sy1 : (wd[q] & 0xffffffu)) : 0u];
+                            tex[q] = rowhit ? t : 0u;
+                            hit[q] = rowhit;
+                        } else {
+                            const uint32_t t = d.pixels[b + (wd[q] & 0xffffffu)];
+                            tex[q] = hk != 0 ? t : 0u;
+                            hit[q] = hk != 0;
+                        }
+                    }
+                }
+                dma_join();  // (the band's background rows, requested before these texels)
+                if (all_opaque) {
+                    _Pragma("unroll") for (int q = 0; q < R; q++) {
+                        if (q < cnt && hit[q]) fb[ys[q] * RES_W + l] = tex[q];  // this lane owns the pixel
+                    }
+                } else {
+                    _Pragma("unroll") for (int q = 0; q < R; q++) {
+                        if (q < cnt) {
+                            uint32_t *dp = &fb[ys[q] * RES_W + l];
+                            *dp = blend(tex[q], *dp, 256, 255u);  // (a transparent texel leaves the pixel as it is: BYTE_MUL(dst, 255) == dst)
+                        }
                     }
                 }
             }
             PG_SYNC();
         }
+    }
+    template <bool MULTI>
+    PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam, uint64_t rowany, int ref_w) {
+        const int nseam = pg_popc64(colseam);
+        const uint32_t band_any = (uint32_t)((rowany >> row0) & ((1ull << BAND_ROWS) - 1ull));
+        if (band_any == 0) return;  // no cell with an image reaches these rows (sky)
+        const uint32_t band_seam = (uint32_t)((rowseam >> row0) & ((1ull << BAND_ROWS) - 1ull)) & band_any;
+        cols_pass<MULTI>(0, band_any, ny_full, ref_w);                    // stage 1: (c0, r0)
+        if (band_seam != 0) cols_pass<MULTI>(1, band_seam, ny_full, ref_w);  // stage 2: (c0, r1) on the doubly covered rows
         if (nseam == 0) return;
         // stage 3: (c1, r0): the doubly covered columns x the band's rows, laid out linearly over the lanes, four per lane and round
         {
@@ -1306,7 +1375,7 @@ struct Renderer {
     // whole band's rows are in flight while the wave goes on to request the band's first cell / sprite texels: whoever reads or
     // writes fb next joins the copies (dma_join) after issuing its own fetches.
     PG_DEV bool bg_dma_ok(const DrawCmd &c) const {
-        return !GEN && !(d.debug_flags & 131072) && c.w > 32 && cmd_opaque(c.aux) && !cmd_mirrored(c.aux) && !cmd_fill(c.aux) && !cmd_rotated(c.aux) && !cmd_tiled(c.aux);
+        return !GEN && !PG_DBG(d, 131072) && c.w > 32 && cmd_opaque(c.aux) && !cmd_mirrored(c.aux) && !cmd_fill(c.aux) && !cmd_rotated(c.aux) && !cmd_tiled(c.aux);
     }
     PG_DEV void exec_bg_dma(const DrawCmd &c) {
         const uint32_t *src = d.pixels + c.src;
@@ -1806,7 +1875,7 @@ struct Renderer {
         }
         // (a turned sprite joins the groups of small ones when the game has rotation records and its bounding box fits; GEN draws them on Qt's generic route)
         const uint64_t small = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && ((PG_LV(r.geom, l) >> 14) & 0x7fu) <= 8u && ((PG_LV(r.geom, l) >> 21) & 0x7fu) <= 8u &&
-                                                (!cmd_rotated(PG_LV(r.aux, l)) || (GameUsesRotation<Game>::value && !GEN && !(d.debug_flags & 524288))) && !cmd_tiled(PG_LV(r.aux, l)));
+                                                (!cmd_rotated(PG_LV(r.aux, l)) || (GameUsesRotation<Game>::value && !GEN && !PG_DBG(d, 524288))) && !cmd_tiled(PG_LV(r.aux, l)));
         while (valid) {
             const int k = pg_ctz64(valid);
             if ((small >> k) & 1ull) {
@@ -2165,7 +2234,7 @@ struct Renderer {
     long long t_mark = 0;
     PG_DEV void phase(int k) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles) {
+        if (PG_PHASES(d)) {
             const long long t = (long long)__builtin_readcyclecounter();
             if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + k, (unsigned long long)(t - t_mark));
             t_mark = (long long)__builtin_readcyclecounter();
@@ -2174,9 +2243,25 @@ struct Renderer {
         (void)k;
 #endif
     }
+    // the solid-colour cells of a pull-form frame (build_pull_tables left their commands in fillcmd)
+    PG_DEV void draw_pull_fills(int nfill) {
+        for (int base = 0; base < nfill; base += 64) {
+            CmdRegs r;
+            PG_R_LANES(l) {
+                const bool in = base + l < nfill;
+                const int si = 2 * (in ? base + l : 0);
+                PG_LV(r.geom, l) = in ? lds->fillcmd[si] : 0u;
+                PG_LV(r.src, l) = in ? lds->fillcmd[si + 1] : 0u;
+                PG_LV(r.aux, l) = cmd_aux(1, false, true, 256) | (1u << 26);
+                PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = 0;
+                if constexpr (GEN) PG_LV(r.e0, l) = PG_LV(r.e1, l) = 0;
+            }
+            run_batch(r);
+        }
+    }
     PG_DEV void render_env() {
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles) t_mark = (long long)__builtin_readcyclecounter();
+        if (PG_PHASES(d)) t_mark = (long long)__builtin_readcyclecounter();
 #endif
         // ---- requests, round 1: what depends on the env index alone -- the header and the fields of the first 64 entity slots
         EntPre epre;
@@ -2192,8 +2277,8 @@ struct Renderer {
         // ---- frame-level set-up (rows [0, 64)) ------------------------------------------------------------------
         row0 = 0;
         row1 = RES_H;
-        if (d.debug_flags & 4) G.n_ents = 0;
-        const bool force_chunks = (d.debug_flags & 4096) != 0;  // test aid: every frame through draw_entities()
+        if PG_DBG(d, 4) G.n_ents = 0;
+        const bool force_chunks = PG_DBG(d, 4096) != 0;  // test aid: every frame through draw_entities()
         bool one_chunk = G.n_ents <= 64 && !force_chunks;  // or: the visible ones fit the register sets
         int win_lx, win_hx, win_ly, win_hy;  // BAG:926-939
         if (Game::center_agent(opt)) {
@@ -2213,10 +2298,10 @@ struct Renderer {
         const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
         // (GEN: every cell is its own generic drawImage, set up lane-parallel per band: neither axis tables nor the pull form)
         const bool use_axes = !GEN && GameDrawsGrid<Game>::value && nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
-        const bool try_pull = GameDrawsGrid<Game>::value && !GEN && use_axes && nx * ny_full <= GamePullCells<Game>::value && !(d.debug_flags & 1024);
+        const bool try_pull = GameDrawsGrid<Game>::value && !GEN && use_axes && nx * ny_full <= GamePullCells<Game>::value && !PG_DBG(d, 1024);
         // ---- requests, round 2: every table lookup of the set-up, in flight together: the background image, the images of the
         // entities (lane = slot) and of the grid object types (lane = type), the first 256 window cells
-        const ImgDesc bg_desc = (opt.use_backgrounds && !(d.debug_flags & 1)) ? d.assets->bg_desc[G.background_index] : ImgDesc{IMG_NONE, 0, 0, 0};
+        const ImgDesc bg_desc = (opt.use_backgrounds && !PG_DBG(d, 1)) ? d.assets->bg_desc[G.background_index] : ImgDesc{IMG_NONE, 0, 0, 0};
         PG_LANE_VAR(ImgDesc, type_desc);
         PG_LANE_ARR(int, cells0, 4);
         PG_R_LANES(l) {
@@ -2249,14 +2334,14 @@ struct Renderer {
             }
         };
         if constexpr (GameCustomBackground<Game>::value) {
-            if (opt.use_backgrounds && !(d.debug_flags & 1)) {
+            if (opt.use_backgrounds && !PG_DBG(d, 1)) {
                 RectD rects[4];
                 const int nr = Game::background_rects(*this, rects);
                 const ImgDesc bgi = bg_desc;
                 _Pragma("unroll") for (int k = 0; k < 4; k++)
                     if (k < nr && rects[k].w > 0) add_bg(bgi, rects[k]);
             }
-        } else if (opt.use_backgrounds && !(d.debug_flags & 1)) {
+        } else if (opt.use_backgrounds && !PG_DBG(d, 1)) {
             const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);
             const ImgDesc bgi = bg_desc;
             if (!GameTiledBackground<Game>::value && G.bg_tile_ratio < 0) fail(PGE_UNSUPPORTED_DRAW);  // (only fruitbot's constructor sets it)
@@ -2396,7 +2481,7 @@ struct Renderer {
             int low_y = win_ly, ny = 0, ncell = 0;
             uint32_t ny_inv = 0;
             const int low_x = win_lx;
-            if (GameDrawsGrid<Game>::value && !(pull || (d.debug_flags & 2))) {  // (the pull form walks screen rows, not cells)
+            if (GameDrawsGrid<Game>::value && !(pull || PG_DBG(d, 2))) {  // (the pull form walks screen rows, not cells)
                 int high_y = win_hy;
                 const float inv_unit = 1.0f / G.unit;
                 const int cy_hi = (int)pg_ceil((double)(G.view_dim - ((float)row0 - G.y_off) * inv_unit)) + 1;
@@ -2410,23 +2495,10 @@ struct Renderer {
             }
             phase(2);
             if constexpr (GameDrawsGrid<Game>::value)
-                if (pull && !(d.debug_flags & 2)) {
-                    if (pull_multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany);
-                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany);
-                    if constexpr (GameHasGridFills<Game>::value) {
-                        for (int base = 0; base < pull_nfill; base += 64) {
-                            CmdRegs r;
-                            PG_R_LANES(l) {
-                                const bool in = base + l < pull_nfill;
-                                const int si = 2 * (in ? base + l : 0);
-                                PG_LV(r.geom, l) = in ? lds->fillcmd[si] : 0u;
-                                PG_LV(r.src, l) = in ? lds->fillcmd[si + 1] : 0u;
-                                PG_LV(r.aux, l) = cmd_aux(1, false, true, 256) | (1u << 26);
-                                PG_LV(r.basex, l) = PG_LV(r.srcy, l) = PG_LV(r.ix, l) = PG_LV(r.iy, l) = 0;
-                            }
-                            run_batch(r);
-                        }
-                    }
+                if (pull && !PG_DBG(d, 2)) {
+                    if (pull_multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w);
+                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w);
+                    if constexpr (GameHasGridFills<Game>::value) draw_pull_fills(pull_nfill);
                 }
             for (int base = 0; base < ncell; base += 64) {
                 CmdRegs r;
@@ -2528,15 +2600,108 @@ struct Renderer {
             if constexpr (GameHasOverlay<Game>::value) Game::draw_overlay(*this);  // game_draw overrides that paint after the base frame
             PG_SYNC();
             phase(4);
-            if (!(d.debug_flags & 8)) store_band();
+            if (!PG_DBG(d, 8)) store_band();
             PG_SYNC();
             phase(5);
         }
 #if !defined(PGAMD_WAVE_EMU)
-        if (d.phase_cycles && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + 15, 1ull);
+        if (PG_PHASES(d) && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + 15, 1ull);
 #else
         if (pg_emu_dma_outstanding() != 0) {  // (a band whose background copies nobody joined: store_band always does)
             fprintf(stderr, "render_env: %d LDS-DMA words still in flight at the end of the frame\n", pg_emu_dma_outstanding());
+            abort();
+        }
+#endif
+        if (G.error) {
+#if defined(PGAMD_WAVE_EMU)
+            pg_report_error(d, env, G.error, ERR_KIND_RENDER, 0, 0);
+#else
+            if (PG_LANE_ID() == 0) pg_report_error(d, env, G.error, ERR_KIND_RENDER, 0, 0);
+#endif
+        }
+    }
+
+    // The frame of a display-list game from its record (FrameRec, written by pg_prep.h's FramePrep::run): the rasterizer proper.  No header,
+    // no options, no fp64: the record's scalars by scalar loads, one entity command per lane, the pull form's tables by LDS-DMA straight into
+    // the arena, then the band passes of render_env for a frame whose commands fit one register set and whose grid is drawn in pull form
+    // (every other frame is queued for render_env by the prep kernel).  Same painter's order: background, z = -1, grid cells, z = 0, z = 1
+    // (BAG:979-1012, 921-970).
+    PG_DEV void raster_env() {
+        typedef FrameRec<Game> Rec;
+        static_assert(!GEN, "generated assets draw through render_env");
+        const uint32_t *rec = d.frame_rec + (size_t)env * Rec::WORDS;
+        const uint32_t flags = rec[Rec::FLAGS], dims = rec[Rec::DIMS];
+        const uint64_t colseam = (uint64_t)rec[Rec::COLSEAM] | ((uint64_t)rec[Rec::COLSEAM + 1] << 32);
+        const uint64_t rowseam = (uint64_t)rec[Rec::ROWSEAM] | ((uint64_t)rec[Rec::ROWSEAM + 1] << 32);
+        const uint64_t rowany = (uint64_t)rec[Rec::ROWANY] | ((uint64_t)rec[Rec::ROWANY + 1] << 32);
+        const uint32_t bg_geom = rec[Rec::BG], bg_basex = rec[Rec::BG + 1], bg_srcy = rec[Rec::BG + 2], bg_ix = rec[Rec::BG + 3], bg_iy = rec[Rec::BG + 4],
+                       bg_src = rec[Rec::BG + 5], bg_aux = rec[Rec::BG + 6];
+        const int ref_w = (int)rec[Rec::REF_W];
+        const int ny_full = (int)(dims & 0xffu), ncmd = (int)((dims >> 8) & 0xffu), nfill = (int)(dims >> 16);
+        const bool pull = (flags & Rec::F_PULL) != 0, multi = (flags & Rec::F_MULTI) != 0;
+        G.error = 0;
+        if constexpr (GameDrawsGrid<Game>::value) {
+            if (pull) {
+                uint32_t *tab = reinterpret_cast<uint32_t *>(lds) + Rec::LDS_TAB_WORD0;
+                const int words = multi ? Rec::TAB_WORDS : Rec::TAB_SINGLE_WORDS;
+                for (int k0 = 0; k0 < words; k0 += 64) {
+                    PG_R_LANES(l) {
+                        if (k0 + l < words) PG_DMA_DWORD(rec + Rec::TAB + k0 + l, tab + k0, l);
+                    }
+                }
+            }
+        }
+        CmdRegs er;
+        PG_LANE_VAR(uint32_t, ez);
+        PG_R_LANES(l) {
+            const bool in = l < ncmd;
+            const pg_u4 *c = reinterpret_cast<const pg_u4 *>(rec + Rec::CMD + Rec::CMD_WORDS * (in ? l : 0));
+            const pg_u4 a = c[0], b = c[1];
+            PG_LV(er.geom, l) = in ? a.x : 0u;
+            PG_LV(er.basex, l) = in ? a.y : 0u;
+            PG_LV(er.srcy, l) = in ? a.z : 0u;
+            PG_LV(er.ix, l) = in ? a.w : 0u;
+            PG_LV(er.iy, l) = in ? b.x : 0u;
+            PG_LV(er.src, l) = in ? b.y : 0u;
+            PG_LV(er.aux, l) = in ? b.z : 0u;
+            PG_LV(ez, l) = in ? b.w : 255u;
+        }
+        const uint64_t ez0 = PG_BALLOT(l, PG_LV(ez, l) == 0u), ez1 = PG_BALLOT(l, PG_LV(ez, l) == 1u), ez2 = PG_BALLOT(l, PG_LV(ez, l) == 2u);
+        dma_join();
+        PG_SYNC();
+        const DrawCmd bc0 = unpack(bg_geom, bg_basex, bg_srcy, bg_ix, bg_iy, bg_src, bg_aux);
+        const bool bg_dma = bg_geom != 0 && bg_dma_ok(bc0);
+        for (int band = 0; band < NUM_BANDS; band++) {
+            row0 = band * BAND_ROWS;
+            row1 = row0 + BAND_ROWS;
+            // a background image that reaches every pixel of the band needs no black underneath (p.fillRect(rect, QColor(0,0,0)))
+            const bool bg_full = bg_dma && bc0.tx1 == 0 && bc0.w == RES_W && bc0.ty1 <= row0 && bc0.ty1 + bc0.h >= row1;
+            if (!bg_full) {
+                for (int base = 0; base < BAND_ROWS * RES_W; base += 64) {
+                    PG_R_LANES(l) { fb[base + l] = 0xff000000u; }
+                }
+            }
+            PG_SYNC();
+            if (bg_geom != 0 && bc0.ty1 < row1 && bc0.ty1 + bc0.h > row0) {
+                if (bg_dma) exec_bg_dma(bc0);
+                else exec_large(bc0);
+            }
+            if (ez0) run_batch(er, ez0);
+            if constexpr (GameDrawsGrid<Game>::value) {
+                if (pull) {
+                    if (multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w);
+                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w);
+                    if constexpr (GameHasGridFills<Game>::value) draw_pull_fills(nfill);
+                }
+            }
+            if (ez1 | ez2) run_batch(er, ez1, ez2);  // z = 0, then z = 1, in one pass
+            PG_SYNC();
+            store_band();
+            PG_SYNC();
+        }
+#if defined(PGAMD_WAVE_EMU)
+        if (pg_emu_dma_outstanding() != 0) {
+            fprintf(stderr, "raster_env: %d LDS-DMA words still in flight at the end of the frame\n", pg_emu_dma_outstanding());
             abort();
         }
 #endif

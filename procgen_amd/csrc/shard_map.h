@@ -26,4 +26,19 @@ struct ShardMap {
     int first_env(int part) const { return env_of(part, 0); }
 };
 
+// Launch slot of sorted position p among the `count` envs of one render launch chunk (kernels.hip render_order_scatter): workgroup j of
+// a launch runs on XCD j mod 8 and each XCD has its own L2, so XCD x takes the x-th eighth of the sorted sequence.  With q = count / 8 and
+// r = count % 8 the XCDs x < r take q + 1 positions and the others q: a bijection of [0, count) for ANY count (round 5's form,
+// (p % q) * 8 + p / q, was one only for multiples of 8: up to 7 envs of a chunk kept stale frames, advisor finding).  Plain integer code,
+// compiled for the host and the device alike.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int render_order_slot(int p, int count) {
+    const int q = count >> 3, r = count & 7;
+    const int head = r * (q + 1);  // positions of the XCDs that take q + 1
+    if (p < head) return (p % (q + 1)) * 8 + p / (q + 1);
+    return q > 0 ? ((p - head) % q) * 8 + r + (p - head) / q : p;
+}
+
 }  // namespace pgamd

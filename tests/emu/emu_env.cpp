@@ -15,6 +15,7 @@
 #include "pg_assetgen.h"
 #include "pg_bgpaint.h"
 #include "pg_render.h"
+#include "pg_prep.h"
 #include "pg_human.h"
 #include "host_state.h"
 #include "state_io.h"
@@ -38,6 +39,9 @@ struct EmuVec {
     std::vector<uint32_t> game_tables;
     std::vector<uint32_t> gen_bg;  // use_generated_assets
     std::vector<int> bg_req;
+    std::vector<uint32_t> frame_rec;  // display-list games (pg_prep.h)
+    std::vector<int> slow_list;
+    long long fast_frames = 0, slow_frames = 0;
     int use_small;
     int dev_error = 0;
     int game_id = -1;
@@ -108,6 +112,36 @@ static void run_all(EmuVec *v, int mode) {
         }
     }
     static RenderLdsT<Game> rlds;
+    if constexpr (GameDisplayList<Game>::value) {
+        if (!v->d.gen_bg && !getenv("PG_EMU_NO_DISPLAY_LIST")) {  // "prep", "raster", "render_list" (pg_prep.h)
+            typedef FrameRec<Game> Rec;
+            if (v->frame_rec.empty()) {
+                v->frame_rec.assign((size_t)v->n * Rec::WORDS, 0xdeadbeefu);  // (a record word the prep wave does not write must not be read)
+                v->slow_list.assign(v->n, -1);
+            }
+            v->d.frame_rec = v->frame_rec.data();
+            int slow_count = 0;
+            for (int e0 = 0; e0 < v->n; e0 += PREP_ENVS) {
+                poison_lds(&rlds);
+                FramePrep<Game> p(v->d, &rlds, &slow_count, v->slow_list.data());
+                p.run(e0, v->n - e0 < PREP_ENVS ? v->n - e0 : PREP_ENVS);
+            }
+            for (int e = 0; e < v->n; e++) {
+                if (!(v->frame_rec[(size_t)e * Rec::WORDS + Rec::FLAGS] & Rec::F_FAST)) continue;
+                poison_lds(&rlds);
+                Renderer<Game> r(v->d, e, &rlds);
+                r.raster_env();
+                v->fast_frames++;
+            }
+            for (int k = 0; k < slow_count; k++) {
+                poison_lds(&rlds);
+                Renderer<Game> r(v->d, v->slow_list[k], &rlds);
+                r.render_env();
+                v->slow_frames++;
+            }
+            return;
+        }
+    }
     for (int e = 0; e < v->n; e++) {  // "render kernel": one wave per env
         if (v->d.gen_bg) {
             poison_lds(&rlds);
@@ -379,6 +413,8 @@ void emu_generated_background(int seed, uint32_t *out250000) {
 }
 void emu_dump_background(void *h, int env, uint32_t *out) { memcpy(out, ((EmuVec *)h)->gen_bg.data() + (size_t)env * GEN_BG_WORDS, sizeof(uint32_t) * GEN_BG_WORDS); }
 long long emu_counter(int k) { return pg_emu_counters()[k]; }
+// display-list games: frames the rasterizer drew from their record / frames the full renderer drew (pg_prep.h)
+long long emu_frame_count(void *h, int slow) { return slow ? ((EmuVec *)h)->slow_frames : ((EmuVec *)h)->fast_frames; }
 void emu_path_counts(void *h, long long *out) {
     EmuVec *v = (EmuVec *)h;
     out[0] = 0;

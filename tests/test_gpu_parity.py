@@ -363,9 +363,142 @@ def test_render_launch_order_by_background_draws_the_same_frames(monkeypatch):
     tiled background and one that draws its own."""
     for game, n, steps in (("coinrun", 8192, 40), ("coinrun", 512, 40), ("fruitbot", 256, 30), ("starpilot", 4096, 30)):
         acts = action_stream(n, steps, seed=13)
-        monkeypatch.delenv("PROCGEN_AMD_RENDER_ORDER", raising=False)
+        monkeypatch.setenv("PROCGEN_AMD_RENDER_ORDER", "0")  # (env order: coinrun's default is itself ordered)
         want = rollout(make_env(n, game), acts)
         monkeypatch.setenv("PROCGEN_AMD_RENDER_ORDER", "4")
         got = rollout(make_env(n, game), acts)
         monkeypatch.delenv("PROCGEN_AMD_RENDER_ORDER")
         assert_rollouts_equal(want, got, f"{game} N={n}: ordered render launch")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [17, 100, 700, 4095, 5000, 70000])
+def test_render_launch_order_is_a_permutation_per_chunk(monkeypatch, n):
+    """The device's launch order (procgen_amd_render_order) after a rebuild: every launch chunk's slots hold exactly that chunk's envs, for
+    handle sizes that are not multiples of 8 (round-5 advisor finding: the scatter was a bijection only for multiples of 8, so up to 7
+    envs of a chunk were never drawn and kept stale frames), and a slot's XCD (slot % 8) sees non-decreasing background images."""
+    import ctypes as C
+
+    monkeypatch.setenv("PROCGEN_AMD_RENDER_ORDER", "2")
+    env = make_env(n, "coinrun", extra_options={"host_observations": False} if n > 8192 else None)
+    acts = action_stream(n, 3, seed=5)
+    env.observe()
+    for a in acts:
+        env.act(a)
+        env.observe()
+    order = np.full(n, -1, dtype=np.int32)
+    chunk = (C.c_int * 2)()
+    env._lib.procgen_amd_render_order.restype = C.c_int
+    got = env._lib.procgen_amd_render_order(env._handle, order.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(n), chunk)
+    assert got == n
+    first, nchunk = chunk[0], chunk[1]
+    bounds = [0, n] if nchunk == 1 else ([0, first, n] if nchunk == 2 else list(range(0, n, first)) + [n])
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        assert np.array_equal(np.sort(order[lo:hi]), np.arange(lo, hi)), f"chunk [{lo}, {hi}) is not a permutation of its envs"
+    env.close()
+
+
+@pytest.mark.gpu
+def test_ordered_render_launch_with_a_handle_size_not_a_multiple_of_eight(monkeypatch):
+    """100 envs, 40 steps, the order rebuilt every 2 steps, against the oracle frame by frame: no env keeps a stale frame."""
+    n, steps = 100, 40
+    acts = action_stream(n, steps, seed=17)
+    monkeypatch.setenv("PROCGEN_AMD_RENDER_ORDER", "0")
+    want = rollout(make_env(n, "coinrun"), acts)
+    monkeypatch.setenv("PROCGEN_AMD_RENDER_ORDER", "2")
+    got = rollout(make_env(n, "coinrun"), acts)
+    assert_rollouts_equal(want, got, "coinrun N=100: ordered render launch vs env order")
+    orc = oracle_env.OracleEnv(n, "coinrun", rand_seed=23)
+    assert_rollouts_equal(rollout(orc, acts), got, "coinrun N=100: ordered render launch vs oracle")
+
+
+CFFI_PYTHON = "/opt/conda/bin/python3.9"  # the interpreter of this image that has cffi (gym3's FFI; the system python has ctypes only)
+
+
+def run_cffi_replay(lib, resource_root, steps):
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    repo = os.path.dirname(here)
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"  # conda's libstdc++ is older than the one the libraries were linked against
+    env.setdefault("QT_QPA_PLATFORM", "offscreen")
+    env.pop("PYTHONPATH", None)
+    return subprocess.run([CFFI_PYTHON, os.path.join(here, "tools", "cffi_replay.py"), lib, os.path.join(repo, "include"),
+                           os.path.join(here, "golden", "coinrun_rollout.npz"), resource_root, str(steps)], env=env, capture_output=True, text=True, timeout=900)
+
+
+def cffi_available():
+    import subprocess
+
+    if not os.path.exists(CFFI_PYTHON):
+        return False
+    return subprocess.run([CFFI_PYTHON, "-c", "import cffi, numpy"], capture_output=True).returncode == 0
+
+
+@pytest.mark.gpu
+def test_boundary_through_cffi():
+    """The boundary through the FFI the reference really uses: gym3's CEnv is a cffi binding (reference procgen/env.py:66,128-136 -- the
+    `c_func_defs` strings are the reference's, verbatim), and `libenv_make` takes `struct libenv_options` BY VALUE (reference
+    src/vecgame.cpp:47-50).  A subprocess under the interpreter that has cffi drives libenv.so through gym3's call sequence and replays
+    tests/golden/coinrun_rollout.npz (compiled reference): rew / first / info / frame CRCs of 513 observations, the get_state bytes at
+    steps 0, 100, 300, 512, a set_state.  The same script drives the compiled reference on the CPU (test_oracle_golden.py)."""
+    if not cffi_available():
+        pytest.skip("no interpreter with cffi in this image")
+    r = run_cffi_replay(HIP_LIB, "/nonexistent/", 10**9)
+    assert r.returncode == 0 and "cffi replay ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def display_list_frames(env):
+    out = (C.c_int * 2)()
+    env._lib.procgen_amd_display_list_frames.restype = C.c_int
+    return (out[0], out[1]) if env._lib.procgen_amd_display_list_frames(env._handle, out) else None
+
+
+@pytest.mark.gpu
+def test_display_list_frames_equal_the_full_renderer(monkeypatch):
+    """coinrun draws a frame with prep -> raster kernels (pg_prep.h: the frame's draw commands and pull tables are built ahead, densely, and
+    the rasterizer draws from the record); the frames the short path cannot draw are queued for the full renderer (render_list).  Same
+    frames as the one-kernel renderer (PROCGEN_AMD_DISPLAY_LIST=0) and as the oracle, at sizes that are not multiples of the four envs a
+    prep wave takes and that span two launch chunks, with the launch order rebuilt on the way; and with every frame sent through the slow
+    list (PROCGEN_AMD_DEBUG & 1048576), which is what a frame with an unusual draw does."""
+    for n, steps in ((4099, 60), (37, 120), (1, 40)):
+        acts = action_stream(n, steps, seed=29)
+        monkeypatch.setenv("PROCGEN_AMD_DISPLAY_LIST", "0")
+        env = make_env(n, "coinrun")
+        assert display_list_frames(env) is None
+        want = rollout(env, acts)
+        monkeypatch.delenv("PROCGEN_AMD_DISPLAY_LIST")
+        env = make_env(n, "coinrun")
+        env.observe()
+        counts = display_list_frames(env)
+        assert counts is not None and counts[0] + counts[1] == n and counts[0] >= n * 9 // 10, counts
+        got = rollout(env, acts)
+        assert_rollouts_equal(want, got, f"coinrun N={n}: display list vs one-kernel renderer")
+        monkeypatch.setenv("PROCGEN_AMD_DEBUG", str(1048576))
+        env = make_env(n, "coinrun")
+        env.observe()
+        assert display_list_frames(env) == (0, n)
+        slow = rollout(env, acts)
+        monkeypatch.delenv("PROCGEN_AMD_DEBUG")
+        assert_rollouts_equal(want, slow, f"coinrun N={n}: every frame through the slow list")
+        if n == 37:
+            orc = oracle_env.OracleEnv(n, "coinrun", rand_seed=23)
+            assert_rollouts_equal(rollout(orc, acts), got, "coinrun N=37: display list vs oracle")
+
+
+@pytest.mark.gpu
+def test_display_list_with_options_that_leave_the_short_path():
+    """Option sets whose frames the rasterizer's short path does not draw (no centred window: no pull form; monochrome assets; paint_vel_info)
+    go to the full renderer frame by frame, and mixed with them the ones it does draw (no backgrounds, restricted themes): against the oracle."""
+    n, steps = 64, 80
+    acts = action_stream(n, steps, seed=31)
+    for kw, fast in (({"center_agent": False}, False), ({"use_monochrome_assets": True}, False), ({"paint_vel_info": True}, False),
+                     ({"use_backgrounds": False}, True), ({"restrict_themes": True}, True)):
+        env = make_env(n, "coinrun", **kw)
+        env.observe()
+        counts = display_list_frames(env)
+        assert counts is not None and ((counts[0] >= n - 2) if fast else (counts[0] == 0)), (kw, counts)
+        orc = oracle_env.OracleEnv(n, "coinrun", rand_seed=23, **kw)
+        assert_rollouts_equal(rollout(orc, acts), rollout(env, acts), f"coinrun {kw}: display list vs oracle")

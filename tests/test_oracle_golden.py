@@ -140,3 +140,18 @@ def test_oracle_with_generated_assets_matches_reference_fixture(golden_dir):
     backgrounds drawn from rand_gen inside game_reset, and Qt's generic span route for the ARGB32 sprites (rotated ones included)."""
     g = np.load(os.path.join(golden_dir, "generated_assets.npz"))
     check_against_generated_assets_fixture(g, lambda game, n, **kw: oracle_env.OracleEnv(n, game, rand_seed=19, **kw), GAMES)
+
+
+def test_cffi_binding_script_drives_the_compiled_reference(golden_dir):
+    """tests/tools/cffi_replay.py -- gym3's cffi call sequence with the reference's own `c_func_defs` (reference procgen/env.py:128-136) --
+    against the reference's own libenv.so (oracle/_ref): the binding the GPU test uses on the HIP library is the one the reference's
+    library accepts (libenv_make's by-value options struct, the pointer tables, get_state / set_state through char buffers)."""
+    import ref_env
+    from test_gpu_parity import cffi_available, run_cffi_replay
+
+    if not ref_env.available():
+        pytest.skip("compiled reference not built (oracle/_ref)")
+    if not cffi_available():
+        pytest.skip("no interpreter with cffi in this image")
+    r = run_cffi_replay(ref_env.REF_LIB, ref_env.ref_assets(), 110)
+    assert r.returncode == 0 and "cffi replay ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

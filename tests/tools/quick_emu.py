@@ -41,5 +41,7 @@ emu.L.emu_counter.restype = ctypes.c_longlong
 c7 = emu.L.emu_counter(7)
 if c7:
     print(f"rotation-record pool: {c7 // 1000000} frames sent to the per-band path, {c7 % 1000000} windows cut")
+emu.L.emu_frame_count.restype = ctypes.c_longlong
+print("display list: frames drawn from their record", emu.L.emu_frame_count(emu.h, 0), "/ by the full renderer", emu.L.emu_frame_count(emu.h, 1))
 print(f"{game} {kw}: {n} envs x {steps} steps, {bad} mismatching steps, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
