@@ -124,6 +124,55 @@ def cpu_baseline(game="coinrun", budget_s=24.0):
             "sweep": {k: round(v[0], 1) for k, v in tried.items()}}
 
 
+def measure_traffic(game, n, pre_rollout):
+    """HBM bytes per step of THIS build on THIS box, measured now: two short `rocprofv3 --pmc` passes of this same script (FETCH_SIZE, then
+    WRITE_SIZE: the TCC takes one of them per pass, MI355X_MICROARCH.md), outside the timed region, each over the pre-rollout plus a few
+    steps.  Per step: every kernel's sum divided by the steps the run drew, counted by what the frame kernels wrote (WRITE_SIZE is exact for
+    the observation store: 12288 B per env-frame, the only store of those kernels).  Returns (upper, raw, detail) in bytes -- raw = FETCH +
+    WRITE as reported; upper = raw + FETCH again, since gfx950's FETCH_SIZE tallies a 128-B request as 64 B for wide coalesced reads (same
+    guide) -- or (None, None, reason)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, None, "unavailable: no rocprofv3 on this box"
+    sums = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable, os.path.join(REPO, "bench.py"), "--steps", "8", "--warmup", "2",
+                   "--game", game, "--num-envs", str(n), "--steady-warmup", str(pre_rollout), "--no-cpu-baseline", "--no-host-landed", "--no-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
+            dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, None, f"unavailable: rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+            c = sqlite3.connect(dbs[0])
+            T = {row[0].rsplit("_0000", 1)[0]: row[0] for row in c.execute("select name from sqlite_master where type='table'")}
+            q = (f"select s.kernel_name, sum(e.value) from {T['rocpd_pmc_event']} e join {T['rocpd_info_pmc']} p on e.pmc_id=p.id "
+                 f"join {T['rocpd_kernel_dispatch']} d on e.event_id=d.event_id join {T['rocpd_info_kernel_symbol']} s on d.kernel_id=s.id "
+                 f"where p.name='{counter}' group by s.kernel_name")
+            sums[counter] = {k: float(v) for k, v in c.execute(q)}
+            c.close()
+        except Exception as ex:  # noqa: BLE001 -- a profiler hiccup must not cost the bench line
+            return None, None, f"unavailable: {type(ex).__name__}: {str(ex)[:200]}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    frame_kernels = [k for k in sums["WRITE_SIZE"] if any(t in k for t in ("6renderI", "6rasterI", "11render_listI", "render<", "raster<", "render_list<"))]
+    steps = sum(sums["WRITE_SIZE"][k] for k in frame_kernels) * 1024.0 / (n * 12288.0)
+    if steps < 1:
+        return None, None, "unavailable: no frame kernel in the counter pass"
+    fetch = sum(sums["FETCH_SIZE"].values()) * 1024.0 / steps
+    write = sum(sums["WRITE_SIZE"].values()) * 1024.0 / steps
+    short = lambda k: k.split("(")[0].replace("pgamd::", "").replace("void ", "")[:60]
+    per_kernel = {short(k): {"fetch_MB": round(sums["FETCH_SIZE"].get(k, 0.0) * 1024.0 / steps / 1e6, 1), "write_MB": round(sums["WRITE_SIZE"].get(k, 0.0) * 1024.0 / steps / 1e6, 1)}
+                  for k in sorted(set(sums["FETCH_SIZE"]) | set(sums["WRITE_SIZE"]), key=lambda k: -(sums["FETCH_SIZE"].get(k, 0.0) + sums["WRITE_SIZE"].get(k, 0.0)))[:8]}
+    return fetch * 2 + write, fetch + write, {"steps_in_pass": round(steps, 1), "fetch_MB_per_step": round(fetch / 1e6, 1), "write_MB_per_step": round(write / 1e6, 1), "per_kernel": per_kernel}
+
+
 KERNEL_POLICY = {"bigfish": "BigFish", "bossfight": "BossFight", "caveflyer": "CaveFlyerT<1600, 2>", "chaser": "Chaser", "climber": "Climber", "coinrun": "CoinRun",
                  "dodgeball": "Dodgeball", "fruitbot": "FruitBot", "heist": "Heist", "jumper": "Jumper", "leaper": "Leaper", "maze": "Maze", "miner": "Miner",
                  "ninja": "Ninja", "plunder": "Plunder", "starpilot": "StarPilot"}  # the policy class a game's kernels are instantiated with (procgen_amd/csrc/game_*.h)
@@ -146,6 +195,7 @@ def main():
     ap.add_argument("--steady-warmup", type=int, default=1500, help="untimed pre-rollout before the W warm-up and K timed steps (0: measure the cold start, as rounds 1-4 did)")
     ap.add_argument("--dry-multi", action="store_true", help="N > 1 ranks on ONE GPU (device 0 for every rank, gloo): exercises the launch path only")
     ap.add_argument("--shard-crc", action="store_true", help="report the CRC32 of every rank's last observations")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (they re-run this script; also what those passes themselves run with)")
     args = ap.parse_args()
 
     import torch
@@ -190,6 +240,11 @@ def main():
         env._lib.procgen_amd_kernel_timing.restype = C.c_double
         env._lib.procgen_amd_kernel_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         env._lib.procgen_amd_tier_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+
+    display_list = False  # the game's frames are drawn by prep -> raster kernels: the dominant kernel is raster<Game>
+    if single and hasattr(env._lib, "procgen_amd_display_list_frames"):
+        env._lib.procgen_amd_display_list_frames.restype = C.c_int
+        display_list = bool(env._lib.procgen_amd_display_list_frames(env._handle, (C.c_int * 2)()))
 
     def render_kernel_window(acts, steps=20):
         """the dominant kernel's own duration: events around each of its launches on the stream it is launched on, over a short window of
@@ -300,17 +355,18 @@ def main():
                        "note": "a second handle made with host observations, as gym3 makes it: frames copied D2H into the caller's registered host array every step (libenv ABI unmodified), first steps after its reset; PCIe Gen5 x16 bounds this at ~5.1 M steps/s per GPU"}
 
     if rank == 0:
-        # HBM bytes per launch (= one step): rocprofv3 PMC passes need their own runs (one counter set per pass), so this is the committed
-        # summary of the latest profile of the same workload -- a static figure, named as such
-        traffic = traffic_source = None
-        for tname in ("r05_hbm_traffic.json", "r04_hbm_traffic.json"):
-            tpath = os.path.join(REPO, "profiles", tname)
-            if os.path.exists(tpath) and args.game == "coinrun":
-                tj = json.load(open(tpath))
-                if tj.get("num_envs") == n:
-                    traffic = round(tj["hbm_bytes_per_step_upper"])
-                    traffic_source = f"profiles/{tname} (static: separate rocprofv3 --pmc passes of this workload in the steady state, upper bound per the gfx950 FETCH_SIZE note; raw {round(tj['hbm_bytes_per_step_raw'])})"
-                    break
+        # HBM bytes per launch (= one step), measured by this run: two rocprofv3 --pmc passes of this same script on this box, outside the
+        # timed region (measure_traffic); null with the reason when the profiler is not there or a pass fails
+        traffic = traffic_raw = traffic_detail = None
+        traffic_source = "not measured (--no-traffic, a joint / sharded handle or N > 1)"
+        if not args.no_traffic and world == 1 and D == 1 and not joint:
+            traffic, traffic_raw, traffic_detail = measure_traffic(args.game, n, args.steady_warmup)
+            if traffic is None:
+                traffic_source, traffic_detail = traffic_detail, None
+            else:
+                traffic, traffic_raw = round(traffic), round(traffic_raw)
+                traffic_source = ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this script (pre-rollout + 10 steps each), all kernels, per step; "
+                                  f"upper bound = WRITE + 2 x FETCH (gfx950 FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md); raw {traffic_raw}")
         total_steps = n * world * args.steps
         value = total_steps / dt
         achieved = ALGO_BYTES_PER_ENV_STEP * n / (kernel_ms * 1e-3) / 1e9
@@ -323,7 +379,7 @@ def main():
                                    f"observations {'landed on host (PCIe inclusive)' if args.host_landed else 'resident in HBM'}",
                        "num_envs_per_gpu": n // D, "sharding": (f"one handle, num_devices={D} contiguous index ranges, no collective" if D > 1 else f"env_offset shards x{world}, no collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source, "traffic_detail": traffic_detail,
                          "launch": "one step = exactly what libenv_act enqueues (step grids + list kernels, render kernels) over all envs of this GPU; HIP events on the library's stream around every libenv_act of the timed loop itself",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "kernel_ms_per_step": round(kernel_ms, 4), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP},
@@ -331,7 +387,7 @@ def main():
         if render_info is not None and render_info[1] > 0:
             gname = KERNEL_POLICY.get(args.game, args.game)
             line["roofline"]["dominant_kernel"] = {
-                "name": f"pgamd::render<{gname}, false>", "avg_us": round(render_info[0] * 1e3, 1), "launches_per_step": round(render_info[1], 2),
+                "name": f"pgamd::raster<{gname}>" if display_list else f"pgamd::render<{gname}, false>", "avg_us": round(render_info[0] * 1e3, 1), "launches_per_step": round(render_info[1], 2),
                 "source": f"HIP events around each launch of the kernel on the stream it is launched on, {render_info[2]} steps right behind the timed ones (procgen_amd_kernel_timing); its launches overlap the step kernels of the other chunk",
                 "achieved_GBs_observation_write": round(12288 * n / max(render_info[1], 1e-9) / (render_info[0] * 1e-3) / 1e9, 1)}
         if pre > 0:

@@ -8,6 +8,7 @@ namespace pgamd {
 
 struct BigFish {
     static constexpr int GAME_ID = GAME_BIGFISH;
+    static constexpr bool DISPLAY_LIST = true;  // frames are drawn prep -> raster (pg_prep.h)
     static constexpr const char *NAME = "bigfish";
     typedef uint8_t cell_t;
     static constexpr int MAX_CELLS = 20 * 20;  // bigfish.cpp:29-30 (padded to a 16-byte multiple below)

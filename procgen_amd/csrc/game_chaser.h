@@ -10,6 +10,7 @@ namespace pgamd {
 
 struct Chaser : BagDefaults<Chaser> {
     static constexpr int GAME_ID = GAME_CHASER;
+    static constexpr bool DISPLAY_LIST = true;  // frames are drawn prep -> raster (pg_prep.h)
     // pg_env.h GameParSmart: blocking / reflecting targets of this game are wall types only, never a smart entity's type,
     // and the hooks basic_step_object calls touch nothing but the moving object
     static constexpr bool PAR_SMART = true;

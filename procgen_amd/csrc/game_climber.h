@@ -8,6 +8,7 @@ namespace pgamd {
 
 struct Climber {
     static constexpr int GAME_ID = GAME_CLIMBER;
+    static constexpr bool DISPLAY_LIST = true;  // frames are drawn prep -> raster (pg_prep.h)
     static constexpr int RENDER_MIN_WAVES = 5;  // 102 -> 96 VGPRs with 12 B of scratch (the phase-counter address), arena 8136 B: five render waves per SIMD measured +4.5 % on the same box (55.9 -> 58.5 M, profiles/r05_try_ab.txt)
     // pg_env.h GameParSmart: blocking / reflecting targets of this game are wall types only, never a smart entity's type,
     // and the hooks basic_step_object calls touch nothing but the moving object

@@ -7,6 +7,7 @@ namespace pgamd {
 
 struct Maze {
     static constexpr int GAME_ID = GAME_MAZE;
+    static constexpr bool DISPLAY_LIST = true;  // frames are drawn prep -> raster (pg_prep.h)
     static constexpr int RENDER_MIN_WAVES = 5;  // the renderer fits 96 VGPRs without scratch and 8136 B of LDS: five waves per SIMD (kernels_game.hip)
     static constexpr const char *NAME = "maze";
     typedef uint8_t cell_t;

@@ -600,11 +600,9 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         d_render_order = dev_alloc<int>(N);  // (bound to d.render_order by the first rebuild)
         d_render_order_scratch = dev_alloc<int>(MAX_CHUNKS * MAX_BACKGROUNDS);
     }
-    // display-list games (pg_prep.h): a frame record per env, and the list of the envs whose frame the full renderer draws
+    // display-list games (pg_prep.h): a frame record per env
     if (const int rec_words = game_frame_rec_words(kernel_id); rec_words > 0 && !o.use_generated_assets && !(getenv("PROCGEN_AMD_DISPLAY_LIST") && atoi(getenv("PROCGEN_AMD_DISPLAY_LIST")) == 0)) {
         d.frame_rec = dev_alloc<uint32_t>(N * (size_t)rec_words);
-        d.slow_list = dev_alloc<int>(N);
-        d.slow_count = dev_alloc<int>(2 * MAX_CHUNKS);
     }
     d.assets = atlas->d_assets;
     d.pixels = atlas->d_pixels;
@@ -708,8 +706,6 @@ VecGame::~VecGame() {
     (void)hipFree(d_reset_list);
     (void)hipFree(d_reset_count);
     if (d.frame_rec) (void)hipFree(d.frame_rec);
-    if (d.slow_list) (void)hipFree(d.slow_list);
-    if (d.slow_count) (void)hipFree(d.slow_count);
     if (d_render_order) (void)hipFree(d_render_order);
     if (d_render_order_scratch) (void)hipFree(d_render_order_scratch);
     if (h_action) (void)hipHostFree(h_action);
@@ -820,7 +816,6 @@ void VecGame::launch_kernels(int mode) {
     LaunchStreams ls = streams();
     for (int c = 0; c < MAX_CHUNKS; c++)
         for (int t = 0; t < NUM_TIERS; t++) ls.list_count[c][t] = mode == 0 ? 0 : host_list_count[c][t];
-    d.step_parity = (int)(step_count & 1);  // (display-list games: which of the two slow-list counter sets this step fills)
     HIP_CHECK(launch_step(kernel_id, d, mode, ls));
     step_count++;
 }

@@ -13,8 +13,8 @@
 //                 lane of the same code.  Visible commands are packed in draw order into the env's record.  (2) Per env: the grid type
 //                 table and the pull form's tables (Renderer::build_type_table / build_pull_tables, unchanged), copied to the record.
 //                 A frame the rasterizer's short path cannot draw (per-cell path, more than 64 visible commands, paint_vel_info,
-//                 monochrome assets, any error) is queued for the full renderer instead: render_list<Game>.
-//   raster<Game>  one wave per env, Renderer::raster_env: loads the record -- header by scalar loads, <= 64 commands one per lane, the
+//                 monochrome assets, any error) is marked: the env's raster workgroup runs the full renderer (Renderer::render_env).
+//   raster<Game>  one wave per env, Renderer::raster_env (Renderer::render_env for a marked frame): loads the record -- header by scalar loads, <= 64 commands one per lane, the
 //                 tables into LDS -- and runs the band passes.  No fp64, no header, no options.
 //
 // Reference: the same calls as pg_render.h -- BasicAbstractGame::game_draw (src/basic-abstract-game.cpp:1009-1012), draw_background
@@ -46,10 +46,9 @@ struct FramePrep {
                   "display-list games: upright sprites, one background image, no overlay, one command set");
     const DevCtx &d;
     Lds *lds;
-    int *slow_count;  // [0]: envs queued for render_list by this launch
-    int *slow_list;
+    int *slow_count;  // (emulation: frames drawn by the full renderer; null on the device)
 
-    PG_DEV FramePrep(const DevCtx &d_, Lds *lds_, int *slow_count_, int *slow_list_) : d(d_), lds(lds_), slow_count(slow_count_), slow_list(slow_list_) {}
+    PG_DEV FramePrep(const DevCtx &d_, Lds *lds_, int *slow_count_ = nullptr) : d(d_), lds(lds_), slow_count(slow_count_) {}
 
     // lane-local: the header of the lane's env into its renderer (the optimizer keeps the fields the drawable's set-up reads)
     PG_DEV static void bind_env(R &r, const DevCtx &d, int env) {
@@ -179,7 +178,7 @@ struct FramePrep {
             uint32_t *rec = d.frame_rec + (size_t)env * Rec::WORDS;
             R r(d, env, lds);
             {
-                const EnvHdr *h = d.hdr + env;
+                const auto *h = PG_SCALAR_PTR(EnvHdr, d.hdr + env);  // (wave-uniform and read-only here: scalar loads)
 #define PG_X(type, name) r.G.name = h->name;
                 PG_HDR_FIELDS(PG_X)
 #undef PG_X
@@ -206,6 +205,7 @@ struct FramePrep {
             uint64_t colseam = 0, rowseam = 0, rowany = ~0ull;
             bool pull = false, multi = false;
             int nfill = 0;
+            uint32_t cellrows = 0, rowstep = 0;
             if constexpr (GameDrawsGrid<Game>::value) {
                 const bool try_pull = nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32 && nx * ny_full <= GamePullCells<Game>::value;
                 PG_LANE_VAR(ImgDesc, type_desc);
@@ -216,10 +216,13 @@ struct FramePrep {
                 }
                 if (try_pull) r.request_window_cells(win_lx, nx, win_ly, ny_full, cells0);
                 r.build_type_table(type_desc);
-                pull = try_pull && r.build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, multi, nfill, cells0);
+                pull = try_pull && r.build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, multi, nfill, cellrows, rowstep, cells0);
             }
             bool fast = ((slow >> e) & 1u) == 0 && r.G.error == 0 && !r.opt.use_monochrome_assets && !(r.G.has_useful_vel_info && r.opt.paint_vel_info) &&
                         (!GameDrawsGrid<Game>::value || pull);
+#if defined(PGAMD_WAVE_EMU)
+            if (!fast && getenv("PG_EMU_SLOW_WHY")) fprintf(stderr, "slow frame env %d: slowbit %d error %d mono %d vel %d pull %d nx %d ny %d n_ents %d\n", env, (int)((slow >> e) & 1u), r.G.error, (int)r.opt.use_monochrome_assets, (int)(r.G.has_useful_vel_info && r.opt.paint_vel_info), (int)pull, nx, ny_full, r.G.n_ents);
+#endif
             if (PG_DBG(d, 1048576)) fast = false;  // test aid: every frame through the full renderer
             PG_SYNC();
             // header: the scalars are wave-uniform; lane k takes word k and one store writes them (the background's words were written by its lane)
@@ -234,6 +237,8 @@ struct FramePrep {
             hw[Rec::ROWANY] = (uint32_t)rowany;
             hw[Rec::ROWANY + 1] = (uint32_t)(rowany >> 32);
             hw[Rec::REF_W] = (uint32_t)d.assets->ref_w;
+            hw[Rec::CELLROWS] = cellrows;
+            hw[Rec::ROWSTEP] = rowstep;
             PG_FOR_LANES(l) {
                 uint32_t v = 0;
                 _Pragma("unroll") for (int k = 0; k < Rec::HDR_WORDS; k++) v = l == k ? hw[k] : v;
@@ -249,13 +254,9 @@ struct FramePrep {
                     }
                 }
             }
-            if (!fast) {
 #if defined(PGAMD_WAVE_EMU)
-                slow_list[(*slow_count)++] = env;
-#else
-                if (PG_LANE_ID() == 0) slow_list[atomicAdd(slow_count, 1)] = env;
+            if (!fast && slow_count) ++*slow_count;  // (the raster kernel's workgroup of this env runs the full renderer: kernels_game.hip raster)
 #endif
-            }
             PG_SYNC();  // (the next env's tables overwrite the arena)
         }
     }

@@ -179,7 +179,6 @@ struct GameRotPool<Game, decltype((void)Game::ROT_POOL_FACTOR)> {
 // LDS arena of one render workgroup (one wave)
 template <class Game>
 struct RenderLdsT {
-    uint32_t fb[BAND_ROWS * RES_W + 64];  // the band being rasterized, 0xffRRGGBB (+ a dump row for masked-off lanes)
     // Tables that are never alive together share their words (the arena bounds how many frames a CU renders at a time: 8 KB is the
     // step from four to five waves per SIMD): the per-cell path's axis table `ax` (setup_tile_axes) lies over ci -- a frame is drawn in
     // pull form or cell by cell --, typesz (set-up only) over words 128..191 of the band buffer (idle during the set-up; build_pull_tables
@@ -195,20 +194,29 @@ struct RenderLdsT {
     uint8_t cellimg[GameDrawsGrid<Game>::value ? GamePullCells<Game>::value : 4];
     uint32_t typeany[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of any size: atlas offset | size class<<27 | opaque<<31 (pull form)
     uint32_t fillcmd[GameHasGridFills<Game>::value ? 2 * 256 : 1];  // solid-colour cells of a pull-form frame: (geom, colour) pairs
+    // cell row r of the window (class 0): [0][r] = first screen row | rows covered << 8 | rows with a sample << 16, [1][r] = 16.16 source row
+    // of the first one; every cell row steps by rowstep (cellrows_pass)
+    uint32_t rowrun[GameDrawsGrid<Game>::value ? 2 : 1][32];
+    uint32_t rowstep;
     uint8_t srcx[GameDrawsGrid<Game>::value ? 3 : 1][2][64];    // size classes 1..3: screen column -> source column, per covering slot
     uint16_t srcyw[GameDrawsGrid<Game>::value ? 3 : 1][2][64];  // size classes 1..3: screen row -> source row * image width
     // ---- end of the record's table part
     uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of this frame (build_type_table)
     uint32_t rot[GameUsesRotation<Game>::value ? GameRotPool<Game>::value * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane (by pool slot: ROT_POOL)
+    // the band being rasterized, 0xffRRGGBB (+ a dump row for masked-off lanes).  Last: the prep kernel of a display-list game (pg_prep.h),
+    // which only builds tables -- and uses the first PREP_FB_WORDS words of the band buffer as their scratch -- allocates the arena up to there
+    uint32_t fb[BAND_ROWS * RES_W + 64];
+    static constexpr int PREP_FB_WORDS = 192;
 };
 // Frame record of a display-list game (pg_prep.h): what prep<Game> leaves in HBM for raster<Game>, per env.  Words:
-//   [0, 16)          header: flags, dims (window rows | visible commands << 8 | grid fills << 16), the pull form's column-seam / row-seam /
-//                    row-any masks, the background command (7 words), the atlas' reference cell width
+//   [0, 20)          header: flags, dims (window rows | visible commands << 8 | grid fills << 16), the pull form's column-seam / row-seam /
+//                    row-any masks, the background command (7 words), the atlas' reference cell width, the cell rows that hold an image, the
+//                    16.16 source step of a screen row
 //   [CMD, CMD + 512) up to 64 entity commands in draw order, 8 words each: geom basex srcy ix iy src aux | render_z + 1
 //   [TAB, ...)       the pull form's tables exactly as they lie in the render arena (RenderLdsT [ci, typeimg))
 template <class Game>
 struct FrameRec {
-    enum : int { FLAGS = 0, DIMS = 1, COLSEAM = 2, ROWSEAM = 4, ROWANY = 6, BG = 8, REF_W = 15, HDR_WORDS = 16, CMD = 16, CMD_WORDS = 8, TAB = CMD + 64 * CMD_WORDS };
+    enum : int { FLAGS = 0, DIMS = 1, COLSEAM = 2, ROWSEAM = 4, ROWANY = 6, BG = 8, REF_W = 15, CELLROWS = 16, ROWSTEP = 17, HDR_WORDS = 20, CMD = 20, CMD_WORDS = 8, TAB = CMD + 64 * CMD_WORDS };
     enum : uint32_t { F_FAST = 1u, F_PULL = 2u, F_MULTI = 4u };
     static constexpr int LDS_TAB_WORD0 = (int)(offsetof(RenderLdsT<Game>, ci) / 4);
     static constexpr int TAB_SINGLE_WORDS = (int)((offsetof(RenderLdsT<Game>, srcx) - offsetof(RenderLdsT<Game>, ci) + 3) / 4);
@@ -838,8 +846,10 @@ struct Renderer {
             }
         }
     }
-    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, uint64_t &colseam, uint64_t &rowseam, uint64_t &rowany, bool &multi, int &nfill_out, PG_LANE_ARR_REF(const int, cells0, 4)) {
+    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, uint64_t &colseam, uint64_t &rowseam, uint64_t &rowany, bool &multi, int &nfill_out, uint32_t &cellrows_out, uint32_t &rowstep_out, PG_LANE_ARR_REF(const int, cells0, 4)) {
         nfill_out = 0;
+        cellrows_out = 0;
+        rowstep_out = 0;
         rowany = ~0ull;
         const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
         uint32_t *present = fb;  // scratch: the band buffer is idle during set-up
@@ -847,6 +857,8 @@ struct Renderer {
         PG_R_LANES(l) {
             present[l] = 0;
             lds->ci[0][l] = lds->ci[1][l] = lds->ri[0][l] = lds->ri[1][l] = 0;
+            if (l < 32) lds->rowrun[0][l] = lds->rowrun[1][l] = 0;
+            if (l == 32) lds->rowstep = 0;
             for (int k = 0; k < 3; k++)
                 for (int sl = 0; sl < 2; sl++) {
                     lds->srcx[k][sl][l] = 0xffu;
@@ -1035,6 +1047,11 @@ struct Renderer {
                     int n = n0;
                     const int end = (int)((b + (uint32_t)step * (uint32_t)(n - 1)) >> 16);
                     if (end < 0 || end >= src_len) --n;
+                    if (k == 0 && !col) {  // the cell row's run of screen rows (cellrows_pass)
+                        lds->rowrun[0][idx] = (uint32_t)t1 | ((uint32_t)n0 << 8) | ((uint32_t)n << 16);
+                        lds->rowrun[1][idx] = b;
+                        lds->rowstep = (uint32_t)step;  // (the same value from every row: the cell rects share their height)
+                    }
                     const uint32_t s1 = idx >= 1 ? span[l - 1] : 0u, s2 = idx >= 2 ? span[l - 2] : 0u;
                     for (int j = 0; j < n0; j++) {
                         const int p = t1 + j;
@@ -1074,6 +1091,8 @@ struct Renderer {
             if ((colseam >> l) & 1ull) lds->seamcols[pg_popc64(colseam & pg_mask_lt(l))] = (uint8_t)l;
         }
         PG_SYNC();
+        cellrows_out = cellrows;
+        rowstep_out = (uint32_t)PG_UNIFORM_I(lds->rowstep);
         return true;
     }
     // texel of the cell under one pixel for the column slot sc / row slot sr, branch-free: lanes without a cell fetch
@@ -1101,145 +1120,209 @@ struct Renderer {
         tex = d.pixels[hit ? (cell & 0x7ffffffu) + rel : 0u];
         return hit;
     }
-    // Stages (c0, r0) and (c0, r1) of the pull form: lane = screen column, rows of the band given by `rowmask` (band-relative bits), row
-    // slot sr.  What a pixel ROW needs is wave-uniform: it comes from a lane copy of the band's row entries, one v_readlane per row,
-    // packed so that scalar code takes it apart (covered<<31 | class-0 sample valid<<30 | cell row<<24 | source row * image width).
-    // What a LANE needs -- the image of the cell (its cell column, the row's cell row) -- changes only with the cell row: it is looked
-    // up once per run of pixel rows under one cell row (5 of them for coinrun), not once per pixel; a run whose cell row shows no image
-    // in any column is skipped whole.  Per pixel that leaves: one add, the texel fetch, SourceOver.  (Round 6; the per-pixel lookup chain
-    // of rounds 2-5 -- two LDS reads and ~25 vector instructions a pixel -- was 42 % of the kernel's vector instructions,
-    // profiles/r06_valu_by_phase.txt.)  An opaque cell image needs no case of its own: its texels have alpha 255 and
-    // SourceOver with alpha 255 is the copy (BYTE_MUL(dst, 0) == 0).
-    template <bool MULTI>
-    PG_DEV void cols_pass(int sr, uint32_t rowmask, int ny_full, int ref_w) {
-        constexpr int R = WIDE_ROWS < 8 ? WIDE_ROWS : 8;  // rows per fetch batch
-        PG_LANE_VAR(uint32_t, rw);
+    // Stages (c0, r0) and (c0, r1) of the pull form -- every pixel's first covering cell column, its one or two covering cell rows -- for a
+    // frame whose cell images share one size: CELL ROW by cell row, in draw order (BAG:941-955 walks a column's cells upwards, so of two cell
+    // rows over one screen row the lower index paints first), lane = screen column.  What a lane needs -- the image of its cell in this
+    // cell row -- is looked up once per cell row (~14 a frame), not once per pixel; a screen row then costs the wave a scalar source-row
+    // step and each lane one texel fetch at (lane offset) + (scalar row base).  A cell row whose images are all opaque (ground, walls,
+    // crates: most of a level) stores its texels without SourceOver; one without any image in this window is never visited.  (Round 6:
+    // the per-pixel lookup chain of rounds 2-5 -- two LDS reads and ~25 vector instructions per pixel row -- was 42 % of the kernel's vector
+    // instructions, profiles/r06_valu_by_phase.txt; a first hoisted form that built its row runs in scalar code cost as many scalar
+    // instructions as it saved vector ones, profiles/r06_call3_ab.txt.)
+    PG_DEV void cellrows_pass(int ny_full, int ref_w, uint32_t cellrows, uint32_t rowstep) {
+        constexpr int K = 3;  // cell rows per round: their lookups go out together, then every texel of their rows, then one wait
+        constexpr int R = 6;  // screen rows of a cell row per round (a taller cell row takes another round for the rest)
+        PG_LANE_VAR(uint32_t, run0);
+        PG_LANE_VAR(uint32_t, run1);
+        PG_LANE_VAR(uint32_t, ce);
         PG_R_LANES(l) {
-            const uint32_t re = lds->ri[sr][row0 + (l & (BAND_ROWS - 1))];
-            PG_LV(rw, l) = (re & 0xc0000000u) | (((re >> 12) & 0x1fu) << 24) | (((re & 0xfffu) * (uint32_t)ref_w) & 0xffffffu);
+            PG_LV(run0, l) = lds->rowrun[0][l & 31];
+            PG_LV(run1, l) = lds->rowrun[1][l & 31];
+            PG_LV(ce, l) = lds->ci[0][l];
         }
-        // rows that can draw: covered by a cell row (and, with one image size, holding a sample of it)
-        uint32_t m = rowmask & (uint32_t)PG_BALLOT(l, l < BAND_ROWS && (PG_LV(rw, l) >> 31) != 0 && (MULTI || ((PG_LV(rw, l) >> 30) & 1u) != 0));
+        // cell rows with an image whose sampled rows reach this band
+        uint32_t m = cellrows & (uint32_t)PG_BALLOT(l, l < 32 && (int)(PG_LV(run0, l) & 0xffu) < row1 &&
+                                                           (int)((PG_LV(run0, l) & 0xffu) + ((PG_LV(run0, l) >> 16) & 0xffu)) > row0);
+        int carry = 0;  // rows of the lowest cell row of `m` drawn by earlier rounds
         while (m != 0) {
-            // the next run: up to R rows of `m` under one cell row
-            int ys[R];
-            uint32_t wd[R];
-            int cnt = 0;
-            const int cy = (int)((PG_READLANE(rw, pg_ctz64((uint64_t)m)) >> 24) & 0x1fu);
-            bool open = true;
-            _Pragma("unroll") for (int q = 0; q < R; q++) {
-                ys[q] = 0;
-                wd[q] = 0;
-                if (open && m != 0) {
-                    const int j = pg_ctz64((uint64_t)m);
-                    const uint32_t w = PG_READLANE(rw, j);
-                    if ((int)((w >> 24) & 0x1fu) == cy) {
-                        ys[q] = j;
-                        wd[q] = w;
-                        cnt = q + 1;
+            int cy[K], ya[K], cnt[K];
+            uint32_t acc[K];  // 16.16 source row of the cell row's first screen row of this round
+            _Pragma("unroll") for (int k = 0; k < K; k++) {
+                cy[k] = 0;
+                ya[k] = row0;
+                cnt[k] = 0;
+                acc[k] = 0;
+                if (m != 0) {
+                    const int c = pg_ctz64((uint64_t)m);
+                    const uint32_t w0 = PG_READLANE(run0, c), b0 = PG_READLANE(run1, c);
+                    const int t1 = (int)(w0 & 0xffu), n = (int)((w0 >> 16) & 0xffu);
+                    const int y0 = (t1 > row0 ? t1 : row0) + carry, y1 = (t1 + n) < row1 ? (t1 + n) : row1;
+                    const int left = y1 - y0;
+                    cy[k] = c;
+                    ya[k] = y0;
+                    cnt[k] = left < R ? left : R;
+                    acc[k] = b0 + (uint32_t)(y0 - t1) * rowstep;
+                    if (left <= R) {
                         m &= m - 1u;
+                        carry = 0;
                     } else {
-                        open = false;
+                        carry += R;
                     }
                 }
             }
-            // the lane's cell of this cell row
-            PG_LANE_VAR(uint32_t, cbase);
-            PG_LANE_VAR(uint32_t, chit);  // 0: nothing to draw in this column; 1: class 0; 2..4: size class 1..3
+            // the lanes' cells of these cell rows
+            PG_LANE_ARR(uint32_t, cbase, K);
+            PG_LANE_ARR(uint32_t, chit, K);  // 0: nothing to draw in this column; 1: a translucent image; 3: an opaque one
             PG_R_LANES(l) {
-                const uint32_t ce = lds->ci[0][l];
-                const uint32_t ct = lds->cellimg[((ce >> 12) & 0x1fu) * (uint32_t)ny_full + (uint32_t)cy];
-                const uint32_t cell = ct < 64u ? typeany[ct & 63u] : CELL_NONE;
-                bool h = (ce >> 31) != 0 && cell != CELL_NONE;
-                uint32_t b = (cell & 0x7ffffffu) + (ce & 0xfffu), hk = 1u;
-                if (MULTI) {
-                    const uint32_t k = (cell >> 27) & 3u;  // (CELL_NONE reads class 3: in bounds, never a hit)
-                    const uint32_t sx1 = lds->srcx[k ? k - 1u : 0u][0][l];
-                    h = h && (k ? sx1 != 0xffu : ((ce >> 30) & 1u) != 0);
-                    b = k ? (cell & 0x7ffffffu) + sx1 : b;
-                    hk = 1u + k;
-                } else {
-                    h = h && ((ce >> 30) & 1u) != 0;
+                const uint32_t e = PG_LV(ce, l);
+                _Pragma("unroll") for (int k = 0; k < K; k++) {
+                    const uint32_t ct = lds->cellimg[((e >> 12) & 0x1fu) * (uint32_t)ny_full + (uint32_t)cy[k]];
+                    const uint32_t cell = ct < 64u ? typeany[ct & 63u] : CELL_NONE;
+                    const bool h = cnt[k] > 0 && (e >> 30) == 3u && cell != CELL_NONE;  // covered, and Qt kept the column's sample
+                    PG_LA(cbase, k, l) = h ? (cell & 0x7ffffffu) + (e & 0xfffu) : 0u;  // (a lane without a cell fetches a word of the atlas' first row and draws nothing)
+                    PG_LA(chit, k, l) = h ? 1u | ((cell >> 31) << 1) : 0u;
                 }
-                PG_LV(cbase, l) = h ? b : 0u;  // (a lane without a cell fetches a word near the start of the atlas and blends nothing)
-                PG_LV(chit, l) = h ? (hk | ((cell >> 31) << 3)) : 0u;  // bit 3: the cell's image is opaque
             }
-            if (PG_BALLOT(l, PG_LV(chit, l) != 0) == 0) continue;  // sky
-            // every image of this cell row opaque (ground, walls, crates: most of a level): its texels replace the pixels, no SourceOver
-            const bool all_opaque = PG_BALLOT(l, PG_LV(chit, l) != 0 && (PG_LV(chit, l) & 8u) == 0) == 0;
+            bool opaque[K];
+            _Pragma("unroll") for (int k = 0; k < K; k++) {
+                if (PG_BALLOT(l, PG_LA(chit, k, l) != 0) == 0) cnt[k] = 0;  // (no image of this cell row in the window's columns)
+                opaque[k] = PG_BALLOT(l, PG_LA(chit, k, l) == 1u) == 0;
+            }
+            if (cnt[0] + cnt[1] + cnt[2] == 0) continue;
+            static_assert(K == 3, "the sum above");
             PG_R_LANES(l) {
-                uint32_t tex[R];
-                bool hit[R];
-                const uint32_t b = PG_LV(cbase, l), hk = PG_LV(chit, l) & 7u;
-                _Pragma("unroll") for (int q = 0; q < R; q++) {
-                    tex[q] = 0;
-                    hit[q] = false;
-                    if (q < cnt) {
-                        if (MULTI) {  // a lane of size class k takes its source row from that class's table; Qt may have dropped the row's sample
-                            const uint32_t sy1 = lds->srcyw[hk >= 2u ? hk - 2u : 0u][sr][row0 + ys[q]];
-                            const bool rowhit = hk != 0 && (hk >= 2u ? sy1 != 0xffffu : ((wd[q] >> 30) & 1u) != 0);
-                            const uint32_t t = d.pixels[rowhit ? b + (hk >= 2u ? sy1 : (wd[q] & 0xffffffu)) : 0u];
-                            tex[q] = rowhit ? t : 0u;
-                            hit[q] = rowhit;
-                        } else {
-                            const uint32_t t = d.pixels[b + (wd[q] & 0xffffffu)];
-                            tex[q] = hk != 0 ? t : 0u;
-                            hit[q] = hk != 0;
+                uint32_t tex[K][R];
+                _Pragma("unroll") for (int k = 0; k < K; k++) {
+                    const uint32_t bl = PG_LA(cbase, k, l);
+                    _Pragma("unroll") for (int q = 0; q < R; q++) {
+                        tex[k][q] = 0;
+                        if (q < cnt[k]) {
+                            const uint32_t srow = (acc[k] + (uint32_t)q * rowstep) >> 16;
+                            const uint32_t *rowp = d.pixels + srow * (uint32_t)ref_w;  // wave-uniform
+                            tex[k][q] = rowp[bl];
                         }
                     }
                 }
                 dma_join();  // (the band's background rows, requested before these texels)
-                if (all_opaque) {
-                    _Pragma("unroll") for (int q = 0; q < R; q++) {
-                        if (q < cnt && hit[q]) fb[ys[q] * RES_W + l] = tex[q];  // this lane owns the pixel
-                    }
-                } else {
-                    _Pragma("unroll") for (int q = 0; q < R; q++) {
-                        if (q < cnt) {
-                            uint32_t *dp = &fb[ys[q] * RES_W + l];
-                            *dp = blend(tex[q], *dp, 256, 255u);  // (a transparent texel leaves the pixel as it is: BYTE_MUL(dst, 255) == dst)
+                _Pragma("unroll") for (int k = 0; k < K; k++) {  // in draw order: of two cell rows over one screen row the lower paints first
+                    const bool h = PG_LA(chit, k, l) != 0;
+                    uint32_t *dp = &fb[(ya[k] - row0) * RES_W + l];  // this lane owns the column
+                    if (opaque[k]) {
+                        if (h) {
+                            _Pragma("unroll") for (int q = 0; q < R; q++)
+                                if (q < cnt[k]) dp[q * RES_W] = tex[k][q];
                         }
+                    } else {
+                        _Pragma("unroll") for (int q = 0; q < R; q++)
+                            if (q < cnt[k]) dp[q * RES_W] = blend(h ? tex[k][q] : 0u, dp[q * RES_W], 256, 255u);  // (a transparent texel leaves the pixel as it is: BYTE_MUL(dst, 255) == dst)
                     }
                 }
             }
             PG_SYNC();
         }
     }
+    // the same two stages pixel by pixel, for a frame with cell images of several sizes (maze, miner): a band of fetches in flight
     template <bool MULTI>
-    PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam, uint64_t rowany, int ref_w) {
+    PG_DEV void rows_pass_by_pixel(int ny_full, int ref_w, uint32_t band_any, uint32_t band_seam) {
+        // stage 1: (c0, r0), lane = screen column
+        for (int yb = row0; yb < row1; yb += WIDE_ROWS) {
+            if (((band_any >> (yb - row0)) & ((1u << WIDE_ROWS) - 1u)) == 0) continue;
+            PG_R_LANES(l) {
+                const uint32_t ce = lds->ci[0][l];
+                uint32_t tex[WIDE_ROWS];
+                bool hit[WIDE_ROWS], opq[WIDE_ROWS];
+                _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
+                    opq[j] = false;
+                    tex[j] = 0;
+                    hit[j] = pull_fetch<MULTI>(ce, lds->ri[0][yb + j], 0, 0, l, yb + j, ny_full, ref_w, tex[j], opq[j]);
+                }
+                dma_join();  // (the band's background rows, requested before these texels)
+                _Pragma("unroll") for (int j = 0; j < WIDE_ROWS; j++) {
+                    uint32_t *dp = &fb[(yb + j - row0) * RES_W + l];  // this lane owns the pixel
+                    const uint32_t old = *dp;
+                    const uint32_t over = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
+                    *dp = hit[j] ? over : old;
+                }
+            }
+            PG_SYNC();
+        }
+        // stage 2: (c0, r1) on the doubly covered rows only, four of them per round; stage 4 walks the same rows
+        for (uint32_t m = band_seam; m != 0;) {
+            int ys[4], cnt = 0;
+            _Pragma("unroll") for (int q = 0; q < 4; q++) {
+                ys[q] = row0;
+                if (m != 0) {
+                    ys[q] = row0 + pg_ctz64((uint64_t)m);
+                    m &= m - 1u;
+                    cnt = q + 1;
+                }
+            }
+            PG_R_LANES(l) {
+                const uint32_t ce = lds->ci[0][l];
+                uint32_t tex[4];
+                bool hit[4], opq[4];
+                _Pragma("unroll") for (int q = 0; q < 4; q++) {
+                    opq[q] = false;
+                    tex[q] = 0;
+                    hit[q] = false;
+                    if (q < cnt) hit[q] = pull_fetch<MULTI>(ce, lds->ri[1][ys[q]], 0, 1, l, ys[q], ny_full, ref_w, tex[q], opq[q]);
+                }
+                dma_join();
+                _Pragma("unroll") for (int q = 0; q < 4; q++) {
+                    if (q < cnt) {
+                        uint32_t *dp = &fb[(ys[q] - row0) * RES_W + l];
+                        const uint32_t old = *dp;
+                        const uint32_t over = opq[q] ? tex[q] : blend(tex[q], old, 256, 255u);
+                        *dp = hit[q] ? over : old;
+                    }
+                }
+            }
+            PG_SYNC();
+        }
+    }
+    template <bool MULTI, int NJ>
+    PG_DEV void seam_cols_round(int base, int npx, uint32_t inv, int nseam, int ny_full, int ref_w) {
+        PG_R_LANES(l) {
+            uint32_t tex[NJ];
+            int fbi[NJ];
+            bool opq[NJ];
+            _Pragma("unroll") for (int j = 0; j < NJ; j++) {
+                const int p = base + j * 64 + l;
+                const bool in = p < npx;
+                const int pc = in ? p : 0;
+                const int yl = (int)(((uint32_t)pc * inv) >> 20);
+                const int x = (int)lds->seamcols[pc - yl * nseam];
+                const bool hit = pull_fetch<MULTI>(lds->ci[1][x], lds->ri[0][row0 + yl], 1, 0, x, row0 + yl, ny_full, ref_w, tex[j], opq[j]) && in;
+                fbi[j] = hit ? yl * RES_W + x : BAND_ROWS * RES_W + l;  // masked-off lanes use the dump row
+            }
+            dma_join();
+            _Pragma("unroll") for (int j = 0; j < NJ; j++) {
+                const uint32_t old = fb[fbi[j]];
+                fb[fbi[j]] = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
+            }
+        }
+        PG_SYNC();
+    }
+    template <bool MULTI>
+    PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam, uint64_t rowany, int ref_w, uint32_t cellrows, uint32_t rowstep) {
         const int nseam = pg_popc64(colseam);
         const uint32_t band_any = (uint32_t)((rowany >> row0) & ((1ull << BAND_ROWS) - 1ull));
         if (band_any == 0) return;  // no cell with an image reaches these rows (sky)
         const uint32_t band_seam = (uint32_t)((rowseam >> row0) & ((1ull << BAND_ROWS) - 1ull)) & band_any;
-        cols_pass<MULTI>(0, band_any, ny_full, ref_w);                    // stage 1: (c0, r0)
-        if (band_seam != 0) cols_pass<MULTI>(1, band_seam, ny_full, ref_w);  // stage 2: (c0, r1) on the doubly covered rows
+        // stages 1 and 2: (c0, r0), and (c0, r1) on the doubly covered rows
+        if (MULTI) rows_pass_by_pixel<MULTI>(ny_full, ref_w, band_any, band_seam);
+        else cellrows_pass(ny_full, ref_w, cellrows, rowstep);
         if (nseam == 0) return;
-        // stage 3: (c1, r0): the doubly covered columns x the band's rows, laid out linearly over the lanes, four per lane and round
+        // stage 3: (c1, r0): the doubly covered columns x the band's rows, laid out linearly over the lanes, one, two or four pixels per lane
+        // and round (coinrun shows two or three such columns, 48 pixels a band: a four-deep round spent three quarters of its instructions
+        // on lanes without a pixel, profiles/r06_raster_ablation.txt)
         {
             const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)nseam - 1u) / (uint32_t)nseam);
             const int npx = nseam * BAND_ROWS;
-            for (int base = 0; base < npx; base += 256) {
-                PG_R_LANES(l) {
-                    uint32_t tex[4];
-                    int fbi[4];
-                    bool opq[4];
-                    _Pragma("unroll") for (int j = 0; j < 4; j++) {
-                        const int p = base + j * 64 + l;
-                        const bool in = p < npx;
-                        const int pc = in ? p : 0;
-                        const int yl = (int)(((uint32_t)pc * inv) >> 20);
-                        const int x = (int)lds->seamcols[pc - yl * nseam];
-                        const bool hit = pull_fetch<MULTI>(lds->ci[1][x], lds->ri[0][row0 + yl], 1, 0, x, row0 + yl, ny_full, ref_w, tex[j], opq[j]) && in;
-                        fbi[j] = hit ? yl * RES_W + x : BAND_ROWS * RES_W + l;  // masked-off lanes use the dump row
-                    }
-                    dma_join();
-                    _Pragma("unroll") for (int j = 0; j < 4; j++) {
-                        const uint32_t old = fb[fbi[j]];
-                        fb[fbi[j]] = opq[j] ? tex[j] : blend(tex[j], old, 256, 255u);
-                    }
-                }
-                PG_SYNC();
-            }
+            if (npx <= 64) seam_cols_round<MULTI, 1>(0, npx, inv, nseam, ny_full, ref_w);
+            else if (npx <= 128) seam_cols_round<MULTI, 2>(0, npx, inv, nseam, ny_full, ref_w);
+            else
+                for (int base = 0; base < npx; base += 256) seam_cols_round<MULTI, 4>(base, npx, inv, nseam, ny_full, ref_w);
         }
         // stage 4: (c1, r1): doubly covered columns x doubly covered rows; lane = seam column, four rows per round
         for (uint32_t m = band_seam; m != 0;) {
@@ -1385,10 +1468,12 @@ struct Renderer {
         PG_R_LANES(l) {
             const bool in = l < c.w;
             const uint32_t *col = src + (int)((c.basex + (uint32_t)(in ? l : 0) * c.ix) >> 16);
-            for (int y = y0; y < y1; y++) {
-                const int syp = (int)((c.srcy0 + (uint32_t)(y - c.ty1) * c.iy) >> 16);
-                uint32_t *row = &fb[(y - row0) * RES_W + c.tx1];
-                if (in) PG_DMA_DWORD(col + syp * sw, row, l);
+            if (in) {  // (one exec mask for the band's rows, not one per row)
+                uint32_t acc = c.srcy0 + (uint32_t)(y0 - c.ty1) * c.iy;
+                for (int y = y0; y < y1; y++, acc += c.iy) {
+                    uint32_t *row = &fb[(y - row0) * RES_W + c.tx1];
+                    PG_DMA_DWORD(col + (int)(acc >> 16) * sw, row, l);
+                }
             }
         }
     }
@@ -2267,7 +2352,7 @@ struct Renderer {
         EntPre epre;
         request_entity_fields(epre);
         {
-            const EnvHdr *h = d.hdr + env;
+            const auto *h = PG_SCALAR_PTR(EnvHdr, d.hdr + env);  // (written by this step's step kernels, read-only here: scalar loads)
 #define PG_X(type, name) G.name = h->name;
             PG_HDR_FIELDS(PG_X)
 #undef PG_X
@@ -2392,8 +2477,9 @@ struct Renderer {
         phase(10);
         bool pull = false, pull_multi = false;
         int pull_nfill = 0;
+        uint32_t pull_cellrows = 0, pull_rowstep = 0;
         if constexpr (GameDrawsGrid<Game>::value)
-            pull = try_pull && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, pull_multi, pull_nfill, cells0);
+            pull = try_pull && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, pull_multi, pull_nfill, pull_cellrows, pull_rowstep, cells0);
 
         if (use_axes && !pull) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);  // only the per-cell path reads the axis tables
 
@@ -2496,8 +2582,8 @@ struct Renderer {
             phase(2);
             if constexpr (GameDrawsGrid<Game>::value)
                 if (pull && !PG_DBG(d, 2)) {
-                    if (pull_multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w);
-                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w);
+                    if (pull_multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w, pull_cellrows, pull_rowstep);
+                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w, pull_cellrows, pull_rowstep);
                     if constexpr (GameHasGridFills<Game>::value) draw_pull_fills(pull_nfill);
                 }
             for (int base = 0; base < ncell; base += 64) {
@@ -2637,6 +2723,7 @@ struct Renderer {
         const uint32_t bg_geom = rec[Rec::BG], bg_basex = rec[Rec::BG + 1], bg_srcy = rec[Rec::BG + 2], bg_ix = rec[Rec::BG + 3], bg_iy = rec[Rec::BG + 4],
                        bg_src = rec[Rec::BG + 5], bg_aux = rec[Rec::BG + 6];
         const int ref_w = (int)rec[Rec::REF_W];
+        const uint32_t cellrows = rec[Rec::CELLROWS], rowstep = rec[Rec::ROWSTEP];
         const int ny_full = (int)(dims & 0xffu), ncmd = (int)((dims >> 8) & 0xffu), nfill = (int)(dims >> 16);
         const bool pull = (flags & Rec::F_PULL) != 0, multi = (flags & Rec::F_MULTI) != 0;
         G.error = 0;
@@ -2682,21 +2769,22 @@ struct Renderer {
                 }
             }
             PG_SYNC();
-            if (bg_geom != 0 && bc0.ty1 < row1 && bc0.ty1 + bc0.h > row0) {
+            if (bg_geom != 0 && bc0.ty1 < row1 && bc0.ty1 + bc0.h > row0 && !PG_DBG(d, 1)) {
                 if (bg_dma) exec_bg_dma(bc0);
                 else exec_large(bc0);
             }
-            if (ez0) run_batch(er, ez0);
+            if (ez0 && !PG_DBG(d, 4)) run_batch(er, ez0);
             if constexpr (GameDrawsGrid<Game>::value) {
-                if (pull) {
-                    if (multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w);
-                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w);
+                if (pull && !PG_DBG(d, 2)) {
+                    if (multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w, cellrows, rowstep);
+                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w, cellrows, rowstep);
                     if constexpr (GameHasGridFills<Game>::value) draw_pull_fills(nfill);
                 }
             }
-            if (ez1 | ez2) run_batch(er, ez1, ez2);  // z = 0, then z = 1, in one pass
+            if ((ez1 | ez2) && !PG_DBG(d, 4)) run_batch(er, ez1, ez2);  // z = 0, then z = 1, in one pass
             PG_SYNC();
-            store_band();
+            if (!PG_DBG(d, 8)) store_band();
+            else dma_join();
             PG_SYNC();
         }
 #if defined(PGAMD_WAVE_EMU)

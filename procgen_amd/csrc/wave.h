@@ -217,6 +217,15 @@ PG_DEV uint32_t pg_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __built
 
 #endif
 
+// A wave-uniform pointer to data no kernel in flight writes (an env's header inside the render kernels, the asset tables): loads through it are
+// scalar loads (constant address space), whatever stores the kernel has made before -- the compiler otherwise falls back to a vector load
+// plus a v_readfirstlane per word as soon as any store precedes the load (69 header words per frame, round 6).
+#if defined(PGAMD_WAVE_EMU)
+#define PG_SCALAR_PTR(T, p) (static_cast<const T *>(p))
+#else
+#define PG_SCALAR_PTR(T, p) ((const __attribute__((address_space(4))) T *)(uintptr_t)(p))
+#endif
+
 // A value the optimizer must take as it is.  Choosing one of several adjacent struct fields with a ?: chain otherwise
 // becomes ONE load at a computed offset, which pins the whole per-env state struct in scratch memory instead of registers.
 #if defined(PGAMD_WAVE_EMU)

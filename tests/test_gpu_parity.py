@@ -459,10 +459,10 @@ def display_list_frames(env):
 @pytest.mark.gpu
 def test_display_list_frames_equal_the_full_renderer(monkeypatch):
     """coinrun draws a frame with prep -> raster kernels (pg_prep.h: the frame's draw commands and pull tables are built ahead, densely, and
-    the rasterizer draws from the record); the frames the short path cannot draw are queued for the full renderer (render_list).  Same
+    the rasterizer draws from the record); the frames the short path cannot draw are drawn by the full renderer inside the prep kernel.  Same
     frames as the one-kernel renderer (PROCGEN_AMD_DISPLAY_LIST=0) and as the oracle, at sizes that are not multiples of the four envs a
-    prep wave takes and that span two launch chunks, with the launch order rebuilt on the way; and with every frame sent through the slow
-    list (PROCGEN_AMD_DEBUG & 1048576), which is what a frame with an unusual draw does."""
+    prep wave takes and that span two launch chunks, with the launch order rebuilt on the way; and with every frame sent to the full
+    renderer (PROCGEN_AMD_DEBUG & 1048576), which is what a frame with an unusual draw does."""
     for n, steps in ((4099, 60), (37, 120), (1, 40)):
         acts = action_stream(n, steps, seed=29)
         monkeypatch.setenv("PROCGEN_AMD_DISPLAY_LIST", "0")
@@ -482,7 +482,7 @@ def test_display_list_frames_equal_the_full_renderer(monkeypatch):
         assert display_list_frames(env) == (0, n)
         slow = rollout(env, acts)
         monkeypatch.delenv("PROCGEN_AMD_DEBUG")
-        assert_rollouts_equal(want, slow, f"coinrun N={n}: every frame through the slow list")
+        assert_rollouts_equal(want, slow, f"coinrun N={n}: every frame by the full renderer inside prep")
         if n == 37:
             orc = oracle_env.OracleEnv(n, "coinrun", rand_seed=23)
             assert_rollouts_equal(rollout(orc, acts), got, "coinrun N=37: display list vs oracle")
@@ -502,3 +502,65 @@ def test_display_list_with_options_that_leave_the_short_path():
         assert counts is not None and ((counts[0] >= n - 2) if fast else (counts[0] == 0)), (kw, counts)
         orc = oracle_env.OracleEnv(n, "coinrun", rand_seed=23, **kw)
         assert_rollouts_equal(rollout(orc, acts), rollout(env, acts), f"coinrun {kw}: display list vs oracle")
+
+
+STATE_PROTOCOL_STEPS = int(os.environ.get("PROCGEN_AMD_STATE_PROTOCOL_STEPS", "10000"))  # reference procgen/state_test.py:9 NUM_STEPS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game", GAMES)
+def test_reference_state_protocol_at_its_own_length(game):
+    """The reference's own state test at its own length (procgen/state_test.py:65-124, `@skip("slow")` upstream): 2 envs, rand_seed 0,
+    10 000 random steps.  (1) two fresh runs are identical; (2) a run that saves the state at every step sees the same rollout, and two
+    such runs the same states; (3) saving AND restoring at every step is transparent; (4) the midpoint state restored into a handle made
+    with another rand_seed resumes the remainder -- observations, rewards, firsts, infos and states."""
+    import zlib
+
+    n, steps = 2, STATE_PROTOCOL_STEPS
+    rng = np.random.RandomState(0)
+    actions = [rng.randint(0, 15, size=(n,)).astype(np.int32) for _ in range(steps)]
+
+    def gather(rand_seed, acts, state=None, get_state=False, set_state_every_step=False):
+        env = make_env(n, game, rand_seed=rand_seed)
+        if state is not None:
+            env.set_state(state)
+        out = {"crc": [], "rew": [], "first": [], "info": [], "state": []}
+
+        def record():
+            rew, ob, first = env.observe()
+            info = env.info_arrays()
+            out["crc"].append([zlib.crc32(ob["rgb"][e].tobytes()) for e in range(n)])
+            out["rew"].append(np.array(rew, copy=True))
+            out["first"].append(np.array(first, copy=True))
+            out["info"].append([np.array(info[k], copy=True) for k in ("prev_level_seed", "prev_level_complete", "level_seed")])
+            if get_state:
+                out["state"].append(env.get_state())
+            if set_state_every_step:
+                env.set_state(out["state"][-1])
+
+        record()
+        for a in acts:
+            env.act(a)
+            record()
+        env.close()
+        return {k: (np.array(v) if k != "state" else v) for k, v in out.items()}
+
+    def same(a, b, lo=0, what=""):
+        for k in ("crc", "rew", "first", "info"):
+            assert np.array_equal(a[k][lo:], b[k]), f"{game}: {what}: {k} differs"
+        if a["state"] and b["state"]:
+            assert a["state"][lo:] == b["state"], f"{game}: {what}: states differ"
+
+    ref = gather(0, actions)
+    same(ref, gather(0, actions), what="second run")
+    st = gather(0, actions, get_state=True)
+    same(ref, st, what="run that saves states")
+    st2 = gather(0, actions, get_state=True)
+    same(st, st2, what="states of two runs")
+    st3 = gather(0, actions, get_state=True, set_state_every_step=True)
+    same(ref, st3, what="save and restore at each step")
+    same(st, st3, what="states under save and restore at each step")
+    off = steps // 2
+    rest = gather(1, actions[off:], state=st["state"][off], get_state=True)
+    same(ref, rest, lo=off, what="midpoint restore into another seed")
+    same(st, rest, lo=off, what="states after the midpoint restore")
