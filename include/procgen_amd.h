@@ -96,6 +96,11 @@ LIBENV_API int procgen_amd_tier_counts(libenv_env *handle, int *out);
 LIBENV_API int procgen_amd_render_order(libenv_env *handle, int *out, int max_envs, int *chunk_out);
 LIBENV_API void procgen_amd_selftest_render_order_slots(int count, int *out);
 
+/* set_state for envs [first, first + count) in one call: state j is the bytes data[offsets[j], offsets[j + 1]) -- the streams get_state /
+ * procgen_amd_get_states produce.  Same result as `count` set_state calls (reference procgen/env.py:148-153, src/vecgame.cpp:447-456: the
+ * reference loops per env); consecutive envs are uploaded block-wise and redrawn by one render launch. */
+LIBENV_API void procgen_amd_set_states(libenv_env *handle, int first, int count, const char *data, const long long *offsets);
+
 /* Display-list games (the frame is drawn by prep -> raster kernels, and by the full renderer for the frames the short
  * path cannot draw).  out[0] = envs whose current frame came from its record, out[1] = envs whose frame the full renderer drew.  Returns 1,
  * or 0 for a handle that renders with one kernel (out untouched).  Single-part handles. */

@@ -16,6 +16,7 @@ struct CoinRun {
     static constexpr int WIDE_ROWS = 8;
     static constexpr int RENDER_MIN_WAVES = 5;     // 96 VGPRs, no scratch (tests/test_no_scratch_memory.py), LDS 8068 B: five render waves per SIMD
     static constexpr bool DISPLAY_LIST = true;     // frames are drawn prep -> raster (pg_prep.h)
+    static constexpr bool PULL_SINGLE_SIZE = true; // every cell image is 64 x 64 (kenney tiles): no size-class tables in the render arena
     static constexpr int PULL_CELLS = 16 * 16;     // the centred window spans visibility / 2 + 1 = 7.5 cells either side of the agent (BAG:926-933)
     static constexpr bool USES_ENTITY_COLLISIONS = false;  // no entity sets collides_with_entities
     // Worst-case entity count: 5 pit sections x 7 walking enemies x (1 + 9 live trails) + agent = 351.

@@ -28,7 +28,7 @@ int chunk_envs_for(int num_envs, int chunks);  // envs per chunk: whole tiles; o
 struct GameEntry {
     int game_id;
     hipError_t (*launch)(const DevCtx &, int mode, const LaunchStreams &);
-    hipError_t (*render_one)(const DevCtx &, int env, hipStream_t);
+    hipError_t (*render_one)(const DevCtx &, int env, int count, hipStream_t);  // redraws envs [env, env + count) with the full renderer
     int cap_t0, cap_t1, cap_t2;  // entity slots of the three LDS arenas; cap_t2 is the HBM table size
     int grid_bytes;
     void (*init_state)(int num_envs, int rand_seed, int env_offset, int env_stride, EnvHdr *hdr, uint32_t *rng);
@@ -41,7 +41,7 @@ struct GameEntry {
 constexpr int MAX_GAME_TABLE_WORDS = 2048;
 // mode 0: initial reset + first observation of every env; mode 1: one step
 hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStreams &ls);
-hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream);
+hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream, int count = 1);
 hipError_t launch_render_human(int game_id, const DevCtx &d, int env_base, int count, hipStream_t stream);
 bool game_supported(int game_id);
 int game_tier_for(int game_id, int slots_needed);

@@ -30,9 +30,9 @@ hipError_t launch_step(int game_id, const DevCtx &d, int mode, const LaunchStrea
     const GameEntry *e = find(game_id);
     return e ? e->launch(d, mode, ls) : hipErrorInvalidValue;
 }
-hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream) {
+hipError_t launch_render_one(int game_id, const DevCtx &d, int env, hipStream_t stream, int count) {
     const GameEntry *e = find(game_id);
-    return e ? e->render_one(d, env, stream) : hipErrorInvalidValue;
+    return e ? e->render_one(d, env, count, stream) : hipErrorInvalidValue;
 }
 hipError_t launch_render_human(int game_id, const DevCtx &d, int env_base, int count, hipStream_t stream) {
     const GameEntry *e = find(game_id);

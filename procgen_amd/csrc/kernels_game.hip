@@ -119,52 +119,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GEN ? 1 : Ga
     r.render_env();
     if (PG_RENDER_TRACE) trace_wave(d, env, 4, true, 8);
 }
-// ---- display-list games (pg_prep.h): prep -> raster ----
-#ifndef PG_PREP_WAVES
-#define PG_PREP_WAVES 1
-#endif
+// ---- display-list games (pg_prep.h): prep -> raster -> render_list ----
 template <class Game>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_PREP_WAVES))) void prep(DevCtx d, int env_base, int count) {
-    // the render arena without its band buffer (but for the words the table builders use as scratch): 4 KB instead of 7.6 KB for coinrun,
+__global__ __launch_bounds__(64) void prep(DevCtx d, int env_base, int count, int chunk) {
+    // the render arena without its band buffer (but for the words the table builders use as scratch): 2.9 KB instead of 6.2 KB for coinrun,
     // i.e. eight waves of this latency-bound kernel per SIMD instead of five
     __shared__ __attribute__((aligned(16))) uint32_t arena[offsetof(RenderLdsT<Game>, fb) / 4 + RenderLdsT<Game>::PREP_FB_WORDS];
     RenderLdsT<Game> *lds = reinterpret_cast<RenderLdsT<Game> *>(arena);
     const int env0 = env_base + (int)blockIdx.x * PREP_ENVS;
     const int left = env_base + count - env0;
-    FramePrep<Game> p(d, lds);
+    FramePrep<Game> p(d, lds, d.slow_count + d.step_parity * MAX_CHUNKS + chunk, d.slow_list + env_base);
     p.run(env0, left < PREP_ENVS ? left : PREP_ENVS);
 }
+// (no occupancy hint and no full renderer in here: 59 VGPRs, so the arena alone bounds the waves per SIMD -- six for coinrun against five
+// with render_env inside, +3.4 % steps/s, profiles/r06_call11_ab.txt)
 template <class Game>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GameRenderMinWaves<PG_GAME>::value))) void raster(DevCtx d, int env_base) {
+__global__ __launch_bounds__(64) void raster(DevCtx d, int env_base, int chunk) {
     __shared__ RenderLdsT<Game> lds;
     const int slot = env_base + (int)blockIdx.x;
     const int env = d.render_order ? __builtin_amdgcn_readfirstlane(d.render_order[slot]) : slot;
     // (the record is read before this kernel's first store: the wave-uniform loads of its header are then scalar loads, not vector loads
     // followed by a v_readfirstlane each)
-    Renderer<Game, false> r(d, env, &lds);
-    // (a frame the short path cannot draw -- a fraction of a percent, or all of them under options like center_agent = false -- takes the full
-    // renderer here: the arena bounds this kernel at five waves per SIMD, so the full renderer's registers cost it no occupancy, while inside
-    // prep they did (57 -> 96+ VGPRs), and a list kernel behind this one cost every launch ~110 us, profiles/r06_call3_timeline.txt)
-    if ((d.frame_rec[(size_t)env * FrameRec<Game>::WORDS + FrameRec<Game>::FLAGS] & FrameRec<Game>::F_FAST) != 0) r.raster_env();
-#if !defined(PG_RASTER_NO_SLOW)  // (measurement builds only: what the full renderer's presence costs this kernel)
-    else r.render_env();
-#endif
+    if ((d.frame_rec[(size_t)env * FrameRec<Game>::WORDS + FrameRec<Game>::FLAGS] & FrameRec<Game>::F_FAST) != 0) {  // (else: on the chunk's slow list)
+        Renderer<Game, false> r(d, env, &lds);
+        r.raster_env();
+    }
     if (d.clear_lists && blockIdx.x == 0 && threadIdx.x < LIST_COUNTERS) const_cast<int *>(d.big_count)[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.slow_count[(d.step_parity ^ 1) * MAX_CHUNKS + chunk] = 0;  // the next step's counter of this chunk
+}
+// the frames of a chunk the rasterizer's short path cannot draw: the full renderer, a small grid walking the chunk's slow list
+template <class Game>
+__global__ __launch_bounds__(64) void render_list(DevCtx d, int env_base, int chunk) {
+    __shared__ RenderLdsT<Game> lds;
+    const int count = d.slow_count[d.step_parity * MAX_CHUNKS + chunk];
+    for (int k = (int)blockIdx.x; k < count; k += (int)gridDim.x) {
+        Renderer<Game, false> r(d, __builtin_amdgcn_readfirstlane(d.slow_list[env_base + k]), &lds);
+        r.render_env();
+        __syncthreads();
+    }
 }
 // clear_lists: this is the step's render of env 0 (every list kernel of the step is done when a render kernel starts); a
 // hipMemsetAsync per step instead was two fill kernels, each tens of microseconds on a busy device with many handles
 // t0 / t1 (null: off): events recorded around the launch of the frame kernel proper -- render, or raster for a display-list game -- on its
 // stream (procgen_amd_kernel_timing: the dominant kernel's own duration)
 template <class Game>
-static void launch_render(const DevCtx &d0, int env_base, int count, hipStream_t st, bool clear_lists = false, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+static void launch_render(const DevCtx &d0, int env_base, int count, hipStream_t st, bool clear_lists = false, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, int chunk = 0) {
     DevCtx d = d0;
     d.clear_lists = clear_lists ? 1 : 0;
     if constexpr (GameDisplayList<Game>::value) {
         if (d.frame_rec && !d.gen_bg) {
-            hipLaunchKernelGGL(prep<Game>, dim3((count + PREP_ENVS - 1) / PREP_ENVS), dim3(64), 0, st, d, env_base, count);
+            hipLaunchKernelGGL(prep<Game>, dim3((count + PREP_ENVS - 1) / PREP_ENVS), dim3(64), 0, st, d, env_base, count, chunk);
             if (t0) (void)hipEventRecord(t0, st);
-            hipLaunchKernelGGL(raster<Game>, dim3(count), dim3(64), 0, st, d, env_base);
+            hipLaunchKernelGGL(raster<Game>, dim3(count), dim3(64), 0, st, d, env_base, chunk);
             if (t1) (void)hipEventRecord(t1, st);
+            hipLaunchKernelGGL(render_list<Game>, dim3(count < 128 ? count : 128), dim3(64), 0, st, d, env_base, chunk);
             return;
         }
     }
@@ -263,7 +271,7 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         // rew / first / info of this chunk's envs, and the list counters, are final here (step, list and reset kernels done): what the
         // early download of the step's small outputs waits for (libenv_hip.cpp VecGame::launch)
         if (ls.outputs_done[c]) PG_TRY(hipEventRecord(ls.outputs_done[c], st));
-        if (!(d.debug_flags & 16)) launch_render<Game>(d, base, count, st, c == 0, ls.render_t0[c], ls.render_t1[c]);
+        if (!(d.debug_flags & 16)) launch_render<Game>(d, base, count, st, c == 0, ls.render_t0[c], ls.render_t1[c], c);
         if (ls.frames_done[c]) PG_TRY(hipEventRecord(ls.frames_done[c], st));
     }
     for (int k = 0; k < 2; k++) {
@@ -289,11 +297,11 @@ static hipError_t launch_human(const DevCtx &d, int env_base, int count, hipStre
 }
 
 template <class Game>
-static hipError_t render_one(const DevCtx &d, int env, hipStream_t stream) {  // re-renders one env (after set_state)
+static hipError_t render_one(const DevCtx &d, int env, int count, hipStream_t stream) {  // re-renders envs [env, env + count) (after set_state / set_states)
     DevCtx d1 = d;
-    d1.render_order = nullptr;  // (env is the env itself here, not a slot of a chunk launch)
-    d1.frame_rec = nullptr;     // (and the full renderer draws it)
-    launch_render<Game>(d1, env, 1, stream);
+    d1.render_order = nullptr;  // (the envs themselves, not slots of a chunk launch)
+    d1.frame_rec = nullptr;     // (and the full renderer draws them)
+    launch_render<Game>(d1, env, count, stream);
     return hipGetLastError();
 }
 

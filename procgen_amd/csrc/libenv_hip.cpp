@@ -265,6 +265,8 @@ struct VecGame {
     uint8_t *d_route[2] = {nullptr, nullptr};
     // PROCGEN_AMD_RENDER_ORDER=K (experiment, off by default): every K steps the render kernel's workgroup -> env map of each launch
     // chunk is re-sorted by background image, images dealt to the XCDs (workgroup j runs on XCD j mod 8, each with its own L2)
+    uint32_t *d_frame_rec = nullptr;  // display-list games: the frame records (DevCtx::frame_rec, null once the handle has gone back to the one-kernel renderer)
+    int slow_streak = 0;              // steps seen to send most frames to the full renderer's list kernel
     int render_order_period = 0;
     int *d_render_order = nullptr, *d_render_order_scratch = nullptr;
     void rebuild_render_order();
@@ -321,6 +323,7 @@ struct VecGame {
     bool load_snapshot_block(int env_idx);                              // the 256-env block of env_idx into the snapshot cache (joins the pending step)
     bool serialize_cached(int env_idx, std::string *out, std::string *err) const;  // env_idx must lie in the cached block; touches no shared state (callable from several threads)
     void set_state(int env_idx, const char *data, int length);
+    void set_states(int first, int count, const char *data, const long long *offsets);  // consecutive envs of one snapshot block
     void snapshot(int env_idx, EnvSnapshot *s, bool single = false);
     static constexpr int SNAP_BLOCK = 256;
     int snap_first = -1, snap_count = 0;  // envs [snap_first, snap_first + snap_count) of the snapshot cache; -1: stale
@@ -565,7 +568,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     d_action = dev_alloc<int32_t>(N);
     d.action = d_action;
     d.obs = dev_alloc<uint8_t>(N * OBS_BYTES);
-    small_bytes = N * 14 + 4 + (2 * LIST_COUNTERS + 1 + ERROR_INFO_WORDS) * sizeof(int);
+    constexpr size_t TAIL_WORDS = 2 * LIST_COUNTERS + 1 + ERROR_INFO_WORDS + 2 * MAX_CHUNKS;  // list counters A, error word, counters B, error record, slow-list counters
+    small_bytes = N * 14 + 4 + TAIL_WORDS * sizeof(int);
     d_small = dev_alloc<uint8_t>(small_bytes);
     d.rew = (float *)d_small;
     d.prev_level_seed = (int32_t *)(d_small + 4 * N);
@@ -586,7 +590,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
         const int words[2] = {(int)(unsigned)(a & 0xffffffffull), (int)(unsigned)(a >> 32)};
         HIP_CHECK(hipMemcpy(d.error + ERROR_INFO_OFFSET + 6, words, sizeof(words), hipMemcpyHostToDevice));
     }
-    small_bytes = tail_off + (2 * LIST_COUNTERS + 1 + ERROR_INFO_WORDS) * sizeof(int);
+    small_bytes = tail_off + TAIL_WORDS * sizeof(int);
+    d.slow_count = (int *)(d_small + tail_off) + 2 * LIST_COUNTERS + 1 + ERROR_INFO_WORDS;
     for (int k = 0; k < 2; k++) {
         d_big_list[k] = dev_alloc<int>(N * NUM_TIERS);
         d_big_count[k] = (int *)(d_small + tail_off) + (LIST_COUNTERS + 1) * k;  // A, then the error word, then B
@@ -602,7 +607,8 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     }
     // display-list games (pg_prep.h): a frame record per env
     if (const int rec_words = game_frame_rec_words(kernel_id); rec_words > 0 && !o.use_generated_assets && !(getenv("PROCGEN_AMD_DISPLAY_LIST") && atoi(getenv("PROCGEN_AMD_DISPLAY_LIST")) == 0)) {
-        d.frame_rec = dev_alloc<uint32_t>(N * (size_t)rec_words);
+        d.frame_rec = d_frame_rec = dev_alloc<uint32_t>(N * (size_t)rec_words);
+        d.slow_list = dev_alloc<int>(N);
     }
     d.assets = atlas->d_assets;
     d.pixels = atlas->d_pixels;
@@ -705,7 +711,8 @@ VecGame::~VecGame() {
     }
     (void)hipFree(d_reset_list);
     (void)hipFree(d_reset_count);
-    if (d.frame_rec) (void)hipFree(d.frame_rec);
+    if (d_frame_rec) (void)hipFree(d_frame_rec);
+    if (d.slow_list) (void)hipFree(d.slow_list);
     if (d_render_order) (void)hipFree(d_render_order);
     if (d_render_order_scratch) (void)hipFree(d_render_order_scratch);
     if (h_action) (void)hipHostFree(h_action);
@@ -816,6 +823,7 @@ void VecGame::launch_kernels(int mode) {
     LaunchStreams ls = streams();
     for (int c = 0; c < MAX_CHUNKS; c++)
         for (int t = 0; t < NUM_TIERS; t++) ls.list_count[c][t] = mode == 0 ? 0 : host_list_count[c][t];
+    d.step_parity = (int)(step_count & 1);  // (display-list games: which of the two slow-list counter sets this step fills)
     HIP_CHECK(launch_step(kernel_id, d, mode, ls));
     step_count++;
 }
@@ -828,6 +836,16 @@ void VecGame::read_tail() {
     for (int c = 0; c < MAX_CHUNKS; c++)
         for (int t = 0; t < NUM_TIERS; t++) host_list_count[c][t] = cnt[c * NUM_TIERS + t];
     if (err && !d.debug_flags) report_device_error(err, tail + 2 * LIST_COUNTERS + 1, "a step");
+    // display-list handles: the frames the step just run sent to the full renderer's list kernel.  When that is most of them, step after
+    // step -- options the rasterizer's short path does not draw: center_agent = false over a wide world, monochrome assets, paint_vel_info --
+    // the handle goes back to the one-kernel renderer, which draws such frames without the detour
+    if (d.frame_rec) {
+        const int *sc = tail + 2 * LIST_COUNTERS + 1 + ERROR_INFO_WORDS + MAX_CHUNKS * (int)((step_count + 1) & 1);
+        int slow = 0;
+        for (int c = 0; c < MAX_CHUNKS; c++) slow += sc[c];
+        if (slow * 2 > num_envs) slow_streak++;  // (a reading may miss a step's count -- the small outputs can be downloaded before the prep kernels have run -- so: four sightings, not four in a row)
+        if (slow_streak >= 4) d.frame_rec = nullptr;
+    }
 }
 
 // The first device-side check that failed ends the run, like the reference's fassert (src/cpp-utils.h:9-11).  The message names the
@@ -1142,6 +1160,104 @@ void VecGame::set_state(int e, const char *data, int length) {  // reference src
     *(uint8_t *)info_ptr[1][e] = plc;
     *(int32_t *)info_ptr[2][e] = s.hdr.current_level_seed;
     if (host_observations) HIP_CHECK(hipMemcpy(ob_ptr[e], d.obs + (size_t)e * OBS_BYTES, OBS_BYTES, hipMemcpyDeviceToHost));
+}
+
+// set_state for a run of consecutive envs that lie in one snapshot block (procgen_amd_set_states): the block's device state is fetched once,
+// every stream is parsed into its env's slice of it (several host threads), the run's slices go back with one copy per array and ONE render
+// launch redraws the run -- instead of eleven synchronous copies, a launch and two joins per env (3.4 k states/s in round 5).
+void VecGame::set_states(int first, int count, const char *data, const long long *offsets) {
+    if (d.opt.use_generated_assets) fatal("fassert failed '!options.use_generated_assets' (BasicAbstractGame::deserialize)\n");  // BAG:1238
+    if (!buffers_set) fatal("set_state called before libenv_set_buffers\n");
+    if (first < 0 || count < 1 || first + count > num_envs || first / SNAP_BLOCK != (first + count - 1) / SNAP_BLOCK) fatal("set_states: envs [%d, %d) are not a run inside one snapshot block\n", first, first + count);
+    use_device();
+    observe();
+    {
+        EnvSnapshot s0;
+        snapshot(first, &s0);  // (fills the block cache: fields the wire format does not carry keep their current values)
+    }
+    const size_t ents_w = (size_t)EF_COUNT * d.ent_cap, rng_w = 2 * MT_STRIDE, grid_b = (size_t)d.grid_bytes;
+    const size_t k0 = (size_t)(first - snap_first);
+    std::vector<std::string> errs((size_t)count);
+    std::vector<char> ok((size_t)count, 1);
+    std::vector<int> gn((size_t)count);
+    int threads = (int)std::thread::hardware_concurrency();
+    threads = threads > 16 ? 16 : (threads < 1 ? 1 : threads);
+    if (threads > count / 8) threads = count / 8 > 0 ? count / 8 : 1;
+    auto work = [&](int t) {
+        for (int j = t; j < count; j += threads) {
+            const size_t k = k0 + (size_t)j;
+            EnvSnapshot s;
+            s.ent_cap = d.ent_cap;
+            s.hdr = snap_hdr[k];
+            s.ents.assign(snap_ents.begin() + k * ents_w, snap_ents.begin() + (k + 1) * ents_w);
+            s.rng.assign(snap_rng.begin() + k * rng_w, snap_rng.begin() + (k + 1) * rng_w);
+            s.grid.assign(snap_grid.begin() + k * grid_b, snap_grid.begin() + (k + 1) * grid_b);
+            gn[(size_t)j] = game_n[first + j];
+            if (!deserialize_state(game_id, d.opt, &s, data + offsets[j], (int)(offsets[j + 1] - offsets[j]), &errs[(size_t)j], &gn[(size_t)j])) {
+                ok[(size_t)j] = 0;
+                continue;
+            }
+            camera_scalars_of_the_observation_frame(&s.hdr);  // (see set_state)
+            s.hdr.big = game_tier_for(kernel_id, 2 * s.hdr.n_ents + 4);
+            snap_hdr[k] = s.hdr;
+            std::copy(s.ents.begin(), s.ents.end(), snap_ents.begin() + k * ents_w);
+            std::copy(s.rng.begin(), s.rng.end(), snap_rng.begin() + k * rng_w);
+            std::copy(s.grid.begin(), s.grid.end(), snap_grid.begin() + k * grid_b);
+        }
+    };
+    if (threads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; t++) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+    }
+    for (int j = 0; j < count; j++)
+        if (!ok[(size_t)j]) fatal("%s\n", errs[(size_t)j].c_str());
+    human_stale = true;
+    if (!route_mirror_valid) {
+        h_route.resize(num_envs);
+        HIP_CHECK(hipMemcpy(h_route.data(), d_route[step_count & 1], num_envs, hipMemcpyDeviceToHost));
+        route_mirror_valid = true;
+    }
+    std::vector<float> rew((size_t)count);
+    std::vector<uint8_t> first_v((size_t)count), plc((size_t)count);
+    std::vector<int32_t> pls((size_t)count), ls((size_t)count);
+    for (int j = 0; j < count; j++) {
+        const EnvHdr &h = snap_hdr[k0 + (size_t)j];
+        game_n[first + j] = gn[(size_t)j];
+        h_route[first + j] = (uint8_t)h.big;
+        rew[(size_t)j] = h.reward;
+        first_v[(size_t)j] = (uint8_t)h.done;
+        plc[(size_t)j] = (uint8_t)h.level_complete;
+        pls[(size_t)j] = h.prev_level_seed;
+        ls[(size_t)j] = h.current_level_seed;
+    }
+    route_dirty = true;
+    HIP_CHECK(hipMemcpy(d.hdr + first, snap_hdr.data() + k0, sizeof(EnvHdr) * count, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.ents + ent_table_base(first, d.ent_cap), snap_ents.data() + k0 * ents_w, ents_w * 4 * count, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy2D(d.rng + (size_t)first * MT_SLOTS * MT_STRIDE, (size_t)MT_SLOTS * MT_STRIDE * 4, snap_rng.data() + k0 * rng_w, rng_w * 4, rng_w * 4, count, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.grid + (size_t)first * grid_b, snap_grid.data() + k0 * grid_b, grid_b * count, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.rew + first, rew.data(), 4 * (size_t)count, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.first + first, first_v.data(), (size_t)count, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.prev_level_seed + first, pls.data(), 4 * (size_t)count, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.prev_level_complete + first, plc.data(), (size_t)count, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d.level_seed + first, ls.data(), 4 * (size_t)count, hipMemcpyHostToDevice));
+    HIP_CHECK(hipStreamSynchronize(nullptr));  // the uploads ran on the null stream: joined before the handle's (non-blocking) stream reads them
+    snap_first = -1;
+    HIP_CHECK(launch_render_one(kernel_id, d, first, stream, count));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    check_late_error("the drawing of restored states");
+    for (int j = 0; j < count; j++) {
+        const int e = first + j;
+        rew_ptr[e] = rew[(size_t)j];
+        first_ptr[e] = first_v[(size_t)j];
+        *(int32_t *)info_ptr[0][e] = pls[(size_t)j];
+        *(uint8_t *)info_ptr[1][e] = plc[(size_t)j];
+        *(int32_t *)info_ptr[2][e] = ls[(size_t)j];
+        if (host_observations) HIP_CHECK(hipMemcpy(ob_ptr[e], d.obs + (size_t)e * OBS_BYTES, OBS_BYTES, hipMemcpyDeviceToHost));
+    }
 }
 
 // the tier lists and the route table the coming step reads, rebuilt from the host's copy after set_state calls
@@ -1509,6 +1625,26 @@ LIBENV_API void set_state(libenv_env *handle, int env_idx, char *data, int lengt
     if (h->P() > 1) libenv_observe(handle);  // refresh the caller's rew / first entries of this env
 }
 
+// set_state for envs [first, first + count): state j is data[offsets[j], offsets[j + 1]).  Runs of consecutive envs that share a part and a
+// snapshot block are restored together (VecGame::set_states); the reference restores env by env (procgen/env.py:148-153, src/vecgame.cpp:447-456)
+LIBENV_API void procgen_amd_set_states(libenv_env *handle, int first, int count, const char *data, const long long *offsets) {
+    Handle *h = (Handle *)handle;
+    if (first < 0 || count < 0 || first + count > h->num_envs) fatal("procgen_amd_set_states: envs [%d, %d) out of range\n", first, first + count);
+    int k = 0;
+    while (k < count) {
+        const int e0 = first + k;
+        VecGame *v = h->parts[h->map.part_of(e0)].get();
+        const int i0 = h->map.index_in_part(e0);
+        int run = 1;
+        while (k + run < count && h->map.part_of(first + k + run) == h->map.part_of(e0) && h->map.index_in_part(first + k + run) == i0 + run &&
+               (i0 + run) / VecGame::SNAP_BLOCK == i0 / VecGame::SNAP_BLOCK)
+            run++;
+        v->set_states(i0, run, data, offsets + k);
+        k += run;
+    }
+    if (h->P() > 1) libenv_observe(handle);  // refresh the caller's rew / first entries
+}
+
 // ---- extension hooks (include/procgen_amd.h) -------------------------------------------------------------
 LIBENV_API int procgen_amd_device_buffers(libenv_env *handle, struct procgen_amd_buffers *out) {
     VecGame *v = ((Handle *)handle)->single();
@@ -1596,7 +1732,12 @@ LIBENV_API int procgen_amd_display_list_frames(libenv_env *handle, int *out) {
     VecGame *v = ((Handle *)handle)->single();
     v->observe();
     const int rec_words = game_frame_rec_words(v->kernel_id);
-    if (!v->d.frame_rec || rec_words <= 0) return 0;
+    if (!v->d_frame_rec || rec_words <= 0) return 0;
+    if (!v->d.frame_rec) {  // the handle went back to the one-kernel renderer (most frames left the short path)
+        out[0] = 0;
+        out[1] = v->num_envs;
+        return 1;
+    }
     HIP_CHECK(hipSetDevice(v->device_id));
     HIP_CHECK(hipStreamSynchronize(v->stream));
     std::vector<uint32_t> flags((size_t)v->num_envs);

@@ -264,8 +264,13 @@ struct DevCtx {
     // launch order of the render kernel (experiment, PROCGEN_AMD_RENDER_ORDER; null = identity): workgroup j of a chunk's launch draws env
     // render_order[env_base + j], a permutation of that chunk's env range sorted by background image
     const int *render_order;  // [num_envs]
-    // display-list games (pg_prep.h; null otherwise): the frame records prep<Game> writes and raster<Game> draws
+    // display-list games (pg_prep.h; null otherwise): the frame records prep<Game> writes and raster<Game> draws, and the envs of a launch
+    // chunk whose frame the rasterizer cannot draw (render_list<Game>: the full renderer): chunk c's entries start at slow_list[its first
+    // env], their count is slow_count[step_parity * MAX_CHUNKS + c]; raster<Game> zeroes the other parity's counter for the next step
     uint32_t *frame_rec;  // [num_envs][FrameRec<Game>::WORDS]
+    int *slow_list;       // [num_envs]
+    int *slow_count;      // [2][MAX_CHUNKS], in the block of small outputs the host downloads every step
+    int step_parity;
     int clear_lists;       // render kernel: zero big_count[] (nobody reads it any more this step; it is the next step's next_big_count)
     unsigned long long *wave_trace;    // [num_envs][32] PROCGEN_AMD_DEBUG & 8192: 100 MHz timestamps of the last step's workgroups: step start / end / kind+HW_ID, render start / end / HW_ID (null otherwise)
     unsigned long long *phase_cycles;  // [4096][32] PROCGEN_AMD_DEBUG & 2048: per-phase wave cycles of the step (0-15) and render (16-31) kernels (null otherwise)

@@ -13,8 +13,10 @@
 //                 lane of the same code.  Visible commands are packed in draw order into the env's record.  (2) Per env: the grid type
 //                 table and the pull form's tables (Renderer::build_type_table / build_pull_tables, unchanged), copied to the record.
 //                 A frame the rasterizer's short path cannot draw (per-cell path, more than 64 visible commands, paint_vel_info,
-//                 monochrome assets, any error) is marked: the env's raster workgroup runs the full renderer (Renderer::render_env).
-//   raster<Game>  one wave per env, Renderer::raster_env (Renderer::render_env for a marked frame): loads the record -- header by scalar loads, <= 64 commands one per lane, the
+//                 monochrome assets, any error) is queued for the full renderer (Renderer::render_env): render_list<Game>, a small grid
+//                 behind the rasterizer -- a fraction of a percent of the frames under default options; a handle most of whose frames
+//                 land there (center_agent = false for a wide world, monochrome assets) goes back to the one-kernel renderer (libenv_hip.cpp).
+//   raster<Game>  one wave per env, Renderer::raster_env: loads the record -- header by scalar loads, <= 64 commands one per lane, the
 //                 tables into LDS -- and runs the band passes.  No fp64, no header, no options.
 //
 // Reference: the same calls as pg_render.h -- BasicAbstractGame::game_draw (src/basic-abstract-game.cpp:1009-1012), draw_background
@@ -46,9 +48,10 @@ struct FramePrep {
                   "display-list games: upright sprites, one background image, no overlay, one command set");
     const DevCtx &d;
     Lds *lds;
-    int *slow_count;  // (emulation: frames drawn by the full renderer; null on the device)
+    int *slow_count;  // [0]: envs queued for render_list by this launch
+    int *slow_list;
 
-    PG_DEV FramePrep(const DevCtx &d_, Lds *lds_, int *slow_count_ = nullptr) : d(d_), lds(lds_), slow_count(slow_count_) {}
+    PG_DEV FramePrep(const DevCtx &d_, Lds *lds_, int *slow_count_, int *slow_list_) : d(d_), lds(lds_), slow_count(slow_count_), slow_list(slow_list_) {}
 
     // lane-local: the header of the lane's env into its renderer (the optimizer keeps the fields the drawable's set-up reads)
     PG_DEV static void bind_env(R &r, const DevCtx &d, int env) {
@@ -205,7 +208,6 @@ struct FramePrep {
             uint64_t colseam = 0, rowseam = 0, rowany = ~0ull;
             bool pull = false, multi = false;
             int nfill = 0;
-            uint32_t cellrows = 0, rowstep = 0;
             if constexpr (GameDrawsGrid<Game>::value) {
                 const bool try_pull = nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32 && nx * ny_full <= GamePullCells<Game>::value;
                 PG_LANE_VAR(ImgDesc, type_desc);
@@ -216,7 +218,7 @@ struct FramePrep {
                 }
                 if (try_pull) r.request_window_cells(win_lx, nx, win_ly, ny_full, cells0);
                 r.build_type_table(type_desc);
-                pull = try_pull && r.build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, multi, nfill, cellrows, rowstep, cells0);
+                pull = try_pull && r.build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, multi, nfill, cells0);
             }
             bool fast = ((slow >> e) & 1u) == 0 && r.G.error == 0 && !r.opt.use_monochrome_assets && !(r.G.has_useful_vel_info && r.opt.paint_vel_info) &&
                         (!GameDrawsGrid<Game>::value || pull);
@@ -237,8 +239,6 @@ struct FramePrep {
             hw[Rec::ROWANY] = (uint32_t)rowany;
             hw[Rec::ROWANY + 1] = (uint32_t)(rowany >> 32);
             hw[Rec::REF_W] = (uint32_t)d.assets->ref_w;
-            hw[Rec::CELLROWS] = cellrows;
-            hw[Rec::ROWSTEP] = rowstep;
             PG_FOR_LANES(l) {
                 uint32_t v = 0;
                 _Pragma("unroll") for (int k = 0; k < Rec::HDR_WORDS; k++) v = l == k ? hw[k] : v;
@@ -254,9 +254,13 @@ struct FramePrep {
                     }
                 }
             }
+            if (!fast) {  // queued for the full renderer (render_list<Game>)
 #if defined(PGAMD_WAVE_EMU)
-            if (!fast && slow_count) ++*slow_count;  // (the raster kernel's workgroup of this env runs the full renderer: kernels_game.hip raster)
+                slow_list[(*slow_count)++] = env;
+#else
+                if (PG_LANE_ID() == 0) slow_list[atomicAdd(slow_count, 1)] = env;
 #endif
+            }
             PG_SYNC();  // (the next env's tables overwrite the arena)
         }
     }

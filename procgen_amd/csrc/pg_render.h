@@ -91,6 +91,16 @@ template <class Game>
 struct GamePullCells<Game, decltype((void)Game::PULL_CELLS)> {
     static constexpr int value = Game::PULL_CELLS;
 };
+// the game's cell images share one size (PULL_SINGLE_SIZE in a policy: coinrun, climber): the arena carries no size-class tables, which is
+// what lets seven instead of five render waves fit a SIMD's share of LDS; a frame that does show a second size takes the per-cell path
+template <class Game, class = void>
+struct GamePullSingle {
+    static constexpr bool value = false;
+};
+template <class Game>
+struct GamePullSingle<Game, decltype((void)Game::PULL_SINGLE_SIZE)> {
+    static constexpr bool value = Game::PULL_SINGLE_SIZE;
+};
 // register sets (64 draw commands each) the frame's visible entities are packed into; a policy that routinely shows
 // more than 64 entities asks for two (RENDER_CMD_SETS)
 template <class Game, class = void>
@@ -194,12 +204,9 @@ struct RenderLdsT {
     uint8_t cellimg[GameDrawsGrid<Game>::value ? GamePullCells<Game>::value : 4];
     uint32_t typeany[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of any size: atlas offset | size class<<27 | opaque<<31 (pull form)
     uint32_t fillcmd[GameHasGridFills<Game>::value ? 2 * 256 : 1];  // solid-colour cells of a pull-form frame: (geom, colour) pairs
-    // cell row r of the window (class 0): [0][r] = first screen row | rows covered << 8 | rows with a sample << 16, [1][r] = 16.16 source row
-    // of the first one; every cell row steps by rowstep (cellrows_pass)
-    uint32_t rowrun[GameDrawsGrid<Game>::value ? 2 : 1][32];
-    uint32_t rowstep;
-    uint8_t srcx[GameDrawsGrid<Game>::value ? 3 : 1][2][64];    // size classes 1..3: screen column -> source column, per covering slot
-    uint16_t srcyw[GameDrawsGrid<Game>::value ? 3 : 1][2][64];  // size classes 1..3: screen row -> source row * image width
+    static constexpr bool SIZE_CLASSES = GameDrawsGrid<Game>::value && !GamePullSingle<Game>::value;
+    uint8_t srcx[SIZE_CLASSES ? 3 : 1][SIZE_CLASSES ? 2 : 1][SIZE_CLASSES ? 64 : 4];    // size classes 1..3: screen column -> source column, per covering slot
+    uint16_t srcyw[SIZE_CLASSES ? 3 : 1][SIZE_CLASSES ? 2 : 1][SIZE_CLASSES ? 64 : 2];  // size classes 1..3: screen row -> source row * image width
     // ---- end of the record's table part
     uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of this frame (build_type_table)
     uint32_t rot[GameUsesRotation<Game>::value ? GameRotPool<Game>::value * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane (by pool slot: ROT_POOL)
@@ -209,14 +216,13 @@ struct RenderLdsT {
     static constexpr int PREP_FB_WORDS = 192;
 };
 // Frame record of a display-list game (pg_prep.h): what prep<Game> leaves in HBM for raster<Game>, per env.  Words:
-//   [0, 20)          header: flags, dims (window rows | visible commands << 8 | grid fills << 16), the pull form's column-seam / row-seam /
-//                    row-any masks, the background command (7 words), the atlas' reference cell width, the cell rows that hold an image, the
-//                    16.16 source step of a screen row
+//   [0, 16)          header: flags, dims (window rows | visible commands << 8 | grid fills << 16), the pull form's column-seam / row-seam /
+//                    row-any masks, the background command (7 words), the atlas' reference cell width
 //   [CMD, CMD + 512) up to 64 entity commands in draw order, 8 words each: geom basex srcy ix iy src aux | render_z + 1
 //   [TAB, ...)       the pull form's tables exactly as they lie in the render arena (RenderLdsT [ci, typeimg))
 template <class Game>
 struct FrameRec {
-    enum : int { FLAGS = 0, DIMS = 1, COLSEAM = 2, ROWSEAM = 4, ROWANY = 6, BG = 8, REF_W = 15, CELLROWS = 16, ROWSTEP = 17, HDR_WORDS = 20, CMD = 20, CMD_WORDS = 8, TAB = CMD + 64 * CMD_WORDS };
+    enum : int { FLAGS = 0, DIMS = 1, COLSEAM = 2, ROWSEAM = 4, ROWANY = 6, BG = 8, REF_W = 15, HDR_WORDS = 16, CMD = 16, CMD_WORDS = 8, TAB = CMD + 64 * CMD_WORDS };
     enum : uint32_t { F_FAST = 1u, F_PULL = 2u, F_MULTI = 4u };
     static constexpr int LDS_TAB_WORD0 = (int)(offsetof(RenderLdsT<Game>, ci) / 4);
     static constexpr int TAB_SINGLE_WORDS = (int)((offsetof(RenderLdsT<Game>, srcx) - offsetof(RenderLdsT<Game>, ci) + 3) / 4);
@@ -846,10 +852,8 @@ struct Renderer {
             }
         }
     }
-    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, uint64_t &colseam, uint64_t &rowseam, uint64_t &rowany, bool &multi, int &nfill_out, uint32_t &cellrows_out, uint32_t &rowstep_out, PG_LANE_ARR_REF(const int, cells0, 4)) {
+    PG_DEV bool build_pull_tables(int win_lx, int nx, int win_ly, int ny_full, uint64_t &colseam, uint64_t &rowseam, uint64_t &rowany, bool &multi, int &nfill_out, PG_LANE_ARR_REF(const int, cells0, 4)) {
         nfill_out = 0;
-        cellrows_out = 0;
-        rowstep_out = 0;
         rowany = ~0ull;
         const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
         uint32_t *present = fb;  // scratch: the band buffer is idle during set-up
@@ -857,13 +861,12 @@ struct Renderer {
         PG_R_LANES(l) {
             present[l] = 0;
             lds->ci[0][l] = lds->ci[1][l] = lds->ri[0][l] = lds->ri[1][l] = 0;
-            if (l < 32) lds->rowrun[0][l] = lds->rowrun[1][l] = 0;
-            if (l == 32) lds->rowstep = 0;
-            for (int k = 0; k < 3; k++)
-                for (int sl = 0; sl < 2; sl++) {
-                    lds->srcx[k][sl][l] = 0xffu;
-                    lds->srcyw[k][sl][l] = 0xffffu;
-                }
+            if constexpr (RenderLds::SIZE_CLASSES)
+                for (int k = 0; k < 3; k++)
+                    for (int sl = 0; sl < 2; sl++) {
+                        lds->srcx[k][sl][l] = 0xffu;
+                        lds->srcyw[k][sl][l] = 0xffffu;
+                    }
         }
         PG_SYNC();
         // cell -> grid object type (kept in cellimg until the classes are known)
@@ -933,32 +936,30 @@ struct Renderer {
             todo &= ~same;
         }
         multi = ncls > 1;
+        if (multi && !RenderLds::SIZE_CLASSES) return false;  // (a second image size in a single-size game's window: the per-cell path)
         PG_R_LANES(l) {
             const uint32_t tv = typeany[l];
             if (tv != CELL_NONE && tv != TYPE_SLOW) typeany[l] = tv | (PG_LV(cls, l) << 27);
         }
         PG_SYNC();
-        uint32_t cellrows = 0;  // bit r: cell row r of the window holds a cell with an image
-        for (int base = 0; base < ncell; base += 64) {
-            PG_LANE_VAR(uint32_t, has);
-            PG_R_LANES(l) {
-                PG_LV(has, l) = 0;
-                if (base + l < ncell) {
-                    const uint8_t t = lds->cellimg[base + l];
-                    if (t != CELL8_NONE && t != CELL8_FILL) PG_LV(has, l) = 1;  // (the cell keeps its type id: pull_fetch goes through typeany)
+        // bit r: cell row r of the window holds a cell with an image.  Cells are x-major (index = column * ny_full + row): every lane marks
+        // the rows of its cells, one OR over the wave folds them (round 6; a scalar fold of each 64-cell chunk's ballot, column by column, was
+        // ~400 scalar instructions a frame)
+        uint32_t cellrows = 0;
+        {
+            PG_LANE_VAR(uint32_t, rowbits);
+            PG_R_LANES(l) { PG_LV(rowbits, l) = 0; }
+            for (int base = 0; base < ncell; base += 64) {
+                PG_R_LANES(l) {
+                    const int cidx = base + l;
+                    if (cidx < ncell) {
+                        const uint8_t t = lds->cellimg[cidx];
+                        const int cx = (int)(((uint32_t)cidx * ny_inv) >> 20);
+                        if (t != CELL8_NONE && t != CELL8_FILL) PG_LV(rowbits, l) |= 1u << (cidx - cx * ny_full);  // (the cell keeps its type id: pull_fetch goes through typeany)
+                    }
                 }
             }
-            // cells are x-major (index = column * ny_full + row): fold the chunk's mask onto the rows, column by column
-            const uint64_t m = PG_BALLOT(l, PG_LV(has, l) != 0);
-            if (m != 0) {
-                const int last = base + 63 < ncell - 1 ? base + 63 : ncell - 1;
-                for (int cx = (int)(((uint32_t)base * ny_inv) >> 20); cx * ny_full <= last; cx++) {
-                    const int lo = cx * ny_full > base ? cx * ny_full : base;
-                    const int hi = (cx + 1) * ny_full < base + 64 ? (cx + 1) * ny_full : base + 64;
-                    const uint64_t bits = (m >> (lo - base)) & (hi - lo >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull));
-                    cellrows |= (uint32_t)(bits << (lo - cx * ny_full));
-                }
-            }
+            cellrows = PG_WAVE_OR(rowbits);
         }
         // pixel spans of the cell columns (lanes 0..31) and rows (lanes 32..63): the rect alone decides them
         PG_R_LANES(l) {
@@ -1047,11 +1048,6 @@ struct Renderer {
                     int n = n0;
                     const int end = (int)((b + (uint32_t)step * (uint32_t)(n - 1)) >> 16);
                     if (end < 0 || end >= src_len) --n;
-                    if (k == 0 && !col) {  // the cell row's run of screen rows (cellrows_pass)
-                        lds->rowrun[0][idx] = (uint32_t)t1 | ((uint32_t)n0 << 8) | ((uint32_t)n << 16);
-                        lds->rowrun[1][idx] = b;
-                        lds->rowstep = (uint32_t)step;  // (the same value from every row: the cell rects share their height)
-                    }
                     const uint32_t s1 = idx >= 1 ? span[l - 1] : 0u, s2 = idx >= 2 ? span[l - 2] : 0u;
                     for (int j = 0; j < n0; j++) {
                         const int p = t1 + j;
@@ -1067,10 +1063,9 @@ struct Renderer {
                             const uint32_t e = (1u << 31) | (sv ? (1u << 30) : 0u) | ((uint32_t)idx << 12) | (sv ? (sc & 0xfffu) : 0u);
                             if (col) lds->ci[slot][p] = e;
                             else lds->ri[slot][p] = e;
-                        } else if (col) {
-                            lds->srcx[k - 1][slot][p] = (uint8_t)(sv ? sc : 0xffu);
-                        } else {
-                            lds->srcyw[k - 1][slot][p] = (uint16_t)(sv ? sc * (uint32_t)cw : 0xffffu);
+                        } else if constexpr (RenderLds::SIZE_CLASSES) {
+                            if (col) lds->srcx[k - 1][slot][p] = (uint8_t)(sv ? sc : 0xffu);
+                            else lds->srcyw[k - 1][slot][p] = (uint16_t)(sv ? sc * (uint32_t)cw : 0xffffu);
                         }
                     }
                 }
@@ -1091,8 +1086,6 @@ struct Renderer {
             if ((colseam >> l) & 1ull) lds->seamcols[pg_popc64(colseam & pg_mask_lt(l))] = (uint8_t)l;
         }
         PG_SYNC();
-        cellrows_out = cellrows;
-        rowstep_out = (uint32_t)PG_UNIFORM_I(lds->rowstep);
         return true;
     }
     // texel of the cell under one pixel for the column slot sc / row slot sr, branch-free: lanes without a cell fetch
@@ -1103,12 +1096,13 @@ struct Renderer {
         const uint32_t both = ce & re;
         const bool covered = (both >> 31) != 0;
         const uint32_t ct = lds->cellimg[((ce >> 12) & 0x1fu) * (uint32_t)ny_full + ((re >> 12) & 0x1fu)];
-        const uint32_t cell = ct < 64u ? typeany[ct & 63u] : CELL_NONE;
+        const uint32_t tv_ = typeany[ct & 63u];  // (read unconditionally: a load inside a ?: arm becomes a branch around it)
+        const uint32_t cell = ct < 64u ? tv_ : CELL_NONE;
         opaque = (cell >> 31) != 0;
         const bool v0 = ((both >> 30) & 1u) != 0;
         uint32_t rel = (re & 0xfffu) * (uint32_t)ref_w + (ce & 0xfffu);
         bool hit = covered && cell != CELL_NONE;
-        if (MULTI) {
+        if constexpr (MULTI && RenderLds::SIZE_CLASSES) {
             const uint32_t k = (cell >> 27) & 3u;  // CELL_NONE reads class 3: in bounds, never a hit
             const uint32_t kk = k ? k - 1u : 0u;
             const uint32_t sx1 = lds->srcx[kk][sc][x], sy1 = lds->srcyw[kk][sr][y];
@@ -1121,100 +1115,79 @@ struct Renderer {
         return hit;
     }
     // Stages (c0, r0) and (c0, r1) of the pull form -- every pixel's first covering cell column, its one or two covering cell rows -- for a
-    // frame whose cell images share one size: CELL ROW by cell row, in draw order (BAG:941-955 walks a column's cells upwards, so of two cell
-    // rows over one screen row the lower index paints first), lane = screen column.  What a lane needs -- the image of its cell in this
-    // cell row -- is looked up once per cell row (~14 a frame), not once per pixel; a screen row then costs the wave a scalar source-row
-    // step and each lane one texel fetch at (lane offset) + (scalar row base).  A cell row whose images are all opaque (ground, walls,
-    // crates: most of a level) stores its texels without SourceOver; one without any image in this window is never visited.  (Round 6:
-    // the per-pixel lookup chain of rounds 2-5 -- two LDS reads and ~25 vector instructions per pixel row -- was 42 % of the kernel's vector
-    // instructions, profiles/r06_valu_by_phase.txt; a first hoisted form that built its row runs in scalar code cost as many scalar
-    // instructions as it saved vector ones, profiles/r06_call3_ab.txt.)
-    PG_DEV void cellrows_pass(int ny_full, int ref_w, uint32_t cellrows, uint32_t rowstep) {
-        constexpr int K = 3;  // cell rows per round: their lookups go out together, then every texel of their rows, then one wait
-        constexpr int R = 6;  // screen rows of a cell row per round (a taller cell row takes another round for the rest)
-        PG_LANE_VAR(uint32_t, run0);
-        PG_LANE_VAR(uint32_t, run1);
+    // frame whose cell images share one size, ROW by row with the cell lookup hoisted: the band's 16 screen rows in order, each a scalar
+    // decode of its row entry (covering cell row, source row); the lanes (lane = screen column) look their cell up only where the cell row
+    // changes (~5 times a band), fetch one texel per row at (scalar row base) + (lane offset), all 16 fetches in flight, and store (opaque
+    // images: ground, walls, crates) or blend them after one wait.  Row slot 1 -- the rows a second cell row covers as well -- follows for
+    // the few rows that have one.  (Round 6.  The per-pixel lookup chain of rounds 2-5 -- two LDS reads and ~25 vector instructions per
+    // pixel row -- was 42 % of the kernel's vector instructions, profiles/r06_valu_by_phase.txt; two cell-row-major forms tried first spent
+    // what they saved on scalar run bookkeeping and on one dependent round trip per cell row, profiles/r06_call3_ab.txt, r06_raster_ablation.txt.)
+    PG_DEV void rows_pass(int ny_full, int ref_w, uint32_t band_any, uint32_t band_seam) {
+        static_assert(BAND_ROWS <= 16, "the band's row entries live in lanes 0..15 (slot 0) and 16..31 (slot 1)");
+        // (plain lane sections: the empty asm a PG_R_LANES section takes its lane id through makes the compiler wait for every texel in
+        // flight before the next row's section, i.e. one fetch at a time)
+        PG_LANE_VAR(uint32_t, riv);
         PG_LANE_VAR(uint32_t, ce);
-        PG_R_LANES(l) {
-            PG_LV(run0, l) = lds->rowrun[0][l & 31];
-            PG_LV(run1, l) = lds->rowrun[1][l & 31];
+        PG_FOR_LANES(l) {
+            PG_LV(riv, l) = lds->ri[(l >> 4) & 1][row0 + (l & (BAND_ROWS - 1))];
             PG_LV(ce, l) = lds->ci[0][l];
         }
-        // cell rows with an image whose sampled rows reach this band
-        uint32_t m = cellrows & (uint32_t)PG_BALLOT(l, l < 32 && (int)(PG_LV(run0, l) & 0xffu) < row1 &&
-                                                           (int)((PG_LV(run0, l) & 0xffu) + ((PG_LV(run0, l) >> 16) & 0xffu)) > row0);
-        int carry = 0;  // rows of the lowest cell row of `m` drawn by earlier rounds
-        while (m != 0) {
-            int cy[K], ya[K], cnt[K];
-            uint32_t acc[K];  // 16.16 source row of the cell row's first screen row of this round
-            _Pragma("unroll") for (int k = 0; k < K; k++) {
-                cy[k] = 0;
-                ya[k] = row0;
-                cnt[k] = 0;
-                acc[k] = 0;
-                if (m != 0) {
-                    const int c = pg_ctz64((uint64_t)m);
-                    const uint32_t w0 = PG_READLANE(run0, c), b0 = PG_READLANE(run1, c);
-                    const int t1 = (int)(w0 & 0xffu), n = (int)((w0 >> 16) & 0xffu);
-                    const int y0 = (t1 > row0 ? t1 : row0) + carry, y1 = (t1 + n) < row1 ? (t1 + n) : row1;
-                    const int left = y1 - y0;
-                    cy[k] = c;
-                    ya[k] = y0;
-                    cnt[k] = left < R ? left : R;
-                    acc[k] = b0 + (uint32_t)(y0 - t1) * rowstep;
-                    if (left <= R) {
-                        m &= m - 1u;
-                        carry = 0;
-                    } else {
-                        carry += R;
+        for (int sr = 0; sr < 2; sr++) {
+            const uint32_t rows = sr ? band_seam : band_any;
+            if (rows == 0) continue;
+            PG_LANE_ARR(uint32_t, tex, BAND_ROWS);  // (row j's word is written before it is read: only rows in `drawn` are)
+            PG_LANE_VAR(uint32_t, hm);     // bit j: this lane draws row j
+            PG_LANE_VAR(uint32_t, cboff);  // byte offset of the lane's cell image of the current cell row + its source column
+            PG_LANE_VAR(uint32_t, hbit);   // 1: the lane has a cell with an image in the current cell row
+            PG_FOR_LANES(l) {
+                PG_LV(hm, l) = 0;
+                PG_LV(cboff, l) = 0;
+                PG_LV(hbit, l) = 0;
+                for (int j = 0; j < BAND_ROWS; j++) PG_LA(tex, j, l) = 0;
+            }
+            int prev_cy = -1;
+            bool translucent = false;  // some cell row of the band shows a translucent image: its rows are composited, not stored
+            uint32_t drawn = 0;        // rows with a fetch in flight
+            _Pragma("unroll") for (int j = 0; j < BAND_ROWS; j++) {
+                if (((rows >> j) & 1u) == 0) continue;
+                const uint32_t e = PG_READLANE(riv, sr * 16 + j);
+                if ((e >> 30) != 3u) continue;  // not covered in this slot, or Qt dropped the row's sample
+                const int cy = (int)((e >> 12) & 0x1fu);
+                if (cy != prev_cy) {
+                    prev_cy = cy;
+                    PG_LANE_VAR(uint32_t, tl);
+                    PG_FOR_LANES(l) {
+                        const uint32_t c = PG_LV(ce, l);
+                        const uint32_t ct = lds->cellimg[((c >> 12) & 0x1fu) * (uint32_t)ny_full + (uint32_t)cy];
+                        const uint32_t tv = typeany[ct & 63u];
+                        const uint32_t cell = ct < 64u ? tv : CELL_NONE;
+                        const bool h = (c >> 30) == 3u && cell != CELL_NONE;  // covered, and Qt kept the column's sample
+                        PG_LV(cboff, l) = h ? ((cell & 0x7ffffffu) + (c & 0xfffu)) << 2 : 0u;  // (a lane without a cell fetches a word of the atlas' first row and draws nothing)
+                        PG_LV(hbit, l) = h ? 1u : 0u;
+                        PG_LV(tl, l) = (h && (cell >> 31) == 0) ? 1u : 0u;
                     }
+                    if (PG_BALLOT(l, PG_LV(tl, l) != 0) != 0) translucent = true;
                 }
-            }
-            // the lanes' cells of these cell rows
-            PG_LANE_ARR(uint32_t, cbase, K);
-            PG_LANE_ARR(uint32_t, chit, K);  // 0: nothing to draw in this column; 1: a translucent image; 3: an opaque one
-            PG_R_LANES(l) {
-                const uint32_t e = PG_LV(ce, l);
-                _Pragma("unroll") for (int k = 0; k < K; k++) {
-                    const uint32_t ct = lds->cellimg[((e >> 12) & 0x1fu) * (uint32_t)ny_full + (uint32_t)cy[k]];
-                    const uint32_t cell = ct < 64u ? typeany[ct & 63u] : CELL_NONE;
-                    const bool h = cnt[k] > 0 && (e >> 30) == 3u && cell != CELL_NONE;  // covered, and Qt kept the column's sample
-                    PG_LA(cbase, k, l) = h ? (cell & 0x7ffffffu) + (e & 0xfffu) : 0u;  // (a lane without a cell fetches a word of the atlas' first row and draws nothing)
-                    PG_LA(chit, k, l) = h ? 1u | ((cell >> 31) << 1) : 0u;
+                const char *rowp = reinterpret_cast<const char *>(d.pixels + (e & 0xfffu) * (uint32_t)ref_w);  // wave-uniform
+                PG_FOR_LANES(l) {
+                    PG_LA(tex, j, l) = *reinterpret_cast<const uint32_t *>(rowp + PG_LV(cboff, l));  // scalar base + 32-bit lane offset
+                    PG_LV(hm, l) |= PG_LV(hbit, l) << j;
                 }
+                drawn |= 1u << j;
             }
-            bool opaque[K];
-            _Pragma("unroll") for (int k = 0; k < K; k++) {
-                if (PG_BALLOT(l, PG_LA(chit, k, l) != 0) == 0) cnt[k] = 0;  // (no image of this cell row in the window's columns)
-                opaque[k] = PG_BALLOT(l, PG_LA(chit, k, l) == 1u) == 0;
-            }
-            if (cnt[0] + cnt[1] + cnt[2] == 0) continue;
-            static_assert(K == 3, "the sum above");
-            PG_R_LANES(l) {
-                uint32_t tex[K][R];
-                _Pragma("unroll") for (int k = 0; k < K; k++) {
-                    const uint32_t bl = PG_LA(cbase, k, l);
-                    _Pragma("unroll") for (int q = 0; q < R; q++) {
-                        tex[k][q] = 0;
-                        if (q < cnt[k]) {
-                            const uint32_t srow = (acc[k] + (uint32_t)q * rowstep) >> 16;
-                            const uint32_t *rowp = d.pixels + srow * (uint32_t)ref_w;  // wave-uniform
-                            tex[k][q] = rowp[bl];
-                        }
-                    }
+            if (drawn == 0) continue;
+            dma_join();  // (the band's background rows, requested before these texels)
+            if (!translucent) {
+                PG_FOR_LANES(l) {
+                    _Pragma("unroll") for (int j = 0; j < BAND_ROWS; j++)
+                        if ((PG_LV(hm, l) >> j) & 1u) fb[j * RES_W + l] = PG_LA(tex, j, l);  // this lane owns the column
                 }
-                dma_join();  // (the band's background rows, requested before these texels)
-                _Pragma("unroll") for (int k = 0; k < K; k++) {  // in draw order: of two cell rows over one screen row the lower paints first
-                    const bool h = PG_LA(chit, k, l) != 0;
-                    uint32_t *dp = &fb[(ya[k] - row0) * RES_W + l];  // this lane owns the column
-                    if (opaque[k]) {
-                        if (h) {
-                            _Pragma("unroll") for (int q = 0; q < R; q++)
-                                if (q < cnt[k]) dp[q * RES_W] = tex[k][q];
-                        }
-                    } else {
-                        _Pragma("unroll") for (int q = 0; q < R; q++)
-                            if (q < cnt[k]) dp[q * RES_W] = blend(h ? tex[k][q] : 0u, dp[q * RES_W], 256, 255u);  // (a transparent texel leaves the pixel as it is: BYTE_MUL(dst, 255) == dst)
+            } else {
+                _Pragma("unroll") for (int j = 0; j < BAND_ROWS; j++) {
+                    if (((drawn >> j) & 1u) == 0) continue;
+                    PG_FOR_LANES(l) {
+                        uint32_t *dp = &fb[j * RES_W + l];
+                        *dp = blend(((PG_LV(hm, l) >> j) & 1u) ? PG_LA(tex, j, l) : 0u, *dp, 256, 255u);  // (a transparent texel leaves the pixel as it is: BYTE_MUL(dst, 255) == dst)
                     }
                 }
             }
@@ -1304,14 +1277,14 @@ struct Renderer {
         PG_SYNC();
     }
     template <bool MULTI>
-    PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam, uint64_t rowany, int ref_w, uint32_t cellrows, uint32_t rowstep) {
+    PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam, uint64_t rowany, int ref_w) {
         const int nseam = pg_popc64(colseam);
         const uint32_t band_any = (uint32_t)((rowany >> row0) & ((1ull << BAND_ROWS) - 1ull));
         if (band_any == 0) return;  // no cell with an image reaches these rows (sky)
         const uint32_t band_seam = (uint32_t)((rowseam >> row0) & ((1ull << BAND_ROWS) - 1ull)) & band_any;
         // stages 1 and 2: (c0, r0), and (c0, r1) on the doubly covered rows
         if (MULTI) rows_pass_by_pixel<MULTI>(ny_full, ref_w, band_any, band_seam);
-        else cellrows_pass(ny_full, ref_w, cellrows, rowstep);
+        else rows_pass(ny_full, ref_w, band_any, band_seam);
         if (nseam == 0) return;
         // stage 3: (c1, r0): the doubly covered columns x the band's rows, laid out linearly over the lanes, one, two or four pixels per lane
         // and round (coinrun shows two or three such columns, 48 pixels a band: a four-deep round spent three quarters of its instructions
@@ -2477,9 +2450,8 @@ struct Renderer {
         phase(10);
         bool pull = false, pull_multi = false;
         int pull_nfill = 0;
-        uint32_t pull_cellrows = 0, pull_rowstep = 0;
         if constexpr (GameDrawsGrid<Game>::value)
-            pull = try_pull && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, pull_multi, pull_nfill, pull_cellrows, pull_rowstep, cells0);
+            pull = try_pull && build_pull_tables(win_lx, nx, win_ly, ny_full, colseam, rowseam, rowany, pull_multi, pull_nfill, cells0);
 
         if (use_axes && !pull) setup_tile_axes(win_lx, nx, win_ly, ny_full, ref_w, ref_h, ix_ref, iy_ref);  // only the per-cell path reads the axis tables
 
@@ -2582,8 +2554,8 @@ struct Renderer {
             phase(2);
             if constexpr (GameDrawsGrid<Game>::value)
                 if (pull && !PG_DBG(d, 2)) {
-                    if (pull_multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w, pull_cellrows, pull_rowstep);
-                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w, pull_cellrows, pull_rowstep);
+                    if (pull_multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w);
+                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w);
                     if constexpr (GameHasGridFills<Game>::value) draw_pull_fills(pull_nfill);
                 }
             for (int base = 0; base < ncell; base += 64) {
@@ -2723,7 +2695,6 @@ struct Renderer {
         const uint32_t bg_geom = rec[Rec::BG], bg_basex = rec[Rec::BG + 1], bg_srcy = rec[Rec::BG + 2], bg_ix = rec[Rec::BG + 3], bg_iy = rec[Rec::BG + 4],
                        bg_src = rec[Rec::BG + 5], bg_aux = rec[Rec::BG + 6];
         const int ref_w = (int)rec[Rec::REF_W];
-        const uint32_t cellrows = rec[Rec::CELLROWS], rowstep = rec[Rec::ROWSTEP];
         const int ny_full = (int)(dims & 0xffu), ncmd = (int)((dims >> 8) & 0xffu), nfill = (int)(dims >> 16);
         const bool pull = (flags & Rec::F_PULL) != 0, multi = (flags & Rec::F_MULTI) != 0;
         G.error = 0;
@@ -2776,8 +2747,8 @@ struct Renderer {
             if (ez0 && !PG_DBG(d, 4)) run_batch(er, ez0);
             if constexpr (GameDrawsGrid<Game>::value) {
                 if (pull && !PG_DBG(d, 2)) {
-                    if (multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w, cellrows, rowstep);
-                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w, cellrows, rowstep);
+                    if (multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w);
+                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w);
                     if constexpr (GameHasGridFills<Game>::value) draw_pull_fills(nfill);
                 }
             }

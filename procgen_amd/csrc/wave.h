@@ -116,6 +116,13 @@ inline int pg_emu_dma_outstanding() {
 #define PG_LA(v, j, l) v[j][l]
 #define PG_LANE_ARR_REF(T, v, N) T (&v)[N][64]
 #define PG_SHFL(v, l, src) v[(src) & 63]  // inside a lane section: the value lane `src` holds (v is only read in that section)
+// wave-uniform code: the OR of a 32-bit lane variable over the 64 lanes
+#define PG_WAVE_OR(v)                              \
+    ({                                             \
+        uint32_t r_ = 0;                           \
+        for (int l_ = 0; l_ < 64; ++l_) r_ |= (uint32_t)v[l_]; \
+        r_;                                        \
+    })
 // atomic OR on a 32-bit word shared by the wave's lanes, returns the old value (the emulation's lanes run one after the other)
 PG_DEV uint32_t pg_atomic_or(uint32_t *p, uint32_t v) {
     const uint32_t o = *p;
@@ -170,7 +177,14 @@ __device__ __forceinline__ int pg_lane_opaque() {
 // through a VGPR; completion is counted by vmcnt like any other load
 #define PG_DMA_DWORD(gptr, lds_base, l) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lds_base), 4, 0, 0)
-#define PG_DMA_JOIN() __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// (the builtin, not an asm string: the compiler's own wait-count bookkeeping sees it and knows that nothing fetched before it is still in
+// flight -- behind an asm it assumed the opposite and put a full vmcnt(0) in front of later, unrelated register writes.  0x0F70 = vmcnt(0),
+// expcnt and lgkmcnt untouched, in gfx9's encoding)
+#define PG_DMA_JOIN()                          \
+    do {                                       \
+        __builtin_amdgcn_s_waitcnt(0x0F70);    \
+        __asm__ volatile("" ::: "memory");     \
+    } while (0)
 // nothing is scheduled across this point: keeps the loads of the next unrolled iteration from being hoisted over this one's arithmetic
 // (and their results from piling up in registers)
 #define PG_BALLOT(l, pred)                              \
@@ -197,6 +211,12 @@ __device__ __forceinline__ int pg_lane_opaque() {
         (decltype(v))__builtin_amdgcn_readlane((int)(v), (k));                                                 \
     })
 #define PG_SHFL(v, l, src) ((decltype(v))__shfl((int)(v), (src), 64))  // ds_bpermute: the value lane `src` holds
+// the OR of a 32-bit lane variable over the wave: a six-step butterfly, result in a scalar register
+__device__ __forceinline__ uint32_t pg_wave_or(uint32_t v) {
+    _Pragma("unroll") for (int o = 32; o >= 1; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o, 64);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+#define PG_WAVE_OR(v) pg_wave_or((uint32_t)(v))
 PG_DEV uint32_t pg_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 // value known to be wave-uniform: move it to an SGPR so branches on it are scalar branches
 #define PG_UNIFORM_I(x) __builtin_amdgcn_readfirstlane((int)(x))

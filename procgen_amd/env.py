@@ -125,10 +125,25 @@ class BaseProcgenEnv(CEnv):
         return result
 
     def set_state(self, states):
+        """reference procgen/env.py:148-153.  Libraries with the batched hook (procgen_amd_set_states, include/procgen_amd.h) take 256 states
+        per call -- one upload and one redraw per block; any other libenv.so (the compiled reference) is restored env by env."""
         assert len(states) == self.num
-        for env_idx in range(self.num):
-            state = states[env_idx]
-            self.call_c_func("set_state", env_idx, state, len(state))
+        if not hasattr(self._lib, "procgen_amd_set_states") or self.num < 4:
+            for env_idx in range(self.num):
+                state = states[env_idx]
+                self.call_c_func("set_state", env_idx, state, len(state))
+            return
+        import ctypes as C
+
+        fn = self._lib.procgen_amd_set_states
+        fn.restype = None
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
+        block = 256
+        for first in range(0, self.num, block):
+            chunk = states[first:first + block]
+            offs = np.zeros(len(chunk) + 1, dtype=np.int64)
+            np.cumsum([len(st) for st in chunk], out=offs[1:])
+            fn(self._handle, first, len(chunk), b"".join(chunk), offs.ctypes.data)
 
     def get_combos(self):
         return [("LEFT", "DOWN"), ("LEFT",), ("LEFT", "UP"), ("DOWN",), (), ("UP",), ("RIGHT", "DOWN"),

@@ -40,6 +40,7 @@ struct EmuVec {
     std::vector<uint32_t> gen_bg;  // use_generated_assets
     std::vector<int> bg_req;
     std::vector<uint32_t> frame_rec;  // display-list games (pg_prep.h)
+    std::vector<int> slow_list;
     long long fast_frames = 0, slow_frames = 0;
     int use_small;
     int dev_error = 0;
@@ -118,22 +119,25 @@ static void run_all(EmuVec *v, int mode) {
                 v->frame_rec.assign((size_t)v->n * Rec::WORDS, 0xdeadbeefu);  // (a record word the prep wave does not write must not be read)
             }
             v->d.frame_rec = v->frame_rec.data();
+            if (v->slow_list.empty()) v->slow_list.assign(v->n, -1);
             int slow_count = 0;
             for (int e0 = 0; e0 < v->n; e0 += PREP_ENVS) {
                 poison_lds(&rlds);
-                FramePrep<Game> p(v->d, &rlds, &slow_count);
+                FramePrep<Game> p(v->d, &rlds, &slow_count, v->slow_list.data());
                 p.run(e0, v->n - e0 < PREP_ENVS ? v->n - e0 : PREP_ENVS);
             }
-            v->slow_frames += slow_count;
-            for (int e = 0; e < v->n; e++) {
+            for (int e = 0; e < v->n; e++) {  // "raster"
+                if (!(v->frame_rec[(size_t)e * Rec::WORDS + Rec::FLAGS] & Rec::F_FAST)) continue;
                 poison_lds(&rlds);
                 Renderer<Game> r(v->d, e, &rlds);
-                if (v->frame_rec[(size_t)e * Rec::WORDS + Rec::FLAGS] & Rec::F_FAST) {
-                    r.raster_env();
-                    v->fast_frames++;
-                } else {
-                    r.render_env();
-                }
+                r.raster_env();
+                v->fast_frames++;
+            }
+            for (int k = 0; k < slow_count; k++) {  // "render_list"
+                poison_lds(&rlds);
+                Renderer<Game> r(v->d, v->slow_list[k], &rlds);
+                r.render_env();
+                v->slow_frames++;
             }
             return;
         }

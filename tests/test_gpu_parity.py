@@ -564,3 +564,52 @@ def test_reference_state_protocol_at_its_own_length(game):
     rest = gather(1, actions[off:], state=st["state"][off], get_state=True)
     same(ref, rest, lo=off, what="midpoint restore into another seed")
     same(st, rest, lo=off, what="states after the midpoint restore")
+
+
+@pytest.mark.gpu
+def test_batched_set_states_equal_per_env_set_state():
+    """procgen_amd_set_states (one upload and one redraw per 256-env block) against the reference's protocol of one set_state per env
+    (procgen/env.py:148-153): the same frames, rewards, firsts, infos right after the restore and over the rollout that follows, for a
+    handle of three blocks and for a two-game joint handle (whose envs alternate between its parts: runs of one)."""
+    for game, n in (("coinrun", 700), ("coinrun,bigfish", 64), ("caveflyer", 300)):
+        src = make_env(n, game)
+        acts = action_stream(n, 60, seed=37)
+        for a in acts[:30]:
+            src.act(a)
+        states = src.get_state()
+        want = rollout(src, acts[30:])
+        one = make_env(n, game, rand_seed=99)
+        for e in range(n):
+            one.call_c_func("set_state", e, states[e], len(states[e]))
+        got_one = rollout(one, acts[30:])
+        many = make_env(n, game, rand_seed=77)
+        many.set_state(states)  # (procgen_amd/env.py: 256 states per procgen_amd_set_states call)
+        assert many.get_state() == states, f"{game}: states read back after the batched restore"
+        got_many = rollout(many, acts[30:])
+        assert_rollouts_equal(want, got_one, f"{game}: per-env restore")
+        assert_rollouts_equal(want, got_many, f"{game}: batched restore")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["PROCGEN_AMD_FIRST_PCT=50", "PROCGEN_AMD_FIRST_PCT=90", "PROCGEN_AMD_CHUNKS=1", "PROCGEN_AMD_CHUNKS=3", "PROCGEN_AMD_CHUNKS=4",
+                                    "PROCGEN_AMD_EARLY_SMALL=0", "PROCGEN_AMD_EARLY_SMALL=1", "PROCGEN_AMD_ORDER=1", "PROCGEN_AMD_ORDER=2", "PROCGEN_AMD_ORDER=3",
+                                    "PROCGEN_AMD_OBS_CHUNK_COPY=0", "PROCGEN_AMD_HOST_THREADS=1", "PROCGEN_AMD_DISPLAY_LIST=0"])
+def test_launch_shape_switches_do_not_change_results(monkeypatch, switch):
+    """Every environment switch of the launch shape (VecGame's constructor / launch_game: how many launch chunks and how they are cut, the
+    order of the list kernels, when the small outputs are downloaded, per-chunk landing of host observations, the issuing threads of a joint
+    handle, the frame kernels of a display-list game) selects among schedules of the same kernels over the same envs: the rollouts are
+    identical.  Sizes at which the switch takes effect: two-stream launches start at 4096 envs, per-chunk landing at 32 768 host-landed envs."""
+    name, value = switch.split("=")
+    if name == "PROCGEN_AMD_OBS_CHUNK_COPY":
+        game, n, steps, kw = "coinrun", 32768, 4, {}
+    elif name == "PROCGEN_AMD_HOST_THREADS":
+        game, n, steps, kw = "coinrun,bigfish,maze,starpilot", 4096, 12, {}
+    else:
+        game, n, steps, kw = "coinrun", 8192, 24, {}
+    acts = action_stream(n, steps, seed=41)
+    monkeypatch.delenv(name, raising=False)
+    want = rollout(make_env(n, game, **kw), acts)
+    monkeypatch.setenv(name, value)
+    got = rollout(make_env(n, game, **kw), acts)
+    monkeypatch.delenv(name)
+    assert_rollouts_equal(want, got, f"{game} N={n}: {switch}")

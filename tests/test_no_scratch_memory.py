@@ -19,7 +19,7 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 HIPCC = "/opt/rocm/bin/hipcc"
 GAMES = ["CoinRun", "Plunder", "Leaper", "FruitBot", "Jumper", "CaveFlyer", "StarPilot", "Climber"]
 SPLIT_RESET = {"Leaper", "Jumper", "CaveFlyer"}
-DISPLAY_LIST = {"CoinRun", "Climber"}  # games (of the ones compiled here) whose frames are drawn by prep -> raster kernels (pg_prep.h)
+DISPLAY_LIST = {"CoinRun", "Climber"}  # games (of the ones compiled here) whose frames are drawn by prep -> raster -> render_list kernels (pg_prep.h)
 # render<Game, false> kernels whose RENDER_MIN_WAVES = 4 hint costs a small spill (bytes per lane) and was adopted because the same-box A/B
 # said so (profiles/r05_rot_pool_ab.txt: leaper +9 %, fruitbot +11 %, jumper +13 % over the same build without the hint; profiles/r05_try_ab.txt: climber's five-wave hint +4.5 %); the limit keeps
 # the spill from growing unnoticed -- a spill in a step kernel, or a larger one here, is still a failure
@@ -37,7 +37,7 @@ def _scratch_bytes(game, tmp):
     kinds = sorted(re.sub(r"^_ZN5pgamd\d+([a-z_0-9]+?)I.*$", r"\1", n) for n in names)
     # ... and render_human, the 512 x 512 info frame (pg_human.h)
     expect = ["render", "render", "render_human", "step_list", "step_list", "step_tier0"] + (["reset_grid", "reset_list"] if game in SPLIT_RESET else [])
-    expect += ["prep", "raster"] if game in DISPLAY_LIST else []
+    expect += ["prep", "raster", "render_list"] if game in DISPLAY_LIST else []
     assert len(names) == len(sizes) and kinds == sorted(expect), (game, names)
     return dict(zip(names, sizes))
 

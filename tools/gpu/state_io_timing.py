@@ -24,4 +24,11 @@ t1 = time.perf_counter()
 print(f"{game} N={n}: set_state of {m} envs {t1 - t0:.2f} s ({m / (t1 - t0):.0f} states/s)", flush=True)
 got = env.get_state()[:m]
 assert got == [st[(e + 1) % n] for e in range(m)], "states restored at other indices must come back byte for byte (game_n is adopted, reference src/game.cpp:253)"
+# the whole vector through the batched hook (procgen_amd_set_states: 256 states per call, one upload + one redraw per block)
+rot = st[1:] + st[:1]
+t0 = time.perf_counter()
+env.set_state(rot)
+t1 = time.perf_counter()
+print(f"{game} N={n}: batched set_state of every env {t1 - t0:.2f} s ({n / (t1 - t0):.0f} states/s)", flush=True)
+assert env.get_state() == rot
 env.close()
