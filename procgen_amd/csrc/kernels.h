@@ -37,6 +37,7 @@ struct GameEntry {
     hipError_t (*render_human)(const DevCtx &, int env_base, int count, hipStream_t);  // the 512 x 512 info frames of envs [env_base, env_base + count) (pg_human.h)
     bool split_reset;  // GameSplit<Game>::value: ended episodes are finished by reset_list kernels behind the step kernels
     int frame_rec_words;  // display-list games (pg_prep.h): words of an env's frame record, FrameRec<Game>::WORDS; 0: the game renders with one kernel
+    hipError_t (*render_slow)(const DevCtx &, int env_base, int count, int chunk, hipStream_t);  // display-list games: render_list<Game> over one chunk's slow list
 };
 constexpr int MAX_GAME_TABLE_WORDS = 2048;
 // mode 0: initial reset + first observation of every env; mode 1: one step
@@ -51,6 +52,7 @@ int game_host_tables(int game_id, const GameOptions &opt, uint32_t *out, int max
 bool (*game_use_block_asset(int game_id))(int);
 bool game_split_reset(int game_id);
 int game_frame_rec_words(int game_id);
+hipError_t launch_render_slow(int game_id, const DevCtx &d, int env_base, int count, int chunk, hipStream_t stream);
 hipError_t launch_paint_backgrounds(const DevCtx &d, int env_base, int count, hipStream_t stream);  // use_generated_assets (pg_bgpaint.h); no-op otherwise
 // render kernel launch order of the envs [base, base + count) of one launch chunk by background image (kernels.hip); scratch: MAX_BACKGROUNDS ints
 hipError_t launch_render_order(const DevCtx &d, int base, int count, int *scratch, int *order, hipStream_t stream);

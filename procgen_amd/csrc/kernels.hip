@@ -73,6 +73,10 @@ bool game_split_reset(int game_id) {
     const GameEntry *e = find(game_id);
     return e ? e->split_reset : false;
 }
+hipError_t launch_render_slow(int game_id, const DevCtx &d, int env_base, int count, int chunk, hipStream_t stream) {
+    const GameEntry *e = find(game_id);
+    return e ? e->render_slow(d, env_base, count, chunk, stream) : hipErrorInvalidValue;
+}
 int game_frame_rec_words(int game_id) {
     const GameEntry *e = find(game_id);
     return e ? e->frame_rec_words : 0;

@@ -172,8 +172,7 @@ static void launch_render(const DevCtx &d0, int env_base, int count, hipStream_t
             if (t0) (void)hipEventRecord(t0, st);
             hipLaunchKernelGGL(raster<Game>, dim3(count), dim3(64), 0, st, d, env_base, chunk);
             if (t1) (void)hipEventRecord(t1, st);
-            hipLaunchKernelGGL(render_list<Game>, dim3(count < 128 ? count : 128), dim3(64), 0, st, d, env_base, chunk);
-            return;
+            return;  // (frames the short path cannot draw: render_slow, launched by libenv_observe when a prep wave raised the flag)
         }
     }
     if (t0) (void)hipEventRecord(t0, st);
@@ -305,6 +304,17 @@ static hipError_t render_one(const DevCtx &d, int env, int count, hipStream_t st
     return hipGetLastError();
 }
 
+// display-list games: the frames of chunk `chunk` = envs [env_base, env_base + count) that its prep kernel queued for the full renderer
+template <class Game>
+static hipError_t render_slow(const DevCtx &d, int env_base, int count, int chunk, hipStream_t stream) {
+    if constexpr (GameDisplayList<Game>::value) {
+        DevCtx d1 = d;
+        d1.render_order = nullptr;
+        hipLaunchKernelGGL(render_list<Game>, dim3(count < 4096 ? count : 4096), dim3(64), 0, stream, d1, env_base, chunk);
+    }
+    return hipGetLastError();
+}
+
 #define PG_CAT2(a, b) a##b
 #define PG_CAT(a, b) PG_CAT2(a, b)
 // a host function (a namespace-scope const table would also be emitted for the device, where the launchers do not exist)
@@ -317,6 +327,7 @@ const GameEntry *PG_CAT(game_entry_, PG_GAME)() {
         launch_human<PG_GAME>,
         GameSplit<PG_GAME>::value,
         GameDisplayList<PG_GAME>::value ? FrameRec<PG_GAME>::WORDS : 0,
+        render_slow<PG_GAME>,
     };
     return &e;
 }

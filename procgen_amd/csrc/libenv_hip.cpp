@@ -221,7 +221,7 @@ struct VecGame {
     hipEvent_t ev_frames[MAX_CHUNKS] = {}, ev_obs = nullptr;
     bool obs_chunk_copy = false;
     int order = 0;  // PROCGEN_AMD_ORDER
-    int first_pct = 75;  // PROCGEN_AMD_FIRST_PCT: share of the first of two chunks
+    int first_pct = 60;  // PROCGEN_AMD_FIRST_PCT: share of the first of two chunks (75 until round 6; profiles/r06_call12_ab.txt: 60 is +2..7 % for five of six games, with the round-5 kernels as well)
     int chunks = 2;  // PROCGEN_AMD_CHUNKS: env range cut in 2 so one chunk's step kernel overlaps the other's render kernel (+6 % measured)
     LaunchStreams streams() const {
         LaunchStreams ls{};
@@ -267,9 +267,12 @@ struct VecGame {
     // chunk is re-sorted by background image, images dealt to the XCDs (workgroup j runs on XCD j mod 8, each with its own L2)
     uint32_t *d_frame_rec = nullptr;  // display-list games: the frame records (DevCtx::frame_rec, null once the handle has gone back to the one-kernel renderer)
     int slow_streak = 0;              // steps seen to send most frames to the full renderer's list kernel
+    bool step_used_display_list = false;  // the step in flight was launched with prep -> raster (read_tail may switch the handle back meanwhile)
+    long long slow_passes = 0;        // draw_slow_frames calls so far (procgen_amd_display_list_frames out[2])
     int render_order_period = 0;
     int *d_render_order = nullptr, *d_render_order_scratch = nullptr;
     void rebuild_render_order();
+    void draw_slow_frames();
     void bind_routing() {  // double-buffered by step parity: this step reads [cur], fills [nxt]
         const int cur = (int)(step_count & 1), nxt = cur ^ 1;
         d.big_list = d_big_list[cur];
@@ -582,10 +585,11 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
     {
         int *rec = nullptr;
         void *rec_dev = nullptr;
-        HIP_CHECK(hipHostMalloc((void **)&rec, 8 * sizeof(int), hipHostMallocMapped));
-        memset(rec, 0, 8 * sizeof(int));
+        HIP_CHECK(hipHostMalloc((void **)&rec, 16 * sizeof(int), hipHostMallocMapped));  // words 0..7: the error record; word 8: the slow-frame flag of a display-list handle
+        memset(rec, 0, 16 * sizeof(int));
         HIP_CHECK(hipHostGetDevicePointer(&rec_dev, rec, 0));
         h_error_rec = rec;
+        d.slow_flag = (int *)rec_dev + 8;
         const unsigned long long a = (unsigned long long)rec_dev;
         const int words[2] = {(int)(unsigned)(a & 0xffffffffull), (int)(unsigned)(a >> 32)};
         HIP_CHECK(hipMemcpy(d.error + ERROR_INFO_OFFSET + 6, words, sizeof(words), hipMemcpyHostToDevice));
@@ -795,6 +799,38 @@ void VecGame::set_buffers(struct libenv_buffers *bufs) {  // reference src/vecga
 // called between steps (the handle's streams are idle): enqueued on the main stream ahead of the step -- the chunk streams fork from it
 // (launch_game), so every render kernel of the step sees the new order; the sort reads the backgrounds as the last step left them (an
 // episode that begins in this step is drawn from a stale slot once, which costs locality, not correctness)
+// Display-list handles (pg_prep.h): the frames of the step just joined that its prep kernels queued for the full renderer -- their raster
+// workgroups left them alone.  Off the hot path by construction: it runs only when a prep wave raised the host-mapped flag.
+void VecGame::draw_slow_frames() {
+    h_error_rec[8] = 0;
+    slow_passes++;
+    const int N = num_envs;
+    const int nchunk = N >= 4096 ? (chunks > 1 ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1) : 1;
+    const int per = chunk_envs_for(N, nchunk);
+    const int first = (nchunk == 2 && first_pct > 0) ? first_chunk_envs(N, first_pct) : 0;
+    int bases[MAX_CHUNKS] = {}, used = 0;
+    for (int c = 0; c < nchunk; c++) {
+        const int base = first > 0 ? (c == 0 ? 0 : first) : c * per;
+        const int count = first > 0 ? (c == 0 ? first : N - first) : ((N - base) < per ? (N - base) : per);
+        if (count <= 0) break;
+        HIP_CHECK(launch_render_slow(kernel_id, d, base, count, c, stream));
+        bases[used++] = base;
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+    check_late_error("the full renderer's pass over a display-list handle's slow frames");
+    if (host_observations) {  // their frames were landed before they were drawn: once more, env by env
+        int counts[MAX_CHUNKS] = {};
+        HIP_CHECK(hipMemcpy(counts, d.slow_count + d.step_parity * MAX_CHUNKS, sizeof(counts), hipMemcpyDeviceToHost));
+        std::vector<int> list;
+        for (int c = 0; c < used; c++) {
+            if (counts[c] <= 0) continue;
+            list.resize((size_t)counts[c]);
+            HIP_CHECK(hipMemcpy(list.data(), d.slow_list + bases[c], sizeof(int) * (size_t)counts[c], hipMemcpyDeviceToHost));
+            for (int e : list) HIP_CHECK(hipMemcpy(ob_contig ? ob_ptr[e] : (void *)(h_obs_stage + (size_t)e * OBS_BYTES), d.obs + (size_t)e * OBS_BYTES, OBS_BYTES, hipMemcpyDeviceToHost));
+        }
+    }
+}
+
 void VecGame::rebuild_render_order() {
     const int N = num_envs;
     const int nchunk = N >= 4096 ? (chunks > 1 ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1) : 1;
@@ -824,6 +860,7 @@ void VecGame::launch_kernels(int mode) {
     for (int c = 0; c < MAX_CHUNKS; c++)
         for (int t = 0; t < NUM_TIERS; t++) ls.list_count[c][t] = mode == 0 ? 0 : host_list_count[c][t];
     d.step_parity = (int)(step_count & 1);  // (display-list games: which of the two slow-list counter sets this step fills)
+    step_used_display_list = d.frame_rec != nullptr;
     HIP_CHECK(launch_step(kernel_id, d, mode, ls));
     step_count++;
 }
@@ -996,6 +1033,7 @@ void VecGame::observe(bool from_api) {  // reference src/vecgame.cpp:363-376,416
     }
     if (early_small) HIP_CHECK(hipStreamSynchronize(stream));  // (the render kernels, the landing of the frames)
     check_late_error();
+    if (step_used_display_list && h_error_rec[8] != 0) draw_slow_frames();  // (a prep wave of this step queued a frame for the full renderer)
     if (host_observations && !ob_contig)
         for (size_t e = 0; e < N; e++) memcpy(ob_ptr[e], h_obs_stage + e * OBS_BYTES, OBS_BYTES);
     if (tk_pending) {  // (the stream is joined: both events have completed)
@@ -1746,6 +1784,15 @@ LIBENV_API int procgen_amd_display_list_frames(libenv_env *handle, int *out) {
     for (uint32_t f : flags) fast += (int)(f & 1u);
     out[0] = fast;
     out[1] = v->num_envs - fast;
+    if (getenv("PROCGEN_AMD_DISPLAY_LIST_REPORT")) {  // measurement aid: how often the full renderer's pass ran, and why the first few frames went there
+        fprintf(stderr, "[procgen_amd display list] %d of %d frames from their record; %lld slow passes in %llu steps\n", fast, v->num_envs, v->slow_passes, (unsigned long long)v->step_count);
+        int shown = 0;
+        for (int e = 0; e < v->num_envs && shown < 8; e++)
+            if (!(flags[(size_t)e] & 1u)) {
+                fprintf(stderr, "  env %d: flags 0x%08x (bit 8 too many / failed commands, 9 error, 10 monochrome, 11 vel info, 12 no pull form; error code %u)\n", e, flags[(size_t)e], flags[(size_t)e] >> 16);
+                shown++;
+            }
+    }
     return 1;
 }
 // host only: out[p] = render_order_slot(p, count) (shard_map.h) for p in [0, count)

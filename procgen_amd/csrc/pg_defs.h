@@ -270,6 +270,7 @@ struct DevCtx {
     uint32_t *frame_rec;  // [num_envs][FrameRec<Game>::WORDS]
     int *slow_list;       // [num_envs]
     int *slow_count;      // [2][MAX_CHUNKS], in the block of small outputs the host downloads every step
+    int *slow_flag;       // host-mapped word: set by a prep wave that queued a frame; the host launches render_list only then (libenv_observe)
     int step_parity;
     int clear_lists;       // render kernel: zero big_count[] (nobody reads it any more this step; it is the next step's next_big_count)
     unsigned long long *wave_trace;    // [num_envs][32] PROCGEN_AMD_DEBUG & 8192: 100 MHz timestamps of the last step's workgroups: step start / end / kind+HW_ID, render start / end / HW_ID (null otherwise)

@@ -12,11 +12,13 @@
 //                 lanes densely, lane = (env, drawable): the fp64 set-up runs at ~60 of 64 lanes, and the background is just one more
 //                 lane of the same code.  Visible commands are packed in draw order into the env's record.  (2) Per env: the grid type
 //                 table and the pull form's tables (Renderer::build_type_table / build_pull_tables, unchanged), copied to the record.
-//                 A frame the rasterizer's short path cannot draw (per-cell path, more than 64 visible commands, paint_vel_info,
-//                 monochrome assets, any error) is queued for the full renderer (Renderer::render_env): render_list<Game>, a small grid
-//                 behind the rasterizer -- a fraction of a percent of the frames under default options; a handle most of whose frames
-//                 land there (center_agent = false for a wide world, monochrome assets) goes back to the one-kernel renderer (libenv_hip.cpp).
-//   raster<Game>  one wave per env, Renderer::raster_env: loads the record -- header by scalar loads, <= 64 commands one per lane, the
+//                 A frame the rasterizer's short path cannot draw (per-cell path, more than 192 visible commands, paint_vel_info,
+//                 monochrome assets, any error) is queued for the full renderer (Renderer::render_env) and a host-mapped flag is raised:
+//                 libenv_observe, having joined the step, then launches render_list<Game> over the queues -- no frame under default
+//                 coinrun options in 77 000 emulated ones; a kernel behind every raster launch cost the step 4-7 % in tail latency.  A handle
+//                 most of whose frames land there (center_agent = false for a wide world, monochrome assets) goes back to the one-kernel
+//                 renderer (libenv_hip.cpp VecGame::read_tail).
+//   raster<Game>  one wave per env, Renderer::raster_env: loads the record -- header by scalar loads, the first 64 commands one per lane, the
 //                 tables into LDS -- and runs the band passes.  No fp64, no header, no options.
 //
 // Reference: the same calls as pg_render.h -- BasicAbstractGame::game_draw (src/basic-abstract-game.cpp:1009-1012), draw_background
@@ -36,7 +38,10 @@ struct GameDisplayList<Game, decltype((void)Game::DISPLAY_LIST)> {
     static constexpr bool value = Game::DISPLAY_LIST;
 };
 
-constexpr int PREP_ENVS = 4;  // envs per prep wave: 4 x (1 + ~25 entities) drawables = two dense passes of 64 lanes for coinrun
+#ifndef PG_PREP_ENVS
+#define PG_PREP_ENVS 4
+#endif
+constexpr int PREP_ENVS = PG_PREP_ENVS;  // envs per prep wave: 4 x (1 + ~25 entities) drawables = two dense passes of 64 lanes for coinrun
 
 template <class Game>
 struct FramePrep {
@@ -152,20 +157,20 @@ struct FramePrep {
                 if (PG_BALLOT(l, (PG_LV(ez, l) & 0xffu) == (uint32_t)e && ((PG_LV(ez, l) >> 17) & 3u) == 3u) != 0) slow |= 1u << e;
                 const uint64_t vis = PG_BALLOT(l, (PG_LV(ez, l) & 0xffu) == (uint32_t)e && ((PG_LV(ez, l) >> 16) & 5u) == 4u && PG_LA(w, 0, l) != 0);
                 const int cnt = pg_popc64(vis);
-                if (ncmd[e] + cnt > 64) slow |= 1u << e;  // more visible commands than the rasterizer's register set
+                if (ncmd[e] + cnt > Rec::MAX_CMDS) slow |= 1u << e;  // more visible commands than a record holds
                 PG_FOR_LANES(l) {
                     const uint32_t f = PG_LV(ez, l);
                     if ((f & 0xffu) == (uint32_t)e && ((f >> 18) & 1u)) {
                         if ((f >> 16) & 1u) {
                             _Pragma("unroll") for (int k = 0; k < 7; k++) rec[Rec::BG + k] = PG_LA(w, k, l);
-                        } else if (((vis >> l) & 1ull) && ncmd[e] + cnt <= 64) {
+                        } else if (((vis >> l) & 1ull) && ncmd[e] + cnt <= Rec::MAX_CMDS) {
                             uint32_t *c = rec + Rec::CMD + 8 * (ncmd[e] + pg_popc64(vis & pg_mask_lt(l)));
                             _Pragma("unroll") for (int k = 0; k < 7; k++) c[k] = PG_LA(w, k, l);
                             c[7] = (f >> 8) & 0xffu;
                         }
                     }
                 }
-                if (ncmd[e] + cnt <= 64) ncmd[e] += cnt;
+                if (ncmd[e] + cnt <= Rec::MAX_CMDS) ncmd[e] += cnt;
             }
         }
         // (the counts move to lanes: the loop below is not unrolled, and a register array indexed by its counter would live in scratch)
@@ -230,7 +235,11 @@ struct FramePrep {
             // header: the scalars are wave-uniform; lane k takes word k and one store writes them (the background's words were written by its lane)
             uint32_t hw[Rec::HDR_WORDS];
             _Pragma("unroll") for (int k = 0; k < Rec::HDR_WORDS; k++) hw[k] = 0;
-            hw[Rec::FLAGS] = (fast ? Rec::F_FAST : 0u) | (pull ? Rec::F_PULL : 0u) | (multi ? Rec::F_MULTI : 0u);
+            // (bits 8..: why a frame left the short path -- more than 64 visible commands or a failed command, an error, monochrome assets,
+            // paint_vel_info, no pull form -- for procgen_amd_display_list_frames' per-env view)
+            hw[Rec::FLAGS] = (fast ? Rec::F_FAST : 0u) | (pull ? Rec::F_PULL : 0u) | (multi ? Rec::F_MULTI : 0u) | (((slow >> e) & 1u) << 8) | ((r.G.error != 0 ? 1u : 0u) << 9) |
+                             ((r.opt.use_monochrome_assets ? 1u : 0u) << 10) | (((r.G.has_useful_vel_info && r.opt.paint_vel_info) ? 1u : 0u) << 11) |
+                             (((GameDrawsGrid<Game>::value && !pull) ? 1u : 0u) << 12) | ((uint32_t)(r.G.error & 0xff) << 16);
             hw[Rec::DIMS] = (uint32_t)(ny_full & 0xff) | ((uint32_t)PG_READLANE(ncmd_l, e) << 8) | ((uint32_t)nfill << 16);
             hw[Rec::COLSEAM] = (uint32_t)colseam;
             hw[Rec::COLSEAM + 1] = (uint32_t)(colseam >> 32);
@@ -258,7 +267,10 @@ struct FramePrep {
 #if defined(PGAMD_WAVE_EMU)
                 slow_list[(*slow_count)++] = env;
 #else
-                if (PG_LANE_ID() == 0) slow_list[atomicAdd(slow_count, 1)] = env;
+                if (PG_LANE_ID() == 0) {
+                    slow_list[atomicAdd(slow_count, 1)] = env;
+                    *reinterpret_cast<volatile int *>(d.slow_flag) = 1;  // (host-mapped: the host sees it when it has joined the step)
+                }
 #endif
             }
             PG_SYNC();  // (the next env's tables overwrite the arena)

@@ -218,11 +218,12 @@ struct RenderLdsT {
 // Frame record of a display-list game (pg_prep.h): what prep<Game> leaves in HBM for raster<Game>, per env.  Words:
 //   [0, 16)          header: flags, dims (window rows | visible commands << 8 | grid fills << 16), the pull form's column-seam / row-seam /
 //                    row-any masks, the background command (7 words), the atlas' reference cell width
-//   [CMD, CMD + 512) up to 64 entity commands in draw order, 8 words each: geom basex srcy ix iy src aux | render_z + 1
+//   [CMD, TAB)       up to MAX_CMDS entity commands in draw order, 8 words each: geom basex srcy ix iy src aux | render_z + 1
 //   [TAB, ...)       the pull form's tables exactly as they lie in the render arena (RenderLdsT [ci, typeimg))
 template <class Game>
 struct FrameRec {
-    enum : int { FLAGS = 0, DIMS = 1, COLSEAM = 2, ROWSEAM = 4, ROWANY = 6, BG = 8, REF_W = 15, HDR_WORDS = 16, CMD = 16, CMD_WORDS = 8, TAB = CMD + 64 * CMD_WORDS };
+    // MAX_CMDS: three register sets' worth -- coinrun's enemies leave eight trail sprites each, and 1 frame in 10 000 shows more than 64 sprites
+    enum : int { FLAGS = 0, DIMS = 1, COLSEAM = 2, ROWSEAM = 4, ROWANY = 6, BG = 8, REF_W = 15, HDR_WORDS = 16, CMD = 16, CMD_WORDS = 8, MAX_CMDS = 192, TAB = CMD + MAX_CMDS * CMD_WORDS };
     enum : uint32_t { F_FAST = 1u, F_PULL = 2u, F_MULTI = 4u };
     static constexpr int LDS_TAB_WORD0 = (int)(offsetof(RenderLdsT<Game>, ci) / 4);
     static constexpr int TAB_SINGLE_WORDS = (int)((offsetof(RenderLdsT<Game>, srcx) - offsetof(RenderLdsT<Game>, ci) + 3) / 4);
@@ -2684,6 +2685,40 @@ struct Renderer {
     // the arena, then the band passes of render_env for a frame whose commands fit one register set and whose grid is drawn in pull form
     // (every other frame is queued for render_env by the prep kernel).  Same painter's order: background, z = -1, grid cells, z = 0, z = 1
     // (BAG:979-1012, 921-970).
+    // commands [SET set, SET set + SET) of a frame record, one per lane (z: the command's layer, render_z + 1; 255 = no command).  SET = 64,
+    // the lanes of a register set; -DPG_CMD_SET_LANES=8 is the emulation tests' way to send ordinary frames down the several-sets path
+#ifndef PG_CMD_SET_LANES
+#define PG_CMD_SET_LANES 64
+#endif
+    static constexpr int CMD_SET = PG_CMD_SET_LANES;
+    PG_DEV void load_cmd_set(const uint32_t *rec, int set, int ncmd, CmdRegs &r, PG_LANE_REF(uint32_t, z)) {
+        typedef FrameRec<Game> Rec;
+        PG_R_LANES(l) {
+            const int k = set * CMD_SET + l;
+            const bool in = l < CMD_SET && k < ncmd;
+            const pg_u4 *c = reinterpret_cast<const pg_u4 *>(rec + Rec::CMD + Rec::CMD_WORDS * (in ? k : 0));
+            const pg_u4 a = c[0], b = c[1];
+            PG_LV(r.geom, l) = in ? a.x : 0u;
+            PG_LV(r.basex, l) = in ? a.y : 0u;
+            PG_LV(r.srcy, l) = in ? a.z : 0u;
+            PG_LV(r.ix, l) = in ? a.w : 0u;
+            PG_LV(r.iy, l) = in ? b.x : 0u;
+            PG_LV(r.src, l) = in ? b.y : 0u;
+            PG_LV(r.aux, l) = in ? b.z : 0u;
+            if constexpr (GEN) PG_LV(r.e0, l) = PG_LV(r.e1, l) = 0;
+            PG_LV(z, l) = in ? b.w : 255u;
+        }
+    }
+    // layer `layer` of the commands past the first register set, in draw order
+    PG_DEV void more_cmd_sets(const uint32_t *rec, int ncmd, uint32_t layer) {
+        for (int set = 1; set * CMD_SET < ncmd; set++) {
+            CmdRegs r;
+            PG_LANE_VAR(uint32_t, z);
+            load_cmd_set(rec, set, ncmd, r, z);
+            const uint64_t m = PG_BALLOT(l, PG_LV(z, l) == layer);
+            if (m) run_batch(r, m);
+        }
+    }
     PG_DEV void raster_env() {
         typedef FrameRec<Game> Rec;
         static_assert(!GEN, "generated assets draw through render_env");
@@ -2711,19 +2746,7 @@ struct Renderer {
         }
         CmdRegs er;
         PG_LANE_VAR(uint32_t, ez);
-        PG_R_LANES(l) {
-            const bool in = l < ncmd;
-            const pg_u4 *c = reinterpret_cast<const pg_u4 *>(rec + Rec::CMD + Rec::CMD_WORDS * (in ? l : 0));
-            const pg_u4 a = c[0], b = c[1];
-            PG_LV(er.geom, l) = in ? a.x : 0u;
-            PG_LV(er.basex, l) = in ? a.y : 0u;
-            PG_LV(er.srcy, l) = in ? a.z : 0u;
-            PG_LV(er.ix, l) = in ? a.w : 0u;
-            PG_LV(er.iy, l) = in ? b.x : 0u;
-            PG_LV(er.src, l) = in ? b.y : 0u;
-            PG_LV(er.aux, l) = in ? b.z : 0u;
-            PG_LV(ez, l) = in ? b.w : 255u;
-        }
+        load_cmd_set(rec, 0, ncmd, er, ez);  // the frame's first 64 commands stay in registers for all passes
         const uint64_t ez0 = PG_BALLOT(l, PG_LV(ez, l) == 0u), ez1 = PG_BALLOT(l, PG_LV(ez, l) == 1u), ez2 = PG_BALLOT(l, PG_LV(ez, l) == 2u);
         dma_join();
         PG_SYNC();
@@ -2745,6 +2768,7 @@ struct Renderer {
                 else exec_large(bc0);
             }
             if (ez0 && !PG_DBG(d, 4)) run_batch(er, ez0);
+            if (ncmd > CMD_SET) more_cmd_sets(rec, ncmd, 0u);
             if constexpr (GameDrawsGrid<Game>::value) {
                 if (pull && !PG_DBG(d, 2)) {
                     if (multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w);
@@ -2752,7 +2776,14 @@ struct Renderer {
                     if constexpr (GameHasGridFills<Game>::value) draw_pull_fills(nfill);
                 }
             }
-            if ((ez1 | ez2) && !PG_DBG(d, 4)) run_batch(er, ez1, ez2);  // z = 0, then z = 1, in one pass
+            if (ncmd <= CMD_SET) {
+                if ((ez1 | ez2) && !PG_DBG(d, 4)) run_batch(er, ez1, ez2);  // z = 0, then z = 1, in one pass
+            } else {  // (1 frame in 10 000: the commands past the first 64 are fetched again for every band and layer)
+                if (ez1) run_batch(er, ez1);
+                more_cmd_sets(rec, ncmd, 1u);
+                if (ez2) run_batch(er, ez2);
+                more_cmd_sets(rec, ncmd, 2u);
+            }
             PG_SYNC();
             if (!PG_DBG(d, 8)) store_band();
             else dma_join();

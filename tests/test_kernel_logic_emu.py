@@ -383,3 +383,32 @@ def test_rotation_record_pool_build_variant_draws_the_same_frames():
         r = subprocess.run([sys.executable, tool, game, "8", "150"] + extra, env=e, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         assert "rotation-record pool:" in r.stdout and " 0 mismatching steps" in r.stdout, r.stdout[-600:]  # (the fallbacks did run)
+
+
+def test_display_list_kernels_match_the_oracle_through_every_path():
+    """The display-list games' frame kernels (pg_prep.h: prep -> raster, the full renderer for queued frames) in the emulation, on poisoned
+    LDS, against the oracle: the six games under default options (every frame from its record), the options that send every frame to the full
+    renderer's queue, and a build whose register sets hold 8 commands instead of 64 (-DPG_CMD_SET_LANES=8), so that ordinary frames take the
+    path a frame with more than 64 visible sprites takes (coinrun: 1 in 10 000, enemy trails) -- commands past the first set fetched per band and
+    layer, drawn in the reference's order."""
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "quick_emu.py")
+    base = dict(os.environ, PG_EMU_GAMES="CoinRun,BigFish,Maze,Miner,Climber,Chaser", PG_EMU_POISON_LDS="1")
+    base.pop("PG_EMU_DEFS", None)
+    cases = [(g, [], None, True) for g in ("coinrun", "bigfish", "maze", "miner", "climber", "chaser")]
+    cases += [("coinrun", ["center_agent=False"], None, False), ("coinrun", ["use_monochrome_assets=True"], None, False), ("coinrun", ["paint_vel_info=True"], None, False),
+              ("climber", ["use_backgrounds=False"], None, True)]
+    cases += [(g, [], "-DPG_CMD_SET_LANES=8", True) for g in ("coinrun", "bigfish", "chaser")]
+    for game, extra, defs, fast in cases:
+        e = dict(base)
+        if defs:
+            e["PG_EMU_DEFS"] = defs
+        r = subprocess.run([sys.executable, tool, game, "8", "120"] + extra, env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and " 0 mismatching steps" in r.stdout, (game, extra, defs, r.stdout[-1200:] + r.stderr[-1200:])
+        import re
+        m = re.search(r"frames drawn from their record (\d+) / by the full renderer (\d+)", r.stdout)
+        assert m, r.stdout[-600:]
+        rec, full = int(m.group(1)), int(m.group(2))
+        assert (rec > 0 and full <= rec) if fast else (rec == 0 and full > 0), (game, extra, rec, full)
