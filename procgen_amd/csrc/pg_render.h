@@ -1123,6 +1123,12 @@ struct Renderer {
     // the few rows that have one.  (Round 6.  The per-pixel lookup chain of rounds 2-5 -- two LDS reads and ~25 vector instructions per
     // pixel row -- was 42 % of the kernel's vector instructions, profiles/r06_valu_by_phase.txt; two cell-row-major forms tried first spent
     // what they saved on scalar run bookkeeping and on one dependent round trip per cell row, profiles/r06_call3_ab.txt, r06_raster_ablation.txt.)
+    // MULTI: the frame shows cell images of several sizes (maze: 128 x 128 sand + 27 x 27 cheese; miner: three sizes): a lane's cell then
+    // has a size class k, its source column comes from that class's column table (looked up with the cell, once per cell row) and its source
+    // row from the class's row table (one LDS read per row and lane instead of the scalar decode); Qt may have dropped a class's last
+    // sample of a row or column, per class.  Measured slower than the per-pixel form for these frames (draw_tiles_pull), so it is the
+    // A/B variant, not the default.
+    template <bool MULTI>
     PG_DEV void rows_pass(int ny_full, int ref_w, uint32_t band_any, uint32_t band_seam) {
         static_assert(BAND_ROWS <= 16, "the band's row entries live in lanes 0..15 (slot 0) and 16..31 (slot 1)");
         // (plain lane sections: the empty asm a PG_R_LANES section takes its lane id through makes the compiler wait for every texel in
@@ -1136,14 +1142,16 @@ struct Renderer {
         for (int sr = 0; sr < 2; sr++) {
             const uint32_t rows = sr ? band_seam : band_any;
             if (rows == 0) continue;
-            PG_LANE_ARR(uint32_t, tex, BAND_ROWS);  // (row j's word is written before it is read: only rows in `drawn` are)
+            PG_LANE_ARR(uint32_t, tex, BAND_ROWS);  // (defined up front: a register the allocator reuses as a temporary is a wait on a fetch in flight)
             PG_LANE_VAR(uint32_t, hm);     // bit j: this lane draws row j
             PG_LANE_VAR(uint32_t, cboff);  // byte offset of the lane's cell image of the current cell row + its source column
             PG_LANE_VAR(uint32_t, hbit);   // 1: the lane has a cell with an image in the current cell row
+            PG_LANE_VAR(uint32_t, kcls);   // MULTI: the size class of that image
             PG_FOR_LANES(l) {
                 PG_LV(hm, l) = 0;
                 PG_LV(cboff, l) = 0;
                 PG_LV(hbit, l) = 0;
+                PG_LV(kcls, l) = 0;
                 for (int j = 0; j < BAND_ROWS; j++) PG_LA(tex, j, l) = 0;
             }
             int prev_cy = -1;
@@ -1152,7 +1160,7 @@ struct Renderer {
             _Pragma("unroll") for (int j = 0; j < BAND_ROWS; j++) {
                 if (((rows >> j) & 1u) == 0) continue;
                 const uint32_t e = PG_READLANE(riv, sr * 16 + j);
-                if ((e >> 30) != 3u) continue;  // not covered in this slot, or Qt dropped the row's sample
+                if (MULTI ? (e >> 31) == 0 : (e >> 30) != 3u) continue;  // not covered in this slot (one size: or Qt dropped the row's sample)
                 const int cy = (int)((e >> 12) & 0x1fu);
                 if (cy != prev_cy) {
                     prev_cy = cy;
@@ -1162,17 +1170,41 @@ struct Renderer {
                         const uint32_t ct = lds->cellimg[((c >> 12) & 0x1fu) * (uint32_t)ny_full + (uint32_t)cy];
                         const uint32_t tv = typeany[ct & 63u];
                         const uint32_t cell = ct < 64u ? tv : CELL_NONE;
-                        const bool h = (c >> 30) == 3u && cell != CELL_NONE;  // covered, and Qt kept the column's sample
-                        PG_LV(cboff, l) = h ? ((cell & 0x7ffffffu) + (c & 0xfffu)) << 2 : 0u;  // (a lane without a cell fetches a word of the atlas' first row and draws nothing)
+                        bool h = (c >> 31) != 0 && cell != CELL_NONE;
+                        uint32_t col = c & 0xfffu, k = 0;
+                        if constexpr (MULTI && RenderLds::SIZE_CLASSES) {
+                            k = (cell >> 27) & 3u;  // (CELL_NONE reads class 3: in bounds, never a hit)
+                            const uint32_t sx1 = lds->srcx[k ? k - 1u : 0u][0][l];
+                            h = h && (k ? sx1 != 0xffu : ((c >> 30) & 1u) != 0);
+                            col = k ? sx1 : col;
+                        } else {
+                            h = h && ((c >> 30) & 1u) != 0;  // Qt kept the column's sample
+                        }
+                        PG_LV(cboff, l) = h ? ((cell & 0x7ffffffu) + col) << 2 : 0u;  // (a lane without a cell fetches a word of the atlas' first row and draws nothing)
                         PG_LV(hbit, l) = h ? 1u : 0u;
+                        PG_LV(kcls, l) = k;
                         PG_LV(tl, l) = (h && (cell >> 31) == 0) ? 1u : 0u;
                     }
                     if (PG_BALLOT(l, PG_LV(tl, l) != 0) != 0) translucent = true;
                 }
-                const char *rowp = reinterpret_cast<const char *>(d.pixels + (e & 0xfffu) * (uint32_t)ref_w);  // wave-uniform
-                PG_FOR_LANES(l) {
-                    PG_LA(tex, j, l) = *reinterpret_cast<const uint32_t *>(rowp + PG_LV(cboff, l));  // scalar base + 32-bit lane offset
-                    PG_LV(hm, l) |= PG_LV(hbit, l) << j;
+                if constexpr (MULTI && RenderLds::SIZE_CLASSES) {
+                    const uint32_t off0 = (e & 0xfffu) * (uint32_t)ref_w;  // class 0: wave-uniform source row
+                    const bool ok0 = ((e >> 30) & 1u) != 0;
+                    const char *base = reinterpret_cast<const char *>(d.pixels);
+                    PG_FOR_LANES(l) {
+                        const uint32_t k = PG_LV(kcls, l);
+                        const uint32_t syw = lds->srcyw[k ? k - 1u : 0u][sr][row0 + j];
+                        const bool h = PG_LV(hbit, l) != 0 && (k ? syw != 0xffffu : ok0);
+                        const uint32_t boff = h ? PG_LV(cboff, l) + ((k ? syw : off0) << 2) : 0u;
+                        PG_LA(tex, j, l) = *reinterpret_cast<const uint32_t *>(base + boff);
+                        PG_LV(hm, l) |= (h ? 1u : 0u) << j;
+                    }
+                } else {
+                    const char *rowp = reinterpret_cast<const char *>(d.pixels + (e & 0xfffu) * (uint32_t)ref_w);  // wave-uniform
+                    PG_FOR_LANES(l) {
+                        PG_LA(tex, j, l) = *reinterpret_cast<const uint32_t *>(rowp + PG_LV(cboff, l));  // scalar base + 32-bit lane offset
+                        PG_LV(hm, l) |= PG_LV(hbit, l) << j;
+                    }
                 }
                 drawn |= 1u << j;
             }
@@ -1284,8 +1316,10 @@ struct Renderer {
         if (band_any == 0) return;  // no cell with an image reaches these rows (sky)
         const uint32_t band_seam = (uint32_t)((rowseam >> row0) & ((1ull << BAND_ROWS) - 1ull)) & band_any;
         // stages 1 and 2: (c0, r0), and (c0, r1) on the doubly covered rows
-        if (MULTI) rows_pass_by_pixel<MULTI>(ny_full, ref_w, band_any, band_seam);
-        else rows_pass(ny_full, ref_w, band_any, band_seam);
+        // (frames with several cell image sizes keep the per-pixel form: the row-major one with per-lane row tables measured 3-10 % SLOWER on
+        // maze, miner, climber, jumper, caveflyer, profiles/r06_call17_ab16.txt; PROCGEN_AMD_DEBUG & 2097152 selects it for the A/B)
+        if (MULTI && !PG_DBG(d, 2097152)) rows_pass_by_pixel<MULTI>(ny_full, ref_w, band_any, band_seam);
+        else rows_pass<MULTI>(ny_full, ref_w, band_any, band_seam);
         if (nseam == 0) return;
         // stage 3: (c1, r0): the doubly covered columns x the band's rows, laid out linearly over the lanes, one, two or four pixels per lane
         // and round (coinrun shows two or three such columns, 48 pixels a band: a four-deep round spent three quarters of its instructions

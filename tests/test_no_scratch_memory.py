@@ -23,13 +23,20 @@ DISPLAY_LIST = {"CoinRun", "Climber"}  # games (of the ones compiled here) whose
 # render<Game, false> kernels whose RENDER_MIN_WAVES = 4 hint costs a small spill (bytes per lane) and was adopted because the same-box A/B
 # said so (profiles/r05_rot_pool_ab.txt: leaper +9 %, fruitbot +11 %, jumper +13 % over the same build without the hint; profiles/r05_try_ab.txt: climber's five-wave hint +4.5 %); the limit keeps
 # the spill from growing unnoticed -- a spill in a step kernel, or a larger one here, is still a failure
-SMALL_SPILLS_THAT_PAID = {("Leaper", True): 32, ("FruitBot", True): 192, ("Jumper", True): 16, ("Climber", True): 16}
+SMALL_SPILLS_THAT_PAID = {("Leaper", True): 32, ("FruitBot", True): 192, ("Jumper", True): 24, ("Climber", True): 16}
+
+
+def _release_games():
+    """the games the Makefile builds with -DPG_RELEASE (RELEASE_GAMES): the guard compiles what ships"""
+    m = re.search(r"^RELEASE_GAMES := (.*)$", open(os.path.join(CSRC, "Makefile")).read(), re.M)
+    return set(m.group(1).split()) if m else set()
 
 
 def _scratch_bytes(game, tmp):
     out = os.path.join(tmp, f"{game}.s")
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing", f"-DPG_GAME={game}",
-                           "--cuda-device-only", "-S", "-c", os.path.join(CSRC, "kernels_game.hip"), "-o", out], cwd=CSRC, stderr=subprocess.DEVNULL)
+    rel = ["-DPG_RELEASE"] if game in _release_games() else []
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing", f"-DPG_GAME={game}"] + rel +
+                          ["--cuda-device-only", "-S", "-c", os.path.join(CSRC, "kernels_game.hip"), "-o", out], cwd=CSRC, stderr=subprocess.DEVNULL)
     text = open(out).read()
     names = re.findall(r"^\s+\.name:\s+(\S+)", text, re.M)
     sizes = [int(x) for x in re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", text, re.M)]

@@ -28,3 +28,4 @@ timeout 600 python tools/gpu/state_io_timing.py 2>&1 | tail -4 | tee gpurun_out/
 timeout 600 python tools/gpu/render_order_ab.py bigfish,coinrun 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_render_order_ab.txt
 timeout 900 python -m pytest tests -q -m gpu -n 4 -k "not protocol_at_its_own_length" 2>&1 | tail -4 | tee gpurun_out/${TAG}_pytest_parallel.log
 grep "fatal:" $PROCGEN_AMD_FATAL_LOG | cut -c1-150 | sed 's/\[pid [0-9]*\] //' | sort | uniq -c
+bash tools/gpu/r6_tcc_channels.sh ${TAG}_tccch 2>&1 | tail -8
