@@ -1139,7 +1139,7 @@ struct Renderer {
             PG_LV(riv, l) = lds->ri[(l >> 4) & 1][row0 + (l & (BAND_ROWS - 1))];
             PG_LV(ce, l) = lds->ci[0][l];
         }
-        for (int sr = 0; sr < 2; sr++) {
+        _Pragma("nounroll") for (int sr = 0; sr < 2; sr++) {  // (one copy of the 16-row body: unrolled, the two copies' scalars spilled into each other)
             const uint32_t rows = sr ? band_seam : band_any;
             if (rows == 0) continue;
             PG_LANE_ARR(uint32_t, tex, BAND_ROWS);  // (defined up front: a register the allocator reuses as a temporary is a wait on a fetch in flight)
@@ -2743,28 +2743,58 @@ struct Renderer {
             PG_LV(z, l) = in ? b.w : 255u;
         }
     }
-    // layer `layer` of the commands past the first register set, in draw order
-    PG_DEV void more_cmd_sets(const uint32_t *rec, int ncmd, uint32_t layer) {
-        for (int set = 1; set * CMD_SET < ncmd; set++) {
-            CmdRegs r;
-            PG_LANE_VAR(uint32_t, z);
-            load_cmd_set(rec, set, ncmd, r, z);
-            const uint64_t m = PG_BALLOT(l, PG_LV(z, l) == layer);
-            if (m) run_batch(r, m);
+    // layers zfirst..zlast of a record's commands, each layer in draw order over all register sets.  The first set lives in registers (er, ez)
+    // for the whole frame, the others -- 1 frame in 10 000 has any -- are fetched again for every band and layer.  One routine for both so that
+    // run_batch is inlined twice in the kernel, not seven times (seven copies doubled its size and its SGPR spills: +750 vector instructions a
+    // frame of spill traffic, profiles/r06_final_sq_insts.csv vs r06_call8_11_ab.txt).
+    // (nsets, not the record pointer and the command count: those two would stay live in scalar registers across the whole band loop for the
+    // sake of this rare path -- and the grid pass in between pays for every live scalar with v_readlane spill traffic: +700 vector
+    // instructions a frame, profiles/r06_call19_ablation.txt -- so the rare path works the pointer out again from the env)
+    PG_DEV void draw_cmd_layers(int nsets, const CmdRegs &er, PG_LANE_REF(const uint32_t, ez), uint32_t zfirst, uint32_t zlast) {
+        typedef FrameRec<Game> Rec;
+        for (uint32_t layer = zfirst; layer <= zlast; layer++) {
+            for (int set = 0; set < nsets; set++) {
+                CmdRegs r;
+                PG_LANE_VAR(uint32_t, z);
+                const uint32_t *rec = nullptr;
+                int ncmd = 0;
+                if (set > 0) {
+                    rec = d.frame_rec + (size_t)PG_UNIFORM_I(pg_opaque_i(env)) * Rec::WORDS;
+                    ncmd = (int)(((uint32_t)PG_UNIFORM_I(rec[Rec::DIMS]) >> 8) & 0xffu);
+                }
+                if (set == 0) {
+                    PG_R_LANES(l) {
+                        PG_LV(r.geom, l) = PG_LV(er.geom, l);
+                        PG_LV(r.basex, l) = PG_LV(er.basex, l);
+                        PG_LV(r.srcy, l) = PG_LV(er.srcy, l);
+                        PG_LV(r.ix, l) = PG_LV(er.ix, l);
+                        PG_LV(r.iy, l) = PG_LV(er.iy, l);
+                        PG_LV(r.src, l) = PG_LV(er.src, l);
+                        PG_LV(r.aux, l) = PG_LV(er.aux, l);
+                        if constexpr (GEN) PG_LV(r.e0, l) = PG_LV(r.e1, l) = 0;
+                        PG_LV(z, l) = PG_LV(ez, l);
+                    }
+                } else {
+                    load_cmd_set(rec, set, ncmd, r, z);
+                }
+                const uint64_t m = PG_BALLOT(l, PG_LV(z, l) == layer);
+                if (m) run_batch(r, m);
+            }
         }
     }
     PG_DEV void raster_env() {
         typedef FrameRec<Game> Rec;
         static_assert(!GEN, "generated assets draw through render_env");
+        static_assert(Rec::HDR_WORDS <= 64, "the header's words live one per lane");
         const uint32_t *rec = d.frame_rec + (size_t)env * Rec::WORDS;
-        const uint32_t flags = rec[Rec::FLAGS], dims = rec[Rec::DIMS];
-        const uint64_t colseam = (uint64_t)rec[Rec::COLSEAM] | ((uint64_t)rec[Rec::COLSEAM + 1] << 32);
-        const uint64_t rowseam = (uint64_t)rec[Rec::ROWSEAM] | ((uint64_t)rec[Rec::ROWSEAM + 1] << 32);
-        const uint64_t rowany = (uint64_t)rec[Rec::ROWANY] | ((uint64_t)rec[Rec::ROWANY + 1] << 32);
-        const uint32_t bg_geom = rec[Rec::BG], bg_basex = rec[Rec::BG + 1], bg_srcy = rec[Rec::BG + 2], bg_ix = rec[Rec::BG + 3], bg_iy = rec[Rec::BG + 4],
-                       bg_src = rec[Rec::BG + 5], bg_aux = rec[Rec::BG + 6];
-        const int ref_w = (int)rec[Rec::REF_W];
-        const int ny_full = (int)(dims & 0xffu), ncmd = (int)((dims >> 8) & 0xffu), nfill = (int)(dims >> 16);
+        // The header lives in ONE vector register, word k in lane k, and every use takes its word with a v_readlane where it is needed.
+        // Held in scalar registers for the frame -- 16 words beside the band loop's own scalars -- the compiler spilled them and restored
+        // whole tuples of them in every basic block of the grid pass: ~10 v_readlane per pixel row, +800 vector instructions a frame
+        // (profiles/r06_call19_ablation.txt).  hdr_word(k) goes through an opaque copy per band, so the reads stay where they are written.
+        PG_LANE_VAR(uint32_t, hv);
+        PG_R_LANES(l) { PG_LV(hv, l) = rec[l < Rec::HDR_WORDS ? l : 0]; }
+        const uint32_t flags = PG_READLANE(hv, Rec::FLAGS), dims = PG_READLANE(hv, Rec::DIMS);
+        const int ncmd = (int)((dims >> 8) & 0xffu);
         const bool pull = (flags & Rec::F_PULL) != 0, multi = (flags & Rec::F_MULTI) != 0;
         G.error = 0;
         if constexpr (GameDrawsGrid<Game>::value) {
@@ -2781,43 +2811,47 @@ struct Renderer {
         CmdRegs er;
         PG_LANE_VAR(uint32_t, ez);
         load_cmd_set(rec, 0, ncmd, er, ez);  // the frame's first 64 commands stay in registers for all passes
-        const uint64_t ez0 = PG_BALLOT(l, PG_LV(ez, l) == 0u), ez1 = PG_BALLOT(l, PG_LV(ez, l) == 1u), ez2 = PG_BALLOT(l, PG_LV(ez, l) == 2u);
+        const int nsets = (ncmd + CMD_SET - 1) / CMD_SET > 0 ? (ncmd + CMD_SET - 1) / CMD_SET : 1;
+        const bool any0 = PG_BALLOT(l, PG_LV(ez, l) == 0u) != 0 || nsets > 1, any12 = PG_BALLOT(l, PG_LV(ez, l) == 1u || PG_LV(ez, l) == 2u) != 0 || nsets > 1;
         dma_join();
         PG_SYNC();
-        const DrawCmd bc0 = unpack(bg_geom, bg_basex, bg_srcy, bg_ix, bg_iy, bg_src, bg_aux);
-        const bool bg_dma = bg_geom != 0 && bg_dma_ok(bc0);
         for (int band = 0; band < NUM_BANDS; band++) {
             row0 = band * BAND_ROWS;
             row1 = row0 + BAND_ROWS;
-            // a background image that reaches every pixel of the band needs no black underneath (p.fillRect(rect, QColor(0,0,0)))
-            const bool bg_full = bg_dma && bc0.tx1 == 0 && bc0.w == RES_W && bc0.ty1 <= row0 && bc0.ty1 + bc0.h >= row1;
-            if (!bg_full) {
-                for (int base = 0; base < BAND_ROWS * RES_W; base += 64) {
-                    PG_R_LANES(l) { fb[base + l] = 0xff000000u; }
+            PG_LANE_VAR(uint32_t, hb);  // this band's view of the header
+            PG_R_LANES(l) { PG_LV(hb, l) = (uint32_t)pg_opaque_i((int)PG_LV(hv, l)); }
+            {
+                const uint32_t bg_geom = PG_READLANE(hb, Rec::BG);
+                const DrawCmd bc0 = unpack(bg_geom, PG_READLANE(hb, Rec::BG + 1), PG_READLANE(hb, Rec::BG + 2), PG_READLANE(hb, Rec::BG + 3), PG_READLANE(hb, Rec::BG + 4),
+                                           PG_READLANE(hb, Rec::BG + 5), PG_READLANE(hb, Rec::BG + 6));
+                const bool bg_dma = bg_geom != 0 && bg_dma_ok(bc0);
+                // a background image that reaches every pixel of the band needs no black underneath (p.fillRect(rect, QColor(0,0,0)))
+                const bool bg_full = bg_dma && bc0.tx1 == 0 && bc0.w == RES_W && bc0.ty1 <= row0 && bc0.ty1 + bc0.h >= row1;
+                if (!bg_full) {
+                    for (int base = 0; base < BAND_ROWS * RES_W; base += 64) {
+                        PG_R_LANES(l) { fb[base + l] = 0xff000000u; }
+                    }
+                }
+                PG_SYNC();
+                if (bg_geom != 0 && bc0.ty1 < row1 && bc0.ty1 + bc0.h > row0 && !PG_DBG(d, 1)) {
+                    if (bg_dma) exec_bg_dma(bc0);
+                    else exec_large(bc0);
                 }
             }
-            PG_SYNC();
-            if (bg_geom != 0 && bc0.ty1 < row1 && bc0.ty1 + bc0.h > row0 && !PG_DBG(d, 1)) {
-                if (bg_dma) exec_bg_dma(bc0);
-                else exec_large(bc0);
-            }
-            if (ez0 && !PG_DBG(d, 4)) run_batch(er, ez0);
-            if (ncmd > CMD_SET) more_cmd_sets(rec, ncmd, 0u);
+            if (any0 && !PG_DBG(d, 4)) draw_cmd_layers(nsets, er, ez, 0u, 0u);
             if constexpr (GameDrawsGrid<Game>::value) {
                 if (pull && !PG_DBG(d, 2)) {
+                    const uint32_t dm = PG_READLANE(hb, Rec::DIMS);
+                    const int ny_full = (int)(dm & 0xffu), ref_w = (int)PG_READLANE(hb, Rec::REF_W);
+                    const uint64_t colseam = (uint64_t)PG_READLANE(hb, Rec::COLSEAM) | ((uint64_t)PG_READLANE(hb, Rec::COLSEAM + 1) << 32);
+                    const uint64_t rowseam = (uint64_t)PG_READLANE(hb, Rec::ROWSEAM) | ((uint64_t)PG_READLANE(hb, Rec::ROWSEAM + 1) << 32);
+                    const uint64_t rowany = (uint64_t)PG_READLANE(hb, Rec::ROWANY) | ((uint64_t)PG_READLANE(hb, Rec::ROWANY + 1) << 32);
                     if (multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w);
                     else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w);
-                    if constexpr (GameHasGridFills<Game>::value) draw_pull_fills(nfill);
+                    if constexpr (GameHasGridFills<Game>::value) draw_pull_fills((int)(dm >> 16));
                 }
             }
-            if (ncmd <= CMD_SET) {
-                if ((ez1 | ez2) && !PG_DBG(d, 4)) run_batch(er, ez1, ez2);  // z = 0, then z = 1, in one pass
-            } else {  // (1 frame in 10 000: the commands past the first 64 are fetched again for every band and layer)
-                if (ez1) run_batch(er, ez1);
-                more_cmd_sets(rec, ncmd, 1u);
-                if (ez2) run_batch(er, ez2);
-                more_cmd_sets(rec, ncmd, 2u);
-            }
+            if (any12 && !PG_DBG(d, 4)) draw_cmd_layers(nsets, er, ez, 1u, 2u);  // z = 0, then z = 1
             PG_SYNC();
             if (!PG_DBG(d, 8)) store_band();
             else dma_join();
