@@ -67,7 +67,10 @@ struct procgen_amd_part {
 };
 /* returns the number of parts; fills out[0 .. min(max_parts, parts)) when out is not NULL */
 LIBENV_API int procgen_amd_part_buffers(libenv_env *handle, struct procgen_amd_part *out, int max_parts);
-/* switch the D2H landing of observations on/off after construction (same meaning as the option) */
+/* switch the D2H landing of observations on/off after construction (same meaning as the option).  The handle keeps the launch shape it
+ * was made with: a handle of >= 32 768 envs made WITH host observations steps in four launch chunks (each chunk's frames landed while the
+ * next are drawn) and stays at four after the landing is switched off -- ~15 % slower kernels than the two chunks a handle made without
+ * host observations uses; make the handle with the mode it will mostly run in. */
 LIBENV_API void procgen_amd_set_host_observations(libenv_env *handle, int enable);
 /* Runs `steps` steps back to back entirely on the device (actions: [steps][num_envs] int32 on the HOST, or
  * NULL to repeat the last actions) and returns the mean device time of one step's kernels in milliseconds,

@@ -1117,10 +1117,12 @@ bool VecGame::serialize_cached(int e, std::string *out, std::string *err) const 
     s.rng.assign(snap_rng.begin() + k * rng_w, snap_rng.begin() + (k + 1) * rng_w);
     s.grid.assign(snap_grid.begin() + k * grid_b, snap_grid.begin() + (k + 1) * grid_b);
     if (render_human && !api_observed) camera_scalars_of_the_observation_frame(&s.hdr);
-    out->resize(1 << 20);  // the reference's MAX_STATE_SIZE (procgen/env.py:20)
+    // (a scratch buffer per thread of the reference's MAX_STATE_SIZE, procgen/env.py:20, allocated once: resizing the output to 1 MiB for every
+    // state zero-filled 256 MiB per block of 256 states of ~40 KB, round-5 advisor finding)
+    static thread_local std::vector<char> scratch(1 << 20);
     int written = 0;
-    if (!serialize_state(game_id, d.opt, game_n[e], s, &(*out)[0], (int)out->size(), &written, err)) return false;
-    out->resize((size_t)written);
+    if (!serialize_state(game_id, d.opt, game_n[e], s, scratch.data(), (int)scratch.size(), &written, err)) return false;
+    out->assign(scratch.data(), (size_t)written);
     return true;
 }
 
