@@ -16,6 +16,7 @@ struct BossFight : BagDefaults<BossFight> {
     static constexpr bool USES_ROTATION = true;  // bullets and trails spin (vrot)
     static constexpr int ROT_POOL_FACTOR = 4;  // (pg_render.h ROT_POOL: 4 x 16 = a record per lane) dozens of turned bullets on screen at once (at 32 records one frame in six falls back to the per-band path)
     static constexpr bool DRAWS_GRID = false;
+    // (tier 0 at 120 slots -- 11 008 bytes, one LDS granule less -- measured +-0: profiles/r06_call27_ab.txt)
     static constexpr int ENT_CAP_T0 = 128, ENT_CAP_T1 = 256, ENT_CAP_T2 = 512;
     static constexpr int RENDER_CMD_SETS = 2;  // frames with more than 64 visible entities are common
 

@@ -17,7 +17,7 @@ struct Chaser : BagDefaults<Chaser> {
     PG_DEV static bool par_smart_type_ok(int t) { return t == PLAYER || t == ENEMY; }
     static constexpr const char *NAME = "chaser";
     typedef uint16_t cell_t;  // MARKER = 1001, ORB = 1002
-    typedef MazeScratch Scratch;
+    typedef MazeScratchT<19, false> Scratch;  // maze_dim 11 / 13 / 19 (chaser.cpp:141-156)
     static constexpr int MAX_CELLS = 19 * 19;  // chaser.cpp:137-160 (extreme mode)
     static constexpr bool HAS_GRID_FILLS = true;
     static constexpr int ENT_CAP_T0 = 24, ENT_CAP_T1 = 32, ENT_CAP_T2 = 48;  // agent + <= 5 large orbs + <= 5 eggs / enemies (+ hatching)
@@ -154,7 +154,7 @@ struct Chaser : BagDefaults<Chaser> {
             e.fail(PGE_ASSERT);
             return;
         }
-        MazeGenDev<E> mg(e, e.s->scratch, md_gen);
+        MazeGenDev<E, Scratch> mg(e, e.s->scratch, md_gen);
         mg.generate_maze_no_dead_ends();
         const int extra_quad = e.randn(4);
         // grid <- maze (walls become MAZE_WALL); maze cell (i, j) is grid index j * md + i

@@ -13,7 +13,7 @@ namespace pgamd {
 struct Heist : BagDefaults<Heist> {
     static constexpr int GAME_ID = GAME_HEIST;
     static constexpr const char *NAME = "heist";
-    typedef MazeScratch Scratch;
+    typedef MazeScratchT<23, true> Scratch;  // maze_dim <= world_dim <= 23 (memory mode, heist.cpp:95-110)
     static constexpr int MAX_CELLS = 23 * 23;  // heist.cpp:95-110 (memory mode)
     static constexpr bool USES_ROTATION = true;
     static constexpr int RENDER_MIN_WAVES = 4;  // with the 16-record rotation pool the arena is 9.7 KB: four render waves per SIMD at <= 128 VGPRs measured +10 % over the pool alone (37.3 -> 41.1 M) on the same box (profiles/r05_rot_pool_ab.txt)
@@ -97,7 +97,7 @@ struct Heist : BagDefaults<Heist> {
         e.ery(ag) = (float)(.375 * (double)maze_scale);
         const float r_ent = maze_scale / 2;
         PG_SYNC();
-        MazeGenDev<E> mg(e, e.s->scratch, maze_dim);
+        MazeGenDev<E, Scratch> mg(e, e.s->scratch, maze_dim);
         mg.generate_maze_with_doors(num_keys);
         e.ex(ag) = -1;
         e.ey(ag) = -1;

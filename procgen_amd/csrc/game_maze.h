@@ -16,7 +16,7 @@ struct Maze {
     static constexpr int ENT_CAP_T0 = 8, ENT_CAP_T1 = 16, ENT_CAP_T2 = 32;  // the agent is the only entity
     template <class E>
     PG_DEV static int slots_needed_next_step(E &e) { return e.G.n_ents + 3; }
-    typedef MazeScratch Scratch;
+    typedef MazeScratchT<31, false> Scratch;  // maze_dim <= world_dim <= 31 (memory mode, maze.cpp:40-53)
 
     static constexpr int GOAL = 2;
 #define MZ_MAZE_DIM(G) (G).gsi0
@@ -114,7 +114,7 @@ struct Maze {
         e.ex(ag) = (float)(margin + .5);
         e.ey(ag) = (float)(margin + .5);
         PG_SYNC();
-        MazeGenDev<E> mg(e, e.s->scratch, maze_dim);
+        MazeGenDev<E, Scratch> mg(e, e.s->scratch, maze_dim);
         mg.generate_maze();
         mg.place_objects(GOAL, 1);
         e.fill_elem(0, 0, world_dim, world_dim, WALL_OBJ);

@@ -51,6 +51,18 @@ template <class Game>
 struct GameRenderMinWaves<Game, decltype((void)Game::RENDER_MIN_WAVES)> {
     static constexpr int value = Game::RENDER_MIN_WAVES;
 };
+// the same for the raster kernel of a display-list game (RASTER_MIN_WAVES; -DPG_RASTER_WAVES=n is the A/B's override)
+template <class Game, class = void>
+struct GameRasterMinWaves {
+    static constexpr int value = 1;
+};
+template <class Game>
+struct GameRasterMinWaves<Game, decltype((void)Game::RASTER_MIN_WAVES)> {
+    static constexpr int value = Game::RASTER_MIN_WAVES;
+};
+#ifndef PG_RASTER_WAVES
+#define PG_RASTER_WAVES GameRasterMinWaves<PG_GAME>::value
+#endif
 // games with SPLIT_RESET: their step kernels carry no level generator (Env NO_RESET, arena without scratch)
 template <class Game, int CAP>
 using StepEnv = Env<Game, CAP, GameSplit<Game>::value>;
@@ -134,8 +146,13 @@ __global__ __launch_bounds__(64) void prep(DevCtx d, int env_base, int count, in
 // (no occupancy hint and no full renderer in here: 59 VGPRs, so the arena alone bounds the waves per SIMD -- six for coinrun against five
 // with render_env inside, +3.4 % steps/s, profiles/r06_call11_ab.txt)
 template <class Game>
-__global__ __launch_bounds__(64) void raster(DevCtx d, int env_base, int chunk) {
-    __shared__ RenderLdsT<Game> lds;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_RASTER_WAVES))) void raster(DevCtx d, int env_base, int chunk) {
+    // (the arena up to the end of the band buffer: typeimg, behind it, is the per-cell path's.  The band buffer of a register-table rasterizer,
+    // and of a game without a grid, starts where the column / row / type tables would lie, RenderLdsT: coinrun 4688 bytes, bigfish 4432 =
+    // four LDS granules of 1280 bytes, eight waves per SIMD)
+    constexpr size_t ARENA_BYTES = GameRasterBandOverTables<Game>::value ? offsetof(RenderLdsT<Game>, ci) + sizeof(RenderLdsT<Game>::fb) : offsetof(RenderLdsT<Game>, typeimg);
+    __shared__ __attribute__((aligned(16))) uint32_t arena[ARENA_BYTES / 4];
+    RenderLdsT<Game> &lds = *reinterpret_cast<RenderLdsT<Game> *>(arena);
     const int slot = env_base + (int)blockIdx.x;
     const int env = d.render_order ? __builtin_amdgcn_readfirstlane(d.render_order[slot]) : slot;
     // (the record is read before this kernel's first store: the wave-uniform loads of its header are then scalar loads, not vector loads

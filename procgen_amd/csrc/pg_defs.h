@@ -10,6 +10,12 @@
 // ablation bits of DevCtx::debug_flags): the kernels read it through these three macros, and -DPG_RELEASE turns them into constants, so a
 // release build carries none of it (profiles/r06_release_ab.txt: the same-box A/B that decides which build __graft_entry__.build() ships).
 #if defined(PG_RELEASE)
+#define PG_RELEASE_STEP
+#define PG_RELEASE_FRAME
+#endif
+// (the step kernels and the frame kernels take it separately -- PG_DBG / PG_PHASES / PG_TRACE are pg_env.h's, PG_FDBG / PG_FPHASES are
+// pg_render.h's and pg_prep.h's -- because the A/B goes per kernel family: -DPG_RELEASE_STEP, -DPG_RELEASE_FRAME; -DPG_RELEASE = both)
+#if defined(PG_RELEASE_STEP)
 #define PG_DBG(d, bits) (false)
 #define PG_PHASES(d) (false)
 #define PG_TRACE(d) (false)
@@ -17,6 +23,13 @@
 #define PG_DBG(d, bits) (((d).debug_flags & (bits)) != 0)
 #define PG_PHASES(d) ((d).phase_cycles != nullptr)
 #define PG_TRACE(d) ((d).wave_trace != nullptr)
+#endif
+#if defined(PG_RELEASE_FRAME)
+#define PG_FDBG(d, bits) (false)
+#define PG_FPHASES(d) (false)
+#else
+#define PG_FDBG(d, bits) (((d).debug_flags & (bits)) != 0)
+#define PG_FPHASES(d) ((d).phase_cycles != nullptr)
 #endif
 
 namespace pgamd {

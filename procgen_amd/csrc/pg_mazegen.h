@@ -9,24 +9,41 @@
 
 namespace pgamd {
 
-constexpr int MG_MAX_DIM = 33;  // maze_dim <= 31 (memory mode), array_dim = maze_dim + 2
 constexpr int MAZE_OFFSET = 1;  // reference src/mazegen.h:14
 
-struct MazeScratch {
-    uint16_t label[1024];       // cell_sets_idxs (cell = maze_dim * y + x)
-    uint16_t free_cells[1024];  // 0xffff = taken (-1 in the reference)
-    uint32_t walls[512];        // x1 | y1<<5 | x2<<10 | y2<<15
-    uint16_t mgrid[MG_MAX_DIM * MG_MAX_DIM + 3];  // MazeGen::grid (index y * array_dim + x); door / key ids exceed 255
+// LDS the generator works in, sized by the largest maze_dim the game asks for (MAXDIM) -- the arena of a step kernel that resets in place
+// carries it, and 1280 bytes more or less of arena are a workgroup more or less per CU (profiles/r06_lds_granule.txt): chaser (<= 19) 3056
+// bytes, heist (<= 23, with doors) 5488, maze (<= 31) 7952; one size for all (8328) held chaser's step kernel at 12 workgroups per CU
+// instead of 16, maze's and heist's at 14.  DOORS: generate_maze_with_doors reuses the arrays as flag sets and cell lists over the
+// (maze_dim + 2)^2 cells of the bordered grid: label -> s0 | s1 | curr, free_cells -> next, walls -> the cell list.
+template <int MAXDIM, bool DOORS>
+struct MazeScratchT {
+    static constexpr int MAX_DIM = MAXDIM;
+    static constexpr bool HAS_DOORS = DOORS;
+    static constexpr int CELLS = MAXDIM * MAXDIM, ACELLS = (MAXDIM + 2) * (MAXDIM + 2);
+    static constexpr int FLAG_STRIDE = (ACELLS + 15) & ~15;                          // bytes of one flag set
+    static constexpr int NWALLS = 2 * ((MAXDIM - 1) / 2) * ((MAXDIM + 1) / 2);       // generate_maze's wall list (mazegen.cpp:140-154)
+    static_assert(MAXDIM % 2 == 1 && NWALLS <= 512, "the alive mask of generate_maze has 512 bits");
+    static constexpr int pg_max(int a, int b) { return a > b ? a : b; }
+    uint16_t label[(pg_max(CELLS, DOORS ? 3 * FLAG_STRIDE / 2 : 0) + 1) & ~1];      // cell_sets_idxs (cell = maze_dim * y + x)
+    uint16_t free_cells[(pg_max(CELLS, DOORS ? FLAG_STRIDE / 2 : 0) + 1) & ~1];     // 0xffff = taken (-1 in the reference)
+    uint32_t walls[pg_max(NWALLS, DOORS ? (ACELLS + 1) / 2 : 0)];                    // x1 | y1<<5 | x2<<10 | y2<<15
+    uint16_t mgrid[ACELLS + 3];  // MazeGen::grid (index y * array_dim + x); door / key ids exceed 255
 };
+typedef MazeScratchT<31, false> MazeScratch;  // maze_dim <= 31 (maze's memory mode), array_dim = maze_dim + 2
 constexpr int MG_EXIT_OBJ = 52, MG_AGENT_OBJ = 53, MG_DOOR_OBJ = 200, MG_KEY_OBJ = 300;  // reference src/object-ids.h
 
-template <class E>
+template <class E, class S = MazeScratch>
 struct MazeGenDev {
     E &e;
-    MazeScratch &m;
+    S &m;
     int maze_dim, array_dim, num_free_cells;
 
-    PG_DEV MazeGenDev(E &e_, MazeScratch &m_, int maze_dim_) : e(e_), m(m_), maze_dim(maze_dim_), array_dim(maze_dim_ + 2), num_free_cells(0) {}
+    // (a maze_dim beyond the scratch's would write past its arrays: the games' choose_world_dim bound it, the emulation checks it)
+    PG_DEV MazeGenDev(E &e_, S &m_, int maze_dim_)
+        : e(e_), m(m_), maze_dim(maze_dim_ > S::MAX_DIM ? S::MAX_DIM : maze_dim_), array_dim(maze_dim + 2), num_free_cells(0) {
+        if (maze_dim_ > S::MAX_DIM) e.fail(PGE_ASSERT);
+    }
 
     PG_DEV int grid_at(int x, int y) const { return (int)m.mgrid[y * array_dim + x]; }
 
@@ -179,8 +196,8 @@ struct MazeGenDev {
     // free_cells -> next flags, walls -> cell lists.  Serial wave-uniform code: a reset-time cost of a few thousand
     // LDS operations.
     PG_DEV uint8_t *flags_s0() { return reinterpret_cast<uint8_t *>(m.label); }
-    PG_DEV uint8_t *flags_s1() { return reinterpret_cast<uint8_t *>(m.label) + 640; }
-    PG_DEV uint8_t *flags_curr() { return reinterpret_cast<uint8_t *>(m.label) + 1280; }
+    PG_DEV uint8_t *flags_s1() { return reinterpret_cast<uint8_t *>(m.label) + S::FLAG_STRIDE; }
+    PG_DEV uint8_t *flags_curr() { return reinterpret_cast<uint8_t *>(m.label) + 2 * S::FLAG_STRIDE; }
     PG_DEV uint8_t *flags_next() { return reinterpret_cast<uint8_t *>(m.free_cells); }
     PG_DEV uint16_t *cell_list() { return reinterpret_cast<uint16_t *>(m.walls); }
 
@@ -309,6 +326,7 @@ struct MazeGenDev {
     }
 
     PG_DEV void generate_maze_with_doors(int num_doors) {  // mazegen.cpp:211-290
+        static_assert(S::HAS_DOORS, "the scratch is sized for the flag sets and the cell list");
         generate_maze();
         const int nc = array_dim * array_dim;
         uint16_t *list = cell_list();

@@ -195,6 +195,7 @@ struct FramePrep {
             r.G.error = 0;
             r.row0 = 0;
             r.row1 = RES_H;
+            r.keep_typeimg = false;  // (this kernel's arena ends inside the band buffer)
             int win_lx, win_hx, win_ly, win_hy;  // BAG:926-939
             if (Game::center_agent(r.opt)) {
                 const float margin = (float)(r.G.visibility / 2.0 + 1);
@@ -230,7 +231,7 @@ struct FramePrep {
 #if defined(PGAMD_WAVE_EMU)
             if (!fast && getenv("PG_EMU_SLOW_WHY")) fprintf(stderr, "slow frame env %d: slowbit %d error %d mono %d vel %d pull %d nx %d ny %d n_ents %d\n", env, (int)((slow >> e) & 1u), r.G.error, (int)r.opt.use_monochrome_assets, (int)(r.G.has_useful_vel_info && r.opt.paint_vel_info), (int)pull, nx, ny_full, r.G.n_ents);
 #endif
-            if (PG_DBG(d, 1048576)) fast = false;  // test aid: every frame through the full renderer
+            if (PG_FDBG(d, 1048576)) fast = false;  // test aid: every frame through the full renderer
             PG_SYNC();
             // header: the scalars are wave-uniform; lane k takes word k and one store writes them (the background's words were written by its lane)
             uint32_t hw[Rec::HDR_WORDS];

@@ -186,6 +186,19 @@ struct GameRotPool<Game, decltype((void)Game::ROT_POOL_FACTOR)> {
     static constexpr int value = PG_ROT_POOL * Game::ROT_POOL_FACTOR < 64 ? PG_ROT_POOL * Game::ROT_POOL_FACTOR : 64;
 };
 
+// The raster kernel of this display-list game keeps the pull form's column / row / type tables in vector registers (RenderLdsT, raster_env):
+// the games whose cell images share one size -- their short path has no other reader of these tables.
+template <class Game>
+struct GameRasterRegTabs {
+    static constexpr bool value = GameDrawsGrid<Game>::value && GamePullSingle<Game>::value;
+};
+// ... and then its band buffer lies where those tables would (RenderLdsT::ci); so does the one of a game that draws no grid (bigfish: 5472 ->
+// 4432 bytes, four LDS granules instead of five).  Neither has rotation records, which lie between the tables and the band buffer.
+template <class Game>
+struct GameRasterBandOverTables {
+    static constexpr bool value = (GameRasterRegTabs<Game>::value || !GameDrawsGrid<Game>::value) && !GameUsesRotation<Game>::value;
+};
+
 // LDS arena of one render workgroup (one wave)
 template <class Game>
 struct RenderLdsT {
@@ -194,26 +207,35 @@ struct RenderLdsT {
     // pull form or cell by cell --, typesz (set-up only) over words 128..191 of the band buffer (idle during the set-up; build_pull_tables
     // keeps its scratch in words 0..127, the entity commands are staged there only after the pull tables are done); see Renderer::ax / typesz.
     // ---- the pull form's tables.  For a display-list game (pg_prep.h) this block IS the table part of an env's frame record: the prep
-    // kernel builds it here and copies it out word by word, the raster kernel copies it back in; [ci, srcx) is all a frame with one cell
-    // image size needs (TAB_SINGLE_END), the size-class tables follow
-    uint32_t ci[2][64];              // screen column -> the (at most two) cell columns covering it
-    uint32_t ri[2][64];              // screen row    -> the (at most two) cell rows covering it
+    // kernel builds it here and copies it out word by word, the raster kernel copies it back in; [seamcols, srcx) is all a frame with one cell
+    // image size needs (TAB_SINGLE_WORDS), the size-class tables follow
     uint8_t seamcols[64];            // screen columns covered by two cell columns
     // window cell -> grid object type (CELL8_NONE: nothing to draw); the type's image is typeany[type].  One byte per cell (round 4; a word
     // per cell with the image in it cost the games with large windows 4 KB of the arena, i.e. two of eleven resident frames per CU)
     uint8_t cellimg[GameDrawsGrid<Game>::value ? GamePullCells<Game>::value : 4];
-    uint32_t typeany[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of any size: atlas offset | size class<<27 | opaque<<31 (pull form)
     uint32_t fillcmd[GameHasGridFills<Game>::value ? 2 * 256 : 1];  // solid-colour cells of a pull-form frame: (geom, colour) pairs
+    // The three tables a register-table rasterizer (GameRasterRegTabs, raster_env) holds in five vector registers -- word k in lane k, read
+    // with ds_bpermute / v_readlane -- instead of in the arena: its band buffer starts HERE (Renderer::fb), its arena ends 1280 bytes earlier.
+    // 1280 bytes is the LDS allocation granule of gfx950 (profiles/r06_lds_granule.txt): coinrun's 5968-byte arena is five of them, 25 frames
+    // per CU; without the three tables it is four, 32 frames per CU = eight waves per SIMD.
+    // (a game that draws no grid -- bigfish, starpilot, plunder, bossfight -- has neither: bossfight's arena 11 632 -> 10 640 bytes, nine LDS granules
+    // instead of ten, 14 frames per CU instead of 12)
+    alignas(16) uint32_t ci[GameDrawsGrid<Game>::value ? 2 : 1][GameDrawsGrid<Game>::value ? 64 : 4];  // screen column -> the (at most two) cell columns covering it
+    uint32_t ri[GameDrawsGrid<Game>::value ? 2 : 1][GameDrawsGrid<Game>::value ? 64 : 4];              // screen row    -> the (at most two) cell rows covering it
+    uint32_t typeany[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of any size: atlas offset | size class<<27 | opaque<<31 (pull form)
     static constexpr bool SIZE_CLASSES = GameDrawsGrid<Game>::value && !GamePullSingle<Game>::value;
     uint8_t srcx[SIZE_CLASSES ? 3 : 1][SIZE_CLASSES ? 2 : 1][SIZE_CLASSES ? 64 : 4];    // size classes 1..3: screen column -> source column, per covering slot
     uint16_t srcyw[SIZE_CLASSES ? 3 : 1][SIZE_CLASSES ? 2 : 1][SIZE_CLASSES ? 64 : 2];  // size classes 1..3: screen row -> source row * image width
     // ---- end of the record's table part
-    uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];    // grid object type -> cell image of this frame (build_type_table)
     uint32_t rot[GameUsesRotation<Game>::value ? GameRotPool<Game>::value * ROT_WORDS : 1];  // rotated commands of the current 64-entity chunk, by lane (by pool slot: ROT_POOL)
     // the band being rasterized, 0xffRRGGBB (+ a dump row for masked-off lanes).  Last: the prep kernel of a display-list game (pg_prep.h),
     // which only builds tables -- and uses the first PREP_FB_WORDS words of the band buffer as their scratch -- allocates the arena up to there
-    uint32_t fb[BAND_ROWS * RES_W + 64];
+    alignas(16) uint32_t fb[BAND_ROWS * RES_W + 64];
     static constexpr int PREP_FB_WORDS = 192;
+    // grid object type -> cell image of this frame (build_type_table), read by the per-cell path of render_env only.  Behind the band buffer:
+    // the raster kernel of a display-list game allocates the arena up to here (one more workgroup per CU for coinrun), the prep kernel up to
+    // PREP_FB_WORDS of the band buffer -- neither touches it (Renderer::keep_typeimg)
+    uint32_t typeimg[GameDrawsGrid<Game>::value ? 64 : 1];
 };
 // Frame record of a display-list game (pg_prep.h): what prep<Game> leaves in HBM for raster<Game>, per env.  Words:
 //   [0, 16)          header: flags, dims (window rows | visible commands << 8 | grid fills << 16), the pull form's column-seam / row-seam /
@@ -225,11 +247,15 @@ struct FrameRec {
     // MAX_CMDS: three register sets' worth -- coinrun's enemies leave eight trail sprites each, and 1 frame in 10 000 shows more than 64 sprites
     enum : int { FLAGS = 0, DIMS = 1, COLSEAM = 2, ROWSEAM = 4, ROWANY = 6, BG = 8, REF_W = 15, HDR_WORDS = 16, CMD = 16, CMD_WORDS = 8, MAX_CMDS = 192, TAB = CMD + MAX_CMDS * CMD_WORDS };
     enum : uint32_t { F_FAST = 1u, F_PULL = 2u, F_MULTI = 4u };
-    static constexpr int LDS_TAB_WORD0 = (int)(offsetof(RenderLdsT<Game>, ci) / 4);
-    static constexpr int TAB_SINGLE_WORDS = (int)((offsetof(RenderLdsT<Game>, srcx) - offsetof(RenderLdsT<Game>, ci) + 3) / 4);
-    static constexpr int TAB_WORDS = (int)((offsetof(RenderLdsT<Game>, typeimg) - offsetof(RenderLdsT<Game>, ci) + 3) / 4);
+    static constexpr int LDS_TAB_WORD0 = (int)(offsetof(RenderLdsT<Game>, seamcols) / 4);
+    static constexpr int TAB_SINGLE_WORDS = (int)((offsetof(RenderLdsT<Game>, srcx) - offsetof(RenderLdsT<Game>, seamcols) + 3) / 4);
+    static constexpr int TAB_WORDS = (int)((offsetof(RenderLdsT<Game>, rot) - offsetof(RenderLdsT<Game>, seamcols) + 3) / 4);
+    // the table block's words of ci / ri / typeany (what a register-table rasterizer loads one word per lane; the words before ci go to LDS)
+    static constexpr int TAB_CI = (int)((offsetof(RenderLdsT<Game>, ci) - offsetof(RenderLdsT<Game>, seamcols)) / 4);
+    static constexpr int TAB_RI = (int)((offsetof(RenderLdsT<Game>, ri) - offsetof(RenderLdsT<Game>, seamcols)) / 4);
+    static constexpr int TAB_TYPEANY = (int)((offsetof(RenderLdsT<Game>, typeany) - offsetof(RenderLdsT<Game>, seamcols)) / 4);
     static constexpr int WORDS = (TAB + (GameDrawsGrid<Game>::value ? TAB_WORDS : 0) + 3) / 4 * 4;  // (records start on 16-byte boundaries)
-    static_assert(offsetof(RenderLdsT<Game>, ci) % 4 == 0 && offsetof(RenderLdsT<Game>, typeimg) % 4 == 0, "the table block is whole words");
+    static_assert(offsetof(RenderLdsT<Game>, seamcols) % 4 == 0 && offsetof(RenderLdsT<Game>, ci) % 4 == 0 && offsetof(RenderLdsT<Game>, rot) % 4 == 0, "the table block is whole words");
 };
 template <bool GEN>
 struct CmdExtra {};
@@ -271,6 +297,13 @@ struct Renderer {
     int ecap;
     const typename Game::cell_t *gg;
     int row0, row1;  // band rows [row0, row1)
+    bool keep_typeimg = true;  // false in the prep kernel: its arena ends before RenderLdsT::typeimg
+    // register-table rasterizer (GameRasterRegTabs): ci[0], ci[1], ri[0], ri[1], typeany of the frame's record, word k in lane k
+    PG_LANE_VAR(uint32_t, tr_ci0);
+    PG_LANE_VAR(uint32_t, tr_ci1);
+    PG_LANE_VAR(uint32_t, tr_ri0);
+    PG_LANE_VAR(uint32_t, tr_ri1);
+    PG_LANE_VAR(uint32_t, tr_ty);
 
     PG_DEV Renderer(const DevCtx &d_, int env_, RenderLds *lds_) : d(d_), env(env_), lds(lds_), fb(lds_->fb), ax(&lds_->ci[0][0]), typeany(lds_->typeany), typesz(lds_->fb + 128) {
         ge = d.ents + ent_table_base(env, d.ent_cap);
@@ -826,7 +859,7 @@ struct Renderer {
                         }
                     }
                 }
-                lds->typeimg[l] = v;
+                if (keep_typeimg) lds->typeimg[l] = v;
                 typeany[l] = any;
                 typesz[l] = sz;
             }
@@ -1092,12 +1125,28 @@ struct Renderer {
     // texel of the cell under one pixel for the column slot sc / row slot sr, branch-free: lanes without a cell fetch
     // atlas word 0 and report no hit (per-lane `if`s around memory operations cost exec-mask juggling on the CU's
     // single scalar unit).  MULTI: the frame has cells of more than one image size.
-    template <bool MULTI>
-    PG_DEV bool pull_fetch(uint32_t ce, uint32_t re, int sc, int sr, int x, int y, int ny_full, int ref_w, uint32_t &tex, bool &opaque) const {
+    // (REG: the tables of a register-table rasterizer -- called from lane sections every lane runs, `l` the calling lane)
+    template <bool REG>
+    PG_DEV uint32_t tab_typeany(int l, uint32_t type) const {
+        if constexpr (REG) return PG_SHFL(tr_ty, l, (int)type);
+        else return typeany[type];
+    }
+    template <bool REG>
+    PG_DEV uint32_t tab_ci1(int l, int x) const {
+        if constexpr (REG) return PG_SHFL(tr_ci1, l, x);
+        else return lds->ci[1][x];
+    }
+    template <bool REG>
+    PG_DEV uint32_t tab_ri(int l, int slot, int y) const {
+        if constexpr (REG) return slot ? PG_SHFL(tr_ri1, l, y) : PG_SHFL(tr_ri0, l, y);
+        else return lds->ri[slot][y];
+    }
+    template <bool MULTI, bool REG = false>
+    PG_DEV bool pull_fetch(uint32_t ce, uint32_t re, int sc, int sr, int x, int y, int ny_full, int ref_w, uint32_t &tex, bool &opaque, int lane = 0) const {
         const uint32_t both = ce & re;
         const bool covered = (both >> 31) != 0;
         const uint32_t ct = lds->cellimg[((ce >> 12) & 0x1fu) * (uint32_t)ny_full + ((re >> 12) & 0x1fu)];
-        const uint32_t tv_ = typeany[ct & 63u];  // (read unconditionally: a load inside a ?: arm becomes a branch around it)
+        const uint32_t tv_ = tab_typeany<REG>(lane, ct & 63u);  // (read unconditionally: a load inside a ?: arm becomes a branch around it)
         const uint32_t cell = ct < 64u ? tv_ : CELL_NONE;
         opaque = (cell >> 31) != 0;
         const bool v0 = ((both >> 30) & 1u) != 0;
@@ -1128,7 +1177,7 @@ struct Renderer {
     // row from the class's row table (one LDS read per row and lane instead of the scalar decode); Qt may have dropped a class's last
     // sample of a row or column, per class.  Measured slower than the per-pixel form for these frames (draw_tiles_pull), so it is the
     // A/B variant, not the default.
-    template <bool MULTI>
+    template <bool MULTI, bool REG = false>
     PG_DEV void rows_pass(int ny_full, int ref_w, uint32_t band_any, uint32_t band_seam) {
         static_assert(BAND_ROWS <= 16, "the band's row entries live in lanes 0..15 (slot 0) and 16..31 (slot 1)");
         // (plain lane sections: the empty asm a PG_R_LANES section takes its lane id through makes the compiler wait for every texel in
@@ -1136,8 +1185,14 @@ struct Renderer {
         PG_LANE_VAR(uint32_t, riv);
         PG_LANE_VAR(uint32_t, ce);
         PG_FOR_LANES(l) {
-            PG_LV(riv, l) = lds->ri[(l >> 4) & 1][row0 + (l & (BAND_ROWS - 1))];
-            PG_LV(ce, l) = lds->ci[0][l];
+            if constexpr (REG) {
+                const uint32_t e0 = PG_SHFL(tr_ri0, l, row0 + (l & (BAND_ROWS - 1))), e1 = PG_SHFL(tr_ri1, l, row0 + (l & (BAND_ROWS - 1)));
+                PG_LV(riv, l) = ((l >> 4) & 1) ? e1 : e0;
+                PG_LV(ce, l) = PG_LV(tr_ci0, l);
+            } else {
+                PG_LV(riv, l) = lds->ri[(l >> 4) & 1][row0 + (l & (BAND_ROWS - 1))];
+                PG_LV(ce, l) = lds->ci[0][l];
+            }
         }
         _Pragma("nounroll") for (int sr = 0; sr < 2; sr++) {  // (one copy of the 16-row body: unrolled, the two copies' scalars spilled into each other)
             const uint32_t rows = sr ? band_seam : band_any;
@@ -1168,7 +1223,7 @@ struct Renderer {
                     PG_FOR_LANES(l) {
                         const uint32_t c = PG_LV(ce, l);
                         const uint32_t ct = lds->cellimg[((c >> 12) & 0x1fu) * (uint32_t)ny_full + (uint32_t)cy];
-                        const uint32_t tv = typeany[ct & 63u];
+                        const uint32_t tv = tab_typeany<REG>(l, ct & 63u);
                         const uint32_t cell = ct < 64u ? tv : CELL_NONE;
                         bool h = (c >> 31) != 0 && cell != CELL_NONE;
                         uint32_t col = c & 0xfffu, k = 0;
@@ -1286,7 +1341,7 @@ struct Renderer {
             PG_SYNC();
         }
     }
-    template <bool MULTI, int NJ>
+    template <bool MULTI, int NJ, bool REG = false>
     PG_DEV void seam_cols_round(int base, int npx, uint32_t inv, int nseam, int ny_full, int ref_w) {
         PG_R_LANES(l) {
             uint32_t tex[NJ];
@@ -1298,7 +1353,7 @@ struct Renderer {
                 const int pc = in ? p : 0;
                 const int yl = (int)(((uint32_t)pc * inv) >> 20);
                 const int x = (int)lds->seamcols[pc - yl * nseam];
-                const bool hit = pull_fetch<MULTI>(lds->ci[1][x], lds->ri[0][row0 + yl], 1, 0, x, row0 + yl, ny_full, ref_w, tex[j], opq[j]) && in;
+                const bool hit = pull_fetch<MULTI, REG>(tab_ci1<REG>(l, x), tab_ri<REG>(l, 0, row0 + yl), 1, 0, x, row0 + yl, ny_full, ref_w, tex[j], opq[j], l) && in;
                 fbi[j] = hit ? yl * RES_W + x : BAND_ROWS * RES_W + l;  // masked-off lanes use the dump row
             }
             dma_join();
@@ -1309,8 +1364,9 @@ struct Renderer {
         }
         PG_SYNC();
     }
-    template <bool MULTI>
+    template <bool MULTI, bool REG = false>
     PG_DEV void draw_tiles_pull(int ny_full, uint64_t colseam, uint64_t rowseam, uint64_t rowany, int ref_w) {
+        static_assert(!(MULTI && REG), "register tables: frames with one cell image size");
         const int nseam = pg_popc64(colseam);
         const uint32_t band_any = (uint32_t)((rowany >> row0) & ((1ull << BAND_ROWS) - 1ull));
         if (band_any == 0) return;  // no cell with an image reaches these rows (sky)
@@ -1318,8 +1374,12 @@ struct Renderer {
         // stages 1 and 2: (c0, r0), and (c0, r1) on the doubly covered rows
         // (frames with several cell image sizes keep the per-pixel form: the row-major one with per-lane row tables measured 3-10 % SLOWER on
         // maze, miner, climber, jumper, caveflyer, profiles/r06_call17_ab16.txt; PROCGEN_AMD_DEBUG & 2097152 selects it for the A/B)
-        if (MULTI && !PG_DBG(d, 2097152)) rows_pass_by_pixel<MULTI>(ny_full, ref_w, band_any, band_seam);
-        else rows_pass<MULTI>(ny_full, ref_w, band_any, band_seam);
+        if constexpr (REG) {
+            rows_pass<false, true>(ny_full, ref_w, band_any, band_seam);
+        } else {
+            if (MULTI && !PG_FDBG(d, 2097152)) rows_pass_by_pixel<MULTI>(ny_full, ref_w, band_any, band_seam);
+            else rows_pass<MULTI>(ny_full, ref_w, band_any, band_seam);
+        }
         if (nseam == 0) return;
         // stage 3: (c1, r0): the doubly covered columns x the band's rows, laid out linearly over the lanes, one, two or four pixels per lane
         // and round (coinrun shows two or three such columns, 48 pixels a band: a four-deep round spent three quarters of its instructions
@@ -1327,10 +1387,10 @@ struct Renderer {
         {
             const uint32_t inv = (uint32_t)(((1u << 20) + (uint32_t)nseam - 1u) / (uint32_t)nseam);
             const int npx = nseam * BAND_ROWS;
-            if (npx <= 64) seam_cols_round<MULTI, 1>(0, npx, inv, nseam, ny_full, ref_w);
-            else if (npx <= 128) seam_cols_round<MULTI, 2>(0, npx, inv, nseam, ny_full, ref_w);
+            if (npx <= 64) seam_cols_round<MULTI, 1, REG>(0, npx, inv, nseam, ny_full, ref_w);
+            else if (npx <= 128) seam_cols_round<MULTI, 2, REG>(0, npx, inv, nseam, ny_full, ref_w);
             else
-                for (int base = 0; base < npx; base += 256) seam_cols_round<MULTI, 4>(base, npx, inv, nseam, ny_full, ref_w);
+                for (int base = 0; base < npx; base += 256) seam_cols_round<MULTI, 4, REG>(base, npx, inv, nseam, ny_full, ref_w);
         }
         // stage 4: (c1, r1): doubly covered columns x doubly covered rows; lane = seam column, four rows per round
         for (uint32_t m = band_seam; m != 0;) {
@@ -1346,7 +1406,7 @@ struct Renderer {
             PG_R_LANES(l) {
                 const bool in = l < nseam;
                 const int x = (int)lds->seamcols[in ? l : 0];
-                const uint32_t ce = lds->ci[1][x];
+                const uint32_t ce = tab_ci1<REG>(l, x);
                 uint32_t tex[4];
                 int fbi[4];
                 bool opq[4];
@@ -1355,7 +1415,7 @@ struct Renderer {
                     tex[q] = 0;
                     fbi[q] = BAND_ROWS * RES_W + l;
                     if (q < cnt) {
-                        const bool hit = pull_fetch<MULTI>(ce, lds->ri[1][ys[q]], 1, 1, x, ys[q], ny_full, ref_w, tex[q], opq[q]) && in;
+                        const bool hit = pull_fetch<MULTI, REG>(ce, tab_ri<REG>(l, 1, ys[q]), 1, 1, x, ys[q], ny_full, ref_w, tex[q], opq[q], l) && in;
                         fbi[q] = hit ? (ys[q] - row0) * RES_W + x : BAND_ROWS * RES_W + l;
                     }
                 }
@@ -1466,7 +1526,7 @@ struct Renderer {
     // whole band's rows are in flight while the wave goes on to request the band's first cell / sprite texels: whoever reads or
     // writes fb next joins the copies (dma_join) after issuing its own fetches.
     PG_DEV bool bg_dma_ok(const DrawCmd &c) const {
-        return !GEN && !PG_DBG(d, 131072) && c.w > 32 && cmd_opaque(c.aux) && !cmd_mirrored(c.aux) && !cmd_fill(c.aux) && !cmd_rotated(c.aux) && !cmd_tiled(c.aux);
+        return !GEN && !PG_FDBG(d, 131072) && c.w > 32 && cmd_opaque(c.aux) && !cmd_mirrored(c.aux) && !cmd_fill(c.aux) && !cmd_rotated(c.aux) && !cmd_tiled(c.aux);
     }
     PG_DEV void exec_bg_dma(const DrawCmd &c) {
         const uint32_t *src = d.pixels + c.src;
@@ -1968,7 +2028,7 @@ struct Renderer {
         }
         // (a turned sprite joins the groups of small ones when the game has rotation records and its bounding box fits; GEN draws them on Qt's generic route)
         const uint64_t small = PG_BALLOT(l, PG_LV(r.geom, l) != 0 && ((PG_LV(r.geom, l) >> 14) & 0x7fu) <= 8u && ((PG_LV(r.geom, l) >> 21) & 0x7fu) <= 8u &&
-                                                (!cmd_rotated(PG_LV(r.aux, l)) || (GameUsesRotation<Game>::value && !GEN && !PG_DBG(d, 524288))) && !cmd_tiled(PG_LV(r.aux, l)));
+                                                (!cmd_rotated(PG_LV(r.aux, l)) || (GameUsesRotation<Game>::value && !GEN && !PG_FDBG(d, 524288))) && !cmd_tiled(PG_LV(r.aux, l)));
         while (valid) {
             const int k = pg_ctz64(valid);
             if ((small >> k) & 1ull) {
@@ -2327,7 +2387,7 @@ struct Renderer {
     long long t_mark = 0;
     PG_DEV void phase(int k) {
 #if !defined(PGAMD_WAVE_EMU)
-        if (PG_PHASES(d)) {
+        if (PG_FPHASES(d)) {
             const long long t = (long long)__builtin_readcyclecounter();
             if (PG_LANE_ID() == 0 && t_mark != 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + k, (unsigned long long)(t - t_mark));
             t_mark = (long long)__builtin_readcyclecounter();
@@ -2354,7 +2414,7 @@ struct Renderer {
     }
     PG_DEV void render_env() {
 #if !defined(PGAMD_WAVE_EMU)
-        if (PG_PHASES(d)) t_mark = (long long)__builtin_readcyclecounter();
+        if (PG_FPHASES(d)) t_mark = (long long)__builtin_readcyclecounter();
 #endif
         // ---- requests, round 1: what depends on the env index alone -- the header and the fields of the first 64 entity slots
         EntPre epre;
@@ -2370,8 +2430,8 @@ struct Renderer {
         // ---- frame-level set-up (rows [0, 64)) ------------------------------------------------------------------
         row0 = 0;
         row1 = RES_H;
-        if PG_DBG(d, 4) G.n_ents = 0;
-        const bool force_chunks = PG_DBG(d, 4096) != 0;  // test aid: every frame through draw_entities()
+        if PG_FDBG(d, 4) G.n_ents = 0;
+        const bool force_chunks = PG_FDBG(d, 4096) != 0;  // test aid: every frame through draw_entities()
         bool one_chunk = G.n_ents <= 64 && !force_chunks;  // or: the visible ones fit the register sets
         int win_lx, win_hx, win_ly, win_hy;  // BAG:926-939
         if (Game::center_agent(opt)) {
@@ -2391,10 +2451,10 @@ struct Renderer {
         const int ref_w = d.assets->ref_w, ref_h = d.assets->ref_h;
         // (GEN: every cell is its own generic drawImage, set up lane-parallel per band: neither axis tables nor the pull form)
         const bool use_axes = !GEN && GameDrawsGrid<Game>::value && nx > 0 && ny_full > 0 && nx <= 32 && ny_full <= 32;
-        const bool try_pull = GameDrawsGrid<Game>::value && !GEN && use_axes && nx * ny_full <= GamePullCells<Game>::value && !PG_DBG(d, 1024);
+        const bool try_pull = GameDrawsGrid<Game>::value && !GEN && use_axes && nx * ny_full <= GamePullCells<Game>::value && !PG_FDBG(d, 1024);
         // ---- requests, round 2: every table lookup of the set-up, in flight together: the background image, the images of the
         // entities (lane = slot) and of the grid object types (lane = type), the first 256 window cells
-        const ImgDesc bg_desc = (opt.use_backgrounds && !PG_DBG(d, 1)) ? d.assets->bg_desc[G.background_index] : ImgDesc{IMG_NONE, 0, 0, 0};
+        const ImgDesc bg_desc = (opt.use_backgrounds && !PG_FDBG(d, 1)) ? d.assets->bg_desc[G.background_index] : ImgDesc{IMG_NONE, 0, 0, 0};
         PG_LANE_VAR(ImgDesc, type_desc);
         PG_LANE_ARR(int, cells0, 4);
         PG_R_LANES(l) {
@@ -2427,14 +2487,14 @@ struct Renderer {
             }
         };
         if constexpr (GameCustomBackground<Game>::value) {
-            if (opt.use_backgrounds && !PG_DBG(d, 1)) {
+            if (opt.use_backgrounds && !PG_FDBG(d, 1)) {
                 RectD rects[4];
                 const int nr = Game::background_rects(*this, rects);
                 const ImgDesc bgi = bg_desc;
                 _Pragma("unroll") for (int k = 0; k < 4; k++)
                     if (k < nr && rects[k].w > 0) add_bg(bgi, rects[k]);
             }
-        } else if (opt.use_backgrounds && !PG_DBG(d, 1)) {
+        } else if (opt.use_backgrounds && !PG_FDBG(d, 1)) {
             const RectD main_rect = get_screen_rect(0, (float)G.main_height, (float)G.main_width, (float)G.main_height, 0);
             const ImgDesc bgi = bg_desc;
             if (!GameTiledBackground<Game>::value && G.bg_tile_ratio < 0) fail(PGE_UNSUPPORTED_DRAW);  // (only fruitbot's constructor sets it)
@@ -2574,7 +2634,7 @@ struct Renderer {
             int low_y = win_ly, ny = 0, ncell = 0;
             uint32_t ny_inv = 0;
             const int low_x = win_lx;
-            if (GameDrawsGrid<Game>::value && !(pull || PG_DBG(d, 2))) {  // (the pull form walks screen rows, not cells)
+            if (GameDrawsGrid<Game>::value && !(pull || PG_FDBG(d, 2))) {  // (the pull form walks screen rows, not cells)
                 int high_y = win_hy;
                 const float inv_unit = 1.0f / G.unit;
                 const int cy_hi = (int)pg_ceil((double)(G.view_dim - ((float)row0 - G.y_off) * inv_unit)) + 1;
@@ -2588,7 +2648,7 @@ struct Renderer {
             }
             phase(2);
             if constexpr (GameDrawsGrid<Game>::value)
-                if (pull && !PG_DBG(d, 2)) {
+                if (pull && !PG_FDBG(d, 2)) {
                     if (pull_multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w);
                     else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w);
                     if constexpr (GameHasGridFills<Game>::value) draw_pull_fills(pull_nfill);
@@ -2693,12 +2753,12 @@ struct Renderer {
             if constexpr (GameHasOverlay<Game>::value) Game::draw_overlay(*this);  // game_draw overrides that paint after the base frame
             PG_SYNC();
             phase(4);
-            if (!PG_DBG(d, 8)) store_band();
+            if (!PG_FDBG(d, 8)) store_band();
             PG_SYNC();
             phase(5);
         }
 #if !defined(PGAMD_WAVE_EMU)
-        if (PG_PHASES(d) && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + 15, 1ull);
+        if (PG_FPHASES(d) && PG_LANE_ID() == 0) atomicAdd(d.phase_cycles + 32 * (env & 4095) + 16 + 15, 1ull);
 #else
         if (pg_emu_dma_outstanding() != 0) {  // (a band whose background copies nobody joined: store_band always does)
             fprintf(stderr, "render_env: %d LDS-DMA words still in flight at the end of the frame\n", pg_emu_dma_outstanding());
@@ -2797,10 +2857,25 @@ struct Renderer {
         const int ncmd = (int)((dims >> 8) & 0xffu);
         const bool pull = (flags & Rec::F_PULL) != 0, multi = (flags & Rec::F_MULTI) != 0;
         G.error = 0;
+        constexpr bool REG = GameRasterRegTabs<Game>::value;
+        if constexpr (GameRasterBandOverTables<Game>::value) fb = &lds->ci[0][0];
+        if constexpr (REG) {
+            // register tables: the band buffer lies over ci / ri / typeany, which this kernel's arena does not hold as tables (RenderLdsT);
+            // those come from the record one word per lane, the words in front of them (seam columns, cell types, fills) by LDS-DMA
+            static_assert(GameRasterBandOverTables<Game>::value, "a register-table rasterizer's band buffer lies over the tables");
+            PG_R_LANES(l) {
+                const uint32_t *t = rec + Rec::TAB;
+                PG_LV(tr_ci0, l) = pull ? t[Rec::TAB_CI + l] : 0u;
+                PG_LV(tr_ci1, l) = pull ? t[Rec::TAB_CI + 64 + l] : 0u;
+                PG_LV(tr_ri0, l) = pull ? t[Rec::TAB_RI + l] : 0u;
+                PG_LV(tr_ri1, l) = pull ? t[Rec::TAB_RI + 64 + l] : 0u;
+                PG_LV(tr_ty, l) = pull ? t[Rec::TAB_TYPEANY + l] : 0u;
+            }
+        }
         if constexpr (GameDrawsGrid<Game>::value) {
             if (pull) {
                 uint32_t *tab = reinterpret_cast<uint32_t *>(lds) + Rec::LDS_TAB_WORD0;
-                const int words = multi ? Rec::TAB_WORDS : Rec::TAB_SINGLE_WORDS;
+                const int words = REG ? Rec::TAB_CI : multi ? Rec::TAB_WORDS : Rec::TAB_SINGLE_WORDS;
                 for (int k0 = 0; k0 < words; k0 += 64) {
                     PG_R_LANES(l) {
                         if (k0 + l < words) PG_DMA_DWORD(rec + Rec::TAB + k0 + l, tab + k0, l);
@@ -2833,27 +2908,31 @@ struct Renderer {
                     }
                 }
                 PG_SYNC();
-                if (bg_geom != 0 && bc0.ty1 < row1 && bc0.ty1 + bc0.h > row0 && !PG_DBG(d, 1)) {
+                if (bg_geom != 0 && bc0.ty1 < row1 && bc0.ty1 + bc0.h > row0 && !PG_FDBG(d, 1)) {
                     if (bg_dma) exec_bg_dma(bc0);
                     else exec_large(bc0);
                 }
             }
-            if (any0 && !PG_DBG(d, 4)) draw_cmd_layers(nsets, er, ez, 0u, 0u);
+            if (any0 && !PG_FDBG(d, 4)) draw_cmd_layers(nsets, er, ez, 0u, 0u);
             if constexpr (GameDrawsGrid<Game>::value) {
-                if (pull && !PG_DBG(d, 2)) {
+                if (pull && !PG_FDBG(d, 2)) {
                     const uint32_t dm = PG_READLANE(hb, Rec::DIMS);
                     const int ny_full = (int)(dm & 0xffu), ref_w = (int)PG_READLANE(hb, Rec::REF_W);
                     const uint64_t colseam = (uint64_t)PG_READLANE(hb, Rec::COLSEAM) | ((uint64_t)PG_READLANE(hb, Rec::COLSEAM + 1) << 32);
                     const uint64_t rowseam = (uint64_t)PG_READLANE(hb, Rec::ROWSEAM) | ((uint64_t)PG_READLANE(hb, Rec::ROWSEAM + 1) << 32);
                     const uint64_t rowany = (uint64_t)PG_READLANE(hb, Rec::ROWANY) | ((uint64_t)PG_READLANE(hb, Rec::ROWANY + 1) << 32);
-                    if (multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w);
-                    else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w);
+                    if constexpr (REG) {
+                        draw_tiles_pull<false, true>(ny_full, colseam, rowseam, rowany, ref_w);  // (a frame with a second image size is not on the short path)
+                    } else {
+                        if (multi) draw_tiles_pull<true>(ny_full, colseam, rowseam, rowany, ref_w);
+                        else draw_tiles_pull<false>(ny_full, colseam, rowseam, rowany, ref_w);
+                    }
                     if constexpr (GameHasGridFills<Game>::value) draw_pull_fills((int)(dm >> 16));
                 }
             }
-            if (any12 && !PG_DBG(d, 4)) draw_cmd_layers(nsets, er, ez, 1u, 2u);  // z = 0, then z = 1
+            if (any12 && !PG_FDBG(d, 4)) draw_cmd_layers(nsets, er, ez, 1u, 2u);  // z = 0, then z = 1
             PG_SYNC();
-            if (!PG_DBG(d, 8)) store_band();
+            if (!PG_FDBG(d, 8)) store_band();
             else dma_join();
             PG_SYNC();
         }

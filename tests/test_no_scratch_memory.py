@@ -26,15 +26,20 @@ DISPLAY_LIST = {"CoinRun", "Climber"}  # games (of the ones compiled here) whose
 SMALL_SPILLS_THAT_PAID = {("Leaper", True): 32, ("FruitBot", True): 192, ("Jumper", True): 24, ("Climber", True): 16}
 
 
-def _release_games():
-    """the games the Makefile builds with -DPG_RELEASE (RELEASE_GAMES): the guard compiles what ships"""
-    m = re.search(r"^RELEASE_GAMES := (.*)$", open(os.path.join(CSRC, "Makefile")).read(), re.M)
-    return set(m.group(1).split()) if m else set()
+def _release_flags(game):
+    """the -DPG_RELEASE* flags the Makefile builds this game with (RELEASE_GAMES, RELEASE_FRAME_GAMES, RELEASE_STEP_GAMES): the guard compiles what ships"""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    flags = []
+    for var, flag in (("RELEASE_GAMES", "-DPG_RELEASE"), ("RELEASE_FRAME_GAMES", "-DPG_RELEASE_FRAME"), ("RELEASE_STEP_GAMES", "-DPG_RELEASE_STEP")):
+        m = re.search(r"^%s [:?]= *(.*)$" % var, mk, re.M)
+        if m and game in m.group(1).split():
+            flags.append(flag)
+    return flags
 
 
 def _scratch_bytes(game, tmp):
     out = os.path.join(tmp, f"{game}.s")
-    rel = ["-DPG_RELEASE"] if game in _release_games() else []
+    rel = _release_flags(game)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing", f"-DPG_GAME={game}"] + rel +
                           ["--cuda-device-only", "-S", "-c", os.path.join(CSRC, "kernels_game.hip"), "-o", out], cwd=CSRC, stderr=subprocess.DEVNULL)
     text = open(out).read()

@@ -3,7 +3,7 @@ TAG=${1:-r6c19}
 R=$GRAFT_REPO_ROOT
 cd $R; mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
-for f in 0 2 4; do
+for f in ${FLAGS:-0 2 4}; do
   PROCGEN_AMD_DEBUG=$f timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES --kernel-trace -d /tmp/${TAG}_f$f -o p -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-host-landed --no-traffic > $R/gpurun_out/${TAG}_f$f.log 2>&1
   python $R/tests/tools/rocpd_summary.py $(find /tmp/${TAG}_f$f -name "*.db" | head -1) > $R/gpurun_out/${TAG}_f$f.csv 2>&1
   rm -rf /tmp/${TAG}_f$f
