@@ -132,8 +132,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GEN ? 1 : Ga
     if (PG_RENDER_TRACE) trace_wave(d, env, 4, true, 8);
 }
 // ---- display-list games (pg_prep.h): prep -> raster -> render_list ----
+#ifndef PG_PREP_WAVES
+#define PG_PREP_WAVES 1
+#endif
 template <class Game>
-__global__ __launch_bounds__(64) void prep(DevCtx d, int env_base, int count, int chunk) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PG_PREP_WAVES))) void prep(DevCtx d, int env_base, int count, int chunk) {
     // the render arena without its band buffer (but for the words the table builders use as scratch): 2.9 KB instead of 6.2 KB for coinrun,
     // i.e. eight waves of this latency-bound kernel per SIMD instead of five
     __shared__ __attribute__((aligned(16))) uint32_t arena[offsetof(RenderLdsT<Game>, fb) / 4 + RenderLdsT<Game>::PREP_FB_WORDS];
@@ -239,13 +242,27 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
     // queue run their kernels one after the other.
     //   main    : tier-1 list          lane[1] : tier-2 list, then chunk 1, 3, ...
     //                                  lane[0] : chunk 0, 2, ...
+    // order 4: chunk 0 -- the step's longest chain -- runs on the MAIN stream, in order behind the upload of the actions, and the tier-1
+    // list takes lane[0]: the first step_tier0 grid then starts with the step instead of a cross-queue event (~20-30 us) later
+    const bool c0_main = ls.order == 4;
+    hipStream_t s_t1 = c0_main ? ls.lane[0] : ls.main;
     PG_TRY(hipEventRecord(ls.fork, ls.main));
-    if (t1) {
-        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, ls.main, d, mode, 0);
-        PG_TRY(hipEventRecord(ls.side_done[0], ls.main));
-    }
     PG_TRY(hipStreamWaitEvent(ls.lane[0], ls.fork, 0));
     PG_TRY(hipStreamWaitEvent(ls.lane[1], ls.fork, 0));
+    const int nchunk = ls.chunks > 1 ? (ls.chunks < MAX_CHUNKS ? ls.chunks : MAX_CHUNKS) : 1;
+    const int per = ((d.num_envs + nchunk - 1) / nchunk + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;
+    // Two chunks are cut unevenly (PROCGEN_AMD_FIRST_PCT, default 75 / 25; games without split resets): with equal chunks the two
+    // streams run in lockstep -- both step kernels, then both render kernels -- and the step / render overlap the chunks exist
+    // for hardly happens.  Measured 25 / 75 or 75 / 25 against 50 / 50: starpilot +9 %, maze +3-6 %, bigfish +4 %, coinrun +1 %
+    // (coinrun only with the large chunk first: its tier-2 list kernel already delays the second stream).  Three or four
+    // chunks, even or uneven (50/30/20, 40/30/20/10, ...), measured 15-18 % slower than two for coinrun and starpilot.
+    const int first = (nchunk == 2 && ls.first_pct > 0) ? first_chunk_envs(d.num_envs, ls.first_pct) : 0;  // (== DevCtx::reset_first)
+    // (submitting chunk 0's step grid ahead of the list kernels -- the device idles until the first large grid is in its queue -- measured
+    // 0 for coinrun and -1.7 % for bigfish, profiles/r06_call32_order16.txt: not kept)
+    if (t1) {
+        hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T1, 1>), dim3(g1), dim3(64), 0, s_t1, d, mode, 0);
+        PG_TRY(hipEventRecord(ls.side_done[0], s_t1));
+    }
     // launch order experiments (PROCGEN_AMD_ORDER): 0 = tier-2 list ahead of chunk 1 on its stream (which also delays that
     // chunk's step kernel: an accidental pipeline); 1 / 3 = tier-2 list on the side stream and chunk c + 1's step kernel
     // explicitly behind chunk c's; 2 = side stream, no chaining
@@ -257,19 +274,11 @@ static hipError_t launch_game(const DevCtx &d, int mode, const LaunchStreams &ls
         hipLaunchKernelGGL((step_list<Game, Game::ENT_CAP_T2, 2>), dim3(g2), dim3(64), 0, s2, d, mode, 0);
         PG_TRY(hipEventRecord(ls.side_done[1], s2));
     }
-    const int nchunk = ls.chunks > 1 ? (ls.chunks < MAX_CHUNKS ? ls.chunks : MAX_CHUNKS) : 1;
-    const int per = ((d.num_envs + nchunk - 1) / nchunk + TILE_ENVS - 1) / TILE_ENVS * TILE_ENVS;
-    // Two chunks are cut unevenly (PROCGEN_AMD_FIRST_PCT, default 75 / 25; games without split resets): with equal chunks the two
-    // streams run in lockstep -- both step kernels, then both render kernels -- and the step / render overlap the chunks exist
-    // for hardly happens.  Measured 25 / 75 or 75 / 25 against 50 / 50: starpilot +9 %, maze +3-6 %, bigfish +4 %, coinrun +1 %
-    // (coinrun only with the large chunk first: its tier-2 list kernel already delays the second stream).  Three or four
-    // chunks, even or uneven (50/30/20, 40/30/20/10, ...), measured 15-18 % slower than two for coinrun and starpilot.
-    const int first = (nchunk == 2 && ls.first_pct > 0) ? first_chunk_envs(d.num_envs, ls.first_pct) : 0;  // (== DevCtx::reset_first)
     for (int c = 0; c < nchunk; c++) {
         const int base = first > 0 ? (c == 0 ? 0 : first) : c * per;
         const int count = first > 0 ? (c == 0 ? first : d.num_envs - first) : ((d.num_envs - base) < per ? (d.num_envs - base) : per);
         if (count <= 0) break;
-        hipStream_t st = ls.lane[c & 1];
+        hipStream_t st = (c0_main && (c & 1) == 0) ? ls.main : ls.lane[c & 1];
         if (chain && c > 0 && mode != 0) PG_TRY(hipStreamWaitEvent(st, ls.step_done[c - 1], 0));
         if (GameSplit<Game>::value && mode == 0) {
             if constexpr (GameSplit<Game>::value) hipLaunchKernelGGL(reset_grid<Game>, dim3(count), dim3(64), 0, st, d, base);

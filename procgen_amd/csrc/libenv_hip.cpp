@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -170,6 +171,14 @@ static std::shared_ptr<DeviceAtlas> shared_atlas(int device, const std::string &
 // Measured (profiles/r05_render_order_ab.txt, device ms per step at 65 536 envs, off -> every 16 steps): miner 1.746 -> 1.430 (+22 %),
 // climber 1.130 -> 1.119, ninja 1.272 -> 1.261, coinrun 1.239 -> 1.230, jumper 1.750 -> 1.739 (+0.6-0.9 % each, and coinrun's render FETCH_SIZE
 // 1.73 -> 0.46 GB per 8 steps' launches, L2 hit rate 61 -> 82 %); caveflyer +0.3 %; maze -1.1 %, heist -1.4 %, bigfish -37 %: off.
+// Which stream a two-chunk handle's first chunk runs on (launch_game `order`): 0 = its own stream, behind an event of the main stream that
+// uploads the actions; 4 = the main stream itself, the tier-1 list kernel on the other one.  Per game, from two same-box sweeps of all 16
+// (profiles/r06_call31_order16.txt, r06_call32_order16.txt; M steps/s at 65 536 envs): plunder +3.0 / +3.4 %, bigfish +1.7 / +1.9 %, climber
+// +0.6 / +2.0 %, miner +1.4 / +1.0 %; coinrun -4 % (its tier-2 list kernel ahead of chunk 1 makes the two chunks a pipeline that order 4
+// shifts), ninja -1 %, starpilot -1 %, the others within +-0.8 %.
+static int default_launch_order(int game_id) {
+    return (game_id == GAME_PLUNDER || game_id == GAME_BIGFISH || game_id == GAME_CLIMBER || game_id == GAME_MINER) ? 4 : 0;
+}
 static int default_render_order_period(int game_id) {
     switch (game_id) {
         case GAME_COINRUN: case GAME_CLIMBER: case GAME_NINJA: case GAME_JUMPER: case GAME_MINER: return 16;
@@ -221,6 +230,7 @@ struct VecGame {
     hipEvent_t ev_frames[MAX_CHUNKS] = {}, ev_obs = nullptr;
     bool obs_chunk_copy = false;
     int order = 0;  // PROCGEN_AMD_ORDER
+
     int first_pct = 60;  // PROCGEN_AMD_FIRST_PCT: share of the first of two chunks (75 until round 6; profiles/r06_call12_ab.txt: 60 is +2..7 % for five of six games, with the round-5 kernels as well)
     int chunks = 2;  // PROCGEN_AMD_CHUNKS: env range cut in 2 so one chunk's step kernel overlaps the other's render kernel (+6 % measured)
     LaunchStreams streams() const {
@@ -239,8 +249,8 @@ struct VecGame {
         for (int c = 0; c < MAX_CHUNKS; c++) ls.outputs_done[c] = early_small ? ev_out[c] : nullptr;
         for (int c = 0; c < MAX_CHUNKS; c++) {
             ls.frames_done[c] = (obs_chunk_copy && host_observations) ? ev_frames[c] : nullptr;
-            ls.render_t0[c] = (time_kernels && time_render) ? tk_r0[c] : nullptr;
-            ls.render_t1[c] = (time_kernels && time_render) ? tk_r1[c] : nullptr;
+            ls.render_t0[c] = (time_kernels && time_render) ? tk_r0[tk_slot][c] : nullptr;
+            ls.render_t1[c] = (time_kernels && time_render) ? tk_r1[tk_slot][c] : nullptr;
         }
         ls.order = order;
         ls.first_pct = first_pct;
@@ -312,8 +322,12 @@ struct VecGame {
     void check_late_error(const char *when = "a step");
     // procgen_amd_kernel_timing: HIP events around the kernels of every libenv_act of the caller's own loop (bench.py: the device time of
     // a step and the wall time of a step then come from the SAME steps)
-    bool time_kernels = false, time_render = false, tk_pending = false;
-    hipEvent_t tk_e0 = nullptr, tk_e1 = nullptr, tk_r0[MAX_CHUNKS] = {}, tk_r1[MAX_CHUNKS] = {};
+    // (two sets of events: a step's durations are read while the NEXT step runs -- in libenv_observe ahead of its wait, or by the query --
+    // so that the three hipEventElapsedTime calls are not part of the device's idle time between two steps)
+    bool time_kernels = false, time_render = false, tk_pending[2] = {false, false};
+    int tk_slot = 0;
+    hipEvent_t tk_e0[2] = {}, tk_e1[2] = {}, tk_r0[2][MAX_CHUNKS] = {}, tk_r1[2][MAX_CHUNKS] = {};
+    void collect_timing(int slot);
     double tk_sum_ms = 0, tk_render_ms = 0;
     int tk_steps = 0, tk_render_launches = 0;
     // host-mapped copy of the error record, written by the first kernel that raises a check (pg_env.h pg_report_error): [0] code (written
@@ -490,8 +504,9 @@ VecGame::VecGame(int nenvs, VecOptions opts, const std::string &forced_name, int
             HIP_CHECK(hipStreamCreateWithFlags(&lane_stream[k], hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&ev_lane[k], hipEventDisableTiming));
         }
+        order = default_launch_order(game_id);
         if (const char *o = getenv("PROCGEN_AMD_ORDER")) order = atoi(o);
-        if (order != 0) HIP_CHECK(hipStreamCreateWithFlags(&side_stream[0], hipStreamNonBlocking));  // four streams at most (hardware queues)
+        if (order != 0 && order != 4) HIP_CHECK(hipStreamCreateWithFlags(&side_stream[0], hipStreamNonBlocking));  // four streams at most (hardware queues)
         for (int c = 0; c < MAX_CHUNKS; c++) HIP_CHECK(hipEventCreateWithFlags(&ev_step[c], hipEventDisableTiming));
         for (int k = 0; k < 3; k++) HIP_CHECK(hipEventCreateWithFlags(&ev_side[k], hipEventDisableTiming));
         const char *es = getenv("PROCGEN_AMD_EARLY_SMALL");
@@ -742,11 +757,13 @@ VecGame::~VecGame() {
         if (ev_out[c]) (void)hipEventDestroy(ev_out[c]);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (tk_e0) (void)hipEventDestroy(tk_e0);
-    if (tk_e1) (void)hipEventDestroy(tk_e1);
-    for (int c = 0; c < MAX_CHUNKS; c++) {
-        if (tk_r0[c]) (void)hipEventDestroy(tk_r0[c]);
-        if (tk_r1[c]) (void)hipEventDestroy(tk_r1[c]);
+    for (int k = 0; k < 2; k++) {
+        if (tk_e0[k]) (void)hipEventDestroy(tk_e0[k]);
+        if (tk_e1[k]) (void)hipEventDestroy(tk_e1[k]);
+        for (int c = 0; c < MAX_CHUNKS; c++) {
+            if (tk_r0[k][c]) (void)hipEventDestroy(tk_r0[k][c]);
+            if (tk_r1[k][c]) (void)hipEventDestroy(tk_r1[k][c]);
+        }
     }
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -928,11 +945,15 @@ void VecGame::check_late_error(const char *when) {
 }
 
 void VecGame::launch(int mode) {
-    if (time_kernels) HIP_CHECK(hipEventRecord(tk_e0, stream));
+    if (time_kernels) {
+        tk_slot ^= 1;
+        if (tk_pending[tk_slot]) collect_timing(tk_slot);  // (two steps back: long complete)
+        HIP_CHECK(hipEventRecord(tk_e0[tk_slot], stream));
+    }
     launch_kernels(mode);
     if (time_kernels) {
-        HIP_CHECK(hipEventRecord(tk_e1, stream));  // (main has joined the chunk streams: behind every kernel of the step)
-        tk_pending = true;
+        HIP_CHECK(hipEventRecord(tk_e1[tk_slot], stream));  // (main has joined the chunk streams: behind every kernel of the step)
+        tk_pending[tk_slot] = true;
     }
     if (early_small) {
         // behind every step kernel of the step (chunk grids on the lane streams, list kernels), not behind the render kernels.  The error
@@ -1007,6 +1028,7 @@ void VecGame::observe(bool from_api) {  // reference src/vecgame.cpp:363-376,416
     }
     if (!pending) return;
     use_device();
+    if (time_kernels) collect_timing(tk_slot ^ 1);  // (the step before the one in flight, while the device is busy)
     if (small_in_flight) {  // the small outputs are on the host while the render kernels still run: scatter them first, join the frames after
         HIP_CHECK(hipEventSynchronize(ev_small));
         small_in_flight = false;
@@ -1031,27 +1053,32 @@ void VecGame::observe(bool from_api) {  // reference src/vecgame.cpp:363-376,416
             *(int32_t *)info_ptr[2][e] = ls[e];
         }
     }
+    // (polling the stream instead of blocking on it measured 0 .. -1 %: the wake-up is not what the device waits for between two steps,
+    // profiles/r06_call30_order_spin.txt)
     if (early_small) HIP_CHECK(hipStreamSynchronize(stream));  // (the render kernels, the landing of the frames)
     check_late_error();
     if (step_used_display_list && h_error_rec[8] != 0) draw_slow_frames();  // (a prep wave of this step queued a frame for the full renderer)
     if (host_observations && !ob_contig)
         for (size_t e = 0; e < N; e++) memcpy(ob_ptr[e], h_obs_stage + e * OBS_BYTES, OBS_BYTES);
-    if (tk_pending) {  // (the stream is joined: both events have completed)
-        float ms = 0.f;
-        HIP_CHECK(hipEventElapsedTime(&ms, tk_e0, tk_e1));
-        tk_sum_ms += ms;
-        tk_steps++;
-        const int nchunk = num_envs < 4096 ? 1 : (chunks > 1 ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1);  // (the render launches of launch_game)
-        for (int c = 0; c < nchunk && time_render; c++) {
-            if (hipEventElapsedTime(&ms, tk_r0[c], tk_r1[c]) == hipSuccess) {
-                tk_render_ms += ms;
-                tk_render_launches++;
-            } else {
-                (void)hipGetLastError();  // (a chunk without envs records nothing)
-            }
+}
+
+// the durations of the step whose events are in `slot` (complete: the stream has been joined since, or a later step has been)
+void VecGame::collect_timing(int slot) {
+    if (!tk_pending[slot]) return;
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, tk_e0[slot], tk_e1[slot]));
+    tk_sum_ms += ms;
+    tk_steps++;
+    const int nchunk = num_envs < 4096 ? 1 : (chunks > 1 ? (chunks < MAX_CHUNKS ? chunks : MAX_CHUNKS) : 1);  // (the render launches of launch_game)
+    for (int c = 0; c < nchunk && time_render; c++) {
+        if (hipEventElapsedTime(&ms, tk_r0[slot][c], tk_r1[slot][c]) == hipSuccess) {
+            tk_render_ms += ms;
+            tk_render_launches++;
+        } else {
+            (void)hipGetLastError();  // (a chunk without envs records nothing)
         }
-        tk_pending = false;
     }
+    tk_pending[slot] = false;
 }
 
 // Host copy of one env's device state.  env.get_state() walks all envs: the state of a block of SNAP_BLOCK consecutive envs is
@@ -1726,6 +1753,8 @@ LIBENV_API double procgen_amd_kernel_timing(libenv_env *handle, int enable, int 
     VecGame *v = ((Handle *)handle)->single();
     v->use_device();
     v->observe();
+    v->collect_timing(0);  // (the stream is joined: every recorded event has completed)
+    v->collect_timing(1);
     const double mean = v->tk_steps > 0 ? v->tk_sum_ms / v->tk_steps : 0.0;
     if (steps_out) *steps_out = v->tk_steps;
     if (render_out) {
@@ -1733,12 +1762,14 @@ LIBENV_API double procgen_amd_kernel_timing(libenv_env *handle, int enable, int 
         render_out[1] = v->tk_steps > 0 ? (double)v->tk_render_launches / v->tk_steps : 0.0;
     }
     if (enable) {
-        if (!v->tk_e0) {
-            HIP_CHECK(hipEventCreate(&v->tk_e0));
-            HIP_CHECK(hipEventCreate(&v->tk_e1));
-            for (int c = 0; c < MAX_CHUNKS; c++) {
-                HIP_CHECK(hipEventCreate(&v->tk_r0[c]));
-                HIP_CHECK(hipEventCreate(&v->tk_r1[c]));
+        if (!v->tk_e0[0]) {
+            for (int k = 0; k < 2; k++) {
+                HIP_CHECK(hipEventCreate(&v->tk_e0[k]));
+                HIP_CHECK(hipEventCreate(&v->tk_e1[k]));
+                for (int c = 0; c < MAX_CHUNKS; c++) {
+                    HIP_CHECK(hipEventCreate(&v->tk_r0[k][c]));
+                    HIP_CHECK(hipEventCreate(&v->tk_r1[k][c]));
+                }
             }
         }
         v->tk_sum_ms = v->tk_render_ms = 0;

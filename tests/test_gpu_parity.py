@@ -595,7 +595,7 @@ def test_batched_set_states_equal_per_env_set_state():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("switch", ["PROCGEN_AMD_FIRST_PCT=50", "PROCGEN_AMD_FIRST_PCT=90", "PROCGEN_AMD_CHUNKS=1", "PROCGEN_AMD_CHUNKS=3", "PROCGEN_AMD_CHUNKS=4",
-                                    "PROCGEN_AMD_EARLY_SMALL=0", "PROCGEN_AMD_EARLY_SMALL=1", "PROCGEN_AMD_ORDER=1", "PROCGEN_AMD_ORDER=2", "PROCGEN_AMD_ORDER=3",
+                                    "PROCGEN_AMD_EARLY_SMALL=0", "PROCGEN_AMD_EARLY_SMALL=1", "PROCGEN_AMD_ORDER=0", "PROCGEN_AMD_ORDER=1", "PROCGEN_AMD_ORDER=2", "PROCGEN_AMD_ORDER=3", "PROCGEN_AMD_ORDER=4",
                                     "PROCGEN_AMD_OBS_CHUNK_COPY=0", "PROCGEN_AMD_HOST_THREADS=1", "PROCGEN_AMD_DISPLAY_LIST=0"])
 def test_launch_shape_switches_do_not_change_results(monkeypatch, switch):
     """Every environment switch of the launch shape (VecGame's constructor / launch_game: how many launch chunks and how they are cut, the
@@ -605,6 +605,8 @@ def test_launch_shape_switches_do_not_change_results(monkeypatch, switch):
     name, value = switch.split("=")
     if name == "PROCGEN_AMD_OBS_CHUNK_COPY":
         game, n, steps, kw = "coinrun", 32768, 4, {}
+    elif switch == "PROCGEN_AMD_ORDER=0":  # (a game whose default is order 4: libenv_hip.cpp default_launch_order)
+        game, n, steps, kw = "bigfish", 8192, 24, {}
     elif name == "PROCGEN_AMD_HOST_THREADS":
         game, n, steps, kw = "coinrun,bigfish,maze,starpilot", 4096, 12, {}
     else:
