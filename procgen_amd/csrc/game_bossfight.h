@@ -14,7 +14,11 @@ struct BossFight : BagDefaults<BossFight> {
     static constexpr int MAX_CELLS = 20 * 20;  // bossfight.cpp:66-67
     static constexpr bool USES_ENTITY_COLLISIONS = true;
     static constexpr bool USES_ROTATION = true;  // bullets and trails spin (vrot)
-    static constexpr int ROT_POOL_FACTOR = 4;  // (pg_render.h ROT_POOL: 4 x 16 = a record per lane) dozens of turned bullets on screen at once (at 32 records one frame in six falls back to the per-band path)
+    // rotation records per frame, in sixteens (pg_render.h ROT_POOL): dozens of turned bullets are on screen at once.  3 x 16 since round 6:
+    // 64 records (a record per lane) made the arena 10 640 bytes, nine LDS granules = 14 frames per CU; 48 make it 9104, eight granules =
+    // 16 frames per CU -- the VGPR bound -- and the frames with more turned sprites than records take the per-band path: +2.7 % on the same
+    // box (profiles/r06_call35_bossfight_rot_pool.txt; at 32 records one frame in six falls back and the game is slower, round 5)
+    static constexpr int ROT_POOL_FACTOR = 3;
     static constexpr bool DRAWS_GRID = false;
     // (tier 0 at 120 slots -- 11 008 bytes, one LDS granule less -- measured +-0: profiles/r06_call27_ab.txt)
     static constexpr int ENT_CAP_T0 = 128, ENT_CAP_T1 = 256, ENT_CAP_T2 = 512;

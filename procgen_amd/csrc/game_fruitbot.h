@@ -13,6 +13,7 @@ struct FruitBot : BagDefaults<FruitBot> {
     static constexpr int MAX_CELLS = 20 * 60;  // fruitbot.cpp:152-160
     static constexpr bool USES_ENTITY_COLLISIONS = true;
     static constexpr bool USES_ROTATION = true;  // the agent is drawn turned by -90 degrees
+    static constexpr bool GRID_RARELY_ON_SCREEN = true;  // the grid holds only SPACE; out-of-bounds walls are the only cells with an image (pg_render.h build_pull_tables)
     static constexpr int RENDER_MIN_WAVES = 4;  // with the 16-record rotation pool the arena is 9.7 KB: four render waves per SIMD at <= 128 VGPRs measured +11 % over the pool alone (20.2 -> 22.5 M) on the same box (profiles/r05_rot_pool_ab.txt)
     static constexpr bool USES_TILED_ENTITIES = true;
     // 10 walls x 2 barriers + doors and locks + 20 presents + <= 19 good + <= 19 bad + agent + <= 2 bullets
